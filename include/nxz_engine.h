@@ -1,0 +1,270 @@
+/*
+ * nxz_engine.h -- C ABI of the MI355X DEFLATE engine (libnxz_engine.so).
+ *
+ * This is the drop-in boundary of the hot path.  In libnxz/power-gzip the
+ * per-byte work (LZ77, Huffman encode/decode, CRC32/Adler32) is done by the
+ * POWER NX accelerator; the library talks to it through exactly six symbols
+ * (everything in the reference's lib/ links with only these undefined:
+ * SURVEY.md 8(b)).  This library provides those six symbols on top of HIP
+ * kernels for gfx950, plus an additive batched interface for device-resident
+ * buffers.
+ *
+ * Reference interfaces replaced (paths relative to the libnxz tree):
+ *   nx_function_begin   lib/gzip_vas.c:144   (decl lib/nx_zlib.h:626)
+ *   nx_function_end     lib/gzip_vas.c:166   (decl lib/nx_zlib.h:627)
+ *   nxu_run_job         lib/gzip_vas.c:281   (decl lib/nx_zlib.h:629), called
+ *                       only from nx_submit_job lib/nx_zlib.c:493
+ *   nx_wait_ticks       lib/gzip_vas.c:203
+ *   tb_freq             lib/gzip_vas.c:92    (read by nx_get_freq inc_nx/nxu.h:81-88)
+ *   __crc32_vpmsum      lib/crc32_power.c    (called from lib/crc32_ppc.c:55)
+ * Wire format of a job (CRB + CPB + CSB + DDE), function codes and completion
+ * codes: inc_nx/nxu.h:155-202, 286-616, 803-857.  The structures below are
+ * declared from the byte layout (all multi-byte fields BIG-ENDIAN); their
+ * offsets are checked against the reference header in tests/test_abi_layout.py.
+ *
+ * No torch / HIP types appear in any signature: plain pointers and sizes.
+ */
+#ifndef NXZ_ENGINE_H
+#define NXZ_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------
+ * Job wire format (nx_gzip_crb_cpb_t compatible, 2048 bytes, 2048-aligned)
+ * ---------------------------------------------------------------------- */
+
+/* Data descriptor element, 16 bytes (inc_nx/nxu.h:155-170).
+ *   count == 0 : direct   -- addr = buffer, bytes = length
+ *   count  > 0 : indirect -- addr = array of `count` direct DDEs, bytes =
+ *                total; at most `bytes` bytes are processed even when the
+ *                list is longer (lib/nx_deflate.c:810-813). */
+typedef struct nxz_dde {
+	uint32_t count_be;   /* dde_count = (be32toh(count_be) >> 8) & 0xff */
+	uint32_t bytes_be;   /* ddebc */
+	uint64_t addr_be;    /* ddead: host virtual address */
+} __attribute__((aligned(16))) nxz_dde_t;
+
+/* Coprocessor status block, 16 bytes (inc_nx/nxu.h:172-202).  With
+ * w = be32toh(flags_be): V = w >> 31, CC = (w >> 8) & 0xff, CE = w & 0xff
+ * (the three CE flags live in the top 3 bits of that byte). */
+typedef struct nxz_csb {
+	uint32_t flags_be;
+	uint32_t tpbc_be;    /* target processed byte count */
+	uint64_t fsaddr_be;
+} __attribute__((aligned(16))) nxz_csb_t;
+
+/* Request block, 256 bytes incl. the CSB at +240 (inc_nx/nxu.h:552-609). */
+typedef struct nxz_crb {
+	uint32_t fc_be;              /* +0   function code = be32toh(fc_be) & 0xff */
+	uint32_t reserved1;          /* +4 */
+	uint64_t csb_address_be;     /* +8 */
+	nxz_dde_t source;            /* +16 */
+	nxz_dde_t target;            /* +32 */
+	uint8_t  ccb[16];            /* +48 */
+	uint8_t  reserved64[176];    /* +64 */
+	volatile nxz_csb_t csb;      /* +240 */
+} __attribute__((aligned(128))) nxz_crb_t;
+
+#define NXZ_LLSZ       286
+#define NXZ_DSZ        30
+#define NXZ_DHT_MAXSZ  288     /* bytes of DHT bit string in the CPB */
+
+/* Parameter block, 1680 bytes (inc_nx/nxu.h:286-542). */
+typedef struct nxz_cpb {
+	/* ---- input region ---- */
+	uint32_t in_adler_be;        /* +0   big-endian Adler-32 to continue from */
+	uint32_t in_crc_le;          /* +4   CRC-32 to continue from; memory order == gzip trailer order
+				      *       (little-endian), see lib/nx_deflate.c:436-449 */
+	uint32_t in_w2_be;           /* +8   w=be32toh: in_histlen = w >> 20 (16-byte units); in_subc = w & 7 */
+	uint32_t in_w3_be;           /* +12  w=be32toh: in_sfbt = (w >> 16) & 15; in_rembytecnt = w & 0xffff;
+				      *       in_dhtlen = w & 0xfff (bits) */
+	uint8_t  in_dht[NXZ_DHT_MAXSZ];  /* +16 */
+	uint8_t  reserved_in[80];    /* +304 */
+	/* ---- output region ---- */
+	uint32_t out_adler_be;       /* +384 */
+	uint32_t out_crc_le;         /* +388 memory order == gzip trailer order (little-endian) */
+	uint32_t out_w2_be;          /* +392 w=be32toh: out_tebc = (w >> 16) & 7; out_subc = w & 0xffff */
+	uint32_t out_w3_be;          /* +396 w=be32toh: out_sfbt = (w >> 16) & 15; out_rembytecnt = w & 0xffff;
+				      *       out_dhtlen = w & 0xfff */
+	union {                      /* +400 */
+		uint32_t out_spbc_be;            /* compress w/o counts, wrap */
+		uint32_t out_lzcount_be[NXZ_LLSZ + NXZ_DSZ];
+		struct {
+			uint8_t  out_dht[NXZ_DHT_MAXSZ];
+			uint32_t out_spbc_decomp_be;     /* +688 */
+		} d;
+		uint8_t  qw25[79 * 16];
+	} u;
+	uint32_t out_spbc_with_count_be; /* +1664 */
+	uint8_t  pad[12];
+} __attribute__((aligned(128))) nxz_cpb_t;
+
+typedef struct nxz_crb_cpb {
+	nxz_crb_t crb;
+	nxz_cpb_t cpb;
+} __attribute__((aligned(2048))) nxz_crb_cpb_t;
+
+/* Function codes (inc_nx/nxu.h:803-816).  Bit 0x08 = resume (history prefix
+ * allowed), bit 0x04 = also return LZ symbol counts, bit 0x02 = dynamic table. */
+enum {
+	NXZ_FC_COMPRESS_FHT               = 0x00,
+	NXZ_FC_COMPRESS_DHT               = 0x02,
+	NXZ_FC_COMPRESS_FHT_COUNT         = 0x04,
+	NXZ_FC_COMPRESS_DHT_COUNT         = 0x06,
+	NXZ_FC_COMPRESS_RESUME_FHT        = 0x08,
+	NXZ_FC_COMPRESS_RESUME_DHT        = 0x0a,
+	NXZ_FC_COMPRESS_RESUME_FHT_COUNT  = 0x0c,
+	NXZ_FC_COMPRESS_RESUME_DHT_COUNT  = 0x0e,
+	NXZ_FC_DECOMPRESS                 = 0x10,
+	NXZ_FC_DECOMPRESS_SINGLE_BLK      = 0x12,
+	NXZ_FC_DECOMPRESS_RESUME          = 0x14,
+	NXZ_FC_DECOMPRESS_RESUME_SINGLE_BLK = 0x16,
+	NXZ_FC_WRAP                       = 0x1e
+};
+
+/* Completion codes written to CSB.CC (inc_nx/nxu.h:823-857). */
+enum {
+	NXZ_CC_OK            = 0,
+	NXZ_CC_DATA_LENGTH   = 3,    /* with CE partial bit: normal "source ran out / trailer follows" */
+	NXZ_CC_INVALID_OP    = 8,
+	NXZ_CC_TARGET_SPACE  = 13,
+	NXZ_CC_INVALID_CRB   = 21,
+	NXZ_CC_TPBC_GT_SPBC  = 64,
+	NXZ_CC_MISSING_CODE  = 66,
+	NXZ_CC_INVALID_DIST  = 67,
+	NXZ_CC_INVALID_DHT   = 68,
+	NXZ_CC_NO_HW         = 254
+};
+/* CE bits as stored in the 3 most significant bits of the CE byte (inc_nx/nxu.h:762-781) */
+#define NXZ_CE_PARTIAL     0x4
+#define NXZ_CE_TERMINATE   0x2
+#define NXZ_CE_TPBC_VALID  0x1
+
+/* ------------------------------------------------------------------------
+ * The six symbols of the reference's device transport
+ * ---------------------------------------------------------------------- */
+
+/* Device handle.  Layout-compatible prefix of the reference's struct
+ * nx_dev_t (lib/nx_zlib.h:178-194): only paste_addr, fd and function are
+ * touched by the transport (lib/gzip_vas.c:94-185); the library allocates
+ * the struct and owns every other field. */
+typedef struct nxz_dev {
+	int   lib_private[8];  /* lock .. creator_pid: owned by the calling library */
+	void *paste_addr;      /* +32 engine context (opaque) */
+	int   fd;              /* +40 HIP device ordinal + 1 */
+	int   function;        /* +44 */
+} nxz_dev_t;
+
+#define NXZ_FUNC_COMP_GZIP 2   /* lib/nx_zlib.h: NX_FUNC_COMP_GZIP */
+
+/* Open the engine on HIP device `pri` (-1 = current / $NXZ_DEVICE).
+ * 0 on success, -1 with errno set (ENODEV when no gfx950 device or the HIP
+ * code object failed to load: there is NO CPU fallback). */
+int nx_function_begin(int function, int pri, void *handle);
+int nx_function_end(void *handle);
+
+/* Run one job synchronously.  Source/target are HOST virtual addresses in
+ * the DDEs; the engine stages them through pinned buffers, runs the kernels
+ * on its stream, writes target, the CPB output region and the CSB (V=1).
+ * Returns 0 when the job retired (result in csb.cc), -EAGAIN on timeout. */
+int nxu_run_job(nxz_crb_cpb_t *job, void *handle);
+
+/* Back-off helper of the retry ladders: sleeps/spins for `ticks` timebase
+ * ticks and returns the accumulated wait. */
+uint64_t nx_wait_ticks(uint64_t ticks, uint64_t accumulated_ticks, int do_sleep);
+
+/* Timebase frequency in Hz (512 MHz, the POWER timebase the library's delay
+ * thresholds are written for). */
+extern uint64_t tb_freq;
+
+/* CRC-32 used by the library's exported crc32() (lib/crc32_ppc.c:55 passes
+ * the pre-inverted crc; this returns the raw register like the vpmsum code). */
+unsigned int __crc32_vpmsum(unsigned int crc, const unsigned char *p, unsigned long len);
+
+/* ------------------------------------------------------------------------
+ * Additive batched interface (device-resident buffers).  Names are outside
+ * the nx_* / zlib namespaces of lib/Versions.
+ * ---------------------------------------------------------------------- */
+
+typedef struct nxz_ctx nxz_ctx_t;
+
+/* One job of a batch.  All pointers are DEVICE pointers; src/dst must be
+ * 16-byte aligned.  For compress jobs `hist_len` bytes at src are history
+ * (multiple of 16, <= 32768; lib/nx_deflate.c:853-855). */
+typedef struct nxz_batch_job {
+	const uint8_t *src;       /* [history][source] */
+	uint8_t       *dst;
+	uint32_t       src_len;   /* bytes at src including history */
+	uint32_t       hist_len;
+	uint32_t       dst_cap;
+	uint32_t       in_crc;    /* running checksums to continue from */
+	uint32_t       in_adler;
+	uint32_t       dht_index; /* DHT jobs: which table of the batch's dht array */
+} nxz_batch_job_t;
+
+/* Per-job result, written by the device (device memory, 32 bytes). */
+typedef struct nxz_batch_result {
+	uint32_t cc;          /* completion code (NXZ_CC_*) */
+	uint32_t tpbc;        /* bytes written to dst (incl. the partial last byte) */
+	uint32_t tebc;        /* valid bits in the last byte, 0 == 8 */
+	uint32_t spbc;        /* source bytes processed incl. history */
+	uint32_t crc;         /* crc32 continued from in_crc */
+	uint32_t adler;
+	uint32_t subc;        /* decompress: unprocessed source bits */
+	uint32_t sfbt;        /* decompress: source final block type */
+} nxz_batch_result_t;
+
+/* DHT table slot for batched dynamic-Huffman jobs (device memory). */
+typedef struct nxz_batch_dht {
+	uint32_t dhtlen;                 /* bits */
+	uint8_t  dht[NXZ_DHT_MAXSZ + 4]; /* RFC1951 3.2.7 bit string, HLIT first */
+} nxz_batch_dht_t;
+
+/* Create / destroy an engine context on a HIP device.  `stream` is a
+ * hipStream_t passed as void* (NULL = the context's own stream). */
+nxz_ctx_t *nxz_ctx_create(int device);
+void       nxz_ctx_destroy(nxz_ctx_t *ctx);
+const char *nxz_last_error(void);
+
+/* Batched compress: jobs[n], results[n] (and dht[], counts[]) are DEVICE
+ * arrays.  fc is one of the NXZ_FC_COMPRESS_* codes and applies to every job.
+ * counts (may be NULL unless fc has the COUNT bit): n x 316 uint32 (host
+ * byte order), LL then D, EOB counted once.
+ * Asynchronous on `stream`; returns 0 or a negative errno. */
+int nxz_batch_compress(nxz_ctx_t *ctx, int fc,
+		       const nxz_batch_job_t *jobs, size_t n,
+		       const nxz_batch_dht_t *dht,
+		       nxz_batch_result_t *results, uint32_t *counts,
+		       void *stream);
+
+/* Batched decompress of independent raw-deflate streams (FC 0x10 semantics,
+ * no resume): each job inflates until final EOB, end of source or full
+ * target; result.sfbt/subc report where it stopped. */
+int nxz_batch_decompress(nxz_ctx_t *ctx,
+			 const nxz_batch_job_t *jobs, size_t n,
+			 nxz_batch_result_t *results, void *stream);
+
+/* Batched wrap (FC 0x1e): copy + crc32 + adler32 from the initial values. */
+int nxz_batch_wrap(nxz_ctx_t *ctx, const nxz_batch_job_t *jobs, size_t n,
+		   nxz_batch_result_t *results, void *stream);
+
+/* Block until everything queued on `stream` by this context has finished. */
+int nxz_ctx_sync(nxz_ctx_t *ctx, void *stream);
+
+/* Worst-case compressed size the engine needs as dst_cap for `src_len`
+ * source bytes (fixed-Huffman literals are 9 bits, + header/EOB + 16-byte
+ * store granularity). */
+size_t nxz_compress_bound(size_t src_len);
+
+/* Library version string. */
+const char *nxz_engine_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NXZ_ENGINE_H */

@@ -1,0 +1,338 @@
+/*
+ * nxz_lz77.c -- deterministic LZ77 match finder + greedy parser, CPU restatement.
+ * TEST INFRASTRUCTURE ONLY (see nxz_oracle.h).
+ *
+ * The reference has no LZ77 source (POWER NX silicon; its output is not even
+ * reproducible run to run: doc/power_nx_gzip_um.pdf 2.5.9.5, mirrored by
+ * lib/nx_dhtgen.c:252-256).  PARITY UNPINNED: this file DEFINES the token
+ * choice that the HIP kernel (power-gzip_amd/csrc/nxz_deflate.hip) must
+ * reproduce bit-for-bit.  The definition is position-parallel by construction
+ * so that a 64-lane-wavefront implementation gives identical results:
+ *
+ *  1. The job source is cut into sub-blocks of NXO_SUBBLOCK (64 KiB) bytes.
+ *     A sub-block sees at most NXO_WINDOW (32 KiB) bytes before it (job
+ *     history + earlier source).  Sub-blocks are matched independently.
+ *  2. Every position p with >= 4 bytes left hashes its next 4 bytes
+ *     (little-endian load * 0x9E3779B1 >> (32-HBITS)).
+ *  3. head[h] holds the LARGEST position inserted so far with hash h.
+ *     Window bytes are inserted first.  Block positions are handled in
+ *     chunks of CHUNK positions: all positions of a chunk look up head[]
+ *     (state before the chunk), then all are inserted (max wins).
+ *  4. A candidate q is a match if dist = p-q <= 32768 and >= 4 bytes agree;
+ *     it is extended to at most 258 bytes / end of sub-block.  A second
+ *     candidate at distance 1 is tried when load32(p-1) == load32(p)
+ *     (byte runs); the longer wins, ties go to the smaller distance.
+ *  5. Parsing is greedy inside segments of PSEG bytes (relative to the
+ *     sub-block start): a match is truncated at the segment end and dropped
+ *     if fewer than 3 bytes remain.  One-step lazy evaluation: a match of
+ *     length L < LAZY_MAX at p is replaced by a literal when position p+1
+ *     has a match longer than L.
+ */
+#include <string.h>
+#include "nxz_oracle.h"
+
+#ifndef NXO_HBITS
+#define NXO_HBITS 13
+#endif
+#ifndef NXO_CHUNK
+#define NXO_CHUNK 64
+#endif
+#ifndef NXO_PSEG
+#define NXO_PSEG 64
+#endif
+#ifndef NXO_PTILE
+#define NXO_PTILE 16384
+#endif
+#ifndef NXO_LAZY_MAX
+#define NXO_LAZY_MAX 32     /* 0 disables lazy evaluation */
+#endif
+#ifndef NXO_RLE
+#define NXO_RLE 1
+#endif
+#define MINMATCH 4
+#define MAXMATCH 258
+
+static inline uint32_t ld32(const uint8_t *p)
+{
+	return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+static inline uint32_t hash4(uint32_t v)
+{
+	return (v * 0x9E3779B1u) >> (32 - NXO_HBITS);
+}
+
+static inline uint32_t match_len(const uint8_t *a, const uint8_t *b, uint32_t maxlen)
+{
+	uint32_t l = 0;
+	while (l < maxlen && a[l] == b[l])
+		l++;
+	return l;
+}
+
+/* Greedy walk with one-step lazy evaluation from position p (relative to the
+ * sub-block start) until p >= stop.  Matches are truncated at `limit`
+ * (dropped if fewer than 3 bytes remain).  Returns the exit position.  With
+ * tok != NULL the tokens are appended at tok[*ntok]. */
+static uint32_t walk(const uint8_t *w, uint32_t h, const uint16_t *mlen, const uint16_t *mdist,
+		     uint32_t p, uint32_t stop, uint32_t limit, uint32_t *tok, size_t *ntok)
+{
+	while (p < stop) {
+		uint32_t len = mlen[p];
+		if (len > limit - p)
+			len = limit - p;
+		if (len >= MINMATCH - 1 && mlen[p] >= MINMATCH) {
+#if NXO_LAZY_MAX
+			if (len < NXO_LAZY_MAX && p + 1 < limit) {
+				uint32_t l2 = mlen[p + 1];
+				if (l2 > limit - p - 1)
+					l2 = limit - p - 1;
+				if (l2 > len) {
+					if (tok) tok[(*ntok)++] = w[h + p];
+					p++;
+					continue;
+				}
+			}
+#endif
+			if (tok) tok[(*ntok)++] = NXO_TOK_MATCH | ((uint32_t)mdist[p] << 8) | (len - 3);
+			p += len;
+		} else {
+			if (tok) tok[(*ntok)++] = w[h + p];
+			p++;
+		}
+	}
+	return p;
+}
+
+/* one sub-block: w[0..h) window, w[h..h+n) block.  n <= NXO_SUBBLOCK, h <= NXO_WINDOW */
+static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *tok)
+{
+	static __thread uint32_t head[1u << NXO_HBITS];
+	static __thread uint16_t mlen[NXO_SUBBLOCK];
+	static __thread uint16_t mdist[NXO_SUBBLOCK];
+	const uint32_t end = h + n;
+	uint32_t c, r, ntok = 0;
+
+	memset(head, 0, sizeof(head));
+	/* 3. window seeding (entries are position+1; 0 == empty) */
+	for (r = 0; r < h && r + 4 <= end; r++) {
+		uint32_t hv = hash4(ld32(w + r));
+		if (head[hv] < r + 1)
+			head[hv] = r + 1;
+	}
+	/* 2-4. match finding per chunk */
+	for (c = 0; c < n; c += NXO_CHUNK) {
+		uint32_t cend = c + NXO_CHUNK < n ? c + NXO_CHUNK : n;
+		uint32_t j;
+		for (j = c; j < cend; j++) {
+			uint32_t len = 0, dist = 0;
+			r = h + j;
+			if (r + 4 <= end) {
+				uint32_t v = ld32(w + r);
+				uint32_t cand = head[hash4(v)];
+				uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+				if (cand != 0 && r - (cand - 1) <= NXO_WINDOW &&
+				    ld32(w + cand - 1) == v) {
+					len = match_len(w + cand - 1, w + r, maxlen);
+					dist = r - (cand - 1);
+				}
+#if NXO_RLE
+				if (r >= 1 && ld32(w + r - 1) == v) {
+					uint32_t l1 = match_len(w + r - 1, w + r, maxlen);
+					if (l1 >= len) {
+						len = l1;
+						dist = 1;
+					}
+				}
+#endif
+			}
+			mlen[j] = (uint16_t)len;
+			mdist[j] = (uint16_t)(dist - 1);
+		}
+		for (j = c; j < cend; j++) {
+			r = h + j;
+			if (r + 4 <= end) {
+				uint32_t hv = hash4(ld32(w + r));
+				if (head[hv] < r + 1)
+					head[hv] = r + 1;
+			}
+		}
+	}
+	/* 5. two-pass segment parse per PTILE */
+	for (c = 0; c < n; c += NXO_PTILE) {
+		uint32_t tend = c + NXO_PTILE < n ? c + NXO_PTILE : n;
+		uint32_t nseg = (tend - c + NXO_PSEG - 1) / NXO_PSEG, s;
+		static __thread uint32_t X[NXO_PTILE / NXO_PSEG];
+		uint32_t entry = c;
+		/* pass 1: speculative walk of every segment from its own start; X = exit */
+		for (s = 0; s < nseg; s++) {
+			uint32_t sb = c + s * NXO_PSEG;
+			uint32_t se = sb + NXO_PSEG < tend ? sb + NXO_PSEG : tend;
+			X[s] = walk(w, h, mlen, mdist, sb, se, tend, NULL, NULL);
+		}
+		/* chain of entered segments: the segment containing `entry` is walked
+		 * for real from `entry` up to its own speculative exit (matches are
+		 * truncated there), which is the entry of the next entered segment */
+		while (entry < tend) {
+			size_t k = ntok;
+			s = (entry - c) / NXO_PSEG;
+			walk(w, h, mlen, mdist, entry, X[s], X[s], tok, &k);
+			ntok = (uint32_t)k;
+			entry = X[s];
+		}
+	}
+	return ntok;
+}
+
+size_t nxo_lz77(const uint8_t *buf, size_t hist, size_t n, uint32_t *tok)
+{
+	size_t off = 0, ntok = 0;
+	while (off < n) {
+		uint32_t bn = n - off < NXO_SUBBLOCK ? (uint32_t)(n - off) : NXO_SUBBLOCK;
+		size_t before = hist + off;
+		uint32_t h = before < NXO_WINDOW ? (uint32_t)before : NXO_WINDOW;
+		ntok += lz77_subblock(buf + before - h, h, bn, tok + ntok);
+		off += bn;
+	}
+	return ntok;
+}
+
+/* ---- symbol mapping (RFC1951 3.2.5) ------------------------------------ */
+static const uint16_t len_base[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
+	35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+static const uint8_t len_extra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
+	3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+static const uint16_t dist_base[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193,
+	257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+static const uint8_t dist_extra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6,
+	7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+
+static inline uint32_t len_sym(uint32_t len)   /* returns index 0..28 */
+{
+	uint32_t s = 28;
+	while (len_base[s] > len)
+		s--;
+	return s;
+}
+
+static inline uint32_t dist_sym(uint32_t dist)
+{
+	uint32_t s = 29;
+	while (dist_base[s] > dist)
+		s--;
+	return s;
+}
+
+void nxo_count(const uint32_t *tok, size_t ntok, uint32_t ll[286], uint32_t d[30])
+{
+	size_t i;
+	memset(ll, 0, 286 * sizeof(uint32_t));
+	memset(d, 0, 30 * sizeof(uint32_t));
+	for (i = 0; i < ntok; i++) {
+		uint32_t t = tok[i];
+		if (t & NXO_TOK_MATCH) {
+			ll[257 + len_sym((t & 0xff) + 3)]++;
+			d[dist_sym(((t >> 8) & 0x7fff) + 1)]++;
+		} else {
+			ll[t & 0xff]++;
+		}
+	}
+	ll[256] = 1;
+}
+
+/* ---- bit writer -------------------------------------------------------- */
+typedef struct {
+	uint8_t *out;
+	size_t cap;
+	uint64_t bits;    /* total bits written */
+	uint64_t acc;
+	unsigned nacc;
+	int ovf;
+} bitw_t;
+
+static void bw_put(bitw_t *b, uint32_t v, unsigned n)
+{
+	b->acc |= (uint64_t)v << b->nacc;
+	b->nacc += n;
+	b->bits += n;
+	while (b->nacc >= 8) {
+		size_t idx = (size_t)((b->bits - b->nacc) >> 3);
+		if (idx < b->cap)
+			b->out[idx] = (uint8_t)b->acc;
+		else
+			b->ovf = 1;
+		b->acc >>= 8;
+		b->nacc -= 8;
+	}
+}
+
+static void bw_flush(bitw_t *b)
+{
+	if (b->nacc) {
+		size_t idx = (size_t)(b->bits >> 3);
+		if (idx < b->cap)
+			b->out[idx] = (uint8_t)b->acc;
+		else
+			b->ovf = 1;
+	}
+}
+
+static int put_tokens(bitw_t *b, const uint32_t *tok, size_t ntok, const nxo_codes_t *c)
+{
+	size_t i;
+	for (i = 0; i < ntok; i++) {
+		uint32_t t = tok[i];
+		if (t & NXO_TOK_MATCH) {
+			uint32_t len = (t & 0xff) + 3, dist = ((t >> 8) & 0x7fff) + 1;
+			uint32_t ls = len_sym(len), ds = dist_sym(dist);
+			if (!c->ll_len[257 + ls] || !c->d_len[ds])
+				return -1;
+			bw_put(b, c->ll_code[257 + ls], c->ll_len[257 + ls]);
+			if (len_extra[ls])
+				bw_put(b, len - len_base[ls], len_extra[ls]);
+			bw_put(b, c->d_code[ds], c->d_len[ds]);
+			if (dist_extra[ds])
+				bw_put(b, dist - dist_base[ds], dist_extra[ds]);
+		} else {
+			if (!c->ll_len[t & 0xff])
+				return -1;
+			bw_put(b, c->ll_code[t & 0xff], c->ll_len[t & 0xff]);
+		}
+	}
+	if (!c->ll_len[256])
+		return -1;
+	bw_put(b, c->ll_code[256], c->ll_len[256]);
+	return 0;
+}
+
+uint64_t nxo_encode_fixed(const uint32_t *tok, size_t ntok, uint8_t *out, size_t out_cap)
+{
+	nxo_codes_t c;
+	bitw_t b = { out, out_cap, 0, 0, 0, 0 };
+	nxo_codes_fixed(&c);
+	bw_put(&b, 1, 1);  /* BFINAL as the engine emits it (UM 5.1.1; host rewrites, nx_deflate.c:158) */
+	bw_put(&b, 1, 2);  /* BTYPE 01 */
+	put_tokens(&b, tok, ntok, &c);
+	bw_flush(&b);
+	return b.ovf ? (uint64_t)-2 : b.bits;
+}
+
+uint64_t nxo_encode_dynamic(const uint32_t *tok, size_t ntok, const uint8_t *dht, int dhtlen,
+			    uint8_t *out, size_t out_cap)
+{
+	nxo_codes_t c;
+	bitw_t b = { out, out_cap, 0, 0, 0, 0 };
+	int i;
+	if (nxo_dht_parse(dht, dhtlen, &c) != dhtlen)
+		return (uint64_t)-1;
+	bw_put(&b, 1, 1);
+	bw_put(&b, 2, 2);  /* BTYPE 10 */
+	for (i = 0; i + 8 <= dhtlen; i += 8)
+		bw_put(&b, dht[i >> 3], 8);
+	if (dhtlen & 7)
+		bw_put(&b, dht[dhtlen >> 3] & ((1u << (dhtlen & 7)) - 1), dhtlen & 7);
+	if (put_tokens(&b, tok, ntok, &c))
+		return (uint64_t)-1;
+	bw_flush(&b);
+	return b.ovf ? (uint64_t)-2 : b.bits;
+}
