@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the DEFLATE hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W [--blocks B] [--mode fht|dht|inflate]
+
+A *step* is one pass of the fixed-Huffman deflate engine (LZ77 + bit-pack kernel, function
+code COMPRESS_FHT) over one batch of B synthetic 64 KiB blocks that are already resident in
+HBM (BASELINE.json configs[1]: "Fixed-Huffman deflate (level 1), 1xMI355X, 1 M synthetic
+64 KiB blocks").  Every rank owns its own B blocks (independent units, no data-path
+collective: weak scaling); the only collectives are the barrier and the reductions of
+{bytes, elapsed}.  Rank 0 prints ONE JSON line.
+
+Inside the timed region: the engine launches only (kernel + tiny result buffer).  Outside:
+data generation, verification of a sample against the CPU oracle and zlib, the CPU baseline.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BLOCK = 65536
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def shard(nblocks_per_rank, rank, world):
+    """Block index range of a rank (contiguous); weak scaling: every rank gets B."""
+    lo = rank * nblocks_per_rank
+    return lo, lo + nblocks_per_rank
+
+
+def gen_blocks(torch, dev, n, first_index, chunk=4096):
+    """Seeded synthetic 64 KiB blocks, generated on the device.
+
+    Recipe (after the reference's generators): first half of every block =
+    uniform text over a 33-symbol alphabet (test/test_utils.c:22-28); second half = LZ copies
+    (samples/makedata.c:51-68): runs (mean length 96) copied from the first half at a per-run
+    distance of 300..32768 bytes.  Chunk c of 4096 blocks uses seed 0x9E3779B97F4A7C15 ^ index.
+    """
+    out = torch.empty((n, BLOCK), dtype=torch.uint8, device=dev)
+    alphabet = torch.tensor(list(b"abcdefghijklmnopqrstuvwxyz .,;!?\n"), dtype=torch.uint8, device=dev)
+    half = BLOCK // 2
+    pos = torch.arange(half, device=dev, dtype=torch.int32).unsqueeze(0)
+    for c0 in range(0, n, chunk):
+        m = min(chunk, n - c0)
+        g = torch.Generator(device=dev)
+        g.manual_seed((0x9E3779B97F4A7C15 ^ (first_index + c0)) & 0x7FFFFFFFFFFFFFFF)
+        text = alphabet[torch.randint(0, 33, (m, half), device=dev, generator=g)]
+        boundary = torch.rand((m, half), device=dev, generator=g) < (1.0 / 96)
+        boundary[:, 0] = True
+        runstart = torch.cummax(torch.where(boundary, pos, torch.zeros_like(pos)), dim=1).values
+        runid = torch.cumsum(boundary.to(torch.int32), dim=1).clamp_(max=1023).to(torch.int64)
+        frac = torch.gather(torch.rand((m, 1024), device=dev, generator=g), 1, runid)
+        off = (frac * (half - 300 - runstart).clamp_(min=0).to(torch.float32)).to(torch.int32)
+        src_idx = (pos + off).clamp_(max=half - 1).to(torch.int64)     # distance = half - off in [300, 32768]
+        out[c0:c0 + m, :half] = text
+        out[c0:c0 + m, half:] = torch.gather(text, 1, src_idx)
+        del text, boundary, runstart, runid, frac, off, src_idx
+    return out
+
+
+def cpu_baseline(blocks_host, budget_s=12.0):
+    """oracle ('port') timed on all host cores on a bounded sample; zlib -1 Z_FIXED beside it."""
+    import oracle_lib as O
+    L = O.lib()
+    L.nxo_bench_deflate.restype = C.c_double
+    L.nxo_bench_deflate.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    cores = os.cpu_count() or 1
+    buf = blocks_host.tobytes()
+    nmax = len(buf) // BLOCK
+    ob = C.c_uint64()
+    # calibrate on a few blocks, then size the sample for ~budget_s/2 per library
+    ncal = min(nmax, 4 * cores)
+    t = L.nxo_bench_deflate(buf, ncal, BLOCK, cores, 0, C.byref(ob))
+    n = int(max(ncal, min(nmax, ncal * (budget_s / 2) / max(t, 1e-3))))
+    t_port = L.nxo_bench_deflate(buf, n, BLOCK, cores, 0, C.byref(ob))
+    port_out = ob.value
+    t_z = L.nxo_bench_deflate(buf, n, BLOCK, cores, 1, C.byref(ob))
+    z_out = ob.value
+    gib = n * BLOCK / 2.0 ** 30
+    return {
+        "value": round(gib / t_port, 4), "unit": "GiB/s", "cores": cores, "kind": "port",
+        "sample": "%d of the same 64 KiB blocks, oracle/nxz_lz77.c fixed-Huffman deflate, %d pthreads" % (n, cores),
+        "ratio": round(n * BLOCK / port_out, 4),
+        "zlib1_fixed_GiB_s": round(gib / t_z, 4), "zlib1_fixed_ratio": round(n * BLOCK / z_out, 4),
+    }
+
+
+def verify_sample(eng, pkg, src, dst, res_host, stride_out, k=48):
+    """oracle + zlib check of the first k blocks (outside the timed region)."""
+    import zlib
+    import oracle_lib as O
+    k = min(k, src.shape[0])
+    s = src[:k].cpu().numpy()
+    d = dst[:k].cpu().numpy()
+    for i in range(k):
+        b = s[i].tobytes()
+        exp, bits = O.deflate_fixed(b)
+        got = d[i, :res_host["tpbc"][i]].tobytes()
+        if got != exp:
+            raise SystemExit("PARITY FAILURE: block %d differs from the oracle" % i)
+        z = zlib.decompressobj(-15)
+        if z.decompress(got) != b or not z.eof:
+            raise SystemExit("ROUND TRIP FAILURE: block %d" % i)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blocks", type=int, default=1 << 20, help="64 KiB blocks per GPU (default 2^20 = 64 GiB)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." %
+                             (args.gpus, args.gpus))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = importlib.import_module("power-gzip_amd")
+    eng = pkg.Engine(local_rank)
+
+    n = args.blocks
+    lo, hi = shard(n, rank, world)
+    stride_out = 73856
+    src = gen_blocks(torch, dev, n, lo)
+    dst = torch.empty((n, stride_out), dtype=torch.uint8, device=dev)
+    lens = np.full(n, BLOCK, np.uint32)
+    jobs = eng.jobs_strided(src, BLOCK, lens, dst, stride_out, stride_out)
+    results = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+
+    def step():
+        eng.compress(pkg.FC_COMPRESS_FHT, jobs, n, results=results)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps          # the engine kernel is the only work on the stream
+
+    res = results.cpu().numpy().view(pkg.RESULT_DTYPE)
+    if not ((res["cc"] == 0) | (res["cc"] == 64)).all():
+        raise SystemExit("engine reported errors: %s" % np.unique(res["cc"]))
+    u_bytes = float(n) * BLOCK
+    c_bytes = float(res["tpbc"].astype(np.float64).sum())
+
+    tot = torch.tensor([u_bytes, c_bytes], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall_max = float(tmax.item())
+    tot_u, tot_c = float(tot[0].item()), float(tot[1].item())
+
+    if rank == 0:
+        verify_sample(eng, pkg, src, dst, res, stride_out)
+        value = tot_u * args.steps / wall_max / 2.0 ** 30
+        achieved = (u_bytes + c_bytes) / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "GiB/s uncompressed in (deflate), fixed-Huffman level 1, synthetic 64 KiB blocks",
+            "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: fixed-Huffman deflate (FC 0x00), %d x 64 KiB synthetic blocks "
+                                   "per GPU (33-symbol text + makedata-style LZ copies), device resident" % n,
+                       "blocks_per_gpu": n, "block_bytes": BLOCK, "ratio": round(tot_u / tot_c, 4),
+                       "parallelism": "shard%d" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "nxz::deflate_kernel<false,false>", "kernel_ms": round(kern_ms, 3),
+                         "algorithmic_bytes_per_launch": u_bytes + c_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = src[:min(n, 4096)].cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(sample)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

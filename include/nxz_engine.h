@@ -205,18 +205,24 @@ typedef struct nxz_batch_job {
 	uint32_t       in_crc;    /* running checksums to continue from */
 	uint32_t       in_adler;
 	uint32_t       dht_index; /* DHT jobs: which table of the batch's dht array */
+	uint32_t       resume;    /* decompress resume state: in_rembytecnt | in_sfbt << 16 | in_subc << 20
+				   * (0 = start at a block header on a byte boundary, FC 0x10) */
+	uint32_t       reserved;
 } nxz_batch_job_t;
 
 /* Per-job result, written by the device (device memory, 32 bytes). */
 typedef struct nxz_batch_result {
 	uint32_t cc;          /* completion code (NXZ_CC_*) */
 	uint32_t tpbc;        /* bytes written to dst (incl. the partial last byte) */
-	uint32_t tebc;        /* valid bits in the last byte, 0 == 8 */
+	uint32_t tebc;        /* compress: valid bits in the last byte, 0 == 8;
+			       * decompress: out_rembytecnt when suspended inside a stored block */
 	uint32_t spbc;        /* source bytes processed incl. history */
 	uint32_t crc;         /* crc32 continued from in_crc */
 	uint32_t adler;
 	uint32_t subc;        /* decompress: unprocessed source bits */
-	uint32_t sfbt;        /* decompress: source final block type */
+	uint32_t sfbt;        /* decompress: bits 0..3 source final block type (inc_nx/nxu.h:466-511),
+			       * bit 8 = final EOB seen, bits 16..27 = out_dhtlen when suspended
+			       * inside a dynamic block (table bits are in the job's dht_io slot) */
 } nxz_batch_result_t;
 
 /* DHT table slot for batched dynamic-Huffman jobs (device memory). */
@@ -233,21 +239,25 @@ const char *nxz_last_error(void);
 
 /* Batched compress: jobs[n], results[n] (and dht[], counts[]) are DEVICE
  * arrays.  fc is one of the NXZ_FC_COMPRESS_* codes and applies to every job.
- * counts (may be NULL unless fc has the COUNT bit): n x 316 uint32 (host
- * byte order), LL then D, EOB counted once.
+ * dht[ntables] (DHT function codes only) are the tables jobs[].dht_index
+ * refers to.  counts (may be NULL unless fc has the COUNT bit): n x 316 uint32
+ * (host byte order), LL then D, EOB counted once.
  * Asynchronous on `stream`; returns 0 or a negative errno. */
 int nxz_batch_compress(nxz_ctx_t *ctx, int fc,
 		       const nxz_batch_job_t *jobs, size_t n,
-		       const nxz_batch_dht_t *dht,
+		       const nxz_batch_dht_t *dht, size_t ntables,
 		       nxz_batch_result_t *results, uint32_t *counts,
 		       void *stream);
 
-/* Batched decompress of independent raw-deflate streams (FC 0x10 semantics,
- * no resume): each job inflates until final EOB, end of source or full
- * target; result.sfbt/subc report where it stopped. */
+/* Batched decompress of raw-deflate streams (FC 0x10, or 0x14 when
+ * jobs[].resume / hist_len are set): each job inflates until final EOB, end
+ * of source or full target (CC 13); result.sfbt/subc report where it
+ * stopped.  dht_io (NULL or n slots): in = table to resume inside a dynamic
+ * block, out = table in force when the job suspended inside one. */
 int nxz_batch_decompress(nxz_ctx_t *ctx,
 			 const nxz_batch_job_t *jobs, size_t n,
-			 nxz_batch_result_t *results, void *stream);
+			 nxz_batch_result_t *results,
+			 nxz_batch_dht_t *dht_io, void *stream);
 
 /* Batched wrap (FC 0x1e): copy + crc32 + adler32 from the initial values. */
 int nxz_batch_wrap(nxz_ctx_t *ctx, const nxz_batch_job_t *jobs, size_t n,

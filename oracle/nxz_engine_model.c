@@ -87,12 +87,19 @@ int nxo_run_job(nxz_crb_cpb_t *j)
 		tpbc = srclen;
 	} else if (nxz_fc_is_compress(fc)) {
 		uint32_t hist = nxz_fc_is_resume(fc) ? nxz_in_histlen(&j->cpb) * 16 : 0;
-		uint32_t n, *tok;
-		uint8_t *out;
+		uint32_t n, *tok, skip, partial = 0;
+		uint8_t *out, *srcbase = src;
 		uint64_t bits;
 		size_t ntok, ocap;
 		if (hist > srclen) hist = srclen;
 		n = srclen - hist;
+		/* only the last 32 KiB of history can be referenced (inc_nx/nxu.h:303-317); one job
+		 * covers one 64 KiB sub-block incl. its window, the rest is left to the caller through
+		 * the engine's byte-count-limit completion (CC 3 + partial, lib/nx_deflate.c:1341-1359) */
+		skip = hist > NXO_WINDOW ? hist - NXO_WINDOW : 0;
+		src += skip; hist -= skip;
+		if (hist + n > NXO_SUBBLOCK) { n = NXO_SUBBLOCK - hist; partial = 1; }
+		srclen = skip + hist + n;
 		tok = malloc(((size_t)n + 1) * sizeof(uint32_t));
 		ocap = (size_t)n * 2 + 1024;
 		out = calloc(1, ocap);
@@ -121,11 +128,15 @@ int nxo_run_job(nxz_crb_cpb_t *j)
 				} else {
 					nxz_wr32(&j->cpb.u.out_spbc_be, srclen);
 				}
-				if (tpbc > srclen)
+				if (tpbc > hist + n)
 					cc = NXZ_CC_TPBC_GT_SPBC;
+				else if (partial) {
+					cc = NXZ_CC_DATA_LENGTH; ce = NXZ_CE_PARTIAL | NXZ_CE_TPBC_VALID;
+				}
 			}
 		}
 		free(tok); free(out);
+		src = srcbase;
 	} else if (fc == NXZ_FC_DECOMPRESS || fc == NXZ_FC_DECOMPRESS_RESUME) {
 		nxo_inflate_state_t st;
 		uint32_t hist = nxz_fc_is_resume(fc) ? nxz_in_histlen(&j->cpb) * 16 : 0;

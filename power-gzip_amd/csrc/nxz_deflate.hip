@@ -1,0 +1,585 @@
+// nxz_deflate.hip -- DEFLATE compression engine for MI355X (gfx950, wave64).
+//
+// Replaces the POWER NX accelerator's COMPRESS function codes
+// (GZIP_FC_COMPRESS_[RESUME_]{FHT,DHT}[_COUNT], issued at
+// /root/reference lib/nx_deflate.c:1808,1841; contract inc_nx/nxu.h:286-616 and
+// the consumer code lib/nx_deflate.c:969-1078).  One workgroup (1024 threads =
+// 16 wavefronts, one per CU: the working set is 159 KiB of LDS) turns one
+// sub-block of <= 64 KiB (history window included) into one deflate block.
+// The algorithm is the position-parallel LZ77 defined in oracle/nxz_lz77.c;
+// this kernel must reproduce that restatement bit for bit.
+//
+// Phases per sub-block (all data stays in LDS between load and the coalesced
+// output flush; HBM traffic is the algorithmic U + C bytes):
+//   load     coalesced 16 B/lane global loads of [window|block] into LDS
+//   cksum    CRC-32 (zero-prefixed frame + fixed-stride GF(2) tree) and Adler-32
+//   seed     window positions -> head[] by LDS atomicMax (order free)
+//   per 16 KiB tile:
+//     hash   every position: 4-byte hash -> cand[] (u16)
+//     chain  ONE wave walks the tile in 64-position steps: lookup head[], then
+//            atomicMax insert (the only serial dependence of the algorithm)
+//     match  every position: verify + extend (capped at 36 B) + distance-1 run check
+//     parse  lane per 16-byte segment: speculative greedy/lazy walk -> exit X[s];
+//            pointer doubling marks the chain of entered segments; entered
+//            segments re-walk [entry, X[s]) and publish token bitmaps
+//     encode per 2048 positions: code lookup, workgroup prefix sum of bit
+//            lengths, LDS atomicOr bit packing, coalesced dword flush
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nxz_device.h"
+
+namespace nxz {
+
+constexpr int NT = 1024;                 // threads per workgroup
+constexpr int HBITS = 13;
+constexpr uint32_t HSIZE = 1u << HBITS;
+constexpr uint32_t PTILE = 16384;        // positions per parse tile
+constexpr uint32_t PSEG = 16;            // positions per parse segment (one lane)
+constexpr uint32_t NSEG = PTILE / PSEG;  // 1024
+constexpr uint32_t ETILE = 2048;         // positions per encode step
+constexpr uint32_t CAPLEN = 36;          // match length cap of the position-parallel pass
+constexpr uint32_t LAZY_MAX = 32;
+constexpr uint32_t MAXMATCH = 258;
+constexpr uint32_t WINDOW = 32768;
+constexpr uint32_t NOHASH = 0xFFFFu;
+
+// ---- LDS carve (bytes) ----
+constexpr uint32_t OFF_IN    = 0;                        // 65536 + 32 pad
+constexpr uint32_t OFF_HEAD  = 65536 + 32;               // 8192 x u32
+constexpr uint32_t OFF_CAND  = OFF_HEAD + HSIZE * 4;     // 16384 x u16
+constexpr uint32_t OFF_MLEN  = OFF_CAND + PTILE * 2;     // 16384 x u8
+constexpr uint32_t OFF_X     = OFF_MLEN + PTILE;         // 1024 x u16
+constexpr uint32_t OFF_ENTRY = OFF_X + NSEG * 2;         // 1024 x u16
+constexpr uint32_t OFF_SBITS = OFF_ENTRY + NSEG * 2;     // 512 x u32   (aliased: MARK u8[1024] during chain marking)
+constexpr uint32_t OFF_MBITS = OFF_SBITS + PTILE / 8;    // 512 x u32   (aliased: JUMP u16[1024])
+constexpr uint32_t OFF_BITS  = OFF_MBITS + PTILE / 8;    // (ETILE*16/8 + 64) bytes of packed output (aliased: CRC table)
+constexpr uint32_t BITS_BYTES = ETILE * 2 + 64;
+constexpr uint32_t OFF_SCAN  = OFF_BITS + BITS_BYTES;    // 64 x u32
+constexpr uint32_t OFF_LLTAB = OFF_SCAN + 256;           // 288 x u32
+constexpr uint32_t OFF_DTAB  = OFF_LLTAB + 288 * 4;      // 32 x u32
+constexpr uint32_t OFF_HIST  = OFF_DTAB + 32 * 4;        // 316 x u32
+constexpr uint32_t OFF_MISC  = OFF_HIST + 316 * 4;       // 16 x u32
+constexpr uint32_t LDS_BYTES = OFF_MISC + 64;
+static_assert(LDS_BYTES <= 163840, "LDS budget");
+static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
+
+enum { M_ERR = 0, M_CARRY_BITS = 1, M_WORDBASE = 2, M_TOTBITS_LO = 3, M_TMP = 4 };
+
+__device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
+{
+	// unaligned little-endian 32-bit load from the LDS input image
+	uint32_t a = inw[r >> 2], b = inw[(r >> 2) + 1];
+	return __builtin_amdgcn_alignbyte(b, a, r & 3);
+}
+
+__device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - HBITS); }
+
+// common prefix of the strings at a and b (a < b), starting the compare at
+// offset `len` (multiple of 4 relative to the starts), clamped to `limit`
+__device__ __forceinline__ uint32_t extend(const uint32_t *inw, uint32_t a, uint32_t b, uint32_t len, uint32_t limit)
+{
+	while (len < limit) {
+		uint32_t x = lds_ld32(inw, a + len) ^ lds_ld32(inw, b + len);
+		if (x) {
+			len += (uint32_t)__builtin_ctz(x) >> 3;
+			break;
+		}
+		len += 4;
+	}
+	return len < limit ? len : limit;
+}
+
+// GF(2)[x] multiply modulo the reflected CRC-32 polynomial
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)
+{
+	uint32_t r = 0;
+#pragma unroll 8
+	for (int i = 0; i < 32; i++) {
+		r ^= (b & 0x80000000u) ? a : 0;
+		a = (a >> 1) ^ ((a & 1) ? 0xedb88320u : 0);
+		b <<= 1;
+	}
+	return r;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		uint32_t u = __shfl_up(v, o, 64);
+		if (lane >= o) v += u;
+	}
+	return v;
+}
+
+struct Walk {
+	const uint32_t *inw;
+	uint8_t *mlen;
+	const uint16_t *cand;
+	uint32_t h, tile_base, end;   // window bytes, tile start (block relative), sub-block end (window relative)
+
+	// true match length at tile position p (stored value is len-3, 0 = none, CAPLEN-3 = capped)
+	__device__ __forceinline__ uint32_t full_len(uint32_t p) const
+	{
+		uint32_t m = mlen[p];
+		if (m == 0) return 0;
+		uint32_t len = m + 3;
+		if (len == CAPLEN) {
+			uint32_t r = h + tile_base + p;
+			uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+			if (maxlen > CAPLEN) {
+				uint32_t q = r - ((uint32_t)cand[p] + 1);
+				len = extend(inw, q, r, CAPLEN, maxlen);
+				mlen[p] = (uint8_t)(len - 3);
+			}
+		}
+		return len;
+	}
+};
+
+// One greedy/lazy step at tile position p (oracle/nxz_lz77.c walk()).  Returns
+// the token length (1 = literal) and whether it is a match.
+__device__ __forceinline__ uint32_t walk_step(const Walk &w, uint32_t p, uint32_t limit, bool &is_match)
+{
+	uint32_t full = w.full_len(p);
+	uint32_t len = full < limit - p ? full : limit - p;
+	is_match = false;
+	if (full >= 4 && len >= 3) {
+		if (len < LAZY_MAX && p + 1 < limit) {
+			uint32_t m2 = w.mlen[p + 1];
+			uint32_t l2 = m2 ? m2 + 3 : 0;
+			if (l2 > limit - p - 1) l2 = limit - p - 1;
+			if (l2 > len) return 1;
+		}
+		is_match = true;
+		return len;
+	}
+	return 1;
+}
+
+template <bool DHT, bool COUNT>
+__global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__restrict__ jobs,
+						     const nxz_dht_prepared_t *__restrict__ tables,
+						     nxz_batch_result_t *__restrict__ results,
+						     uint32_t *__restrict__ counts)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint32_t *inw = (uint32_t *)(lds + OFF_IN);
+	uint32_t *head = (uint32_t *)(lds + OFF_HEAD);
+	uint16_t *cand = (uint16_t *)(lds + OFF_CAND);
+	uint8_t *mlen = lds + OFF_MLEN;
+	uint16_t *X = (uint16_t *)(lds + OFF_X);
+	uint16_t *entry = (uint16_t *)(lds + OFF_ENTRY);
+	uint32_t *sbits = (uint32_t *)(lds + OFF_SBITS);
+	uint32_t *mbits = (uint32_t *)(lds + OFF_MBITS);
+	uint8_t *mark = lds + OFF_SBITS;
+	uint16_t *jump = (uint16_t *)(lds + OFF_MBITS);
+	uint32_t *bitbuf = (uint32_t *)(lds + OFF_BITS);
+	uint32_t *scan = (uint32_t *)(lds + OFF_SCAN);
+	uint32_t *lltab = (uint32_t *)(lds + OFF_LLTAB);
+	uint32_t *dtab = (uint32_t *)(lds + OFF_DTAB);
+	uint32_t *hist = (uint32_t *)(lds + OFF_HIST);
+	uint32_t *misc = (uint32_t *)(lds + OFF_MISC);
+
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const nxz_batch_job_t job = jobs[blockIdx.x];
+	const uint32_t total = job.src_len;                  // window + block
+	const uint32_t h = job.hist_len < total ? job.hist_len : total;
+	const uint32_t n = total - h;
+	const uint32_t end = total;
+	const uint8_t *__restrict__ src = job.src;
+
+	// ---------------- load ----------------
+	{
+		const uint4 *s4 = (const uint4 *)src;
+		uint4 *d4 = (uint4 *)inw;
+		uint32_t nfull = total >> 4;
+		for (uint32_t i = t; i < nfull; i += NT) d4[i] = s4[i];
+		// tail bytes + zero pad (so that over-reads past `end` are defined)
+		uint32_t base = nfull << 4;
+		for (uint32_t i = base + t; i < base + 48 && i < 65536 + 32; i += NT)
+			lds[OFF_IN + i] = i < total ? src[i] : 0;
+	}
+	for (uint32_t i = t; i < HSIZE; i += NT) head[i] = 0;
+	if (t < 316) hist[t] = 0;
+	if (t < 16) misc[t] = 0;
+	if (DHT) {
+		const nxz_dht_prepared_t *tb = &tables[job.dht_index];
+		if (t < 288) lltab[t] = tb->ll[t];
+		if (t < 32) dtab[t] = tb->d[t];
+	} else {
+		if (t < 288) {
+			// RFC1951 3.2.6 fixed code; entry = bit-reversed code | len << 16
+			uint32_t len, code;
+			if (t < 144) { len = 8; code = 0x30 + t; }
+			else if (t < 256) { len = 9; code = 0x190 + (t - 144); }
+			else if (t < 280) { len = 7; code = t - 256; }
+			else { len = 8; code = 0xC0 + (t - 280); }
+			lltab[t] = (__builtin_bitreverse32(code) >> (32 - len)) | (len << 16);
+		}
+		if (t < 32) dtab[t] = (__builtin_bitreverse32((uint32_t)t) >> 27) | (5u << 16);
+	}
+	// CRC byte table lives in the (not yet used) bit buffer
+	if (t < 256) {
+		uint32_t c = t;
+		for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1) ? 0xedb88320u : 0);
+		bitbuf[t] = c;
+	}
+	__syncthreads();
+
+	// ---------------- checksums of the non-history source ----------------
+	uint32_t out_crc, out_adler;
+	{
+		// frame of 1024 x 64 B slices, data right-aligned (leading zeros do not change a raw CRC)
+		const uint32_t pad = 65536 - n;
+		uint32_t lo = (uint32_t)t * 64, hi = lo + 64;           // frame offsets of this slice
+		uint32_t crc = 0, s1 = 0, sj = 0;
+		uint32_t initx = job.in_crc ^ 0xffffffffu;               // folded into the first 4 data bytes
+		if (hi > pad) {
+			uint32_t f0 = lo > pad ? lo : pad;
+			for (uint32_t f = f0; f < hi; f++) {
+				uint32_t i = f - pad;                            // data index
+				uint32_t b = lds[OFF_IN + h + i];
+				uint32_t bx = b ^ (i < 4 ? (initx >> (8 * i)) & 0xff : 0);
+				crc = bitbuf[(crc ^ bx) & 0xff] ^ (crc >> 8);
+				s1 += b;
+				sj += b * (n - i);                               // weight of byte i in Adler's s2
+			}
+		}
+		// CRC tree: combine neighbours, distance doubles; multiplier x^(8*64*2^l)
+		uint32_t mult = 0;                                           // x^(512) computed below
+		{
+			uint32_t m = 0x00800000u;                            // x^8
+			for (int k = 0; k < 6; k++) m = gf_mul(m, m);        // x^(8*64)
+			mult = m;
+		}
+#pragma unroll 1
+		for (int o = 1; o < 64; o <<= 1) {
+			uint32_t right = __shfl_down(crc, o, 64);
+			if ((lane & (2 * o - 1)) == 0) crc = gf_mul(crc, mult) ^ right;
+			mult = gf_mul(mult, mult);
+		}
+		if (lane == 0) scan[wave] = crc;
+		// Adler partial sums
+		uint32_t a1 = s1, a2 = sj % 65521u;
+		for (int o = 32; o > 0; o >>= 1) {
+			a1 += __shfl_down(a1, o, 64);
+			a2 += __shfl_down(a2, o, 64);
+		}
+		if (lane == 0) { scan[16 + wave] = a1; scan[32 + wave] = a2 % 65521u; }
+		__syncthreads();
+		if (wave == 0) {
+			uint32_t c = lane < 16 ? scan[lane] : 0;
+#pragma unroll 1
+			for (int o = 1; o < 16; o <<= 1) {
+				uint32_t right = __shfl_down(c, o, 64);
+				if ((lane & (2 * o - 1)) == 0) c = gf_mul(c, mult) ^ right;
+				mult = gf_mul(mult, mult);
+			}
+			uint32_t b1 = lane < 16 ? scan[16 + lane] : 0, b2 = lane < 16 ? scan[32 + lane] : 0;
+			for (int o = 8; o > 0; o >>= 1) {
+				b1 += __shfl_down(b1, o, 64);
+				b2 += __shfl_down(b2, o, 64);
+			}
+			if (lane == 0) {
+				if (n < 4) {
+					// too short for the init folding trick: plain bytewise
+					c = initx;
+					for (uint32_t i = 0; i < n; i++) c = bitbuf[(c ^ lds[OFF_IN + h + i]) & 0xff] ^ (c >> 8);
+				}
+				uint32_t ia = job.in_adler & 0xffff, ib = job.in_adler >> 16;
+				uint32_t s1f = (ia + b1) % 65521u;
+				uint32_t s2f = (uint32_t)(((uint64_t)ib + (uint64_t)n * ia + b2) % 65521u);
+				scan[48] = c ^ 0xffffffffu;
+				scan[49] = (s2f << 16) | s1f;
+			}
+		}
+		__syncthreads();
+		out_crc = scan[48];
+		out_adler = scan[49];
+		__syncthreads();
+	}
+	// clear the bit buffer (it held the CRC table)
+	for (uint32_t i = t; i < BITS_BYTES / 4; i += NT) bitbuf[i] = 0;
+
+	// ---------------- seed head[] with the window ----------------
+	for (uint32_t r = t; r < h; r += NT)
+		if (r + 4 <= end) atomicMax(&head[hash4(lds_ld32(inw, r))], r + 1);
+
+	// ---------------- block header ----------------
+	// misc[M_CARRY_BITS]: bits pending in bitbuf[0..]; misc[M_WORDBASE]: dwords already flushed
+	uint32_t *dstw = (uint32_t *)job.dst;
+	const uint32_t cap_words = job.dst_cap >> 2;
+	if (DHT) {
+		const nxz_dht_prepared_t *tb = &tables[job.dht_index];
+		uint32_t hb = tb->dhtlen + 3;                       // header bits
+		uint32_t nw = hb >> 5;                              // full words
+		for (uint32_t i = t; i <= nw; i += NT) {
+			uint32_t cur = i < 73 ? tb->dhtw[i] : 0, prev = i ? tb->dhtw[i - 1] : 0;
+			uint32_t w = (cur << 3) | (i ? prev >> 29 : 5u);
+			if (i < nw) { if (i < cap_words) dstw[i] = w; }
+			else bitbuf[0] = (hb & 31) ? (w & ((1u << (hb & 31)) - 1)) : 0;
+		}
+		if (t == 0) { misc[M_CARRY_BITS] = hb & 31; misc[M_WORDBASE] = nw; if (nw > cap_words) misc[M_ERR] = NXZ_CC_TARGET_SPACE; }
+	} else {
+		if (t == 0) { bitbuf[0] = 3u; misc[M_CARRY_BITS] = 3; misc[M_WORDBASE] = 0; }
+	}
+	__syncthreads();
+
+	Walk W{inw, mlen, cand, h, 0, end};
+
+	// ================= tiles =================
+	for (uint32_t tb0 = 0; tb0 < n; tb0 += PTILE) {
+		const uint32_t tn = n - tb0 < PTILE ? n - tb0 : PTILE;       // positions in this tile
+		const uint32_t nseg = (tn + PSEG - 1) / PSEG;
+		W.tile_base = tb0;
+
+		// ---- hash ----
+		for (uint32_t i = t; i < tn; i += NT) {
+			uint32_t r = h + tb0 + i;
+			cand[i] = (r + 4 <= end) ? (uint16_t)hash4(lds_ld32(inw, r)) : (uint16_t)NOHASH;
+		}
+		__syncthreads();
+
+		// ---- chain: one wave, 64 positions per step; lookups see every earlier step ----
+		if (wave == 0) {
+#pragma unroll 2
+			for (uint32_t i = lane; i < tn; i += 64) {
+				uint32_t hv = cand[i];
+				uint32_t r = h + tb0 + i;
+				uint32_t c = NOHASH;
+				if (hv != NOHASH) {
+					uint32_t old = __hip_atomic_load(&head[hv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if (old != 0 && r + 1 - old <= WINDOW) c = r - old;       // dist-1
+				}
+				cand[i] = (uint16_t)c;
+				// every lane's lookup above is issued before any lane's insert below (same wave)
+				if (hv != NOHASH) atomicMax(&head[hv], r + 1);
+			}
+		}
+		__syncthreads();
+
+		// ---- match: verify, extend (capped), distance-1 run check ----
+		for (uint32_t i = t; i < tn; i += NT) {
+			uint32_t r = h + tb0 + i;
+			uint32_t len = 0, c = cand[i];
+			if (r + 4 <= end) {
+				uint32_t v = lds_ld32(inw, r);
+				uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+				uint32_t lim = maxlen < CAPLEN ? maxlen : CAPLEN;
+				if (c != NOHASH) {
+					uint32_t q = r - (c + 1);
+					if (lds_ld32(inw, q) == v) len = extend(inw, q, r, 4, lim);
+					else c = NOHASH;
+				}
+				if (r >= 1 && lds_ld32(inw, r - 1) == v) {
+					uint32_t l1 = extend(inw, r - 1, r, 4, lim);
+					// oracle: the run wins when its FULL length >= the hash match's full length.
+					// Capped lengths compare equal only if both reach the cap; then the run's
+					// full length (limited only by maxlen) must be compared exactly.
+					bool take = l1 > len;
+					if (l1 == len) {
+						if (len < lim || lim == maxlen) take = true;
+						else {
+							uint32_t fa = extend(inw, r - (c + 1), r, CAPLEN, maxlen);
+							uint32_t fb = extend(inw, r - 1, r, CAPLEN, maxlen);
+							take = fb >= fa;
+						}
+					}
+					if (take) { len = l1; c = 0; }
+				}
+			}
+			mlen[i] = len >= 4 ? (uint8_t)(len - 3) : 0;
+			cand[i] = (uint16_t)c;
+		}
+		// chain bookkeeping init
+		for (uint32_t s = t; s < NSEG; s += NT) mark[s] = 0;
+		__syncthreads();
+
+		// ---- parse pass 1: speculative walk of segment s from its own start ----
+		if ((uint32_t)t < nseg) {
+			uint32_t p = t * PSEG, stop = p + PSEG < tn ? p + PSEG : tn;
+			while (p < stop) {
+				bool m;
+				p += walk_step(W, p, tn, m);
+			}
+			X[t] = (uint16_t)p;
+			jump[t] = (uint16_t)(p >= tn ? NSEG : p / PSEG);
+		}
+		if (t == 0) mark[0] = 1;
+		__syncthreads();
+		// ---- chain of entered segments by pointer doubling ----
+		for (int k = 0; k < 10; k++) {
+			uint32_t j = NSEG, j2 = NSEG;
+			if ((uint32_t)t < nseg) {
+				j = jump[t];
+				if (j < NSEG) {
+					if (mark[t]) mark[j] = 1;
+					j2 = jump[j];
+				}
+			}
+			__syncthreads();
+			if ((uint32_t)t < nseg) jump[t] = (uint16_t)j2;
+			__syncthreads();
+		}
+		// entries: entered segment s hands its exit to the segment that contains it
+		bool entered = (uint32_t)t < nseg && mark[t];
+		uint32_t myx = (uint32_t)t < nseg ? X[t] : 0;
+		__syncthreads();
+		if (t == 0) entry[0] = 0;
+		if (entered && myx < tn) entry[myx / PSEG] = (uint16_t)myx;
+		// token bitmaps (alias mark/jump) are cleared now
+		__syncthreads();
+		uint32_t mye = entered ? entry[t] : 0;
+		__syncthreads();
+		for (uint32_t i = t; i < PTILE / 32; i += NT) { sbits[i] = 0; mbits[i] = 0; }
+		__syncthreads();
+
+		// ---- parse pass 2: entered segments walk [entry, X[s]) for real ----
+		if (entered) {
+			uint32_t p = mye, lim = myx;
+			while (p < lim) {
+				bool m;
+				uint32_t l = walk_step(W, p, lim, m);
+				atomicOr(&sbits[p >> 5], 1u << (p & 31));
+				if (m) {
+					atomicOr(&mbits[p >> 5], 1u << (p & 31));
+					mlen[p] = (uint8_t)(l - 3);
+				}
+				p += l;
+			}
+		}
+		__syncthreads();
+
+		// ---- encode ----
+		for (uint32_t e0 = 0; e0 < tn; e0 += ETILE) {
+			const uint32_t en = tn - e0 < ETILE ? tn - e0 : ETILE;
+			// two consecutive positions per thread
+			uint64_t val[2]; uint32_t nb[2];
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				uint32_t p = e0 + 2 * t + k;
+				val[k] = 0; nb[k] = 0;
+				if (2u * t + k < en && (sbits[p >> 5] >> (p & 31) & 1)) {
+					if (mbits[p >> 5] >> (p & 31) & 1) {
+						uint32_t l = mlen[p];                       // len-3
+						uint32_t d = cand[p];                       // dist-1
+						uint32_t le = l < 8 ? 0 : (29 - __builtin_clz(l));
+						uint32_t ls = l == 255 ? 28 : (le << 2) + (l >> le);
+						if (l == 255) le = 0;
+						uint32_t de = d < 4 ? 0 : (30 - __builtin_clz(d));
+						uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
+						uint32_t lt = lltab[257 + ls], dt = dtab[ds];
+						uint32_t ll = lt >> 16, dl = dt >> 16;
+						if (DHT && (ll == 0 || dl == 0)) misc[M_ERR] = NXZ_CC_MISSING_CODE;
+						uint64_t v = lt & 0xffff;
+						uint32_t b = ll;
+						v |= (uint64_t)(l & ((1u << le) - 1)) << b; b += le;
+						v |= (uint64_t)(dt & 0xffff) << b; b += dl;
+						v |= (uint64_t)(d & ((1u << de) - 1)) << b; b += de;
+						val[k] = v; nb[k] = b;
+						if (COUNT) { atomicAdd(&hist[257 + ls], 1u); atomicAdd(&hist[286 + ds], 1u); }
+					} else {
+						uint32_t byte = lds[OFF_IN + h + tb0 + p];
+						uint32_t lt = lltab[byte];
+						if (DHT && (lt >> 16) == 0) misc[M_ERR] = NXZ_CC_MISSING_CODE;
+						val[k] = lt & 0xffff; nb[k] = lt >> 16;
+						if (COUNT) atomicAdd(&hist[byte], 1u);
+					}
+				}
+			}
+			// workgroup exclusive prefix sum of bit counts
+			uint32_t mine = nb[0] + nb[1];
+			uint32_t incl = wave_incl_scan(mine, lane);
+			if (lane == 63) scan[wave] = incl;
+			__syncthreads();
+			uint32_t carry = misc[M_CARRY_BITS], wordbase = misc[M_WORDBASE];
+			uint32_t woff = 0, tot = 0;
+#pragma unroll
+			for (int w = 0; w < 16; w++) {
+				uint32_t s = scan[w];
+				if (w < wave) woff += s;
+				tot += s;
+			}
+			uint32_t bitpos = carry + woff + incl - mine;
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				if (nb[k]) {
+					uint32_t wi = bitpos >> 5, sh = bitpos & 31;
+					uint64_t lo = val[k] << sh;
+					atomicOr(&bitbuf[wi], (uint32_t)lo);
+					uint32_t mid = (uint32_t)(lo >> 32);
+					if (mid) atomicOr(&bitbuf[wi + 1], mid);
+					uint32_t hi2 = sh ? (uint32_t)(val[k] >> (64 - sh)) : 0;
+					if (hi2) atomicOr(&bitbuf[wi + 2], hi2);
+					bitpos += nb[k];
+				}
+			}
+			__syncthreads();
+			// flush full dwords, keep the partial one
+			uint32_t allbits = carry + tot, nw = allbits >> 5;
+			uint32_t last = bitbuf[nw];                                   // read before anyone rewrites word 0
+			for (uint32_t i = t; i < nw; i += NT) {
+				if (wordbase + i < cap_words) dstw[wordbase + i] = bitbuf[i];
+			}
+			__syncthreads();
+			for (uint32_t i = t; i <= nw + 2 && i < BITS_BYTES / 4; i += NT) bitbuf[i] = (i == 0) ? last : 0;
+			if (t == 0) {
+				misc[M_CARRY_BITS] = allbits & 31;
+				misc[M_WORDBASE] = wordbase + nw;
+				if (wordbase + nw > cap_words) misc[M_ERR] = NXZ_CC_TARGET_SPACE;
+			}
+			__syncthreads();
+		}
+	}
+
+	// ---------------- EOB + tail ----------------
+	if (t == 0) {
+		uint32_t carry = misc[M_CARRY_BITS], wordbase = misc[M_WORDBASE];
+		uint32_t lt = lltab[256];
+		uint32_t cc = misc[M_ERR];
+		if (DHT && (lt >> 16) == 0) cc = NXZ_CC_MISSING_CODE;
+		if (DHT && tables[job.dht_index].status) cc = NXZ_CC_INVALID_DHT;
+		uint64_t acc = (uint64_t)bitbuf[0] | ((uint64_t)(lt & 0xffff) << carry);
+		uint32_t bits = carry + (lt >> 16);
+		uint64_t totbits = (uint64_t)wordbase * 32 + bits;
+		uint32_t tpbc = (uint32_t)((totbits + 7) >> 3);
+		if (tpbc > job.dst_cap) cc = cc ? cc : NXZ_CC_TARGET_SPACE;
+		if (cc != NXZ_CC_TARGET_SPACE) {
+			uint8_t *o = job.dst + (size_t)wordbase * 4;
+			for (uint32_t k = 0; k < (bits + 7) / 8; k++) o[k] = (uint8_t)(acc >> (8 * k));
+		}
+		if (cc == 0 && tpbc > total) cc = NXZ_CC_TPBC_GT_SPBC;
+		nxz_batch_result_t r;
+		r.cc = cc; r.tpbc = cc == NXZ_CC_TARGET_SPACE ? 0 : tpbc; r.tebc = (uint32_t)(totbits & 7);
+		r.spbc = total; r.crc = out_crc; r.adler = out_adler; r.subc = 0; r.sfbt = 0;
+		results[blockIdx.x] = r;
+	}
+	if (COUNT) {
+		__syncthreads();
+		if (t < 316) counts[(size_t)blockIdx.x * 316 + t] = (t == 256) ? 1u : hist[t];
+	}
+}
+
+} // namespace nxz
+
+extern "C" int nxz_launch_deflate(int dht, int count, const nxz_batch_job_t *jobs, size_t n,
+				  const nxz_dht_prepared_t *tables, nxz_batch_result_t *results,
+				  uint32_t *counts, hipStream_t stream)
+{
+	using namespace nxz;
+	static bool attr_done = false;
+	void (*k)(const nxz_batch_job_t *, const nxz_dht_prepared_t *, nxz_batch_result_t *, uint32_t *);
+	if (dht) k = count ? deflate_kernel<true, true> : deflate_kernel<true, false>;
+	else     k = count ? deflate_kernel<false, true> : deflate_kernel<false, false>;
+	if (!attr_done) {
+		hipFuncSetAttribute((const void *)deflate_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+		hipFuncSetAttribute((const void *)deflate_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+		hipFuncSetAttribute((const void *)deflate_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+		hipFuncSetAttribute((const void *)deflate_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+		attr_done = true;
+	}
+	if (n == 0) return 0;
+	hipLaunchKernelGGL(k, dim3((unsigned)n), dim3(NT), LDS_BYTES, stream, jobs, tables, results, counts);
+	return (int)hipGetLastError();
+}

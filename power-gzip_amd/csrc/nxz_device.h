@@ -1,0 +1,30 @@
+// nxz_device.h -- structures shared by the host side of the engine and its HIP kernels.
+#ifndef NXZ_DEVICE_H
+#define NXZ_DEVICE_H
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/nxz_engine.h"
+
+// A DHT bit string (RFC1951 3.2.7, HLIT first, as carried in the CPB: inc_nx/nxu.h:390-393)
+// parsed once on the device into what the encoder needs.
+typedef struct nxz_dht_prepared {
+	uint32_t dhtlen;      // bits
+	uint32_t status;      // 0 ok, else NXZ_CC_INVALID_DHT
+	uint32_t dhtw[74];    // the bit string, zero padded
+	uint32_t ll[288];     // bit-reversed code | length << 16 (length 0 = symbol absent)
+	uint32_t d[32];
+} nxz_dht_prepared_t;
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+extern "C" {
+int nxz_launch_deflate(int dht, int count, const nxz_batch_job_t *jobs, size_t n,
+		       const nxz_dht_prepared_t *tables, nxz_batch_result_t *results,
+		       uint32_t *counts, hipStream_t stream);
+int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_dht_prepared_t *out, hipStream_t stream);
+int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
+int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
+		       nxz_batch_dht_t *dht_io, hipStream_t stream);
+}
+#endif
+#endif

@@ -1,0 +1,532 @@
+// nxz_engine.cpp -- host side of libnxz_engine.so: the C ABI of include/nxz_engine.h
+// on top of the HIP kernels (nxz_deflate.hip, nxz_inflate.hip, nxz_misc.hip).
+//
+// What it replaces in the reference (paths relative to the libnxz tree):
+//   lib/gzip_vas.c  -- open /dev/crypto/nx-gzip, VAS window, copy/paste of the
+//                      CRB, CSB polling (:94-417).  Here: a HIP stream per job
+//                      slot, pinned staging of the DDE gather/scatter lists,
+//                      kernel launch, and completion written to the CSB.
+//   lib/crc32_power.c -- __crc32_vpmsum (vector CRC on POWER).  Here: slice-by-8.
+// There is NO CPU fallback for the engine ops: without a gfx950 device
+// nx_function_begin fails with ENODEV and nxu_run_job completes jobs with
+// CC = NXZ_CC_NO_HW.
+#include <hip/hip_runtime.h>
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+#include <condition_variable>
+#include <mutex>
+#include <vector>
+#include "nxz_device.h"
+#include "../../include/nxz_wire.h"
+
+#define NXZ_VERSION "nxz-engine 0.1 (gfx950)"
+#define SUBBLOCK 65536u
+#define SLOTS 8
+
+static thread_local char g_err[256];
+static void set_err(const char *what, hipError_t e)
+{
+	snprintf(g_err, sizeof(g_err), "%s: %s", what, e == hipSuccess ? "error" : hipGetErrorString(e));
+}
+#define HIPCHK(x, fail) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(#x, e_); fail; } } while (0)
+
+extern "C" const char *nxz_last_error(void) { return g_err; }
+extern "C" const char *nxz_engine_version(void) { return NXZ_VERSION; }
+extern "C" size_t nxz_compress_bound(size_t n) { return ((n * 9 + 7) / 8 + 16 + 15) & ~(size_t)15; }
+
+// one in-flight single job (nxu_run_job)
+struct Slot {
+	hipStream_t stream = nullptr;
+	uint8_t *h_in = nullptr, *h_out = nullptr;      // pinned
+	uint8_t *d_in = nullptr, *d_out = nullptr;
+	nxz_batch_job_t *h_job = nullptr, *d_job = nullptr;
+	nxz_batch_result_t *h_res = nullptr, *d_res = nullptr;
+	nxz_batch_dht_t *h_dht = nullptr, *d_dht = nullptr;
+	nxz_dht_prepared_t *d_prep = nullptr;
+	uint32_t *h_cnt = nullptr, *d_cnt = nullptr;
+	bool busy = false;
+};
+
+#define OUT_CAP (SUBBLOCK * 2 + 4096)    /* staging for one job's target */
+#define INF_SRC_CAP (1u << 20)           /* decompress: source bytes taken per job */
+#define INF_OUT_CAP (4u << 20)
+
+struct nxz_ctx {
+	int device = 0;
+	int refs = 0;
+	hipStream_t stream = nullptr;                 // default stream for batch calls
+	std::mutex mtx;
+	std::condition_variable cv;
+	Slot slots[SLOTS];
+	// batch scratch
+	nxz_dht_prepared_t *d_prepared = nullptr;
+	size_t prepared_cap = 0;
+};
+
+static std::mutex g_mtx;
+static nxz_ctx *g_ctx[64];
+
+static bool slot_init(Slot &s)
+{
+	HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), return false);
+	HIPCHK(hipHostMalloc((void **)&s.h_in, INF_SRC_CAP + 64), return false);
+	HIPCHK(hipHostMalloc((void **)&s.h_out, INF_OUT_CAP), return false);
+	HIPCHK(hipMalloc((void **)&s.d_in, INF_SRC_CAP + 64), return false);
+	HIPCHK(hipMalloc((void **)&s.d_out, INF_OUT_CAP), return false);
+	HIPCHK(hipHostMalloc((void **)&s.h_job, sizeof(nxz_batch_job_t)), return false);
+	HIPCHK(hipMalloc((void **)&s.d_job, sizeof(nxz_batch_job_t)), return false);
+	HIPCHK(hipHostMalloc((void **)&s.h_res, sizeof(nxz_batch_result_t)), return false);
+	HIPCHK(hipMalloc((void **)&s.d_res, sizeof(nxz_batch_result_t)), return false);
+	HIPCHK(hipHostMalloc((void **)&s.h_dht, sizeof(nxz_batch_dht_t)), return false);
+	HIPCHK(hipMalloc((void **)&s.d_dht, sizeof(nxz_batch_dht_t)), return false);
+	HIPCHK(hipMalloc((void **)&s.d_prep, sizeof(nxz_dht_prepared_t)), return false);
+	HIPCHK(hipHostMalloc((void **)&s.h_cnt, 316 * 4), return false);
+	HIPCHK(hipMalloc((void **)&s.d_cnt, 316 * 4), return false);
+	return true;
+}
+
+static void slot_free(Slot &s)
+{
+	if (s.stream) (void)hipStreamDestroy(s.stream);
+	(void)hipHostFree(s.h_in); (void)hipHostFree(s.h_out); (void)hipFree(s.d_in); (void)hipFree(s.d_out);
+	(void)hipHostFree(s.h_job); (void)hipFree(s.d_job); (void)hipHostFree(s.h_res); (void)hipFree(s.d_res);
+	(void)hipHostFree(s.h_dht); (void)hipFree(s.d_dht); (void)hipFree(s.d_prep);
+	(void)hipHostFree(s.h_cnt); (void)hipFree(s.d_cnt);
+	s = Slot();
+}
+
+extern "C" nxz_ctx_t *nxz_ctx_create(int device)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		snprintf(g_err, sizeof(g_err), "no HIP device: the DEFLATE engine needs a gfx950 GPU (no CPU fallback)");
+		errno = ENODEV;
+		return nullptr;
+	}
+	if (device < 0) {
+		const char *e = getenv("NXZ_DEVICE");
+		device = e ? atoi(e) : 0;
+		if (!e) (void)hipGetDevice(&device);
+	}
+	if (device >= ndev || device >= 64) { errno = ENODEV; snprintf(g_err, sizeof(g_err), "device %d out of range", device); return nullptr; }
+	std::lock_guard<std::mutex> g(g_mtx);
+	if (g_ctx[device]) { g_ctx[device]->refs++; return g_ctx[device]; }
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, device), { errno = ENODEV; return nullptr; });
+	if (!strstr(prop.gcnArchName, "gfx950")) {
+		snprintf(g_err, sizeof(g_err), "device %d is %s: this engine is built for gfx950 only", device, prop.gcnArchName);
+		errno = ENODEV;
+		return nullptr;
+	}
+	HIPCHK(hipSetDevice(device), { errno = ENODEV; return nullptr; });
+	nxz_ctx *c = new nxz_ctx();
+	c->device = device;
+	c->refs = 1;
+	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), { delete c; errno = ENODEV; return nullptr; });
+	g_ctx[device] = c;
+	return c;
+}
+
+extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
+{
+	if (!c) return;
+	std::lock_guard<std::mutex> g(g_mtx);
+	if (--c->refs > 0) return;
+	(void)hipSetDevice(c->device);
+	for (auto &s : c->slots) if (s.stream) slot_free(s);
+	if (c->d_prepared) (void)hipFree(c->d_prepared);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	g_ctx[c->device] = nullptr;
+	delete c;
+}
+
+extern "C" int nxz_ctx_sync(nxz_ctx_t *c, void *stream)
+{
+	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	HIPCHK(hipStreamSynchronize(s), return -EIO);
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// batched, device-resident interface
+// ---------------------------------------------------------------------------
+extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *jobs, size_t n,
+				  const nxz_batch_dht_t *dht, size_t ntables, nxz_batch_result_t *results,
+				  uint32_t *counts, void *stream)
+{
+	if (!c || !nxz_fc_is_compress((uint32_t)fc) || (fc & 1)) return -EINVAL;
+	const bool isdht = nxz_fc_is_dht((uint32_t)fc), count = nxz_fc_has_count((uint32_t)fc);
+	if (count && !counts) return -EINVAL;
+	if (isdht && (!dht || !ntables)) return -EINVAL;
+	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	if (isdht) {
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			if (c->prepared_cap < ntables) {
+				// grows only: warm up once with the largest batch before timing a loop
+				if (c->d_prepared) { (void)hipStreamSynchronize(s); (void)hipFree(c->d_prepared); }
+				c->d_prepared = nullptr; c->prepared_cap = 0;
+				HIPCHK(hipMalloc((void **)&c->d_prepared, ntables * sizeof(nxz_dht_prepared_t)), return -ENOMEM);
+				c->prepared_cap = ntables;
+			}
+		}
+		int rc = nxz_launch_dht_prepare(dht, ntables, c->d_prepared, s);
+		if (rc) { set_err("dht prepare launch", (hipError_t)rc); return -EIO; }
+	}
+	int rc = nxz_launch_deflate(isdht, count, jobs, n, c->d_prepared, results, counts, s);
+	if (rc) { set_err("deflate launch", (hipError_t)rc); return -EIO; }
+	return 0;
+}
+
+extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n,
+				    nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, void *stream)
+{
+	if (!c) return -EINVAL;
+	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	int rc = nxz_launch_inflate(jobs, n, results, dht_io, s);
+	if (rc) { set_err("inflate launch", (hipError_t)rc); return -EIO; }
+	return 0;
+}
+
+extern "C" int nxz_batch_wrap(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n,
+			      nxz_batch_result_t *results, void *stream)
+{
+	if (!c) return -EINVAL;
+	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	int rc = nxz_launch_wrap(jobs, n, results, s);
+	if (rc) { set_err("wrap launch", (hipError_t)rc); return -EIO; }
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// the reference's transport symbols
+// ---------------------------------------------------------------------------
+extern "C" uint64_t tb_freq = 512000000ull;
+
+static uint64_t tb_now(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (uint64_t)ts.tv_sec * 512000000ull + (uint64_t)ts.tv_nsec * 512ull / 1000ull;
+}
+
+extern "C" uint64_t nx_wait_ticks(uint64_t ticks, uint64_t accumulated, int do_sleep)
+{
+	uint64_t t0 = tb_now(), t1 = t0;
+	if (do_sleep && accumulated > 110000) {
+		uint64_t us = accumulated / 512;
+		usleep(us > 1000 ? 1000 : (useconds_t)us);
+		t1 = tb_now();
+	} else {
+		while (t1 - t0 <= ticks) t1 = tb_now();
+	}
+	return accumulated + (t1 - t0);
+}
+
+extern "C" int nx_function_begin(int function, int pri, void *handle)
+{
+	nxz_dev_t *h = (nxz_dev_t *)handle;
+	if (function != NXZ_FUNC_COMP_GZIP || !h) { errno = EINVAL; return -1; }
+	nxz_ctx_t *c = nxz_ctx_create(pri);
+	if (!c) { if (!errno) errno = ENODEV; fprintf(stderr, "nxz: %s\n", g_err); return -1; }
+	h->function = function;
+	h->paste_addr = c;
+	h->fd = c->device + 1;
+	return 0;
+}
+
+extern "C" int nx_function_end(void *handle)
+{
+	nxz_dev_t *h = (nxz_dev_t *)handle;
+	if (!h) return -1;
+	if (h->paste_addr) nxz_ctx_destroy((nxz_ctx_t *)h->paste_addr);
+	h->paste_addr = nullptr;
+	h->fd = 0;
+	return 0;
+}
+
+static Slot *slot_acquire(nxz_ctx *c)
+{
+	std::unique_lock<std::mutex> g(c->mtx);
+	for (;;) {
+		for (auto &s : c->slots) {
+			if (!s.busy) {
+				s.busy = true;
+				if (!s.stream) {
+					g.unlock();
+					(void)hipSetDevice(c->device);
+					bool ok = slot_init(s);
+					g.lock();
+					if (!ok) { s.busy = false; return nullptr; }
+				}
+				return &s;
+			}
+		}
+		c->cv.wait(g);
+	}
+}
+
+static void slot_release(nxz_ctx *c, Slot *s)
+{
+	{ std::lock_guard<std::mutex> g(c->mtx); s->busy = false; }
+	c->cv.notify_one();
+}
+
+// gather `want` bytes starting `skip` bytes into the DDE list
+static uint32_t dde_gather(const nxz_dde_t *d, uint32_t skip, uint8_t *dst, uint32_t want)
+{
+	uint32_t total = nxz_dde_bytes(d), cnt = nxz_dde_count(d), got = 0;
+	if (cnt == 0) {
+		if (skip >= total) return 0;
+		uint32_t k = total - skip < want ? total - skip : want;
+		memcpy(dst, (const uint8_t *)nxz_dde_addr(d) + skip, k);
+		return k;
+	}
+	const nxz_dde_t *l = (const nxz_dde_t *)nxz_dde_addr(d);
+	uint32_t off = 0;
+	for (uint32_t i = 0; i < cnt && off < total && got < want; i++) {
+		uint32_t k = nxz_dde_bytes(&l[i]);
+		if (k > total - off) k = total - off;
+		uint32_t lo = off, hi = off + k;
+		if (hi > skip) {
+			uint32_t from = lo > skip ? 0 : skip - lo;
+			uint32_t take = k - from < want - got ? k - from : want - got;
+			memcpy(dst + got, (const uint8_t *)nxz_dde_addr(&l[i]) + from, take);
+			got += take;
+		}
+		off += k;
+	}
+	return got;
+}
+
+static uint32_t dde_capacity(const nxz_dde_t *d)
+{
+	uint32_t total = nxz_dde_bytes(d), cnt = nxz_dde_count(d), sum = 0;
+	if (cnt == 0) return total;
+	const nxz_dde_t *l = (const nxz_dde_t *)nxz_dde_addr(d);
+	for (uint32_t i = 0; i < cnt; i++) sum += nxz_dde_bytes(&l[i]);
+	return sum < total ? sum : total;
+}
+
+static void dde_scatter(const nxz_dde_t *d, const uint8_t *src, uint32_t n)
+{
+	uint32_t cnt = nxz_dde_count(d), off = 0;
+	if (cnt == 0) { if (n) memcpy(nxz_dde_addr(d), src, n); return; }
+	const nxz_dde_t *l = (const nxz_dde_t *)nxz_dde_addr(d);
+	for (uint32_t i = 0; i < cnt && off < n; i++) {
+		uint32_t k = nxz_dde_bytes(&l[i]);
+		if (k > n - off) k = n - off;
+		memcpy(nxz_dde_addr(&l[i]), src + off, k);
+		off += k;
+	}
+}
+
+static void put_cksums(nxz_crb_cpb_t *j, uint32_t crc, uint32_t adler)
+{
+	nxz_wr32(&j->cpb.out_adler_be, adler);
+	j->cpb.out_crc_le = htole32(crc);
+}
+
+static int run_compress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
+{
+	uint32_t srctotal = nxz_dde_bytes(&j->crb.source);
+	uint32_t hist = nxz_fc_is_resume(fc) ? nxz_in_histlen(&j->cpb) * 16 : 0;
+	if (hist > srctotal) hist = srctotal;
+	// only the last 32 KiB of history can be referenced (inc_nx/nxu.h:303-317)
+	uint32_t skip = hist > 32768 ? hist - 32768 : 0;
+	uint32_t h = hist - skip;
+	uint32_t n = srctotal - hist;
+	bool partial = false;
+	if (h + n > SUBBLOCK) { n = SUBBLOCK - h; partial = true; }     // byte-count limit -> CC 3 partial
+	uint32_t got = dde_gather(&j->crb.source, skip, s->h_in, h + n);
+	if (got < h) { h = got; n = 0; } else n = got - h;
+	uint32_t cap = dde_capacity(&j->crb.target);
+	uint32_t dcap = cap < OUT_CAP ? cap & ~3u : OUT_CAP;
+	if (cap < 4) dcap = 0;
+	bool dht = nxz_fc_is_dht(fc), count = nxz_fc_has_count(fc);
+
+	nxz_batch_job_t *bj = s->h_job;
+	bj->src = s->d_in; bj->dst = s->d_out; bj->src_len = h + n; bj->hist_len = h;
+	bj->dst_cap = dcap; bj->in_crc = nxz_in_crc(&j->cpb); bj->in_adler = nxz_in_adler(&j->cpb); bj->dht_index = 0;
+	HIPCHK(hipMemcpyAsync(s->d_in, s->h_in, h + n, hipMemcpyHostToDevice, s->stream), return -EIO);
+	HIPCHK(hipMemcpyAsync(s->d_job, bj, sizeof(*bj), hipMemcpyHostToDevice, s->stream), return -EIO);
+	if (dht) {
+		uint32_t dhtlen = nxz_in_dhtlen(&j->cpb);
+		s->h_dht->dhtlen = dhtlen;
+		memcpy(s->h_dht->dht, j->cpb.in_dht, NXZ_DHT_MAXSZ);
+		HIPCHK(hipMemcpyAsync(s->d_dht, s->h_dht, sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s->stream), return -EIO);
+		if (nxz_launch_dht_prepare(s->d_dht, 1, s->d_prep, s->stream)) return -EIO;
+	}
+	if (nxz_launch_deflate(dht, count, s->d_job, 1, s->d_prep, s->d_res, s->d_cnt, s->stream)) return -EIO;
+	HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
+	if (count) HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, 316 * 4, hipMemcpyDeviceToHost, s->stream), return -EIO);
+	HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
+
+	nxz_batch_result_t r = *s->h_res;
+	uint32_t cc = r.cc, ce = 0, tpbc = 0;
+	if (dht && cc == 0) {
+		// status of the table parse travels in the prepared table; a bad table shows as missing codes
+	}
+	if (cc == NXZ_CC_TARGET_SPACE || cc == NXZ_CC_MISSING_CODE || cc == NXZ_CC_INVALID_DHT) {
+		ce = NXZ_CE_TERMINATE;
+	} else {
+		tpbc = r.tpbc;
+		if (tpbc > cap) { cc = NXZ_CC_TARGET_SPACE; ce = NXZ_CE_TERMINATE; tpbc = 0; }
+	}
+	if (ce != NXZ_CE_TERMINATE) {
+		HIPCHK(hipMemcpyAsync(s->h_out, s->d_out, tpbc, hipMemcpyDeviceToHost, s->stream), return -EIO);
+		HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
+		dde_scatter(&j->crb.target, s->h_out, tpbc);
+		nxz_putf(&j->cpb.out_w2_be, 16, 3, r.tebc);
+		put_cksums(j, r.crc, r.adler);
+		uint32_t spbc = skip + r.spbc;
+		if (count) {
+			for (int i = 0; i < 316; i++) nxz_wr32(&j->cpb.u.out_lzcount_be[i], s->h_cnt[i]);
+			nxz_wr32(&j->cpb.out_spbc_with_count_be, spbc);
+		} else {
+			nxz_wr32(&j->cpb.u.out_spbc_be, spbc);
+		}
+		if (cc == 0 && partial) { cc = NXZ_CC_DATA_LENGTH; ce = NXZ_CE_PARTIAL | NXZ_CE_TPBC_VALID; }
+	}
+	nxz_csb_complete(j, cc, ce, tpbc);
+	return 0;
+}
+
+static int run_wrap(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j)
+{
+	uint32_t n = nxz_dde_bytes(&j->crb.source), cap = dde_capacity(&j->crb.target);
+	if (n > INF_SRC_CAP) n = INF_SRC_CAP;
+	if (n > cap) { nxz_csb_complete(j, NXZ_CC_TARGET_SPACE, NXZ_CE_TERMINATE, 0); return 0; }
+	n = dde_gather(&j->crb.source, 0, s->h_in, n);
+	nxz_batch_job_t *bj = s->h_job;
+	memset(bj, 0, sizeof(*bj));
+	bj->src = s->d_in; bj->dst = s->d_out; bj->src_len = n; bj->dst_cap = INF_OUT_CAP;
+	HIPCHK(hipMemcpyAsync(s->d_in, s->h_in, n, hipMemcpyHostToDevice, s->stream), return -EIO);
+	HIPCHK(hipMemcpyAsync(s->d_job, bj, sizeof(*bj), hipMemcpyHostToDevice, s->stream), return -EIO);
+	if (nxz_launch_wrap(s->d_job, 1, s->d_res, s->stream)) return -EIO;
+	HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
+	HIPCHK(hipMemcpyAsync(s->h_out, s->d_out, n, hipMemcpyDeviceToHost, s->stream), return -EIO);
+	HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
+	dde_scatter(&j->crb.target, s->h_out, n);
+	put_cksums(j, s->h_res->crc, s->h_res->adler);
+	nxz_wr32(&j->cpb.u.out_spbc_be, n);
+	nxz_csb_complete(j, s->h_res->cc, 0, n);
+	return 0;
+}
+
+static int run_decompress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
+{
+	uint32_t srctotal = nxz_dde_bytes(&j->crb.source);
+	bool resume = nxz_fc_is_resume(fc);
+	uint32_t hist = resume ? nxz_in_histlen(&j->cpb) * 16 : 0;
+	if (hist > srctotal) hist = srctotal;
+	uint32_t take = srctotal > INF_SRC_CAP ? INF_SRC_CAP : srctotal;
+	if (take < hist) take = hist;
+	uint32_t got = dde_gather(&j->crb.source, 0, s->h_in, take);
+	if (got < hist) hist = got;
+	uint32_t cap = dde_capacity(&j->crb.target);
+	uint32_t dcap = cap < INF_OUT_CAP ? cap : INF_OUT_CAP;
+	nxz_batch_job_t *bj = s->h_job;
+	memset(bj, 0, sizeof(*bj));
+	bj->src = s->d_in; bj->dst = s->d_out; bj->src_len = got; bj->hist_len = hist; bj->dst_cap = dcap;
+	bj->in_crc = nxz_in_crc(&j->cpb); bj->in_adler = nxz_in_adler(&j->cpb);
+	if (resume) {
+		uint32_t sfbt = nxz_in_sfbt(&j->cpb);
+		bj->resume = (sfbt << 16) | (nxz_in_subc(&j->cpb) << 20);
+		if ((sfbt & 0xe) == 0x8) bj->resume |= nxz_in_rembytecnt(&j->cpb);
+		if ((sfbt & 0xe) == 0xc) {
+			s->h_dht->dhtlen = nxz_in_dhtlen(&j->cpb);
+			memcpy(s->h_dht->dht, j->cpb.in_dht, NXZ_DHT_MAXSZ);
+			HIPCHK(hipMemcpyAsync(s->d_dht, s->h_dht, sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s->stream), return -EIO);
+		}
+	}
+	HIPCHK(hipMemcpyAsync(s->d_in, s->h_in, got, hipMemcpyHostToDevice, s->stream), return -EIO);
+	HIPCHK(hipMemcpyAsync(s->d_job, bj, sizeof(*bj), hipMemcpyHostToDevice, s->stream), return -EIO);
+	if (nxz_launch_inflate(s->d_job, 1, s->d_res, s->d_dht, s->stream)) return -EIO;
+	HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
+	HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
+	nxz_batch_result_t r = *s->h_res;
+	uint32_t cc = r.cc, ce = 0, tpbc = 0;
+	if (cc != 0 && cc != NXZ_CC_DATA_LENGTH) {
+		ce = NXZ_CE_TERMINATE;
+	} else {
+		tpbc = r.tpbc;
+		uint32_t sfbt = r.sfbt & 0xf;
+		if (tpbc) {
+			HIPCHK(hipMemcpyAsync(s->h_out, s->d_out, tpbc, hipMemcpyDeviceToHost, s->stream), return -EIO);
+		}
+		if ((sfbt & 0xe) == 0xc)
+			HIPCHK(hipMemcpyAsync(s->h_dht, s->d_dht, sizeof(nxz_batch_dht_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
+		HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
+		dde_scatter(&j->crb.target, s->h_out, tpbc);
+		put_cksums(j, r.crc, r.adler);
+		nxz_wr32(&j->cpb.out_w2_be, r.subc & 0xffff);
+		nxz_wr32(&j->cpb.out_w3_be, 0);
+		nxz_putf(&j->cpb.out_w3_be, 16, 4, sfbt);
+		if ((sfbt & 0xe) == 0x8) nxz_putf(&j->cpb.out_w3_be, 0, 16, r.tebc);
+		else if ((sfbt & 0xe) == 0xc) {
+			nxz_putf(&j->cpb.out_w3_be, 0, 12, s->h_dht->dhtlen);
+			memset(j->cpb.u.d.out_dht, 0, NXZ_DHT_MAXSZ);
+			memcpy(j->cpb.u.d.out_dht, s->h_dht->dht, (s->h_dht->dhtlen + 7) / 8);
+		}
+		nxz_wr32(&j->cpb.u.d.out_spbc_decomp_be, r.spbc);
+		if (cc == NXZ_CC_DATA_LENGTH) ce = NXZ_CE_PARTIAL | NXZ_CE_TPBC_VALID;
+	}
+	nxz_csb_complete(j, cc, ce, tpbc);
+	return 0;
+}
+
+extern "C" int nxu_run_job(nxz_crb_cpb_t *j, void *handle)
+{
+	nxz_dev_t *h = (nxz_dev_t *)handle;
+	nxz_ctx *c = h ? (nxz_ctx *)h->paste_addr : nullptr;
+	if (!j) return -EINVAL;
+	if (!c) { nxz_csb_complete(j, NXZ_CC_NO_HW, NXZ_CE_TERMINATE, 0); return 0; }
+	uint32_t fc = nxz_fc(j);
+	Slot *s = slot_acquire(c);
+	if (!s) { nxz_csb_complete(j, NXZ_CC_NO_HW, NXZ_CE_TERMINATE, 0); return 0; }
+	(void)hipSetDevice(c->device);
+	int rc;
+	if (fc == NXZ_FC_WRAP) rc = run_wrap(c, s, j);
+	else if (nxz_fc_is_compress(fc) && !(fc & 1)) rc = run_compress(c, s, j, fc);
+	else if (fc == NXZ_FC_DECOMPRESS || fc == NXZ_FC_DECOMPRESS_RESUME) rc = run_decompress(c, s, j, fc);
+	else { nxz_csb_complete(j, NXZ_CC_INVALID_OP, NXZ_CE_TERMINATE, 0); rc = 0; }
+	slot_release(c, s);
+	if (rc) { fprintf(stderr, "nxz: job failed: %s\n", g_err); return -EAGAIN; }
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// __crc32_vpmsum: raw CRC-32 register update (no pre/post inversion), slice-by-8
+// ---------------------------------------------------------------------------
+static uint32_t crc_t[8][256];
+static std::once_flag crc_once;
+static void crc_tables(void)
+{
+	for (uint32_t i = 0; i < 256; i++) {
+		uint32_t c = i;
+		for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1) ? 0xedb88320u : 0);
+		crc_t[0][i] = c;
+	}
+	for (uint32_t i = 0; i < 256; i++)
+		for (int k = 1; k < 8; k++) crc_t[k][i] = crc_t[0][crc_t[k - 1][i] & 0xff] ^ (crc_t[k - 1][i] >> 8);
+}
+
+extern "C" unsigned int __crc32_vpmsum(unsigned int crc, const unsigned char *p, unsigned long len)
+{
+	std::call_once(crc_once, crc_tables);
+	while (len && ((uintptr_t)p & 7)) { crc = crc_t[0][(crc ^ *p++) & 0xff] ^ (crc >> 8); len--; }
+	while (len >= 8) {
+		uint64_t v; memcpy(&v, p, 8);
+		v = le64toh(v) ^ crc;
+		crc = crc_t[7][v & 0xff] ^ crc_t[6][(v >> 8) & 0xff] ^ crc_t[5][(v >> 16) & 0xff] ^ crc_t[4][(v >> 24) & 0xff] ^
+		      crc_t[3][(v >> 32) & 0xff] ^ crc_t[2][(v >> 40) & 0xff] ^ crc_t[1][(v >> 48) & 0xff] ^ crc_t[0][v >> 56];
+		p += 8; len -= 8;
+	}
+	while (len--) crc = crc_t[0][(crc ^ *p++) & 0xff] ^ (crc >> 8);
+	return crc;
+}

@@ -1,0 +1,500 @@
+// nxz_inflate.hip -- DEFLATE decompression engine for MI355X (gfx950, wave64).
+//
+// Replaces the POWER NX accelerator's GZIP_FC_DECOMPRESS / _RESUME function
+// codes (issued at /root/reference lib/nx_inflate.c:909-912; resume inputs
+// inc_nx/nxu.h:296-393, outputs :403-541, consumer lib/nx_inflate.c:1308-1609).
+// Same decisions as the CPU restatement oracle/nxz_inflate.c.
+//
+// One wavefront per stream (workgroup = 64 lanes, 43 KiB LDS -> 3 streams per
+// CU, 768 per chip): a deflate stream is serial by construction, so the
+// symbol loop is wave-uniform and the lanes are used where there is width:
+//   - coalesced 16 B/lane staging of the compressed input into LDS
+//   - decode-table construction (lane per symbol)
+//   - match copies (lane per byte, pattern-replicated for dist < len)
+//   - 16 KiB coalesced flushes of the LDS output window + CRC-32/Adler-32
+//     (lane per 256-byte slice, GF(2) tree combine)
+// The 32 KiB circular output window in LDS is also the history, so match
+// sources never touch HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nxz_device.h"
+
+namespace nxzi {
+
+constexpr uint32_t WIN = 32768, WMASK = WIN - 1;
+constexpr uint32_t FLUSH = 16384;
+constexpr uint32_t STAGE = 4096;             // staged compressed bytes
+constexpr int LBITS = 11, DBITS = 9;
+
+struct Huff {
+	uint16_t fast[1 << LBITS];   // symbol | len << 12 ; 0 = use slow path
+	uint16_t sym[288];           // symbols sorted by (len, symbol)
+	uint16_t count[16];
+};
+struct HuffD {
+	uint16_t fast[1 << DBITS];
+	uint16_t sym[32];
+	uint16_t count[16];
+};
+
+struct Smem {
+	uint8_t win[WIN];
+	uint32_t stage[STAGE / 4 + 4];
+	Huff hl;
+	HuffD hd;
+	uint8_t lens[320];
+	uint32_t red[3 * 64];
+	uint32_t crctab[256];
+};
+
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)
+{
+	uint32_t r = 0;
+#pragma unroll 8
+	for (int i = 0; i < 32; i++) {
+		r ^= (b & 0x80000000u) ? a : 0;
+		a = (a >> 1) ^ ((a & 1) ? 0xedb88320u : 0);
+		b <<= 1;
+	}
+	return r;
+}
+
+__device__ __forceinline__ uint32_t gf_xpow8(uint32_t n)   // x^(8n)
+{
+	uint32_t r = 0x80000000u, sq = 0x00800000u;
+	while (n) { if (n & 1) r = gf_mul(r, sq); sq = gf_mul(sq, sq); n >>= 1; }
+	return r;
+}
+
+// Build the decode tables for `n` symbols with code lengths len[] (wave cooperative).
+template <int FB, typename H>
+__device__ void build(H &h, const uint8_t *len, int n, int lane)
+{
+	for (int i = lane; i < (1 << FB); i += 64) h.fast[i] = 0;
+	if (lane < 16) h.count[lane] = 0;
+	__syncthreads();
+	if (lane == 0) {
+		uint16_t offs[16];
+		for (int i = 0; i < n; i++) h.count[len[i]]++;
+		h.count[0] = 0;
+		offs[1] = 0;
+		for (int i = 1; i < 15; i++) offs[i + 1] = offs[i] + h.count[i];
+		for (int i = 0; i < n; i++) if (len[i]) h.sym[offs[len[i]]++] = (uint16_t)i;
+	}
+	__syncthreads();
+	// canonical codes: next[l]; each lane recomputes (16 steps) then handles symbols lane, lane+64, ...
+	uint32_t next[16], c = 0;
+	for (int b = 1; b <= 15; b++) { c = (c + (b > 1 ? h.count[b - 1] : 0)) << 1; next[b] = c; }
+	// rank of symbol i among symbols of equal length = number of smaller symbols with that length
+	for (int i = lane; i < n; i += 64) {
+		uint32_t l = len[i];
+		if (l == 0 || l > (uint32_t)FB) continue;
+		uint32_t rank = 0;
+		for (int k = 0; k < i; k++) rank += (len[k] == l);
+		uint32_t code = next[l] + rank;
+		uint32_t rev = __builtin_bitreverse32(code) >> (32 - l);
+		for (uint32_t idx = rev; idx < (1u << FB); idx += (1u << l)) h.fast[idx] = (uint16_t)(i | (l << 12));
+	}
+	__syncthreads();
+}
+
+struct Bits {
+	const uint8_t *src;       // global
+	uint32_t srclen;
+	uint64_t total_bits;      // 8*srclen
+	uint64_t pos;             // next unread bit
+	uint32_t stage_base;      // byte offset of stage[0] in src (multiple of 16), 0xffffffff = none
+	uint32_t *stage;
+	int lane;
+
+	__device__ void restage(uint32_t byte)
+	{
+		// all lanes: load STAGE bytes starting at byte & ~15
+		uint32_t base = byte & ~15u;
+		__syncthreads();
+		for (uint32_t i = lane; i < STAGE / 16; i += 64) {
+			uint32_t off = base + i * 16;
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (off + 16 <= srclen) v = *(const uint4 *)(src + off);
+			else if (off < srclen) {
+				uint32_t w[4] = {0, 0, 0, 0};
+				for (uint32_t k = 0; off + k < srclen; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
+				v = make_uint4(w[0], w[1], w[2], w[3]);
+			}
+			((uint4 *)stage)[i] = v;
+		}
+		stage_base = base;
+		__syncthreads();
+	}
+	// make sure [byte, byte+span) is staged (wave-uniform call)
+	__device__ __forceinline__ void ensure(uint32_t byte, uint32_t span)
+	{
+		if (stage_base == 0xffffffffu || byte < stage_base || byte + span > stage_base + STAGE) restage(byte);
+	}
+	// peek up to 32 bits at the current position (bits past the end read as 0)
+	__device__ __forceinline__ uint32_t peek()
+	{
+		ensure((uint32_t)(pos >> 3), 8);
+		return raw_peek();
+	}
+	__device__ __forceinline__ uint32_t raw_peek() const
+	{
+		uint32_t byte = (uint32_t)(pos >> 3);
+		uint32_t o = byte - stage_base;
+		uint32_t a = stage[o >> 2], b = stage[(o >> 2) + 1], c = stage[(o >> 2) + 2];
+		uint32_t lo = __builtin_amdgcn_alignbyte(b, a, o & 3);
+		uint32_t hi = __builtin_amdgcn_alignbyte(c, b, o & 3);
+		uint32_t sh = (uint32_t)pos & 7;
+		return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+	}
+	__device__ __forceinline__ bool have(uint32_t n) const { return pos + n <= total_bits; }
+};
+
+template <int FB, typename H>
+__device__ __forceinline__ int decode_sym(const H &h, uint32_t bits, uint32_t &nbits)
+{
+	uint32_t e = h.fast[bits & ((1u << FB) - 1)];
+	if (e) { nbits = e >> 12; return (int)(e & 0xfff); }
+	// slow canonical walk (codes longer than FB bits)
+	int code = 0, first = 0, index = 0;
+	for (int len = 1; len <= 15; len++) {
+		code |= (int)(bits & 1); bits >>= 1;
+		int count = h.count[len];
+		if (code - count < first) { nbits = len; return h.sym[index + (code - first)]; }
+		index += count; first += count; first <<= 1; code <<= 1;
+	}
+	nbits = 16;
+	return -2;
+}
+
+__device__ const uint16_t LEN_BASE[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
+	35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+__device__ const uint8_t LEN_EXTRA[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+__device__ const uint16_t DIST_BASE[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193,
+	257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+__device__ const uint8_t DIST_EXTRA[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+
+// Parse a dynamic block header at b.pos (after the 3 header bits).  Returns
+// 0 ok (lens filled, b.pos advanced, *tbits = table bits), 1 out of source, <0 invalid.
+__device__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist, uint32_t &tbits)
+{
+	const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+	uint64_t start = b.pos;
+	if (!b.have(14)) return 1;
+	uint32_t v = b.peek();
+	hlit = (v & 31) + 257; hdist = ((v >> 5) & 31) + 1;
+	int hclen = ((v >> 10) & 15) + 4;
+	b.pos += 14;
+	if (hlit > 286 || hdist > 30) return -1;
+	uint8_t cl[19];
+	for (int i = 0; i < 19; i++) cl[i] = 0;
+	for (int i = 0; i < hclen; i++) {
+		if (!b.have(3)) return 1;
+		cl[order[i]] = (uint8_t)(b.peek() & 7);
+		b.pos += 3;
+	}
+	// canonical code-length code (<= 7 bits): tiny table in registers via bit-by-bit decode
+	uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kraft = 0;
+	for (int i = 0; i < 19; i++) cnt[cl[i]]++;
+	cnt[0] = 0;
+	for (int l = 1; l <= 7; l++) kraft += cnt[l] << (7 - l);
+	if (kraft > 128) return -2;
+	uint8_t sorted[19]; int ns = 0;
+	for (int l = 1; l <= 7; l++) for (int i = 0; i < 19; i++) if (cl[i] == l) sorted[ns++] = (uint8_t)i;
+	int n = 0, prev = 0;
+	while (n < hlit + hdist) {
+		if (!b.have(1)) return 1;
+		uint32_t bits = b.peek();
+		int code = 0, first = 0, index = 0, sym = -1, len;
+		for (len = 1; len <= 7; len++) {
+			code |= (int)(bits & 1); bits >>= 1;
+			int count = (int)cnt[len];
+			if (code - count < first) { sym = sorted[index + (code - first)]; break; }
+			index += count; first += count; first <<= 1; code <<= 1;
+		}
+		if (sym < 0) return b.have(7) ? -3 : 1;
+		if (!b.have((uint32_t)len)) return 1;
+		b.pos += len;
+		if (sym < 16) { if (b.lane == 0) sm.lens[n] = (uint8_t)sym; n++; prev = sym; }
+		else {
+			int eb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
+			if (!b.have((uint32_t)eb)) return 1;
+			int rep = (int)(b.peek() & ((1u << eb) - 1)) + (sym == 18 ? 11 : 3);
+			b.pos += eb;
+			int val = 0;
+			if (sym == 16) { if (n == 0) return -4; val = prev; }
+			if (n + rep > hlit + hdist) return -5;
+			if (b.lane == 0) for (int k = 0; k < rep; k++) sm.lens[n + k] = (uint8_t)val;
+			n += rep;
+			if (sym != 16) prev = 0;
+		}
+	}
+	tbits = (uint32_t)(b.pos - start);
+	__syncthreads();
+	if (sm.lens[256] == 0) return -6;
+	// over-subscription check (lane 0 could do it; uniform loop is short enough)
+	uint32_t k1 = 0, k2 = 0;
+	for (int i = 0; i < hlit; i++) if (sm.lens[i]) k1 += 1u << (15 - sm.lens[i]);
+	for (int i = 0; i < hdist; i++) if (sm.lens[hlit + i]) k2 += 1u << (15 - sm.lens[hlit + i]);
+	if (k1 > (1u << 15) || k2 > (1u << 15)) return -7;
+	return 0;
+}
+
+// job.resume: rembytecnt | sfbt << 16 | subc << 20.  results: tebc field carries out_rembytecnt.
+__global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__restrict__ jobs,
+						     nxz_batch_result_t *__restrict__ results,
+						     nxz_batch_dht_t *__restrict__ dht_io)
+{
+	__shared__ __attribute__((aligned(16))) Smem sm;
+	const int lane = threadIdx.x;
+	const nxz_batch_job_t job = jobs[blockIdx.x];
+	const uint32_t hist = job.hist_len < job.src_len ? job.hist_len : job.src_len;
+	const uint32_t srclen = job.src_len - hist;
+	const uint8_t *src = job.src + hist;
+	uint8_t *dst = job.dst;
+	const uint32_t cap = job.dst_cap;
+
+	for (int i = lane; i < 256; i += 64) {
+		uint32_t c = i;
+		for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1) ? 0xedb88320u : 0);
+		sm.crctab[i] = c;
+	}
+	// history (the last <= 32 KiB before the output) goes into the window just below position 0
+	{
+		uint32_t h = hist > WIN ? WIN : hist;
+		const uint8_t *hp = job.src + (hist - h);
+		for (uint32_t i = lane; i < h; i += 64) sm.win[(0u - h + i) & WMASK] = hp[i];
+	}
+	__syncthreads();
+
+	Bits b;
+	b.src = src; b.srclen = srclen; b.total_bits = (uint64_t)srclen * 8; b.pos = 0;
+	b.stage_base = 0xffffffffu; b.stage = sm.stage; b.lane = lane;
+	uint32_t in_subc = (job.resume >> 20) & 7, in_sfbt = (job.resume >> 16) & 15, in_rem = job.resume & 0xffff;
+	if (srclen && in_subc) b.pos = 8 - in_subc;
+
+	uint32_t out = 0, flushed = 0;             // bytes produced / bytes already written to dst
+	uint32_t crc_state = job.in_crc ^ 0xffffffffu;
+	uint32_t ad1 = job.in_adler & 0xffff, ad2 = job.in_adler >> 16;
+	int state = 0;                             // 0 header, 1 stored, 2 coded
+	uint32_t bfinal = 0, btype = 0, rem = 0;
+	uint32_t cc = 0, o_sfbt = 0, o_subc = 0, o_rem = 0, dhtbits = 0;
+	bool final_eob = false, have_dht = false;
+
+	// flush window bytes [flushed, upto) to dst and fold them into the checksums
+	auto flush = [&](uint32_t upto) {
+		while (flushed < upto) {
+			uint32_t n = upto - flushed < FLUSH ? upto - flushed : FLUSH;
+			// right-aligned frame of 64 x 256 B slices
+			uint32_t pad = FLUSH - n, lo = lane * 256, hi = lo + 256;
+			uint32_t c = 0, s1 = 0, s2w = 0;
+			if (hi > pad) {
+				for (uint32_t f = lo > pad ? lo : pad; f < hi; f++) {
+					uint32_t i = f - pad;
+					uint32_t byte = sm.win[(flushed + i) & WMASK];
+					c = sm.crctab[(c ^ byte) & 0xff] ^ (c >> 8);
+					s1 += byte; s2w += byte * (n - i);
+				}
+			}
+			uint32_t mult = gf_xpow8(256);
+			for (int o = 1; o < 64; o <<= 1) {
+				uint32_t right = __shfl_down(c, o, 64);
+				if ((lane & (2 * o - 1)) == 0) c = gf_mul(c, mult) ^ right;
+				mult = gf_mul(mult, mult);
+			}
+			c = __shfl(c, 0, 64);
+			uint32_t t1 = s1, t2 = s2w % 65521u;
+			for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_down(t1, o, 64); t2 += __shfl_down(t2, o, 64); }
+			t1 = __shfl(t1, 0, 64); t2 = __shfl(t2, 0, 64);
+			crc_state = gf_mul(crc_state, n == FLUSH ? mult : gf_xpow8(n)) ^ c;   // mult == x^(8*16384) after the tree
+			ad2 = (uint32_t)((ad2 + (uint64_t)n * ad1 + t2) % 65521u);
+			ad1 = (ad1 + t1) % 65521u;
+			// coalesced copy out (dst + flushed is 16 B aligned when flushed is a multiple of FLUSH)
+			for (uint32_t i = lane * 16; i < n; i += 64 * 16) {
+				if (i + 16 <= n) {
+					uint4 v = *(const uint4 *)&sm.win[(flushed + i) & WMASK];
+					*(uint4 *)(dst + flushed + i) = v;
+				} else {
+					for (uint32_t k = i; k < n; k++) dst[flushed + k] = sm.win[(flushed + k) & WMASK];
+				}
+			}
+			flushed += n;
+			__syncthreads();
+		}
+	};
+
+	// resume state
+	if (in_sfbt & 8) {
+		uint32_t kind = (in_sfbt >> 1) & 7;
+		bfinal = in_sfbt & 1;
+		if (kind == 4) { state = 1; btype = 0; rem = in_rem; }
+		else if (kind == 5) { state = 2; btype = 1; }
+		else if (kind == 6) {
+			state = 2; btype = 2;
+			// re-parse the table handed back by the caller
+			const nxz_batch_dht_t *t = &dht_io[blockIdx.x];
+			Bits tb;
+			tb.src = t->dht; tb.srclen = (t->dhtlen + 7) / 8; tb.total_bits = t->dhtlen; tb.pos = 0;
+			tb.stage_base = 0xffffffffu; tb.stage = sm.stage; tb.lane = lane;
+			int hlit, hdist; uint32_t tbits;
+			int rc = read_dht(tb, sm, hlit, hdist, tbits);
+			if (rc != 0 || tbits != t->dhtlen) { cc = NXZ_CC_INVALID_DHT; goto done; }
+			build<LBITS>(sm.hl, sm.lens, hlit, lane);
+			build<DBITS>(sm.hd, sm.lens + hlit, hdist, lane);
+			have_dht = true; dhtbits = t->dhtlen;
+			b.stage_base = 0xffffffffu;
+		}
+	}
+	if (state == 2 && btype == 1) {
+		for (int i = lane; i < 288; i += 64) sm.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+		if (lane < 30) sm.lens[288 + lane] = 5;
+		__syncthreads();
+		build<LBITS>(sm.hl, sm.lens, 288, lane);
+		build<DBITS>(sm.hd, sm.lens + 288, 30, lane);
+	}
+
+	for (;;) {
+		if (state == 0) {
+			uint64_t hdr = b.pos;
+			if (!b.have(3)) { o_sfbt = 0xe; o_subc = (uint32_t)(b.total_bits - hdr); break; }
+			uint32_t v = b.peek();
+			bfinal = v & 1; btype = (v >> 1) & 3;
+			b.pos += 3;
+			if (btype == 0) {
+				b.pos = (b.pos + 7) & ~7ull;
+				if (!b.have(32)) { o_sfbt = 0xe | bfinal; o_subc = (uint32_t)(b.total_bits - hdr); break; }
+				uint32_t w = b.peek();
+				b.pos += 32;
+				if (((w ^ (w >> 16)) & 0xffff) != 0xffff) { cc = NXZ_CC_INVALID_DHT; break; }
+				rem = w & 0xffff;
+				state = 1;
+			} else if (btype == 1) {
+				for (int i = lane; i < 288; i += 64) sm.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+				if (lane < 30) sm.lens[288 + lane] = 5;
+				__syncthreads();
+				build<LBITS>(sm.hl, sm.lens, 288, lane);
+				build<DBITS>(sm.hd, sm.lens + 288, 30, lane);
+				state = 2;
+			} else if (btype == 2) {
+				int hlit, hdist; uint32_t tbits;
+				uint64_t tstart = b.pos;
+				int rc = read_dht(b, sm, hlit, hdist, tbits);
+				if (rc == 1) { o_sfbt = 0xe | bfinal; o_subc = (uint32_t)(b.total_bits - hdr); break; }
+				if (rc < 0) { cc = NXZ_CC_INVALID_DHT; break; }
+				build<LBITS>(sm.hl, sm.lens, hlit, lane);
+				build<DBITS>(sm.hd, sm.lens + hlit, hdist, lane);
+				// keep the table bits for a possible suspend inside this block
+				if (dht_io) {
+					nxz_batch_dht_t *t = &dht_io[blockIdx.x];
+					uint64_t save = b.pos;
+					b.ensure((uint32_t)(tstart >> 3), 320);
+					for (uint32_t i = lane; i < (tbits + 31) / 32; i += 64) {
+						b.pos = tstart + (uint64_t)i * 32;
+						uint32_t w = b.raw_peek();
+						if ((i + 1) * 32 > tbits && (tbits & 31)) w &= (1u << (tbits & 31)) - 1;
+						((uint32_t *)t->dht)[i] = w;       // dht[] is 4-byte aligned inside the struct
+					}
+					b.pos = save;
+					if (lane == 0) t->dhtlen = tbits;
+				}
+				have_dht = true; dhtbits = tbits;
+				state = 2;
+			} else { cc = NXZ_CC_INVALID_DHT; break; }
+		} else if (state == 1) {
+			// stored bytes: byte aligned; copy through the window
+			uint32_t srcleft = (uint32_t)((b.total_bits - b.pos) >> 3);
+			uint32_t n = rem < srcleft ? rem : srcleft;
+			if (n > cap - out) { cc = NXZ_CC_TARGET_SPACE; break; }
+			uint32_t sp = (uint32_t)(b.pos >> 3);
+			while (n) {
+				uint32_t room = FLUSH - (out - flushed);
+				uint32_t k = n < room ? n : room;
+				for (uint32_t i = lane; i < k; i += 64) sm.win[(out + i) & WMASK] = src[sp + i];
+				out += k; sp += k; n -= k; rem -= k;
+				__syncthreads();
+				if (out - flushed == FLUSH) flush(out);
+			}
+			b.pos = (uint64_t)sp * 8;
+			if (rem) { o_sfbt = 0x8 | bfinal; o_subc = 0; o_rem = rem; break; }
+			if (bfinal) { final_eob = true; break; }
+			state = 0;
+		} else {
+			uint64_t sym_start = b.pos;
+			uint32_t sfbt = (btype == 1 ? 0xa : 0xc) | bfinal;
+			uint32_t bits = b.peek(), nb;
+			int sym = decode_sym<LBITS>(sm.hl, bits, nb);
+			if (sym < 0 || !b.have(nb)) {
+				if (!b.have(sym < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total_bits - sym_start); break; }
+				cc = NXZ_CC_MISSING_CODE; break;
+			}
+			b.pos += nb;
+			if (sym < 256) {
+				if (out >= cap) { cc = NXZ_CC_TARGET_SPACE; break; }
+				if (lane == 0) sm.win[out & WMASK] = (uint8_t)sym;
+				out++;
+			} else if (sym == 256) {
+				if (bfinal) { final_eob = true; break; }
+				state = 0;
+				continue;
+			} else {
+				sym -= 257;
+				if (sym >= 29) { cc = NXZ_CC_MISSING_CODE; break; }
+				uint32_t eb = LEN_EXTRA[sym];
+				bits = b.peek();
+				if (!b.have(eb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total_bits - sym_start); break; }
+				uint32_t len = LEN_BASE[sym] + (bits & ((1u << eb) - 1));
+				b.pos += eb;
+				bits = b.peek();
+				int ds = decode_sym<DBITS>(sm.hd, bits, nb);
+				if (ds < 0 || !b.have(nb)) {
+					if (!b.have(ds < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total_bits - sym_start); break; }
+					cc = NXZ_CC_INVALID_DIST; break;
+				}
+				if (ds >= 30) { cc = NXZ_CC_INVALID_DIST; break; }
+				b.pos += nb;
+				eb = DIST_EXTRA[ds];
+				bits = b.peek();
+				if (!b.have(eb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total_bits - sym_start); break; }
+				uint32_t dist = DIST_BASE[ds] + (bits & ((1u << eb) - 1));
+				b.pos += eb;
+				if (dist > out + hist || dist > WIN) { cc = NXZ_CC_INVALID_DIST; break; }
+				if (len > cap - out) { cc = NXZ_CC_TARGET_SPACE; break; }
+				// lane per byte; source pattern repeats with period dist
+				for (uint32_t i = lane; i < len; i += 64) {
+					uint32_t k = dist >= len ? i : i % dist;
+					sm.win[(out + i) & WMASK] = sm.win[(out - dist + k) & WMASK];
+				}
+				out += len;
+			}
+			if (out - flushed >= FLUSH) { __syncthreads(); flush(flushed + FLUSH); }
+		}
+	}
+	if (final_eob) { o_sfbt = 0; o_subc = (uint32_t)(b.total_bits - b.pos); }
+done:
+	__syncthreads();
+	if (cc == 0) flush(out);
+	if (lane == 0) {
+		nxz_batch_result_t r;
+		uint32_t spbc = job.src_len, subc = o_subc;
+		if (final_eob && subc > 0xfff8) {              // 16-bit SUBC: leave the excess unread
+			uint32_t drop = (subc - 0xfff8 + 7) / 8;
+			spbc -= drop; subc -= drop * 8;
+		}
+		if (cc == 0 && !(final_eob && subc < 8)) cc = NXZ_CC_DATA_LENGTH;
+		r.cc = cc; r.tpbc = (cc == 0 || cc == NXZ_CC_DATA_LENGTH) ? out : 0;
+		r.tebc = o_rem; r.spbc = spbc;
+		r.crc = crc_state ^ 0xffffffffu; r.adler = (ad2 << 16) | ad1;
+		r.subc = subc; r.sfbt = o_sfbt | (final_eob ? 0x100u : 0) | (((o_sfbt & 0xe) == 0xc && have_dht) ? (dhtbits << 16) : 0);
+		results[blockIdx.x] = r;
+	}
+}
+
+} // namespace nxzi
+
+extern "C" int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
+				  nxz_batch_dht_t *dht_io, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL(nxzi::inflate_kernel, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
+	return (int)hipGetLastError();
+}

@@ -1,0 +1,158 @@
+"""ctypes binding of libnxz_engine.so (include/nxz_engine.h).
+
+Fails loudly when the shared library is missing or no gfx950 device is present: there is
+no CPU fallback on the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+FC_COMPRESS_FHT = 0x00
+FC_COMPRESS_DHT = 0x02
+FC_COMPRESS_FHT_COUNT = 0x04
+FC_COMPRESS_DHT_COUNT = 0x06
+FC_COMPRESS_RESUME_FHT = 0x08
+FC_COMPRESS_RESUME_DHT_COUNT = 0x0E
+FC_DECOMPRESS = 0x10
+FC_DECOMPRESS_RESUME = 0x14
+FC_WRAP = 0x1E
+
+# nxz_batch_job_t / nxz_batch_result_t / nxz_batch_dht_t
+JOB_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("src_len", "<u4"), ("hist_len", "<u4"),
+                      ("dst_cap", "<u4"), ("in_crc", "<u4"), ("in_adler", "<u4"), ("dht_index", "<u4"),
+                      ("resume", "<u4"), ("reserved", "<u4")])
+RESULT_DTYPE = np.dtype([("cc", "<u4"), ("tpbc", "<u4"), ("tebc", "<u4"), ("spbc", "<u4"),
+                         ("crc", "<u4"), ("adler", "<u4"), ("subc", "<u4"), ("sfbt", "<u4")])
+DHT_DTYPE = np.dtype([("dhtlen", "<u4"), ("dht", "u1", (292,))])
+assert JOB_DTYPE.itemsize == 48 and RESULT_DTYPE.itemsize == 32 and DHT_DTYPE.itemsize == 296
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(HERE, "libnxz_engine.so")
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree engine.  Raises EngineError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise EngineError("%s not built: run `make -C power-gzip_amd/csrc` (or __graft_entry__.build())" % p)
+        L = C.CDLL(p)
+        L.nxz_ctx_create.restype = C.c_void_p
+        L.nxz_ctx_create.argtypes = [C.c_int]
+        L.nxz_ctx_destroy.argtypes = [C.c_void_p]
+        L.nxz_last_error.restype = C.c_char_p
+        L.nxz_engine_version.restype = C.c_char_p
+        L.nxz_compress_bound.restype = C.c_size_t
+        L.nxz_compress_bound.argtypes = [C.c_size_t]
+        L.nxz_batch_compress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nxz_batch_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nxz_batch_wrap.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.nxz_ctx_sync.argtypes = [C.c_void_p, C.c_void_p]
+        L.nx_function_begin.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.nx_function_end.argtypes = [C.c_void_p]
+        L.nxu_run_job.argtypes = [C.c_void_p, C.c_void_p]
+        L.nx_wait_ticks.restype = C.c_uint64
+        L.nx_wait_ticks.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
+        L.__crc32_vpmsum.restype = C.c_uint
+        L.__crc32_vpmsum.argtypes = [C.c_uint, C.c_char_p, C.c_ulong]
+        _lib = L
+    return _lib
+
+
+class Engine:
+    """One engine context on a HIP device; batch calls take torch CUDA tensors."""
+
+    def __init__(self, device=0):
+        import torch
+        self.torch = torch
+        self.L = load_library()
+        if not torch.cuda.is_available():
+            raise EngineError("no GPU visible: the DEFLATE engine has no CPU fallback")
+        self.device = device
+        self.ctx = self.L.nxz_ctx_create(device)
+        if not self.ctx:
+            raise EngineError("nxz_ctx_create failed: %s" % self.L.nxz_last_error().decode())
+        self.dev = torch.device("cuda", device)
+
+    def close(self):
+        if self.ctx:
+            self.L.nxz_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    # ---- helpers -------------------------------------------------------
+    def stream_handle(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def to_device(self, arr: np.ndarray):
+        t = self.torch.from_numpy(arr.view(np.uint8).reshape(-1).copy())
+        return t.to(self.dev)
+
+    def jobs_strided(self, src, src_stride, src_lens, dst, dst_stride, dst_cap, hist_len=0, dht_index=None,
+                     in_crc=0, in_adler=1, resume=0):
+        """Job array for n buffers laid out at fixed strides inside two device tensors."""
+        n = len(src_lens)
+        j = np.zeros(n, JOB_DTYPE)
+        idx = np.arange(n, dtype=np.uint64)
+        j["src"] = np.uint64(src.data_ptr()) + idx * np.uint64(src_stride)
+        j["dst"] = np.uint64(dst.data_ptr()) + idx * np.uint64(dst_stride)
+        j["src_len"] = src_lens
+        j["hist_len"] = hist_len
+        j["dst_cap"] = dst_cap
+        j["in_crc"] = in_crc
+        j["in_adler"] = in_adler
+        j["resume"] = resume
+        if dht_index is not None:
+            j["dht_index"] = dht_index
+        return self.to_device(j)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError("%s failed (%d): %s" % (what, rc, self.L.nxz_last_error().decode()))
+
+    # ---- batched entry points (asynchronous on torch's current stream) --
+    def compress(self, fc, jobs, n, results=None, dht=None, ntables=0, counts=None):
+        t = self.torch
+        if results is None:
+            results = t.empty(n * RESULT_DTYPE.itemsize, dtype=t.uint8, device=self.dev)
+        if (fc & 0x4) and counts is None:
+            counts = t.empty(n * 316, dtype=t.int32, device=self.dev)
+        rc = self.L.nxz_batch_compress(self.ctx, fc, jobs.data_ptr(), n,
+                                       dht.data_ptr() if dht is not None else None, ntables,
+                                       results.data_ptr(), counts.data_ptr() if counts is not None else None,
+                                       self.stream_handle())
+        self._check(rc, "nxz_batch_compress")
+        return results, counts
+
+    def decompress(self, jobs, n, results=None, dht_io=None):
+        t = self.torch
+        if results is None:
+            results = t.empty(n * RESULT_DTYPE.itemsize, dtype=t.uint8, device=self.dev)
+        rc = self.L.nxz_batch_decompress(self.ctx, jobs.data_ptr(), n, results.data_ptr(),
+                                         dht_io.data_ptr() if dht_io is not None else None, self.stream_handle())
+        self._check(rc, "nxz_batch_decompress")
+        return results
+
+    def wrap(self, jobs, n, results=None):
+        t = self.torch
+        if results is None:
+            results = t.empty(n * RESULT_DTYPE.itemsize, dtype=t.uint8, device=self.dev)
+        self._check(self.L.nxz_batch_wrap(self.ctx, jobs.data_ptr(), n, results.data_ptr(), self.stream_handle()),
+                    "nxz_batch_wrap")
+        return results
+
+    def results_to_host(self, results):
+        self.torch.cuda.synchronize(self.dev)
+        return results.cpu().numpy().view(RESULT_DTYPE)

@@ -1,0 +1,79 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/nxz_engine.h declares, and the wire structures have the reference's layout.
+No compute calls (no GPU here)."""
+import ctypes as C
+import importlib
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pkg = importlib.import_module("power-gzip_amd")
+
+# offsets probed from the reference's inc_nx/nxu.h with offsetof() (recorded as data)
+REF_LAYOUT = {
+    "sizeof(nxz_crb_t)": 256, "sizeof(nxz_crb_cpb_t)": 2048,
+    "sizeof(nxz_dde_t)": 16, "sizeof(nxz_csb_t)": 16,
+    "offsetof(nxz_crb_t, source)": 16, "offsetof(nxz_crb_t, target)": 32, "offsetof(nxz_crb_t, csb)": 240,
+    "offsetof(nxz_crb_cpb_t, cpb)": 256,
+    "offsetof(nxz_cpb_t, in_crc_le)": 4, "offsetof(nxz_cpb_t, in_w2_be)": 8, "offsetof(nxz_cpb_t, in_w3_be)": 12,
+    "offsetof(nxz_cpb_t, in_dht)": 16, "offsetof(nxz_cpb_t, out_adler_be)": 384, "offsetof(nxz_cpb_t, out_crc_le)": 388,
+    "offsetof(nxz_cpb_t, out_w2_be)": 392, "offsetof(nxz_cpb_t, out_w3_be)": 396, "offsetof(nxz_cpb_t, u)": 400,
+    "offsetof(nxz_cpb_t, u.d.out_spbc_decomp_be)": 688, "offsetof(nxz_cpb_t, out_spbc_with_count_be)": 1664,
+    "offsetof(nxz_dev_t, paste_addr)": 32, "offsetof(nxz_dev_t, fd)": 40, "offsetof(nxz_dev_t, function)": 44,
+    "sizeof(nxz_batch_job_t)": 48, "sizeof(nxz_batch_result_t)": 32, "sizeof(nxz_batch_dht_t)": 296,
+}
+
+
+def test_wire_layout_matches_reference(tmp_path):
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "nxz_engine.h"', 'int main(void){']
+    for k in REF_LAYOUT:
+        src.append('printf("%s=%%zu\\n", (size_t)%s);' % (k.replace('"', ''), k))
+    src.append("return 0;}")
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = dict(line.rsplit("=", 1) for line in out.strip().splitlines())
+    for k, v in REF_LAYOUT.items():
+        assert int(got[k]) == v, k
+
+
+def test_library_exports_every_declared_symbol():
+    p = pkg.lib_path()
+    assert os.path.exists(p), "build first: __graft_entry__.build()"
+    lib = C.CDLL(p)
+    hdr = open(os.path.join(ROOT, "include", "nxz_engine.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(nx[uz]?_\w+|__crc32_vpmsum|nx_\w+)\s*\(", hdr))
+    names |= {"tb_freq"}
+    names = {n for n in names if not n.endswith("_t")}
+    assert {"nx_function_begin", "nx_function_end", "nxu_run_job", "nx_wait_ticks", "__crc32_vpmsum",
+            "nxz_batch_compress", "nxz_batch_decompress", "nxz_batch_wrap", "nxz_ctx_create"} <= names
+    for n in sorted(names):
+        assert hasattr(lib, n), "missing export: " + n
+    assert C.c_uint64.in_dll(lib, "tb_freq").value == 512000000
+
+
+def test_host_side_helpers_without_gpu():
+    """__crc32_vpmsum and nx_wait_ticks are pure host code (lib/crc32_ppc.c:22-67 wraps the former)."""
+    import zlib
+    L = pkg.engine.load_library()
+    data = bytes(range(256)) * 37 + b"tail"
+    for init in (0, 0x12345678):
+        # crc32_ppc: crc = ~crc; crc = __crc32_vpmsum(crc, p, len); return ~crc
+        raw = L.__crc32_vpmsum((~init) & 0xffffffff, data, len(data))
+        assert (~raw) & 0xffffffff == zlib.crc32(data, init)
+    t = L.nx_wait_ticks(100, 5, 0)
+    assert t >= 105
+
+
+def test_engine_refuses_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.EngineError):
+        pkg.Engine(0)

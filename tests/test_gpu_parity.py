@@ -1,0 +1,384 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP engine, called through the
+C ABI (libnxz_engine.so), against the CPU oracle on the same seeded inputs -- bit exact."""
+import ctypes as C
+import importlib
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from datagen import make_block
+
+pytestmark = pytest.mark.gpu
+pkg = importlib.import_module("power-gzip_amd")
+crb = importlib.import_module("power-gzip_amd.crb")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STRIDE_IN = 65536
+STRIDE_OUT = 73856  # nxz_compress_bound(65536) rounded up
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = pkg.Engine(0)
+    yield e
+    e.close()
+
+
+def pack_blocks(eng, blocks, stride):
+    import torch
+    host = np.zeros((len(blocks), stride), np.uint8)
+    for i, b in enumerate(blocks):
+        host[i, :len(b)] = np.frombuffer(b, np.uint8)
+    return torch.from_numpy(host).to(eng.dev)
+
+
+BLOCK_CASES = [("zeros", 65536), ("text33", 65536), ("lz", 65536), ("random", 65536), ("alice", 65536),
+               ("lz", 0), ("lz", 1), ("lz", 2), ("lz", 3), ("lz", 4), ("lz", 5), ("text33", 15), ("text33", 16),
+               ("text33", 17), ("text33", 63), ("text33", 64), ("text33", 65), ("lz", 2047), ("lz", 2048),
+               ("lz", 2049), ("lz", 16383), ("lz", 16384), ("lz", 16385), ("alice", 40000), ("zeros", 300),
+               ("zeros", 16384), ("random", 5000), ("lz", 65535), ("alice", 32768), ("lz", 49152)]
+
+
+def test_fixed_huffman_bit_exact(eng):
+    import torch
+    blocks = [make_block(k, n, seed=i) for i, (k, n) in enumerate(BLOCK_CASES)]
+    blocks += [make_block("lz", 65536, seed=100 + i) for i in range(40)]
+    src = pack_blocks(eng, blocks, STRIDE_IN)
+    dst = torch.zeros((len(blocks), STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    lens = np.array([len(b) for b in blocks], np.uint32)
+    jobs = eng.jobs_strided(src, STRIDE_IN, lens, dst, STRIDE_OUT, STRIDE_OUT)
+    res, _ = eng.compress(pkg.FC_COMPRESS_FHT, jobs, len(blocks))
+    r = eng.results_to_host(res)
+    out = dst.cpu().numpy()
+    for i, b in enumerate(blocks):
+        exp, bits = O.deflate_fixed(b)
+        assert r["tpbc"][i] == len(exp), (i, BLOCK_CASES[i] if i < len(BLOCK_CASES) else "lz64k")
+        assert r["tebc"][i] == bits % 8
+        assert out[i, :len(exp)].tobytes() == exp, i
+        assert r["spbc"][i] == len(b)
+        assert r["crc"][i] == zlib.crc32(b) and r["adler"][i] == zlib.adler32(b), i
+        assert r["cc"][i] == (64 if len(exp) > len(b) else 0), i
+        d = zlib.decompressobj(-15)
+        assert d.decompress(exp) == b and d.eof
+
+
+def test_history_and_running_checksums(eng):
+    import torch
+    hist = make_block("text33", 32768, 5)
+    blocks, hlens = [], []
+    for hl, n, seed in [(32768, 20000, 1), (16, 100, 2), (4096, 32768, 3), (32768, 32768, 4), (1024, 0, 5)]:
+        body = hist[:n] if seed % 2 else make_block("lz", n, seed)
+        blocks.append(hist[-hl:] + body)
+        hlens.append(hl)
+    src = pack_blocks(eng, blocks, STRIDE_IN)
+    dst = torch.zeros((len(blocks), STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, STRIDE_IN, np.array([len(b) for b in blocks], np.uint32), dst, STRIDE_OUT,
+                            STRIDE_OUT, hist_len=np.array(hlens, np.uint32), in_crc=0xdeadbeef, in_adler=0x00c0ffee)
+    res, _ = eng.compress(pkg.FC_COMPRESS_RESUME_FHT, jobs, len(blocks))
+    r = eng.results_to_host(res)
+    out = dst.cpu().numpy()
+    for i, (b, hl) in enumerate(zip(blocks, hlens)):
+        exp, bits = O.deflate_fixed(b, hist=hl)
+        assert out[i, :len(exp)].tobytes() == exp and r["tpbc"][i] == len(exp), i
+        assert r["spbc"][i] == len(b)
+        assert r["crc"][i] == zlib.crc32(b[hl:], 0xdeadbeef), i
+        assert r["adler"][i] == zlib.adler32(b[hl:], 0x00c0ffee), i
+
+
+def _dht_array(tables):
+    arr = np.zeros(len(tables), pkg.DHT_DTYPE)
+    for i, (bits, n) in enumerate(tables):
+        arr["dhtlen"][i] = n
+        arr["dht"][i, :len(bits)] = np.frombuffer(bits, np.uint8)
+    return arr
+
+
+def test_dynamic_huffman_and_counts_bit_exact(eng):
+    import torch
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "builtin_dht.json")))
+    kinds = [("alice", 65536), ("lz", 65536), ("text33", 30000), ("zeros", 65536), ("random", 4096), ("lz", 7)]
+    blocks = [make_block(k, n, seed=50 + i) for i, (k, n) in enumerate(kinds)]
+    tables = [(bytes.fromhex(g[0]["dht"]), g[0]["dhtlen"]), (bytes.fromhex(g[7]["dht"]), g[7]["dhtlen"])]
+    # plus an exact table per block (may miss codes for other blocks)
+    for b in blocks[:2]:
+        tok, nt = O.lz77(b)
+        ll, d = O.counts(tok, nt)
+        tables.append(O.dhtgen(ll, d))
+    dht = eng.to_device(_dht_array(tables))
+    use = [0, 1, 2, 0, 1, 3]          # job 5 uses block 1's exact table on other data -> may be CC 66
+    src = pack_blocks(eng, blocks, STRIDE_IN)
+    dst = torch.zeros((len(blocks), STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, STRIDE_IN, np.array([len(b) for b in blocks], np.uint32), dst, STRIDE_OUT,
+                            STRIDE_OUT, dht_index=np.array(use, np.uint32))
+    res, cnt = eng.compress(pkg.FC_COMPRESS_DHT_COUNT, jobs, len(blocks), dht=dht, ntables=len(tables))
+    r = eng.results_to_host(res)
+    out = dst.cpu().numpy()
+    cnt = cnt.cpu().numpy().view(np.uint32).reshape(len(blocks), 316)
+    for i, b in enumerate(blocks):
+        bits, n = tables[use[i]]
+        exp, nbits = O.deflate_dynamic(b, bits, n)
+        if exp is None:
+            assert r["cc"][i] == 66, i
+            continue
+        assert r["tpbc"][i] == len(exp) and r["tebc"][i] == nbits % 8, i
+        assert out[i, :len(exp)].tobytes() == exp, i
+        tok, nt = O.lz77(b)
+        ll, d = O.counts(tok, nt)
+        assert list(cnt[i]) == list(ll) + list(d), i
+        dz = zlib.decompressobj(-15)
+        assert dz.decompress(exp) == b and dz.eof
+
+
+def test_invalid_dht_is_cc68(eng):
+    import torch
+    b = make_block("alice", 1000, 1)
+    dht = eng.to_device(_dht_array([(b"\xff" * 40, 300)]))
+    src = pack_blocks(eng, [b], STRIDE_IN)
+    dst = torch.zeros((1, STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, STRIDE_IN, np.array([len(b)], np.uint32), dst, STRIDE_OUT, STRIDE_OUT)
+    res, _ = eng.compress(pkg.FC_COMPRESS_DHT, jobs, 1, dht=dht, ntables=1)
+    assert eng.results_to_host(res)["cc"][0] == 68
+
+
+def test_target_too_small_is_cc13(eng):
+    import torch
+    b = make_block("random", 65536, 1)
+    src = pack_blocks(eng, [b], STRIDE_IN)
+    dst = torch.zeros((1, STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, STRIDE_IN, np.array([len(b)], np.uint32), dst, STRIDE_OUT, 32768)
+    res, _ = eng.compress(pkg.FC_COMPRESS_FHT, jobs, 1)
+    r = eng.results_to_host(res)
+    assert r["cc"][0] == 13 and r["tpbc"][0] == 0
+    assert not dst[0, 32768:].any()          # nothing written past the capacity
+
+
+def test_wrap(eng):
+    import torch
+    blocks = [make_block("random", n, n) for n in (0, 1, 3, 4, 5, 255, 256, 4097, 60000)]
+    src = pack_blocks(eng, blocks, STRIDE_IN)
+    dst = torch.zeros((len(blocks), STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, STRIDE_IN, np.array([len(b) for b in blocks], np.uint32), dst, STRIDE_OUT, STRIDE_OUT)
+    r = eng.results_to_host(eng.wrap(jobs, len(blocks)))
+    out = dst.cpu().numpy()
+    for i, b in enumerate(blocks):
+        assert r["cc"][i] == 0 and r["tpbc"][i] == len(b)
+        assert out[i, :len(b)].tobytes() == b
+        assert r["crc"][i] == zlib.crc32(b) and r["adler"][i] == zlib.adler32(b), i
+
+
+def _zstreams():
+    data = {k: make_block(k, n, seed=7) for k, n in [("alice", 65536), ("lz", 65536), ("random", 20000),
+                                                      ("zeros", 65536), ("text33", 3000)]}
+    out = []
+    for name, d in data.items():
+        for level, strat in [(1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                             (6, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_HUFFMAN_ONLY)]:
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strat)
+            out.append((d, co.compress(d) + co.flush()))
+    big = make_block("lz", 300000, 11) + make_block("alice", 200000, 12)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    out.append((big, co.compress(big[:250000]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(big[250000:]) + co.flush()))
+    return out
+
+
+def test_inflate_zlib_streams_bit_exact(eng):
+    import torch
+    streams = _zstreams()
+    cstride = max(len(c) for _, c in streams) + 64
+    cstride = (cstride + 15) & ~15
+    ostride = (max(len(d) for d, _ in streams) + 15) & ~15
+    src = pack_blocks(eng, [c + b"TRAILER8" for _, c in streams], cstride)
+    dst = torch.zeros((len(streams), ostride), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, cstride, np.array([len(c) + 8 for _, c in streams], np.uint32), dst, ostride, ostride)
+    r = eng.results_to_host(eng.decompress(jobs, len(streams)))
+    out = dst.cpu().numpy()
+    for i, (d, c) in enumerate(streams):
+        assert r["cc"][i] == 3 and (r["sfbt"][i] & 0xf) == 0 and r["sfbt"][i] & 0x100, i   # trailer follows the final EOB
+        assert r["tpbc"][i] == len(d), i
+        assert out[i, :len(d)].tobytes() == d, i
+        assert r["crc"][i] == zlib.crc32(d) and r["adler"][i] == zlib.adler32(d), i
+        assert r["subc"][i] // 8 == 8, i
+
+
+def test_inflate_suspend_state_matches_oracle(eng):
+    """cut streams at arbitrary bytes: CC 3, SFBT/SUBC/rembytecnt/tpbc/dht must equal the CPU model."""
+    import random
+    import torch
+    rnd = random.Random(3)
+    streams = _zstreams()
+    cases = []
+    for d, c in streams[:18]:
+        for _ in range(6):
+            cases.append((d, c[:rnd.randrange(0, len(c))]))
+    cstride = (max(len(c) for _, c in cases) + 31) & ~15
+    ostride = (max(len(d) for d, _ in cases) + 15) & ~15
+    src = pack_blocks(eng, [c for _, c in cases], cstride)
+    dst = torch.zeros((len(cases), ostride), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, cstride, np.array([len(c) for _, c in cases], np.uint32), dst, ostride, ostride)
+    dht_io = torch.zeros(len(cases) * pkg.DHT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
+    r = eng.results_to_host(eng.decompress(jobs, len(cases), dht_io=dht_io))
+    out = dst.cpu().numpy()
+    dio = dht_io.cpu().numpy().view(pkg.DHT_DTYPE)
+    for i, (d, c) in enumerate(cases):
+        exp, st = O.inflate(c, ostride)
+        assert st.err == 0
+        assert r["tpbc"][i] == st.tpbc and out[i, :st.tpbc].tobytes() == exp, i
+        assert (r["sfbt"][i] & 0xf) == st.out_sfbt and r["subc"][i] == st.out_subc, i
+        if (st.out_sfbt & 0xe) == 0x8:
+            assert r["tebc"][i] == st.out_rembytecnt
+        if (st.out_sfbt & 0xe) == 0xc:
+            assert dio["dhtlen"][i] == st.out_dhtlen
+            nb = (st.out_dhtlen + 7) // 8
+            assert dio["dht"][i, :nb].tobytes() == bytes(st.out_dht)[:nb], i
+
+
+def test_inflate_resume_chain(eng):
+    """feed a stream in pieces through resume jobs with history, like lib/nx_inflate.c:1464-1609 does."""
+    import torch
+    d, c = _zstreams()[-1]
+    c = c + b"12345678"
+    piece = 40000
+    ostride = 1 << 20
+    out = b""
+    pos = 0
+    resume = 0
+    dht_state = None
+    crc, adler = 0, 1
+    for _ in range(100):
+        chunk = c[pos:pos + piece]
+        hist = out[-32768:]
+        hpad = (-len(hist)) % 16
+        srcbuf = bytes(hpad) + hist + chunk      # history length must be a multiple of 16
+        src = pack_blocks(eng, [srcbuf], (len(srcbuf) + 31) & ~15)
+        dst = torch.zeros((1, ostride), dtype=torch.uint8, device=eng.dev)
+        jobs = eng.jobs_strided(src, 0, np.array([len(srcbuf)], np.uint32), dst, 0, ostride,
+                                hist_len=len(hist) + hpad, in_crc=crc, in_adler=adler, resume=resume)
+        dht_io = torch.zeros(pkg.DHT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
+        if dht_state is not None:
+            dht_io = eng.to_device(dht_state)
+        r = eng.results_to_host(eng.decompress(jobs, 1, dht_io=dht_io))[0]
+        assert r["cc"] in (0, 3), r
+        out += dst[0, :r["tpbc"]].cpu().numpy().tobytes()
+        crc, adler = int(r["crc"]), int(r["adler"])
+        sfbt = int(r["sfbt"]) & 0xf
+        if r["sfbt"] & 0x100:
+            consumed = pos + len(chunk) - int(r["subc"]) // 8
+            assert c[consumed:] == b"12345678"
+            break
+        back = (int(r["subc"]) + 7) // 8
+        pos += len(chunk) - back
+        resume = (sfbt << 16) | ((int(r["subc"]) % 8) << 20) | (int(r["tebc"]) if (sfbt & 0xe) == 8 else 0)
+        dht_state = dht_io.cpu().numpy().view(pkg.DHT_DTYPE).copy() if (sfbt & 0xe) == 0xc else None
+    assert out == d
+    assert crc == zlib.crc32(d) and adler == zlib.adler32(d)
+
+
+# ---------------------------------------------------------------------------
+# the six transport symbols: nxu_run_job on host buffers vs the CPU engine model
+# ---------------------------------------------------------------------------
+def _run_both(eng, handle, setup_kwargs, src_bufs_bytes, dst_sizes):
+    """returns (gpu_job, gpu_dst_bytes, cpu_job, cpu_dst_bytes)"""
+    res = []
+    for which in ("gpu", "cpu"):
+        j = crb.Job()
+        srcs = [C.create_string_buffer(b, len(b)) for b in src_bufs_bytes]
+        dsts = [C.create_string_buffer(n) for n in dst_sizes]
+        j.setup(src_bufs=srcs, dst_bufs=dsts, **setup_kwargs)
+        if which == "gpu":
+            rc = eng.L.nxu_run_job(C.c_void_p(j.addr), C.byref(handle))
+        else:
+            rc = O.lib().nxo_run_job(C.c_void_p(j.addr))
+        assert rc == 0 and j.valid == 1
+        res.append((j, b"".join(d.raw for d in dsts)))
+    return res[0][0], res[0][1], res[1][0], res[1][1]
+
+
+@pytest.fixture(scope="module")
+def handle(eng):
+    h = crb.DevHandle()
+    assert eng.L.nx_function_begin(2, -1, C.byref(h)) == 0
+    assert h.paste_addr and h.fd > 0 and h.function == 2
+    yield h
+    eng.L.nx_function_end(C.byref(h))
+
+
+def test_nxu_run_job_compress_matches_model(eng, handle):
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "builtin_dht.json")))
+    dht0, dhtlen0 = bytes.fromhex(g[0]["dht"]), g[0]["dhtlen"]
+    hist = make_block("alice", 4096, 1)
+    body = make_block("alice", 30000, 2)
+    cases = [
+        dict(fc=0x08, src=[hist, body], hist_qw=256, dst=[70000]),
+        dict(fc=0x08, src=[body[:100], body[100:5000], body[5000:]], hist_qw=0, dst=[1000, 80000]),  # gather + scatter
+        dict(fc=0x0e, src=[hist, body], hist_qw=256, dst=[70000], dht=(dht0, dhtlen0)),
+        dict(fc=0x0c, src=[body], hist_qw=0, dst=[70000]),
+        dict(fc=0x08, src=[make_block("random", 3000, 3)], hist_qw=0, dst=[8000]),         # expands -> CC 64
+        dict(fc=0x08, src=[body], hist_qw=0, dst=[512]),                                    # CC 13
+        dict(fc=0x08, src=[make_block("lz", 100000, 4)], hist_qw=0, dst=[200000]),          # > 64 KiB -> CC 3 partial
+        dict(fc=0x1e, src=[body[:7000]], hist_qw=0, dst=[60000]),                           # wrap
+    ]
+    for k, cse in enumerate(cases):
+        kw = dict(fc=cse["fc"], histlen_qw=cse["hist_qw"], in_crc=0x1234 if cse["fc"] != 0x1e else 0,
+                  in_adler=77 if cse["fc"] != 0x1e else 1)
+        if "dht" in cse:
+            kw.update(dht=cse["dht"][0], dhtlen=cse["dht"][1])
+        gj, gd, cj, cd = _run_both(eng, handle, kw, cse["src"], cse["dst"])
+        assert gj.cc == cj.cc and gj.ce3 == cj.ce3, (k, gj.cc, cj.cc)
+        if cj.cc in (0, 3, 64):
+            assert gj.tpbc == cj.tpbc and gd[:cj.tpbc] == cd[:cj.tpbc], k
+            assert gj.out_crc == cj.out_crc and gj.out_adler == cj.out_adler, k
+            if cse["fc"] != 0x1e:
+                assert gj.out_tebc == cj.out_tebc, k
+            if cse["fc"] & 0x4 and cse["fc"] != 0x1e:
+                assert gj.lzcounts == cj.lzcounts and gj.out_spbc_count == cj.out_spbc_count, k
+            else:
+                assert gj.out_spbc == cj.out_spbc, k
+
+
+def test_nxu_run_job_decompress_matches_model(eng, handle):
+    d, c = _zstreams()[1]
+    trailer = b"\x01\x02\x03\x04\x05\x06\x07\x08"
+    cases = [dict(fc=0x10, src=[c + trailer], dst=[len(d) + 100]),
+             dict(fc=0x10, src=[c[:1000], c[1000:] + trailer], dst=[1000, len(d)]),
+             dict(fc=0x10, src=[c], dst=[len(d)]),                      # ends exactly at EOB -> CC 0
+             dict(fc=0x10, src=[c[:len(c) // 2]], dst=[len(d)]),        # suspended
+             dict(fc=0x10, src=[c], dst=[len(d) // 2])]                 # CC 13
+    for k, cse in enumerate(cases):
+        gj, gd, cj, cd = _run_both(eng, handle, dict(fc=cse["fc"]), cse["src"], cse["dst"])
+        assert gj.cc == cj.cc and gj.ce3 == cj.ce3, (k, gj.cc, cj.cc)
+        if cj.cc in (0, 3):
+            assert gj.tpbc == cj.tpbc and gd[:cj.tpbc] == cd[:cj.tpbc], k
+            assert (gj.out_sfbt, gj.out_subc, gj.out_spbc_decomp) == (cj.out_sfbt, cj.out_subc, cj.out_spbc_decomp), k
+            assert gj.out_crc == cj.out_crc and gj.out_adler == cj.out_adler, k
+            if (cj.out_sfbt & 0xe) == 0xc:
+                assert gj.out_dhtlen == cj.out_dhtlen
+                assert gj.out_dht[:(cj.out_dhtlen + 7) // 8] == cj.out_dht[:(cj.out_dhtlen + 7) // 8]
+
+
+def test_full_size_roundtrip_property(eng):
+    """BASELINE-sized blocks at scale: compress on the GPU, inflate on the GPU, compare on the GPU
+    (size-independent property; the oracle is not in the loop)."""
+    import torch
+    n = 2048
+    g = torch.Generator(device="cpu").manual_seed(1)
+    base = torch.from_numpy(np.frombuffer(make_block("lz", 1 << 20, 9) + make_block("alice", 1 << 20, 10), np.uint8).copy())
+    idx = torch.randint(0, base.numel() - 65536, (n,), generator=g)
+    src = torch.stack([base[i:i + 65536] for i in idx.tolist()]).to(eng.dev)
+    src[::7] ^= torch.randint(0, 3, (src[::7].shape[0], 65536), dtype=torch.uint8, generator=g).to(eng.dev) // 2
+    comp = torch.zeros((n, STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    lens = np.full(n, 65536, np.uint32)
+    jobs = eng.jobs_strided(src, 65536, lens, comp, STRIDE_OUT, STRIDE_OUT)
+    r = eng.results_to_host(eng.compress(pkg.FC_COMPRESS_FHT, jobs, n)[0])
+    assert (r["cc"] == 0).all()
+    back = torch.zeros((n, 65536), dtype=torch.uint8, device=eng.dev)
+    jobs2 = eng.jobs_strided(comp, STRIDE_OUT, r["tpbc"].astype(np.uint32), back, 65536, 65536)
+    r2 = eng.results_to_host(eng.decompress(jobs2, n))
+    assert (r2["cc"] == 0).all() and (r2["tpbc"] == 65536).all()
+    assert torch.equal(back, src)
+    assert (r2["crc"] == r["crc"]).all() and (r2["adler"] == r["adler"]).all()
+    ratio = 65536.0 * n / r["tpbc"].sum()
+    assert ratio > 1.5
