@@ -38,7 +38,7 @@
 #define NXO_CHUNK 64
 #endif
 #ifndef NXO_PSEG
-#define NXO_PSEG 64
+#define NXO_PSEG 16
 #endif
 #ifndef NXO_PTILE
 #define NXO_PTILE 16384
@@ -104,6 +104,9 @@ static uint32_t walk(const uint8_t *w, uint32_t h, const uint16_t *mlen, const u
 	return p;
 }
 
+/* debug taps (tools/debug_tokens.py) */
+uint16_t *nxo_dbg_mlen, *nxo_dbg_mdist; uint32_t *nxo_dbg_x;
+
 /* one sub-block: w[0..h) window, w[h..h+n) block.  n <= NXO_SUBBLOCK, h <= NXO_WINDOW */
 static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *tok)
 {
@@ -158,6 +161,7 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 			}
 		}
 	}
+	if (nxo_dbg_mlen) { memcpy(nxo_dbg_mlen, mlen, n * 2); memcpy(nxo_dbg_mdist, mdist, n * 2); }
 	/* 5. two-pass segment parse per PTILE */
 	for (c = 0; c < n; c += NXO_PTILE) {
 		uint32_t tend = c + NXO_PTILE < n ? c + NXO_PTILE : n;
@@ -170,6 +174,7 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 			uint32_t se = sb + NXO_PSEG < tend ? sb + NXO_PSEG : tend;
 			X[s] = walk(w, h, mlen, mdist, sb, se, tend, NULL, NULL);
 		}
+		if (nxo_dbg_x) for (s = 0; s < nseg; s++) nxo_dbg_x[c / NXO_PSEG + s] = X[s];
 		/* chain of entered segments: the segment containing `entry` is walked
 		 * for real from `entry` up to its own speculative exit (matches are
 		 * truncated there), which is the entry of the next entered segment */

@@ -28,6 +28,9 @@
 #include <stdint.h>
 #include "nxz_device.h"
 
+// Debug aid (tools/debug_tokens.py): when set, workgroup 0 dumps its per-position arrays.
+__device__ uint32_t *nxz_debug_buf = nullptr;
+
 namespace nxz {
 
 constexpr int NT = 1024;                 // threads per workgroup
@@ -343,18 +346,22 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 
 		// ---- chain: one wave, 64 positions per step; lookups see every earlier step ----
 		if (wave == 0) {
-#pragma unroll 2
-			for (uint32_t i = lane; i < tn; i += 64) {
-				uint32_t hv = cand[i];
+			// The trip count must be wave-uniform: with a per-lane bound the compiler peels the
+			// remainder iteration in FRONT of the unrolled loop and the lanes stop marching in
+			// step, which breaks "every lookup of a step precedes every insert of that step".
+			for (uint32_t base = 0; base < tn; base += 64) {
+				uint32_t i = base + lane;
+				uint32_t hv = i < tn ? (uint32_t)cand[i] : NOHASH;
 				uint32_t r = h + tb0 + i;
 				uint32_t c = NOHASH;
 				if (hv != NOHASH) {
 					uint32_t old = __hip_atomic_load(&head[hv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					if (old != 0 && r + 1 - old <= WINDOW) c = r - old;       // dist-1
 				}
-				cand[i] = (uint16_t)c;
-				// every lane's lookup above is issued before any lane's insert below (same wave)
+				__builtin_amdgcn_wave_barrier();
+				if (i < tn) cand[i] = (uint16_t)c;
 				if (hv != NOHASH) atomicMax(&head[hv], r + 1);
+				__builtin_amdgcn_wave_barrier();
 			}
 		}
 		__syncthreads();
@@ -395,6 +402,8 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// chain bookkeeping init
 		for (uint32_t s = t; s < NSEG; s += NT) mark[s] = 0;
 		__syncthreads();
+		if (nxz_debug_buf && blockIdx.x == 0)
+			for (uint32_t i = t; i < tn; i += NT) nxz_debug_buf[(tb0 / PTILE) * 65536 + i] = cand[i] | ((uint32_t)mlen[i] << 16);
 
 		// ---- parse pass 1: speculative walk of segment s from its own start ----
 		if ((uint32_t)t < nseg) {
@@ -431,6 +440,8 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// token bitmaps (alias mark/jump) are cleared now
 		__syncthreads();
 		uint32_t mye = entered ? entry[t] : 0;
+		if (nxz_debug_buf && blockIdx.x == 0 && (uint32_t)t < nseg)
+			nxz_debug_buf[(tb0 / PTILE) * 65536 + 16384 + t] = myx | (mye << 16) | (entered ? 0x80000000u : 0);
 		__syncthreads();
 		for (uint32_t i = t; i < PTILE / 32; i += NT) { sbits[i] = 0; mbits[i] = 0; }
 		__syncthreads();
@@ -562,6 +573,11 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 }
 
 } // namespace nxz
+
+extern "C" int nxz_debug_set(uint32_t *buf)
+{
+	return (int)hipMemcpyToSymbol(HIP_SYMBOL(nxz_debug_buf), &buf, sizeof(buf));
+}
 
 extern "C" int nxz_launch_deflate(int dht, int count, const nxz_batch_job_t *jobs, size_t n,
 				  const nxz_dht_prepared_t *tables, nxz_batch_result_t *results,

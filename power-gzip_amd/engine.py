@@ -45,6 +45,9 @@ def load_library():
     """dlopen the in-tree engine.  Raises EngineError (never falls back) when it is missing."""
     global _lib
     if _lib is None:
+        # torch first: it ships its own libamdhip64.so.7; loading it before the engine makes both
+        # share ONE HIP runtime (same soname), which is what lets them share streams and pointers
+        import torch  # noqa: F401
         p = lib_path()
         if not os.path.exists(p):
             raise EngineError("%s not built: run `make -C power-gzip_amd/csrc` (or __graft_entry__.build())" % p)
