@@ -78,7 +78,7 @@ def cpu_baseline(blocks_host, budget_s=12.0):
     nmax = len(buf) // BLOCK
     ob = C.c_uint64()
     # calibrate on a few blocks, then size the sample for ~budget_s/2 per library
-    ncal = min(nmax, 4 * cores)
+    ncal = min(nmax, 8 * cores)
     t = L.nxo_bench_deflate(buf, ncal, BLOCK, cores, 0, C.byref(ob))
     n = int(max(ncal, min(nmax, ncal * (budget_s / 2) / max(t, 1e-3))))
     t_port = L.nxo_bench_deflate(buf, n, BLOCK, cores, 0, C.byref(ob))
@@ -207,7 +207,7 @@ def main():
                          "algorithmic_bytes_per_launch": u_bytes + c_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample = src[:min(n, 4096)].cpu().numpy()
+            sample = src[:min(n, 32768)].cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(sample)
         print(json.dumps(line), flush=True)
     if distributed:

@@ -231,8 +231,8 @@ typedef struct nxz_batch_dht {
 	uint8_t  dht[NXZ_DHT_MAXSZ + 4]; /* RFC1951 3.2.7 bit string, HLIT first */
 } nxz_batch_dht_t;
 
-/* Create / destroy an engine context on a HIP device.  `stream` is a
- * hipStream_t passed as void* (NULL = the context's own stream). */
+/* Create / destroy an engine context on a HIP device.  In the batch calls
+ * `stream` is a hipStream_t passed as void* (NULL = the HIP default stream). */
 nxz_ctx_t *nxz_ctx_create(int device);
 void       nxz_ctx_destroy(nxz_ctx_t *ctx);
 const char *nxz_last_error(void);

@@ -30,6 +30,9 @@
 
 // Debug aid (tools/debug_tokens.py): when set, workgroup 0 dumps its per-position arrays.
 __device__ uint32_t *nxz_debug_buf = nullptr;
+// Diagnostic only (tools/phase_profile.py): per-phase cycle sums of every workgroup's thread 0.
+__device__ unsigned long long *nxz_prof_buf = nullptr;
+#define PROF(idx) do { if (prof) { if (t == 0) { unsigned long long now_ = clock64(); atomicAdd(&prof[idx], now_ - tprev); tprev = now_; } } } while (0)
 
 namespace nxz {
 
@@ -185,6 +188,8 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 	uint32_t *misc = (uint32_t *)(lds + OFF_MISC);
 
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	unsigned long long *prof = nxz_prof_buf;
+	unsigned long long tprev = prof ? clock64() : 0;
 	const nxz_batch_job_t job = jobs[blockIdx.x];
 	const uint32_t total = job.src_len;                  // window + block
 	const uint32_t h = job.hist_len < total ? job.hist_len : total;
@@ -229,6 +234,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		bitbuf[t] = c;
 	}
 	__syncthreads();
+	PROF(0);
 
 	// ---------------- checksums of the non-history source ----------------
 	uint32_t out_crc, out_adler;
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		out_adler = scan[49];
 		__syncthreads();
 	}
+	PROF(1);
 	// clear the bit buffer (it held the CRC table)
 	for (uint32_t i = t; i < BITS_BYTES / 4; i += NT) bitbuf[i] = 0;
 
@@ -330,6 +337,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 	__syncthreads();
 
 	Walk W{inw, mlen, cand, h, 0, end};
+	PROF(2);
 
 	// ================= tiles =================
 	for (uint32_t tb0 = 0; tb0 < n; tb0 += PTILE) {
@@ -343,6 +351,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			cand[i] = (r + 4 <= end) ? (uint16_t)hash4(lds_ld32(inw, r)) : (uint16_t)NOHASH;
 		}
 		__syncthreads();
+		PROF(3);
 
 		// ---- chain: one wave, 64 positions per step; lookups see every earlier step ----
 		if (wave == 0) {
@@ -365,6 +374,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			}
 		}
 		__syncthreads();
+		PROF(4);
 
 		// ---- match: verify, extend (capped), distance-1 run check ----
 		for (uint32_t i = t; i < tn; i += NT) {
@@ -405,6 +415,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		if (nxz_debug_buf && blockIdx.x == 0)
 			for (uint32_t i = t; i < tn; i += NT) nxz_debug_buf[(tb0 / PTILE) * 65536 + i] = cand[i] | ((uint32_t)mlen[i] << 16);
 
+		PROF(5);
 		// ---- parse pass 1: speculative walk of segment s from its own start ----
 		if ((uint32_t)t < nseg) {
 			uint32_t p = t * PSEG, stop = p + PSEG < tn ? p + PSEG : tn;
@@ -417,6 +428,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		}
 		if (t == 0) mark[0] = 1;
 		__syncthreads();
+		PROF(6);
 		// ---- chain of entered segments by pointer doubling ----
 		for (int k = 0; k < 10; k++) {
 			uint32_t j = NSEG, j2 = NSEG;
@@ -446,6 +458,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		for (uint32_t i = t; i < PTILE / 32; i += NT) { sbits[i] = 0; mbits[i] = 0; }
 		__syncthreads();
 
+		PROF(7);
 		// ---- parse pass 2: entered segments walk [entry, X[s]) for real ----
 		if (entered) {
 			uint32_t p = mye, lim = myx;
@@ -461,6 +474,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			}
 		}
 		__syncthreads();
+		PROF(8);
 
 		// ---- encode ----
 		for (uint32_t e0 = 0; e0 < tn; e0 += ETILE) {
@@ -544,6 +558,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		}
 	}
 
+	PROF(9);
 	// ---------------- EOB + tail ----------------
 	if (t == 0) {
 		uint32_t carry = misc[M_CARRY_BITS], wordbase = misc[M_WORDBASE];
@@ -577,6 +592,11 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 extern "C" int nxz_debug_set(uint32_t *buf)
 {
 	return (int)hipMemcpyToSymbol(HIP_SYMBOL(nxz_debug_buf), &buf, sizeof(buf));
+}
+
+extern "C" int nxz_prof_set(unsigned long long *buf)
+{
+	return (int)hipMemcpyToSymbol(HIP_SYMBOL(nxz_prof_buf), &buf, sizeof(buf));
 }
 
 extern "C" int nxz_launch_deflate(int dht, int count, const nxz_batch_job_t *jobs, size_t n,

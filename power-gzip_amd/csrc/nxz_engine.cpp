@@ -146,7 +146,7 @@ extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 
 extern "C" int nxz_ctx_sync(nxz_ctx_t *c, void *stream)
 {
-	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
 	HIPCHK(hipStreamSynchronize(s), return -EIO);
 	return 0;
 }
@@ -162,7 +162,7 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 	const bool isdht = nxz_fc_is_dht((uint32_t)fc), count = nxz_fc_has_count((uint32_t)fc);
 	if (count && !counts) return -EINVAL;
 	if (isdht && (!dht || !ntables)) return -EINVAL;
-	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
 	if (isdht) {
 		{
 			std::lock_guard<std::mutex> g(c->mtx);
@@ -186,7 +186,7 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 				    nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, void *stream)
 {
 	if (!c) return -EINVAL;
-	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
 	int rc = nxz_launch_inflate(jobs, n, results, dht_io, s);
 	if (rc) { set_err("inflate launch", (hipError_t)rc); return -EIO; }
 	return 0;
@@ -196,7 +196,7 @@ extern "C" int nxz_batch_wrap(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t 
 			      nxz_batch_result_t *results, void *stream)
 {
 	if (!c) return -EINVAL;
-	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
 	int rc = nxz_launch_wrap(jobs, n, results, s);
 	if (rc) { set_err("wrap launch", (hipError_t)rc); return -EIO; }
 	return 0;

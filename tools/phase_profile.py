@@ -1,0 +1,31 @@
+"""Diagnostic: per-phase cycle shares of the deflate kernel (thread 0 of every workgroup)."""
+import ctypes as C, importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import bench
+pkg = importlib.import_module("power-gzip_amd")
+NAMES = ["load", "cksum", "seed+hdr", "hash", "chain", "match", "pass1", "mark", "pass2", "encode(+all tiles)", "tail"]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+eng = pkg.Engine(0)
+src = bench.gen_blocks(torch, eng.dev, n, 0)
+if len(sys.argv) > 2 and sys.argv[2] == "alice":
+    from datagen import make_block
+    b = np.frombuffer(make_block("alice", 65536, 1), np.uint8)
+    src[:] = torch.from_numpy(b.copy()).to(eng.dev)
+dst = torch.empty((n, 73856), dtype=torch.uint8, device=eng.dev)
+jobs = eng.jobs_strided(src, 65536, np.full(n, 65536, np.uint32), dst, 73856, 73856)
+prof = torch.zeros(16, dtype=torch.int64, device=eng.dev)
+eng.L.nxz_prof_set.argtypes = [C.c_void_p]
+eng.compress(pkg.FC_COMPRESS_FHT, jobs, n)
+torch.cuda.synchronize()
+assert eng.L.nxz_prof_set(prof.data_ptr()) == 0
+eng.compress(pkg.FC_COMPRESS_FHT, jobs, n)
+torch.cuda.synchronize()
+eng.L.nxz_prof_set(None)
+p = prof.cpu().numpy().astype(np.float64) / n
+tot = p.sum()
+for i, name in enumerate(NAMES[:10]):
+    print("%-20s %10.0f cycles/block  %5.1f%%" % (name, p[i], 100 * p[i] / tot))
+print("total %.0f cycles/block (s_memtime ticks = 100 MHz? see guide)" % tot)
