@@ -52,7 +52,7 @@ constexpr uint32_t NOHASH = 0xFFFFu;
 // ---- LDS carve (bytes) ----
 constexpr uint32_t OFF_IN    = 0;                        // 65536 + 32 pad
 constexpr uint32_t OFF_HEAD  = 65536 + 32;               // 8192 x u32
-constexpr uint32_t OFF_CAND  = OFF_HEAD + HSIZE * 4;     // 16384 x u16
+constexpr uint32_t OFF_CAND  = OFF_HEAD + HSIZE * 4 + 16; // 16384 x u16 (head[HSIZE] is a dummy slot)
 constexpr uint32_t OFF_MLEN  = OFF_CAND + PTILE * 2;     // 16384 x u8
 constexpr uint32_t OFF_X     = OFF_MLEN + PTILE;         // 1024 x u16
 constexpr uint32_t OFF_ENTRY = OFF_X + NSEG * 2;         // 1024 x u16
@@ -108,6 +108,30 @@ __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)
 	return r;
 }
 
+// x^(8*64*k) mod P for k = 0..1023 (compile-time): what a 64-byte slice that is followed by k
+// more slices has to be multiplied with.
+constexpr uint32_t cgf_mul(uint32_t a, uint32_t b)
+{
+	uint32_t r = 0;
+	for (int i = 0; i < 32; i++) {
+		if (b & 0x80000000u) r ^= a;
+		a = (a >> 1) ^ ((a & 1) ? 0xedb88320u : 0);
+		b <<= 1;
+	}
+	return r;
+}
+struct PowTab { uint32_t v[1024]; };
+constexpr PowTab make_pow()
+{
+	PowTab p{};
+	uint32_t m = 0x00800000u;                 // x^8
+	for (int k = 0; k < 6; k++) m = cgf_mul(m, m);   // x^512
+	p.v[0] = 0x80000000u;
+	for (int i = 1; i < 1024; i++) p.v[i] = cgf_mul(p.v[i - 1], m);
+	return p;
+}
+__device__ const PowTab CRC_POW = make_pow();
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
 #pragma unroll
@@ -124,22 +148,11 @@ struct Walk {
 	const uint16_t *cand;
 	uint32_t h, tile_base, end;   // window bytes, tile start (block relative), sub-block end (window relative)
 
-	// true match length at tile position p (stored value is len-3, 0 = none, CAPLEN-3 = capped)
+	// match length at tile position p (stored value is len-3, 0 = none; exact after run extension)
 	__device__ __forceinline__ uint32_t full_len(uint32_t p) const
 	{
 		uint32_t m = mlen[p];
-		if (m == 0) return 0;
-		uint32_t len = m + 3;
-		if (len == CAPLEN) {
-			uint32_t r = h + tile_base + p;
-			uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-			if (maxlen > CAPLEN) {
-				uint32_t q = r - ((uint32_t)cand[p] + 1);
-				len = extend(inw, q, r, CAPLEN, maxlen);
-				mlen[p] = (uint8_t)(len - 3);
-			}
-		}
-		return len;
+		return m ? m + 3 : 0;
 	}
 };
 
@@ -227,49 +240,52 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		}
 		if (t < 32) dtab[t] = (__builtin_bitreverse32((uint32_t)t) >> 27) | (5u << 16);
 	}
-	// CRC byte table lives in the (not yet used) bit buffer
-	if (t < 256) {
-		uint32_t c = t;
-		for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1) ? 0xedb88320u : 0);
+	// slice-by-4 CRC tables live in the (not yet used) bit buffer: T[k][i] = i advanced by k+1 zero bytes
+	{
+		uint32_t c = t & 255;
+		for (int k = 0; k < 8 * ((t >> 8) + 1); k++) c = (c >> 1) ^ ((c & 1) ? 0xedb88320u : 0);
 		bitbuf[t] = c;
 	}
 	__syncthreads();
 	PROF(0);
 
 	// ---------------- checksums of the non-history source ----------------
+	// The stream is cut into 64-byte slices aligned in LDS.  Thread t owns full slice
+	// s = t - 1025 + K (K-1 = slice holding the last byte), i.e. the full slices are right
+	// aligned on thread 1023 and leading threads see an all-zero prefix, which does not
+	// change a raw (init 0) CRC.  Slices are read as 4 x ds_read_b128 and fed through a
+	// slice-by-4 table; the tree combine multiplies by x^(8*64*2^level).  The last
+	// (partial) slice is finished bytewise by one lane.  in_crc is folded into the first
+	// data dword (history length is a multiple of 16, so that dword is aligned).
 	uint32_t out_crc, out_adler;
 	{
-		// frame of 1024 x 64 B slices, data right-aligned (leading zeros do not change a raw CRC)
-		const uint32_t pad = 65536 - n;
-		uint32_t lo = (uint32_t)t * 64, hi = lo + 64;           // frame offsets of this slice
+		uint32_t *T = bitbuf;                                   // T[k*256 + i], k = 0..3
+		const uint32_t K1 = n ? (end - 1) >> 6 : 0;             // index of the last slice
+		const bool tail_only = n == 0 || (h >> 6) == K1;        // all data inside the last slice
+		const uint32_t initx = job.in_crc ^ 0xffffffffu;
+		int sidx = (int)t - 1024 + (int)K1;                     // my full slice (valid if >= h>>6 and < K1)
 		uint32_t crc = 0, s1 = 0, sj = 0;
-		uint32_t initx = job.in_crc ^ 0xffffffffu;               // folded into the first 4 data bytes
-		if (hi > pad) {
-			uint32_t f0 = lo > pad ? lo : pad;
-			for (uint32_t f = f0; f < hi; f++) {
-				uint32_t i = f - pad;                            // data index
-				uint32_t b = lds[OFF_IN + h + i];
-				uint32_t bx = b ^ (i < 4 ? (initx >> (8 * i)) & 0xff : 0);
-				crc = bitbuf[(crc ^ bx) & 0xff] ^ (crc >> 8);
-				s1 += b;
-				sj += b * (n - i);                               // weight of byte i in Adler's s2
+		if (!tail_only && sidx >= (int)(h >> 6) && sidx < (int)K1) {
+			const uint4 *sp = (const uint4 *)(lds + OFF_IN + (uint32_t)sidx * 64);
+			uint4 q[4] = { sp[0], sp[1], sp[2], sp[3] };
+			const uint32_t *w = (const uint32_t *)q;
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				uint32_t a = (uint32_t)sidx * 64 + 4 * k;           // LDS address of this dword
+				uint32_t v = w[k];
+				if (a < h) continue;                                // history bytes: not part of the stream
+				uint32_t i = a - h;
+				uint32_t b0 = v & 0xff, b1 = (v >> 8) & 0xff, b2 = (v >> 16) & 0xff, b3 = v >> 24;
+				s1 += b0 + b1 + b2 + b3;
+				sj += (b0 + b1 + b2 + b3) * (n - i) - (b1 + 2 * b2 + 3 * b3);
+				uint32_t c = crc ^ v ^ (i == 0 ? initx : 0);
+				crc = T[768 + (c & 0xff)] ^ T[512 + ((c >> 8) & 0xff)] ^ T[256 + ((c >> 16) & 0xff)] ^ T[c >> 24];
 			}
 		}
-		// CRC tree: combine neighbours, distance doubles; multiplier x^(8*64*2^l)
-		uint32_t mult = 0;                                           // x^(512) computed below
-		{
-			uint32_t m = 0x00800000u;                            // x^8
-			for (int k = 0; k < 6; k++) m = gf_mul(m, m);        // x^(8*64)
-			mult = m;
-		}
-#pragma unroll 1
-		for (int o = 1; o < 64; o <<= 1) {
-			uint32_t right = __shfl_down(crc, o, 64);
-			if ((lane & (2 * o - 1)) == 0) crc = gf_mul(crc, mult) ^ right;
-			mult = gf_mul(mult, mult);
-		}
+		// every slice is weighted by x^(8 * bytes that follow it): thread t is followed by 1023-t slices
+		crc = gf_mul(crc, CRC_POW.v[1023 - t]);
+		for (int o = 32; o > 0; o >>= 1) crc ^= __shfl_down(crc, o, 64);
 		if (lane == 0) scan[wave] = crc;
-		// Adler partial sums
 		uint32_t a1 = s1, a2 = sj % 65521u;
 		for (int o = 32; o > 0; o >>= 1) {
 			a1 += __shfl_down(a1, o, 64);
@@ -279,23 +295,23 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		__syncthreads();
 		if (wave == 0) {
 			uint32_t c = lane < 16 ? scan[lane] : 0;
-#pragma unroll 1
-			for (int o = 1; o < 16; o <<= 1) {
-				uint32_t right = __shfl_down(c, o, 64);
-				if ((lane & (2 * o - 1)) == 0) c = gf_mul(c, mult) ^ right;
-				mult = gf_mul(mult, mult);
-			}
 			uint32_t b1 = lane < 16 ? scan[16 + lane] : 0, b2 = lane < 16 ? scan[32 + lane] : 0;
 			for (int o = 8; o > 0; o >>= 1) {
+				c ^= __shfl_down(c, o, 64);
 				b1 += __shfl_down(b1, o, 64);
 				b2 += __shfl_down(b2, o, 64);
 			}
 			if (lane == 0) {
-				if (n < 4) {
-					// too short for the init folding trick: plain bytewise
-					c = initx;
-					for (uint32_t i = 0; i < n; i++) c = bitbuf[(c ^ lds[OFF_IN + h + i]) & 0xff] ^ (c >> 8);
+				// last slice, bytewise, continuing from the tree result
+				uint32_t a0 = tail_only ? h : K1 * 64;
+				if (tail_only) c = initx;
+				uint32_t t1 = 0, t2 = 0;
+				for (uint32_t a = a0; a < end; a++) {
+					uint32_t byte = lds[OFF_IN + a];
+					c = T[(c ^ byte) & 0xff] ^ (c >> 8);
+					t1 += byte; t2 += byte * (end - a);
 				}
+				b1 += t1; b2 += t2 % 65521u;
 				uint32_t ia = job.in_adler & 0xffff, ib = job.in_adler >> 16;
 				uint32_t s1f = (ia + b1) % 65521u;
 				uint32_t s2f = (uint32_t)(((uint64_t)ib + (uint64_t)n * ia + b2) % 65521u);
@@ -346,31 +362,39 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		W.tile_base = tb0;
 
 		// ---- hash ----
-		for (uint32_t i = t; i < tn; i += NT) {
+		// cand[i] = byte offset of the position's head[] slot (dummy slot for positions without a
+		// hash and for the padding up to a multiple of 512 positions, so the chain loop is guard free)
+		const uint32_t tnpad = (tn + 511) & ~511u;
+		for (uint32_t i = t; i < tnpad; i += NT) {
 			uint32_t r = h + tb0 + i;
-			cand[i] = (r + 4 <= end) ? (uint16_t)hash4(lds_ld32(inw, r)) : (uint16_t)NOHASH;
+			cand[i] = (i < tn && r + 4 <= end) ? (uint16_t)(hash4(lds_ld32(inw, r)) * 4) : (uint16_t)(HSIZE * 4);
 		}
 		__syncthreads();
 		PROF(3);
 
 		// ---- chain: one wave, 64 positions per step; lookups see every earlier step ----
 		if (wave == 0) {
-			// The trip count must be wave-uniform: with a per-lane bound the compiler peels the
-			// remainder iteration in FRONT of the unrolled loop and the lanes stop marching in
-			// step, which breaks "every lookup of a step precedes every insert of that step".
-			for (uint32_t base = 0; base < tn; base += 64) {
-				uint32_t i = base + lane;
-				uint32_t hv = i < tn ? (uint32_t)cand[i] : NOHASH;
-				uint32_t r = h + tb0 + i;
-				uint32_t c = NOHASH;
-				if (hv != NOHASH) {
-					uint32_t old = __hip_atomic_load(&head[hv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					if (old != 0 && r + 1 - old <= WINDOW) c = r - old;       // dist-1
+			// The serial part of the algorithm, kept to ~7 instructions per 64-position step: load
+			// the slot offset, look the slot up, insert, store the candidate position (16 bit; an
+			// empty slot gives 0xffff which no position can use).  The trip count is wave-uniform
+			// and 8 steps are issued back to back: the LDS executes one wave's operations in order,
+			// so lookup(k+1) only has to be ISSUED after insert(k); results are consumed afterwards.
+			constexpr int U = 8;
+			const uint8_t *headb = (const uint8_t *)head;
+			for (uint32_t base = 0; base < tnpad; base += 64 * U) {
+				uint32_t off[U], old[U];
+#pragma unroll
+				for (int u = 0; u < U; u++) off[u] = cand[base + 64 * u + lane];
+#pragma unroll
+				for (int u = 0; u < U; u++) {
+					uint32_t *slot = (uint32_t *)(headb + off[u]);
+					old[u] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					__builtin_amdgcn_wave_barrier();
+					atomicMax(slot, h + tb0 + base + 64 * u + lane + 1);
+					__builtin_amdgcn_wave_barrier();
 				}
-				__builtin_amdgcn_wave_barrier();
-				if (i < tn) cand[i] = (uint16_t)c;
-				if (hv != NOHASH) atomicMax(&head[hv], r + 1);
-				__builtin_amdgcn_wave_barrier();
+#pragma unroll
+				for (int u = 0; u < U; u++) cand[base + 64 * u + lane] = (uint16_t)(old[u] - 1);
 			}
 		}
 		__syncthreads();
@@ -379,15 +403,15 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// ---- match: verify, extend (capped), distance-1 run check ----
 		for (uint32_t i = t; i < tn; i += NT) {
 			uint32_t r = h + tb0 + i;
-			uint32_t len = 0, c = cand[i];
+			uint32_t len = 0, c = NOHASH;
 			if (r + 4 <= end) {
 				uint32_t v = lds_ld32(inw, r);
 				uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
 				uint32_t lim = maxlen < CAPLEN ? maxlen : CAPLEN;
-				if (c != NOHASH) {
-					uint32_t q = r - (c + 1);
-					if (lds_ld32(inw, q) == v) len = extend(inw, q, r, 4, lim);
-					else c = NOHASH;
+				uint32_t q = cand[i];                       // candidate position (0xffff: none)
+				if (q < r && r - q <= WINDOW && lds_ld32(inw, q) == v) {
+					len = extend(inw, q, r, 4, lim);
+					c = r - q - 1;
 				}
 				if (r >= 1 && lds_ld32(inw, r - 1) == v) {
 					uint32_t l1 = extend(inw, r - 1, r, 4, lim);
@@ -409,7 +433,65 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			mlen[i] = len >= 4 ? (uint8_t)(len - 3) : 0;
 			cand[i] = (uint16_t)c;
 		}
-		// chain bookkeeping init
+		__syncthreads();
+		// ---- run extension: exact lengths for the positions that hit the cap ----
+		// A capped position p (distance d) has natural length N(p); every later capped position q
+		// with the same distance and q - p <= N(p) - CAPLEN lies inside the same match and has
+		// N(q) = N(p) - (q - p).  So only "heads" compare bytes -- a whole wave per head, 256
+		// conflict-free bytes per step -- and they hand the exact length (clamped to 258 / end) to
+		// the positions they cover.  Two waves covering the same position write the same value.
+		{
+			uint32_t *hb = mbits;                             // head bitmap
+			for (uint32_t i0 = wave * 64; i0 < ((tn + 63) & ~63u); i0 += NT) {
+				uint32_t i = i0 + lane;
+				bool capped = i < tn && mlen[i] == CAPLEN - 3;
+				bool headp = capped && !(i > 0 && mlen[i - 1] == CAPLEN - 3 && cand[i - 1] == cand[i]);
+				unsigned long long bh = __ballot(headp);
+				if (lane == 0) { hb[i0 >> 5] = (uint32_t)bh; hb[(i0 >> 5) + 1] = (uint32_t)(bh >> 32); }
+			}
+			__syncthreads();
+			const uint32_t nwords = ((tn + 63) >> 6) << 1;
+			for (uint32_t wd = wave; wd < nwords; wd += NT / 64) {
+				uint32_t bits = __hip_atomic_load(&hb[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				while (bits) {
+					uint32_t hp = (wd << 5) + (uint32_t)__builtin_ctz(bits);
+					uint32_t d = cand[hp];
+					uint32_t r0 = h + tb0 + hp, q0 = r0 - (d + 1);
+					// natural length, as far as any position of this tile can use it
+					uint32_t lmax = (tn - 1 - hp) + MAXMATCH;
+					if (lmax > end - r0) lmax = end - r0;
+					uint32_t N = lmax;
+					for (uint32_t ob = CAPLEN; ob < lmax; ob += 256) {
+						uint32_t o = ob + 4 * lane;
+						uint32_t x = lds_ld32(inw, q0 + o) ^ lds_ld32(inw, r0 + o);
+						unsigned long long mm = __ballot(x != 0);
+						if (mm) {
+							int fl = __builtin_ctzll(mm);
+							uint32_t xf = __shfl(x, fl, 64);
+							uint32_t nn = ob + 4 * fl + ((uint32_t)__builtin_ctz(xf) >> 3);
+							N = nn < lmax ? nn : lmax;
+							break;
+						}
+					}
+					// hand the exact length to every capped position of the same distance it covers
+					uint32_t ce = hp + (N - CAPLEN) + 1;
+					if (ce > tn) ce = tn;
+					for (uint32_t q = hp + lane; q < ce; q += 64) {
+						if (mlen[q] == CAPLEN - 3 && cand[q] == d) {
+							uint32_t full = N - (q - hp), rq = r0 + (q - hp);
+							if (full > MAXMATCH) full = MAXMATCH;
+							if (full > end - rq) full = end - rq;
+							mlen[q] = (uint8_t)(full - 3);
+							if (q != hp) atomicAnd(&hb[q >> 5], ~(1u << (q & 31)));
+						}
+					}
+					__builtin_amdgcn_wave_barrier();
+					bits = __hip_atomic_load(&hb[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & (~1u << (hp & 31));
+				}
+			}
+		}
+		__syncthreads();
+		// chain bookkeeping init (mark/jump alias the two bitmaps)
 		for (uint32_t s = t; s < NSEG; s += NT) mark[s] = 0;
 		__syncthreads();
 		if (nxz_debug_buf && blockIdx.x == 0)
