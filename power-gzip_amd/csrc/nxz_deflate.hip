@@ -54,12 +54,14 @@ constexpr uint32_t OFF_IN    = 0;                        // 65536 + 32 pad
 constexpr uint32_t OFF_HEAD  = 65536 + 32;               // 8192 x u32
 constexpr uint32_t OFF_CAND  = OFF_HEAD + HSIZE * 4 + 16; // 16384 x u16 (head[HSIZE] is a dummy slot)
 constexpr uint32_t OFF_MLEN  = OFF_CAND + PTILE * 2;     // 16384 x u8
-constexpr uint32_t OFF_X     = OFF_MLEN + PTILE;         // 1024 x u16
-constexpr uint32_t OFF_ENTRY = OFF_X + NSEG * 2;         // 1024 x u16
-constexpr uint32_t OFF_SBITS = OFF_ENTRY + NSEG * 2;     // 512 x u32   (aliased: MARK u8[1024] during chain marking)
+constexpr uint32_t OFF_SBITS = OFF_MLEN + PTILE;         // 512 x u32   (aliased: MARK u8[1024] during chain marking)
 constexpr uint32_t OFF_MBITS = OFF_SBITS + PTILE / 8;    // 512 x u32   (aliased: JUMP u16[1024])
-constexpr uint32_t OFF_BITS  = OFF_MBITS + PTILE / 8;    // (ETILE*16/8 + 64) bytes of packed output (aliased: CRC table)
+constexpr uint32_t OFF_X     = OFF_MBITS + PTILE / 8;    // 1024 x u16  } dead after the parse: together with
+constexpr uint32_t OFF_ENTRY = OFF_X + NSEG * 2;         // 1024 x u16  } BITS they form the bit-pack window
+constexpr uint32_t OFF_BITS  = OFF_ENTRY + NSEG * 2;     // 4096 + 64 bytes (aliased: CRC tables before the first tile)
 constexpr uint32_t BITS_BYTES = ETILE * 2 + 64;
+constexpr uint32_t OFF_WIN   = OFF_X;                    // bit-pack window: WWORDS dwords + 16 dwords of spill
+constexpr uint32_t WWORDS    = (NSEG * 4 + ETILE * 2) / 4;   // 2048
 constexpr uint32_t OFF_SCAN  = OFF_BITS + BITS_BYTES;    // 64 x u32
 constexpr uint32_t OFF_LLTAB = OFF_SCAN + 256;           // 288 x u32
 constexpr uint32_t OFF_DTAB  = OFF_LLTAB + 288 * 4;      // 32 x u32
@@ -69,7 +71,7 @@ constexpr uint32_t LDS_BYTES = OFF_MISC + 64;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
-enum { M_ERR = 0, M_CARRY_BITS = 1, M_WORDBASE = 2, M_TOTBITS_LO = 3, M_TMP = 4 };
+enum { M_ERR = 0, M_CARRY_BITS = 1, M_WORDBASE = 2, M_CARRY_WORD = 3, M_TMP = 4 };
 
 __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
 {
@@ -140,6 +142,39 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 		if (lane >= o) v += u;
 	}
 	return v;
+}
+
+// Full match evaluation of one position (oracle/nxz_lz77.c step 4): hash candidate q16 and the
+// distance-1 run candidate, both extended up to CAPLEN; returns the capped length (0 = none) and
+// the chosen distance-1.
+__device__ __forceinline__ void match_full(const uint32_t *inw, uint32_t r, uint32_t q, uint32_t end,
+					   uint32_t &len_out, uint32_t &c_out)
+{
+	uint32_t len = 0, c = NOHASH;
+	uint32_t v = lds_ld32(inw, r);
+	uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+	uint32_t lim = maxlen < CAPLEN ? maxlen : CAPLEN;
+	if (q < r && r - q <= WINDOW && lds_ld32(inw, q) == v) {
+		len = extend(inw, q, r, 4, lim);
+		c = r - q - 1;
+	}
+	if (r >= 1 && lds_ld32(inw, r - 1) == v) {
+		uint32_t l1 = extend(inw, r - 1, r, 4, lim);
+		// oracle: the run wins when its FULL length >= the hash match's full length.  Capped
+		// lengths compare equal only if both reach the cap; then compare the full lengths.
+		bool take = l1 > len;
+		if (l1 == len) {
+			if (len < lim || lim == maxlen) take = true;
+			else {
+				uint32_t fa = extend(inw, r - (c + 1), r, CAPLEN, maxlen);
+				uint32_t fb = extend(inw, r - 1, r, CAPLEN, maxlen);
+				take = fb >= fa;
+			}
+		}
+		if (take) { len = l1; c = 0; }
+	}
+	len_out = len >= 4 ? len : 0;
+	c_out = len >= 4 ? c : NOHASH;
 }
 
 struct Walk {
@@ -325,8 +360,6 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		__syncthreads();
 	}
 	PROF(1);
-	// clear the bit buffer (it held the CRC table)
-	for (uint32_t i = t; i < BITS_BYTES / 4; i += NT) bitbuf[i] = 0;
 
 	// ---------------- seed head[] with the window ----------------
 	for (uint32_t r = t; r < h; r += NT)
@@ -344,11 +377,11 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			uint32_t cur = i < 73 ? tb->dhtw[i] : 0, prev = i ? tb->dhtw[i - 1] : 0;
 			uint32_t w = (cur << 3) | (i ? prev >> 29 : 5u);
 			if (i < nw) { if (i < cap_words) dstw[i] = w; }
-			else bitbuf[0] = (hb & 31) ? (w & ((1u << (hb & 31)) - 1)) : 0;
+			else misc[M_CARRY_WORD] = (hb & 31) ? (w & ((1u << (hb & 31)) - 1)) : 0;
 		}
 		if (t == 0) { misc[M_CARRY_BITS] = hb & 31; misc[M_WORDBASE] = nw; if (nw > cap_words) misc[M_ERR] = NXZ_CC_TARGET_SPACE; }
 	} else {
-		if (t == 0) { bitbuf[0] = 3u; misc[M_CARRY_BITS] = 3; misc[M_WORDBASE] = 0; }
+		if (t == 0) { misc[M_CARRY_WORD] = 3u; misc[M_CARRY_BITS] = 3; misc[M_WORDBASE] = 0; }
 	}
 	__syncthreads();
 
@@ -365,6 +398,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// cand[i] = byte offset of the position's head[] slot (dummy slot for positions without a
 		// hash and for the padding up to a multiple of 512 positions, so the chain loop is guard free)
 		const uint32_t tnpad = (tn + 511) & ~511u;
+		for (uint32_t i = t; i < PTILE / 32; i += NT) sbits[i] = 0;     // capped-position bitmap of the match phase
 		for (uint32_t i = t; i < tnpad; i += NT) {
 			uint32_t r = h + tb0 + i;
 			cand[i] = (i < tn && r + 4 <= end) ? (uint16_t)(hash4(lds_ld32(inw, r)) * 4) : (uint16_t)(HSIZE * 4);
@@ -400,40 +434,75 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		__syncthreads();
 		PROF(4);
 
-		// ---- match: verify, extend (capped), distance-1 run check ----
-		for (uint32_t i = t; i < tn; i += NT) {
-			uint32_t r = h + tb0 + i;
-			uint32_t len = 0, c = NOHASH;
-			if (r + 4 <= end) {
-				uint32_t v = lds_ld32(inw, r);
-				uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-				uint32_t lim = maxlen < CAPLEN ? maxlen : CAPLEN;
-				uint32_t q = cand[i];                       // candidate position (0xffff: none)
-				if (q < r && r - q <= WINDOW && lds_ld32(inw, q) == v) {
-					len = extend(inw, q, r, 4, lim);
-					c = r - q - 1;
+		// ---- match, stage 1 (branch free, every position): verify both candidates and compare
+		// bytes 4..7.  Lengths below 8 are final here.  The rest (about one position in seven for
+		// text) goes to a per-wave queue and is finished 64 at a time by stage 2, so that the
+		// divergent extension loop runs on full wavefronts instead of dragging 60 idle lanes.
+		{
+			uint16_t *queue = (uint16_t *)(lds + OFF_X) + wave * 128;
+			uint32_t *cb = sbits;                             // capped-position bitmap (zeroed in the hash phase)
+			uint32_t qcnt = 0;
+			auto stage2 = [&](uint32_t nq) {
+				uint32_t i = lane < nq ? (uint32_t)queue[lane] : 0xffffffffu;
+				__builtin_amdgcn_wave_barrier();
+				if (nq > 64 && 64 + lane < nq) queue[lane] = queue[64 + lane];
+				if (i != 0xffffffffu) {
+					uint32_t len, c;
+					match_full(inw, h + tb0 + i, cand[i], end, len, c);
+					mlen[i] = len ? (uint8_t)(len - 3) : 0;
+					cand[i] = (uint16_t)c;
+					if (len == CAPLEN) atomicOr(&cb[i >> 5], 1u << (i & 31));
 				}
-				if (r >= 1 && lds_ld32(inw, r - 1) == v) {
-					uint32_t l1 = extend(inw, r - 1, r, 4, lim);
-					// oracle: the run wins when its FULL length >= the hash match's full length.
-					// Capped lengths compare equal only if both reach the cap; then the run's
-					// full length (limited only by maxlen) must be compared exactly.
-					bool take = l1 > len;
-					if (l1 == len) {
-						if (len < lim || lim == maxlen) take = true;
-						else {
-							uint32_t fa = extend(inw, r - (c + 1), r, CAPLEN, maxlen);
-							uint32_t fb = extend(inw, r - 1, r, CAPLEN, maxlen);
-							take = fb >= fa;
-						}
-					}
-					if (take) { len = l1; c = 0; }
+			};
+			for (uint32_t i0 = wave * 64; i0 < ((tn + 63) & ~63u); i0 += NT) {
+				const uint32_t i = i0 + lane;
+				const uint32_t r = h + tb0 + i;
+				const bool ok = i < tn && r + 4 <= end;
+				// the dword that holds r, one before and two after: bytes r-1 .. r+7 in registers.
+				// (Only 2-way selects below: a 3-way select on a computed index makes hipcc build a
+				// lookup table in scratch memory.)
+				const uint32_t rw = r >> 2, ro = r & 3;
+				const uint32_t dm1 = inw[rw ? rw - 1 : 0], d0 = inw[rw], d1 = inw[rw + 1], d2 = inw[rw + 2];
+				const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, ro), v4 = __builtin_amdgcn_alignbyte(d2, d1, ro);
+				const uint32_t vm1 = ro ? __builtin_amdgcn_alignbyte(d1, d0, ro - 1) : __builtin_amdgcn_alignbyte(d0, dm1, 3);
+				const uint32_t v3 = ro ? __builtin_amdgcn_alignbyte(d2, d1, ro - 1) : __builtin_amdgcn_alignbyte(d1, d0, 3);
+				const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+				uint32_t q = ok ? (uint32_t)cand[i] : 0xffffu;
+				const bool qok = ok && q < r && r - q <= WINDOW;
+				if (!qok) q = 0;
+				const uint32_t qa = q >> 2, u0 = inw[qa], u1 = inw[qa + 1], u2 = inw[qa + 2];
+				const uint32_t qv = __builtin_amdgcn_alignbyte(u1, u0, q & 3), qv4 = __builtin_amdgcn_alignbyte(u2, u1, q & 3);
+				uint32_t lenA = 0, lenB = 0;
+				if (qok && qv == v) {
+					uint32_t x = qv4 ^ v4;
+					lenA = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
+					if (lenA > maxlen) lenA = maxlen;
+				}
+				if (ok && r >= 1 && vm1 == v) {
+					uint32_t x = v3 ^ v4;
+					lenB = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
+					if (lenB > maxlen) lenB = maxlen;
+				}
+				const bool finA = lenA < 8 || lenA == maxlen, finB = lenB < 8 || lenB == maxlen;
+				const bool needs = ok && !(finA && finB);
+				if (i < tn && !needs) {
+					uint32_t len = lenA, c = r - q - 1;
+					if (lenB >= 4 && lenB >= lenA) { len = lenB; c = 0; }
+					mlen[i] = len >= 4 ? (uint8_t)(len - 3) : 0;
+					cand[i] = len >= 4 ? (uint16_t)c : (uint16_t)NOHASH;
+				}
+				unsigned long long m = __ballot(needs);
+				if (m) {
+					if (needs) queue[qcnt + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
+					qcnt += (uint32_t)__popcll(m);
+					__builtin_amdgcn_wave_barrier();
+					if (qcnt >= 64) { stage2(qcnt); qcnt -= 64; }
 				}
 			}
-			mlen[i] = len >= 4 ? (uint8_t)(len - 3) : 0;
-			cand[i] = (uint16_t)c;
+			if (qcnt) stage2(qcnt);
 		}
 		__syncthreads();
+		PROF(10);
 		// ---- run extension: exact lengths for the positions that hit the cap ----
 		// A capped position p (distance d) has natural length N(p); every later capped position q
 		// with the same distance and q - p <= N(p) - CAPLEN lies inside the same match and has
@@ -442,14 +511,21 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// the positions they cover.  Two waves covering the same position write the same value.
 		{
 			uint32_t *hb = mbits;                             // head bitmap
-			for (uint32_t i0 = wave * 64; i0 < ((tn + 63) & ~63u); i0 += NT) {
-				uint32_t i = i0 + lane;
-				bool capped = i < tn && mlen[i] == CAPLEN - 3;
-				bool headp = capped && !(i > 0 && mlen[i - 1] == CAPLEN - 3 && cand[i - 1] == cand[i]);
-				unsigned long long bh = __ballot(headp);
-				if (lane == 0) { hb[i0 >> 5] = (uint32_t)bh; hb[(i0 >> 5) + 1] = (uint32_t)(bh >> 32); }
+			const uint32_t *cb = sbits;
+			if (t < PTILE / 32) {
+				uint32_t cw = cb[t], hw = 0;
+				if (cw) {
+					uint32_t prevw = t ? cb[t - 1] : 0;
+					for (uint32_t m = cw; m; m &= m - 1) {
+						uint32_t bpos = (uint32_t)__builtin_ctz(m), pp = (uint32_t)t * 32 + bpos;
+						bool pc = bpos ? (cw >> (bpos - 1)) & 1 : (prevw >> 31) & 1;
+						if (!(pc && cand[pp - 1] == cand[pp])) hw |= 1u << bpos;
+					}
+				}
+				hb[t] = hw;
 			}
 			__syncthreads();
+			PROF(11);
 			const uint32_t nwords = ((tn + 63) >> 6) << 1;
 			for (uint32_t wd = wave; wd < nwords; wd += NT / 64) {
 				uint32_t bits = __hip_atomic_load(&hb[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -559,84 +635,109 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		PROF(8);
 
 		// ---- encode ----
-		for (uint32_t e0 = 0; e0 < tn; e0 += ETILE) {
-			const uint32_t en = tn - e0 < ETILE ? tn - e0 : ETILE;
-			// two consecutive positions per thread
-			uint64_t val[2]; uint32_t nb[2];
-#pragma unroll
-			for (int k = 0; k < 2; k++) {
-				uint32_t p = e0 + 2 * t + k;
-				val[k] = 0; nb[k] = 0;
-				if (2u * t + k < en && (sbits[p >> 5] >> (p & 31) & 1)) {
-					if (mbits[p >> 5] >> (p & 31) & 1) {
-						uint32_t l = mlen[p];                       // len-3
-						uint32_t d = cand[p];                       // dist-1
-						uint32_t le = l < 8 ? 0 : (29 - __builtin_clz(l));
-						uint32_t ls = l == 255 ? 28 : (le << 2) + (l >> le);
-						if (l == 255) le = 0;
-						uint32_t de = d < 4 ? 0 : (30 - __builtin_clz(d));
-						uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
-						uint32_t lt = lltab[257 + ls], dt = dtab[ds];
-						uint32_t ll = lt >> 16, dl = dt >> 16;
-						if (DHT && (ll == 0 || dl == 0)) misc[M_ERR] = NXZ_CC_MISSING_CODE;
-						uint64_t v = lt & 0xffff;
-						uint32_t b = ll;
-						v |= (uint64_t)(l & ((1u << le) - 1)) << b; b += le;
-						v |= (uint64_t)(dt & 0xffff) << b; b += dl;
-						v |= (uint64_t)(d & ((1u << de) - 1)) << b; b += de;
-						val[k] = v; nb[k] = b;
-						if (COUNT) { atomicAdd(&hist[257 + ls], 1u); atomicAdd(&hist[286 + ds], 1u); }
-					} else {
-						uint32_t byte = lds[OFF_IN + h + tb0 + p];
-						uint32_t lt = lltab[byte];
-						if (DHT && (lt >> 16) == 0) misc[M_ERR] = NXZ_CC_MISSING_CODE;
-						val[k] = lt & 0xffff; nb[k] = lt >> 16;
-						if (COUNT) atomicAdd(&hist[byte], 1u);
-					}
-				}
+		// Thread t owns the tokens that START in positions [16t, 16t+16).  One workgroup prefix
+		// sum of their bit counts per tile; then the codes are OR-ed into a 8 KiB LDS window
+		// (X/ENTRY/BITS regions) and flushed as coalesced dwords, window after window.
+		{
+			uint32_t *win = (uint32_t *)(lds + OFF_WIN);
+			const uint32_t p0 = (uint32_t)t * PSEG;
+			uint32_t sb = 0, mb = 0;
+			if (p0 < tn) {
+				sb = (sbits[p0 >> 5] >> (p0 & 31)) & 0xffffu;
+				mb = (mbits[p0 >> 5] >> (p0 & 31)) & 0xffffu;
 			}
-			// workgroup exclusive prefix sum of bit counts
-			uint32_t mine = nb[0] + nb[1];
+			auto token = [&](uint32_t p, bool ismatch, uint64_t &v, uint32_t &nb, bool count) {
+				if (ismatch) {
+					uint32_t l = mlen[p];                       // len-3
+					uint32_t d = cand[p];                       // dist-1
+					uint32_t le = l < 8 ? 0 : (29 - __builtin_clz(l));
+					uint32_t ls = l == 255 ? 28 : (le << 2) + (l >> le);
+					if (l == 255) le = 0;
+					uint32_t de = d < 4 ? 0 : (30 - __builtin_clz(d));
+					uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
+					uint32_t lt = lltab[257 + ls], dt = dtab[ds];
+					uint32_t ll = lt >> 16, dl = dt >> 16;
+					if (DHT && (ll == 0 || dl == 0)) misc[M_ERR] = NXZ_CC_MISSING_CODE;
+					v = lt & 0xffff;
+					nb = ll;
+					v |= (uint64_t)(l & ((1u << le) - 1)) << nb; nb += le;
+					v |= (uint64_t)(dt & 0xffff) << nb; nb += dl;
+					v |= (uint64_t)(d & ((1u << de) - 1)) << nb; nb += de;
+					if (COUNT && count) { atomicAdd(&hist[257 + ls], 1u); atomicAdd(&hist[286 + ds], 1u); }
+				} else {
+					uint32_t byte = lds[OFF_IN + h + tb0 + p];
+					uint32_t lt = lltab[byte];
+					if (DHT && (lt >> 16) == 0) misc[M_ERR] = NXZ_CC_MISSING_CODE;
+					v = lt & 0xffff; nb = lt >> 16;
+					if (COUNT && count) atomicAdd(&hist[byte], 1u);
+				}
+			};
+			uint32_t mine = 0;
+			for (uint32_t m = sb; m; m &= m - 1) {
+				uint32_t k = (uint32_t)__builtin_ctz(m);
+				uint64_t v; uint32_t nb;
+				token(p0 + k, (mb >> k) & 1, v, nb, true);
+				mine += nb;
+			}
 			uint32_t incl = wave_incl_scan(mine, lane);
 			if (lane == 63) scan[wave] = incl;
-			__syncthreads();
-			uint32_t carry = misc[M_CARRY_BITS], wordbase = misc[M_WORDBASE];
+			__syncthreads();                                   // also: X/ENTRY are dead from here on
+			PROF(12);
+			uint32_t carry = misc[M_CARRY_BITS], wordbase = misc[M_WORDBASE], carryword = misc[M_CARRY_WORD];
 			uint32_t woff = 0, tot = 0;
 #pragma unroll
 			for (int w = 0; w < 16; w++) {
-				uint32_t s = scan[w];
-				if (w < wave) woff += s;
-				tot += s;
+				uint32_t sc = scan[w];
+				if (w < wave) woff += sc;
+				tot += sc;
 			}
-			uint32_t bitpos = carry + woff + incl - mine;
-#pragma unroll
-			for (int k = 0; k < 2; k++) {
-				if (nb[k]) {
-					uint32_t wi = bitpos >> 5, sh = bitpos & 31;
-					uint64_t lo = val[k] << sh;
-					atomicOr(&bitbuf[wi], (uint32_t)lo);
+			const uint32_t total = carry + tot;                // bits of this tile's stream incl. the carried partial word
+			uint32_t bitpos = carry + woff + incl - mine;      // my first token, in that stream
+			for (uint32_t i = t; i < WWORDS + 16; i += NT) win[i] = (i == 0) ? carryword : 0;
+			__syncthreads();
+			PROF(13);
+			uint32_t rest = sb;
+			for (uint32_t wlo = 0;; wlo += WWORDS * 32) {
+				const uint32_t whi = wlo + WWORDS * 32;
+				while (rest && bitpos < whi) {
+					uint32_t k = (uint32_t)__builtin_ctz(rest);
+					rest &= rest - 1;
+					uint64_t v; uint32_t nb;
+					token(p0 + k, (mb >> k) & 1, v, nb, false);
+					uint32_t rel = bitpos - wlo, wi = rel >> 5, sh = rel & 31;
+					uint64_t lo = v << sh;
+					atomicOr(&win[wi], (uint32_t)lo);
 					uint32_t mid = (uint32_t)(lo >> 32);
-					if (mid) atomicOr(&bitbuf[wi + 1], mid);
-					uint32_t hi2 = sh ? (uint32_t)(val[k] >> (64 - sh)) : 0;
-					if (hi2) atomicOr(&bitbuf[wi + 2], hi2);
-					bitpos += nb[k];
+					if (mid) atomicOr(&win[wi + 1], mid);
+					uint32_t hi2 = sh ? (uint32_t)(v >> (64 - sh)) : 0;
+					if (hi2) atomicOr(&win[wi + 2], hi2);
+					bitpos += nb;
 				}
+				__syncthreads();
+				PROF(14);
+				const bool lastw = total <= whi;
+				const uint32_t nw = lastw ? (total - wlo) >> 5 : WWORDS;
+				for (uint32_t i = t; i < nw; i += NT)
+					if (wordbase + i < cap_words) dstw[wordbase + i] = win[i];
+				// what stays: the partial last dword, or the spill of tokens that crossed the window end
+				uint32_t keep = 0;
+				if (t < 3) keep = lastw ? (t == 0 ? win[nw] : 0) : win[WWORDS + t];
+				__syncthreads();
+				wordbase += nw;
+				if (lastw) {
+					if (t == 0) {
+						misc[M_CARRY_BITS] = total & 31;
+						misc[M_CARRY_WORD] = keep;
+						misc[M_WORDBASE] = wordbase;
+						if (wordbase > cap_words) misc[M_ERR] = NXZ_CC_TARGET_SPACE;
+					}
+					break;
+				}
+				for (uint32_t i = t; i < WWORDS + 16; i += NT) win[i] = (i < 3) ? keep : 0;
+				__syncthreads();
 			}
 			__syncthreads();
-			// flush full dwords, keep the partial one
-			uint32_t allbits = carry + tot, nw = allbits >> 5;
-			uint32_t last = bitbuf[nw];                                   // read before anyone rewrites word 0
-			for (uint32_t i = t; i < nw; i += NT) {
-				if (wordbase + i < cap_words) dstw[wordbase + i] = bitbuf[i];
-			}
-			__syncthreads();
-			for (uint32_t i = t; i <= nw + 2 && i < BITS_BYTES / 4; i += NT) bitbuf[i] = (i == 0) ? last : 0;
-			if (t == 0) {
-				misc[M_CARRY_BITS] = allbits & 31;
-				misc[M_WORDBASE] = wordbase + nw;
-				if (wordbase + nw > cap_words) misc[M_ERR] = NXZ_CC_TARGET_SPACE;
-			}
-			__syncthreads();
+			PROF(15);
 		}
 	}
 
@@ -648,7 +749,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		uint32_t cc = misc[M_ERR];
 		if (DHT && (lt >> 16) == 0) cc = NXZ_CC_MISSING_CODE;
 		if (DHT && tables[job.dht_index].status) cc = NXZ_CC_INVALID_DHT;
-		uint64_t acc = (uint64_t)bitbuf[0] | ((uint64_t)(lt & 0xffff) << carry);
+		uint64_t acc = (uint64_t)misc[M_CARRY_WORD] | ((uint64_t)(lt & 0xffff) << carry);
 		uint32_t bits = carry + (lt >> 16);
 		uint64_t totbits = (uint64_t)wordbase * 32 + bits;
 		uint32_t tpbc = (uint32_t)((totbits + 7) >> 3);

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench
 pkg = importlib.import_module("power-gzip_amd")
-NAMES = ["load", "cksum", "seed+hdr", "hash", "chain", "match", "pass1", "mark", "pass2", "encode(+all tiles)", "tail"]
+NAMES = ["load", "cksum", "seed+hdr", "hash", "chain", "runext-heads", "pass1", "mark", "pass2", "(tail)", "match", "runext-bitmap", "enc-count+scan", "enc-clear", "enc-emit", "enc-flush"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = pkg.Engine(0)
 src = bench.gen_blocks(torch, eng.dev, n, 0)
@@ -26,6 +26,6 @@ torch.cuda.synchronize()
 eng.L.nxz_prof_set(None)
 p = prof.cpu().numpy().astype(np.float64) / n
 tot = p.sum()
-for i, name in enumerate(NAMES[:10]):
+for i, name in enumerate(NAMES):
     print("%-20s %10.0f cycles/block  %5.1f%%" % (name, p[i], 100 * p[i] / tot))
 print("total %.0f cycles/block (s_memtime ticks = 100 MHz? see guide)" % tot)
