@@ -71,7 +71,7 @@ constexpr uint32_t LDS_BYTES = OFF_MISC + 64;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
-enum { M_ERR = 0, M_CARRY_BITS = 1, M_WORDBASE = 2, M_CARRY_WORD = 3, M_TMP = 4 };
+enum { M_ERR = 0, M_CARRY_BITS = 1, M_WORDBASE = 2, M_CARRY_WORD = 3, M_PROGRESS = 4, M_TICKET = 5 };
 
 __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
 {
@@ -399,22 +399,31 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// hash and for the padding up to a multiple of 512 positions, so the chain loop is guard free)
 		const uint32_t tnpad = (tn + 511) & ~511u;
 		for (uint32_t i = t; i < PTILE / 32; i += NT) sbits[i] = 0;     // capped-position bitmap of the match phase
+		if (t == 0) { misc[M_PROGRESS] = 0; misc[M_TICKET] = 0; }
+#pragma unroll 4
 		for (uint32_t i = t; i < tnpad; i += NT) {
 			uint32_t r = h + tb0 + i;
-			cand[i] = (i < tn && r + 4 <= end) ? (uint16_t)(hash4(lds_ld32(inw, r)) * 4) : (uint16_t)(HSIZE * 4);
+			uint32_t v = lds_ld32(inw, r < end ? r : 0);
+			cand[i] = (i < tn && r + 4 <= end) ? (uint16_t)(hash4(v) * 4) : (uint16_t)(HSIZE * 4);
 		}
 		__syncthreads();
 		PROF(3);
 
-		// ---- chain: one wave, 64 positions per step; lookups see every earlier step ----
+		// ---- chain (wave 0) overlapped with match (every wave) ----
+		// The chain is the only serial dependence of the algorithm.  Wave 0 walks the tile in
+		// 512-position pieces and publishes how many are done; all waves (wave 0 too, once the chain
+		// is finished) draw piece numbers from a ticket counter and run the match stages on a piece
+		// as soon as it is published, so the other 15 waves do not idle behind the chain.
+		const uint32_t npieces = tnpad >> 9;
 		if (wave == 0) {
-			// The serial part of the algorithm, kept to ~7 instructions per 64-position step: load
-			// the slot offset, look the slot up, insert, store the candidate position (16 bit; an
-			// empty slot gives 0xffff which no position can use).  The trip count is wave-uniform
-			// and 8 steps are issued back to back: the LDS executes one wave's operations in order,
-			// so lookup(k+1) only has to be ISSUED after insert(k); results are consumed afterwards.
+			// ~7 instructions per 64-position step: load the slot offset, look the slot up, insert,
+			// store the candidate position (16 bit; an empty slot gives 0xffff which no position
+			// can use).  The trip count is wave-uniform and 8 steps are issued back to back: the LDS
+			// executes one wave's operations in order, so lookup(k+1) only has to be ISSUED after
+			// insert(k); results are consumed afterwards.
 			constexpr int U = 8;
 			const uint8_t *headb = (const uint8_t *)head;
+			__builtin_amdgcn_s_setprio(3);                    // the chain is the critical path of this phase
 			for (uint32_t base = 0; base < tnpad; base += 64 * U) {
 				uint32_t off[U], old[U];
 #pragma unroll
@@ -429,9 +438,11 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				}
 #pragma unroll
 				for (int u = 0; u < U; u++) cand[base + 64 * u + lane] = (uint16_t)(old[u] - 1);
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], (base >> 9) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
+			__builtin_amdgcn_s_setprio(0);
 		}
-		__syncthreads();
 		PROF(4);
 
 		// ---- match, stage 1 (branch free, every position): verify both candidates and compare
@@ -454,7 +465,15 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					if (len == CAPLEN) atomicOr(&cb[i >> 5], 1u << (i & 31));
 				}
 			};
-			for (uint32_t i0 = wave * 64; i0 < ((tn + 63) & ~63u); i0 += NT) {
+			for (;;) {
+			uint32_t piece = 0;
+			if (lane == 0) piece = atomicAdd(&misc[M_TICKET], 1u);
+			piece = __builtin_amdgcn_readfirstlane(piece);
+			if (piece >= npieces) break;
+			while (__hip_atomic_load(&misc[M_PROGRESS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= piece)
+				__builtin_amdgcn_s_sleep(4);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			for (uint32_t i0 = piece << 9; i0 < (piece << 9) + 512 && i0 < tn; i0 += 64) {
 				const uint32_t i = i0 + lane;
 				const uint32_t r = h + tb0 + i;
 				const bool ok = i < tn && r + 4 <= end;
@@ -499,6 +518,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					if (qcnt >= 64) { stage2(qcnt); qcnt -= 64; }
 				}
 			}
+			}
 			if (qcnt) stage2(qcnt);
 		}
 		__syncthreads();
@@ -526,8 +546,11 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			}
 			__syncthreads();
 			PROF(11);
-			const uint32_t nwords = ((tn + 63) >> 6) << 1;
-			for (uint32_t wd = wave; wd < nwords; wd += NT / 64) {
+			// wave w owns head words [32w, 32w+32); one load finds the non-empty ones
+			uint32_t myword = wave * 32 + (lane & 31);
+			unsigned long long nonempty = __ballot(lane < 32 && hb[myword] != 0);
+			for (; nonempty; nonempty &= nonempty - 1) {
+				const uint32_t wd = wave * 32 + (uint32_t)__builtin_ctzll(nonempty);
 				uint32_t bits = __hip_atomic_load(&hb[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				while (bits) {
 					uint32_t hp = (wd << 5) + (uint32_t)__builtin_ctz(bits);
@@ -588,31 +611,31 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		__syncthreads();
 		PROF(6);
 		// ---- chain of entered segments by pointer doubling ----
-		for (int k = 0; k < 10; k++) {
-			uint32_t j = NSEG, j2 = NSEG;
-			if ((uint32_t)t < nseg) {
-				j = jump[t];
-				if (j < NSEG) {
-					if (mark[t]) mark[j] = 1;
-					j2 = jump[j];
+		{
+			uint16_t *ja = jump, *jb = entry;                  // entry[] is free until the chain is known
+			for (int k = 0; k < 10; k++) {
+				if ((uint32_t)t < nseg) {
+					uint32_t j = ja[t], j2 = NSEG;
+					if (j < NSEG) {
+						if (mark[t]) mark[j] = 1;
+						j2 = ja[j];
+					}
+					jb[t] = (uint16_t)j2;
 				}
+				__syncthreads();
+				uint16_t *tmp = ja; ja = jb; jb = tmp;
 			}
-			__syncthreads();
-			if ((uint32_t)t < nseg) jump[t] = (uint16_t)j2;
-			__syncthreads();
 		}
 		// entries: entered segment s hands its exit to the segment that contains it
 		bool entered = (uint32_t)t < nseg && mark[t];
 		uint32_t myx = (uint32_t)t < nseg ? X[t] : 0;
-		__syncthreads();
 		if (t == 0) entry[0] = 0;
 		if (entered && myx < tn) entry[myx / PSEG] = (uint16_t)myx;
-		// token bitmaps (alias mark/jump) are cleared now
 		__syncthreads();
 		uint32_t mye = entered ? entry[t] : 0;
 		if (nxz_debug_buf && blockIdx.x == 0 && (uint32_t)t < nseg)
 			nxz_debug_buf[(tb0 / PTILE) * 65536 + 16384 + t] = myx | (mye << 16) | (entered ? 0x80000000u : 0);
-		__syncthreads();
+		// token bitmaps (alias mark/jump, which are dead now) are cleared
 		for (uint32_t i = t; i < PTILE / 32; i += NT) { sbits[i] = 0; mbits[i] = 0; }
 		__syncthreads();
 
