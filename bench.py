@@ -67,13 +67,25 @@ def gen_blocks(torch, dev, n, first_index, chunk=4096):
     return out
 
 
+def usable_cores():
+    """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(blocks_host, budget_s=12.0):
     """oracle ('port') timed on all host cores on a bounded sample; zlib -1 Z_FIXED beside it."""
     import oracle_lib as O
     L = O.lib()
     L.nxo_bench_deflate.restype = C.c_double
     L.nxo_bench_deflate.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     buf = blocks_host.tobytes()
     nmax = len(buf) // BLOCK
     ob = C.c_uint64()
