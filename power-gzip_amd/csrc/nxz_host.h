@@ -1,0 +1,27 @@
+// nxz_host.h -- internal declarations shared by the host-side sources of libnxz_amd.so
+#ifndef NXZ_HOST_H
+#define NXZ_HOST_H
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/nxz_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct nxz_dht_state;
+typedef struct nxz_dht_state nxz_dht_state;
+
+void nxz_fill_zero_lzcounts(uint32_t *ll, uint32_t *d, uint32_t val);
+int  nxz_dhtgen(uint32_t *lhist, int num_lhist, uint32_t *dhist, int num_dhist,
+		uint8_t *dht, int *dht_num_bytes, int *dht_num_valid_bits);
+nxz_dht_state *nxz_dht_begin(void);
+void nxz_dht_end(nxz_dht_state *s);
+nxz_dht_state *nxz_dht_copy(const nxz_dht_state *s);
+void nxz_dht_lookup(nxz_dht_state *s, const uint32_t *counts, long source_bytes,
+		    uint8_t *dht_out, uint32_t *dhtlen_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
