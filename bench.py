@@ -37,6 +37,16 @@ def shard(nblocks_per_rank, rank, world):
     return lo, lo + nblocks_per_rank
 
 
+def reduce_totals(torch, dist, dev, u_bytes, c_bytes, wall, distributed):
+    """The only collectives of the run: SUM of {uncompressed, compressed} bytes, MAX of elapsed."""
+    tot = torch.tensor([u_bytes, c_bytes], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tot[0].item()), float(tot[1].item()), float(tmax.item())
+
+
 def gen_blocks(torch, dev, n, first_index, chunk=4096):
     """Seeded synthetic 64 KiB blocks, generated on the device.
 
@@ -192,13 +202,7 @@ def main():
     u_bytes = float(n) * BLOCK
     c_bytes = float(res["tpbc"].astype(np.float64).sum())
 
-    tot = torch.tensor([u_bytes, c_bytes], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if distributed:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall_max = float(tmax.item())
-    tot_u, tot_c = float(tot[0].item()), float(tot[1].item())
+    tot_u, tot_c, wall_max = reduce_totals(torch, dist, dev, u_bytes, c_bytes, wall, distributed)
 
     if rank == 0:
         verify_sample(eng, pkg, src, dst, res, stride_out)

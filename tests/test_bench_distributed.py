@@ -1,0 +1,59 @@
+"""CPU test of the multi-GPU path of bench.py: world_size 2 over gloo.  The hot path shards by
+independent blocks (no data-path collective); what is distributed is the shard assignment and
+the reduction of {bytes, elapsed} that forms the aggregate GiB/s."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _worker(rank, world, port, q):
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = bench.shard(1000, rank, world)
+    # every rank generates ITS OWN blocks from the global block index (seeded by index)
+    blocks = bench.gen_blocks(torch, torch.device("cpu"), 4, lo, chunk=2)
+    u = float(blocks.numel())
+    c = u / (2.0 + rank)                       # pretend compressed sizes
+    wall = 1.0 + 0.5 * rank                    # rank 1 is the slow one
+    tot_u, tot_c, wall_max = bench.reduce_totals(torch, dist, torch.device("cpu"), u, c, wall, True)
+    q.put((rank, lo, hi, tot_u, tot_c, wall_max, int(blocks[0, :64].sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_reduction():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, u0, c0, w0, s0), (r1, lo1, hi1, u1, c1, w1, s1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 1000, 1000, 2000)            # contiguous, disjoint shards
+    assert u0 == u1 == 2 * 4 * 65536                                 # SUM over ranks
+    assert abs(c0 - (4 * 65536 / 2.0 + 4 * 65536 / 3.0)) < 1e-6 and c0 == c1
+    assert w0 == w1 == 1.5                                           # MAX over ranks
+    assert s0 != s1                                                  # different shards -> different data
+
+
+def test_generator_is_deterministic_per_block_index():
+    import bench
+    a = bench.gen_blocks(torch, torch.device("cpu"), 4, 8, chunk=4)
+    b = bench.gen_blocks(torch, torch.device("cpu"), 4, 8, chunk=4)
+    assert torch.equal(a, b)
+    # makedata-style: second half copies from the first half -> compressible
+    import zlib
+    blk = a[1].numpy().tobytes()
+    assert len(zlib.compress(blk, 1)) < 0.7 * len(blk)
