@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=1 << 20, help="64 KiB blocks per GPU (default 2^20 = 64 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inflate", action="store_true", help="skip the inflate leg (round trip of the output)")
     args = ap.parse_args()
 
     import torch
@@ -199,6 +200,32 @@ def main():
     res = results.cpu().numpy().view(pkg.RESULT_DTYPE)
     if not ((res["cc"] == 0) | (res["cc"] == 64)).all():
         raise SystemExit("engine reported errors: %s" % np.unique(res["cc"]))
+
+    # second leg of the metric (uncompressed bytes OUT of inflate), measured after the timed deflate
+    # region on the same device-resident data: the inflate engine decodes the deflate engine's output
+    # and the result is compared with the source on the device (bit-exact round trip at full size).
+    inflate_info = None
+    if not args.no_inflate:
+        back = torch.empty((n, BLOCK), dtype=torch.uint8, device=dev)
+        jobs2 = eng.jobs_strided(dst, stride_out, res["tpbc"].astype(np.uint32), back, BLOCK, BLOCK)
+        res2 = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        eng.decompress(jobs2, n, results=res2)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(max(1, args.steps // 2)):
+            eng.decompress(jobs2, n, results=res2)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        inf_ms = e0.elapsed_time(e1) / max(1, args.steps // 2)
+        r2 = res2.cpu().numpy().view(pkg.RESULT_DTYPE)
+        ok = bool(torch.equal(back, src)) and bool((r2["cc"] == 0).all()) and bool((r2["crc"] == res["crc"]).all())
+        if not ok:
+            raise SystemExit("ROUND TRIP FAILURE at full size (inflate of the deflate output != source)")
+        inflate_info = {"value": round(float(n) * BLOCK / (inf_ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out",
+                        "ms_per_pass": round(inf_ms, 3), "kernel": "nxzl::inflate_lanes_kernel + cksum_kernel",
+                        "roundtrip_bit_exact": True}
+        del back
     u_bytes = float(n) * BLOCK
     c_bytes = float(res["tpbc"].astype(np.float64).sum())
 
@@ -222,6 +249,8 @@ def main():
                          "kernel": "nxz::deflate_kernel<false,false>", "kernel_ms": round(kern_ms, 3),
                          "algorithmic_bytes_per_launch": u_bytes + c_bytes},
         }
+        if inflate_info:
+            line["inflate"] = inflate_info
         if world == 1 and not args.no_cpu_baseline:
             sample = src[:min(n, 32768)].cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(sample)

@@ -65,6 +65,7 @@ struct nxz_ctx {
 	// batch scratch
 	nxz_dht_prepared_t *d_prepared = nullptr;
 	size_t prepared_cap = 0;
+	uint8_t *d_lanes_ws = nullptr;                // per-lane decode tables of the batched inflate kernel
 };
 
 static std::mutex g_mtx;
@@ -139,6 +140,7 @@ extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 	(void)hipSetDevice(c->device);
 	for (auto &s : c->slots) if (s.stream) slot_free(s);
 	if (c->d_prepared) (void)hipFree(c->d_prepared);
+	if (c->d_lanes_ws) (void)hipFree(c->d_lanes_ws);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	g_ctx[c->device] = nullptr;
 	delete c;
@@ -187,7 +189,21 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 {
 	if (!c) return -EINVAL;
 	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
-	int rc = nxz_launch_inflate(jobs, n, results, dht_io, s);
+	int rc;
+	if (n >= 32) {
+		// many streams: one stream per lane (nxz_inflate_lanes.hip); the table workspace is made once
+		int init = 0;
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			if (!c->d_lanes_ws) {
+				HIPCHK(hipMalloc((void **)&c->d_lanes_ws, nxz_inflate_lanes_workspace()), return -ENOMEM);
+				init = 1;
+			}
+		}
+		rc = nxz_launch_inflate_lanes(jobs, n, results, dht_io, c->d_lanes_ws, init, s);
+	} else {
+		rc = nxz_launch_inflate(jobs, n, results, dht_io, s);
+	}
 	if (rc) { set_err("inflate launch", (hipError_t)rc); return -EIO; }
 	return 0;
 }

@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t gf_xpow8(uint32_t n)   // x^(8n)
 
 // Build the decode tables for `n` symbols with code lengths len[] (wave cooperative).
 template <int FB, typename H>
-__device__ void build(H &h, const uint8_t *len, int n, int lane)
+__device__ __forceinline__ void build(H &h, const uint8_t *len, int n, int lane)
 {
 	for (int i = lane; i < (1 << FB); i += 64) h.fast[i] = 0;
 	if (lane < 16) h.count[lane] = 0;
@@ -107,7 +107,7 @@ struct Bits {
 	uint32_t *stage;
 	int lane;
 
-	__device__ void restage(uint32_t byte)
+	__device__ __forceinline__ void restage(uint32_t byte)
 	{
 		// all lanes: load STAGE bytes starting at byte & ~15
 		uint32_t base = byte & ~15u;
@@ -148,7 +148,38 @@ struct Bits {
 		return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
 	}
 	__device__ __forceinline__ bool have(uint32_t n) const { return pos + n <= total_bits; }
+
+	// ---- register bit buffer for the symbol loop: `bb` holds bits [pos, pos+bc) ----
+	uint64_t bb = 0; uint32_t bc = 0;
+	__device__ __forceinline__ void bb_sync() { bb = 0; bc = 0; }            // after pos was changed by hand
+	__device__ __forceinline__ void bb_fill()                                 // make bc >= 32
+	{
+		if (bc >= 32) return;
+		uint64_t p2 = pos + bc;                                               // first bit not in bb
+		uint32_t byte = (uint32_t)(p2 >> 3);
+		ensure(byte, 12);
+		uint32_t o = byte - stage_base;
+		uint32_t a = stage[o >> 2], b = stage[(o >> 2) + 1];
+		uint32_t v = __builtin_amdgcn_alignbyte(b, a, o & 3);
+		uint32_t sh = (uint32_t)p2 & 7;                                       // bits of that byte already consumed/held
+		// take the (32 - sh) fresh bits of v
+		bb |= (uint64_t)(v >> sh) << bc;
+		bc += 32 - sh;
+	}
+	__device__ __forceinline__ void bb_drop(uint32_t n) { bb >>= n; bc -= n; pos += n; }
 };
+
+// RFC1951 3.2.5 length / distance code parameters, computed
+__device__ __forceinline__ void len_params(uint32_t s, uint32_t &base, uint32_t &extra)
+{
+	extra = s < 8 || s == 28 ? 0 : (s - 4) >> 2;
+	base = s < 8 ? 3 + s : s == 28 ? 258 : ((4 + (s & 3)) << extra) + 3;
+}
+__device__ __forceinline__ void dist_params(uint32_t d, uint32_t &base, uint32_t &extra)
+{
+	extra = d < 4 ? 0 : (d - 2) >> 1;
+	base = d < 4 ? d + 1 : ((2 + (d & 1)) << extra) + 1;
+}
 
 template <int FB, typename H>
 __device__ __forceinline__ int decode_sym(const H &h, uint32_t bits, uint32_t &nbits)
@@ -167,7 +198,7 @@ __device__ __forceinline__ int decode_sym(const H &h, uint32_t bits, uint32_t &n
 	return -2;
 }
 
-__device__ const uint16_t LEN_BASE[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
+__device__ const uint16_t LEN_BASE_UNUSED[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
 	35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
 __device__ const uint8_t LEN_EXTRA[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
 __device__ const uint16_t DIST_BASE[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193,
@@ -176,7 +207,7 @@ __device__ const uint8_t DIST_EXTRA[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 
 
 // Parse a dynamic block header at b.pos (after the 3 header bits).  Returns
 // 0 ok (lens filled, b.pos advanced, *tbits = table bits), 1 out of source, <0 invalid.
-__device__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist, uint32_t &tbits)
+__device__ __forceinline__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist, uint32_t &tbits)
 {
 	const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
 	uint64_t start = b.pos;
@@ -354,6 +385,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	}
 
 	for (;;) {
+		if (state != 2) b.bb_sync();
 		if (state == 0) {
 			uint64_t hdr = b.pos;
 			if (!b.have(3)) { o_sfbt = 0xe; o_subc = (uint32_t)(b.total_bits - hdr); break; }
@@ -419,15 +451,16 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			if (bfinal) { final_eob = true; break; }
 			state = 0;
 		} else {
-			uint64_t sym_start = b.pos;
-			uint32_t sfbt = (btype == 1 ? 0xa : 0xc) | bfinal;
-			uint32_t bits = b.peek(), nb;
-			int sym = decode_sym<LBITS>(sm.hl, bits, nb);
+			const uint64_t sym_start = b.pos;
+			const uint32_t sfbt = (btype == 1 ? 0xa : 0xc) | bfinal;
+			uint32_t nb;
+			b.bb_fill();
+			int sym = decode_sym<LBITS>(sm.hl, (uint32_t)b.bb, nb);
 			if (sym < 0 || !b.have(nb)) {
 				if (!b.have(sym < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total_bits - sym_start); break; }
 				cc = NXZ_CC_MISSING_CODE; break;
 			}
-			b.pos += nb;
+			b.bb_drop(nb);
 			if (sym < 256) {
 				if (out >= cap) { cc = NXZ_CC_TARGET_SPACE; break; }
 				if (lane == 0) sm.win[out & WMASK] = (uint8_t)sym;
@@ -439,24 +472,26 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			} else {
 				sym -= 257;
 				if (sym >= 29) { cc = NXZ_CC_MISSING_CODE; break; }
-				uint32_t eb = LEN_EXTRA[sym];
-				bits = b.peek();
+				uint32_t lbase, eb;
+				len_params((uint32_t)sym, lbase, eb);
+				b.bb_fill();
 				if (!b.have(eb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total_bits - sym_start); break; }
-				uint32_t len = LEN_BASE[sym] + (bits & ((1u << eb) - 1));
-				b.pos += eb;
-				bits = b.peek();
-				int ds = decode_sym<DBITS>(sm.hd, bits, nb);
+				uint32_t len = lbase + ((uint32_t)b.bb & ((1u << eb) - 1));
+				b.bb_drop(eb);
+				b.bb_fill();
+				int ds = decode_sym<DBITS>(sm.hd, (uint32_t)b.bb, nb);
 				if (ds < 0 || !b.have(nb)) {
 					if (!b.have(ds < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total_bits - sym_start); break; }
 					cc = NXZ_CC_INVALID_DIST; break;
 				}
 				if (ds >= 30) { cc = NXZ_CC_INVALID_DIST; break; }
-				b.pos += nb;
-				eb = DIST_EXTRA[ds];
-				bits = b.peek();
+				b.bb_drop(nb);
+				uint32_t dbase;
+				dist_params((uint32_t)ds, dbase, eb);
+				b.bb_fill();
 				if (!b.have(eb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total_bits - sym_start); break; }
-				uint32_t dist = DIST_BASE[ds] + (bits & ((1u << eb) - 1));
-				b.pos += eb;
+				uint32_t dist = dbase + ((uint32_t)b.bb & ((1u << eb) - 1));
+				b.bb_drop(eb);
 				if (dist > out + hist || dist > WIN) { cc = NXZ_CC_INVALID_DIST; break; }
 				if (len > cap - out) { cc = NXZ_CC_TARGET_SPACE; break; }
 				// lane per byte; source pattern repeats with period dist

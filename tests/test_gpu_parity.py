@@ -185,9 +185,10 @@ def _zstreams():
     return out
 
 
-def test_inflate_zlib_streams_bit_exact(eng):
+@pytest.mark.parametrize("copies", [1, 3])          # 31 streams: wave-per-stream kernel; 93: lane-per-stream kernel
+def test_inflate_zlib_streams_bit_exact(eng, copies):
     import torch
-    streams = _zstreams()
+    streams = _zstreams() * copies
     cstride = max(len(c) for _, c in streams) + 64
     cstride = (cstride + 15) & ~15
     ostride = (max(len(d) for d, _ in streams) + 15) & ~15
