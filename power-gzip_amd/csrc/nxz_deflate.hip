@@ -636,76 +636,79 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		if (nxz_debug_buf && blockIdx.x == 0 && (uint32_t)t < nseg)
 			nxz_debug_buf[(tb0 / PTILE) * 65536 + 16384 + t] = myx | (mye << 16) | (entered ? 0x80000000u : 0);
 		// token bitmaps (alias mark/jump, which are dead now) are cleared
-		for (uint32_t i = t; i < PTILE / 32; i += NT) { sbits[i] = 0; mbits[i] = 0; }
+		for (uint32_t i = t; i < PTILE / 32; i += NT) mbits[i] = 0;
 		__syncthreads();
 
 		PROF(7);
 		// ---- parse pass 2: entered segments walk [entry, X[s]) for real ----
+		// The walk assembles the Huffman codes of its tokens right away into a lane-private bit
+		// string held in registers (8 dwords + a partial one; longer ranges fall back to a second
+		// walk in the encode phase), sums their bits for the encoder's prefix sum and feeds the LZ
+		// histogram; match tokens are flagged in a bitmap and get their final length.
+		uint32_t mine = 0;
+		uint32_t lw0 = 0, lw1 = 0, lw2 = 0, lw3 = 0, lw4 = 0, lw5 = 0, lw6 = 0, lw7 = 0, lpart = 0;
+		bool loverflow = false;
 		if (entered) {
 			uint32_t p = mye, lim = myx;
+			uint64_t acc = 0; uint32_t accn = 0, nwords = 0;
+			auto put = [&](uint32_t part, uint32_t nbits) {
+				acc |= (uint64_t)part << accn;
+				accn += nbits;
+				if (accn >= 32) {
+					uint32_t wv = (uint32_t)acc;
+					// predicated register file write: a dynamically indexed array would live in scratch
+					lw0 = nwords == 0 ? wv : lw0; lw1 = nwords == 1 ? wv : lw1; lw2 = nwords == 2 ? wv : lw2; lw3 = nwords == 3 ? wv : lw3;
+					lw4 = nwords == 4 ? wv : lw4; lw5 = nwords == 5 ? wv : lw5; lw6 = nwords == 6 ? wv : lw6; lw7 = nwords == 7 ? wv : lw7;
+					loverflow |= nwords >= 8;
+					nwords++;
+					acc >>= 32; accn -= 32;
+				}
+			};
 			while (p < lim) {
 				bool m;
 				uint32_t l = walk_step(W, p, lim, m);
-				atomicOr(&sbits[p >> 5], 1u << (p & 31));
 				if (m) {
 					atomicOr(&mbits[p >> 5], 1u << (p & 31));
 					mlen[p] = (uint8_t)(l - 3);
-				}
-				p += l;
-			}
-		}
-		__syncthreads();
-		PROF(8);
-
-		// ---- encode ----
-		// Thread t owns the tokens that START in positions [16t, 16t+16).  One workgroup prefix
-		// sum of their bit counts per tile; then the codes are OR-ed into a 8 KiB LDS window
-		// (X/ENTRY/BITS regions) and flushed as coalesced dwords, window after window.
-		{
-			uint32_t *win = (uint32_t *)(lds + OFF_WIN);
-			const uint32_t p0 = (uint32_t)t * PSEG;
-			uint32_t sb = 0, mb = 0;
-			if (p0 < tn) {
-				sb = (sbits[p0 >> 5] >> (p0 & 31)) & 0xffffu;
-				mb = (mbits[p0 >> 5] >> (p0 & 31)) & 0xffffu;
-			}
-			auto token = [&](uint32_t p, bool ismatch, uint64_t &v, uint32_t &nb, bool count) {
-				if (ismatch) {
-					uint32_t l = mlen[p];                       // len-3
-					uint32_t d = cand[p];                       // dist-1
-					uint32_t le = l < 8 ? 0 : (29 - __builtin_clz(l));
-					uint32_t ls = l == 255 ? 28 : (le << 2) + (l >> le);
-					if (l == 255) le = 0;
+					uint32_t l3 = l - 3, d = cand[p];
+					uint32_t le = l3 < 8 ? 0 : (29 - __builtin_clz(l3));
+					uint32_t ls = l3 == 255 ? 28 : (le << 2) + (l3 >> le);
+					if (l3 == 255) le = 0;
 					uint32_t de = d < 4 ? 0 : (30 - __builtin_clz(d));
 					uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
 					uint32_t lt = lltab[257 + ls], dt = dtab[ds];
 					uint32_t ll = lt >> 16, dl = dt >> 16;
 					if (DHT && (ll == 0 || dl == 0)) misc[M_ERR] = NXZ_CC_MISSING_CODE;
-					v = lt & 0xffff;
-					nb = ll;
-					v |= (uint64_t)(l & ((1u << le) - 1)) << nb; nb += le;
-					v |= (uint64_t)(dt & 0xffff) << nb; nb += dl;
-					v |= (uint64_t)(d & ((1u << de) - 1)) << nb; nb += de;
-					if (COUNT && count) { atomicAdd(&hist[257 + ls], 1u); atomicAdd(&hist[286 + ds], 1u); }
+					put((lt & 0xffff) | ((l3 & ((1u << le) - 1)) << ll), ll + le);               // <= 20 bits
+					put((dt & 0xffff) | ((d & ((1u << de) - 1)) << dl), dl + de);                // <= 28 bits
+					mine += ll + le + dl + de;
+					if (COUNT) { atomicAdd(&hist[257 + ls], 1u); atomicAdd(&hist[286 + ds], 1u); }
 				} else {
 					uint32_t byte = lds[OFF_IN + h + tb0 + p];
 					uint32_t lt = lltab[byte];
 					if (DHT && (lt >> 16) == 0) misc[M_ERR] = NXZ_CC_MISSING_CODE;
-					v = lt & 0xffff; nb = lt >> 16;
-					if (COUNT && count) atomicAdd(&hist[byte], 1u);
+					put(lt & 0xffff, lt >> 16);
+					mine += lt >> 16;
+					if (COUNT) atomicAdd(&hist[byte], 1u);
 				}
-			};
-			uint32_t mine = 0;
-			for (uint32_t m = sb; m; m &= m - 1) {
-				uint32_t k = (uint32_t)__builtin_ctz(m);
-				uint64_t v; uint32_t nb;
-				token(p0 + k, (mb >> k) & 1, v, nb, true);
-				mine += nb;
+				p += l;
 			}
-			uint32_t incl = wave_incl_scan(mine, lane);
-			if (lane == 63) scan[wave] = incl;
-			__syncthreads();                                   // also: X/ENTRY are dead from here on
-			PROF(12);
+			lpart = (uint32_t)acc;
+			loverflow |= nwords > 8 || (nwords == 8 && accn != 0);
+		}
+		uint32_t incl = wave_incl_scan(mine, lane);
+		if (lane == 63) scan[wave] = incl;
+		__syncthreads();                                       // X/ENTRY are dead from here on
+		PROF(8);
+
+		// ---- encode ----
+		// An entered lane owns the tokens of its range [entry, X[s]); the workgroup prefix sum of
+		// the bit counts gives it a bit offset.  Codes are assembled in a 64-bit register and leave
+		// as whole dwords: plain stores for the dwords a lane owns entirely, atomicOr for the shared
+		// first/last ones.  The 8 KiB LDS window (X/ENTRY/BITS regions) is flushed as coalesced
+		// dwords, window after window.
+		{
+			uint32_t *win = (uint32_t *)(lds + OFF_WIN);
 			uint32_t carry = misc[M_CARRY_BITS], wordbase = misc[M_WORDBASE], carryword = misc[M_CARRY_WORD];
 			uint32_t woff = 0, tot = 0;
 #pragma unroll
@@ -716,25 +719,76 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			}
 			const uint32_t total = carry + tot;                // bits of this tile's stream incl. the carried partial word
 			uint32_t bitpos = carry + woff + incl - mine;      // my first token, in that stream
+			const uint32_t bend = bitpos + mine;
 			for (uint32_t i = t; i < WWORDS + 16; i += NT) win[i] = (i == 0) ? carryword : 0;
 			__syncthreads();
 			PROF(13);
-			uint32_t rest = sb;
+			uint32_t p = mye;
+			const uint32_t plim = (entered && loverflow) ? myx : 0;
+			bool done = !entered || loverflow || mine == 0;
 			for (uint32_t wlo = 0;; wlo += WWORDS * 32) {
 				const uint32_t whi = wlo + WWORDS * 32;
-				while (rest && bitpos < whi) {
-					uint32_t k = (uint32_t)__builtin_ctz(rest);
-					rest &= rest - 1;
-					uint64_t v; uint32_t nb;
-					token(p0 + k, (mb >> k) & 1, v, nb, false);
-					uint32_t rel = bitpos - wlo, wi = rel >> 5, sh = rel & 31;
-					uint64_t lo = v << sh;
-					atomicOr(&win[wi], (uint32_t)lo);
-					uint32_t mid = (uint32_t)(lo >> 32);
-					if (mid) atomicOr(&win[wi + 1], mid);
-					uint32_t hi2 = sh ? (uint32_t)(v >> (64 - sh)) : 0;
-					if (hi2) atomicOr(&win[wi + 2], hi2);
-					bitpos += nb;
+				if (!done && bitpos < whi) {
+					// my whole range (<= 8 dwords + partial) goes out in one go, shifted to its bit offset
+					const uint32_t sh = bitpos & 31, w0i = (bitpos - wlo) >> 5;
+					const uint32_t nfull = mine >> 5, npart = mine & 31;            // source dwords
+					uint32_t prev = 0;
+#pragma unroll
+					for (uint32_t k = 0; k <= 9; k++) {
+						uint32_t cur = k == 0 ? lw0 : k == 1 ? lw1 : k == 2 ? lw2 : k == 3 ? lw3 : k == 4 ? lw4 : k == 5 ? lw5
+							     : k == 6 ? lw6 : k == 7 ? lw7 : 0;
+						if (k == nfull) cur = npart ? lpart & ((1u << npart) - 1) : 0;
+						if (k > nfull) cur = 0;
+						uint32_t o = sh ? (cur << sh) | (prev >> (32 - sh)) : cur;
+						prev = cur;
+						// output dword k covers stream bits [32*(w0i+k)+wlo, +32)
+						const uint32_t wbit = wlo + 32 * (w0i + k);
+						if (wbit < bend) {
+							if (k == 0 || wbit + 32 > bend) atomicOr(&win[w0i + k], o);
+							else win[w0i + k] = o;
+						}
+					}
+					done = true;
+				}
+				if (p < plim && bitpos < whi) {
+					// fallback for ranges that did not fit the register bit string: second walk
+					uint64_t acc = 0;
+					uint32_t accn = (bitpos - wlo) & 31, accw = (bitpos - wlo) >> 5;
+					bool firstword = true;
+					auto put = [&](uint32_t part, uint32_t nbits) {
+						acc |= (uint64_t)part << accn;
+						accn += nbits;
+						if (accn >= 32) {
+							if (firstword || wlo + 32 * accw + 32 > bend) atomicOr(&win[accw], (uint32_t)acc);
+							else win[accw] = (uint32_t)acc;
+							firstword = false;
+							acc >>= 32; accn -= 32; accw++;
+						}
+					};
+					while (p < plim && bitpos < whi) {
+						uint32_t adv;
+						if (mbits[p >> 5] >> (p & 31) & 1) {
+							uint32_t l = mlen[p], d = cand[p];            // len-3, dist-1
+							uint32_t le = l < 8 ? 0 : (29 - __builtin_clz(l));
+							uint32_t ls = l == 255 ? 28 : (le << 2) + (l >> le);
+							if (l == 255) le = 0;
+							uint32_t de = d < 4 ? 0 : (30 - __builtin_clz(d));
+							uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
+							uint32_t lt = lltab[257 + ls], dt = dtab[ds];
+							uint32_t ll = lt >> 16, dl = dt >> 16;
+							put((lt & 0xffff) | ((l & ((1u << le) - 1)) << ll), ll + le);
+							put((dt & 0xffff) | ((d & ((1u << de) - 1)) << dl), dl + de);
+							bitpos += ll + le + dl + de;
+							adv = l + 3;
+						} else {
+							uint32_t lt = lltab[lds[OFF_IN + h + tb0 + p]];
+							put(lt & 0xffff, lt >> 16);
+							bitpos += lt >> 16;
+							adv = 1;
+						}
+						p += adv;
+					}
+					if (accn) atomicOr(&win[accw], (uint32_t)acc);
 				}
 				__syncthreads();
 				PROF(14);
@@ -744,7 +798,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					if (wordbase + i < cap_words) dstw[wordbase + i] = win[i];
 				// what stays: the partial last dword, or the spill of tokens that crossed the window end
 				uint32_t keep = 0;
-				if (t < 3) keep = lastw ? (t == 0 ? win[nw] : 0) : win[WWORDS + t];
+				if (t < 16) keep = lastw ? (t == 0 ? win[nw] : 0) : win[WWORDS + t];
 				__syncthreads();
 				wordbase += nw;
 				if (lastw) {
@@ -756,7 +810,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					}
 					break;
 				}
-				for (uint32_t i = t; i < WWORDS + 16; i += NT) win[i] = (i < 3) ? keep : 0;
+				for (uint32_t i = t; i < WWORDS + 16; i += NT) win[i] = (i < 16) ? keep : 0;
 				__syncthreads();
 			}
 			__syncthreads();
