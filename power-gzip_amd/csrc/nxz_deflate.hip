@@ -400,11 +400,19 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		const uint32_t tnpad = (tn + 511) & ~511u;
 		for (uint32_t i = t; i < PTILE / 32; i += NT) sbits[i] = 0;     // capped-position bitmap of the match phase
 		if (t == 0) { misc[M_PROGRESS] = 0; misc[M_TICKET] = 0; }
-#pragma unroll 4
-		for (uint32_t i = t; i < tnpad; i += NT) {
-			uint32_t r = h + tb0 + i;
-			uint32_t v = lds_ld32(inw, r < end ? r : 0);
-			cand[i] = (i < tn && r + 4 <= end) ? (uint16_t)(hash4(v) * 4) : (uint16_t)(HSIZE * 4);
+		// Within a 512-position piece the slots are stored transposed -- lane l keeps its 8 steps
+		// (positions l, l+64, ..) in one 16-byte group -- so that the chain wave moves a piece's
+		// slot offsets and results with one ds_read_b128 / ds_write_b128 per lane.
+		const uint32_t npieces = tnpad >> 9;
+		for (uint32_t piece = wave; piece < npieces; piece += NT / 64) {
+			uint32_t o[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				uint32_t i = (piece << 9) + (u << 6) + lane, r = h + tb0 + i;
+				uint32_t v = lds_ld32(inw, r < end ? r : 0);
+				o[u] = (i < tn && r + 4 <= end) ? hash4(v) * 4 : HSIZE * 4;
+			}
+			((uint4 *)cand)[(piece << 6) + lane] = make_uint4(o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | o[5] << 16, o[6] | o[7] << 16);
 		}
 		__syncthreads();
 		PROF(3);
@@ -414,32 +422,31 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// 512-position pieces and publishes how many are done; all waves (wave 0 too, once the chain
 		// is finished) draw piece numbers from a ticket counter and run the match stages on a piece
 		// as soon as it is published, so the other 15 waves do not idle behind the chain.
-		const uint32_t npieces = tnpad >> 9;
 		if (wave == 0) {
-			// ~7 instructions per 64-position step: load the slot offset, look the slot up, insert,
-			// store the candidate position (16 bit; an empty slot gives 0xffff which no position
-			// can use).  The trip count is wave-uniform and 8 steps are issued back to back: the LDS
-			// executes one wave's operations in order, so lookup(k+1) only has to be ISSUED after
-			// insert(k); results are consumed afterwards.
-			constexpr int U = 8;
+			// ~5 instructions per 64-position step: look the slot up, insert; the slot offsets come in
+			// and the candidate positions (16 bit; an empty slot gives 0xffff which no position can
+			// use) go out 8 steps at a time.  The trip count is wave-uniform and the 8 steps are
+			// issued back to back: the LDS executes one wave's operations in order, so lookup(k+1)
+			// only has to be ISSUED after insert(k); results are consumed afterwards.
 			const uint8_t *headb = (const uint8_t *)head;
 			__builtin_amdgcn_s_setprio(3);                    // the chain is the critical path of this phase
-			for (uint32_t base = 0; base < tnpad; base += 64 * U) {
-				uint32_t off[U], old[U];
+			for (uint32_t piece = 0; piece < npieces; piece++) {
+				const uint4 pk = ((const uint4 *)cand)[(piece << 6) + lane];
+				const uint32_t off[8] = { pk.x & 0xffff, pk.x >> 16, pk.y & 0xffff, pk.y >> 16, pk.z & 0xffff, pk.z >> 16, pk.w & 0xffff, pk.w >> 16 };
+				uint32_t old[8];
 #pragma unroll
-				for (int u = 0; u < U; u++) off[u] = cand[base + 64 * u + lane];
-#pragma unroll
-				for (int u = 0; u < U; u++) {
+				for (int u = 0; u < 8; u++) {
 					uint32_t *slot = (uint32_t *)(headb + off[u]);
 					old[u] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					__builtin_amdgcn_wave_barrier();
-					atomicMax(slot, h + tb0 + base + 64 * u + lane + 1);
+					atomicMax(slot, h + tb0 + (piece << 9) + 64 * u + lane + 1);
 					__builtin_amdgcn_wave_barrier();
 				}
 #pragma unroll
-				for (int u = 0; u < U; u++) cand[base + 64 * u + lane] = (uint16_t)(old[u] - 1);
+				for (int u = 0; u < 8; u++) old[u] = (old[u] - 1) & 0xffff;
+				((uint4 *)cand)[(piece << 6) + lane] = make_uint4(old[0] | old[1] << 16, old[2] | old[3] << 16, old[4] | old[5] << 16, old[6] | old[7] << 16);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], (base >> 9) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 			__builtin_amdgcn_s_setprio(0);
 		}
@@ -473,8 +480,12 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			while (__hip_atomic_load(&misc[M_PROGRESS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= piece)
 				__builtin_amdgcn_s_sleep(4);
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			const uint4 pk = ((const uint4 *)cand)[(piece << 6) + lane];
+			const uint64_t qlo = pk.x | ((uint64_t)pk.y << 32), qhi = pk.z | ((uint64_t)pk.w << 32);
+			__builtin_amdgcn_wave_barrier();                  // all 8 candidates are in registers before cand[] is rewritten
 			for (uint32_t i0 = piece << 9; i0 < (piece << 9) + 512 && i0 < tn; i0 += 64) {
-				const uint32_t i = i0 + lane;
+				const uint32_t i = i0 + lane, ustep = (i0 >> 6) & 7;
+				const uint32_t qcand = (uint32_t)((ustep < 4 ? qlo : qhi) >> (16 * (ustep & 3))) & 0xffffu;
 				const uint32_t r = h + tb0 + i;
 				const bool ok = i < tn && r + 4 <= end;
 				// the dword that holds r, one before and two after: bytes r-1 .. r+7 in registers.
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				const uint32_t vm1 = ro ? __builtin_amdgcn_alignbyte(d1, d0, ro - 1) : __builtin_amdgcn_alignbyte(d0, dm1, 3);
 				const uint32_t v3 = ro ? __builtin_amdgcn_alignbyte(d2, d1, ro - 1) : __builtin_amdgcn_alignbyte(d1, d0, 3);
 				const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-				uint32_t q = ok ? (uint32_t)cand[i] : 0xffffu;
+				uint32_t q = ok ? qcand : 0xffffu;
 				const bool qok = ok && q < r && r - q <= WINDOW;
 				if (!qok) q = 0;
 				const uint32_t qa = q >> 2, u0 = inw[qa], u1 = inw[qa + 1], u2 = inw[qa + 2];
@@ -510,6 +521,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					mlen[i] = len >= 4 ? (uint8_t)(len - 3) : 0;
 					cand[i] = len >= 4 ? (uint16_t)c : (uint16_t)NOHASH;
 				}
+				if (needs) cand[i] = (uint16_t)qcand;             // stage 2 reads the candidate from its natural slot
 				unsigned long long m = __ballot(needs);
 				if (m) {
 					if (needs) queue[qcnt + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
