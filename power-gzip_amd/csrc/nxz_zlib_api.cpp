@@ -1,0 +1,201 @@
+// nxz_zlib_api.cpp -- the unprefixed zlib entry points (LD_PRELOAD drop-in), dispatching per
+// stream between the MI355X engine (nx_*, libnxz_amd.so) and software zlib.
+//
+// Counterpart of the reference's dispatch layer: the unprefixed functions at the bottom of
+// lib/nx_deflate.c:2236-2580, lib/nx_inflate.c:1982-2364, lib/nx_compress.c:77-117,
+// lib/nx_uncompr.c:90-149 and the dlopen trampolines of lib/sw_zlib.c:57-336.
+//   NX_GZIP_TYPE_SELECTOR = 0 auto (default), 1 software zlib, 2 engine   (lib/nx_zlib.c:1067-1088)
+// Auto: one-shot calls of <= 1024 bytes go to zlib (lib/nx_zlib.h:88-89); everything goes to zlib
+// when no engine can be opened.  A stream stays with the backend that initialised it; which one
+// that was is read from the state tag, so no stream map is needed (the reference keeps one for
+// its switchable AUTO streams, lib/nx_map.c).
+#include <zlib.h>
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include "../../include/nxz_engine.h"
+#include "../../include/nxz_zlib.h"
+
+namespace {
+
+enum { MODE_AUTO = 0, MODE_SW = 1, MODE_NX = 2 };
+constexpr uint64_t MAGIC_DEF = 0x6e787a2d64656621ull, MAGIC_INF = 0x6e787a2d696e6621ull;   // nxz_stream.cpp
+
+struct Sw {
+	void *h = nullptr;
+#define SWF(ret, name, args) ret (*name) args = nullptr;
+	SWF(const char *, zlibVersion, (void))
+	SWF(int, deflateInit_, (z_streamp, int, const char *, int))
+	SWF(int, deflateInit2_, (z_streamp, int, int, int, int, int, const char *, int))
+	SWF(int, deflate, (z_streamp, int))
+	SWF(int, deflateEnd, (z_streamp))
+	SWF(int, deflateReset, (z_streamp))
+	SWF(int, deflateResetKeep, (z_streamp))
+	SWF(uLong, deflateBound, (z_streamp, uLong))
+	SWF(int, deflateSetHeader, (z_streamp, gz_headerp))
+	SWF(int, deflateSetDictionary, (z_streamp, const Bytef *, uInt))
+	SWF(int, deflateCopy, (z_streamp, z_streamp))
+	SWF(int, deflateParams, (z_streamp, int, int))
+	SWF(int, inflateInit_, (z_streamp, const char *, int))
+	SWF(int, inflateInit2_, (z_streamp, int, const char *, int))
+	SWF(int, inflate, (z_streamp, int))
+	SWF(int, inflateEnd, (z_streamp))
+	SWF(int, inflateReset, (z_streamp))
+	SWF(int, inflateReset2, (z_streamp, int))
+	SWF(int, inflateSetDictionary, (z_streamp, const Bytef *, uInt))
+	SWF(int, inflateGetHeader, (z_streamp, gz_headerp))
+	SWF(int, inflateSyncPoint, (z_streamp))
+	SWF(int, inflateCopy, (z_streamp, z_streamp))
+	SWF(int, compress, (Bytef *, uLongf *, const Bytef *, uLong))
+	SWF(int, compress2, (Bytef *, uLongf *, const Bytef *, uLong, int))
+	SWF(uLong, compressBound, (uLong))
+	SWF(int, uncompress, (Bytef *, uLongf *, const Bytef *, uLong))
+	SWF(int, uncompress2, (Bytef *, uLongf *, const Bytef *, uLong *))
+	SWF(uLong, crc32, (uLong, const Bytef *, uInt))
+	SWF(uLong, adler32, (uLong, const Bytef *, uInt))
+	SWF(uLong, crc32_combine, (uLong, uLong, z_off_t))
+	SWF(uLong, adler32_combine, (uLong, uLong, z_off_t))
+#undef SWF
+} sw;
+
+int g_mode = MODE_AUTO;
+bool g_engine = false;
+std::once_flag g_once;
+
+void init_once()
+{
+	const char *m = getenv("NX_GZIP_TYPE_SELECTOR");
+	if (m) g_mode = atoi(m) == 1 ? MODE_SW : atoi(m) == 2 ? MODE_NX : MODE_AUTO;
+	const char *path = getenv("NXZ_ZLIB_PATH");
+	// RTLD_DEEPBIND: the real zlib must bind its own internal calls to itself, not to this shim
+	sw.h = dlopen(path ? path : "libz.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+	if (sw.h) {
+#define REG(name) *(void **)(&sw.name) = dlsym(sw.h, #name);
+		REG(zlibVersion) REG(deflateInit_) REG(deflateInit2_) REG(deflate) REG(deflateEnd) REG(deflateReset)
+		REG(deflateResetKeep) REG(deflateBound) REG(deflateSetHeader) REG(deflateSetDictionary) REG(deflateCopy)
+		REG(deflateParams) REG(inflateInit_) REG(inflateInit2_) REG(inflate) REG(inflateEnd) REG(inflateReset)
+		REG(inflateReset2) REG(inflateSetDictionary) REG(inflateGetHeader) REG(inflateSyncPoint) REG(inflateCopy)
+		REG(compress) REG(compress2) REG(compressBound) REG(uncompress) REG(uncompress2) REG(crc32) REG(adler32)
+		REG(crc32_combine) REG(adler32_combine)
+#undef REG
+	} else if (g_mode != MODE_NX) {
+		fprintf(stderr, "nxz: cannot dlopen software zlib (%s): forcing engine mode\n", dlerror());
+		g_mode = MODE_NX;                                  // lib/nx_zlib.c:1357-1360
+	}
+	if (g_mode != MODE_SW) {
+		nxz_dev_t probe;
+		memset(&probe, 0, sizeof(probe));
+		if (nx_function_begin(NXZ_FUNC_COMP_GZIP, -1, &probe) == 0) { g_engine = true; nx_function_end(&probe); }
+		else if (g_mode == MODE_NX) fprintf(stderr, "nxz: NX_GZIP_TYPE_SELECTOR=2 but no engine is available\n");
+	}
+}
+
+inline void init() { std::call_once(g_once, init_once); }
+inline bool want_nx() { init(); return g_mode == MODE_NX || (g_mode == MODE_AUTO && g_engine); }
+inline bool is_nx(z_streamp s, uint64_t magic) { return s && s->state && *(const uint64_t *)s->state == magic; }
+
+} // namespace
+
+#define EXPORT extern "C" __attribute__((visibility("default")))
+
+EXPORT const char *zlibVersion(void) { init(); return sw.zlibVersion ? sw.zlibVersion() : ZLIB_VERSION; }
+
+// ---- deflate ----
+EXPORT int deflateInit2_(z_streamp s, int level, int method, int wbits, int memLevel, int strategy, const char *ver, int size)
+{
+	if (want_nx()) {
+		int rc = nx_deflateInit2_(s, level, method, wbits, memLevel, strategy, ver, size);
+		// parameters the engine does not take (small windows, Z_FILTERED, ...) go to software in auto mode
+		if (rc == Z_OK || g_mode == MODE_NX || !sw.deflateInit2_) return rc;
+	}
+	return sw.deflateInit2_ ? sw.deflateInit2_(s, level, method, wbits, memLevel, strategy, ver, size) : Z_STREAM_ERROR;
+}
+EXPORT int deflateInit_(z_streamp s, int level, const char *ver, int size)
+{
+	return deflateInit2_(s, level, Z_DEFLATED, 15, 8, Z_DEFAULT_STRATEGY, ver, size);
+}
+#define DISPATCH_DEF(call_nx, call_sw, err) do { init(); if (is_nx(s, MAGIC_DEF)) return call_nx; return sw.deflate ? call_sw : err; } while (0)
+EXPORT int deflate(z_streamp s, int flush) { DISPATCH_DEF(nx_deflate(s, flush), sw.deflate(s, flush), Z_STREAM_ERROR); }
+EXPORT int deflateEnd(z_streamp s) { DISPATCH_DEF(nx_deflateEnd(s), sw.deflateEnd(s), Z_STREAM_ERROR); }
+EXPORT int deflateReset(z_streamp s) { DISPATCH_DEF(nx_deflateReset(s), sw.deflateReset(s), Z_STREAM_ERROR); }
+EXPORT int deflateResetKeep(z_streamp s) { DISPATCH_DEF(nx_deflateResetKeep(s), sw.deflateResetKeep(s), Z_STREAM_ERROR); }
+EXPORT int deflateSetHeader(z_streamp s, gz_headerp h) { DISPATCH_DEF(nx_deflateSetHeader(s, h), sw.deflateSetHeader(s, h), Z_STREAM_ERROR); }
+EXPORT int deflateSetDictionary(z_streamp s, const Bytef *d, uInt n) { DISPATCH_DEF(nx_deflateSetDictionary(s, d, n), sw.deflateSetDictionary(s, d, n), Z_STREAM_ERROR); }
+EXPORT int deflateParams(z_streamp s, int level, int strategy)
+{
+	init();
+	if (is_nx(s, MAGIC_DEF)) return Z_OK;                     // the engine has one speed; accepted and ignored
+	return sw.deflateParams ? sw.deflateParams(s, level, strategy) : Z_STREAM_ERROR;
+}
+EXPORT int deflateCopy(z_streamp d, z_streamp s) { DISPATCH_DEF(nx_deflateCopy(d, s), sw.deflateCopy(d, s), Z_STREAM_ERROR); }
+EXPORT uLong deflateBound(z_streamp s, uLong n)
+{
+	init();
+	if (is_nx(s, MAGIC_DEF)) return nx_deflateBound(s, n);
+	uLong a = nx_deflateBound(nullptr, n), b = sw.deflateBound ? sw.deflateBound(s, n) : 0;   // lib/nx_compress.c:113-117
+	return a > b ? a : b;
+}
+
+// ---- inflate ----
+EXPORT int inflateInit2_(z_streamp s, int wbits, const char *ver, int size)
+{
+	if (want_nx()) {
+		int rc = nx_inflateInit2_(s, wbits, ver, size);
+		if (rc == Z_OK || g_mode == MODE_NX || !sw.inflateInit2_) return rc;
+	}
+	return sw.inflateInit2_ ? sw.inflateInit2_(s, wbits, ver, size) : Z_STREAM_ERROR;
+}
+EXPORT int inflateInit_(z_streamp s, const char *ver, int size) { return inflateInit2_(s, 15, ver, size); }
+#define DISPATCH_INF(call_nx, call_sw) do { init(); if (is_nx(s, MAGIC_INF)) return call_nx; return sw.inflate ? call_sw : Z_STREAM_ERROR; } while (0)
+EXPORT int inflate(z_streamp s, int flush) { DISPATCH_INF(nx_inflate(s, flush), sw.inflate(s, flush)); }
+EXPORT int inflateEnd(z_streamp s) { DISPATCH_INF(nx_inflateEnd(s), sw.inflateEnd(s)); }
+EXPORT int inflateReset(z_streamp s) { DISPATCH_INF(nx_inflateReset(s), sw.inflateReset(s)); }
+EXPORT int inflateReset2(z_streamp s, int w) { DISPATCH_INF(nx_inflateReset2(s, w), sw.inflateReset2(s, w)); }
+EXPORT int inflateSetDictionary(z_streamp s, const Bytef *d, uInt n) { DISPATCH_INF(nx_inflateSetDictionary(s, d, n), sw.inflateSetDictionary(s, d, n)); }
+EXPORT int inflateGetHeader(z_streamp s, gz_headerp h) { DISPATCH_INF(nx_inflateGetHeader(s, h), sw.inflateGetHeader(s, h)); }
+EXPORT int inflateSyncPoint(z_streamp s) { DISPATCH_INF(nx_inflateSyncPoint(s), (sw.inflateSyncPoint ? sw.inflateSyncPoint(s) : Z_STREAM_ERROR)); }
+EXPORT int inflateCopy(z_streamp d, z_streamp s)
+{
+	init();
+	if (is_nx(s, MAGIC_INF)) return Z_STREAM_ERROR;            // not offered by the engine layer yet
+	return sw.inflateCopy ? sw.inflateCopy(d, s) : Z_STREAM_ERROR;
+}
+
+// ---- one-shot (lib/nx_compress.c:77-117, lib/nx_uncompr.c:90-149) ----
+EXPORT int compress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen, int level)
+{
+	init();
+	bool nx = g_mode == MODE_NX || (g_mode == MODE_AUTO && g_engine && sourceLen > 1024);
+	if (nx) return nx_compress2(dest, destLen, source, sourceLen, level);
+	return sw.compress2 ? sw.compress2(dest, destLen, source, sourceLen, level) : Z_STREAM_ERROR;
+}
+EXPORT int compress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen)
+{
+	return compress2(dest, destLen, source, sourceLen, Z_DEFAULT_COMPRESSION);
+}
+EXPORT uLong compressBound(uLong n)
+{
+	init();
+	uLong a = nx_compressBound(n), b = sw.compressBound ? sw.compressBound(n) : 0;
+	return a > b ? a : b;
+}
+EXPORT int uncompress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong *sourceLen)
+{
+	init();
+	bool nx = g_mode == MODE_NX || (g_mode == MODE_AUTO && g_engine && *sourceLen > 1024);
+	if (nx) return nx_uncompress2(dest, destLen, source, sourceLen);
+	if (sw.uncompress2) return sw.uncompress2(dest, destLen, source, sourceLen);
+	return sw.uncompress ? sw.uncompress(dest, destLen, source, *sourceLen) : Z_STREAM_ERROR;
+}
+EXPORT int uncompress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen)
+{
+	return uncompress2(dest, destLen, source, &sourceLen);
+}
+
+// ---- checksums: host code either way (lib/nx_crc.c:437-446 routes crc32 to the vector CRC) ----
+EXPORT uLong crc32(uLong crc, const Bytef *buf, uInt len) { return nx_crc32(crc, buf, len); }
+EXPORT uLong adler32(uLong adler, const Bytef *buf, uInt len) { return nx_adler32(adler, buf, len); }
+EXPORT uLong crc32_combine(uLong a, uLong b, z_off_t n) { return nx_crc32_combine(a, b, n); }
+EXPORT uLong adler32_combine(uLong a, uLong b, z_off_t n) { return nx_adler32_combine(a, b, n); }

@@ -1,0 +1,98 @@
+"""BASELINE configs[0] and the LD_PRELOAD drop-in: the unprefixed zlib API of libnxz_preload.so.
+CPU: software mode (NX_GZIP_TYPE_SELECTOR=1) and auto mode without a GPU both end in system zlib
+(the reference's sw_zlib.c path), so the bytes must equal zlib's.  GPU: engine mode."""
+import os
+import subprocess
+import sys
+import zlib
+
+import pytest
+
+from datagen import make_block, ALICE_LIKE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRELOAD = os.path.join(ROOT, "power-gzip_amd", "libnxz_preload.so")
+
+ONE_SHOT = r'''
+import ctypes as C, sys, zlib
+L = C.CDLL(sys.argv[1])
+L.compressBound.restype = C.c_ulong; L.compressBound.argtypes = [C.c_ulong]
+L.compress.argtypes = [C.c_char_p, C.POINTER(C.c_ulong), C.c_char_p, C.c_ulong]
+L.uncompress.argtypes = [C.c_char_p, C.POINTER(C.c_ulong), C.c_char_p, C.c_ulong]
+data = open(sys.argv[2], "rb").read()
+n = L.compressBound(len(data)); dst = C.create_string_buffer(n); dl = C.c_ulong(n)
+assert L.compress(dst, C.byref(dl), data, len(data)) == 0
+comp = dst.raw[:dl.value]
+back = C.create_string_buffer(len(data)); bl = C.c_ulong(len(data))
+assert L.uncompress(back, C.byref(bl), comp, len(comp)) == 0 and back.raw[:bl.value] == data
+assert zlib.decompress(comp) == data
+sys.stdout.write(comp.hex())
+'''
+
+
+def run_one_shot(tmp_path, data, selector):
+    f = tmp_path / "in.bin"
+    f.write_bytes(data)
+    env = dict(os.environ, NX_GZIP_TYPE_SELECTOR=str(selector))
+    out = subprocess.run([sys.executable, "-c", ONE_SHOT, PRELOAD, str(f)], env=env, check=True, capture_output=True, text=True)
+    return bytes.fromhex(out.stdout)
+
+
+def test_config1_one_shot_software_path_equals_zlib(tmp_path):
+    # nx_compress()/nx_uncompress() one-shot on alice29-like text through the CPU fallback: the
+    # output is identical to system zlib compress2(level -1) because it IS zlib
+    data = ALICE_LIKE(152089)
+    assert run_one_shot(tmp_path, data, 1) == zlib.compress(data, -1)
+
+
+def test_auto_mode_without_engine_falls_back_to_zlib(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: auto mode would use the engine")
+    data = make_block("lz", 50000, 3)
+    assert run_one_shot(tmp_path, data, 0) == zlib.compress(data, -1)
+
+
+PY_ZLIB = r'''
+import zlib, sys
+data = open(sys.argv[1], "rb").read()
+c = zlib.compress(data, 6)
+assert zlib.decompress(c) == data
+co = zlib.compressobj(6, zlib.DEFLATED, 31)
+g = co.compress(data[:70000]) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(data[70000:]) + co.flush()
+do = zlib.decompressobj(47)
+assert do.decompress(g) == data and do.eof
+assert zlib.crc32(data) == int(sys.argv[2]) and zlib.adler32(data) == int(sys.argv[3])
+sys.stdout.write("%d %d" % (len(c), len(g)))
+'''
+
+
+def _ld_preload_python(tmp_path, selector):
+    data = ALICE_LIKE(200000, seed=5)
+    f = tmp_path / "in.bin"
+    f.write_bytes(data)
+    env = dict(os.environ, NX_GZIP_TYPE_SELECTOR=str(selector), LD_PRELOAD=PRELOAD)
+    out = subprocess.run([sys.executable, "-c", PY_ZLIB, str(f), str(zlib.crc32(data)), str(zlib.adler32(data))],
+                         env=env, check=True, capture_output=True, text=True)
+    return [int(x) for x in out.stdout.split()], data
+
+
+def test_ld_preload_software_mode(tmp_path):
+    # README.md:15-18 of the reference: LD_PRELOAD=libnxz.so application
+    (n1, n2), data = _ld_preload_python(tmp_path, 1)
+    assert n1 == len(zlib.compress(data, 6))
+
+
+@pytest.mark.gpu
+def test_ld_preload_engine_mode_python_zlib(tmp_path):
+    # an unmodified application (CPython's zlib module) running on the MI355X engine
+    (n1, n2), data = _ld_preload_python(tmp_path, 2)
+    assert n1 < len(data) / 1.8 and n2 < len(data) / 1.8
+
+
+@pytest.mark.gpu
+def test_one_shot_engine_mode(tmp_path):
+    data = ALICE_LIKE(152089)
+    comp = run_one_shot(tmp_path, data, 2)
+    assert comp[:2] == b"\x78\x01" and zlib.decompress(comp) == data      # FLEVEL 0 header of the engine layer (Q3)
+    assert len(comp) < 0.55 * len(data)
