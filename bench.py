@@ -77,6 +77,23 @@ def gen_blocks(torch, dev, n, first_index, chunk=4096):
     return out
 
 
+def pmc_traffic(n_blocks):
+    """HBM bytes per launch from the committed PMC pass (profiles/*pmc_traffic.json, collected with
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload and corrected as
+    MI355X_MICROARCH.md prescribes), scaled to this launch's block count; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        if d.get("block_bytes") != BLOCK:
+            return None
+        return float(d["traffic_bytes_per_block"]) * n_blocks
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def usable_cores():
     """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -245,7 +262,7 @@ def main():
                        "blocks_per_gpu": n, "block_bytes": BLOCK, "ratio": round(tot_u / tot_c, 4),
                        "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(n),
                          "kernel": "nxz::deflate_kernel<false,false>", "kernel_ms": round(kern_ms, 3),
                          "algorithmic_bytes_per_launch": u_bytes + c_bytes},
         }
