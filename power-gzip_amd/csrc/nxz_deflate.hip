@@ -133,6 +133,16 @@ constexpr PowTab make_pow()
 	return p;
 }
 __device__ const PowTab CRC_POW = make_pow();
+// x^(8 r) mod P for r = 0..64
+struct Pow8Tab { uint32_t v[65]; };
+constexpr Pow8Tab make_pow8()
+{
+	Pow8Tab p{};
+	p.v[0] = 0x80000000u;
+	for (int i = 1; i <= 64; i++) p.v[i] = cgf_mul(p.v[i - 1], 0x00800000u);
+	return p;
+}
+__device__ const Pow8Tab CRC_POW8 = make_pow8();
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
@@ -244,6 +254,10 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 	const uint32_t n = total - h;
 	const uint32_t end = total;
 	const uint8_t *__restrict__ src = job.src;
+	// CRC weights (constant memory), fetched up front so that their latency hides behind the load phase
+	const uint32_t K1 = n ? (end - 1) >> 6 : 0;              // 64-byte slice (LDS aligned) that holds the last byte
+	const uint32_t pw_slice = CRC_POW.v[(1022 - t) & 1023];  // x^(512 (1022 - t))
+	const uint32_t pw_tail = CRC_POW8.v[end - K1 * 64];      // x^(8 r), r = bytes of the last slice
 
 	// ---------------- load ----------------
 	{
@@ -285,22 +299,21 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 	PROF(0);
 
 	// ---------------- checksums of the non-history source ----------------
-	// The stream is cut into 64-byte slices aligned in LDS.  Thread t owns full slice
-	// s = t - 1025 + K (K-1 = slice holding the last byte), i.e. the full slices are right
-	// aligned on thread 1023 and leading threads see an all-zero prefix, which does not
-	// change a raw (init 0) CRC.  Slices are read as 4 x ds_read_b128 and fed through a
-	// slice-by-4 table; the tree combine multiplies by x^(8*64*2^level).  The last
-	// (partial) slice is finished bytewise by one lane.  in_crc is folded into the first
-	// data dword (history length is a multiple of 16, so that dword is aligned).
+	// The stream is cut into 64-byte slices aligned in LDS; K1 is the slice that holds the last
+	// byte (r = 1..64 bytes of it are data).  Thread 1023 owns that last slice, thread t < 1023 the
+	// full slice K1 - (1023 - t); leading threads without a slice contribute 0, which does not
+	// change a raw (init 0) CRC.  Slices are read as 4 x ds_read_b128 and fed through a slice-by-4
+	// table.  A full slice followed by j more full slices and the r tail bytes weighs
+	// x^(512 j) * x^(8 r): the first factor is applied per thread, the XOR reduce is linear, so the
+	// second is applied once to the reduced value before the tail slice's CRC joins.  in_crc is
+	// XORed into the state in front of the first data byte (history length is a multiple of 16).
 	uint32_t out_crc, out_adler;
 	{
 		uint32_t *T = bitbuf;                                   // T[k*256 + i], k = 0..3
-		const uint32_t K1 = n ? (end - 1) >> 6 : 0;             // index of the last slice
-		const bool tail_only = n == 0 || (h >> 6) == K1;        // all data inside the last slice
 		const uint32_t initx = job.in_crc ^ 0xffffffffu;
-		int sidx = (int)t - 1024 + (int)K1;                     // my full slice (valid if >= h>>6 and < K1)
+		const int sidx = (int)t - 1023 + (int)K1;               // my slice
 		uint32_t crc = 0, s1 = 0, sj = 0;
-		if (!tail_only && sidx >= (int)(h >> 6) && sidx < (int)K1) {
+		if (n && sidx >= (int)(h >> 6)) {
 			const uint4 *sp = (const uint4 *)(lds + OFF_IN + (uint32_t)sidx * 64);
 			uint4 q[4] = { sp[0], sp[1], sp[2], sp[3] };
 			const uint32_t *w = (const uint32_t *)q;
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			for (int k = 0; k < 16; k++) {
 				uint32_t a = (uint32_t)sidx * 64 + 4 * k;           // LDS address of this dword
 				uint32_t v = w[k];
-				if (a < h) continue;                                // history bytes: not part of the stream
+				if (a < h || a + 4 > end) continue;                 // history / past the end: not part of the stream
 				uint32_t i = a - h;
 				uint32_t b0 = v & 0xff, b1 = (v >> 8) & 0xff, b2 = (v >> 16) & 0xff, b3 = v >> 24;
 				s1 += b0 + b1 + b2 + b3;
@@ -316,11 +329,23 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				uint32_t c = crc ^ v ^ (i == 0 ? initx : 0);
 				crc = T[768 + (c & 0xff)] ^ T[512 + ((c >> 8) & 0xff)] ^ T[256 + ((c >> 16) & 0xff)] ^ T[c >> 24];
 			}
+			if (t == 1023 && (end & 3)) {
+				// the last 1..3 bytes of the stream
+				const uint32_t a = end & ~3u, nb = end & 3, i = a - h;
+				const uint32_t v = inw[a >> 2] & ((1u << (8 * nb)) - 1);
+				uint32_t b0 = v & 0xff, b1 = (v >> 8) & 0xff, b2 = (v >> 16) & 0xff;
+				s1 += b0 + b1 + b2;
+				sj += (b0 + b1 + b2) * (n - i) - (b1 + 2 * b2);
+				if (i == 0) crc ^= initx;
+				for (uint32_t k = 0; k < nb; k++) crc = T[(crc ^ (v >> (8 * k))) & 0xff] ^ (crc >> 8);
+			}
 		}
-		// every slice is weighted by x^(8 * bytes that follow it): thread t is followed by 1023-t slices
-		crc = gf_mul(crc, CRC_POW.v[1023 - t]);
+		uint32_t tailcrc = 0;
+		if (t == 1023) { tailcrc = crc; crc = 0; }
+		else crc = gf_mul(crc, pw_slice);
 		for (int o = 32; o > 0; o >>= 1) crc ^= __shfl_down(crc, o, 64);
 		if (lane == 0) scan[wave] = crc;
+		if (t == 1023) scan[50] = tailcrc;
 		uint32_t a1 = s1, a2 = sj % 65521u;
 		for (int o = 32; o > 0; o >>= 1) {
 			a1 += __shfl_down(a1, o, 64);
@@ -337,16 +362,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				b2 += __shfl_down(b2, o, 64);
 			}
 			if (lane == 0) {
-				// last slice, bytewise, continuing from the tree result
-				uint32_t a0 = tail_only ? h : K1 * 64;
-				if (tail_only) c = initx;
-				uint32_t t1 = 0, t2 = 0;
-				for (uint32_t a = a0; a < end; a++) {
-					uint32_t byte = lds[OFF_IN + a];
-					c = T[(c ^ byte) & 0xff] ^ (c >> 8);
-					t1 += byte; t2 += byte * (end - a);
-				}
-				b1 += t1; b2 += t2 % 65521u;
+				c = n ? gf_mul(c, pw_tail) ^ scan[50] : initx;
 				uint32_t ia = job.in_adler & 0xffff, ib = job.in_adler >> 16;
 				uint32_t s1f = (ia + b1) % 65521u;
 				uint32_t s2f = (uint32_t)(((uint64_t)ib + (uint64_t)n * ia + b2) % 65521u);
@@ -610,13 +626,56 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 
 		PROF(5);
 		// ---- parse pass 1: speculative walk of segment s from its own start ----
-		if ((uint32_t)t < nseg) {
-			uint32_t p = t * PSEG, stop = p + PSEG < tn ? p + PSEG : tn;
-			while (p < stop) {
-				bool m;
-				p += walk_step(W, p, tn, m);
+		// The 16 stored lengths of the segment (+1 for the lazy look-ahead) are fetched with one
+		// 16-byte LDS read and the walk runs out of registers.
+		uint32_t sm0 = 0, sm1 = 0, sm2 = 0, sm3 = 0, seg_next = 0, seg_nz = 0;
+		const uint32_t p0 = (uint32_t)t * PSEG;
+		auto seg_m = [&](uint32_t k) -> uint32_t {              // stored length (len-3, 0 = none) of position p0+k, k <= 16
+			// two levels of 2-way selects (a 4-way select on a computed index becomes a scratch table)
+			const uint32_t a = (k & 8) ? sm2 : sm0, b = (k & 8) ? sm3 : sm1;
+			const uint32_t w = (k & 4) ? b : a;
+			const uint32_t v = (w >> (8 * (k & 3))) & 0xff;
+			return (k & 16) ? seg_next : v;
+		};
+		// one greedy/lazy step on register data (same decisions as walk_step)
+		auto seg_step = [&](uint32_t p, uint32_t limit, bool &is_match) -> uint32_t {
+			const uint32_t k = p - p0, cur = seg_m(k);
+			const uint32_t full = cur ? cur + 3 : 0;
+			const uint32_t len = full < limit - p ? full : limit - p;
+			is_match = false;
+			if (full >= 4 && len >= 3) {
+				if (len < LAZY_MAX && p + 1 < limit) {
+					uint32_t m2 = seg_m(k + 1);
+					uint32_t l2 = m2 ? m2 + 3 : 0;
+					if (l2 > limit - p - 1) l2 = limit - p - 1;
+					if (l2 > len) return 1;
+				}
+				is_match = true;
+				return len;
 			}
-			X[t] = (uint16_t)p;
+			return 1;
+		};
+		if ((uint32_t)t < nseg) {
+			const uint4 mv = *(const uint4 *)(mlen + p0);
+			sm0 = mv.x; sm1 = mv.y; sm2 = mv.z; sm3 = mv.w;
+			seg_next = p0 + 16 < tn ? mlen[p0 + 16] : 0;
+			// 16-bit mask of positions that have a match (non-zero byte), 4 bits per dword
+			auto nz4 = [](uint32_t w) -> uint32_t {
+				uint32_t x = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;
+				return (((x >> 7) * 0x00204081u) >> 21) & 0xf;
+			};
+			seg_nz = nz4(sm0) | nz4(sm1) << 4 | nz4(sm2) << 8 | nz4(sm3) << 12;
+			uint32_t p = p0, stop = p + PSEG < tn ? p + PSEG : tn;
+			while (p < stop) {
+				// branch free: skip the literals in front of the next match, then take one step there
+				const uint32_t rest = seg_nz >> (p - p0);
+				p += rest ? (uint32_t)__builtin_ctz(rest) : stop - p;
+				bool m;
+				const uint32_t adv = seg_step(p < stop ? p : p0, tn, m);
+				p += p < stop ? adv : 0;
+			}
+			if (p > stop && stop == tn) p = tn;
+			X[t] = (uint16_t)(p < tn ? p : tn);
 			jump[t] = (uint16_t)(p >= tn ? NSEG : p / PSEG);
 		}
 		if (t == 0) mark[0] = 1;
@@ -677,31 +736,58 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				}
 			};
 			while (p < lim) {
+				const uint32_t k = p - p0;
+				// all literal step (wave uniform): no lane of this wave has a match in its next
+				// positions, so up to four literals per lane go out with one input load
+				const uint32_t rest = k < 16 ? seg_nz >> k : 1;
+				uint32_t run = rest ? (uint32_t)__builtin_ctz(rest) : 16 - k;
+				if (run > lim - p) run = lim - p;
+				if (!__ballot(run == 0)) {
+					if (run > 4) run = 4;
+					const uint32_t v = lds_ld32(inw, h + tb0 + p);
+					const uint32_t b0 = v & 0xff, b1 = (v >> 8) & 0xff, b2 = (v >> 16) & 0xff, b3 = v >> 24;
+					const uint32_t t0 = lltab[b0], t1 = run > 1 ? lltab[b1] : 0, t2 = run > 2 ? lltab[b2] : 0, t3 = run > 3 ? lltab[b3] : 0;
+					if (DHT && ((t0 >> 16) == 0 || (run > 1 && (t1 >> 16) == 0) || (run > 2 && (t2 >> 16) == 0) || (run > 3 && (t3 >> 16) == 0)))
+						misc[M_ERR] = NXZ_CC_MISSING_CODE;
+					put((t0 & 0xffff) | (t1 & 0xffff) << (t0 >> 16), (t0 >> 16) + (t1 >> 16));       // <= 30 bits
+					put((t2 & 0xffff) | (t3 & 0xffff) << (t2 >> 16), (t2 >> 16) + (t3 >> 16));
+					mine += (t0 >> 16) + (t1 >> 16) + (t2 >> 16) + (t3 >> 16);
+					if (COUNT) {
+						atomicAdd(&hist[b0], 1u);
+						if (run > 1) atomicAdd(&hist[b1], 1u);
+						if (run > 2) atomicAdd(&hist[b2], 1u);
+						if (run > 3) atomicAdd(&hist[b3], 1u);
+					}
+					p += run;
+					continue;
+				}
+				// one token per lane; literal and match share one (select based) code path so that a
+				// wave with both kinds does not execute two divergent branches
 				bool m;
-				uint32_t l = walk_step(W, p, lim, m);
+				uint32_t l;
+				if (k < 16) l = seg_step(p, lim, m);
+				else l = walk_step(W, p, lim, m);                 // beyond my segment (unsynchronised range): LDS data
+				const uint32_t byte = lds[OFF_IN + h + tb0 + p], d = cand[p];
+				const uint32_t l3 = l - 3;
+				uint32_t le = l3 < 8 ? 0 : (29 - __builtin_clz(l3 | 8));
+				const uint32_t ls = l3 == 255 ? 28 : (le << 2) + (l3 >> le);
+				if (l3 == 255) le = 0;
+				uint32_t de = d < 4 ? 0 : (30 - __builtin_clz(d | 4));
+				const uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
+				if (!m) { le = 0; de = 0; }
+				const uint32_t lt = lltab[m ? 257 + ls : byte], dt = m ? dtab[ds & 31] : 0;
+				const uint32_t ll = lt >> 16, dl = dt >> 16;
+				if (DHT && (ll == 0 || (m && dl == 0))) misc[M_ERR] = NXZ_CC_MISSING_CODE;
+				put((lt & 0xffff) | ((l3 & ((1u << le) - 1)) << ll), ll + le);               // <= 20 bits
+				put((dt & 0xffff) | ((d & ((1u << de) - 1)) << dl), dl + de);                // <= 28 bits (0 for a literal)
+				mine += ll + le + dl + de;
 				if (m) {
 					atomicOr(&mbits[p >> 5], 1u << (p & 31));
-					mlen[p] = (uint8_t)(l - 3);
-					uint32_t l3 = l - 3, d = cand[p];
-					uint32_t le = l3 < 8 ? 0 : (29 - __builtin_clz(l3));
-					uint32_t ls = l3 == 255 ? 28 : (le << 2) + (l3 >> le);
-					if (l3 == 255) le = 0;
-					uint32_t de = d < 4 ? 0 : (30 - __builtin_clz(d));
-					uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
-					uint32_t lt = lltab[257 + ls], dt = dtab[ds];
-					uint32_t ll = lt >> 16, dl = dt >> 16;
-					if (DHT && (ll == 0 || dl == 0)) misc[M_ERR] = NXZ_CC_MISSING_CODE;
-					put((lt & 0xffff) | ((l3 & ((1u << le) - 1)) << ll), ll + le);               // <= 20 bits
-					put((dt & 0xffff) | ((d & ((1u << de) - 1)) << dl), dl + de);                // <= 28 bits
-					mine += ll + le + dl + de;
-					if (COUNT) { atomicAdd(&hist[257 + ls], 1u); atomicAdd(&hist[286 + ds], 1u); }
-				} else {
-					uint32_t byte = lds[OFF_IN + h + tb0 + p];
-					uint32_t lt = lltab[byte];
-					if (DHT && (lt >> 16) == 0) misc[M_ERR] = NXZ_CC_MISSING_CODE;
-					put(lt & 0xffff, lt >> 16);
-					mine += lt >> 16;
-					if (COUNT) atomicAdd(&hist[byte], 1u);
+					mlen[p] = (uint8_t)l3;
+				}
+				if (COUNT) {
+					atomicAdd(&hist[m ? 257 + ls : byte], 1u);
+					if (m) atomicAdd(&hist[286 + ds], 1u);
 				}
 				p += l;
 			}
