@@ -560,17 +560,31 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		{
 			uint32_t *hb = mbits;                             // head bitmap
 			const uint32_t *cb = sbits;
-			if (t < PTILE / 32) {
-				uint32_t cw = cb[t], hw = 0;
-				if (cw) {
-					uint32_t prevw = t ? cb[t - 1] : 0;
-					for (uint32_t m = cw; m; m &= m - 1) {
-						uint32_t bpos = (uint32_t)__builtin_ctz(m), pp = (uint32_t)t * 32 + bpos;
-						bool pc = bpos ? (cw >> (bpos - 1)) & 1 : (prevw >> 31) & 1;
-						if (!(pc && cand[pp - 1] == cand[pp])) hw |= 1u << bpos;
+			// head = capped position whose predecessor is not a capped position of the same
+			// distance, or that sits on a 256-position boundary (so that one very long match is
+			// shared by many waves and nobody compares more than MAXMATCH + 256 bytes).
+			// 16 positions per thread, their candidates compared in registers.
+			{
+				const uint32_t cw = cb[t >> 1];
+				const uint32_t bits = (t & 1) ? cw >> 16 : cw & 0xffff;
+				uint32_t hw = 0;
+				if (bits) {
+					const uint32_t prevbit = (t & 1) ? (cw >> 15) & 1 : (t ? cb[(t >> 1) - 1] >> 31 : 0);
+					const uint4 c0 = ((const uint4 *)cand)[2 * t], c1 = ((const uint4 *)cand)[2 * t + 1];
+					const uint32_t cprev = t ? cand[16 * t - 1] : 0;
+					const uint32_t w[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+					uint32_t eq = 0;                              // bit j: cand[16t+j] == cand[16t+j-1]
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						const uint32_t before = j ? w[j - 1] >> 16 : cprev;
+						eq |= (uint32_t)((w[j] & 0xffff) == before) << (2 * j);
+						eq |= (uint32_t)((w[j] >> 16) == (w[j] & 0xffff)) << (2 * j + 1);
 					}
+					const uint32_t follows = ((bits << 1) | prevbit) & eq;
+					hw = bits & ~follows;
+					if ((t & 15) == 0) hw |= bits & 1;
 				}
-				hb[t] = hw;
+				((uint16_t *)hb)[t] = (uint16_t)hw;
 			}
 			__syncthreads();
 			PROF(11);
@@ -585,7 +599,8 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					uint32_t d = cand[hp];
 					uint32_t r0 = h + tb0 + hp, q0 = r0 - (d + 1);
 					// natural length, as far as any position of this tile can use it
-					uint32_t lmax = (tn - 1 - hp) + MAXMATCH;
+					const uint32_t nb = (hp | 255) + 1 < tn ? (hp | 255) + 1 : tn;   // my cover ends at the next boundary
+					uint32_t lmax = (nb - 1 - hp) + MAXMATCH;
 					if (lmax > end - r0) lmax = end - r0;
 					uint32_t N = lmax;
 					for (uint32_t ob = CAPLEN; ob < lmax; ob += 256) {
@@ -602,7 +617,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					}
 					// hand the exact length to every capped position of the same distance it covers
 					uint32_t ce = hp + (N - CAPLEN) + 1;
-					if (ce > tn) ce = tn;
+					if (ce > nb) ce = nb;
 					for (uint32_t q = hp + lane; q < ce; q += 64) {
 						if (mlen[q] == CAPLEN - 3 && cand[q] == d) {
 							uint32_t full = N - (q - hp), rq = r0 + (q - hp);
