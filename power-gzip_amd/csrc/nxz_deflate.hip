@@ -43,10 +43,10 @@ constexpr uint32_t PTILE = 16384;        // positions per parse tile
 constexpr uint32_t PSEG = 16;            // positions per parse segment (one lane)
 constexpr uint32_t NSEG = PTILE / PSEG;  // 1024
 constexpr uint32_t ETILE = 2048;         // positions per encode step
-constexpr uint32_t CAPLEN = 36;          // match length cap of the position-parallel pass
 constexpr uint32_t LAZY_MAX = 32;
 constexpr uint32_t MAXMATCH = 258;
 constexpr uint32_t WINDOW = 32768;
+constexpr uint32_t LCAP = 40;            // lane-serial tail extension stops here; 16 lanes per tail beyond
 constexpr uint32_t NOHASH = 0xFFFFu;
 
 // ---- LDS carve (bytes) ----
@@ -71,7 +71,7 @@ constexpr uint32_t LDS_BYTES = OFF_MISC + 64;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
-enum { M_ERR = 0, M_CARRY_BITS = 1, M_WORDBASE = 2, M_CARRY_WORD = 3, M_PROGRESS = 4, M_TICKET = 5 };
+enum { M_ERR = 0, M_CARRY_BITS = 1, M_WORDBASE = 2, M_CARRY_WORD = 3, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6 };
 
 __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
 {
@@ -152,39 +152,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 		if (lane >= o) v += u;
 	}
 	return v;
-}
-
-// Full match evaluation of one position (oracle/nxz_lz77.c step 4): hash candidate q16 and the
-// distance-1 run candidate, both extended up to CAPLEN; returns the capped length (0 = none) and
-// the chosen distance-1.
-__device__ __forceinline__ void match_full(const uint32_t *inw, uint32_t r, uint32_t q, uint32_t end,
-					   uint32_t &len_out, uint32_t &c_out)
-{
-	uint32_t len = 0, c = NOHASH;
-	uint32_t v = lds_ld32(inw, r);
-	uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-	uint32_t lim = maxlen < CAPLEN ? maxlen : CAPLEN;
-	if (q < r && r - q <= WINDOW && lds_ld32(inw, q) == v) {
-		len = extend(inw, q, r, 4, lim);
-		c = r - q - 1;
-	}
-	if (r >= 1 && lds_ld32(inw, r - 1) == v) {
-		uint32_t l1 = extend(inw, r - 1, r, 4, lim);
-		// oracle: the run wins when its FULL length >= the hash match's full length.  Capped
-		// lengths compare equal only if both reach the cap; then compare the full lengths.
-		bool take = l1 > len;
-		if (l1 == len) {
-			if (len < lim || lim == maxlen) take = true;
-			else {
-				uint32_t fa = extend(inw, r - (c + 1), r, CAPLEN, maxlen);
-				uint32_t fb = extend(inw, r - 1, r, CAPLEN, maxlen);
-				take = fb >= fa;
-			}
-		}
-		if (take) { len = l1; c = 0; }
-	}
-	len_out = len >= 4 ? len : 0;
-	c_out = len >= 4 ? c : NOHASH;
 }
 
 struct Walk {
@@ -414,8 +381,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// cand[i] = byte offset of the position's head[] slot (dummy slot for positions without a
 		// hash and for the padding up to a multiple of 512 positions, so the chain loop is guard free)
 		const uint32_t tnpad = (tn + 511) & ~511u;
-		for (uint32_t i = t; i < PTILE / 32; i += NT) sbits[i] = 0;     // capped-position bitmap of the match phase
-		if (t == 0) { misc[M_PROGRESS] = 0; misc[M_TICKET] = 0; }
+		if (t == 0) { misc[M_PROGRESS] = 0; misc[M_TICKET] = 0; misc[M_DEFER] = 0; }
 		// Within a 512-position piece the slots are stored transposed -- lane l keeps its 8 steps
 		// (positions l, l+64, ..) in one 16-byte group -- so that the chain wave moves a piece's
 		// slot offsets and results with one ds_read_b128 / ds_write_b128 per lane.
@@ -468,172 +434,257 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		}
 		PROF(4);
 
-		// ---- match, stage 1 (branch free, every position): verify both candidates and compare
-		// bytes 4..7.  Lengths below 8 are final here.  The rest (about one position in seven for
-		// text) goes to a per-wave queue and is finished 64 at a time by stage 2, so that the
-		// divergent extension loop runs on full wavefronts instead of dragging 60 idle lanes.
+		// ---- match ----
+		// Natural match lengths obey N(p) = N(p+1) + 1 for neighbours that match at the same
+		// distance, so of a run of positions inside one long match only the LAST one (the "tail")
+		// compares bytes; the others get their length from it afterwards.  The distance-1 candidate
+		// needs no compares at all: its length is the run of "byte equals its predecessor" flags.
+		//   M1 (every position, branch free): validate the hash candidate (window, 4 bytes) and
+		//      compare bytes 4..7.  Lengths below 8 are final.  A position with 8 equal bytes whose
+		//      successor matches at the same distance is a "long member" (bitmap kb); the other long
+		//      ones are tails and go to a per-wave queue.
+		//   M2 (queue, 64 at a time): extend the tails up to 258 / the end of the data.
+		//   M3 (16 positions per thread, after a barrier): long members take their length from the
+		//      end of their chain; distance-1 runs are evaluated and win ties (oracle/nxz_lz77.c 4).
+		uint32_t *kb = mbits;                                 // bitmap: long member
 		{
 			uint16_t *queue = (uint16_t *)(lds + OFF_X) + wave * 128;
-			uint32_t *cb = sbits;                             // capped-position bitmap (zeroed in the hash phase)
 			uint32_t qcnt = 0;
+			// tails that are still equal after LCAP bytes: 16 lanes per tail, 64 bytes per step
+			uint16_t *lq = (uint16_t *)(lds + OFF_X + 4096) + wave * 128;
+			uint32_t lqn = 0;
+			auto longext = [&](uint32_t nl) {
+				const uint32_t g = lane >> 4, li = lane & 15;
+				for (uint32_t base = 0; base < nl; base += 4) {
+					const bool act = base + g < nl;
+					const uint32_t i = act ? (uint32_t)lq[base + g] : 0;
+					const uint32_t r = h + tb0 + i, q = r - cand[i] - 1;
+					const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+					uint32_t N = 0;
+					bool done = !act;
+					for (uint32_t off = LCAP;; off += 64) {
+						const uint32_t o = off + 4 * li;
+						uint32_t x = 0;
+						if (!done && o < maxlen) x = lds_ld32(inw, q + o) ^ lds_ld32(inw, r + o);
+						const bool ev = !done && (x != 0 || o + 4 >= maxlen);   // mismatch or end of the compare
+						const unsigned long long mm = __ballot(ev);
+						const uint32_t gm = (uint32_t)(mm >> (16 * g)) & 0xffffu;
+						uint32_t myN = x ? o + ((uint32_t)__builtin_ctz(x) >> 3) : maxlen;
+						if (myN > maxlen) myN = maxlen;
+						const uint32_t firstN = __shfl(myN, gm ? (g << 4) + (uint32_t)__builtin_ctz(gm) : (uint32_t)lane, 64);
+						if (!done && gm) { N = firstN; done = true; }
+						if (!__ballot(!done)) break;
+					}
+					if (act && li == 0) mlen[i] = (uint8_t)(N - 3);
+				}
+			};
 			auto stage2 = [&](uint32_t nq) {
 				uint32_t i = lane < nq ? (uint32_t)queue[lane] : 0xffffffffu;
 				__builtin_amdgcn_wave_barrier();
 				if (nq > 64 && 64 + lane < nq) queue[lane] = queue[64 + lane];
+				bool lg = false;
 				if (i != 0xffffffffu) {
-					uint32_t len, c;
-					match_full(inw, h + tb0 + i, cand[i], end, len, c);
-					mlen[i] = len ? (uint8_t)(len - 3) : 0;
-					cand[i] = (uint16_t)c;
-					if (len == CAPLEN) atomicOr(&cb[i >> 5], 1u << (i & 31));
+					const uint32_t r = h + tb0 + i, q = r - cand[i] - 1;
+					const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+					const uint32_t len = extend(inw, q, r, 8, maxlen < LCAP ? maxlen : LCAP);
+					mlen[i] = (uint8_t)(len - 3);
+					lg = len == LCAP && maxlen > LCAP;
+				}
+				const unsigned long long ml = __ballot(lg);
+				if (ml) {
+					if (lg) lq[lqn + __popcll(ml & ((1ull << lane) - 1))] = (uint16_t)i;
+					lqn += (uint32_t)__popcll(ml);
+					__builtin_amdgcn_wave_barrier();
+					if (lqn >= 64) { longext(lqn); lqn = 0; }
 				}
 			};
 			for (;;) {
-			uint32_t piece = 0;
-			if (lane == 0) piece = atomicAdd(&misc[M_TICKET], 1u);
-			piece = __builtin_amdgcn_readfirstlane(piece);
-			if (piece >= npieces) break;
-			while (__hip_atomic_load(&misc[M_PROGRESS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= piece)
-				__builtin_amdgcn_s_sleep(4);
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			const uint4 pk = ((const uint4 *)cand)[(piece << 6) + lane];
-			const uint64_t qlo = pk.x | ((uint64_t)pk.y << 32), qhi = pk.z | ((uint64_t)pk.w << 32);
-			__builtin_amdgcn_wave_barrier();                  // all 8 candidates are in registers before cand[] is rewritten
-			for (uint32_t i0 = piece << 9; i0 < (piece << 9) + 512 && i0 < tn; i0 += 64) {
-				const uint32_t i = i0 + lane, ustep = (i0 >> 6) & 7;
-				const uint32_t qcand = (uint32_t)((ustep < 4 ? qlo : qhi) >> (16 * (ustep & 3))) & 0xffffu;
-				const uint32_t r = h + tb0 + i;
-				const bool ok = i < tn && r + 4 <= end;
-				// the dword that holds r, one before and two after: bytes r-1 .. r+7 in registers.
-				// (Only 2-way selects below: a 3-way select on a computed index makes hipcc build a
-				// lookup table in scratch memory.)
-				const uint32_t rw = r >> 2, ro = r & 3;
-				const uint32_t dm1 = inw[rw ? rw - 1 : 0], d0 = inw[rw], d1 = inw[rw + 1], d2 = inw[rw + 2];
-				const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, ro), v4 = __builtin_amdgcn_alignbyte(d2, d1, ro);
-				const uint32_t vm1 = ro ? __builtin_amdgcn_alignbyte(d1, d0, ro - 1) : __builtin_amdgcn_alignbyte(d0, dm1, 3);
-				const uint32_t v3 = ro ? __builtin_amdgcn_alignbyte(d2, d1, ro - 1) : __builtin_amdgcn_alignbyte(d1, d0, 3);
-				const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-				uint32_t q = ok ? qcand : 0xffffu;
-				const bool qok = ok && q < r && r - q <= WINDOW;
-				if (!qok) q = 0;
-				const uint32_t qa = q >> 2, u0 = inw[qa], u1 = inw[qa + 1], u2 = inw[qa + 2];
-				const uint32_t qv = __builtin_amdgcn_alignbyte(u1, u0, q & 3), qv4 = __builtin_amdgcn_alignbyte(u2, u1, q & 3);
-				uint32_t lenA = 0, lenB = 0;
-				if (qok && qv == v) {
-					uint32_t x = qv4 ^ v4;
-					lenA = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
+				uint32_t piece = 0;
+				if (lane == 0) piece = atomicAdd(&misc[M_TICKET], 1u);
+				piece = __builtin_amdgcn_readfirstlane(piece);
+				if (piece >= npieces) break;
+				while (__hip_atomic_load(&misc[M_PROGRESS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= piece)
+					__builtin_amdgcn_s_sleep(4);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				const uint4 pk = ((const uint4 *)cand)[(piece << 6) + lane];
+				const uint64_t qlo = pk.x | ((uint64_t)pk.y << 32), qhi = pk.z | ((uint64_t)pk.w << 32);
+				__builtin_amdgcn_wave_barrier();                  // all 8 candidates are in registers before cand[] is rewritten
+				// The 64-position steps run from the last to the first, so that the successor of lane
+				// 63 (lane 0 of the step behind it) is known.  The successor of the piece's last
+				// position belongs to another piece: that link is settled after the barrier.
+				uint32_t nxt_key = 0xffffffffu;
+				for (int ustep = 7; ustep >= 0; ustep--) {
+					const uint32_t i0 = (piece << 9) + ((uint32_t)ustep << 6);
+					if (i0 >= tn) continue;
+					const uint32_t i = i0 + lane;
+					const uint32_t qcand = (uint32_t)((ustep < 4 ? qlo : qhi) >> (16 * (ustep & 3))) & 0xffffu;
+					const uint32_t r = h + tb0 + i;
+					const bool ok = i < tn && r + 4 <= end;
+					const uint32_t rw = r >> 2, ro = r & 3;
+					const uint32_t d0 = inw[rw], d1 = inw[rw + 1], d2 = inw[rw + 2];
+					const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, ro), v4 = __builtin_amdgcn_alignbyte(d2, d1, ro);
+					const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+					uint32_t q = ok ? qcand : 0xffffu;
+					const bool qok = ok && q < r && r - q <= WINDOW;
+					if (!qok) q = 0;
+					const uint32_t qa = q >> 2, u0 = inw[qa], u1 = inw[qa + 1], u2 = inw[qa + 2];
+					const uint32_t qv = __builtin_amdgcn_alignbyte(u1, u0, q & 3), qv4 = __builtin_amdgcn_alignbyte(u2, u1, q & 3);
+					const bool okA = qok && qv == v;
+					const uint32_t dA = r - q - 1;
+					const uint32_t x = qv4 ^ v4;
+					uint32_t lenA = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
 					if (lenA > maxlen) lenA = maxlen;
+					const bool raw8 = okA && lenA == 8;             // at least 8 bytes
+					const bool lng = raw8 && maxlen > 8;            // ... and possibly more
+					// what the predecessor needs to know: my distance and whether I have 8 bytes
+					const uint32_t key = okA ? dA | (uint32_t)raw8 << 16 : 0xffffffffu;
+					uint32_t skey = __shfl_down(key, 1, 64);
+					if (lane == 63) skey = nxt_key;
+					nxt_key = __builtin_amdgcn_readfirstlane(key);
+					const bool plast = ustep == 7 && lane == 63 && i + 1 < tn;   // successor unknown yet
+					const bool same_d = skey != 0xffffffffu && (skey & 0xffff) == dA;
+					// same match as the successor: N = N(successor) + 1, which is 8 (known) unless
+					// the successor has 8 bytes or more too
+					const bool member = lng && same_d && (skey >> 16);
+					const bool needs = lng && !same_d && !plast;
+					if (i < tn) {
+						mlen[i] = okA ? (uint8_t)(lenA - 3) : 0;
+						cand[i] = okA ? (uint16_t)dA : (uint16_t)NOHASH;
+					}
+					if (lng && plast) atomicOr(&misc[M_DEFER], 1u << (piece & 31));
+					const unsigned long long mk = __ballot(member);
+					if (lane == 0) ((uint2 *)kb)[i0 >> 6] = make_uint2((uint32_t)mk, (uint32_t)(mk >> 32));
+					unsigned long long m = __ballot(needs);
+					if (m) {
+						if (needs) queue[qcnt + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
+						qcnt += (uint32_t)__popcll(m);
+						__builtin_amdgcn_wave_barrier();
+						if (qcnt >= 64) { stage2(qcnt); qcnt -= 64; }
+					}
 				}
-				if (ok && r >= 1 && vm1 == v) {
-					uint32_t x = v3 ^ v4;
-					lenB = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
-					if (lenB > maxlen) lenB = maxlen;
-				}
-				const bool finA = lenA < 8 || lenA == maxlen, finB = lenB < 8 || lenB == maxlen;
-				const bool needs = ok && !(finA && finB);
-				if (i < tn && !needs) {
-					uint32_t len = lenA, c = r - q - 1;
-					if (lenB >= 4 && lenB >= lenA) { len = lenB; c = 0; }
-					mlen[i] = len >= 4 ? (uint8_t)(len - 3) : 0;
-					cand[i] = len >= 4 ? (uint16_t)c : (uint16_t)NOHASH;
-				}
-				if (needs) cand[i] = (uint16_t)qcand;             // stage 2 reads the candidate from its natural slot
-				unsigned long long m = __ballot(needs);
-				if (m) {
-					if (needs) queue[qcnt + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
-					qcnt += (uint32_t)__popcll(m);
-					__builtin_amdgcn_wave_barrier();
-					if (qcnt >= 64) { stage2(qcnt); qcnt -= 64; }
-				}
-			}
 			}
 			if (qcnt) stage2(qcnt);
+			if (lqn) longext(lqn);
+		}
+		__syncthreads();                                       // the long-tail queues live where the flags go
+		// ---- M3a: e(x) = "byte x equals byte x-1" flags for the tile and 288 positions beyond ----
+		{
+			uint16_t *eb16 = (uint16_t *)bitbuf;
+			const uint32_t ngroups = (tn + 288 + 15) / 16 + 2;
+			for (uint32_t g = t; g < ngroups; g += NT) {
+				const uint32_t r0 = h + tb0 + 16 * g;                 // 16-byte aligned
+				uint32_t bits = 0;
+				if (r0 < end) {
+					const uint4 dv = *(const uint4 *)(lds + OFF_IN + r0);
+					const uint32_t pv = r0 ? inw[(r0 >> 2) - 1] : 0;
+					auto eq4 = [](uint32_t d, uint32_t prev) -> uint32_t {
+						const uint32_t xx = d ^ __builtin_amdgcn_alignbyte(d, prev, 3);      // byte k: b[k] ^ b[k-1]
+						const uint32_t nzb = (((xx & 0x7f7f7f7fu) + 0x7f7f7f7fu) | xx) & 0x80808080u;
+						return ~((((nzb >> 7) * 0x00204081u) >> 21)) & 0xf;
+					};
+					bits = eq4(dv.x, pv) | eq4(dv.y, dv.x) << 4 | eq4(dv.z, dv.y) << 8 | eq4(dv.w, dv.z) << 12;
+					if (r0 == 0) bits &= ~1u;
+					if (end - r0 < 16) bits &= (1u << (end - r0)) - 1;
+				}
+				eb16[g] = (uint16_t)bits;
+			}
+		}
+		__syncthreads();
+		// the piece-last long positions: member if the first position of the next piece continues
+		// the match, tail (extended right here) otherwise
+		if (t < 32 && (misc[M_DEFER] >> t) & 1) {
+			const uint32_t i = ((uint32_t)t << 9) + 511;
+			if (cand[i + 1] == cand[i]) {
+				if (mlen[i + 1] >= 5) kb[i >> 5] |= 0x80000000u;      // successor has 8 bytes or more: member
+			} else {
+				const uint32_t r = h + tb0 + i, q = r - cand[i] - 1;
+				const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+				mlen[i] = (uint8_t)(extend(inw, q, r, 8, maxlen) - 3);
+			}
 		}
 		__syncthreads();
 		PROF(10);
-		// ---- run extension: exact lengths for the positions that hit the cap ----
-		// A capped position p (distance d) has natural length N(p); every later capped position q
-		// with the same distance and q - p <= N(p) - CAPLEN lies inside the same match and has
-		// N(q) = N(p) - (q - p).  So only "heads" compare bytes -- a whole wave per head, 256
-		// conflict-free bytes per step -- and they hand the exact length (clamped to 258 / end) to
-		// the positions they cover.  Two waves covering the same position write the same value.
-		{
-			uint32_t *hb = mbits;                             // head bitmap
-			const uint32_t *cb = sbits;
-			// head = capped position whose predecessor is not a capped position of the same
-			// distance, or that sits on a 256-position boundary (so that one very long match is
-			// shared by many waves and nobody compares more than MAXMATCH + 256 bytes).
-			// 16 positions per thread, their candidates compared in registers.
-			{
-				const uint32_t cw = cb[t >> 1];
-				const uint32_t bits = (t & 1) ? cw >> 16 : cw & 0xffff;
-				uint32_t hw = 0;
-				if (bits) {
-					const uint32_t prevbit = (t & 1) ? (cw >> 15) & 1 : (t ? cb[(t >> 1) - 1] >> 31 : 0);
-					const uint4 c0 = ((const uint4 *)cand)[2 * t], c1 = ((const uint4 *)cand)[2 * t + 1];
-					const uint32_t cprev = t ? cand[16 * t - 1] : 0;
-					const uint32_t w[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
-					uint32_t eq = 0;                              // bit j: cand[16t+j] == cand[16t+j-1]
-#pragma unroll
-					for (int j = 0; j < 8; j++) {
-						const uint32_t before = j ? w[j - 1] >> 16 : cprev;
-						eq |= (uint32_t)((w[j] & 0xffff) == before) << (2 * j);
-						eq |= (uint32_t)((w[j] >> 16) == (w[j] & 0xffff)) << (2 * j + 1);
-					}
-					const uint32_t follows = ((bits << 1) | prevbit) & eq;
-					hw = bits & ~follows;
-					if ((t & 15) == 0) hw |= bits & 1;
-				}
-				((uint16_t *)hb)[t] = (uint16_t)hw;
+		// ---- M3: long members, then distance-1 runs ----
+		const uint32_t p0 = (uint32_t)t * PSEG;
+		// first clear bit of a bitmap at or after bit s (below limit)
+		auto first_zero = [](const uint32_t *bm, uint32_t s0, uint32_t limit) -> uint32_t {
+			uint32_t wi = s0 >> 5;
+			uint32_t w = ~bm[wi] & (~0u << (s0 & 31));
+			while (!w) {
+				wi++;
+				if (wi * 32 >= limit) return limit;
+				w = ~bm[wi];
 			}
-			__syncthreads();
-			PROF(11);
-			// wave w owns head words [32w, 32w+32); one load finds the non-empty ones
-			uint32_t myword = wave * 32 + (lane & 31);
-			unsigned long long nonempty = __ballot(lane < 32 && hb[myword] != 0);
-			for (; nonempty; nonempty &= nonempty - 1) {
-				const uint32_t wd = wave * 32 + (uint32_t)__builtin_ctzll(nonempty);
-				uint32_t bits = __hip_atomic_load(&hb[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				while (bits) {
-					uint32_t hp = (wd << 5) + (uint32_t)__builtin_ctz(bits);
-					uint32_t d = cand[hp];
-					uint32_t r0 = h + tb0 + hp, q0 = r0 - (d + 1);
-					// natural length, as far as any position of this tile can use it
-					const uint32_t nb = (hp | 255) + 1 < tn ? (hp | 255) + 1 : tn;   // my cover ends at the next boundary
-					uint32_t lmax = (nb - 1 - hp) + MAXMATCH;
-					if (lmax > end - r0) lmax = end - r0;
-					uint32_t N = lmax;
-					for (uint32_t ob = CAPLEN; ob < lmax; ob += 256) {
-						uint32_t o = ob + 4 * lane;
-						uint32_t x = lds_ld32(inw, q0 + o) ^ lds_ld32(inw, r0 + o);
-						unsigned long long mm = __ballot(x != 0);
-						if (mm) {
-							int fl = __builtin_ctzll(mm);
-							uint32_t xf = __shfl(x, fl, 64);
-							uint32_t nn = ob + 4 * fl + ((uint32_t)__builtin_ctz(xf) >> 3);
-							N = nn < lmax ? nn : lmax;
-							break;
-						}
-					}
-					// hand the exact length to every capped position of the same distance it covers
-					uint32_t ce = hp + (N - CAPLEN) + 1;
-					if (ce > nb) ce = nb;
-					for (uint32_t q = hp + lane; q < ce; q += 64) {
-						if (mlen[q] == CAPLEN - 3 && cand[q] == d) {
-							uint32_t full = N - (q - hp), rq = r0 + (q - hp);
-							if (full > MAXMATCH) full = MAXMATCH;
-							if (full > end - rq) full = end - rq;
-							mlen[q] = (uint8_t)(full - 3);
-							if (q != hp) atomicAnd(&hb[q >> 5], ~(1u << (q & 31)));
-						}
-					}
-					__builtin_amdgcn_wave_barrier();
-					bits = __hip_atomic_load(&hb[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & (~1u << (hp & 31));
+			const uint32_t pos = wi * 32 + (uint32_t)__builtin_ctz(w);
+			return pos < limit ? pos : limit;
+		};
+		if (p0 < tn) {
+			// members of my 16 positions, last to first: N = (end of the chain) - position; the chain
+			// ends at the first non-member behind it, whose length is final (M1, M2 or the link pass)
+			const uint32_t kb16 = ((const uint16_t *)kb)[t];
+			uint32_t kbits = kb16, e_cur = 0, last_j = 32;
+			while (kbits) {
+				const uint32_t j = 31 - (uint32_t)__builtin_clz(kbits);
+				kbits &= ~(1u << j);
+				const uint32_t i = p0 + j;
+				if (last_j != j + 1) {
+					const uint32_t z = ~kb16 & (0xfffeu << j) & 0xffffu;
+					// more than 258 + 16 positions away is as good as infinitely far
+					const uint32_t lim = p0 + 16 + 272 < tn ? p0 + 16 + 272 : tn;
+					const uint32_t T = z ? p0 + (uint32_t)__builtin_ctz(z) : first_zero(kb, p0 + 16, lim);
+					e_cur = T < lim ? T + mlen[T] + 3 : T + MAXMATCH;
 				}
+				last_j = j;
+				const uint32_t r = h + tb0 + i;
+				const uint32_t ml = end - r < MAXMATCH ? end - r : MAXMATCH;
+				const uint32_t N = e_cur - i < ml ? e_cur - i : ml;
+				mlen[i] = (uint8_t)(N - 3);
 			}
 		}
 		__syncthreads();
+		PROF(11);
+		uint32_t sm0 = 0, sm1 = 0, sm2 = 0, sm3 = 0;          // final stored lengths (len-3, 0 = none) of my 16 positions
+		if (p0 < tn) {
+			const uint32_t *eb = bitbuf;
+			const uint32_t e32 = lds_ld32(eb, 2 * t);               // my 16 flags and the next 16
+			const uint32_t e16 = e32 & 0xffff;
+			const uint32_t r4 = e32 & (e32 >> 1) & (e32 >> 2) & (e32 >> 3) & 0xffff;   // runs of >= 4 that start in my group
+			const uint4 mv = *(const uint4 *)(mlen + p0);
+			sm0 = mv.x; sm1 = mv.y; sm2 = mv.z; sm3 = mv.w;
+			if (r4) {
+				// distance 1: the length is the run of e flags that starts at the position; it wins ties
+				const uint4 c0 = ((const uint4 *)cand)[2 * t], c1 = ((const uint4 *)cand)[2 * t + 1];
+				const uint32_t mw[4] = { mv.x, mv.y, mv.z, mv.w };
+				uint32_t cw[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+				uint32_t zb = 16;
+				if (e16 >> 15) zb = first_zero(eb, p0 + 16, p0 + 16 + 272) - p0;
+				const uint32_t r15 = h + tb0 + p0 + 15;
+				uint32_t om[4] = { 0, 0, 0, 0 };
+#pragma unroll
+				for (int j = 15; j >= 0; j--) {
+					const uint32_t i = p0 + j, r = r15 - (15 - j);
+					const uint32_t room = end > r ? end - r : 0;
+					const uint32_t ml = room < MAXMATCH ? room : MAXMATCH;
+					const uint32_t mj = (mw[j >> 2] >> (8 * (j & 3))) & 0xff;
+					uint32_t cj = (cw[j >> 1] >> (16 * (j & 1))) & 0xffff;
+					const uint32_t NA = mj ? mj + 3 : 0;
+					const uint32_t zmask = ~e16 & (0xffffu << j) & 0xffffu;
+					const uint32_t zpos = zmask ? (uint32_t)__builtin_ctz(zmask) : zb;
+					uint32_t NB = zpos - j;
+					if (NB > ml) NB = ml;
+					uint32_t len = NA;
+					if (NB >= 4 && NB >= NA && i < tn) { len = NB; cj = 0; }
+					om[j >> 2] |= (len ? len - 3 : 0) << (8 * (j & 3));
+					cw[j >> 1] = (cw[j >> 1] & ~(0xffffu << (16 * (j & 1)))) | cj << (16 * (j & 1));
+				}
+				sm0 = om[0]; sm1 = om[1]; sm2 = om[2]; sm3 = om[3];
+				*(uint4 *)(mlen + p0) = make_uint4(sm0, sm1, sm2, sm3);
+				((uint4 *)cand)[2 * t] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+				((uint4 *)cand)[2 * t + 1] = make_uint4(cw[4], cw[5], cw[6], cw[7]);
+			}
+		}
 		// chain bookkeeping init (mark/jump alias the two bitmaps)
+		__syncthreads();
 		for (uint32_t s = t; s < NSEG; s += NT) mark[s] = 0;
 		__syncthreads();
 		if (nxz_debug_buf && blockIdx.x == 0)
@@ -643,8 +694,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// ---- parse pass 1: speculative walk of segment s from its own start ----
 		// The 16 stored lengths of the segment (+1 for the lazy look-ahead) are fetched with one
 		// 16-byte LDS read and the walk runs out of registers.
-		uint32_t sm0 = 0, sm1 = 0, sm2 = 0, sm3 = 0, seg_next = 0, seg_nz = 0;
-		const uint32_t p0 = (uint32_t)t * PSEG;
+		uint32_t seg_next = 0, seg_nz = 0;
 		auto seg_m = [&](uint32_t k) -> uint32_t {              // stored length (len-3, 0 = none) of position p0+k, k <= 16
 			// two levels of 2-way selects (a 4-way select on a computed index becomes a scratch table)
 			const uint32_t a = (k & 8) ? sm2 : sm0, b = (k & 8) ? sm3 : sm1;
@@ -671,8 +721,6 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			return 1;
 		};
 		if ((uint32_t)t < nseg) {
-			const uint4 mv = *(const uint4 *)(mlen + p0);
-			sm0 = mv.x; sm1 = mv.y; sm2 = mv.z; sm3 = mv.w;
 			seg_next = p0 + 16 < tn ? mlen[p0 + 16] : 0;
 			// 16-bit mask of positions that have a match (non-zero byte), 4 bits per dword
 			auto nz4 = [](uint32_t w) -> uint32_t {

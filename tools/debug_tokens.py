@@ -84,10 +84,9 @@ def main():
         tile, i = divmod(p, 16384)
         v = int(d[tile * 65536 + i]); gc, gm = v & 0xffff, (v >> 16) & 0xff
         ol, odist = om[p], od[p]
-        exp_m = 0 if ol < 4 else min(ol, 36) - 3
+        exp_m = 0 if ol < 4 else ol - 3
         exp_c = odist if ol >= 4 else None
-        # the GPU may have extended a capped length in place
-        ok = (gm == exp_m or (ol > 36 and gm == ol - 3)) and (exp_c is None or gc == exp_c)
+        ok = gm == exp_m and (exp_c is None or gc == exp_c)
         if not ok:
             nbad += 1
             if nbad < 8:

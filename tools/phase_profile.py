@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench
 pkg = importlib.import_module("power-gzip_amd")
-NAMES = ["load", "cksum", "seed+hdr", "hash", "chain", "runext-heads", "pass1", "mark", "pass2", "(tail)", "match", "runext-bitmap", "enc-count+scan", "enc-clear", "enc-emit", "enc-flush"]
+NAMES = ["load", "cksum", "seed+hdr", "hash", "chain", "M3b dist-1 runs", "pass1", "mark", "pass2", "(tail)", "match(M1+M2)+eflags", "M3a members", "enc-count+scan", "enc-clear", "enc-emit", "enc-flush"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = pkg.Engine(0)
 src = bench.gen_blocks(torch, eng.dev, n, 0)
