@@ -382,19 +382,24 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// hash and for the padding up to a multiple of 512 positions, so the chain loop is guard free)
 		const uint32_t tnpad = (tn + 511) & ~511u;
 		if (t == 0) { misc[M_PROGRESS] = 0; misc[M_TICKET] = 0; misc[M_DEFER] = 0; }
-		// Within a 512-position piece the slots are stored transposed -- lane l keeps its 8 steps
-		// (positions l, l+64, ..) in one 16-byte group -- so that the chain wave moves a piece's
-		// slot offsets and results with one ds_read_b128 / ds_write_b128 per lane.
+		// Four consecutive positions per lane: two aligned dwords give the four 4-byte strings.
 		const uint32_t npieces = tnpad >> 9;
-		for (uint32_t piece = wave; piece < npieces; piece += NT / 64) {
-			uint32_t o[8];
-#pragma unroll
-			for (int u = 0; u < 8; u++) {
-				uint32_t i = (piece << 9) + (u << 6) + lane, r = h + tb0 + i;
-				uint32_t v = lds_ld32(inw, r < end ? r : 0);
-				o[u] = (i < tn && r + 4 <= end) ? hash4(v) * 4 : HSIZE * 4;
+		for (uint32_t g = t; g < tnpad / 4; g += NT) {
+			const uint32_t i = 4 * g, r = h + tb0 + i;              // r is a multiple of 4
+			const uint32_t d0 = inw[r >> 2], d1 = inw[(r >> 2) + 1];
+			uint32_t o0 = (hash4(d0) << 2), o1 = (hash4(__builtin_amdgcn_alignbyte(d1, d0, 1)) << 2);
+			uint32_t o2 = (hash4(__builtin_amdgcn_alignbyte(d1, d0, 2)) << 2), o3 = (hash4(__builtin_amdgcn_alignbyte(d1, d0, 3)) << 2);
+			if (i + 4 > tn || r + 7 > end) {                        // ragged end of the tile / of the data
+				if (i + 0 >= tn || r + 4 > end) o0 = HSIZE * 4;
+				if (i + 1 >= tn || r + 5 > end) o1 = HSIZE * 4;
+				if (i + 2 >= tn || r + 6 > end) o2 = HSIZE * 4;
+				if (i + 3 >= tn || r + 7 > end) o3 = HSIZE * 4;
 			}
-			((uint4 *)cand)[(piece << 6) + lane] = make_uint4(o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | o[5] << 16, o[6] | o[7] << 16);
+			// stored transposed inside the 512-position piece -- lane l of the chain wave keeps its 8
+			// steps (positions l, l+64, ..) in one 16-byte group -- so that the chain wave moves a
+			// piece's slot offsets and results with one ds_read_b128 / ds_write_b128 per lane
+			uint16_t *cp = cand + (i & ~511u) + ((i & 63) << 3) + ((i >> 6) & 7);
+			cp[0] = (uint16_t)o0; cp[8] = (uint16_t)o1; cp[16] = (uint16_t)o2; cp[24] = (uint16_t)o3;
 		}
 		__syncthreads();
 		PROF(3);
@@ -404,16 +409,21 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// 512-position pieces and publishes how many are done; all waves (wave 0 too, once the chain
 		// is finished) draw piece numbers from a ticket counter and run the match stages on a piece
 		// as soon as it is published, so the other 15 waves do not idle behind the chain.
+		const unsigned long long tphase_ = prof ? clock64() : 0;
 		if (wave == 0) {
-			// ~5 instructions per 64-position step: look the slot up, insert; the slot offsets come in
-			// and the candidate positions (16 bit; an empty slot gives 0xffff which no position can
-			// use) go out 8 steps at a time.  The trip count is wave-uniform and the 8 steps are
-			// issued back to back: the LDS executes one wave's operations in order, so lookup(k+1)
-			// only has to be ISSUED after insert(k); results are consumed afterwards.
+			// Per 64-position step: look the slot up, insert (max wins).  The LDS executes one wave's
+			// operations in order, so lookup(k+1) only has to be ISSUED after insert(k); nothing waits
+			// for a result inside a piece.  The slot offsets of the next piece are fetched ahead and
+			// the candidate positions of the previous piece (16 bit; an empty slot gives 0xffff, which
+			// no position can use) are written one piece late, so no LDS round trip is exposed.
+			// Publishing needs no wait either: the flag store follows the data stores in LDS order.
 			const uint8_t *headb = (const uint8_t *)head;
 			__builtin_amdgcn_s_setprio(3);                    // the chain is the critical path of this phase
+			uint4 pkn = ((const uint4 *)cand)[lane];
+			uint32_t oldp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 			for (uint32_t piece = 0; piece < npieces; piece++) {
-				const uint4 pk = ((const uint4 *)cand)[(piece << 6) + lane];
+				const uint4 pk = pkn;
+				if (piece + 1 < npieces) pkn = ((const uint4 *)cand)[((piece + 1) << 6) + lane];
 				const uint32_t off[8] = { pk.x & 0xffff, pk.x >> 16, pk.y & 0xffff, pk.y >> 16, pk.z & 0xffff, pk.z >> 16, pk.w & 0xffff, pk.w >> 16 };
 				uint32_t old[8];
 #pragma unroll
@@ -424,12 +434,21 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					atomicMax(slot, h + tb0 + (piece << 9) + 64 * u + lane + 1);
 					__builtin_amdgcn_wave_barrier();
 				}
+				if (piece) {
 #pragma unroll
-				for (int u = 0; u < 8; u++) old[u] = (old[u] - 1) & 0xffff;
-				((uint4 *)cand)[(piece << 6) + lane] = make_uint4(old[0] | old[1] << 16, old[2] | old[3] << 16, old[4] | old[5] << 16, old[6] | old[7] << 16);
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					for (int u = 0; u < 8; u++) oldp[u] = (oldp[u] - 1) & 0xffff;
+					((uint4 *)cand)[((piece - 1) << 6) + lane] = make_uint4(oldp[0] | oldp[1] << 16, oldp[2] | oldp[3] << 16, oldp[4] | oldp[5] << 16, oldp[6] | oldp[7] << 16);
+					asm volatile("" ::: "memory");
+					if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+#pragma unroll
+				for (int u = 0; u < 8; u++) oldp[u] = old[u];
 			}
+#pragma unroll
+			for (int u = 0; u < 8; u++) oldp[u] = (oldp[u] - 1) & 0xffff;
+			((uint4 *)cand)[((npieces - 1) << 6) + lane] = make_uint4(oldp[0] | oldp[1] << 16, oldp[2] | oldp[3] << 16, oldp[4] | oldp[5] << 16, oldp[6] | oldp[7] << 16);
+			asm volatile("" ::: "memory");
+			if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], npieces, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			__builtin_amdgcn_s_setprio(0);
 		}
 		PROF(4);
@@ -446,7 +465,8 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		//   M2 (queue, 64 at a time): extend the tails up to 258 / the end of the data.
 		//   M3 (16 positions per thread, after a barrier): long members take their length from the
 		//      end of their chain; distance-1 runs are evaluated and win ties (oracle/nxz_lz77.c 4).
-		uint32_t *kb = mbits;                                 // bitmap: long member
+		uint32_t *kb = mbits;                                 // bitmap: long members (and the gaps inside their chains)
+		uint32_t *vb = sbits;                                 // bitmap: position has a verified candidate
 		{
 			uint16_t *queue = (uint16_t *)(lds + OFF_X) + wave * 128;
 			uint32_t qcnt = 0;
@@ -503,70 +523,103 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				if (lane == 0) piece = atomicAdd(&misc[M_TICKET], 1u);
 				piece = __builtin_amdgcn_readfirstlane(piece);
 				if (piece >= npieces) break;
+				unsigned long long w0_ = prof ? clock64() : 0;
 				while (__hip_atomic_load(&misc[M_PROGRESS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= piece)
 					__builtin_amdgcn_s_sleep(4);
+				if (prof && wave == 1 && lane == 0) atomicAdd(&prof[16], clock64() - w0_);
+				unsigned long long w1_ = prof ? clock64() : 0;
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				const uint4 pk = ((const uint4 *)cand)[(piece << 6) + lane];
 				const uint64_t qlo = pk.x | ((uint64_t)pk.y << 32), qhi = pk.z | ((uint64_t)pk.w << 32);
 				__builtin_amdgcn_wave_barrier();                  // all 8 candidates are in registers before cand[] is rewritten
-				// The 64-position steps run from the last to the first, so that the successor of lane
-				// 63 (lane 0 of the step behind it) is known.  The successor of the piece's last
-				// position belongs to another piece: that link is settled after the barrier.
-				uint32_t nxt_key = 0xffffffffu;
+				// The 64-position steps run from the last to the first, so that a successor in the
+				// step behind is known.  The successor of the piece's last position belongs to another
+				// piece: that link is settled after the barrier.
+				uint32_t nxt_key = 0xffffffffu, nxt_low8 = 0;     // first candidate of the step behind, and where it sits
+				const uint32_t wsh = lane < 32 ? lane + 1 : lane - 31;
 				for (int ustep = 7; ustep >= 0; ustep--) {
 					const uint32_t i0 = (piece << 9) + ((uint32_t)ustep << 6);
 					if (i0 >= tn) continue;
+					// steps that are far enough from the end of the tile and of the data need no clamps
+					const bool full = i0 + 64 <= tn && h + tb0 + i0 + 64 + MAXMATCH + 8 <= end;
 					const uint32_t i = i0 + lane;
-					const uint32_t qcand = (uint32_t)((ustep < 4 ? qlo : qhi) >> (16 * (ustep & 3))) & 0xffffu;
 					const uint32_t r = h + tb0 + i;
-					const bool ok = i < tn && r + 4 <= end;
-					const uint32_t rw = r >> 2, ro = r & 3;
+					const uint32_t qc = (uint32_t)((ustep < 4 ? qlo : qhi) >> (16 * (ustep & 3))) & 0xffffu;   // candidate position from the chain
+					const bool ok = full || (i < tn && r + 4 <= end);
+					const uint32_t maxlen = full || end - r >= MAXMATCH ? MAXMATCH : end - r;
+					const uint32_t dA = r - qc - 1;                 // distance - 1; wraps to something huge if qc >= r
+					const bool qok = ok && dA < WINDOW;
+					const uint32_t q = full || qok ? qc : 0;
+					const uint32_t rw = r >> 2, ro = lane & 3;      // h, tb0, i0 are multiples of 4
 					const uint32_t d0 = inw[rw], d1 = inw[rw + 1], d2 = inw[rw + 2];
 					const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, ro), v4 = __builtin_amdgcn_alignbyte(d2, d1, ro);
-					const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-					uint32_t q = ok ? qcand : 0xffffu;
-					const bool qok = ok && q < r && r - q <= WINDOW;
-					if (!qok) q = 0;
 					const uint32_t qa = q >> 2, u0 = inw[qa], u1 = inw[qa + 1], u2 = inw[qa + 2];
 					const uint32_t qv = __builtin_amdgcn_alignbyte(u1, u0, q & 3), qv4 = __builtin_amdgcn_alignbyte(u2, u1, q & 3);
 					const bool okA = qok && qv == v;
-					const uint32_t dA = r - q - 1;
 					const uint32_t x = qv4 ^ v4;
 					uint32_t lenA = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
 					if (lenA > maxlen) lenA = maxlen;
 					const bool raw8 = okA && lenA == 8;             // at least 8 bytes
 					const bool lng = raw8 && maxlen > 8;            // ... and possibly more
-					// what the predecessor needs to know: my distance and whether I have 8 bytes
+					// The successor: the next position with a verified candidate, if it is at most 8
+					// positions away (then it lies inside my match when I have 8 bytes).  It may sit in
+					// the first lanes of the step behind this one.
+					const unsigned long long mok = __ballot(okA);
+					const uint32_t mlo = (uint32_t)mok, mhi = (uint32_t)(mok >> 32);
+					const uint64_t wsrc = lane < 32 ? ((uint64_t)mhi << 32 | mlo) : ((uint64_t)nxt_low8 << 32 | mhi);
+					const uint32_t win = (uint32_t)(wsrc >> wsh) & 0xff;
+					const uint32_t gapm1 = win ? (uint32_t)__builtin_ctz(win) : 8;
+					const uint32_t nl = lane + 1 + gapm1;
+					// what a predecessor needs to know: my distance and whether I have 8 bytes
 					const uint32_t key = okA ? dA | (uint32_t)raw8 << 16 : 0xffffffffu;
-					uint32_t skey = __shfl_down(key, 1, 64);
-					if (lane == 63) skey = nxt_key;
-					nxt_key = __builtin_amdgcn_readfirstlane(key);
-					const bool plast = ustep == 7 && lane == 63 && i + 1 < tn;   // successor unknown yet
-					const bool same_d = skey != 0xffffffffu && (skey & 0xffff) == dA;
-					// same match as the successor: N = N(successor) + 1, which is 8 (known) unless
-					// the successor has 8 bytes or more too
-					const bool member = lng && same_d && (skey >> 16);
+					uint32_t skey = __shfl(key, nl & 63, 64);
+					if (nl >= 64) skey = nxt_key;
+					const bool plast = ustep == 7 && lane == 63 && i + 1 < tn;   // successor in the next piece: settled later
+					const bool same_d = win != 0 && (skey & 0xffff) == dA;
+					// same match as the successor: N = N(successor) + gap; for a direct successor with
+					// less than 8 bytes that is 8, which is what M1 stores anyway
+					const bool member = lng && same_d && !(gapm1 == 0 && !((skey >> 16) & 1));
 					const bool needs = lng && !same_d && !plast;
-					if (i < tn) {
+					if (full || i < tn) {
 						mlen[i] = okA ? (uint8_t)(lenA - 3) : 0;
 						cand[i] = okA ? (uint16_t)dA : (uint16_t)NOHASH;
 					}
 					if (lng && plast) atomicOr(&misc[M_DEFER], 1u << (piece & 31));
-					const unsigned long long mk = __ballot(member);
-					if (lane == 0) ((uint2 *)kb)[i0 >> 6] = make_uint2((uint32_t)mk, (uint32_t)(mk >> 32));
+					// kb: members and the positions between a member and its successor, so that the
+					// first clear bit behind a member is the end of its chain.  Adding the member mask
+					// to (members | positions without candidate) carries through exactly those.
+					const unsigned long long ma = __ballot(member);
+					const unsigned long long pz = ~mok | ma, rz = pz + ma;
+					const unsigned long long mk = ma | ((pz ^ rz) & ~mok);
+					if (lane == 0) {
+						((uint2 *)vb)[i0 >> 6] = make_uint2(mlo, mhi);
+						((uint2 *)kb)[i0 >> 6] = make_uint2((uint32_t)mk, (uint32_t)(mk >> 32));
+						if (rz < pz && (nxt_low8 & 1) == 0)         // the chain runs on into the step behind
+							kb[(i0 >> 5) + 2] |= (nxt_low8 & (0u - nxt_low8)) - 1;
+					}
+					nxt_low8 = mlo & 0xff;
+					nxt_key = __builtin_amdgcn_readlane(key, mok ? (int)__builtin_ctzll(mok) : 0);
 					unsigned long long m = __ballot(needs);
 					if (m) {
 						if (needs) queue[qcnt + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
 						qcnt += (uint32_t)__popcll(m);
 						__builtin_amdgcn_wave_barrier();
-						if (qcnt >= 64) { stage2(qcnt); qcnt -= 64; }
+						if (qcnt >= 64) { unsigned long long w2_ = prof ? clock64() : 0; stage2(qcnt); qcnt -= 64; if (prof && wave == 1 && lane == 0) atomicAdd(&prof[18], clock64() - w2_); }
 					}
 				}
+				if (prof && wave == 1 && lane == 0) { atomicAdd(&prof[17], clock64() - w1_); atomicAdd(&prof[19], 1ull); }
+				if (prof && lane == 0) { atomicAdd(&prof[40 + wave], 1ull); }
 			}
+			PROF(20);
+			if (prof && lane == 0) atomicAdd(&prof[24 + wave], clock64() - tphase_);
 			if (qcnt) stage2(qcnt);
+			PROF(21);
 			if (lqn) longext(lqn);
+			PROF(22);
+			if (prof && lane == 0) atomicAdd(&prof[48 + wave], clock64() - tphase_);
 		}
 		__syncthreads();                                       // the long-tail queues live where the flags go
+		PROF(23);
 		// ---- M3a: e(x) = "byte x equals byte x-1" flags for the tile and 288 positions beyond ----
 		{
 			uint16_t *eb16 = (uint16_t *)bitbuf;
@@ -622,19 +675,24 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			// members of my 16 positions, last to first: N = (end of the chain) - position; the chain
 			// ends at the first non-member behind it, whose length is final (M1, M2 or the link pass)
 			const uint32_t kb16 = ((const uint16_t *)kb)[t];
-			uint32_t kbits = kb16, e_cur = 0, last_j = 32;
+			uint32_t kbits = kb16 & ((const uint16_t *)vb)[t], e_cur = 0, T_prev = 0xffffffffu, T_ext = 0xffffffffu;
+			// more than 258 + 16 positions away is as good as infinitely far
+			const uint32_t lim = p0 + 16 + 272 < tn ? p0 + 16 + 272 : tn;
 			while (kbits) {
 				const uint32_t j = 31 - (uint32_t)__builtin_clz(kbits);
 				kbits &= ~(1u << j);
 				const uint32_t i = p0 + j;
-				if (last_j != j + 1) {
-					const uint32_t z = ~kb16 & (0xfffeu << j) & 0xffffu;
-					// more than 258 + 16 positions away is as good as infinitely far
-					const uint32_t lim = p0 + 16 + 272 < tn ? p0 + 16 + 272 : tn;
-					const uint32_t T = z ? p0 + (uint32_t)__builtin_ctz(z) : first_zero(kb, p0 + 16, lim);
-					e_cur = T < lim ? T + mlen[T] + 3 : T + MAXMATCH;
+				const uint32_t z = ~kb16 & (0xfffeu << j) & 0xffffu;
+				uint32_t T;
+				if (z) T = p0 + (uint32_t)__builtin_ctz(z);
+				else {
+					if (T_ext == 0xffffffffu) T_ext = first_zero(kb, p0 + 16, lim);
+					T = T_ext;
 				}
-				last_j = j;
+				if (T != T_prev) {
+					e_cur = T < lim ? T + mlen[T] + 3 : T + MAXMATCH;
+					T_prev = T;
+				}
 				const uint32_t r = h + tb0 + i;
 				const uint32_t ml = end - r < MAXMATCH ? end - r : MAXMATCH;
 				const uint32_t N = e_cur - i < ml ? e_cur - i : ml;
