@@ -25,6 +25,7 @@
 //     encode per 2048 positions: code lookup, workgroup prefix sum of bit
 //            lengths, LDS atomicOr bit packing, coalesced dword flush
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include "nxz_device.h"
 
@@ -32,7 +33,10 @@
 __device__ uint32_t *nxz_debug_buf = nullptr;
 // Diagnostic only (tools/phase_profile.py): per-phase cycle sums of every workgroup's thread 0.
 __device__ unsigned long long *nxz_prof_buf = nullptr;
-#define PROF(idx) do { if (prof) { if (t == 0) { unsigned long long now_ = clock64(); atomicAdd(&prof[idx], now_ - tprev); tprev = now_; } } } while (0)
+// Pointers into device memory are used through address space 1: generic ("flat") accesses make
+// the compiler drain the LDS queue completely at every wait that follows them.
+#define NXZ_GLOBAL __attribute__((address_space(1)))
+#define PROF(idx) do { if (prof) { if (t == 0) { unsigned long long now_ = clock64(); __hip_atomic_fetch_add(&prof[idx], now_ - tprev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tprev = now_; } } } while (0)
 
 namespace nxz {
 
@@ -95,6 +99,24 @@ __device__ __forceinline__ uint32_t extend(const uint32_t *inw, uint32_t a, uint
 		len += 4;
 	}
 	return len < limit ? len : limit;
+}
+
+// number of equal bytes (0..16) of the strings at a and b, compared over 16 bytes with one LDS round trip
+__device__ __forceinline__ uint32_t equal16(const uint32_t *inw, uint32_t a, uint32_t b)
+{
+	const uint32_t aw = a >> 2, bw = b >> 2, as = a & 3, bs = b & 3;
+	const uint32_t a0 = inw[aw], a1 = inw[aw + 1], a2 = inw[aw + 2], a3 = inw[aw + 3], a4 = inw[aw + 4];
+	const uint32_t b0 = inw[bw], b1 = inw[bw + 1], b2 = inw[bw + 2], b3 = inw[bw + 3], b4 = inw[bw + 4];
+	const uint32_t x0 = __builtin_amdgcn_alignbyte(a1, a0, as) ^ __builtin_amdgcn_alignbyte(b1, b0, bs);
+	const uint32_t x1 = __builtin_amdgcn_alignbyte(a2, a1, as) ^ __builtin_amdgcn_alignbyte(b2, b1, bs);
+	const uint32_t x2 = __builtin_amdgcn_alignbyte(a3, a2, as) ^ __builtin_amdgcn_alignbyte(b3, b2, bs);
+	const uint32_t x3 = __builtin_amdgcn_alignbyte(a4, a3, as) ^ __builtin_amdgcn_alignbyte(b4, b3, bs);
+	uint32_t n = 16;
+	if (x3) n = 12 + ((uint32_t)__builtin_ctz(x3) >> 3);
+	if (x2) n = 8 + ((uint32_t)__builtin_ctz(x2) >> 3);
+	if (x1) n = 4 + ((uint32_t)__builtin_ctz(x1) >> 3);
+	if (x0) n = (uint32_t)__builtin_ctz(x0) >> 3;
+	return n;
 }
 
 // GF(2)[x] multiply modulo the reflected CRC-32 polynomial
@@ -213,14 +235,15 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 	uint32_t *misc = (uint32_t *)(lds + OFF_MISC);
 
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	unsigned long long *prof = nxz_prof_buf;
+	NXZ_GLOBAL unsigned long long *prof = (NXZ_GLOBAL unsigned long long *)nxz_prof_buf;
+	NXZ_GLOBAL uint32_t *dbg = (NXZ_GLOBAL uint32_t *)nxz_debug_buf;
 	unsigned long long tprev = prof ? clock64() : 0;
 	const nxz_batch_job_t job = jobs[blockIdx.x];
 	const uint32_t total = job.src_len;                  // window + block
 	const uint32_t h = job.hist_len < total ? job.hist_len : total;
 	const uint32_t n = total - h;
 	const uint32_t end = total;
-	const uint8_t *__restrict__ src = job.src;
+	const NXZ_GLOBAL uint8_t *src = (const NXZ_GLOBAL uint8_t *)job.src;
 	// CRC weights (constant memory), fetched up front so that their latency hides behind the load phase
 	const uint32_t K1 = n ? (end - 1) >> 6 : 0;              // 64-byte slice (LDS aligned) that holds the last byte
 	const uint32_t pw_slice = CRC_POW.v[(1022 - t) & 1023];  // x^(512 (1022 - t))
@@ -228,8 +251,9 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 
 	// ---------------- load ----------------
 	{
-		const uint4 *s4 = (const uint4 *)src;
-		uint4 *d4 = (uint4 *)inw;
+		typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+		const NXZ_GLOBAL v4u *s4 = (const NXZ_GLOBAL v4u *)src;
+		v4u *d4 = (v4u *)inw;
 		uint32_t nfull = total >> 4;
 		for (uint32_t i = t; i < nfull; i += NT) d4[i] = s4[i];
 		// tail bytes + zero pad (so that over-reads past `end` are defined)
@@ -350,7 +374,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 
 	// ---------------- block header ----------------
 	// misc[M_CARRY_BITS]: bits pending in bitbuf[0..]; misc[M_WORDBASE]: dwords already flushed
-	uint32_t *dstw = (uint32_t *)job.dst;
+	NXZ_GLOBAL uint32_t *dstw = (NXZ_GLOBAL uint32_t *)job.dst;
 	const uint32_t cap_words = job.dst_cap >> 2;
 	if (DHT) {
 		const nxz_dht_prepared_t *tb = &tables[job.dht_index];
@@ -379,27 +403,36 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 
 		// ---- hash ----
 		// cand[i] = byte offset of the position's head[] slot (dummy slot for positions without a
-		// hash and for the padding up to a multiple of 512 positions, so the chain loop is guard free)
+		// hash and for the padding up to a multiple of 512 positions, so the chain loop is guard free).
+		// Four consecutive positions per lane (two aligned dwords give the four 4-byte strings); a
+		// wave then transposes its 512-position piece in place -- lane l of the chain wave gets its 8
+		// steps (positions l, l+64, ..) as one 16-byte group -- so that the chain wave moves a piece's
+		// slot offsets and results with one ds_read_b128 / ds_write_b128 per lane.
 		const uint32_t tnpad = (tn + 511) & ~511u;
-		if (t == 0) { misc[M_PROGRESS] = 0; misc[M_TICKET] = 0; misc[M_DEFER] = 0; }
-		// Four consecutive positions per lane: two aligned dwords give the four 4-byte strings.
 		const uint32_t npieces = tnpad >> 9;
-		for (uint32_t g = t; g < tnpad / 4; g += NT) {
-			const uint32_t i = 4 * g, r = h + tb0 + i;              // r is a multiple of 4
-			const uint32_t d0 = inw[r >> 2], d1 = inw[(r >> 2) + 1];
-			uint32_t o0 = (hash4(d0) << 2), o1 = (hash4(__builtin_amdgcn_alignbyte(d1, d0, 1)) << 2);
-			uint32_t o2 = (hash4(__builtin_amdgcn_alignbyte(d1, d0, 2)) << 2), o3 = (hash4(__builtin_amdgcn_alignbyte(d1, d0, 3)) << 2);
-			if (i + 4 > tn || r + 7 > end) {                        // ragged end of the tile / of the data
-				if (i + 0 >= tn || r + 4 > end) o0 = HSIZE * 4;
-				if (i + 1 >= tn || r + 5 > end) o1 = HSIZE * 4;
-				if (i + 2 >= tn || r + 6 > end) o2 = HSIZE * 4;
-				if (i + 3 >= tn || r + 7 > end) o3 = HSIZE * 4;
+		if (t == 0) { misc[M_PROGRESS] = 0; misc[M_TICKET] = 0; misc[M_DEFER] = 0; }
+		sbits[t] = 0;                                           // vb and kb (adjacent, 2 x 512 words)
+		for (uint32_t piece = wave; piece < npieces; piece += NT / 64) {
+#pragma unroll
+			for (int it = 0; it < 2; it++) {
+				const uint32_t i = (piece << 9) + (it << 8) + 4 * lane, r = h + tb0 + i;   // r is a multiple of 4
+				const uint32_t d0 = inw[r >> 2], d1 = inw[(r >> 2) + 1];
+				uint32_t o0 = hash4(d0) << 2, o1 = hash4(__builtin_amdgcn_alignbyte(d1, d0, 1)) << 2;
+				uint32_t o2 = hash4(__builtin_amdgcn_alignbyte(d1, d0, 2)) << 2, o3 = hash4(__builtin_amdgcn_alignbyte(d1, d0, 3)) << 2;
+				if (i + 4 > tn || r + 7 > end) {                    // ragged end of the tile / of the data
+					if (i + 0 >= tn || r + 4 > end) o0 = HSIZE * 4;
+					if (i + 1 >= tn || r + 5 > end) o1 = HSIZE * 4;
+					if (i + 2 >= tn || r + 6 > end) o2 = HSIZE * 4;
+					if (i + 3 >= tn || r + 7 > end) o3 = HSIZE * 4;
+				}
+				*(uint2 *)(cand + i) = make_uint2(o0 | o1 << 16, o2 | o3 << 16);
 			}
-			// stored transposed inside the 512-position piece -- lane l of the chain wave keeps its 8
-			// steps (positions l, l+64, ..) in one 16-byte group -- so that the chain wave moves a
-			// piece's slot offsets and results with one ds_read_b128 / ds_write_b128 per lane
-			uint16_t *cp = cand + (i & ~511u) + ((i & 63) << 3) + ((i >> 6) & 7);
-			cp[0] = (uint16_t)o0; cp[8] = (uint16_t)o1; cp[16] = (uint16_t)o2; cp[24] = (uint16_t)o3;
+			__builtin_amdgcn_wave_barrier();
+			uint32_t o[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) o[u] = cand[(piece << 9) + (u << 6) + lane];
+			__builtin_amdgcn_wave_barrier();                      // LDS runs a wave's operations in order: reads before the write
+			((uint4 *)cand)[(piece << 6) + lane] = make_uint4(o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | o[5] << 16, o[6] | o[7] << 16);
 		}
 		__syncthreads();
 		PROF(3);
@@ -409,7 +442,6 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// 512-position pieces and publishes how many are done; all waves (wave 0 too, once the chain
 		// is finished) draw piece numbers from a ticket counter and run the match stages on a piece
 		// as soon as it is published, so the other 15 waves do not idle behind the chain.
-		const unsigned long long tphase_ = prof ? clock64() : 0;
 		if (wave == 0) {
 			// Per 64-position step: look the slot up, insert (max wins).  The LDS executes one wave's
 			// operations in order, so lookup(k+1) only has to be ISSUED after insert(k); nothing waits
@@ -419,65 +451,83 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			// Publishing needs no wait either: the flag store follows the data stores in LDS order.
 			const uint8_t *headb = (const uint8_t *)head;
 			__builtin_amdgcn_s_setprio(3);                    // the chain is the critical path of this phase
-			uint4 pkn = ((const uint4 *)cand)[lane];
-			uint32_t oldp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-			for (uint32_t piece = 0; piece < npieces; piece++) {
-				const uint4 pk = pkn;
-				if (piece + 1 < npieces) pkn = ((const uint4 *)cand)[((piece + 1) << 6) + lane];
+			// Four pieces per loop trip in straight-line code (the compiler drains the LDS queue at a
+			// loop back edge); pieces past the end work on the dummy slot.
+			auto steps = [&](auto half, const uint4 pk, uint32_t piece, uint32_t (&old)[8]) {
+				constexpr int U0 = decltype(half)::value * 4;
 				const uint32_t off[8] = { pk.x & 0xffff, pk.x >> 16, pk.y & 0xffff, pk.y >> 16, pk.z & 0xffff, pk.z >> 16, pk.w & 0xffff, pk.w >> 16 };
-				uint32_t old[8];
 #pragma unroll
-				for (int u = 0; u < 8; u++) {
+				for (int u = U0; u < U0 + 4; u++) {
 					uint32_t *slot = (uint32_t *)(headb + off[u]);
 					old[u] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					__builtin_amdgcn_wave_barrier();
 					atomicMax(slot, h + tb0 + (piece << 9) + 64 * u + lane + 1);
 					__builtin_amdgcn_wave_barrier();
 				}
-				if (piece) {
+			};
+			auto emit = [&](uint32_t (&o)[8], uint32_t piece) {
 #pragma unroll
-					for (int u = 0; u < 8; u++) oldp[u] = (oldp[u] - 1) & 0xffff;
-					((uint4 *)cand)[((piece - 1) << 6) + lane] = make_uint4(oldp[0] | oldp[1] << 16, oldp[2] | oldp[3] << 16, oldp[4] | oldp[5] << 16, oldp[6] | oldp[7] << 16);
-					asm volatile("" ::: "memory");
-					if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				}
-#pragma unroll
-				for (int u = 0; u < 8; u++) oldp[u] = old[u];
+				for (int u = 0; u < 8; u++) o[u] = (o[u] - 1) & 0xffff;
+				((uint4 *)cand)[(piece << 6) + lane] = make_uint4(o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | o[5] << 16, o[6] | o[7] << 16);
+				__builtin_amdgcn_wave_barrier();
+				if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__builtin_amdgcn_wave_barrier();
+			};
+			const uint32_t dm = HSIZE * 4 | (HSIZE * 4) << 16;
+			const uint4 dummy = make_uint4(dm, dm, dm, dm);
+			for (uint32_t base = 0; base < npieces; base += 4) {
+				const uint4 *cp = (const uint4 *)cand + (base << 6) + lane;
+				const uint4 pk0 = cp[0];
+				const uint4 pk1 = base + 1 < npieces ? cp[64] : dummy;
+				const uint4 pk2 = base + 2 < npieces ? cp[128] : dummy;
+				const uint4 pk3 = base + 3 < npieces ? cp[192] : dummy;
+				uint32_t o0[8], o1[8], o2[8], o3[8];
+				// a piece's results are packed and published half a piece later: the wait for them
+				// then leaves the younger operations in flight
+				const std::integral_constant<int, 0> H0; const std::integral_constant<int, 1> H1;
+				steps(H0, pk0, base, o0); steps(H1, pk0, base, o0);
+				steps(H0, pk1, base + 1, o1);
+				emit(o0, base);
+				steps(H1, pk1, base + 1, o1);
+				steps(H0, pk2, base + 2, o2);
+				emit(o1, base + 1);
+				steps(H1, pk2, base + 2, o2);
+				steps(H0, pk3, base + 3, o3);
+				emit(o2, base + 2);
+				steps(H1, pk3, base + 3, o3);
+				emit(o3, base + 3);
 			}
-#pragma unroll
-			for (int u = 0; u < 8; u++) oldp[u] = (oldp[u] - 1) & 0xffff;
-			((uint4 *)cand)[((npieces - 1) << 6) + lane] = make_uint4(oldp[0] | oldp[1] << 16, oldp[2] | oldp[3] << 16, oldp[4] | oldp[5] << 16, oldp[6] | oldp[7] << 16);
-			asm volatile("" ::: "memory");
-			if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], npieces, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			__builtin_amdgcn_s_setprio(0);
 		}
 		PROF(4);
 
 		// ---- match ----
-		// Natural match lengths obey N(p) = N(p+1) + 1 for neighbours that match at the same
-		// distance, so of a run of positions inside one long match only the LAST one (the "tail")
-		// compares bytes; the others get their length from it afterwards.  The distance-1 candidate
-		// needs no compares at all: its length is the run of "byte equals its predecessor" flags.
-		//   M1 (every position, branch free): validate the hash candidate (window, 4 bytes) and
-		//      compare bytes 4..7.  Lengths below 8 are final.  A position with 8 equal bytes whose
-		//      successor matches at the same distance is a "long member" (bitmap kb); the other long
-		//      ones are tails and go to a per-wave queue.
-		//   M2 (queue, 64 at a time): extend the tails up to 258 / the end of the data.
-		//   M3 (16 positions per thread, after a barrier): long members take their length from the
-		//      end of their chain; distance-1 runs are evaluated and win ties (oracle/nxz_lz77.c 4).
+		// Natural match lengths obey N(p) = N(p') + (p' - p) for positions p < p' that match at the
+		// same distance when p' lies inside p's match, so of the positions inside one long match
+		// only the LAST one (the "tail") compares bytes; the others get their length from it
+		// afterwards.  The distance-1 candidate needs no compares at all: its length is the run of
+		// "byte equals its predecessor" flags.
+		//   M1 (four consecutive positions per lane): validate the hash candidate (window, 4 bytes)
+		//      and compare bytes 4..7.  Lengths below 8 are final.  Positions with 8 equal bytes
+		//      ("long") are collected in a per-wave queue.
+		//   M2 (queue, 64 at a time): a long position whose successor -- the next position with a
+		//      verified candidate, at most 8 away -- matches at the same distance is a member of
+		//      that successor's chain (bitmap kb: members and the gaps inside chains); the others
+		//      are tails and are extended, lane-serial up to LCAP bytes, 16 lanes per tail beyond.
+		//   M3 (after a barrier): members take their length from the end of their chain;
+		//      distance-1 runs are evaluated and win ties (oracle/nxz_lz77.c step 4).
 		uint32_t *kb = mbits;                                 // bitmap: long members (and the gaps inside their chains)
 		uint32_t *vb = sbits;                                 // bitmap: position has a verified candidate
 		{
-			uint16_t *queue = (uint16_t *)(lds + OFF_X) + wave * 128;
-			uint32_t qcnt = 0;
-			// tails that are still equal after LCAP bytes: 16 lanes per tail, 64 bytes per step
-			uint16_t *lq = (uint16_t *)(lds + OFF_X + 4096) + wave * 128;
+			uint16_t *lq = (uint16_t *)(lds + OFF_X) + wave * 128;          // long positions: quad number | position bits << 12
+			uint16_t *xq = (uint16_t *)(lds + OFF_X + 4096) + wave * 64;    // tails beyond LCAP
 			uint32_t lqn = 0;
+			// tails that are still equal after LCAP bytes: 16 lanes per tail, 64 bytes per step
 			auto longext = [&](uint32_t nl) {
 				const uint32_t g = lane >> 4, li = lane & 15;
 				for (uint32_t base = 0; base < nl; base += 4) {
 					const bool act = base + g < nl;
-					const uint32_t i = act ? (uint32_t)lq[base + g] : 0;
+					const uint32_t i = act ? (uint32_t)xq[base + g] : 0;
 					const uint32_t r = h + tb0 + i, q = r - cand[i] - 1;
 					const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
 					uint32_t N = 0;
@@ -498,24 +548,65 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					if (act && li == 0) mlen[i] = (uint8_t)(N - 3);
 				}
 			};
+			// 64 long positions: member of the successor's chain, or tail
 			auto stage2 = [&](uint32_t nq) {
-				uint32_t i = lane < nq ? (uint32_t)queue[lane] : 0xffffffffu;
+				const uint32_t ent = lane < nq ? (uint32_t)lq[lane] : 0;
 				__builtin_amdgcn_wave_barrier();
-				if (nq > 64 && 64 + lane < nq) queue[lane] = queue[64 + lane];
+				if (nq > 64 && 64 + lane < nq) lq[lane] = lq[64 + lane];
+				// almost always one position per entry; more only when neighbours have different distances
+				for (uint32_t pb = ent >> 12; __ballot(pb != 0); pb &= pb - 1) {
+				const uint32_t i = pb ? ((ent & 0xfff) << 2) + (uint32_t)__builtin_ctz(pb) : 0xffffffffu;
 				bool lg = false;
 				if (i != 0xffffffffu) {
-					const uint32_t r = h + tb0 + i, q = r - cand[i] - 1;
+					// round trip 1: my distance and the verified positions i+1 .. i+32, not looking
+					// beyond the piece (another wave's)
+					const uint32_t dA = cand[i];
+					const uint32_t pend = (i | 511) + 1 < tn ? (i | 511) + 1 : tn;
+					uint32_t w32 = (uint32_t)((((uint64_t)vb[((i + 1) >> 5) + 1] << 32) | vb[(i + 1) >> 5]) >> ((i + 1) & 31));
+					if (pend - i <= 32) w32 &= (1u << (pend - i - 1)) - 1;
+					const uint32_t g1 = w32 ? (uint32_t)__builtin_ctz(w32) : 32, sp = w32 ? i + 1 + g1 : i;
+					// round trip 2: the successor's entry and (speculatively) bytes 8..23 of both strings
+					const uint32_t r = h + tb0 + i, q = r - dA - 1;
 					const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-					const uint32_t len = extend(inw, q, r, 8, maxlen < LCAP ? maxlen : LCAP);
-					mlen[i] = (uint8_t)(len - 3);
-					lg = len == LCAP && maxlen > LCAP;
+					const bool same_d = w32 != 0 && cand[sp] == dA;
+					const uint32_t msp = mlen[sp];
+					uint32_t len = 8 + equal16(inw, q + 8, r + 8);
+					if (g1 < 8 && same_d) {
+						// the successor lies inside my 8 bytes: N = N(successor) + gap; for a direct
+						// successor with less than 8 bytes that is 8, which is what M1 stored
+						if (g1 || msp >= 5) {
+							const uint64_t km = (uint64_t)((2u << g1) - 1) << (i & 31);          // bits i .. sp-1
+							atomicOr(&kb[i >> 5], (uint32_t)km);
+							if (km >> 32) atomicOr(&kb[(i >> 5) + 1], (uint32_t)(km >> 32));
+						}
+					} else if (w32 == 0 && i + 1 == pend && pend < tn) {
+						// last position of the piece: settled after the barrier
+						atomicOr(&misc[M_DEFER], 1u << ((i >> 9) & 31));
+					} else {
+						// tail: extend, lane-serial up to LCAP = 8 + 2 x 16 bytes
+						if (len == 24) len += equal16(inw, q + 24, r + 24);
+						if (len > maxlen) len = maxlen;
+						mlen[i] = (uint8_t)(len - 3);
+						lg = len == LCAP && maxlen > LCAP;
+						if (lg && same_d) {
+							// LCAP (> 32 + 8) bytes are equal, so the successor (at most 32 away) lies
+							// inside my match: member of its chain after all
+							const uint64_t km = (((uint64_t)2 << g1) - 1) << (i & 31);           // bits i .. sp-1
+							atomicOr(&kb[i >> 5], (uint32_t)km);
+							if (km >> 32) atomicOr(&kb[(i >> 5) + 1], (uint32_t)(km >> 32));
+							lg = false;
+						}
+					}
 				}
 				const unsigned long long ml = __ballot(lg);
+				if (prof && wave == 1 && lane == 0) { __hip_atomic_fetch_add(&prof[16], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(&prof[17], (unsigned long long)__popcll(ml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 				if (ml) {
-					if (lg) lq[lqn + __popcll(ml & ((1ull << lane) - 1))] = (uint16_t)i;
-					lqn += (uint32_t)__popcll(ml);
+					if (lg) xq[__popcll(ml & ((1ull << lane) - 1))] = (uint16_t)i;
 					__builtin_amdgcn_wave_barrier();
-					if (lqn >= 64) { longext(lqn); lqn = 0; }
+					unsigned long long w0_ = prof ? clock64() : 0;
+					longext((uint32_t)__popcll(ml));
+					if (prof && wave == 1 && lane == 0) __hip_atomic_fetch_add(&prof[18], clock64() - w0_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 				}
 			};
 			for (;;) {
@@ -523,100 +614,90 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				if (lane == 0) piece = atomicAdd(&misc[M_TICKET], 1u);
 				piece = __builtin_amdgcn_readfirstlane(piece);
 				if (piece >= npieces) break;
-				unsigned long long w0_ = prof ? clock64() : 0;
 				while (__hip_atomic_load(&misc[M_PROGRESS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= piece)
 					__builtin_amdgcn_s_sleep(4);
-				if (prof && wave == 1 && lane == 0) atomicAdd(&prof[16], clock64() - w0_);
-				unsigned long long w1_ = prof ? clock64() : 0;
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				const uint4 pk = ((const uint4 *)cand)[(piece << 6) + lane];
-				const uint64_t qlo = pk.x | ((uint64_t)pk.y << 32), qhi = pk.z | ((uint64_t)pk.w << 32);
-				__builtin_amdgcn_wave_barrier();                  // all 8 candidates are in registers before cand[] is rewritten
-				// The 64-position steps run from the last to the first, so that a successor in the
-				// step behind is known.  The successor of the piece's last position belongs to another
-				// piece: that link is settled after the barrier.
-				uint32_t nxt_key = 0xffffffffu, nxt_low8 = 0;     // first candidate of the step behind, and where it sits
-				const uint32_t wsh = lane < 32 ? lane + 1 : lane - 31;
-				for (int ustep = 7; ustep >= 0; ustep--) {
-					const uint32_t i0 = (piece << 9) + ((uint32_t)ustep << 6);
-					if (i0 >= tn) continue;
-					// steps that are far enough from the end of the tile and of the data need no clamps
-					const bool full = i0 + 64 <= tn && h + tb0 + i0 + 64 + MAXMATCH + 8 <= end;
-					const uint32_t i = i0 + lane;
-					const uint32_t r = h + tb0 + i;
-					const uint32_t qc = (uint32_t)((ustep < 4 ? qlo : qhi) >> (16 * (ustep & 3))) & 0xffffu;   // candidate position from the chain
-					const bool ok = full || (i < tn && r + 4 <= end);
-					const uint32_t maxlen = full || end - r >= MAXMATCH ? MAXMATCH : end - r;
-					const uint32_t dA = r - qc - 1;                 // distance - 1; wraps to something huge if qc >= r
-					const bool qok = ok && dA < WINDOW;
-					const uint32_t q = full || qok ? qc : 0;
-					const uint32_t rw = r >> 2, ro = lane & 3;      // h, tb0, i0 are multiples of 4
-					const uint32_t d0 = inw[rw], d1 = inw[rw + 1], d2 = inw[rw + 2];
-					const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, ro), v4 = __builtin_amdgcn_alignbyte(d2, d1, ro);
-					const uint32_t qa = q >> 2, u0 = inw[qa], u1 = inw[qa + 1], u2 = inw[qa + 2];
-					const uint32_t qv = __builtin_amdgcn_alignbyte(u1, u0, q & 3), qv4 = __builtin_amdgcn_alignbyte(u2, u1, q & 3);
-					const bool okA = qok && qv == v;
-					const uint32_t x = qv4 ^ v4;
-					uint32_t lenA = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
-					if (lenA > maxlen) lenA = maxlen;
-					const bool raw8 = okA && lenA == 8;             // at least 8 bytes
-					const bool lng = raw8 && maxlen > 8;            // ... and possibly more
-					// The successor: the next position with a verified candidate, if it is at most 8
-					// positions away (then it lies inside my match when I have 8 bytes).  It may sit in
-					// the first lanes of the step behind this one.
-					const unsigned long long mok = __ballot(okA);
-					const uint32_t mlo = (uint32_t)mok, mhi = (uint32_t)(mok >> 32);
-					const uint64_t wsrc = lane < 32 ? ((uint64_t)mhi << 32 | mlo) : ((uint64_t)nxt_low8 << 32 | mhi);
-					const uint32_t win = (uint32_t)(wsrc >> wsh) & 0xff;
-					const uint32_t gapm1 = win ? (uint32_t)__builtin_ctz(win) : 8;
-					const uint32_t nl = lane + 1 + gapm1;
-					// what a predecessor needs to know: my distance and whether I have 8 bytes
-					const uint32_t key = okA ? dA | (uint32_t)raw8 << 16 : 0xffffffffu;
-					uint32_t skey = __shfl(key, nl & 63, 64);
-					if (nl >= 64) skey = nxt_key;
-					const bool plast = ustep == 7 && lane == 63 && i + 1 < tn;   // successor in the next piece: settled later
-					const bool same_d = win != 0 && (skey & 0xffff) == dA;
-					// same match as the successor: N = N(successor) + gap; for a direct successor with
-					// less than 8 bytes that is 8, which is what M1 stores anyway
-					const bool member = lng && same_d && !(gapm1 == 0 && !((skey >> 16) & 1));
-					const bool needs = lng && !same_d && !plast;
-					if (full || i < tn) {
-						mlen[i] = okA ? (uint8_t)(lenA - 3) : 0;
-						cand[i] = okA ? (uint16_t)dA : (uint16_t)NOHASH;
-					}
-					if (lng && plast) atomicOr(&misc[M_DEFER], 1u << (piece & 31));
-					// kb: members and the positions between a member and its successor, so that the
-					// first clear bit behind a member is the end of its chain.  Adding the member mask
-					// to (members | positions without candidate) carries through exactly those.
-					const unsigned long long ma = __ballot(member);
-					const unsigned long long pz = ~mok | ma, rz = pz + ma;
-					const unsigned long long mk = ma | ((pz ^ rz) & ~mok);
-					if (lane == 0) {
-						((uint2 *)vb)[i0 >> 6] = make_uint2(mlo, mhi);
-						((uint2 *)kb)[i0 >> 6] = make_uint2((uint32_t)mk, (uint32_t)(mk >> 32));
-						if (rz < pz && (nxt_low8 & 1) == 0)         // the chain runs on into the step behind
-							kb[(i0 >> 5) + 2] |= (nxt_low8 & (0u - nxt_low8)) - 1;
-					}
-					nxt_low8 = mlo & 0xff;
-					nxt_key = __builtin_amdgcn_readlane(key, mok ? (int)__builtin_ctzll(mok) : 0);
-					unsigned long long m = __ballot(needs);
+				// back to the natural order: position i of the piece at cand[i]
+				{
+					const uint4 pk = ((const uint4 *)cand)[(piece << 6) + lane];
+					__builtin_amdgcn_wave_barrier();
+					uint16_t *cp = cand + (piece << 9) + lane;
+					cp[0] = (uint16_t)pk.x; cp[64] = (uint16_t)(pk.x >> 16); cp[128] = (uint16_t)pk.y; cp[192] = (uint16_t)(pk.y >> 16);
+					cp[256] = (uint16_t)pk.z; cp[320] = (uint16_t)(pk.z >> 16); cp[384] = (uint16_t)pk.w; cp[448] = (uint16_t)(pk.w >> 16);
+					__builtin_amdgcn_wave_barrier();
+				}
+				// upper half first, so that a successor's entry is in place when a long position is
+				// classified
+#pragma unroll 1
+				for (int it = 1; it >= 0; it--) {
+					const uint32_t ib = (piece << 9) + ((uint32_t)it << 8);
+					if (ib >= tn) continue;
+					const uint32_t i4 = ib + 4 * lane, r4 = h + tb0 + i4;       // r4 is a multiple of 4
+					uint32_t qbits = 0;
+					auto quad = [&](auto fullt) {
+						// FULL: far enough from the end of the tile and of the data, no clamps needed
+						constexpr bool FULL = decltype(fullt)::value;
+						const uint2 qq = *(const uint2 *)(cand + i4);
+						const uint32_t d0 = inw[r4 >> 2], d1 = inw[(r4 >> 2) + 1], d2 = inw[(r4 >> 2) + 2];
+						uint32_t mw = 0, c01 = 0, c23 = 0, vbits = 0, kbits = 0;
+						bool okA[4], raw8[4], lng[4];
+						uint32_t dA[4];
+#pragma unroll
+						for (int j = 0; j < 4; j++) {
+							const uint32_t qc = ((j & 2 ? qq.y : qq.x) >> (16 * (j & 1))) & 0xffff;   // candidate position from the chain
+							const uint32_t i = i4 + j, r = r4 + j;
+							const bool ok = FULL || (i < tn && r + 4 <= end);
+							const uint32_t maxlen = FULL || end - r >= MAXMATCH ? MAXMATCH : end - r;
+							dA[j] = r - qc - 1;                         // distance - 1; wraps to something huge if qc >= r
+							const bool qok = ok && dA[j] < WINDOW;
+							const uint32_t q = FULL || qok ? qc : 0;
+							const uint32_t v = j ? __builtin_amdgcn_alignbyte(d1, d0, j) : d0, v4 = j ? __builtin_amdgcn_alignbyte(d2, d1, j) : d1;
+							const uint32_t qa = q >> 2, u0 = inw[qa], u1 = inw[qa + 1], u2 = inw[qa + 2];
+							const uint32_t qv = __builtin_amdgcn_alignbyte(u1, u0, q & 3), qv4 = __builtin_amdgcn_alignbyte(u2, u1, q & 3);
+							okA[j] = qok && qv == v;
+							const uint32_t x = qv4 ^ v4;
+							uint32_t lenA = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
+							if (!FULL && lenA > maxlen) lenA = maxlen;
+							raw8[j] = okA[j] && lenA == 8;              // at least 8 bytes
+							lng[j] = raw8[j] && (FULL || maxlen > 8);   // ... and possibly more
+							mw |= (okA[j] ? lenA - 3 : 0) << (8 * j);
+							const uint32_t cj = okA[j] ? dA[j] : NOHASH;
+							if (j < 2) c01 |= cj << (16 * j); else c23 |= cj << (16 * (j - 2));
+							vbits |= (uint32_t)okA[j] << j;
+						}
+						// Long positions whose successor (the next verified position) is one of my four
+						// are settled right here: member of its chain if the distance is the same -- N =
+						// N(successor) + gap, which for a direct successor with less than 8 bytes is the 8
+						// stored above -- tail otherwise.  Tails and the long position whose successor
+						// lies beyond my four go to the queue.
+						bool has = false, nraw = false;
+						uint32_t nd = 0, nj = 4;
+#pragma unroll
+						for (int j = 3; j >= 0; j--) {
+							if (lng[j]) {
+								if (has && dA[j] == nd) { if (nj - j > 1 || nraw) kbits |= ((1u << (nj - j)) - 1) << j; }
+								else qbits |= 1u << j;
+							}
+							if (okA[j]) { has = true; nd = dA[j]; nj = j; nraw = raw8[j]; }
+						}
+						*(uint32_t *)(mlen + i4) = mw;
+						*(uint2 *)(cand + i4) = make_uint2(c01, c23);
+						if (vbits) atomicOr(&vb[i4 >> 5], vbits << (i4 & 31));
+						if (kbits) atomicOr(&kb[i4 >> 5], kbits << (i4 & 31));
+					};
+					if (ib + 256 <= tn && h + tb0 + ib + 256 + MAXMATCH + 8 <= end) quad(std::true_type{});
+					else quad(std::false_type{});
+					// queue entry: quad number | position bits
+					const unsigned long long m = __ballot(qbits != 0);
 					if (m) {
-						if (needs) queue[qcnt + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
-						qcnt += (uint32_t)__popcll(m);
+						if (qbits) lq[lqn + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((i4 >> 2) | qbits << 12);
+						lqn += (uint32_t)__popcll(m);
 						__builtin_amdgcn_wave_barrier();
-						if (qcnt >= 64) { unsigned long long w2_ = prof ? clock64() : 0; stage2(qcnt); qcnt -= 64; if (prof && wave == 1 && lane == 0) atomicAdd(&prof[18], clock64() - w2_); }
+						if (lqn >= 64) { stage2(lqn); lqn -= 64; }
 					}
 				}
-				if (prof && wave == 1 && lane == 0) { atomicAdd(&prof[17], clock64() - w1_); atomicAdd(&prof[19], 1ull); }
-				if (prof && lane == 0) { atomicAdd(&prof[40 + wave], 1ull); }
 			}
-			PROF(20);
-			if (prof && lane == 0) atomicAdd(&prof[24 + wave], clock64() - tphase_);
-			if (qcnt) stage2(qcnt);
-			PROF(21);
-			if (lqn) longext(lqn);
-			PROF(22);
-			if (prof && lane == 0) atomicAdd(&prof[48 + wave], clock64() - tphase_);
+			if (lqn) stage2(lqn);
 		}
 		__syncthreads();                                       // the long-tail queues live where the flags go
 		PROF(23);
@@ -745,8 +826,8 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		__syncthreads();
 		for (uint32_t s = t; s < NSEG; s += NT) mark[s] = 0;
 		__syncthreads();
-		if (nxz_debug_buf && blockIdx.x == 0)
-			for (uint32_t i = t; i < tn; i += NT) nxz_debug_buf[(tb0 / PTILE) * 65536 + i] = cand[i] | ((uint32_t)mlen[i] << 16);
+		if (dbg && blockIdx.x == 0)
+			for (uint32_t i = t; i < tn; i += NT) dbg[(tb0 / PTILE) * 65536 + i] = cand[i] | ((uint32_t)mlen[i] << 16);
 
 		PROF(5);
 		// ---- parse pass 1: speculative walk of segment s from its own start ----
@@ -825,8 +906,8 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		if (entered && myx < tn) entry[myx / PSEG] = (uint16_t)myx;
 		__syncthreads();
 		uint32_t mye = entered ? entry[t] : 0;
-		if (nxz_debug_buf && blockIdx.x == 0 && (uint32_t)t < nseg)
-			nxz_debug_buf[(tb0 / PTILE) * 65536 + 16384 + t] = myx | (mye << 16) | (entered ? 0x80000000u : 0);
+		if (dbg && blockIdx.x == 0 && (uint32_t)t < nseg)
+			dbg[(tb0 / PTILE) * 65536 + 16384 + t] = myx | (mye << 16) | (entered ? 0x80000000u : 0);
 		// token bitmaps (alias mark/jump, which are dead now) are cleared
 		for (uint32_t i = t; i < PTILE / 32; i += NT) mbits[i] = 0;
 		__syncthreads();
@@ -1051,7 +1132,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		uint32_t tpbc = (uint32_t)((totbits + 7) >> 3);
 		if (tpbc > job.dst_cap) cc = cc ? cc : NXZ_CC_TARGET_SPACE;
 		if (cc != NXZ_CC_TARGET_SPACE) {
-			uint8_t *o = job.dst + (size_t)wordbase * 4;
+			NXZ_GLOBAL uint8_t *o = (NXZ_GLOBAL uint8_t *)job.dst + (size_t)wordbase * 4;
 			for (uint32_t k = 0; k < (bits + 7) / 8; k++) o[k] = (uint8_t)(acc >> (8 * k));
 		}
 		if (cc == 0 && tpbc > total) cc = NXZ_CC_TPBC_GT_SPBC;

@@ -26,9 +26,7 @@ torch.cuda.synchronize()
 eng.L.nxz_prof_set(None)
 p = prof.cpu().numpy().astype(np.float64) / n
 tot = p[:16].sum() + p[20:24].sum()
-print("wave0: loop-after-chain %.0f final-stage2 %.0f final-longext %.0f barrier %.0f" % tuple(p[20:24]))
-print("per-wave loop end / final end / pieces:", " ".join("%.0f/%.0f/%.1f" % (p[24+w], p[48+w], p[40+w]) for w in range(16)))
-print("wave1: wait %.0f  pieces(M1+M2) %.0f  of which stage2 %.0f  pieces %.1f" % (p[16], p[17], p[18], p[19]))
+print("wave1: stage2 calls %.1f  long tails %.1f  longext cycles %.0f  stage2 cycles (incl longext) %.0f" % (p[16], p[17], p[18], p[19]))
 for i, name in enumerate(NAMES):
     print("%-20s %10.0f cycles/block  %5.1f%%" % (name, p[i], 100 * p[i] / tot))
 print("total %.0f cycles/block (s_memtime ticks = 100 MHz? see guide)" % tot)
