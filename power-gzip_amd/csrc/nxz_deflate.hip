@@ -307,18 +307,42 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		if (n && sidx >= (int)(h >> 6)) {
 			const uint4 *sp = (const uint4 *)(lds + OFF_IN + (uint32_t)sidx * 64);
 			uint4 q[4] = { sp[0], sp[1], sp[2], sp[3] };
-			const uint32_t *w = (const uint32_t *)q;
+			uint32_t *w = (uint32_t *)q;
+			const uint32_t a0 = (uint32_t)sidx * 64;                // LDS address of the slice
+			if (a0 < h || a0 + 64 > end) {
+				// first / last slice: dwords of the history or past the end are not part of the stream
+#pragma unroll
+				for (int k = 0; k < 16; k++)
+					if (a0 + 4 * k < h || a0 + 4 * k + 4 > end) w[k] = 0;
+			}
+			// Adler: S = sum of the bytes, Wt = sum of byte * (offset in the slice); a byte at stream
+			// offset i weighs (n - i) in the second sum
+			uint32_t S = 0, Wt = 0;
 #pragma unroll
 			for (int k = 0; k < 16; k++) {
-				uint32_t a = (uint32_t)sidx * 64 + 4 * k;           // LDS address of this dword
-				uint32_t v = w[k];
-				if (a < h || a + 4 > end) continue;                 // history / past the end: not part of the stream
-				uint32_t i = a - h;
-				uint32_t b0 = v & 0xff, b1 = (v >> 8) & 0xff, b2 = (v >> 16) & 0xff, b3 = v >> 24;
-				s1 += b0 + b1 + b2 + b3;
-				sj += (b0 + b1 + b2 + b3) * (n - i) - (b1 + 2 * b2 + 3 * b3);
-				uint32_t c = crc ^ v ^ (i == 0 ? initx : 0);
-				crc = T[768 + (c & 0xff)] ^ T[512 + ((c >> 8) & 0xff)] ^ T[256 + ((c >> 16) & 0xff)] ^ T[c >> 24];
+				S = __builtin_amdgcn_udot4(w[k], 0x01010101u, S, false);
+				Wt = __builtin_amdgcn_udot4(w[k], 0x03020100u + 0x04040404u * k, Wt, false);
+			}
+			s1 = S;
+			sj = S * (n + h - a0) - Wt;
+			// CRC: zero dwords in front of the first data dword leave a zero state alone (the history
+			// is a multiple of 16 bytes, so the stream starts at dword 0, 4, 8 or 12 of its slice);
+			// past the end only thread 1023 has dwords, and they come last
+			const uint32_t kfirst = a0 < h ? (h - a0) >> 2 : 0;
+			if (a0 <= h && h < a0 + 64) {
+				if (h + 4 <= end) {
+					if (kfirst == 0) w[0] ^= initx;
+					if (kfirst == 4) w[4] ^= initx;
+					if (kfirst == 8) w[8] ^= initx;
+					if (kfirst == 12) w[12] ^= initx;
+				}
+			}
+			const uint32_t nd = a0 + 64 <= end ? 16 : (end - a0) >> 2;   // full data dwords in my slice
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const uint32_t c = crc ^ w[k];
+				const uint32_t nc = T[768 + (c & 0xff)] ^ T[512 + ((c >> 8) & 0xff)] ^ T[256 + ((c >> 16) & 0xff)] ^ T[c >> 24];
+				crc = (uint32_t)k < nd ? nc : crc;
 			}
 			if (t == 1023 && (end & 3)) {
 				// the last 1..3 bytes of the stream
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				uint32_t b0 = v & 0xff, b1 = (v >> 8) & 0xff, b2 = (v >> 16) & 0xff;
 				s1 += b0 + b1 + b2;
 				sj += (b0 + b1 + b2) * (n - i) - (b1 + 2 * b2);
-				if (i == 0) crc ^= initx;
+				if (i == 0) crc ^= initx;                           // stream shorter than 4 bytes
 				for (uint32_t k = 0; k < nb; k++) crc = T[(crc ^ (v >> (8 * k))) & 0xff] ^ (crc >> 8);
 			}
 		}
@@ -446,8 +470,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			// Per 64-position step: look the slot up, insert (max wins).  The LDS executes one wave's
 			// operations in order, so lookup(k+1) only has to be ISSUED after insert(k); nothing waits
 			// for a result inside a piece.  The slot offsets of the next piece are fetched ahead and
-			// the candidate positions of the previous piece (16 bit; an empty slot gives 0xffff, which
-			// no position can use) are written one piece late, so no LDS round trip is exposed.
+			// the candidate positions of the previous piece (16 bit) are written one piece late, so no LDS round trip is exposed.
 			// Publishing needs no wait either: the flag store follows the data stores in LDS order.
 			const uint8_t *headb = (const uint8_t *)head;
 			__builtin_amdgcn_s_setprio(3);                    // the chain is the critical path of this phase
@@ -466,9 +489,9 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				}
 			};
 			auto emit = [&](uint32_t (&o)[8], uint32_t piece) {
-#pragma unroll
-				for (int u = 0; u < 8; u++) o[u] = (o[u] - 1) & 0xffff;
-				((uint4 *)cand)[(piece << 6) + lane] = make_uint4(o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | o[5] << 16, o[6] | o[7] << 16);
+				// position + 1 (0 = empty slot), 16 bits each; the consumer subtracts the 1
+				((uint4 *)cand)[(piece << 6) + lane] = make_uint4(__builtin_amdgcn_perm(o[1], o[0], 0x05040100), __builtin_amdgcn_perm(o[3], o[2], 0x05040100),
+										  __builtin_amdgcn_perm(o[5], o[4], 0x05040100), __builtin_amdgcn_perm(o[7], o[6], 0x05040100));
 				__builtin_amdgcn_wave_barrier();
 				if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				__builtin_amdgcn_wave_barrier();
@@ -644,7 +667,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 						uint32_t dA[4];
 #pragma unroll
 						for (int j = 0; j < 4; j++) {
-							const uint32_t qc = ((j & 2 ? qq.y : qq.x) >> (16 * (j & 1))) & 0xffff;   // candidate position from the chain
+							const uint32_t qc = (uint16_t)((uint16_t)((j & 2 ? qq.y : qq.x) >> (16 * (j & 1))) - 1);   // candidate position from the chain (0xffff = none)
 							const uint32_t i = i4 + j, r = r4 + j;
 							const bool ok = FULL || (i < tn && r + 4 <= end);
 							const uint32_t maxlen = FULL || end - r >= MAXMATCH ? MAXMATCH : end - r;
