@@ -543,7 +543,8 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		uint32_t *vb = sbits;                                 // bitmap: position has a verified candidate
 		{
 			uint16_t *lq = (uint16_t *)(lds + OFF_X) + wave * 128;          // long positions: quad number | position bits << 12
-			uint16_t *xq = (uint16_t *)(lds + OFF_X + 4096) + wave * 64;    // tails beyond LCAP
+			uint16_t *xq = (uint16_t *)(lds + OFF_X + 4096) + wave * 128;   // tails beyond LCAP
+			uint32_t xqn = 0;
 			uint32_t lqn = 0;
 			// tails that are still equal after LCAP bytes: 16 lanes per tail, 64 bytes per step
 			auto longext = [&](uint32_t nl) {
@@ -622,13 +623,12 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					}
 				}
 				const unsigned long long ml = __ballot(lg);
-				if (prof && wave == 1 && lane == 0) { __hip_atomic_fetch_add(&prof[16], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(&prof[17], (unsigned long long)__popcll(ml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 				if (ml) {
-					if (lg) xq[__popcll(ml & ((1ull << lane) - 1))] = (uint16_t)i;
+					// collected until a few rounds of four are worth the trip
+					if (lg) xq[xqn + __popcll(ml & ((1ull << lane) - 1))] = (uint16_t)i;
+					xqn += (uint32_t)__popcll(ml);
 					__builtin_amdgcn_wave_barrier();
-					unsigned long long w0_ = prof ? clock64() : 0;
-					longext((uint32_t)__popcll(ml));
-					if (prof && wave == 1 && lane == 0) __hip_atomic_fetch_add(&prof[18], clock64() - w0_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (xqn >= 16) { longext(xqn); xqn = 0; }
 				}
 				}
 			};
@@ -688,21 +688,17 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 							if (j < 2) c01 |= cj << (16 * j); else c23 |= cj << (16 * (j - 2));
 							vbits |= (uint32_t)okA[j] << j;
 						}
-						// Long positions whose successor (the next verified position) is one of my four
-						// are settled right here: member of its chain if the distance is the same -- N =
-						// N(successor) + gap, which for a direct successor with less than 8 bytes is the 8
-						// stored above -- tail otherwise.  Tails and the long position whose successor
-						// lies beyond my four go to the queue.
-						bool has = false, nraw = false;
-						uint32_t nd = 0, nj = 4;
+						// A long position whose direct successor is one of my four, verified and at the same
+						// distance, is settled right here: N = N(successor) + 1, which is the 8 stored above
+						// unless the successor has 8 bytes too -- then it is a member of the successor's
+						// chain.  Every other long position goes to the queue.
 #pragma unroll
-						for (int j = 3; j >= 0; j--) {
-							if (lng[j]) {
-								if (has && dA[j] == nd) { if (nj - j > 1 || nraw) kbits |= ((1u << (nj - j)) - 1) << j; }
-								else qbits |= 1u << j;
-							}
-							if (okA[j]) { has = true; nd = dA[j]; nj = j; nraw = raw8[j]; }
+						for (int j = 0; j < 3; j++) {
+							const bool direct = okA[j + 1] && dA[j] == dA[j + 1];
+							kbits |= (uint32_t)(lng[j] && direct && raw8[j + 1]) << j;
+							qbits |= (uint32_t)(lng[j] && !direct) << j;
 						}
+						qbits |= (uint32_t)lng[3] << 3;
 						*(uint32_t *)(mlen + i4) = mw;
 						*(uint2 *)(cand + i4) = make_uint2(c01, c23);
 						if (vbits) atomicOr(&vb[i4 >> 5], vbits << (i4 & 31));
@@ -721,9 +717,10 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				}
 			}
 			if (lqn) stage2(lqn);
+			if (xqn) longext(xqn);
 		}
 		__syncthreads();                                       // the long-tail queues live where the flags go
-		PROF(23);
+		PROF(12);
 		// ---- M3a: e(x) = "byte x equals byte x-1" flags for the tile and 288 positions beyond ----
 		{
 			uint16_t *eb16 = (uint16_t *)bitbuf;
@@ -782,15 +779,25 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		const uint32_t p0 = (uint32_t)t * PSEG;
 		// first clear bit of a bitmap at or after bit s (below limit)
 		auto first_zero = [](const uint32_t *bm, uint32_t s0, uint32_t limit) -> uint32_t {
-			uint32_t wi = s0 >> 5;
-			uint32_t w = ~bm[wi] & (~0u << (s0 & 31));
-			while (!w) {
-				wi++;
+			// 128 bits per LDS round trip
+			uint32_t wi = (s0 >> 5) & ~3u;
+			uint4 q = *(const uint4 *)(bm + wi);
+			// bits below s0 count as set
+			const uint32_t sw = (s0 >> 5) & 3, lowmask = ~(~0u << (s0 & 31));
+			uint32_t w0 = ~q.x, w1 = ~q.y, w2 = ~q.z, w3 = ~q.w;
+			if (sw > 0) w0 = 0; if (sw > 1) w1 = 0; if (sw > 2) w2 = 0;
+			if (sw == 0) w0 &= ~lowmask; else if (sw == 1) w1 &= ~lowmask; else if (sw == 2) w2 &= ~lowmask; else w3 &= ~lowmask;
+			for (;;) {
+				if (w0 | w1 | w2 | w3) {
+					const uint32_t pos = wi * 32 + (w0 ? (uint32_t)__builtin_ctz(w0) : w1 ? 32 + (uint32_t)__builtin_ctz(w1)
+								  : w2 ? 64 + (uint32_t)__builtin_ctz(w2) : 96 + (uint32_t)__builtin_ctz(w3));
+					return pos < limit ? pos : limit;
+				}
+				wi += 4;
 				if (wi * 32 >= limit) return limit;
-				w = ~bm[wi];
+				q = *(const uint4 *)(bm + wi);
+				w0 = ~q.x; w1 = ~q.y; w2 = ~q.z; w3 = ~q.w;
 			}
-			const uint32_t pos = wi * 32 + (uint32_t)__builtin_ctz(w);
-			return pos < limit ? pos : limit;
 		};
 		if (p0 < tn) {
 			// members of my 16 positions, last to first: N = (end of the chain) - position; the chain

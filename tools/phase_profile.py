@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench
 pkg = importlib.import_module("power-gzip_amd")
-NAMES = ["load", "cksum", "seed+hdr", "hash", "chain", "M3b dist-1 runs", "pass1", "mark", "pass2", "(tail)", "match(M1+M2)+eflags", "M3a members", "enc-count+scan", "enc-clear", "enc-emit", "enc-flush"]
+NAMES = ["load", "cksum", "seed+hdr", "hash", "chain (wave 0)", "M3b dist-1 runs", "pass1", "mark", "pass2", "(tail)", "e-flags + piece links", "M3a members", "match after the chain", "enc-clear", "enc-emit", "enc-flush"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = pkg.Engine(0)
 src = bench.gen_blocks(torch, eng.dev, n, 0)
@@ -25,8 +25,7 @@ eng.compress(pkg.FC_COMPRESS_FHT, jobs, n)
 torch.cuda.synchronize()
 eng.L.nxz_prof_set(None)
 p = prof.cpu().numpy().astype(np.float64) / n
-tot = p[:16].sum() + p[20:24].sum()
-print("wave1: stage2 calls %.1f  long tails %.1f  longext cycles %.0f  stage2 cycles (incl longext) %.0f" % (p[16], p[17], p[18], p[19]))
+tot = p[:16].sum()
 for i, name in enumerate(NAMES):
     print("%-20s %10.0f cycles/block  %5.1f%%" % (name, p[i], 100 * p[i] / tot))
 print("total %.0f cycles/block (s_memtime ticks = 100 MHz? see guide)" % tot)
