@@ -32,6 +32,29 @@ def make_block(kind: str, n: int, seed: int = 0) -> bytes:
             for _ in range(ln):
                 buf.append(buf[-dist])
         return bytes(buf[:n])
+    if kind == "periodic":
+        # a short random period repeated: every position sits inside one very long match
+        period = rnd.choice([2, 3, 5, 7, 63, 64, 65, 300, 511, 512, 513, 4099])
+        unit = rnd.randbytes(period)
+        return (unit * (n // period + 1))[:n]
+    if kind == "binary":
+        # two symbols in runs: every hash slot collides, runs of all lengths
+        out = bytearray()
+        while len(out) < n:
+            out += bytes([rnd.choice(b"ab")]) * rnd.choice([1, 1, 2, 3, 4, 5, 8, 9, 17, 40, 41, 260, 600])
+        return bytes(out[:n])
+    if kind == "sparse":
+        # long copies of far-away text with single-byte edits: long matches, broken chains,
+        # candidates that change in the middle of a match
+        buf = bytearray(rnd.choices(ALPHABET33, k=max(1, n // 4)))
+        while len(buf) < n:
+            src = rnd.randrange(0, len(buf))
+            ln = rnd.choice([9, 12, 24, 39, 40, 41, 72, 258, 259, 300, 700, 1500])
+            chunk = bytearray(buf[src:src + ln])
+            if chunk and rnd.random() < 0.5:
+                chunk[rnd.randrange(len(chunk))] ^= 1
+            buf += chunk
+        return bytes(buf[:n])
     raise ValueError(kind)
 
 

@@ -41,6 +41,9 @@ BLOCK_CASES = [("zeros", 65536), ("text33", 65536), ("lz", 65536), ("random", 65
                ("text33", 17), ("text33", 63), ("text33", 64), ("text33", 65), ("lz", 2047), ("lz", 2048),
                ("lz", 2049), ("lz", 16383), ("lz", 16384), ("lz", 16385), ("alice", 40000), ("zeros", 300),
                ("zeros", 16384), ("random", 5000), ("lz", 65535), ("alice", 32768), ("lz", 49152)]
+# long matches, broken chains, piece (512) and tile (16384) boundaries
+BLOCK_CASES += [("periodic", 65536)] * 12 + [("binary", 65536)] * 6 + [("sparse", 65536)] * 12 + \
+               [("periodic", 16384 + 511), ("periodic", 513), ("binary", 16385), ("sparse", 33000), ("sparse", 511), ("sparse", 1025)]
 
 
 def test_fixed_huffman_bit_exact(eng):
