@@ -1010,13 +1010,15 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					p += run;
 					continue;
 				}
-				// one token per lane; literal and match share one (select based) code path so that a
-				// wave with both kinds does not execute two divergent branches
+				// one token per lane -- or two, if both are literals; literal and match share one
+				// (select based) code path so that a wave with both kinds does not execute two
+				// divergent branches: a match fills both puts, a literal pair one each
 				bool m;
 				uint32_t l;
 				if (k < 16) l = seg_step(p, lim, m);
 				else l = walk_step(W, p, lim, m);                 // beyond my segment (unsynchronised range): LDS data
-				const uint32_t byte = lds[OFF_IN + h + tb0 + p], d = cand[p];
+				const bool two = !m && k < 15 && !((seg_nz >> (k + 1)) & 1) && p + 1 < lim;   // the next position is a literal for sure
+				const uint32_t byte = lds[OFF_IN + h + tb0 + p], byte2 = lds[OFF_IN + h + tb0 + p + 1], d = cand[p];
 				const uint32_t l3 = l - 3;
 				uint32_t le = l3 < 8 ? 0 : (29 - __builtin_clz(l3 | 8));
 				const uint32_t ls = l3 == 255 ? 28 : (le << 2) + (l3 >> le);
@@ -1024,11 +1026,12 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				uint32_t de = d < 4 ? 0 : (30 - __builtin_clz(d | 4));
 				const uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
 				if (!m) { le = 0; de = 0; }
-				const uint32_t lt = lltab[m ? 257 + ls : byte], dt = m ? dtab[ds & 31] : 0;
+				const uint32_t lt = lltab[m ? 257 + ls : byte];
+				const uint32_t dt = m ? dtab[ds & 31] : two ? lltab[byte2] : 0;   // second put: distance code or second literal
 				const uint32_t ll = lt >> 16, dl = dt >> 16;
-				if (DHT && (ll == 0 || (m && dl == 0))) misc[M_ERR] = NXZ_CC_MISSING_CODE;
+				if (DHT && (ll == 0 || ((m || two) && dl == 0))) misc[M_ERR] = NXZ_CC_MISSING_CODE;
 				put((lt & 0xffff) | ((l3 & ((1u << le) - 1)) << ll), ll + le);               // <= 20 bits
-				put((dt & 0xffff) | ((d & ((1u << de) - 1)) << dl), dl + de);                // <= 28 bits (0 for a literal)
+				put((dt & 0xffff) | ((d & ((1u << de) - 1)) << dl), dl + de);                // <= 28 bits (0 for a single literal)
 				mine += ll + le + dl + de;
 				if (m) {
 					atomicOr(&mbits[p >> 5], 1u << (p & 31));
@@ -1037,8 +1040,9 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				if (COUNT) {
 					atomicAdd(&hist[m ? 257 + ls : byte], 1u);
 					if (m) atomicAdd(&hist[286 + ds], 1u);
+					if (two) atomicAdd(&hist[byte2], 1u);
 				}
-				p += l;
+				p += l + (uint32_t)two;
 			}
 			lpart = (uint32_t)acc;
 			loverflow |= nwords > 8 || (nwords == 8 && accn != 0);

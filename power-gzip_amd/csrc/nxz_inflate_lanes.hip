@@ -447,43 +447,157 @@ __device__ __forceinline__ uint32_t xpow8(uint32_t n)
 	return r;
 }
 
+// x^(512 k) mod P for k = 0..1023 (compile time): the weight of a 64-byte slice that is followed by k more slices
+constexpr uint32_t cgf_mul(uint32_t a, uint32_t b)
+{
+	uint32_t r = 0;
+	for (int i = 0; i < 32; i++) {
+		if (b & 0x80000000u) r ^= a;
+		a = (a >> 1) ^ ((a & 1) ? 0xedb88320u : 0);
+		b <<= 1;
+	}
+	return r;
+}
+struct PowTab { uint32_t v[1024]; };
+constexpr PowTab make_pow()
+{
+	PowTab p{};
+	uint32_t m = 0x00800000u;                 // x^8
+	for (int k = 0; k < 6; k++) m = cgf_mul(m, m);   // x^512
+	p.v[0] = 0x80000000u;
+	for (int i = 1; i < 1024; i++) p.v[i] = cgf_mul(p.v[i - 1], m);
+	return p;
+}
+__device__ const PowTab CRC_POW = make_pow();
+
+// CRC-32 and Adler-32 of every job's output (results[].tpbc bytes at job.dst), continued from
+// job.in_crc / job.in_adler.  One workgroup per job; the output is cut into 64 KiB chunks and
+// those into 64-byte slices: a thread feeds its slices through a slice-by-4 table (16-byte
+// loads, v_dot4 for the Adler sums), weighs a slice's raw CRC by x^(8 * bytes that follow it in
+// the chunk), and the XOR of all of them is the chunk's raw CRC (same scheme as the deflate
+// kernel, nxz_deflate.hip).  Outputs that are not 16-byte aligned take the bytewise path.
 __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__restrict__ jobs, nxz_batch_result_t *__restrict__ results)
 {
-	__shared__ uint32_t tab[256];
+	__shared__ uint32_t T[1024];            // T[k*256 + i] = i advanced by k+1 zero bytes
 	__shared__ uint32_t red[3][256];
-	const int t = threadIdx.x;
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const nxz_batch_job_t job = jobs[blockIdx.x];
 	const uint32_t n = results[blockIdx.x].tpbc;
-	{
+	for (int k = 0; k < 4; k++) {
 		uint32_t c = t;
-		for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1) ? 0xedb88320u : 0);
-		tab[t] = c;
+		for (int i = 0; i < 8 * (k + 1); i++) c = (c >> 1) ^ ((c & 1) ? 0xedb88320u : 0);
+		T[k * 256 + t] = c;
 	}
 	__syncthreads();
 	const uint8_t *p = job.dst;
-	uint32_t per = ((n + 255) / 256 + 15) & ~15u;
-	uint32_t lo = (uint32_t)t * per, hi = lo + per < n ? lo + per : n;
-	uint32_t crc = 0, s1 = 0, s2 = 0;
-	for (uint32_t i = lo; i < hi; i++) {
-		uint32_t byte = p[i];
-		crc = tab[(crc ^ byte) & 0xff] ^ (crc >> 8);
-		s1 += byte; s2 += s1;
-		if ((i & 0xfff) == 0xfff) { s1 %= 65521u; s2 %= 65521u; }
-	}
-	red[0][t] = crc; red[1][t] = s1 % 65521u; red[2][t] = s2 % 65521u;
-	__syncthreads();
-	if (t == 0) {
-		uint32_t c = job.in_crc ^ 0xffffffffu, a1 = job.in_adler & 0xffff, a2 = job.in_adler >> 16;
-		uint32_t xp = xpow8(per);
-		for (uint32_t k = 0; k < 256; k++) {
-			uint32_t klo = k * per; if (klo >= n) break;
-			uint32_t len = klo + per < n ? per : n - klo;
-			c = gf_mul(c, len == per ? xp : xpow8(len)) ^ red[0][k];
-			a2 = (uint32_t)((a2 + (uint64_t)len * a1 + red[2][k]) % 65521u);
-			a1 = (a1 + red[1][k]) % 65521u;
+	if ((uintptr_t)p & 15) {
+		// bytewise: 256 contiguous pieces
+		uint32_t per = ((n + 255) / 256 + 15) & ~15u;
+		uint32_t lo = (uint32_t)t * per, hi = lo + per < n ? lo + per : n;
+		uint32_t crc = 0, s1 = 0, s2 = 0;
+		for (uint32_t i = lo; i < hi; i++) {
+			uint32_t byte = p[i];
+			crc = T[(crc ^ byte) & 0xff] ^ (crc >> 8);
+			s1 += byte; s2 += s1;
+			if ((i & 0xfff) == 0xfff) { s1 %= 65521u; s2 %= 65521u; }
 		}
-		results[blockIdx.x].crc = c ^ 0xffffffffu;
-		results[blockIdx.x].adler = (a2 << 16) | a1;
+		red[0][t] = crc; red[1][t] = s1 % 65521u; red[2][t] = s2 % 65521u;
+		__syncthreads();
+		if (t == 0) {
+			uint32_t c = job.in_crc ^ 0xffffffffu, a1 = job.in_adler & 0xffff, a2 = job.in_adler >> 16;
+			uint32_t xp = xpow8(per);
+			for (uint32_t k = 0; k < 256; k++) {
+				uint32_t klo = k * per; if (klo >= n) break;
+				uint32_t len = klo + per < n ? per : n - klo;
+				c = gf_mul(c, len == per ? xp : xpow8(len)) ^ red[0][k];
+				a2 = (uint32_t)((a2 + (uint64_t)len * a1 + red[2][k]) % 65521u);
+				a1 = (a1 + red[1][k]) % 65521u;
+			}
+			results[blockIdx.x].crc = c ^ 0xffffffffu;
+			results[blockIdx.x].adler = (a2 << 16) | a1;
+		}
+		return;
+	}
+	uint32_t c_run = job.in_crc ^ 0xffffffffu, a1_run = job.in_adler & 0xffff, a2_run = job.in_adler >> 16;   // thread 0
+	for (uint32_t base = 0; base < n; base += 65536) {
+		const uint32_t len = n - base < 65536 ? n - base : 65536;
+		const uint32_t K1 = (len - 1) >> 6, r = len - K1 * 64;        // last slice and its bytes (1..64)
+		uint32_t crc_w = 0, tailcrc = 0, s1 = 0, s2 = 0;
+		for (uint32_t sl = t; sl <= K1; sl += 256) {
+			const uint4 *sp = (const uint4 *)(p + base + (size_t)sl * 64);
+			const uint32_t nb = sl < K1 ? 64 : r;                     // data bytes in this slice
+			uint4 q[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				q[k] = make_uint4(0, 0, 0, 0);
+				if (16u * k < nb) {
+					if ((size_t)base + (size_t)sl * 64 + 16 * k + 16 <= job.dst_cap) q[k] = sp[k];
+					else {                                          // never read past the caller's buffer
+						const uint8_t *bp = (const uint8_t *)&sp[k];
+						uint32_t ww[4] = { 0, 0, 0, 0 };
+#pragma unroll
+						for (int b = 0; b < 16; b++)
+							if (16u * k + b < nb) ww[b >> 2] |= (uint32_t)bp[b] << (8 * (b & 3));
+						q[k] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+					}
+				}
+			}
+			uint32_t *w = (uint32_t *)q;
+			if (nb < 64) {
+#pragma unroll
+				for (int k = 0; k < 16; k++) {
+					if (4u * k >= nb) w[k] = 0;
+					else if (4u * k + 4 > nb) w[k] &= (1u << (8 * (nb & 3))) - 1;
+				}
+			}
+			uint32_t S = 0, Wt = 0;
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				S = __builtin_amdgcn_udot4(w[k], 0x01010101u, S, false);
+				Wt = __builtin_amdgcn_udot4(w[k], 0x03020100u + 0x04040404u * k, Wt, false);
+			}
+			s1 += S;
+			s2 = (s2 + S * (len - sl * 64) - Wt) % 65521u;
+			uint32_t crc = 0;
+			const uint32_t nd = nb >> 2;                               // full dwords
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const uint32_t c = crc ^ w[k];
+				const uint32_t nc = T[768 + (c & 0xff)] ^ T[512 + ((c >> 8) & 0xff)] ^ T[256 + ((c >> 16) & 0xff)] ^ T[c >> 24];
+				crc = (uint32_t)k < nd ? nc : crc;
+			}
+			if (nb & 3) {
+				uint32_t v = 0;                                     // w[nd] without a dynamic index (that would put w[] in scratch)
+#pragma unroll
+				for (int k = 0; k < 16; k++) v = (uint32_t)k == nd ? w[k] : v;
+				for (uint32_t k = 0; k < (nb & 3); k++) crc = T[(crc ^ (v >> (8 * k))) & 0xff] ^ (crc >> 8);
+			}
+			if (sl == K1) tailcrc = crc;
+			else crc_w ^= gf_mul(crc, CRC_POW.v[K1 - 1 - sl]);
+		}
+		for (int o = 32; o > 0; o >>= 1) {
+			crc_w ^= __shfl_down(crc_w, o, 64);
+			tailcrc ^= __shfl_down(tailcrc, o, 64);
+			s1 += __shfl_down(s1, o, 64);
+			s2 += __shfl_down(s2, o, 64);
+		}
+		__syncthreads();
+		if (lane == 0) { red[0][wave] = crc_w; red[0][4 + wave] = tailcrc; red[1][wave] = s1; red[2][wave] = s2 % 65521u; }
+		__syncthreads();
+		if (t == 0) {
+			const uint32_t full = red[0][0] ^ red[0][1] ^ red[0][2] ^ red[0][3];
+			const uint32_t tail = red[0][4] ^ red[0][5] ^ red[0][6] ^ red[0][7];
+			const uint32_t chunk = gf_mul(full, xpow8(r)) ^ tail;          // raw CRC of the chunk
+			c_run = gf_mul(c_run, xpow8(len)) ^ chunk;
+			const uint32_t b1 = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) % 65521u;
+			const uint32_t b2 = (red[2][0] + red[2][1] + red[2][2] + red[2][3]) % 65521u;
+			a2_run = (uint32_t)((a2_run + (uint64_t)len * a1_run + b2) % 65521u);
+			a1_run = (a1_run + b1) % 65521u;
+		}
+	}
+	if (t == 0) {
+		results[blockIdx.x].crc = c_run ^ 0xffffffffu;
+		results[blockIdx.x].adler = (a2_run << 16) | a1_run;
 	}
 }
 

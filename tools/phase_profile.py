@@ -26,6 +26,7 @@ torch.cuda.synchronize()
 eng.L.nxz_prof_set(None)
 p = prof.cpu().numpy().astype(np.float64) / n
 tot = p[:16].sum()
+print("pass2 wave-steps per block: literal-only %.0f, general %.0f (avg active lanes %.1f)" % (p[16], p[17], p[18] / max(p[17], 1)))
 for i, name in enumerate(NAMES):
     print("%-20s %10.0f cycles/block  %5.1f%%" % (name, p[i], 100 * p[i] / tot))
 print("total %.0f cycles/block (s_memtime ticks = 100 MHz? see guide)" % tot)
