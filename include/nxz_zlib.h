@@ -54,6 +54,14 @@ unsigned long nx_adler32(unsigned long adler, const unsigned char *buf, size_t l
 unsigned long nx_crc32_combine(unsigned long crc1, unsigned long crc2, off_t len2);
 unsigned long nx_adler32_combine(unsigned long adler1, unsigned long adler2, off_t len2);
 
+/* Dynamic-Huffman table builder, bit for bit what dhtgen() of lib/nx_dhtgen.c:945-1034 produces
+ * (pinned by tests/golden/dhtgen_vectors.json), and a batched form for the device-resident path
+ * (additive): counts = n x 316 words as the COUNT function codes write them, tables = n x
+ * nxz_batch_dht_t (include/nxz_engine.h); zero counts are raised to 1 first (lib/nx_dhtgen.c:235). */
+int nxz_dhtgen(unsigned int *lhist, int num_lhist, unsigned int *dhist, int num_dhist,
+	       unsigned char *dht, int *dht_num_bytes, int *dht_num_valid_bits);
+int nxz_dhtgen_batch(const unsigned int *counts, size_t n, void *tables, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -254,3 +254,36 @@ extern "C" void nxz_dht_lookup(nxz_dht_state *s, const uint32_t *counts, long so
 	memcpy(dht_out, e->dht, (e->dhtlen + 7) / 8);
 	*dhtlen_out = e->dhtlen;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Batched table builder for the device-resident path: counts[n][316] (what the COUNT function
+// codes write: 286 literal/length + 30 distance counts) -> one table per job, on `nthreads` host
+// threads.  Zero counts are raised to 1 first (fill_zero_lzcounts, lib/nx_dhtgen.c:235) so that
+// a table can also code a block it was not made from.
+#include <thread>
+extern "C" int nxz_dhtgen_batch(const uint32_t *counts, size_t n, nxz_batch_dht_t *tables, int nthreads)
+{
+	if (!counts || !tables) return -1;
+	if (nthreads < 1) nthreads = 1;
+	auto work = [&](size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; i++) {
+			uint32_t ll[286], d[30];
+			memcpy(ll, counts + i * 316, sizeof(ll));
+			memcpy(d, counts + i * 316 + 286, sizeof(d));
+			ll[256] = 1;
+			nxz_fill_zero_lzcounts(ll, d, 1);
+			int nb = 0, vb = 0;
+			memset(tables[i].dht, 0, sizeof(tables[i].dht));
+			nxz_dhtgen(ll, 286, d, 30, tables[i].dht, &nb, &vb);
+			tables[i].dhtlen = (uint32_t)(nb * 8 - (vb ? 8 - vb : 0));
+		}
+	};
+	std::vector<std::thread> th;
+	const size_t per = (n + (size_t)nthreads - 1) / (size_t)nthreads;
+	for (int k = 0; k < nthreads; k++) {
+		size_t lo = (size_t)k * per, hi = lo + per < n ? lo + per : n;
+		if (lo < hi) th.emplace_back(work, lo, hi);
+	}
+	for (auto &t : th) t.join();
+	return 0;
+}

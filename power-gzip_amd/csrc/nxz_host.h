@@ -13,6 +13,7 @@ struct nxz_dht_state;
 typedef struct nxz_dht_state nxz_dht_state;
 
 void nxz_fill_zero_lzcounts(uint32_t *ll, uint32_t *d, uint32_t val);
+int  nxz_dhtgen_batch(const uint32_t *counts, size_t n, nxz_batch_dht_t *tables, int nthreads);
 int  nxz_dhtgen(uint32_t *lhist, int num_lhist, uint32_t *dhist, int num_dhist,
 		uint8_t *dht, int *dht_num_bytes, int *dht_num_valid_bits);
 nxz_dht_state *nxz_dht_begin(void);
