@@ -60,7 +60,8 @@ unsigned long nx_adler32_combine(unsigned long adler1, unsigned long adler2, off
  * nxz_batch_dht_t (include/nxz_engine.h); zero counts are raised to 1 first (lib/nx_dhtgen.c:235). */
 int nxz_dhtgen(unsigned int *lhist, int num_lhist, unsigned int *dhist, int num_dhist,
 	       unsigned char *dht, int *dht_num_bytes, int *dht_num_valid_bits);
-int nxz_dhtgen_batch(const unsigned int *counts, size_t n, void *tables, int nthreads);
+struct nxz_batch_dht;
+int nxz_dhtgen_batch(const unsigned int *counts, size_t n, struct nxz_batch_dht *tables, int nthreads);
 
 #ifdef __cplusplus
 }
