@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "nxz_device.h"
+#include "nxz_lane_io.h"
 
 namespace nxzl {
 
@@ -30,38 +31,6 @@ __device__ __forceinline__ Tab tab_at(const uint8_t *ws)
 	return Tab{ (const uint16_t *)(ws + WS_LIT), (const uint16_t *)(ws + WS_DIST), (const uint16_t *)(ws + WS_LCNT),
 		    (const uint16_t *)(ws + WS_LSYM), (const uint16_t *)(ws + WS_DCNT), (const uint16_t *)(ws + WS_DSYM) };
 }
-
-// per-lane bit reader over global memory
-struct BitRd {
-	const uint8_t *src; uint32_t srclen;
-	uint64_t bb; uint32_t bc;        // bb holds bits [pos, pos + bc)
-	uint64_t pos;                    // next unread bit
-	__device__ __forceinline__ uint64_t total() const { return (uint64_t)srclen * 8; }
-	__device__ __forceinline__ bool have(uint32_t n) const { return pos + n <= total(); }
-	__device__ __forceinline__ void sync() { bb = 0; bc = 0; }
-	__device__ __forceinline__ void fill()            // bc >= 32 afterwards (zero bits past the end)
-	{
-		if (bc >= 32) return;
-		uint64_t p2 = pos + bc;
-		uint32_t byte = (uint32_t)(p2 >> 3), sh = (uint32_t)p2 & 7;
-		uint32_t v = 0;
-		if (byte + 4 <= srclen) {
-			v = (uint32_t)src[byte] | (uint32_t)src[byte + 1] << 8 | (uint32_t)src[byte + 2] << 16 | (uint32_t)src[byte + 3] << 24;
-		} else {
-			for (uint32_t k = 0; k < 4; k++) if (byte + k < srclen) v |= (uint32_t)src[byte + k] << (8 * k);
-		}
-		bb |= (uint64_t)(v >> sh) << bc;
-		bc += 32 - sh;
-	}
-	__device__ __forceinline__ void drop(uint32_t n) { bb >>= n; bc -= n; pos += n; }
-	__device__ __forceinline__ uint32_t take(uint32_t n)      // caller checked have(n), n <= 16
-	{
-		fill();
-		uint32_t v = (uint32_t)bb & ((1u << n) - 1);
-		drop(n);
-		return v;
-	}
-};
 
 template <int FB>
 __device__ __forceinline__ int decode(const uint16_t *fast, const uint16_t *cnt, const uint16_t *symt, uint32_t bits, uint32_t &nb)
@@ -169,7 +138,8 @@ __global__ __launch_bounds__(64) void inflate_lanes_kernel(const nxz_batch_job_t
 		const uint32_t in_subc = (job.resume >> 20) & 7, in_sfbt = (job.resume >> 16) & 15, in_rem = job.resume & 0xffff;
 		if (b.srclen && in_subc) b.pos = 8 - in_subc;
 
-		uint32_t out = 0, cc = 0, o_sfbt = 0, o_subc = 0, o_rem = 0, dhtbits = 0;
+		OutWr w{ dst, 0, 0, 0, ((uintptr_t)dst & 3) == 0 };
+		uint32_t cc = 0, o_sfbt = 0, o_subc = 0, o_rem = 0, dhtbits = 0;
 		uint32_t bfinal = 0, btype = 0, rem = 0;
 		int state = active ? 0 : 3;                              // 0 header, 1 stored, 2 coded, 3 done, 4 = need table build
 		bool final_eob = false;
@@ -328,9 +298,10 @@ __global__ __launch_bounds__(64) void inflate_lanes_kernel(const nxz_batch_job_t
 					uint32_t sp = (uint32_t)(b.pos >> 3);
 					uint32_t srcleft = b.srclen - sp;
 					uint32_t k = rem < srcleft ? rem : srcleft;
-					if (k > cap - out) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
-					for (uint32_t i = 0; i < k; i++) dst[out + i] = b.src[sp + i];
-					out += k; rem -= k; b.pos = (uint64_t)(sp + k) * 8; b.sync();
+					if (k > cap - w.out) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
+					w.flush();
+					for (uint32_t i = 0; i < k; i++) dst[w.out + i] = b.src[sp + i];
+					w.out += k; rem -= k; b.pos = (uint64_t)(sp + k) * 8; b.sync();
 					if (rem) { o_sfbt = 0x8 | bfinal; o_subc = 0; o_rem = rem; state = 3; break; }
 					if (bfinal) { final_eob = true; state = 3; break; }
 					state = 0;
@@ -347,8 +318,8 @@ __global__ __launch_bounds__(64) void inflate_lanes_kernel(const nxz_batch_job_t
 					}
 					b.drop(nb);
 					if (sym < 256) {
-						if (out >= cap) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
-						dst[out++] = (uint8_t)sym;
+						if (w.out >= cap) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
+						w.lit((uint32_t)sym);
 					} else if (sym == 256) {
 						if (bfinal) { final_eob = true; state = 3; break; }
 						state = 0;
@@ -376,40 +347,29 @@ __global__ __launch_bounds__(64) void inflate_lanes_kernel(const nxz_batch_job_t
 						if (!b.have(eb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); state = 3; break; }
 						uint32_t dist = dbase + ((uint32_t)b.bb & ((1u << eb) - 1));
 						b.drop(eb);
-						if (dist > out + hist || dist > 32768) { cc = NXZ_CC_INVALID_DIST; state = 3; break; }
-						if (len > cap - out) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
-						if (dist > out) {
+						if (dist > w.out + hist || dist > 32768) { cc = NXZ_CC_INVALID_DIST; state = 3; break; }
+						if (len > cap - w.out) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
+						w.flush();
+						if (dist > w.out) {
 							// (part of) the source is in the history buffer
 							for (uint32_t i = 0; i < len; i++) {
-								int64_t sidx = (int64_t)out + i - dist;
-								dst[out + i] = sidx < 0 ? hsrc[hist + sidx] : dst[sidx];
+								int64_t sidx = (int64_t)w.out + i - dist;
+								dst[w.out + i] = sidx < 0 ? hsrc[hist + sidx] : dst[sidx];
 							}
-						} else if (dist >= 8) {
-							const uint8_t *s = dst + out - dist; uint8_t *d = dst + out;
-							uint32_t i = 0;
-							for (; i + 8 <= len; i += 8) {
-								uint8_t t0 = s[i], t1 = s[i + 1], t2 = s[i + 2], t3 = s[i + 3], t4 = s[i + 4], t5 = s[i + 5], t6 = s[i + 6], t7 = s[i + 7];
-								d[i] = t0; d[i + 1] = t1; d[i + 2] = t2; d[i + 3] = t3; d[i + 4] = t4; d[i + 5] = t5; d[i + 6] = t6; d[i + 7] = t7;
-							}
-							for (; i < len; i++) d[i] = s[i];
-						} else {
-							// short period: fetch the pattern once, then only store
-							uint64_t pat = 0;
-							for (uint32_t i = 0; i < dist; i++) pat |= (uint64_t)dst[out - dist + i] << (8 * i);
-							for (uint32_t i = 0, k = 0; i < len; i++) { dst[out + i] = (uint8_t)(pat >> (8 * k)); k = k + 1 == dist ? 0 : k + 1; }
-						}
-						out += len;
+							w.out += len;
+						} else w.copy(len, dist);
 					}
 				}
 			}
 		}
+		w.flush();
 		if (active) {
 			if (final_eob) { o_sfbt = 0; o_subc = (uint32_t)(b.total() - b.pos); }
 			nxz_batch_result_t r;
 			uint32_t spbc = job.src_len, subc = o_subc;
 			if (final_eob && subc > 0xfff8) { uint32_t drop = (subc - 0xfff8 + 7) / 8; spbc -= drop; subc -= drop * 8; }
 			if (cc == 0 && !(final_eob && subc < 8)) cc = NXZ_CC_DATA_LENGTH;
-			r.cc = cc; r.tpbc = (cc == 0 || cc == NXZ_CC_DATA_LENGTH) ? out : 0;
+			r.cc = cc; r.tpbc = (cc == 0 || cc == NXZ_CC_DATA_LENGTH) ? w.out : 0;
 			r.tebc = o_rem; r.spbc = spbc; r.crc = 0; r.adler = 0;
 			r.subc = subc; r.sfbt = o_sfbt | (final_eob ? 0x100u : 0) | (((o_sfbt & 0xe) == 0xc) ? (dhtbits << 16) : 0);
 			results[jid] = r;

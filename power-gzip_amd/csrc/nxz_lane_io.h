@@ -1,0 +1,108 @@
+// nxz_lane_io.h -- the per-lane bit reader and output writer of the lane-per-stream inflate kernel
+// (nxz_inflate_lanes.hip).  Plain C++ apart from the NXZ_LANE_* macros, so that the CPU test
+// (tests/test_lane_io.py) can run exactly this code under AddressSanitizer.
+#ifndef NXZ_LANE_IO_H
+#define NXZ_LANE_IO_H
+#include <stdint.h>
+#ifdef __HIPCC__
+#define NXZ_LANE_FN __device__ __forceinline__
+#define NXZ_LANE_ALIGNBYTE(hi, lo, sh) __builtin_amdgcn_alignbyte(hi, lo, sh)
+#else
+#define NXZ_LANE_FN inline
+static inline uint32_t nxz_lane_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+	return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (sh & 3)));
+}
+#define NXZ_LANE_ALIGNBYTE(hi, lo, sh) nxz_lane_alignbyte(hi, lo, sh)
+#endif
+
+namespace nxzl {
+
+// per-lane bit reader over global memory
+struct BitRd {
+	const uint8_t *src; uint32_t srclen;
+	uint64_t bb; uint32_t bc;        // bb holds bits [pos, pos + bc)
+	uint64_t pos;                    // next unread bit
+	NXZ_LANE_FN uint64_t total() const { return (uint64_t)srclen * 8; }
+	NXZ_LANE_FN bool have(uint32_t n) const { return pos + n <= total(); }
+	NXZ_LANE_FN void sync() { bb = 0; bc = 0; }
+	NXZ_LANE_FN void fill()            // bc >= 32 afterwards (zero bits past the end)
+	{
+		if (bc >= 32) return;
+		const uint64_t p2 = pos + bc;
+		const uint32_t byte = (uint32_t)(p2 >> 3), sh = (uint32_t)p2 & 7;
+		// the 4 bytes at src + byte from two aligned dwords (never touching a dword that holds no
+		// byte of the source), bytes past the end read as zero
+		uint32_t v = 0;
+		if (byte < srclen) {
+			const uintptr_t a = (uintptr_t)src + byte;
+			const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
+			const uint32_t bo = (uint32_t)a & 3, left = srclen - byte;         // bytes of the source from here on
+			const uint32_t lo = w[0], hi = bo + left > 4 ? w[1] : 0;
+			v = NXZ_LANE_ALIGNBYTE(hi, lo, bo);
+			if (left < 4) v &= (1u << (8 * left)) - 1;
+		}
+		bb |= (uint64_t)(v >> sh) << bc;
+		bc += 32 - sh;
+	}
+	NXZ_LANE_FN void drop(uint32_t n) { bb >>= n; bc -= n; pos += n; }
+	NXZ_LANE_FN uint32_t take(uint32_t n)      // caller checked have(n), n <= 16
+	{
+		fill();
+		uint32_t v = (uint32_t)bb & ((1u << n) - 1);
+		drop(n);
+		return v;
+	}
+};
+
+// per-lane output: literals are collected four at a time once the output position is 4-byte aligned
+struct OutWr {
+	uint8_t *dst;
+	uint32_t out;        // bytes produced (including the pending ones)
+	uint32_t wb, wn;     // pending literal bytes (wn = 0..3), they belong to dst[out - wn, out)
+	bool al;             // dst is 4-byte aligned: dword stores allowed
+	NXZ_LANE_FN void lit(uint32_t sym)
+	{
+		if (wn == 0 && (!al || (out & 3))) { dst[out++] = (uint8_t)sym; return; }
+		wb |= sym << (8 * wn);
+		wn++; out++;
+		if (wn == 4) { *(uint32_t *)(dst + out - 4) = wb; wb = 0; wn = 0; }
+	}
+	NXZ_LANE_FN void flush()
+	{
+		for (uint32_t k = 0; k < wn; k++) dst[out - wn + k] = (uint8_t)(wb >> (8 * k));
+		wb = 0; wn = 0;
+	}
+	// copy len bytes from distance dist (1 <= dist <= out), pending bytes flushed by the caller
+	NXZ_LANE_FN void copy(uint32_t len, uint32_t dist)
+	{
+		uint8_t *d = dst + out;
+		const uint8_t *s = d - dist;
+		uint32_t i = 0;
+		if (al && len >= 8 && dist != 3) {
+			for (; (out + i) & 3; i++) d[i] = s[i];                             // align the destination (< 4 bytes)
+			if (dist >= 4) {
+				// source dwords from two aligned loads; the source lies at least 4 bytes behind
+				const uintptr_t sa = (uintptr_t)(s + i);
+				const uint32_t *sw = (const uint32_t *)(sa & ~(uintptr_t)3);
+				const uint32_t bo = (uint32_t)sa & 3;
+				uint32_t lo = sw[0];
+				for (uint32_t k = 1; i + 4 <= len; i += 4, k++) {
+					uint32_t v = lo;
+					if (bo) { const uint32_t hi = sw[k]; v = NXZ_LANE_ALIGNBYTE(hi, lo, bo); lo = hi; }
+					*(uint32_t *)(d + i) = v;
+					if (!bo) lo = sw[k];
+				}
+			} else {
+				// period 1 or 2: one dword pattern
+				const uint32_t v = dist == 1 ? s[i] * 0x01010101u : ((uint32_t)s[i] | (uint32_t)s[i + 1] << 8) * 0x00010001u;   // the bytes at distance 1 / 2
+				for (; i + 4 <= len; i += 4) *(uint32_t *)(d + i) = v;
+			}
+		}
+		for (; i < len; i++) d[i] = s[i];
+		out += len;
+	}
+};
+
+} // namespace nxzl
+#endif

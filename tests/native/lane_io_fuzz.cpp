@@ -1,0 +1,61 @@
+// CPU fuzz of the lane-per-stream inflate kernel's bit reader and output writer
+// (power-gzip_amd/csrc/nxz_lane_io.h) against bytewise references, run under AddressSanitizer by
+// tests/test_lane_io.py.  Buffers are sized to the 4-byte words that cover them: the helpers may
+// read the word that holds the first / last byte, never a word beyond.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "nxz_lane_io.h"
+using namespace nxzl;
+
+static void fill_ref(BitRd &b)
+{
+	if (b.bc >= 32) return;
+	uint64_t p2 = b.pos + b.bc;
+	uint32_t byte = (uint32_t)(p2 >> 3), sh = (uint32_t)p2 & 7, v = 0;
+	for (uint32_t k = 0; k < 4; k++) if (byte + k < b.srclen) v |= (uint32_t)b.src[byte + k] << (8 * k);
+	b.bb |= (uint64_t)(v >> sh) << b.bc;
+	b.bc += 32 - sh;
+}
+
+int main()
+{
+	srand(1);
+	for (int it = 0; it < 200000; it++) {
+		uint32_t n = rand() % 40, off = rand() % 8;
+		std::vector<uint8_t> buf(((off + n + 3) & ~3u) ? ((off + n + 3) & ~3u) : 4);
+		for (auto &x : buf) x = (uint8_t)rand();
+		BitRd a{ buf.data() + off, n, 0, 0, (uint64_t)(rand() % (n * 8 + 20)) }, b = a;
+		for (int k = 0; k < 6; k++) {
+			a.fill(); fill_ref(b);
+			if (a.bb != b.bb || a.bc != b.bc) { printf("fill mismatch\n"); return 1; }
+			uint32_t dr = rand() % 17; if (dr > a.bc) dr = a.bc;
+			a.drop(dr); b.drop(dr);
+		}
+	}
+	for (int it = 0; it < 40000; it++) {
+		uint32_t cap = 64 + rand() % 900, off = (rand() % 2) ? 0 : rand() % 4;
+		std::vector<uint8_t> m1((off + cap + 3) & ~3u), m2(off + cap);
+		uint8_t *ref = m2.data() + off; uint32_t rout = 0;
+		OutWr w{ m1.data() + off, 0, 0, 0, (((uintptr_t)(m1.data() + off)) & 3) == 0 };
+		for (;;) {
+			if (rand() % 3 && w.out) {
+				uint32_t dist = 1 + rand() % (w.out < 40 ? w.out : 40);
+				if (rand() % 4 == 0) dist = 1 + rand() % w.out;
+				uint32_t len = 3 + rand() % 256; if (len > cap - w.out) break;
+				w.flush(); w.copy(len, dist);
+				for (uint32_t i = 0; i < len; i++) ref[rout + i] = ref[rout + i - dist];
+				rout += len;
+			} else {
+				if (w.out >= cap) break;
+				uint8_t c = (uint8_t)rand(); w.lit(c); ref[rout++] = c;
+			}
+		}
+		w.flush();
+		if (w.out != rout || memcmp(m1.data() + off, ref, rout)) { printf("output mismatch, case %d\n", it); return 1; }
+	}
+	printf("ok\n");
+	return 0;
+}
