@@ -20,7 +20,8 @@ namespace nxzl {
 
 constexpr int LB = 10, DB = 8;                       // fast-table index bits
 constexpr uint32_t WS_LIT = 0, WS_DIST = 2048, WS_LCNT = 2560, WS_LSYM = 2592, WS_DCNT = 3168, WS_DSYM = 3200;
-constexpr uint32_t WS_BYTES = 3328;
+constexpr uint32_t WS_LENS = 320;                     // code lengths of the block being set up (last part of a slot)
+constexpr uint32_t WS_BYTES = 3328 + WS_LENS;
 
 struct Tab {                                         // one table set (workspace view)
 	const uint16_t *lit, *dist, *lcnt, *lsym, *dcnt, *dsym;
@@ -113,13 +114,12 @@ struct LaneState {
 };
 
 // results.tebc carries out_rembytecnt; results.sfbt bit 8 = final EOB, bits 16.. = dhtlen (see nxz_engine.h)
-__global__ __launch_bounds__(64) void inflate_lanes_kernel(const nxz_batch_job_t *__restrict__ jobs, size_t n,
+__global__ __launch_bounds__(64, 4) void inflate_lanes_kernel(const nxz_batch_job_t *__restrict__ jobs, size_t n,
 							   nxz_batch_result_t *__restrict__ results,
 							   nxz_batch_dht_t *__restrict__ dht_io,
 							   uint8_t *__restrict__ workspace, const uint8_t *__restrict__ fixed_ws)
 {
 	__shared__ uint8_t lens_s[320];
-	__shared__ uint32_t hdr_s[4];
 	const int lane = threadIdx.x;
 	uint8_t *myws = workspace + ((size_t)blockIdx.x * 64 + lane + 1) * WS_BYTES;   // slot 0 = fixed tables
 
@@ -158,113 +158,127 @@ __global__ __launch_bounds__(64) void inflate_lanes_kernel(const nxz_batch_job_t
 		// The wave loops until every lane is done.  Lanes in state 4 (need a dynamic table) are
 		// served one at a time by the whole wave.
 		for (;;) {
-			// ---------- cooperative dynamic-table builds ----------
+			// ---------- dynamic tables ----------
+			// Every lane that needs a table parses its own block header at the same time (HLIT /
+			// HDIST / HCLEN + code lengths, into its slice of the workspace); only the construction
+			// of the lookup tables is done by the whole wave, one owner after the other.
+			int rc = 0, hlit = 0, hdist = 0;
+			if (state == 4) {
+				uint8_t *mylens = myws + WS_BYTES - WS_LENS;
+				BitRd r = b;
+				if (table_from_slot) {
+					const nxz_batch_dht_t *t = &dht_io[jid];
+					r.src = t->dht; r.srclen = (t->dhtlen + 7) / 8; r.bb = 0; r.bc = 0; r.pos = 0;
+				}
+				const uint64_t tbits_avail = table_from_slot ? dht_io[jid].dhtlen : r.total();
+				auto have = [&](uint32_t k) { return r.pos + k <= tbits_avail; };
+				tstart = r.pos;
+				if (!have(14)) rc = 1;
+				else {
+					uint32_t v = r.take(14);
+					hlit = (int)(v & 31) + 257; hdist = (int)((v >> 5) & 31) + 1;
+					int hclen = (int)((v >> 10) & 15) + 4;
+					if (hlit > 286 || hdist > 30) rc = -1;
+					// code-length code lengths, 3 bits each, packed 19 x 3 bits
+					uint64_t clp = 0;
+					for (int i = 0; i < hclen && !rc; i++) {
+						if (!have(3)) { rc = 1; break; }
+						const uint64_t order = 0x0F0E0D0C0B0A0908ull;   // unused (kept simple below)
+						(void)order;
+						static const uint8_t ord[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+						clp |= (uint64_t)r.take(3) << (3 * ord[i]);
+					}
+					if (!rc) {
+						// canonical code of the <= 7-bit code-length alphabet: counts (8 x 5 bits) and sorted symbols (19 x 5 bits)
+						uint64_t cnts = 0; uint32_t kraft = 0;
+						for (int i = 0; i < 19; i++) { uint32_t l = (uint32_t)(clp >> (3 * i)) & 7; if (l) { cnts += 1ull << (5 * l); kraft += 128u >> l; } }
+						if (kraft > 128) rc = -2;
+						uint64_t s_lo = 0, s_hi = 0; int ns = 0;               // sorted symbol list, 5 bits each
+						for (uint32_t l = 1; l <= 7; l++) for (int i = 0; i < 19; i++) if (((uint32_t)(clp >> (3 * i)) & 7) == l) {
+							if (ns < 12) s_lo |= (uint64_t)i << (5 * ns); else s_hi |= (uint64_t)i << (5 * (ns - 12));
+							ns++;
+						}
+						int nlen = 0, prev = 0;
+						uint32_t k1 = 0, k2 = 0, eob = 0;                      // Kraft sums (x 32768) and the end-of-block length
+						auto emit = [&](uint32_t val, int rep) {
+							for (int k = 0; k < rep; k++) mylens[nlen + k] = (uint8_t)val;
+							if (val) {
+								const int nl = hlit - nlen < 0 ? 0 : hlit - nlen < rep ? hlit - nlen : rep;   // how many are literal/length codes
+								k1 += (uint32_t)nl * (32768u >> val);
+								k2 += (uint32_t)(rep - nl) * (32768u >> val);
+							}
+							if (nlen <= 256 && 256 < nlen + rep) eob = val;
+							nlen += rep;
+						};
+						while (!rc && nlen < hlit + hdist) {
+							if (!have(1)) { rc = 1; break; }
+							r.fill();
+							uint32_t bits = (uint32_t)r.bb;
+							int code = 0, first = 0, index = 0, sym = -1, len;
+							for (len = 1; len <= 7; len++) {
+								code |= (int)(bits & 1); bits >>= 1;
+								int c = (int)((cnts >> (5 * len)) & 31);
+								if (code - c < first) {
+									int k = index + (code - first);
+									sym = (int)((k < 12 ? s_lo >> (5 * k) : s_hi >> (5 * (k - 12))) & 31);
+									break;
+								}
+								index += c; first += c; first <<= 1; code <<= 1;
+							}
+							if (sym < 0) { rc = have(7) ? -3 : 1; break; }
+							if (!have((uint32_t)len)) { rc = 1; break; }
+							r.drop((uint32_t)len);
+							if (sym < 16) { emit((uint32_t)sym, 1); prev = sym; }
+							else {
+								int eb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
+								if (!have((uint32_t)eb)) { rc = 1; break; }
+								int rep = (int)r.take((uint32_t)eb) + (sym == 18 ? 11 : 3);
+								int val = 0;
+								if (sym == 16) { if (nlen == 0) { rc = -4; break; } val = prev; }
+								if (nlen + rep > hlit + hdist) { rc = -5; break; }
+								emit((uint32_t)val, rep);
+								if (sym != 16) prev = 0;
+							}
+						}
+						if (!rc) {
+							if (eob == 0) rc = -6;
+							if (k1 > 32768u || k2 > 32768u) rc = -7;
+						}
+					}
+				}
+				if (!rc) {
+					dhtbits = (uint32_t)(r.pos - tstart);
+					if (table_from_slot) { if (dhtbits != dht_io[jid].dhtlen) rc = -8; }
+					else {
+						// keep the table bits for a possible suspend inside this block
+						if (dht_io) {
+							nxz_batch_dht_t *t = &dht_io[jid];
+							BitRd c = b; c.sync();
+							for (uint32_t i = 0; i * 8 < dhtbits; i++) {
+								uint32_t k = dhtbits - i * 8 < 8 ? dhtbits - i * 8 : 8;
+								c.fill();
+								t->dht[i] = (uint8_t)((uint32_t)c.bb & ((1u << k) - 1));
+								c.drop(k);
+							}
+							t->dhtlen = dhtbits;
+						}
+						b = r; b.sync();
+					}
+				}
+			}
 			unsigned long long need = __ballot(state == 4);
 			while (need) {
 				const int owner = __builtin_ctzll(need);
 				need &= need - 1;
-				// the owner parses HLIT/HDIST/HCLEN + code lengths into LDS
-				int rc = 0, hlit = 0, hdist = 0;
-				if (lane == owner) {
-					BitRd r = b;
-					if (table_from_slot) {
-						const nxz_batch_dht_t *t = &dht_io[jid];
-						r.src = t->dht; r.srclen = (t->dhtlen + 7) / 8; r.bb = 0; r.bc = 0; r.pos = 0;
-					}
-					const uint64_t tbits_avail = table_from_slot ? dht_io[jid].dhtlen : r.total();
-					auto have = [&](uint32_t k) { return r.pos + k <= tbits_avail; };
-					tstart = r.pos;
-					if (!have(14)) rc = 1;
-					else {
-						uint32_t v = r.take(14);
-						hlit = (int)(v & 31) + 257; hdist = (int)((v >> 5) & 31) + 1;
-						int hclen = (int)((v >> 10) & 15) + 4;
-						if (hlit > 286 || hdist > 30) rc = -1;
-						// code-length code lengths, 3 bits each, packed 19 x 3 bits
-						uint64_t clp = 0;
-						for (int i = 0; i < hclen && !rc; i++) {
-							if (!have(3)) { rc = 1; break; }
-							const uint64_t order = 0x0F0E0D0C0B0A0908ull;   // unused (kept simple below)
-							(void)order;
-							static const uint8_t ord[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
-							clp |= (uint64_t)r.take(3) << (3 * ord[i]);
-						}
-						if (!rc) {
-							// canonical code of the <= 7-bit code-length alphabet: counts (8 x 5 bits) and sorted symbols (19 x 5 bits)
-							uint64_t cnts = 0; uint32_t kraft = 0;
-							for (int i = 0; i < 19; i++) { uint32_t l = (uint32_t)(clp >> (3 * i)) & 7; if (l) { cnts += 1ull << (5 * l); kraft += 128u >> l; } }
-							if (kraft > 128) rc = -2;
-							uint64_t s_lo = 0, s_hi = 0; int ns = 0;               // sorted symbol list, 5 bits each
-							for (uint32_t l = 1; l <= 7; l++) for (int i = 0; i < 19; i++) if (((uint32_t)(clp >> (3 * i)) & 7) == l) {
-								if (ns < 12) s_lo |= (uint64_t)i << (5 * ns); else s_hi |= (uint64_t)i << (5 * (ns - 12));
-								ns++;
-							}
-							int nlen = 0, prev = 0;
-							while (!rc && nlen < hlit + hdist) {
-								if (!have(1)) { rc = 1; break; }
-								r.fill();
-								uint32_t bits = (uint32_t)r.bb;
-								int code = 0, first = 0, index = 0, sym = -1, len;
-								for (len = 1; len <= 7; len++) {
-									code |= (int)(bits & 1); bits >>= 1;
-									int c = (int)((cnts >> (5 * len)) & 31);
-									if (code - c < first) {
-										int k = index + (code - first);
-										sym = (int)((k < 12 ? s_lo >> (5 * k) : s_hi >> (5 * (k - 12))) & 31);
-										break;
-									}
-									index += c; first += c; first <<= 1; code <<= 1;
-								}
-								if (sym < 0) { rc = have(7) ? -3 : 1; break; }
-								if (!have((uint32_t)len)) { rc = 1; break; }
-								r.drop((uint32_t)len);
-								if (sym < 16) { lens_s[nlen++] = (uint8_t)sym; prev = sym; }
-								else {
-									int eb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
-									if (!have((uint32_t)eb)) { rc = 1; break; }
-									int rep = (int)r.take((uint32_t)eb) + (sym == 18 ? 11 : 3);
-									int val = 0;
-									if (sym == 16) { if (nlen == 0) { rc = -4; break; } val = prev; }
-									if (nlen + rep > hlit + hdist) { rc = -5; break; }
-									for (int k = 0; k < rep; k++) lens_s[nlen + k] = (uint8_t)val;
-									nlen += rep;
-									if (sym != 16) prev = 0;
-								}
-							}
-							if (!rc) {
-								if (lens_s[256] == 0) rc = -6;
-								uint32_t k1 = 0, k2 = 0;
-								for (int i = 0; i < hlit; i++) if (lens_s[i]) k1 += 32768u >> lens_s[i];
-								for (int i = 0; i < hdist; i++) if (lens_s[hlit + i]) k2 += 32768u >> lens_s[hlit + i];
-								if (k1 > 32768u || k2 > 32768u) rc = -7;
-							}
-						}
-					}
-					if (!rc) {
-						dhtbits = (uint32_t)(r.pos - tstart);
-						if (table_from_slot) { if (dhtbits != dht_io[jid].dhtlen) rc = -8; }
-						else {
-							// keep the table bits for a possible suspend inside this block
-							if (dht_io) {
-								nxz_batch_dht_t *t = &dht_io[jid];
-								BitRd c = b; c.sync();
-								for (uint32_t i = 0; i * 8 < dhtbits; i++) {
-									uint32_t k = dhtbits - i * 8 < 8 ? dhtbits - i * 8 : 8;
-									c.fill();
-									t->dht[i] = (uint8_t)((uint32_t)c.bb & ((1u << k) - 1));
-									c.drop(k);
-								}
-								t->dhtlen = dhtbits;
-							}
-							b = r; b.sync();
-						}
-					}
-					hdr_s[0] = (uint32_t)rc; hdr_s[1] = (uint32_t)hlit; hdr_s[2] = (uint32_t)hdist;
-				}
-				__syncthreads();
-				const int orc = (int)hdr_s[0], ohlit = (int)hdr_s[1], ohdist = (int)hdr_s[2];
+				const int orc = __shfl(rc, owner, 64), ohlit = __shfl(hlit, owner, 64), ohdist = __shfl(hdist, owner, 64);
 				uint8_t *ows = workspace + ((size_t)blockIdx.x * 64 + owner + 1) * WS_BYTES;
-				if (orc == 0) build_tables(ows, lens_s, ohlit, ohdist, lane);
+				if (orc == 0) {
+					const uint8_t *olens = ows + WS_BYTES - WS_LENS;
+					__syncthreads();
+					for (int i = lane; i < ohlit + ohdist; i += 64) lens_s[i] = olens[i];
+					__syncthreads();
+					build_tables(ows, lens_s, ohlit, ohdist, lane);
+				}
 				__syncthreads();
 				if (lane == owner) {
 					if (orc == 0) { T = tab_at(myws); state = 2; }
