@@ -37,6 +37,8 @@ int nx_inflate(z_streamp strm, int flush);
 int nx_inflateEnd(z_streamp strm);
 int nx_inflateReset(z_streamp strm);
 int nx_inflateReset2(z_streamp strm, int windowBits);
+int nx_inflateResetKeep(z_streamp strm);
+int nx_inflateCopy(z_streamp dest, z_streamp source);         /* lib/nx_inflate.c:1876-1942 */
 int nx_inflateSetDictionary(z_streamp strm, const unsigned char *dictionary, unsigned int dictLength);
 int nx_inflateSyncPoint(z_streamp strm);
 int nx_inflateGetHeader(z_streamp strm, gz_headerp head);
@@ -53,6 +55,15 @@ unsigned long nx_crc32(unsigned long crc, const unsigned char *buf, size_t len);
 unsigned long nx_adler32(unsigned long adler, const unsigned char *buf, size_t len);
 unsigned long nx_crc32_combine(unsigned long crc1, unsigned long crc2, off_t len2);
 unsigned long nx_adler32_combine(unsigned long adler1, unsigned long adler2, off_t len2);
+unsigned long nx_crc32_combine64(unsigned long crc1, unsigned long crc2, off_t len2);
+unsigned long nx_adler32_combine64(unsigned long adler1, unsigned long adler2, off_t len2);
+
+/* gz files (lib/nx_gzlib.c:68-329) */
+void *nx_gzopen(const char *path, const char *mode);
+void *nx_gzdopen(int fd, const char *mode);
+int nx_gzwrite(void *file, const void *buf, unsigned len);
+int nx_gzread(void *file, void *buf, unsigned len);
+int nx_gzclose(void *file);
 
 /* Dynamic-Huffman table builder, bit for bit what dhtgen() of lib/nx_dhtgen.c:945-1034 produces
  * (pinned by tests/golden/dhtgen_vectors.json), and a batched form for the device-resident path

@@ -691,6 +691,30 @@ int inflate_reset(z_streamp strm)
 
 extern "C" int nx_inflateReset(z_streamp strm) { return inflate_reset(strm); }
 
+// The reference's inflateResetKeep is the same reset (lib/nx_inflate.c: resets state, totals and history).
+extern "C" int nx_inflateResetKeep(z_streamp strm) { return inflate_reset(strm); }
+
+// Deep copy of a decompression stream (lib/nx_inflate.c:1876-1942): state, pending output,
+// history, carried source bytes and the resume fields; the copy gets its own engine handle.
+extern "C" int nx_inflateCopy(z_streamp dest, z_streamp source)
+{
+	Inflate *s = istate(source);
+	if (!s || !dest) return Z_STREAM_ERROR;
+	Inflate *d = new (std::nothrow) Inflate();
+	if (!d || !d->jb.job || !d->eng.begin()) { delete d; return Z_MEM_ERROR; }
+	*dest = *source;
+	d->z = dest; d->wrap = s->wrap; d->window_bits = s->window_bits; d->st = s->st;
+	d->held = s->held; d->nheld = s->nheld; d->gzflags = s->gzflags; d->xlen = s->xlen; d->zcmf = s->zcmf; d->dictid = s->dictid;
+	d->gzhead = s->gzhead; d->hcrc = s->hcrc;
+	d->pend = s->pend; d->pend_off = s->pend_off; d->hist = s->hist; d->carry = s->carry;
+	d->sfbt = s->sfbt; d->subc = s->subc; d->rem = s->rem; d->dhtlen = s->dhtlen; memcpy(d->dht, s->dht, sizeof(d->dht));
+	d->resuming = s->resuming; d->crc = s->crc; d->adler = s->adler; d->total_out = s->total_out;
+	memcpy(d->trailer, s->trailer, sizeof(d->trailer)); d->ntrailer = s->ntrailer;
+	d->sync_point = s->sync_point; d->have_dict = s->have_dict; d->ratio = s->ratio;
+	dest->state = (struct internal_state *)d;
+	return Z_OK;
+}
+
 extern "C" int nx_inflateReset2(z_streamp strm, int windowBits)
 {
 	Inflate *s = istate(strm);
@@ -980,6 +1004,9 @@ extern "C" unsigned long nx_adler32(unsigned long adler, const unsigned char *bu
 	if (buf == Z_NULL) return 1;
 	return sw_adler32((uint32_t)adler, buf, len);
 }
+
+extern "C" unsigned long nx_crc32_combine64(unsigned long crc1, unsigned long crc2, off_t len2) { return nx_crc32_combine(crc1, crc2, len2); }
+extern "C" unsigned long nx_adler32_combine64(unsigned long a1, unsigned long a2, off_t len2) { return nx_adler32_combine(a1, a2, len2); }
 
 extern "C" unsigned long nx_crc32_combine(unsigned long crc1, unsigned long crc2, off_t len2)
 {

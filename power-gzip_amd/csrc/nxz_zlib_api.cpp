@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <set>
 #include "../../include/nxz_engine.h"
 #include "../../include/nxz_zlib.h"
 
@@ -48,6 +49,12 @@ struct Sw {
 	SWF(int, inflateGetHeader, (z_streamp, gz_headerp))
 	SWF(int, inflateSyncPoint, (z_streamp))
 	SWF(int, inflateCopy, (z_streamp, z_streamp))
+	SWF(int, inflateResetKeep, (z_streamp))
+	SWF(gzFile, gzopen, (const char *, const char *))
+	SWF(gzFile, gzdopen, (int, const char *))
+	SWF(int, gzread, (gzFile, voidp, unsigned))
+	SWF(int, gzwrite, (gzFile, voidpc, unsigned))
+	SWF(int, gzclose, (gzFile))
 	SWF(int, compress, (Bytef *, uLongf *, const Bytef *, uLong))
 	SWF(int, compress2, (Bytef *, uLongf *, const Bytef *, uLong, int))
 	SWF(uLong, compressBound, (uLong))
@@ -78,7 +85,7 @@ void init_once()
 		REG(deflateParams) REG(inflateInit_) REG(inflateInit2_) REG(inflate) REG(inflateEnd) REG(inflateReset)
 		REG(inflateReset2) REG(inflateSetDictionary) REG(inflateGetHeader) REG(inflateSyncPoint) REG(inflateCopy)
 		REG(compress) REG(compress2) REG(compressBound) REG(uncompress) REG(uncompress2) REG(crc32) REG(adler32)
-		REG(crc32_combine) REG(adler32_combine)
+		REG(crc32_combine) REG(adler32_combine) REG(inflateResetKeep) REG(gzopen) REG(gzdopen) REG(gzread) REG(gzwrite) REG(gzclose)
 #undef REG
 	} else if (g_mode != MODE_NX) {
 		fprintf(stderr, "nxz: cannot dlopen software zlib (%s): forcing engine mode\n", dlerror());
@@ -156,12 +163,8 @@ EXPORT int inflateReset2(z_streamp s, int w) { DISPATCH_INF(nx_inflateReset2(s, 
 EXPORT int inflateSetDictionary(z_streamp s, const Bytef *d, uInt n) { DISPATCH_INF(nx_inflateSetDictionary(s, d, n), sw.inflateSetDictionary(s, d, n)); }
 EXPORT int inflateGetHeader(z_streamp s, gz_headerp h) { DISPATCH_INF(nx_inflateGetHeader(s, h), sw.inflateGetHeader(s, h)); }
 EXPORT int inflateSyncPoint(z_streamp s) { DISPATCH_INF(nx_inflateSyncPoint(s), (sw.inflateSyncPoint ? sw.inflateSyncPoint(s) : Z_STREAM_ERROR)); }
-EXPORT int inflateCopy(z_streamp d, z_streamp s)
-{
-	init();
-	if (is_nx(s, MAGIC_INF)) return Z_STREAM_ERROR;            // not offered by the engine layer yet
-	return sw.inflateCopy ? sw.inflateCopy(d, s) : Z_STREAM_ERROR;
-}
+EXPORT int inflateCopy(z_streamp d, z_streamp s) { DISPATCH_INF(nx_inflateCopy(d, s), (sw.inflateCopy ? sw.inflateCopy(d, s) : Z_STREAM_ERROR)); }
+EXPORT int inflateResetKeep(z_streamp s) { DISPATCH_INF(nx_inflateResetKeep(s), (sw.inflateResetKeep ? sw.inflateResetKeep(s) : Z_STREAM_ERROR)); }
 
 // ---- one-shot (lib/nx_compress.c:77-117, lib/nx_uncompr.c:90-149) ----
 EXPORT int compress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen, int level)
@@ -199,3 +202,31 @@ EXPORT uLong crc32(uLong crc, const Bytef *buf, uInt len) { return nx_crc32(crc,
 EXPORT uLong adler32(uLong adler, const Bytef *buf, uInt len) { return nx_adler32(adler, buf, len); }
 EXPORT uLong crc32_combine(uLong a, uLong b, z_off_t n) { return nx_crc32_combine(a, b, n); }
 EXPORT uLong adler32_combine(uLong a, uLong b, z_off_t n) { return nx_adler32_combine(a, b, n); }
+EXPORT uLong crc32_combine64(uLong a, uLong b, z_off64_t n) { return nx_crc32_combine(a, b, (off_t)n); }
+EXPORT uLong adler32_combine64(uLong a, uLong b, z_off64_t n) { return nx_adler32_combine(a, b, (off_t)n); }
+
+// ---- gz files (lib/nx_gzlib.c:331-354): the engine's layer or software zlib's, per handle ----
+namespace {
+std::mutex g_gz_mu;
+std::set<void *> g_gz_nx;
+bool gz_is_nx(void *f) { std::lock_guard<std::mutex> l(g_gz_mu); return g_gz_nx.count(f) != 0; }
+void *gz_track(void *f) { if (f) { std::lock_guard<std::mutex> l(g_gz_mu); g_gz_nx.insert(f); } return f; }
+}
+EXPORT gzFile gzopen(const char *path, const char *mode)
+{
+	if (want_nx()) { void *f = gz_track(nx_gzopen(path, mode)); if (f || g_mode == MODE_NX || !sw.gzopen) return (gzFile)f; }
+	return sw.gzopen ? sw.gzopen(path, mode) : nullptr;
+}
+EXPORT gzFile gzdopen(int fd, const char *mode)
+{
+	if (want_nx()) { void *f = gz_track(nx_gzdopen(fd, mode)); if (f || g_mode == MODE_NX || !sw.gzdopen) return (gzFile)f; }
+	return sw.gzdopen ? sw.gzdopen(fd, mode) : nullptr;
+}
+EXPORT int gzread(gzFile f, voidp buf, unsigned len) { init(); return gz_is_nx(f) ? nx_gzread(f, buf, len) : sw.gzread ? sw.gzread(f, buf, len) : -1; }
+EXPORT int gzwrite(gzFile f, voidpc buf, unsigned len) { init(); return gz_is_nx(f) ? nx_gzwrite(f, buf, len) : sw.gzwrite ? sw.gzwrite(f, buf, len) : 0; }
+EXPORT int gzclose(gzFile f)
+{
+	init();
+	if (gz_is_nx(f)) { { std::lock_guard<std::mutex> l(g_gz_mu); g_gz_nx.erase(f); } return nx_gzclose(f); }
+	return sw.gzclose ? sw.gzclose(f) : Z_STREAM_ERROR;
+}

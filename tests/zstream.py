@@ -54,6 +54,18 @@ def load(kind):
         for f in ("nx_crc32_combine", "nx_adler32_combine"):
             getattr(L, f).restype = C.c_ulong
             getattr(L, f).argtypes = [C.c_ulong, C.c_ulong, C.c_long]
+        L.nx_inflateCopy.argtypes = [C.POINTER(ZStream), C.POINTER(ZStream)]
+        L.nx_inflateResetKeep.argtypes = [C.POINTER(ZStream)]
+        L.nx_gzopen.restype = C.c_void_p
+        L.nx_gzopen.argtypes = [C.c_char_p, C.c_char_p]
+        L.nx_gzdopen.restype = C.c_void_p
+        L.nx_gzdopen.argtypes = [C.c_int, C.c_char_p]
+        L.nx_gzwrite.argtypes = [C.c_void_p, C.c_char_p, C.c_uint]
+        L.nx_gzread.argtypes = [C.c_void_p, C.c_char_p, C.c_uint]
+        L.nx_gzclose.argtypes = [C.c_void_p]
+        for f in ("nx_crc32_combine64", "nx_adler32_combine64"):
+            getattr(L, f).restype = C.c_ulong
+            getattr(L, f).argtypes = [C.c_ulong, C.c_ulong, C.c_long]
         _libs[kind] = L
     return _libs[kind]
 
