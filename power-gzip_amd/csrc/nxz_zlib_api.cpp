@@ -200,6 +200,8 @@ EXPORT int uncompress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong s
 // ---- checksums: host code either way (lib/nx_crc.c:437-446 routes crc32 to the vector CRC) ----
 EXPORT uLong crc32(uLong crc, const Bytef *buf, uInt len) { return nx_crc32(crc, buf, len); }
 EXPORT uLong adler32(uLong adler, const Bytef *buf, uInt len) { return nx_adler32(adler, buf, len); }
+EXPORT uLong crc32_z(uLong crc, const Bytef *buf, z_size_t len) { return nx_crc32(crc, buf, len); }
+EXPORT uLong adler32_z(uLong adler, const Bytef *buf, z_size_t len) { return nx_adler32(adler, buf, len); }
 EXPORT uLong crc32_combine(uLong a, uLong b, z_off_t n) { return nx_crc32_combine(a, b, n); }
 EXPORT uLong adler32_combine(uLong a, uLong b, z_off_t n) { return nx_adler32_combine(a, b, n); }
 EXPORT uLong crc32_combine64(uLong a, uLong b, z_off64_t n) { return nx_crc32_combine(a, b, (off_t)n); }
