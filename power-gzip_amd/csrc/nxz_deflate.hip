@@ -64,6 +64,12 @@ constexpr uint32_t OFF_X     = OFF_MBITS + PTILE / 8;    // 1024 x u16  } dead a
 constexpr uint32_t OFF_ENTRY = OFF_X + NSEG * 2;         // 1024 x u16  } BITS they form the bit-pack window
 constexpr uint32_t OFF_BITS  = OFF_ENTRY + NSEG * 2;     // 4096 + 64 bytes (aliased: CRC tables before the first tile)
 constexpr uint32_t BITS_BYTES = ETILE * 2 + 64;
+// during the match phase the window region holds: 16 x 96 queue entries (long positions), 16 x 80
+// (tails beyond LCAP) and the e-flag bitmap (PTILE + 288 bits)
+constexpr uint32_t OFF_LQ    = OFF_X;
+constexpr uint32_t OFF_XQ    = OFF_LQ + 16 * 96 * 2;
+constexpr uint32_t OFF_EB    = OFF_XQ + 16 * 80 * 2;     // 2096 bytes
+static_assert(OFF_EB % 16 == 0 && OFF_EB + 2096 <= OFF_BITS + BITS_BYTES, "match-phase carve");
 constexpr uint32_t OFF_WIN   = OFF_X;                    // bit-pack window: WWORDS dwords + 16 dwords of spill
 constexpr uint32_t WWORDS    = (NSEG * 4 + ETILE * 2) / 4;   // 2048
 constexpr uint32_t OFF_SCAN  = OFF_BITS + BITS_BYTES;    // 64 x u32
@@ -458,6 +464,29 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			__builtin_amdgcn_wave_barrier();                      // LDS runs a wave's operations in order: reads before the write
 			((uint4 *)cand)[(piece << 6) + lane] = make_uint4(o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | o[5] << 16, o[6] | o[7] << 16);
 		}
+		// e(x) = "byte x equals byte x-1" flags for the tile and 288 positions beyond: the lengths of the
+		// distance-1 candidates are runs of these flags (used by the match phase and M3)
+		{
+			uint16_t *eb16 = (uint16_t *)(lds + OFF_EB);
+			const uint32_t ngroups = (tn + 288 + 15) / 16 + 2;
+			for (uint32_t g = t; g < ngroups; g += NT) {
+				const uint32_t r0 = h + tb0 + 16 * g;                 // 16-byte aligned
+				uint32_t bits = 0;
+				if (r0 < end) {
+					const uint4 dv = *(const uint4 *)(lds + OFF_IN + r0);
+					const uint32_t pv = r0 ? inw[(r0 >> 2) - 1] : 0;
+					auto eq4 = [](uint32_t d, uint32_t prev) -> uint32_t {
+						const uint32_t xx = d ^ __builtin_amdgcn_alignbyte(d, prev, 3);      // byte k: b[k] ^ b[k-1]
+						const uint32_t nzb = (((xx & 0x7f7f7f7fu) + 0x7f7f7f7fu) | xx) & 0x80808080u;
+						return ~((((nzb >> 7) * 0x00204081u) >> 21)) & 0xf;
+					};
+					bits = eq4(dv.x, pv) | eq4(dv.y, dv.x) << 4 | eq4(dv.z, dv.y) << 8 | eq4(dv.w, dv.z) << 12;
+					if (r0 == 0) bits &= ~1u;
+					if (end - r0 < 16) bits &= (1u << (end - r0)) - 1;
+				}
+				eb16[g] = (uint16_t)bits;
+			}
+		}
 		__syncthreads();
 		PROF(3);
 
@@ -539,11 +568,39 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		//      are tails and are extended, lane-serial up to LCAP bytes, 16 lanes per tail beyond.
 		//   M3 (after a barrier): members take their length from the end of their chain;
 		//      distance-1 runs are evaluated and win ties (oracle/nxz_lz77.c step 4).
+		// first clear bit of a bitmap at or after bit s (below limit)
+		auto first_zero = [](const uint32_t *bm, uint32_t s0, uint32_t limit) -> uint32_t {
+			// 128 bits per LDS round trip
+			uint32_t wi = (s0 >> 5) & ~3u;
+			uint4 q = *(const uint4 *)(bm + wi);
+			// bits below s0 count as set
+			const uint32_t sw = (s0 >> 5) & 3, lowmask = ~(~0u << (s0 & 31));
+			uint32_t w0 = ~q.x, w1 = ~q.y, w2 = ~q.z, w3 = ~q.w;
+			if (sw > 0) w0 = 0; if (sw > 1) w1 = 0; if (sw > 2) w2 = 0;
+			if (sw == 0) w0 &= ~lowmask; else if (sw == 1) w1 &= ~lowmask; else if (sw == 2) w2 &= ~lowmask; else w3 &= ~lowmask;
+			for (;;) {
+				if (w0 | w1 | w2 | w3) {
+					const uint32_t pos = wi * 32 + (w0 ? (uint32_t)__builtin_ctz(w0) : w1 ? 32 + (uint32_t)__builtin_ctz(w1)
+								  : w2 ? 64 + (uint32_t)__builtin_ctz(w2) : 96 + (uint32_t)__builtin_ctz(w3));
+					return pos < limit ? pos : limit;
+				}
+				wi += 4;
+				if (wi * 32 >= limit) return limit;
+				q = *(const uint4 *)(bm + wi);
+				w0 = ~q.x; w1 = ~q.y; w2 = ~q.z; w3 = ~q.w;
+			}
+		};
 		uint32_t *kb = mbits;                                 // bitmap: long members (and the gaps inside their chains)
 		uint32_t *vb = sbits;                                 // bitmap: position has a verified candidate
 		{
-			uint16_t *lq = (uint16_t *)(lds + OFF_X) + wave * 128;          // long positions: quad number | position bits << 12
-			uint16_t *xq = (uint16_t *)(lds + OFF_X + 4096) + wave * 128;   // tails beyond LCAP
+			const uint32_t *eb = (const uint32_t *)(lds + OFF_EB);
+			// 32 bits of a bitmap from bit b on
+			auto bits32 = [](const uint32_t *bm, uint32_t b) -> uint32_t {
+				const uint32_t lo = bm[b >> 5], hi = bm[(b >> 5) + 1], sh = b & 31;
+				return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+			};
+			uint16_t *lq = (uint16_t *)(lds + OFF_LQ) + wave * 96;          // long positions: quad number | position bits << 12
+			uint16_t *xq = (uint16_t *)(lds + OFF_XQ) + wave * 80;          // tails beyond LCAP
 			uint32_t xqn = 0;
 			uint32_t lqn = 0;
 			// tails that are still equal after LCAP bytes: 16 lanes per tail, 64 bytes per step
@@ -606,6 +663,10 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					} else if (w32 == 0 && i + 1 == pend && pend < tn) {
 						// last position of the piece: settled after the barrier
 						atomicOr(&misc[M_DEFER], 1u << ((i >> 9) & 31));
+					} else if (i >= 32 && bits32(eb, i - 31) == 0xffffffffu && first_zero(eb, i, i + 272) - i >= maxlen) {
+						// inside a long run of equal bytes (it began at least 32 positions back and goes on
+						// for maxlen): the distance-1 candidate is at least as long as anything and wins
+						// ties, here and for every position that could link to this one -- nothing to do
 					} else {
 						// tail: extend, lane-serial up to LCAP = 8 + 2 x 16 bytes
 						if (len == 24) len += equal16(inw, q + 24, r + 24);
@@ -622,7 +683,25 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 						}
 					}
 				}
-				const unsigned long long ml = __ballot(lg);
+				unsigned long long ml = __ballot(lg);
+				if (__popcll(ml) >= 12) {
+					// many long tails at once (periodic data, candidates at ever changing distances):
+					// every lane finishes its own, 16 bytes per LDS round trip
+					const uint32_t r = h + tb0 + i, q = lg ? r - cand[i] - 1 : 0;
+					const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+					uint32_t len = LCAP;
+					while (__ballot(lg)) {
+						if (lg) {
+							const uint32_t k = equal16(inw, q + len, r + len);
+							len += k;
+							if (k < 16 || len >= maxlen) {
+								lg = false;
+								mlen[i] = (uint8_t)((len < maxlen ? len : maxlen) - 3);
+							}
+						}
+					}
+					ml = 0;
+				}
 				if (ml) {
 					// collected until a few rounds of four are worth the trip
 					if (lg) xq[xqn + __popcll(ml & ((1ull << lane) - 1))] = (uint16_t)i;
@@ -712,38 +791,15 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 						if (qbits) lq[lqn + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((i4 >> 2) | qbits << 12);
 						lqn += (uint32_t)__popcll(m);
 						__builtin_amdgcn_wave_barrier();
-						if (lqn >= 64) { stage2(lqn); lqn -= 64; }
+						while (lqn >= 32) { stage2(lqn); lqn = lqn > 64 ? lqn - 64 : 0; }
 					}
 				}
 			}
 			if (lqn) stage2(lqn);
 			if (xqn) longext(xqn);
 		}
-		__syncthreads();                                       // the long-tail queues live where the flags go
-		PROF(12);
-		// ---- M3a: e(x) = "byte x equals byte x-1" flags for the tile and 288 positions beyond ----
-		{
-			uint16_t *eb16 = (uint16_t *)bitbuf;
-			const uint32_t ngroups = (tn + 288 + 15) / 16 + 2;
-			for (uint32_t g = t; g < ngroups; g += NT) {
-				const uint32_t r0 = h + tb0 + 16 * g;                 // 16-byte aligned
-				uint32_t bits = 0;
-				if (r0 < end) {
-					const uint4 dv = *(const uint4 *)(lds + OFF_IN + r0);
-					const uint32_t pv = r0 ? inw[(r0 >> 2) - 1] : 0;
-					auto eq4 = [](uint32_t d, uint32_t prev) -> uint32_t {
-						const uint32_t xx = d ^ __builtin_amdgcn_alignbyte(d, prev, 3);      // byte k: b[k] ^ b[k-1]
-						const uint32_t nzb = (((xx & 0x7f7f7f7fu) + 0x7f7f7f7fu) | xx) & 0x80808080u;
-						return ~((((nzb >> 7) * 0x00204081u) >> 21)) & 0xf;
-					};
-					bits = eq4(dv.x, pv) | eq4(dv.y, dv.x) << 4 | eq4(dv.z, dv.y) << 8 | eq4(dv.w, dv.z) << 12;
-					if (r0 == 0) bits &= ~1u;
-					if (end - r0 < 16) bits &= (1u << (end - r0)) - 1;
-				}
-				eb16[g] = (uint16_t)bits;
-			}
-		}
 		__syncthreads();
+		PROF(12);
 		// the piece-last long positions: member if the first position of the next piece continues
 		// the match, tail otherwise -- extended right here by the whole wave, 256 bytes per step
 		if (wave == 0) {
@@ -777,28 +833,6 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		PROF(10);
 		// ---- M3: long members, then distance-1 runs ----
 		const uint32_t p0 = (uint32_t)t * PSEG;
-		// first clear bit of a bitmap at or after bit s (below limit)
-		auto first_zero = [](const uint32_t *bm, uint32_t s0, uint32_t limit) -> uint32_t {
-			// 128 bits per LDS round trip
-			uint32_t wi = (s0 >> 5) & ~3u;
-			uint4 q = *(const uint4 *)(bm + wi);
-			// bits below s0 count as set
-			const uint32_t sw = (s0 >> 5) & 3, lowmask = ~(~0u << (s0 & 31));
-			uint32_t w0 = ~q.x, w1 = ~q.y, w2 = ~q.z, w3 = ~q.w;
-			if (sw > 0) w0 = 0; if (sw > 1) w1 = 0; if (sw > 2) w2 = 0;
-			if (sw == 0) w0 &= ~lowmask; else if (sw == 1) w1 &= ~lowmask; else if (sw == 2) w2 &= ~lowmask; else w3 &= ~lowmask;
-			for (;;) {
-				if (w0 | w1 | w2 | w3) {
-					const uint32_t pos = wi * 32 + (w0 ? (uint32_t)__builtin_ctz(w0) : w1 ? 32 + (uint32_t)__builtin_ctz(w1)
-								  : w2 ? 64 + (uint32_t)__builtin_ctz(w2) : 96 + (uint32_t)__builtin_ctz(w3));
-					return pos < limit ? pos : limit;
-				}
-				wi += 4;
-				if (wi * 32 >= limit) return limit;
-				q = *(const uint4 *)(bm + wi);
-				w0 = ~q.x; w1 = ~q.y; w2 = ~q.z; w3 = ~q.w;
-			}
-		};
 		if (p0 < tn) {
 			// members of my 16 positions, last to first: N = (end of the chain) - position; the chain
 			// ends at the first non-member behind it, whose length is final (M1, M2 or the link pass)
@@ -831,7 +865,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		PROF(11);
 		uint32_t sm0 = 0, sm1 = 0, sm2 = 0, sm3 = 0;          // final stored lengths (len-3, 0 = none) of my 16 positions
 		if (p0 < tn) {
-			const uint32_t *eb = bitbuf;
+			const uint32_t *eb = (const uint32_t *)(lds + OFF_EB);
 			const uint32_t e32 = lds_ld32(eb, 2 * t);               // my 16 flags and the next 16
 			const uint32_t e16 = e32 & 0xffff;
 			const uint32_t r4 = e32 & (e32 >> 1) & (e32 >> 2) & (e32 >> 3) & 0xffff;   // runs of >= 4 that start in my group

@@ -10,9 +10,9 @@ NAMES = ["load", "cksum", "seed+hdr", "hash", "chain (wave 0)", "M3b dist-1 runs
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = pkg.Engine(0)
 src = bench.gen_blocks(torch, eng.dev, n, 0)
-if len(sys.argv) > 2 and sys.argv[2] == "alice":
+if len(sys.argv) > 2:
     from datagen import make_block
-    b = np.frombuffer(make_block("alice", 65536, 1), np.uint8)
+    b = np.frombuffer(make_block(sys.argv[2], 65536, 1), np.uint8)
     src[:] = torch.from_numpy(b.copy()).to(eng.dev)
 dst = torch.empty((n, 73856), dtype=torch.uint8, device=eng.dev)
 jobs = eng.jobs_strided(src, 65536, np.full(n, 65536, np.uint32), dst, 73856, 73856)
