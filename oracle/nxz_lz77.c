@@ -18,6 +18,8 @@
  *     Window bytes are inserted first.  Block positions are handled in
  *     chunks of CHUNK positions: all positions of a chunk look up head[]
  *     (state before the chunk), then all are inserted (max wins).
+ *     Positions deep inside a byte run (the 12 bytes p-8 .. p+3 all equal)
+ *     take no part in the table, neither lookup nor insert.
  *  4. A candidate q is a match if dist = p-q <= 32768 and >= 4 bytes agree;
  *     it is extended to at most 258 bytes / end of sub-block.  A second
  *     candidate at distance 1 is tried when load32(p-1) == load32(p)
@@ -108,6 +110,20 @@ static uint32_t walk(const uint8_t *w, uint32_t h, const uint16_t *mlen, const u
 uint16_t *nxo_dbg_mlen, *nxo_dbg_mdist; uint32_t *nxo_dbg_x;
 
 /* one sub-block: w[0..h) window, w[h..h+n) block.  n <= NXO_SUBBLOCK, h <= NXO_WINDOW */
+/* Positions deep inside a run of one byte value -- the 12 bytes w[r-8 .. r+3] are all the same --
+ * are left out of the hash table (neither looked up nor inserted): there the distance-1 candidate is
+ * what counts, and a table in which thousands of positions share one slot is of no use to anyone. */
+static inline int deep_in_run(const uint8_t *w, uint32_t r)
+{
+	uint32_t k;
+	if (r < 8)
+		return 0;
+	for (k = r - 8; k < r + 3; k++)
+		if (w[k] != w[k + 1])
+			return 0;
+	return 1;
+}
+
 static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *tok)
 {
 	static __thread uint32_t head[1u << NXO_HBITS];
@@ -120,6 +136,8 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 	/* 3. window seeding (entries are position+1; 0 == empty) */
 	for (r = 0; r < h && r + 4 <= end; r++) {
 		uint32_t hv = hash4(ld32(w + r));
+		if (deep_in_run(w, r))
+			continue;
 		if (head[hv] < r + 1)
 			head[hv] = r + 1;
 	}
@@ -132,7 +150,7 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 			r = h + j;
 			if (r + 4 <= end) {
 				uint32_t v = ld32(w + r);
-				uint32_t cand = head[hash4(v)];
+				uint32_t cand = deep_in_run(w, r) ? 0 : head[hash4(v)];
 				uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
 				if (cand != 0 && r - (cand - 1) <= NXO_WINDOW &&
 				    ld32(w + cand - 1) == v) {
@@ -154,7 +172,7 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 		}
 		for (j = c; j < cend; j++) {
 			r = h + j;
-			if (r + 4 <= end) {
+			if (r + 4 <= end && !deep_in_run(w, r)) {
 				uint32_t hv = hash4(ld32(w + r));
 				if (head[hv] < r + 1)
 					head[hv] = r + 1;

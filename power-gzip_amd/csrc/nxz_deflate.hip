@@ -56,7 +56,7 @@ constexpr uint32_t NOHASH = 0xFFFFu;
 // ---- LDS carve (bytes) ----
 constexpr uint32_t OFF_IN    = 0;                        // 65536 + 32 pad
 constexpr uint32_t OFF_HEAD  = 65536 + 32;               // 8192 x u32
-constexpr uint32_t OFF_CAND  = OFF_HEAD + HSIZE * 4 + 16; // 16384 x u16 (head[HSIZE] is a dummy slot)
+constexpr uint32_t OFF_CAND  = OFF_HEAD + HSIZE * 4 + 256; // 16384 x u16 (head[HSIZE + lane]: one dummy slot per lane of the chain wave)
 constexpr uint32_t OFF_MLEN  = OFF_CAND + PTILE * 2;     // 16384 x u8
 constexpr uint32_t OFF_SBITS = OFF_MLEN + PTILE;         // 512 x u32   (aliased: MARK u8[1024] during chain marking)
 constexpr uint32_t OFF_MBITS = OFF_SBITS + PTILE / 8;    // 512 x u32   (aliased: JUMP u16[1024])
@@ -68,7 +68,8 @@ constexpr uint32_t BITS_BYTES = ETILE * 2 + 64;
 // (tails beyond LCAP) and the e-flag bitmap (PTILE + 288 bits)
 constexpr uint32_t OFF_LQ    = OFF_X;
 constexpr uint32_t OFF_XQ    = OFF_LQ + 16 * 96 * 2;
-constexpr uint32_t OFF_EB    = OFF_XQ + 16 * 80 * 2;     // 2096 bytes
+constexpr uint32_t OFF_EB    = OFF_XQ + 16 * 80 * 2;     // 2096 bytes; bit EBO + i = flag of tile position i
+constexpr uint32_t EBO       = 32;                       // flags of the 32 positions in front of the tile come first
 static_assert(OFF_EB % 16 == 0 && OFF_EB + 2096 <= OFF_BITS + BITS_BYTES, "match-phase carve");
 constexpr uint32_t OFF_WIN   = OFF_X;                    // bit-pack window: WWORDS dwords + 16 dwords of spill
 constexpr uint32_t WWORDS    = (NSEG * 4 + ETILE * 2) / 4;   // 2048
@@ -400,7 +401,11 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 
 	// ---------------- seed head[] with the window ----------------
 	for (uint32_t r = t; r < h; r += NT)
-		if (r + 4 <= end) atomicMax(&head[hash4(lds_ld32(inw, r))], r + 1);
+		if (r + 4 <= end) {
+			const uint32_t v = lds_ld32(inw, r);
+			const bool deep = r >= 8 && lds_ld32(inw, r - 8) == v && lds_ld32(inw, r - 4) == v && v == __builtin_amdgcn_alignbyte(v, v, 1);
+			if (!deep) atomicMax(&head[hash4(v)], r + 1);
+		}
 
 	// ---------------- block header ----------------
 	// misc[M_CARRY_BITS]: bits pending in bitbuf[0..]; misc[M_WORDBASE]: dwords already flushed
@@ -447,13 +452,25 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			for (int it = 0; it < 2; it++) {
 				const uint32_t i = (piece << 9) + (it << 8) + 4 * lane, r = h + tb0 + i;   // r is a multiple of 4
 				const uint32_t d0 = inw[r >> 2], d1 = inw[(r >> 2) + 1];
-				uint32_t o0 = hash4(d0) << 2, o1 = hash4(__builtin_amdgcn_alignbyte(d1, d0, 1)) << 2;
-				uint32_t o2 = hash4(__builtin_amdgcn_alignbyte(d1, d0, 2)) << 2, o3 = hash4(__builtin_amdgcn_alignbyte(d1, d0, 3)) << 2;
+				const uint32_t v1 = __builtin_amdgcn_alignbyte(d1, d0, 1), v2 = __builtin_amdgcn_alignbyte(d1, d0, 2), v3 = __builtin_amdgcn_alignbyte(d1, d0, 3);
+				uint32_t o0 = hash4(d0) << 2, o1 = hash4(v1) << 2, o2 = hash4(v2) << 2, o3 = hash4(v3) << 2;
+				// positions that take no part in the table get the dummy slot of their chain lane
+				const uint32_t dummy = (HSIZE + ((4 * lane) & 63)) * 4;
 				if (i + 4 > tn || r + 7 > end) {                    // ragged end of the tile / of the data
-					if (i + 0 >= tn || r + 4 > end) o0 = HSIZE * 4;
-					if (i + 1 >= tn || r + 5 > end) o1 = HSIZE * 4;
-					if (i + 2 >= tn || r + 6 > end) o2 = HSIZE * 4;
-					if (i + 3 >= tn || r + 7 > end) o3 = HSIZE * 4;
+					if (i + 0 >= tn || r + 4 > end) o0 = dummy;
+					if (i + 1 >= tn || r + 5 > end) o1 = dummy + 4;
+					if (i + 2 >= tn || r + 6 > end) o2 = dummy + 8;
+					if (i + 3 >= tn || r + 7 > end) o3 = dummy + 12;
+				}
+				// deep inside a run of one byte value (the 12 bytes r-8 .. r+3 are equal, oracle/nxz_lz77.c
+				// deep_in_run): no lookup, no insert.  The 8 bytes r-4 .. r+3 of the first position
+				// are a cheap necessary condition for all four.
+				if (r >= 8 && d0 == __builtin_amdgcn_alignbyte(d0, d0, 1) && inw[(r >> 2) - 1] == d0) {
+					auto deep = [&](uint32_t rr, uint32_t v) { return lds_ld32(inw, rr - 8) == v && lds_ld32(inw, rr - 4) == v && v == __builtin_amdgcn_alignbyte(v, v, 1); };
+					if (deep(r, d0)) o0 = dummy;
+					if (deep(r + 1, v1)) o1 = dummy + 4;
+					if (deep(r + 2, v2)) o2 = dummy + 8;
+					if (deep(r + 3, v3)) o3 = dummy + 12;
 				}
 				*(uint2 *)(cand + i) = make_uint2(o0 | o1 << 16, o2 | o3 << 16);
 			}
@@ -468,9 +485,10 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// distance-1 candidates are runs of these flags (used by the match phase and M3)
 		{
 			uint16_t *eb16 = (uint16_t *)(lds + OFF_EB);
-			const uint32_t ngroups = (tn + 288 + 15) / 16 + 2;
+			const uint32_t ngroups = (tn + EBO + 288 + 15) / 16 + 2;
 			for (uint32_t g = t; g < ngroups; g += NT) {
-				const uint32_t r0 = h + tb0 + 16 * g;                 // 16-byte aligned
+				const int32_t r0s = (int32_t)(h + tb0 + 16 * g) - (int32_t)EBO;     // 16-byte aligned, may lie in front of the data
+				const uint32_t r0 = r0s < 0 ? end : (uint32_t)r0s;
 				uint32_t bits = 0;
 				if (r0 < end) {
 					const uint4 dv = *(const uint4 *)(lds + OFF_IN + r0);
@@ -525,7 +543,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				__builtin_amdgcn_wave_barrier();
 			};
-			const uint32_t dm = HSIZE * 4 | (HSIZE * 4) << 16;
+			const uint32_t dm = (HSIZE + lane) * 4 | ((HSIZE + lane) * 4) << 16;
 			const uint4 dummy = make_uint4(dm, dm, dm, dm);
 			for (uint32_t base = 0; base < npieces; base += 4) {
 				const uint4 *cp = (const uint4 *)cand + (base << 6) + lane;
@@ -663,10 +681,6 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					} else if (w32 == 0 && i + 1 == pend && pend < tn) {
 						// last position of the piece: settled after the barrier
 						atomicOr(&misc[M_DEFER], 1u << ((i >> 9) & 31));
-					} else if (i >= 32 && bits32(eb, i - 31) == 0xffffffffu && first_zero(eb, i, i + 272) - i >= maxlen) {
-						// inside a long run of equal bytes (it began at least 32 positions back and goes on
-						// for maxlen): the distance-1 candidate is at least as long as anything and wins
-						// ties, here and for every position that could link to this one -- nothing to do
 					} else {
 						// tail: extend, lane-serial up to LCAP = 8 + 2 x 16 bytes
 						if (len == 24) len += equal16(inw, q + 24, r + 24);
@@ -740,6 +754,9 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 						// FULL: far enough from the end of the tile and of the data, no clamps needed
 						constexpr bool FULL = decltype(fullt)::value;
 						const uint2 qq = *(const uint2 *)(cand + i4);
+						// deep-in-run positions took no part in the table (what the chain wave left
+						// in their place is meaningless): flags i-7 .. i+3 all set
+						const uint32_t w14 = bits32(eb, EBO + i4 - 7);
 						const uint32_t d0 = inw[r4 >> 2], d1 = inw[(r4 >> 2) + 1], d2 = inw[(r4 >> 2) + 2];
 						uint32_t mw = 0, c01 = 0, c23 = 0, vbits = 0, kbits = 0;
 						bool okA[4], raw8[4], lng[4];
@@ -748,7 +765,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 						for (int j = 0; j < 4; j++) {
 							const uint32_t qc = (uint16_t)((uint16_t)((j & 2 ? qq.y : qq.x) >> (16 * (j & 1))) - 1);   // candidate position from the chain (0xffff = none)
 							const uint32_t i = i4 + j, r = r4 + j;
-							const bool ok = FULL || (i < tn && r + 4 <= end);
+							const bool ok = (FULL || (i < tn && r + 4 <= end)) && ((w14 >> j) & 0x7ff) != 0x7ff;
 							const uint32_t maxlen = FULL || end - r >= MAXMATCH ? MAXMATCH : end - r;
 							dA[j] = r - qc - 1;                         // distance - 1; wraps to something huge if qc >= r
 							const bool qok = ok && dA[j] < WINDOW;
@@ -866,7 +883,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		uint32_t sm0 = 0, sm1 = 0, sm2 = 0, sm3 = 0;          // final stored lengths (len-3, 0 = none) of my 16 positions
 		if (p0 < tn) {
 			const uint32_t *eb = (const uint32_t *)(lds + OFF_EB);
-			const uint32_t e32 = lds_ld32(eb, 2 * t);               // my 16 flags and the next 16
+			const uint32_t e32 = lds_ld32(eb, 2 * t + EBO / 8);     // my 16 flags and the next 16
 			const uint32_t e16 = e32 & 0xffff;
 			const uint32_t r4 = e32 & (e32 >> 1) & (e32 >> 2) & (e32 >> 3) & 0xffff;   // runs of >= 4 that start in my group
 			const uint4 mv = *(const uint4 *)(mlen + p0);
@@ -877,7 +894,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				const uint32_t mw[4] = { mv.x, mv.y, mv.z, mv.w };
 				uint32_t cw[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
 				uint32_t zb = 16;
-				if (e16 >> 15) zb = first_zero(eb, p0 + 16, p0 + 16 + 272) - p0;
+				if (e16 >> 15) zb = first_zero(eb, EBO + p0 + 16, EBO + p0 + 16 + 272) - EBO - p0;
 				const uint32_t r15 = h + tb0 + p0 + 15;
 				uint32_t om[4] = { 0, 0, 0, 0 };
 #pragma unroll
