@@ -706,9 +706,11 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					uint32_t len = LCAP;
 					while (__ballot(lg)) {
 						if (lg) {
-							const uint32_t k = equal16(inw, q + len, r + len);
+							// 32 bytes per round trip
+							const uint32_t k1 = equal16(inw, q + len, r + len), k2 = equal16(inw, q + len + 16, r + len + 16);
+							const uint32_t k = k1 == 16 ? 16 + k2 : k1;
 							len += k;
-							if (k < 16 || len >= maxlen) {
+							if (k < 32 || len >= maxlen) {
 								lg = false;
 								mlen[i] = (uint8_t)((len < maxlen ? len : maxlen) - 3);
 							}
@@ -818,33 +820,29 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		__syncthreads();
 		PROF(12);
 		// the piece-last long positions: member if the first position of the next piece continues
-		// the match, tail otherwise -- extended right here by the whole wave, 256 bytes per step
-		if (wave == 0) {
-			const uint32_t i = ((uint32_t)lane << 9) + 511;
-			bool need = false;
-			if (lane < 32 && (misc[M_DEFER] >> lane) & 1) {
-				if (cand[i + 1] == cand[i]) {
-					if (mlen[i + 1] >= 5) kb[i >> 5] |= 0x80000000u;      // successor has 8 bytes or more: member
-				} else need = true;
+		// the match, tail otherwise -- extended right here by a whole wave, 256 bytes per step
+		for (uint32_t pc = wave; pc < 32; pc += NT / 64) {
+			if (!((misc[M_DEFER] >> pc) & 1)) continue;
+			const uint32_t ii = (pc << 9) + 511;
+			if (cand[ii + 1] == cand[ii]) {
+				if (lane == 0 && mlen[ii + 1] >= 5) kb[ii >> 5] |= 0x80000000u;     // successor has 8 bytes or more: member
+				continue;
 			}
-			for (unsigned long long nm = __ballot(need); nm; nm &= nm - 1) {
-				const uint32_t ii = ((uint32_t)__builtin_ctzll(nm) << 9) + 511;
-				const uint32_t r = h + tb0 + ii, q = r - cand[ii] - 1;
-				const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-				uint32_t N = maxlen;
-				for (uint32_t ob = 8; ob < maxlen; ob += 256) {
-					const uint32_t o = ob + 4 * lane;
-					const uint32_t x = o < maxlen ? lds_ld32(inw, q + o) ^ lds_ld32(inw, r + o) : 0;
-					const unsigned long long mm = __ballot(x != 0);
-					if (mm) {
-						const int fl = __builtin_ctzll(mm);
-						const uint32_t nn = ob + 4 * fl + ((uint32_t)__builtin_ctz(__shfl(x, fl, 64)) >> 3);
-						N = nn < maxlen ? nn : maxlen;
-						break;
-					}
+			const uint32_t r = h + tb0 + ii, q = r - cand[ii] - 1;
+			const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+			uint32_t N = maxlen;
+			for (uint32_t ob = 8; ob < maxlen; ob += 256) {
+				const uint32_t o = ob + 4 * lane;
+				const uint32_t x = o < maxlen ? lds_ld32(inw, q + o) ^ lds_ld32(inw, r + o) : 0;
+				const unsigned long long mm = __ballot(x != 0);
+				if (mm) {
+					const int fl = __builtin_ctzll(mm);
+					const uint32_t nn = ob + 4 * fl + ((uint32_t)__builtin_ctz(__shfl(x, fl, 64)) >> 3);
+					N = nn < maxlen ? nn : maxlen;
+					break;
 				}
-				if (lane == 0) mlen[ii] = (uint8_t)(N - 3);
 			}
+			if (lane == 0) mlen[ii] = (uint8_t)(N - 3);
 		}
 		__syncthreads();
 		PROF(10);
