@@ -746,6 +746,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				}
 				// upper half first, so that a successor's entry is in place when a long position is
 				// classified
+				uint32_t upper_key0 = 0xffffffffu;                 // first position of the half piece behind the current one
 #pragma unroll 1
 				for (int it = 1; it >= 0; it--) {
 					const uint32_t ib = (piece << 9) + ((uint32_t)it << 8);
@@ -796,7 +797,17 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 							kbits |= (uint32_t)(lng[j] && direct && raw8[j + 1]) << j;
 							qbits |= (uint32_t)(lng[j] && !direct) << j;
 						}
-						qbits |= (uint32_t)lng[3] << 3;
+						// my last position: its direct successor is the first position of the next lane (of
+						// the half piece processed before this one for lane 63; unknown at the piece end)
+						{
+							const uint32_t key0 = okA[0] ? dA[0] | (uint32_t)raw8[0] << 16 : 0xffffffffu;
+							uint32_t skey = __shfl_down(key0, 1, 64);
+							if (lane == 63) skey = upper_key0;
+							upper_key0 = __builtin_amdgcn_readfirstlane(key0);
+							const bool direct = skey != 0xffffffffu && (skey & 0xffff) == dA[3];
+							kbits |= (uint32_t)(lng[3] && direct && (skey >> 16)) << 3;
+							qbits |= (uint32_t)(lng[3] && !direct) << 3;
+						}
 						*(uint32_t *)(mlen + i4) = mw;
 						*(uint2 *)(cand + i4) = make_uint2(c01, c23);
 						if (vbits) atomicOr(&vb[i4 >> 5], vbits << (i4 & 31));

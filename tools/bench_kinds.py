@@ -21,4 +21,15 @@ for kind in ("zeros", "random", "text33", "alice", "lz", "periodic", "binary", "
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
     r = eng.results_to_host(res)
     okb = r["cc"] == 0
-    print("%-9s %7.1f GiB/s   ratio %6.2f   cc=0 for %d of %d" % (kind, n * 65536 / dt / 2**30, (okb.sum() * 65536) / max(1, int(r["tpbc"][okb].sum())), okb.sum(), n))
+    line = "%-9s deflate %7.1f GiB/s   ratio %6.2f   cc=0 for %d of %d" % (kind, n * 65536 / dt / 2**30, (okb.sum() * 65536) / max(1, int(r["tpbc"][okb].sum())), okb.sum(), n)
+    if okb.all():
+        back = torch.empty((n, 65536), dtype=torch.uint8, device=eng.dev)
+        jd = eng.jobs_strided(dst, 73856, r["tpbc"].astype(np.uint32), back, 65536, 65536)
+        rd = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
+        eng.decompress(jd, n, results=rd); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): eng.decompress(jd, n, results=rd)
+        torch.cuda.synchronize(); dt2 = (time.perf_counter() - t0) / 3
+        assert torch.equal(back, src)
+        line += "   inflate %7.1f GiB/s (round trip ok)" % (n * 65536 / dt2 / 2**30)
+    print(line)
