@@ -393,8 +393,8 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			}
 		}
 		__syncthreads();
-		out_crc = scan[48];
-		out_adler = scan[49];
+		out_crc = __builtin_amdgcn_readfirstlane(scan[48]);      // wave-uniform: keep them in scalar registers until the end
+		out_adler = __builtin_amdgcn_readfirstlane(scan[49]);
 		__syncthreads();
 	}
 	PROF(1);
@@ -874,7 +874,11 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				uint32_t T;
 				if (z) T = p0 + (uint32_t)__builtin_ctz(z);
 				else {
-					if (T_ext == 0xffffffffu) T_ext = first_zero(kb, p0 + 16, lim);
+					if (T_ext == 0xffffffffu) {
+						uint32_t s0 = p0 + 16;
+						asm volatile("" : "+v"(s0));                  // not hoisted out of the tile loop (it would be spilled)
+						T_ext = first_zero(kb, s0, lim);
+					}
 					T = T_ext;
 				}
 				if (T != T_prev) {
@@ -903,7 +907,11 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				const uint32_t mw[4] = { mv.x, mv.y, mv.z, mv.w };
 				uint32_t cw[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
 				uint32_t zb = 16;
-				if (e16 >> 15) zb = first_zero(eb, EBO + p0 + 16, EBO + p0 + 16 + 272) - EBO - p0;
+				if (e16 >> 15) {
+					uint32_t s0 = EBO + p0 + 16;
+					asm volatile("" : "+v"(s0));                      // as above
+					zb = first_zero(eb, s0, s0 + 272) - EBO - p0;
+				}
 				const uint32_t r15 = h + tb0 + p0 + 15;
 				uint32_t om[4] = { 0, 0, 0, 0 };
 #pragma unroll
