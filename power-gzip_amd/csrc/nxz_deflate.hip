@@ -83,6 +83,7 @@ static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
 enum { M_ERR = 0, M_CARRY_BITS = 1, M_WORDBASE = 2, M_CARRY_WORD = 3, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6 };
+static_assert(M_TICKET == M_PROGRESS + 1 && M_DEFER == M_PROGRESS + 2, "cleared together");
 
 __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
 {
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// slot offsets and results with one ds_read_b128 / ds_write_b128 per lane.
 		const uint32_t tnpad = (tn + 511) & ~511u;
 		const uint32_t npieces = tnpad >> 9;
-		if (t == 0) { misc[M_PROGRESS] = 0; misc[M_TICKET] = 0; misc[M_DEFER] = 0; }
+		if (t < 3) misc[M_PROGRESS + t] = 0;                    // M_PROGRESS, M_TICKET, M_DEFER
 		sbits[t] = 0;                                           // vb and kb (adjacent, 2 x 512 words)
 		for (uint32_t piece = wave; piece < npieces; piece += NT / 64) {
 #pragma unroll
