@@ -71,8 +71,12 @@ constexpr uint32_t OFF_XQ    = OFF_LQ + 16 * 96 * 2;
 constexpr uint32_t OFF_EB    = OFF_XQ + 16 * 80 * 2;     // 2096 bytes; bit EBO + i = flag of tile position i
 constexpr uint32_t EBO       = 32;                       // flags of the 32 positions in front of the tile come first
 static_assert(OFF_EB % 16 == 0 && OFF_EB + 2096 <= OFF_BITS + BITS_BYTES, "match-phase carve");
-constexpr uint32_t OFF_WIN   = OFF_X;                    // bit-pack window: WWORDS dwords + 16 dwords of spill
-constexpr uint32_t WWORDS    = (NSEG * 4 + ETILE * 2) / 4;   // 2048
+// bit-pack window of the encode phase: MBITS, X, ENTRY and BITS together (the token bitmap of the
+// final walk lives in SBITS): WWORDS dwords + 16 dwords of spill.  10 KiB hold a whole tile's output
+// whenever the data shrinks to 5/8 or less.
+constexpr uint32_t OFF_WIN   = OFF_MBITS;
+constexpr uint32_t WWORDS    = (PTILE / 8 + NSEG * 4 + ETILE * 2) / 4;   // 2560
+static_assert(OFF_WIN + (WWORDS + 16) * 4 <= OFF_BITS + BITS_BYTES, "window");
 constexpr uint32_t OFF_SCAN  = OFF_BITS + BITS_BYTES;    // 64 x u32
 constexpr uint32_t OFF_LLTAB = OFF_SCAN + 256;           // 288 x u32
 constexpr uint32_t OFF_DTAB  = OFF_LLTAB + 288 * 4;      // 32 x u32
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 	uint16_t *entry = (uint16_t *)(lds + OFF_ENTRY);
 	uint32_t *sbits = (uint32_t *)(lds + OFF_SBITS);
 	uint32_t *mbits = (uint32_t *)(lds + OFF_MBITS);
+	uint32_t *tokbits = sbits;                           // match-token bitmap of the final walk (SBITS is free by then)
 	uint8_t *mark = lds + OFF_SBITS;
 	uint16_t *jump = (uint16_t *)(lds + OFF_MBITS);
 	uint32_t *bitbuf = (uint32_t *)(lds + OFF_BITS);
@@ -1025,7 +1030,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		if (dbg && blockIdx.x == 0 && (uint32_t)t < nseg)
 			dbg[(tb0 / PTILE) * 65536 + 16384 + t] = myx | (mye << 16) | (entered ? 0x80000000u : 0);
 		// token bitmaps (alias mark/jump, which are dead now) are cleared
-		for (uint32_t i = t; i < PTILE / 32; i += NT) mbits[i] = 0;
+		for (uint32_t i = t; i < PTILE / 32; i += NT) tokbits[i] = 0;
 		__syncthreads();
 
 		PROF(7);
@@ -1103,7 +1108,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				put((dt & 0xffff) | ((d & ((1u << de) - 1)) << dl), dl + de);                // <= 28 bits (0 for a single literal)
 				mine += ll + le + dl + de;
 				if (m) {
-					atomicOr(&mbits[p >> 5], 1u << (p & 31));
+					atomicOr(&tokbits[p >> 5], 1u << (p & 31));
 					mlen[p] = (uint8_t)l3;
 				}
 				if (COUNT) {
@@ -1187,7 +1192,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					};
 					while (p < plim && bitpos < whi) {
 						uint32_t adv;
-						if (mbits[p >> 5] >> (p & 31) & 1) {
+						if (tokbits[p >> 5] >> (p & 31) & 1) {
 							uint32_t l = mlen[p], d = cand[p];            // len-3, dist-1
 							uint32_t le = l < 8 ? 0 : (29 - __builtin_clz(l));
 							uint32_t ls = l == 255 ? 28 : (le << 2) + (l >> le);
