@@ -1032,6 +1032,9 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		// token bitmaps (alias mark/jump, which are dead now) are cleared
 		for (uint32_t i = t; i < PTILE / 32; i += NT) tokbits[i] = 0;
 		__syncthreads();
+		// ... and so is the bit-pack window of the encode phase: MBITS / X / ENTRY / BITS are all dead
+		// now (every thread has its entry), the final walk does not touch them
+		for (uint32_t i = t; i < WWORDS + 16; i += NT) ((uint32_t *)(lds + OFF_WIN))[i] = 0;
 
 		PROF(7);
 		// ---- parse pass 2: entered segments walk [entry, X[s]) for real ----
@@ -1145,8 +1148,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			const uint32_t total = carry + tot;                // bits of this tile's stream incl. the carried partial word
 			uint32_t bitpos = carry + woff + incl - mine;      // my first token, in that stream
 			const uint32_t bend = bitpos + mine;
-			for (uint32_t i = t; i < WWORDS + 16; i += NT) win[i] = (i == 0) ? carryword : 0;
-			__syncthreads();
+			if (t == 0 && carryword) atomicOr(&win[0], carryword);    // the window was cleared before the final walk
 			PROF(13);
 			uint32_t p = mye;
 			const uint32_t plim = (entered && loverflow) ? myx : 0;
