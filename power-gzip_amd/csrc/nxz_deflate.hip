@@ -86,7 +86,7 @@ constexpr uint32_t LDS_BYTES = OFF_MISC + 64;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
-enum { M_ERR = 0, M_CARRY_BITS = 1, M_WORDBASE = 2, M_CARRY_WORD = 3, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6 };
+enum { M_ERR = 0, M_CARRY_BITS = 1, M_WORDBASE = 2, M_CARRY_WORD = 3, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7 };
 static_assert(M_TICKET == M_PROGRESS + 1 && M_DEFER == M_PROGRESS + 2, "cleared together");
 
 __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
@@ -226,7 +226,7 @@ template <bool DHT, bool COUNT>
 __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__restrict__ jobs,
 						     const nxz_dht_prepared_t *__restrict__ tables,
 						     nxz_batch_result_t *__restrict__ results,
-						     uint32_t *__restrict__ counts)
+						     uint32_t *__restrict__ counts, uint32_t njobs, uint32_t *__restrict__ next_job)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	uint32_t *inw = (uint32_t *)(lds + OFF_IN);
@@ -247,11 +247,21 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 	uint32_t *hist = (uint32_t *)(lds + OFF_HIST);
 	uint32_t *misc = (uint32_t *)(lds + OFF_MISC);
 
-	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	NXZ_GLOBAL unsigned long long *prof = (NXZ_GLOBAL unsigned long long *)nxz_prof_buf;
 	NXZ_GLOBAL uint32_t *dbg = (NXZ_GLOBAL uint32_t *)nxz_debug_buf;
+	// The grid is one workgroup per CU (the LDS image allows no more); a workgroup starts with job
+	// blockIdx.x and then draws further jobs from a counter (or strides by the grid without one), so
+	// nothing waits for a dispatch in between and slow jobs do not pile up in one place.  The draw
+	// for the job after this one is issued at once; its latency hides behind the work.
+	for (uint32_t bid = blockIdx.x; bid < njobs;) {
+	if (next_job && threadIdx.x == 0) misc[M_NEXT] = gridDim.x + atomicAdd(next_job, 1u);   // parked in LDS, not in a register
+	// (the thread index is made opaque per job: what is derived from it would otherwise be hoisted out
+	// of this loop and kept -- spilled -- for the whole kernel)
+	int tid_ = threadIdx.x;
+	asm volatile("" : "+v"(tid_));
+	const int t = tid_, lane = t & 63, wave = t >> 6;
 	unsigned long long tprev = prof ? clock64() : 0;
-	const nxz_batch_job_t job = jobs[blockIdx.x];
+	const nxz_batch_job_t job = jobs[bid];
 	const uint32_t total = job.src_len;                  // window + block
 	const uint32_t h = job.hist_len < total ? job.hist_len : total;
 	const uint32_t n = total - h;
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 	}
 	for (uint32_t i = t; i < HSIZE; i += NT) head[i] = 0;
 	if (t < 316) hist[t] = 0;
-	if (t < 16) misc[t] = 0;
+	if (t < 16 && t != M_NEXT) misc[t] = 0;
 	if (DHT) {
 		const nxz_dht_prepared_t *tb = &tables[job.dht_index];
 		if (t < 288) lltab[t] = tb->ll[t];
@@ -947,7 +957,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		__syncthreads();
 		for (uint32_t s = t; s < NSEG; s += NT) mark[s] = 0;
 		__syncthreads();
-		if (dbg && blockIdx.x == 0)
+		if (dbg && bid == 0)
 			for (uint32_t i = t; i < tn; i += NT) dbg[(tb0 / PTILE) * 65536 + i] = cand[i] | ((uint32_t)mlen[i] << 16);
 
 		PROF(5);
@@ -1027,7 +1037,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		if (entered && myx < tn) entry[myx / PSEG] = (uint16_t)myx;
 		__syncthreads();
 		uint32_t mye = entered ? entry[t] : 0;
-		if (dbg && blockIdx.x == 0 && (uint32_t)t < nseg)
+		if (dbg && bid == 0 && (uint32_t)t < nseg)
 			dbg[(tb0 / PTILE) * 65536 + 16384 + t] = myx | (mye << 16) | (entered ? 0x80000000u : 0);
 		// token bitmaps (alias mark/jump, which are dead now) are cleared
 		for (uint32_t i = t; i < PTILE / 32; i += NT) tokbits[i] = 0;
@@ -1266,11 +1276,16 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		nxz_batch_result_t r;
 		r.cc = cc; r.tpbc = cc == NXZ_CC_TARGET_SPACE ? 0 : tpbc; r.tebc = (uint32_t)(totbits & 7);
 		r.spbc = total; r.crc = out_crc; r.adler = out_adler; r.subc = 0; r.sfbt = 0;
-		results[blockIdx.x] = r;
+		results[bid] = r;
 	}
 	if (COUNT) {
 		__syncthreads();
-		if (t < 316) counts[(size_t)blockIdx.x * 316 + t] = (t == 256) ? 1u : hist[t];
+		if (t < 316) counts[(size_t)bid * 316 + t] = (t == 256) ? 1u : hist[t];
+	}
+	__syncthreads();                                           // the LDS image is reused by the next job
+	const uint32_t drawn = next_job ? misc[M_NEXT] : bid + gridDim.x;
+	__syncthreads();                                           // misc[M_NEXT] is rewritten at the top
+	bid = drawn;
 	}
 }
 
@@ -1288,11 +1303,11 @@ extern "C" int nxz_prof_set(unsigned long long *buf)
 
 extern "C" int nxz_launch_deflate(int dht, int count, const nxz_batch_job_t *jobs, size_t n,
 				  const nxz_dht_prepared_t *tables, nxz_batch_result_t *results,
-				  uint32_t *counts, hipStream_t stream)
+				  uint32_t *counts, uint32_t *job_counter, hipStream_t stream)
 {
 	using namespace nxz;
 	static bool attr_done = false;
-	void (*k)(const nxz_batch_job_t *, const nxz_dht_prepared_t *, nxz_batch_result_t *, uint32_t *);
+	void (*k)(const nxz_batch_job_t *, const nxz_dht_prepared_t *, nxz_batch_result_t *, uint32_t *, uint32_t, uint32_t *);
 	if (dht) k = count ? deflate_kernel<true, true> : deflate_kernel<true, false>;
 	else     k = count ? deflate_kernel<false, true> : deflate_kernel<false, false>;
 	if (!attr_done) {
@@ -1303,6 +1318,16 @@ extern "C" int nxz_launch_deflate(int dht, int count, const nxz_batch_job_t *job
 		attr_done = true;
 	}
 	if (n == 0) return 0;
-	hipLaunchKernelGGL(k, dim3((unsigned)n), dim3(NT), LDS_BYTES, stream, jobs, tables, results, counts);
+	static int ncu = 0;
+	if (!ncu) {
+		int dev = 0;
+		hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+		if (ncu <= 0) ncu = 256;
+	}
+	const unsigned grid = (unsigned)(n < (size_t)ncu ? n : (size_t)ncu);
+	if (n <= grid) job_counter = nullptr;                      // one job per workgroup: nothing to draw
+	if (job_counter && hipMemsetAsync(job_counter, 0, sizeof(uint32_t), stream) != hipSuccess) job_counter = nullptr;
+	hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS_BYTES, stream, jobs, tables, results, counts, (uint32_t)n, job_counter);
 	return (int)hipGetLastError();
 }

@@ -20,7 +20,7 @@ typedef struct nxz_dht_prepared {
 extern "C" {
 int nxz_launch_deflate(int dht, int count, const nxz_batch_job_t *jobs, size_t n,
 		       const nxz_dht_prepared_t *tables, nxz_batch_result_t *results,
-		       uint32_t *counts, hipStream_t stream);
+		       uint32_t *counts, uint32_t *job_counter, hipStream_t stream);   /* job_counter: one device word per launch in flight, or NULL */
 int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_dht_prepared_t *out, hipStream_t stream);
 int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,

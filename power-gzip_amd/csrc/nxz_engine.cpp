@@ -66,7 +66,10 @@ struct nxz_ctx {
 	nxz_dht_prepared_t *d_prepared = nullptr;
 	size_t prepared_cap = 0;
 	uint8_t *d_lanes_ws = nullptr;                // per-lane decode tables of the batched inflate kernel
+	uint32_t *d_job_counters = nullptr;           // job counters of the batched deflate launches (ring)
+	unsigned next_counter = 0;
 };
+static constexpr unsigned JOB_COUNTERS = 256;
 
 static std::mutex g_mtx;
 static nxz_ctx *g_ctx[64];
@@ -141,6 +144,7 @@ extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 	for (auto &s : c->slots) if (s.stream) slot_free(s);
 	if (c->d_prepared) (void)hipFree(c->d_prepared);
 	if (c->d_lanes_ws) (void)hipFree(c->d_lanes_ws);
+	if (c->d_job_counters) (void)hipFree(c->d_job_counters);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	g_ctx[c->device] = nullptr;
 	delete c;
@@ -179,7 +183,13 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 		int rc = nxz_launch_dht_prepare(dht, ntables, c->d_prepared, s);
 		if (rc) { set_err("dht prepare launch", (hipError_t)rc); return -EIO; }
 	}
-	int rc = nxz_launch_deflate(isdht, count, jobs, n, c->d_prepared, results, counts, s);
+	uint32_t *jc = nullptr;
+	{
+		std::lock_guard<std::mutex> g(c->mtx);
+		if (!c->d_job_counters && hipMalloc((void **)&c->d_job_counters, JOB_COUNTERS * sizeof(uint32_t)) != hipSuccess) c->d_job_counters = nullptr;
+		if (c->d_job_counters) jc = c->d_job_counters + (c->next_counter++ % JOB_COUNTERS);
+	}
+	int rc = nxz_launch_deflate(isdht, count, jobs, n, c->d_prepared, results, counts, jc, s);
 	if (rc) { set_err("deflate launch", (hipError_t)rc); return -EIO; }
 	return 0;
 }
@@ -377,7 +387,7 @@ static int run_compress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 		HIPCHK(hipMemcpyAsync(s->d_dht, s->h_dht, sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s->stream), return -EIO);
 		if (nxz_launch_dht_prepare(s->d_dht, 1, s->d_prep, s->stream)) return -EIO;
 	}
-	if (nxz_launch_deflate(dht, count, s->d_job, 1, s->d_prep, s->d_res, s->d_cnt, s->stream)) return -EIO;
+	if (nxz_launch_deflate(dht, count, s->d_job, 1, s->d_prep, s->d_res, s->d_cnt, nullptr, s->stream)) return -EIO;
 	HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
 	if (count) HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, 316 * 4, hipMemcpyDeviceToHost, s->stream), return -EIO);
 	HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
