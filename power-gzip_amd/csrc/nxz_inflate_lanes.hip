@@ -363,6 +363,7 @@ __global__ __launch_bounds__(64, 4) void inflate_lanes_kernel(const nxz_batch_jo
 						b.drop(eb);
 						if (dist > w.out + hist || dist > 32768) { cc = NXZ_CC_INVALID_DIST; state = 3; break; }
 						if (len > cap - w.out) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
+						if (w.al && len <= 8 && dist >= len + 4 && dist <= w.out) { w.copy_short(len, dist); continue; }
 						w.flush();
 						if (dist > w.out) {
 							// (part of) the source is in the history buffer

@@ -73,6 +73,29 @@ struct OutWr {
 		for (uint32_t k = 0; k < wn; k++) dst[out - wn + k] = (uint8_t)(wb >> (8 * k));
 		wb = 0; wn = 0;
 	}
+	// append n <= 8 bytes (low byte first), through the same four-at-a-time path as the literals
+	NXZ_LANE_FN void append(uint64_t v, uint32_t n)
+	{
+		while (n) {
+			if (wn == 0 && (!al || (out & 3))) { dst[out++] = (uint8_t)v; v >>= 8; n--; continue; }
+			const uint32_t k = 4 - wn < n ? 4 - wn : n;
+			wb |= (uint32_t)(v & (k == 4 ? 0xffffffffu : (1u << (8 * k)) - 1)) << (8 * wn);
+			wn += k; out += k; n -= k;
+			v = k == 4 ? v >> 32 : v >> (8 * k);
+			if (wn == 4) { *(uint32_t *)(dst + out - 4) = wb; wb = 0; wn = 0; }
+		}
+	}
+	// a short match (len <= 8) whose source lies clear of the pending bytes (dist >= len + 4): fetch
+	// the source bytes with aligned dword loads and append them -- no flush, no byte stores
+	NXZ_LANE_FN void copy_short(uint32_t len, uint32_t dist)
+	{
+		const uintptr_t sa = (uintptr_t)(dst + out - dist);
+		const uint32_t *sw = (const uint32_t *)(sa & ~(uintptr_t)3);
+		const uint32_t bo = (uint32_t)sa & 3;
+		const uint32_t w0 = sw[0], w1 = bo + len > 4 ? sw[1] : 0, w2 = bo + len > 8 ? sw[2] : 0;
+		const uint32_t lo = NXZ_LANE_ALIGNBYTE(w1, w0, bo), hi = NXZ_LANE_ALIGNBYTE(w2, w1, bo);
+		append(((uint64_t)hi << 32) | lo, len);
+	}
 	// copy len bytes from distance dist (1 <= dist <= out), pending bytes flushed by the caller
 	NXZ_LANE_FN void copy(uint32_t len, uint32_t dist)
 	{

@@ -44,8 +44,9 @@ int main()
 			if (rand() % 3 && w.out) {
 				uint32_t dist = 1 + rand() % (w.out < 40 ? w.out : 40);
 				if (rand() % 4 == 0) dist = 1 + rand() % w.out;
-				uint32_t len = 3 + rand() % 256; if (len > cap - w.out) break;
-				w.flush(); w.copy(len, dist);
+				uint32_t len = 3 + rand() % ((rand() & 1) ? 8 : 256); if (len > cap - w.out) break;
+				if (w.al && len <= 8 && dist >= len + 4) w.copy_short(len, dist);      // as the kernel chooses
+				else { w.flush(); w.copy(len, dist); }
 				for (uint32_t i = 0; i < len; i++) ref[rout + i] = ref[rout + i - dist];
 				rout += len;
 			} else {
