@@ -386,3 +386,43 @@ def test_full_size_roundtrip_property(eng):
     assert (r2["crc"] == r["crc"]).all() and (r2["adler"] == r["adler"]).all()
     ratio = 65536.0 * n / r["tpbc"].sum()
     assert ratio > 1.5
+
+
+def test_batches_on_two_streams_at_once(eng):
+    """Two batched compress launches in flight on different streams (each draws its jobs from its own
+    counter) give what they give one after the other; more jobs than workgroups, fewer, and one."""
+    import torch
+    res_seq, res_par = [], []
+    for n in (1, 7, 300, 2000):
+        blocks = [make_block(("alice", "lz", "zeros", "random", "periodic")[i % 5], 65536 if i % 3 else 30000 + i, seed=i) for i in range(n)]
+        src = pack_blocks(eng, blocks, STRIDE_IN)
+        lens = np.array([len(b) for b in blocks], np.uint32)
+        outs = []
+        for mode in ("seq", "par"):
+            d1 = torch.zeros((n, STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+            d2 = torch.zeros((n, STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+            j1 = eng.jobs_strided(src, STRIDE_IN, lens, d1, STRIDE_OUT, STRIDE_OUT)
+            j2 = eng.jobs_strided(src, STRIDE_IN, lens, d2, STRIDE_OUT, STRIDE_OUT)
+            r1 = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
+            r2 = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
+            torch.cuda.synchronize()
+            if mode == "seq":
+                eng.compress(pkg.FC_COMPRESS_FHT, j1, n, results=r1)
+                torch.cuda.synchronize()
+                eng.compress(pkg.FC_COMPRESS_FHT, j2, n, results=r2)
+            else:
+                s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+                with torch.cuda.stream(s1):
+                    eng.compress(pkg.FC_COMPRESS_FHT, j1, n, results=r1)
+                with torch.cuda.stream(s2):
+                    eng.compress(pkg.FC_COMPRESS_FHT, j2, n, results=r2)
+            torch.cuda.synchronize()
+            outs.append((d1.cpu().numpy(), d2.cpu().numpy(), eng.results_to_host(r1).copy(), eng.results_to_host(r2).copy()))
+        (a1, a2, ra1, ra2), (b1, b2, rb1, rb2) = outs
+        for x, y in ((ra1, rb1), (ra2, rb2), (ra1, ra2)):
+            assert (x["cc"] == y["cc"]).all() and (x["tpbc"] == y["tpbc"]).all() and (x["crc"] == y["crc"]).all()
+        assert (a1 == b1).all() and (a2 == b2).all() and (a1 == a2).all()
+        for i in (0, n // 2, n - 1):
+            if ra1["cc"][i] == 0:
+                exp, _ = O.deflate_fixed(blocks[i])
+                assert a1[i, :len(exp)].tobytes() == exp
