@@ -1014,17 +1014,25 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		if (t == 0) mark[0] = 1;
 		__syncthreads();
 		PROF(6);
-		// ---- chain of entered segments by pointer doubling ----
+		// ---- chain of entered segments by pointer jumping ----
+		// Four hops per round (one barrier per round is what costs): a marked segment marks the
+		// segments 1, 2 and 3 jumps ahead, and the jump array is replaced by its fourth power.
+		// 4^5 = 1024 segments.
 		{
 			uint16_t *ja = jump, *jb = entry;                  // entry[] is free until the chain is known
-			for (int k = 0; k < 10; k++) {
+			uint32_t j1 = (uint32_t)t < nseg ? ja[t] : NSEG;   // my own entry stays in a register from round to round
+			for (int k = 0; k < 5; k++) {
 				if ((uint32_t)t < nseg) {
-					uint32_t j = ja[t], j2 = NSEG;
-					if (j < NSEG) {
-						if (mark[t]) mark[j] = 1;
-						j2 = ja[j];
+					const uint32_t j2 = j1 < NSEG ? ja[j1] : NSEG;
+					const uint32_t j3 = j2 < NSEG ? ja[j2] : NSEG;
+					const uint32_t j4 = j3 < NSEG ? ja[j3] : NSEG;
+					if (mark[t]) {
+						if (j1 < NSEG) mark[j1] = 1;
+						if (j2 < NSEG) mark[j2] = 1;
+						if (j3 < NSEG) mark[j3] = 1;
 					}
-					jb[t] = (uint16_t)j2;
+					jb[t] = (uint16_t)j4;
+					j1 = j4;
 				}
 				__syncthreads();
 				uint16_t *tmp = ja; ja = jb; jb = tmp;
