@@ -563,10 +563,12 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			const uint4 dummy = make_uint4(dm, dm, dm, dm);
 			for (uint32_t base = 0; base < npieces; base += 4) {
 				const uint4 *cp = (const uint4 *)cand + (base << 6) + lane;
+				// (unconditional 16-byte loads of an existing piece, then a select: a branch would split
+				// them into dword loads)
+				const uint32_t last = npieces - 1 - base;              // >= 0
+				const uint4 l1 = cp[64 * (last < 1 ? last : 1)], l2 = cp[64 * (last < 2 ? last : 2)], l3 = cp[64 * (last < 3 ? last : 3)];
 				const uint4 pk0 = cp[0];
-				const uint4 pk1 = base + 1 < npieces ? cp[64] : dummy;
-				const uint4 pk2 = base + 2 < npieces ? cp[128] : dummy;
-				const uint4 pk3 = base + 3 < npieces ? cp[192] : dummy;
+				const uint4 pk1 = last >= 1 ? l1 : dummy, pk2 = last >= 2 ? l2 : dummy, pk3 = last >= 3 ? l3 : dummy;
 				uint32_t o0[8], o1[8], o2[8], o3[8];
 				// a piece's results are packed and published half a piece later: the wait for them
 				// then leaves the younger operations in flight
