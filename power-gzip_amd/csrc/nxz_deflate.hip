@@ -700,18 +700,24 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 						// last position of the piece: settled after the barrier
 						atomicOr(&misc[M_DEFER], 1u << ((i >> 9) & 31));
 					} else {
-						// tail: extend, lane-serial up to LCAP = 8 + 2 x 16 bytes
-						if (len == 24) len += equal16(inw, q + 24, r + 24);
-						if (len > maxlen) len = maxlen;
-						mlen[i] = (uint8_t)(len - 3);
-						lg = len == LCAP && maxlen > LCAP;
-						if (lg && same_d) {
-							// LCAP (> 32 + 8) bytes are equal, so the successor (at most 32 away) lies
-							// inside my match: member of its chain after all
-							const uint64_t km = (((uint64_t)2 << g1) - 1) << (i & 31);           // bits i .. sp-1
+						// 24 bytes are compared by now.  A mismatch among them makes the length final.
+						// Otherwise a successor (same distance) inside those bytes makes me a member of
+						// its chain; failing that 16 more bytes are compared (LCAP = 8 + 2 x 16), after
+						// which a successor up to 32 away qualifies, and what is still open becomes a
+						// long tail.
+						bool open = len == 24 && maxlen > 24;
+						bool member = open && same_d && g1 < 24;
+						if (!member) {
+							if (open) { len += equal16(inw, q + 24, r + 24); open = len == LCAP && maxlen > LCAP; }
+							if (len > maxlen) len = maxlen;
+							mlen[i] = (uint8_t)(len - 3);
+							member = open && same_d;
+							lg = open && !same_d;
+						}
+						if (member) {
+							const uint64_t km = (((uint64_t)2 << g1) - 1) << (i & 31);               // bits i .. sp-1
 							atomicOr(&kb[i >> 5], (uint32_t)km);
 							if (km >> 32) atomicOr(&kb[(i >> 5) + 1], (uint32_t)(km >> 32));
-							lg = false;
 						}
 					}
 				}
