@@ -1327,10 +1327,10 @@ extern "C" int nxz_launch_deflate(int dht, int count, const nxz_batch_job_t *job
 	if (dht) k = count ? deflate_kernel<true, true> : deflate_kernel<true, false>;
 	else     k = count ? deflate_kernel<false, true> : deflate_kernel<false, false>;
 	if (!attr_done) {
-		hipFuncSetAttribute((const void *)deflate_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-		hipFuncSetAttribute((const void *)deflate_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-		hipFuncSetAttribute((const void *)deflate_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-		hipFuncSetAttribute((const void *)deflate_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+		(void)hipFuncSetAttribute((const void *)deflate_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+		(void)hipFuncSetAttribute((const void *)deflate_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+		(void)hipFuncSetAttribute((const void *)deflate_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+		(void)hipFuncSetAttribute((const void *)deflate_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 		attr_done = true;
 	}
 	if (n == 0) return 0;

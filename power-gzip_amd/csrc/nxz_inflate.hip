@@ -198,13 +198,6 @@ __device__ __forceinline__ int decode_sym(const H &h, uint32_t bits, uint32_t &n
 	return -2;
 }
 
-__device__ const uint16_t LEN_BASE_UNUSED[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
-	35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
-__device__ const uint8_t LEN_EXTRA[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
-__device__ const uint16_t DIST_BASE[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193,
-	257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
-__device__ const uint8_t DIST_EXTRA[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
-
 // Parse a dynamic block header at b.pos (after the 3 header bits).  Returns
 // 0 ok (lens filled, b.pos advanced, *tbits = table bits), 1 out of source, <0 invalid.
 __device__ __forceinline__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist, uint32_t &tbits)
