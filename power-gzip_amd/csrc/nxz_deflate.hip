@@ -5,25 +5,32 @@
 // /root/reference lib/nx_deflate.c:1808,1841; contract inc_nx/nxu.h:286-616 and
 // the consumer code lib/nx_deflate.c:969-1078).  One workgroup (1024 threads =
 // 16 wavefronts, one per CU: the working set is 159 KiB of LDS) turns one
-// sub-block of <= 64 KiB (history window included) into one deflate block.
+// sub-block of <= 64 KiB (history window included) into one deflate block; the grid is one
+// persistent workgroup per CU that draws job after job from a counter.
 // The algorithm is the position-parallel LZ77 defined in oracle/nxz_lz77.c;
 // this kernel must reproduce that restatement bit for bit.
 //
 // Phases per sub-block (all data stays in LDS between load and the coalesced
 // output flush; HBM traffic is the algorithmic U + C bytes):
 //   load     coalesced 16 B/lane global loads of [window|block] into LDS
-//   cksum    CRC-32 (zero-prefixed frame + fixed-stride GF(2) tree) and Adler-32
+//   cksum    CRC-32 (64-byte slices, slice-by-4, GF(2) weights, XOR reduce) and Adler-32 (v_dot4)
 //   seed     window positions -> head[] by LDS atomicMax (order free)
 //   per 16 KiB tile:
-//     hash   every position: 4-byte hash -> cand[] (u16)
-//     chain  ONE wave walks the tile in 64-position steps: lookup head[], then
-//            atomicMax insert (the only serial dependence of the algorithm)
-//     match  every position: verify + extend (capped at 36 B) + distance-1 run check
+//     hash   four positions per lane: 4-byte hash -> slot offsets, transposed per 512-position
+//            piece for the chain wave; "byte equals predecessor" flag bitmap
+//     chain  ONE wave walks the tile in 64-position steps: lookup head[], then atomicMax insert
+//            (the only serial dependence of the algorithm), four pieces per loop trip, results
+//            published half a piece late ...
+//     match  ... while all waves take published pieces: verify the candidate, compare 8 bytes
+//            (M1, four positions per lane); positions with 8 equal bytes are classified from a
+//            queue: member of its successor's chain, or tail that compares on (M2); after a
+//            barrier members read their length off the chain end and the distance-1 runs are
+//            evaluated from the flag bitmap (M3)
 //     parse  lane per 16-byte segment: speculative greedy/lazy walk -> exit X[s];
-//            pointer doubling marks the chain of entered segments; entered
-//            segments re-walk [entry, X[s]) and publish token bitmaps
-//     encode per 2048 positions: code lookup, workgroup prefix sum of bit
-//            lengths, LDS atomicOr bit packing, coalesced dword flush
+//            pointer jumping marks the chain of entered segments; entered segments re-walk
+//            [entry, X[s]) and assemble their Huffman codes in a register bit string
+//     encode workgroup prefix sum of the bit counts, shifted dword emission into a 10 KiB LDS
+//            window, coalesced dword flush
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
