@@ -464,3 +464,39 @@ def test_seeded_fuzz_against_oracle(eng):
         assert r["cc"][i] == 0 and r["tpbc"][i] == len(exp), (i, len(b), hl, r["cc"][i])
         assert out[i, :len(exp)].tobytes() == exp, (i, len(b), hl)
         assert r["crc"][i] == zlib.crc32(b[hl:], 0x1234abcd) and r["adler"][i] == zlib.adler32(b[hl:], 0x00010001), i
+
+
+def test_seeded_inflate_fuzz(eng):
+    """600 zlib-made raw deflate streams (levels 0-9, default / fixed / Huffman-only / RLE strategies,
+    sizes 0 .. 64 KiB, several blocks per stream through Z_FULL_FLUSH) through the batched inflate:
+    output, length and both checksums."""
+    import random
+    import torch
+    rnd = random.Random(7)
+    kinds = ["zeros", "random", "text33", "alice", "lz", "periodic", "binary", "sparse"]
+    streams = []
+    for i in range(600):
+        n = rnd.choice([0, 1, 2, 15, 16, 17, 255, 4096, 65535, 65536]) if rnd.random() < 0.3 else rnd.randrange(0, 65537)
+        d = make_block(rnd.choice(kinds), n, seed=300 + i)
+        co = zlib.compressobj(rnd.randrange(0, 10), zlib.DEFLATED, -15, 8,
+                              rnd.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED]))
+        c = b""
+        pos = 0
+        while pos < n and rnd.random() < 0.5:                       # a few flushed pieces -> several blocks
+            k = rnd.randrange(1, n - pos + 1)
+            c += co.compress(d[pos:pos + k]) + co.flush(rnd.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+            pos += k
+        c += co.compress(d[pos:]) + co.flush()
+        streams.append((d, c))
+    cstride = (max(len(c) for _, c in streams) + 64 + 15) & ~15
+    ostride = 65536 + 16
+    src = pack_blocks(eng, [c for _, c in streams], cstride)
+    dst = torch.zeros((len(streams), ostride), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, cstride, np.array([len(c) for _, c in streams], np.uint32), dst, ostride, ostride)
+    r = eng.results_to_host(eng.decompress(jobs, len(streams)))
+    out = dst.cpu().numpy()
+    for i, (d, c) in enumerate(streams):
+        assert r["cc"][i] == 0 and r["sfbt"][i] & 0x100, (i, r["cc"][i], len(d))
+        assert r["tpbc"][i] == len(d), i
+        assert out[i, :len(d)].tobytes() == d, i
+        assert r["crc"][i] == zlib.crc32(d) and r["adler"][i] == zlib.adler32(d), i
