@@ -846,13 +846,17 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 					};
 					if (ib + 256 <= tn && h + tb0 + ib + 256 + MAXMATCH + 8 <= end) quad(std::true_type{});
 					else quad(std::false_type{});
-					// queue entry: quad number | position bits
-					const unsigned long long m = __ballot(qbits != 0);
-					if (m) {
-						if (qbits) lq[lqn + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((i4 >> 2) | qbits << 12);
+					// queue entry: quad number | position bits.  One position per entry as a rule (a lane's
+					// second position gets an entry of its own), so that a batch is one pass in stage2
+					for (uint32_t rest = qbits, round = 0; round < 2; round++) {
+						const uint32_t bits = round ? rest : rest & (0u - rest);      // lowest position first, then what is left
+						const unsigned long long m = __ballot(bits != 0);
+						if (!m) break;
+						if (bits) lq[lqn + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((i4 >> 2) | bits << 12);
 						lqn += (uint32_t)__popcll(m);
 						__builtin_amdgcn_wave_barrier();
 						while (lqn >= 32) { stage2(lqn); lqn = lqn > 64 ? lqn - 64 : 0; }
+						rest &= rest - 1;
 					}
 				}
 			}
