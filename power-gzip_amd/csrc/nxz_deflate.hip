@@ -828,6 +828,15 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 							kbits |= (uint32_t)(lng[j] && direct && raw8[j + 1]) << j;
 							qbits |= (uint32_t)(lng[j] && !direct) << j;
 						}
+						// ... or whose successor is two or three positions on, still among my four (the
+						// positions in between have no candidate): member, the gap belongs to the chain
+						{
+							const bool g13 = lng[1] && !okA[2] && okA[3] && dA[1] == dA[3];
+							const bool g02 = lng[0] && !okA[1] && okA[2] && dA[0] == dA[2];
+							const bool g03 = lng[0] && !okA[1] && !okA[2] && okA[3] && dA[0] == dA[3];
+							kbits |= (g13 ? 6u : 0u) | (g02 ? 3u : 0u) | (g03 ? 7u : 0u);
+							qbits &= ~((g13 ? 2u : 0u) | (g02 || g03 ? 1u : 0u));
+						}
 						// my last position: its direct successor is the first position of the next lane (of
 						// the half piece processed before this one for lane 63; unknown at the piece end)
 						{
