@@ -937,6 +937,8 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		}
 		__syncthreads();
 		PROF(11);
+		// chain bookkeeping init: mark[] aliases the vb bitmap, which nobody reads any more
+		for (uint32_t s = t; s < NSEG; s += NT) mark[s] = 0;
 		uint32_t sm0 = 0, sm1 = 0, sm2 = 0, sm3 = 0;          // final stored lengths (len-3, 0 = none) of my 16 positions
 		if (p0 < tn) {
 			const uint32_t *eb = (const uint32_t *)(lds + OFF_EB);
@@ -981,9 +983,6 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				((uint4 *)cand)[2 * t + 1] = make_uint4(cw[4], cw[5], cw[6], cw[7]);
 			}
 		}
-		// chain bookkeeping init (mark/jump alias the two bitmaps)
-		__syncthreads();
-		for (uint32_t s = t; s < NSEG; s += NT) mark[s] = 0;
 		__syncthreads();
 		if (dbg && bid == 0)
 			for (uint32_t i = t; i < tn; i += NT) dbg[(tb0 / PTILE) * 65536 + i] = cand[i] | ((uint32_t)mlen[i] << 16);
@@ -1286,8 +1285,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 				for (uint32_t i = t; i < WWORDS + 16; i += NT) win[i] = (i < 16) ? keep : 0;
 				__syncthreads();
 			}
-			__syncthreads();
-			PROF(15);
+			PROF(15);                                          // (the loop is left right behind a barrier)
 		}
 	}
 
