@@ -36,7 +36,7 @@
 #include <stdint.h>
 #include "nxz_device.h"
 
-// Debug aid (tools/debug_tokens.py): when set, workgroup 0 dumps its per-position arrays.
+// Debug aid (tests/debug_tokens.py): when set, workgroup 0 dumps its per-position arrays.
 __device__ uint32_t *nxz_debug_buf = nullptr;
 // Diagnostic only (tools/phase_profile.py): per-phase cycle sums of every workgroup's thread 0.
 __device__ unsigned long long *nxz_prof_buf = nullptr;
