@@ -105,21 +105,6 @@ __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
 
 __device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - HBITS); }
 
-// common prefix of the strings at a and b (a < b), starting the compare at
-// offset `len` (multiple of 4 relative to the starts), clamped to `limit`
-__device__ __forceinline__ uint32_t extend(const uint32_t *inw, uint32_t a, uint32_t b, uint32_t len, uint32_t limit)
-{
-	while (len < limit) {
-		uint32_t x = lds_ld32(inw, a + len) ^ lds_ld32(inw, b + len);
-		if (x) {
-			len += (uint32_t)__builtin_ctz(x) >> 3;
-			break;
-		}
-		len += 4;
-	}
-	return len < limit ? len : limit;
-}
-
 // number of equal bytes (0..16) of the strings at a and b, compared over 16 bytes with one LDS round trip
 __device__ __forceinline__ uint32_t equal16(const uint32_t *inw, uint32_t a, uint32_t b)
 {
