@@ -372,7 +372,7 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		}
 		uint32_t tailcrc = 0;
 		if (t == 1023) { tailcrc = crc; crc = 0; }
-		else crc = gf_mul(crc, pw_slice);
+		else if (crc) crc = gf_mul(crc, pw_slice);              // (waves without data skip the multiply: small jobs)
 		for (int o = 32; o > 0; o >>= 1) crc ^= __shfl_down(crc, o, 64);
 		if (lane == 0) scan[wave] = crc;
 		if (t == 1023) scan[50] = tailcrc;

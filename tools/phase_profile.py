@@ -15,7 +15,8 @@ if len(sys.argv) > 2:
     b = np.frombuffer(make_block(sys.argv[2], 65536, 1), np.uint8)
     src[:] = torch.from_numpy(b.copy()).to(eng.dev)
 dst = torch.empty((n, 73856), dtype=torch.uint8, device=eng.dev)
-jobs = eng.jobs_strided(src, 65536, np.full(n, 65536, np.uint32), dst, 73856, 73856)
+size = int(sys.argv[3]) if len(sys.argv) > 3 else 65536             # bytes of each block that are compressed
+jobs = eng.jobs_strided(src, 65536, np.full(n, size, np.uint32), dst, 73856, 73856)
 prof = torch.zeros(64, dtype=torch.int64, device=eng.dev)
 eng.L.nxz_prof_set.argtypes = [C.c_void_p]
 eng.compress(pkg.FC_COMPRESS_FHT, jobs, n)
