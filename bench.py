@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the DEFLATE hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W [--blocks B] [--no-inflate] [--no-cpu-baseline]
+  python bench.py --gpus N --steps K --warmup W [--blocks B] [--no-inflate] [--no-cpu-baseline] [--no-dht]
 
 A *step* is one pass of the fixed-Huffman deflate engine (LZ77 + bit-pack kernel, function
 code COMPRESS_FHT) over one batch of B synthetic 64 KiB blocks that are already resident in
@@ -160,6 +160,64 @@ def oracle_parity(blocks_host, dst, res_host, k=48):
     return k
 
 
+def dht_leg(torch, eng, pkg, src, dst, n, stride_out, group=64, sample=256):
+    """Dynamic-Huffman leg (BASELINE configs[2] shape, same blocks): one table per `group` consecutive
+    blocks, built by the host generator (nxz_dhtgen_batch in libnxz_amd.so, the part the reference
+    also keeps on the host, lib/nx_dhtgen.c) from the LZ77 symbol counts of the group's first block;
+    then every block is encoded with its group's table.  Timed end to end (count pass + copy of the
+    counts + host tables + copy of the tables + encode pass); ratio next to zlib -1 (default
+    strategy) on a sample whose outputs zlib inflates back to the input."""
+    import zlib
+    H = C.CDLL(os.path.join(ROOT, "power-gzip_amd", "libnxz_amd.so"))
+    H.nxz_dhtgen_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    H.nxz_dhtgen_batch.restype = C.c_int
+    nthreads = usable_cores()
+    ng = (n + group - 1) // group
+    lens = np.full(n, BLOCK, np.uint32)
+    jobs_lead = eng.jobs_strided(src, BLOCK * group, np.full(ng, BLOCK, np.uint32), dst, stride_out * group, stride_out)
+    jobs_all = eng.jobs_strided(src, BLOCK, lens, dst, stride_out, stride_out,
+                                dht_index=(np.arange(n) // group).astype(np.uint32))
+    counts = torch.empty(ng * 316, dtype=torch.int32, device=eng.dev)
+    tables = np.zeros(ng, pkg.DHT_DTYPE)
+    res = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
+
+    def one_pass():
+        eng.compress(pkg.FC_COMPRESS_FHT_COUNT, jobs_lead, ng, counts=counts)
+        c = counts.cpu().numpy().view(np.uint32)
+        if H.nxz_dhtgen_batch(c.ctypes.data, ng, tables.ctypes.data, nthreads) != 0:
+            raise SystemExit("nxz_dhtgen_batch failed")
+        eng.compress(pkg.FC_COMPRESS_DHT, jobs_all, n, results=res, dht=eng.to_device(tables), ntables=ng)
+
+    one_pass()
+    torch.cuda.synchronize(eng.dev)
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one_pass()
+    torch.cuda.synchronize(eng.dev)
+    dt = (time.perf_counter() - t0) / reps
+    r = eng.results_to_host(res)
+    if not (r["cc"] == 0).all():
+        raise SystemExit("dynamic-Huffman leg: engine reported errors %s" % np.unique(r["cc"]))
+    m = min(n, sample)
+    hs = src[:m].cpu().numpy()
+    out = dst[:m].cpu().numpy()
+    z1 = 0
+    for i in range(m):
+        b = hs[i].tobytes()
+        z = zlib.decompressobj(-15)
+        if z.decompress(out[i, :r["tpbc"][i]].tobytes()) != b or not z.eof:
+            raise SystemExit("ROUND TRIP FAILURE (dynamic Huffman): block %d" % i)
+        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+        z1 += len(c.compress(b) + c.flush())
+    ours = int(r["tpbc"][:m].sum())
+    return {"value": round(n * BLOCK / dt / 2.0 ** 30, 3), "unit": "GiB/s uncompressed in, end to end",
+            "ms_per_pass": round(dt * 1e3, 3), "ratio": round(n * float(BLOCK) / float(r["tpbc"].astype(np.float64).sum()), 4),
+            "zlib1_ratio_sample": round(m * BLOCK / z1, 4), "ratio_vs_zlib1": round(z1 / ours, 4),
+            "tables": "one per %d blocks from the first block's counts, %d host threads" % (group, nthreads),
+            "sample": "%d blocks inflated with zlib and compressed with zlib -1" % m}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +226,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=1 << 20, help="64 KiB blocks per GPU (default 2^20 = 64 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inflate", action="store_true", help="skip the inflate leg (round trip of the output)")
+    ap.add_argument("--no-dht", action="store_true", help="skip the dynamic-Huffman leg (N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -281,6 +340,8 @@ def main():
             sample = src[:min(n, 32768)].cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(sample)
             line["cpu_baseline"]["parity_checked_blocks"] = oracle_parity(sample, dst, res)
+        if world == 1 and not args.no_dht:
+            line["dht"] = dht_leg(torch, eng, pkg, src, dst, n, stride_out)      # overwrites dst: last leg
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
