@@ -17,6 +17,7 @@
 #include <cstring>
 #include <vector>
 #include "nxz_host.h"
+#include "../../include/nxz_config.h"
 
 namespace {
 
@@ -170,16 +171,21 @@ struct nxz_dht_state {
 	long bytes_since_refresh = 0;
 };
 
-static void top3(const uint32_t *ll, int key[3])
+// The cache keys of a table: the three most frequent symbols among the literals (dht_config bit 0
+// clear, the default) or among literals and lengths (bit 0 set), found with the reference's single
+// scan (lib/nx_dht.c:169-237): a new maximum pushes the old one to second place but leaves the
+// third untouched, and only strictly greater counts move anything (so ties keep the lower symbol).
+extern "C" void nxz_dht_top_keys(const uint32_t *ll, int lit_and_len, int key[3])
 {
-	// two most frequent literals and the most frequent length symbol (lib/nx_dht.c:169-237)
-	int a = -1, b = -1, c = -1;
-	for (int i = 0; i < 256; i++) {
-		if (a < 0 || ll[i] > ll[a]) { b = a; a = i; }
-		else if (b < 0 || ll[i] > ll[b]) b = i;
+	const int scan = lit_and_len ? 286 : 256;
+	uint32_t cnt[3] = {0, 0, 0};
+	key[0] = key[1] = key[2] = -1;
+	for (int i = 0; i < scan; i++) {
+		const uint32_t c = ll[i];
+		if (c > cnt[0]) { cnt[1] = cnt[0]; key[1] = key[0]; cnt[0] = c; key[0] = i; }
+		else if (c > cnt[1]) { cnt[2] = cnt[1]; key[2] = key[1]; cnt[1] = c; key[1] = i; }
+		else if (c > cnt[2]) { cnt[2] = c; key[2] = i; }
 	}
-	for (int i = 257; i < 286; i++) if (c < 0 || ll[i] > ll[c]) c = i;
-	key[0] = a; key[1] = b; key[2] = c;
 }
 
 extern "C" nxz_dht_state *nxz_dht_begin(void)
@@ -219,14 +225,15 @@ extern "C" void nxz_dht_lookup(nxz_dht_state *s, const uint32_t *counts, long so
 		s->bytes_since_refresh = 0;
 	} else {
 		s->bytes_since_refresh += source_bytes;
-		if (s->last && s->bytes_since_refresh < 512 * 1024) {
+		if (s->last && source_bytes != 0 && s->bytes_since_refresh < 512 * 1024) {
 			e = s->last;                                   // amortise the lookup (lib/nx_dht.c:480-566)
 		} else {
-			s->bytes_since_refresh = 0;
+			s->bytes_since_refresh = source_bytes;         // :543
 			int key[3];
-			top3(counts, key);
+			nxz_dht_top_keys(counts, nxz_config()->dht & 1, key);
+			// a cached table serves when its two top symbols are the job's (dht_search_cache, :434-478)
 			for (auto &c : s->cache)
-				if (c.valid && c.key[0] == key[0] && c.key[1] == key[1] && c.key[2] == key[2]) { c.accessed = 1; e = &c; break; }
+				if (c.valid && c.key[0] == key[0] && c.key[1] == key[1]) { c.accessed = 1; e = &c; break; }
 			if (!e) {
 				// clock replacement, then generate a universal table (no missing codes)
 				for (;;) {

@@ -16,6 +16,7 @@ void nxz_fill_zero_lzcounts(uint32_t *ll, uint32_t *d, uint32_t val);
 int  nxz_dhtgen_batch(const uint32_t *counts, size_t n, nxz_batch_dht_t *tables, int nthreads);
 int  nxz_dhtgen(uint32_t *lhist, int num_lhist, uint32_t *dhist, int num_dhist,
 		uint8_t *dht, int *dht_num_bytes, int *dht_num_valid_bits);
+void nxz_dht_top_keys(const uint32_t *ll, int lit_and_len, int key[3]);
 nxz_dht_state *nxz_dht_begin(void);
 void nxz_dht_end(nxz_dht_state *s);
 nxz_dht_state *nxz_dht_copy(const nxz_dht_state *s);

@@ -20,6 +20,7 @@
 #include <new>
 #include <vector>
 #include "nxz_host.h"
+#include "../../include/nxz_config.h"
 #include "../../include/nxz_wire.h"
 #include "../../include/nxz_zlib.h"
 
@@ -28,7 +29,6 @@ namespace {
 constexpr uint64_t MAGIC_DEF = 0x6e787a2d64656621ull, MAGIC_INF = 0x6e787a2d696e6621ull;
 constexpr uint32_t JOB_UNIT = 65536;          // engine sub-block incl. history
 constexpr uint32_t WINDOW = 32768;
-constexpr uint32_t CACHE_THRESHOLD = 8192;    // lib/nx_zlib.c:1116 cache_threshold
 constexpr uint32_t STORED_MAX = 60000;        // lib/nx_deflate.c:125
 enum { HDR_RAW = 0, HDR_ZLIB = 1, HDR_GZIP = 2 };
 
@@ -51,7 +51,7 @@ struct Engine {
 	bool begin()
 	{
 		memset(&dev, 0, sizeof(dev));
-		open = nx_function_begin(NXZ_FUNC_COMP_GZIP, -1, &dev) == 0;
+		open = nx_function_begin(NXZ_FUNC_COMP_GZIP, nxz_config()->dev_num, &dev) == 0;   // NX_GZIP_DEV_NUM
 		return open;
 	}
 	void end() { if (open) nx_function_end(&dev); open = false; }
@@ -405,7 +405,9 @@ extern "C" int nx_deflateInit2_(z_streamp strm, int level, int method, int windo
 	if (!s->eng.begin()) { delete s; return Z_STREAM_ERROR; }                                  // "cannot open NX device"
 	s->z = strm;
 	s->wrap = windowBits < 0 ? HDR_RAW : windowBits > 15 ? HDR_GZIP : HDR_ZLIB;
-	s->level = level; s->strategy = strategy; s->max_history = maxhist;
+	s->level = level; s->max_history = maxhist;
+	// NX_GZIP_STRATEGY=0 forces fixed Huffman whatever the caller asked for (lib/nx_deflate.c:648-652)
+	s->strategy = (strategy == Z_FIXED || nxz_config()->strategy_override == 0) ? Z_FIXED : Z_DEFAULT_STRATEGY;
 	strm->state = (struct internal_state *)s;
 	return deflate_reset_keep(strm);
 }
@@ -429,6 +431,7 @@ extern "C" int nx_deflateEnd(z_streamp strm)
 extern "C" unsigned long nx_deflateBound(z_streamp strm, unsigned long sourceLen)
 {
 	(void)strm;
+	nxz_stats_inc("deflateBound");                                                            // :1920
 	long pg = sysconf(_SC_PAGESIZE);
 	return sourceLen * 2 + (unsigned long)std::min<long>(pg, 1 << 16);                         // :1922 (Q1)
 }
@@ -494,7 +497,7 @@ extern "C" int nx_deflate(z_streamp strm, int flush)
 	for (int guard = 0; guard < 0xffff; guard++) {
 		if (s->st >= Deflate::BFINAL) return deflate_end_of_stream(s);
 		const size_t avail = s->used + strm->avail_in;
-		if (avail <= CACHE_THRESHOLD && flush == Z_NO_FLUSH && s->dict_len == 0 && !s->pending()) {
+		if (avail <= nxz_config()->cache_threshold && flush == Z_NO_FLUSH && s->dict_len == 0 && !s->pending()) {
 			// small input, no flush requested: just remember it (:1729-1741, cache_input :783)
 			s->fifo.insert(s->fifo.end(), strm->next_in, strm->next_in + strm->avail_in);
 			s->used += strm->avail_in;

@@ -4,7 +4,10 @@
 // Counterpart of the reference's dispatch layer: the unprefixed functions at the bottom of
 // lib/nx_deflate.c:2236-2580, lib/nx_inflate.c:1982-2364, lib/nx_compress.c:77-117,
 // lib/nx_uncompr.c:90-149 and the dlopen trampolines of lib/sw_zlib.c:57-336.
-//   NX_GZIP_TYPE_SELECTOR = 0 auto (default), 1 software zlib, 2 engine   (lib/nx_zlib.c:1067-1088)
+//   NX_GZIP_TYPE_SELECTOR = 0 auto (default), 1 software zlib, 2 engine, 3 engine deflate + zlib
+//   inflate; NX_GZIP_COMP_MODE / NX_GZIP_DEC_MODE per direction; the same keys in the file named by
+//   NX_GZIP_CONFIG (lib/nx_zlib.c:1067-1217; parsed by nxz_config.cpp).  NX_GZIP_TRACE=8 gathers the
+//   reference's call statistics here, in the dispatch layer, as lib/nx_deflate.c:2472-2520 does.
 // Auto: one-shot calls of <= 1024 bytes go to zlib (lib/nx_zlib.h:88-89); everything goes to zlib
 // when no engine can be opened.  A stream stays with the backend that initialised it; which one
 // that was is read from the state tag, so no stream map is needed (the reference keeps one for
@@ -18,6 +21,8 @@
 #include <set>
 #include "../../include/nxz_engine.h"
 #include "../../include/nxz_zlib.h"
+#include "../../include/nxz_config.h"
+#include <time.h>
 
 namespace {
 
@@ -67,14 +72,15 @@ struct Sw {
 #undef SWF
 } sw;
 
-int g_mode = MODE_AUTO;
+int g_mode_def = MODE_AUTO, g_mode_inf = MODE_AUTO;      // nx_config.mode.deflate / .inflate
 bool g_engine = false;
 std::once_flag g_once;
 
 void init_once()
 {
-	const char *m = getenv("NX_GZIP_TYPE_SELECTOR");
-	if (m) g_mode = atoi(m) == 1 ? MODE_SW : atoi(m) == 2 ? MODE_NX : MODE_AUTO;
+	const nxz_config_t *cfg = nxz_config();
+	g_mode_def = cfg->mode_deflate;
+	g_mode_inf = cfg->mode_inflate;
 	const char *path = getenv("NXZ_ZLIB_PATH");
 	// RTLD_DEEPBIND: the real zlib must bind its own internal calls to itself, not to this shim
 	sw.h = dlopen(path ? path : "libz.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
@@ -87,21 +93,25 @@ void init_once()
 		REG(compress) REG(compress2) REG(compressBound) REG(uncompress) REG(uncompress2) REG(crc32) REG(adler32)
 		REG(crc32_combine) REG(adler32_combine) REG(inflateResetKeep) REG(gzopen) REG(gzdopen) REG(gzread) REG(gzwrite) REG(gzclose)
 #undef REG
-	} else if (g_mode != MODE_NX) {
+	} else if (g_mode_def != MODE_NX || g_mode_inf != MODE_NX) {
 		fprintf(stderr, "nxz: cannot dlopen software zlib (%s): forcing engine mode\n", dlerror());
-		g_mode = MODE_NX;                                  // lib/nx_zlib.c:1357-1360
+		g_mode_def = g_mode_inf = MODE_NX;                 // lib/nx_zlib.c:1357-1360
 	}
-	if (g_mode != MODE_SW) {
+	if (g_mode_def != MODE_SW || g_mode_inf != MODE_SW) {
 		nxz_dev_t probe;
 		memset(&probe, 0, sizeof(probe));
-		if (nx_function_begin(NXZ_FUNC_COMP_GZIP, -1, &probe) == 0) { g_engine = true; nx_function_end(&probe); }
-		else if (g_mode == MODE_NX) fprintf(stderr, "nxz: NX_GZIP_TYPE_SELECTOR=2 but no engine is available\n");
+		if (nx_function_begin(NXZ_FUNC_COMP_GZIP, cfg->dev_num, &probe) == 0) { g_engine = true; nx_function_end(&probe); }
+		else if (g_mode_def == MODE_NX || g_mode_inf == MODE_NX) fprintf(stderr, "nxz: engine mode selected but no engine is available\n");
 	}
+	nxz_log(2, "nxz preload: deflate mode %d, inflate mode %d, engine %s\n", g_mode_def, g_mode_inf, g_engine ? "open" : "absent");
 }
 
 inline void init() { std::call_once(g_once, init_once); }
-inline bool want_nx() { init(); return g_mode == MODE_NX || (g_mode == MODE_AUTO && g_engine); }
+inline bool want_nx(int mode) { return mode == MODE_NX || (mode == MODE_AUTO && g_engine); }
+inline bool want_nx_def() { init(); return want_nx(g_mode_def); }
+inline bool want_nx_inf() { init(); return want_nx(g_mode_inf); }
 inline bool is_nx(z_streamp s, uint64_t magic) { return s && s->state && *(const uint64_t *)s->state == magic; }
+inline uint64_t now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
 
 } // namespace
 
@@ -112,10 +122,12 @@ EXPORT const char *zlibVersion(void) { init(); return sw.zlibVersion ? sw.zlibVe
 // ---- deflate ----
 EXPORT int deflateInit2_(z_streamp s, int level, int method, int wbits, int memLevel, int strategy, const char *ver, int size)
 {
-	if (want_nx()) {
+	const bool nx = want_nx_def();
+	nxz_stats_inc("deflateInit");
+	if (nx) {
 		int rc = nx_deflateInit2_(s, level, method, wbits, memLevel, strategy, ver, size);
 		// parameters the engine does not take (small windows, Z_FILTERED, ...) go to software in auto mode
-		if (rc == Z_OK || g_mode == MODE_NX || !sw.deflateInit2_) return rc;
+		if (rc == Z_OK || g_mode_def == MODE_NX || !sw.deflateInit2_) return rc;
 	}
 	return sw.deflateInit2_ ? sw.deflateInit2_(s, level, method, wbits, memLevel, strategy, ver, size) : Z_STREAM_ERROR;
 }
@@ -124,8 +136,19 @@ EXPORT int deflateInit_(z_streamp s, int level, const char *ver, int size)
 	return deflateInit2_(s, level, Z_DEFLATED, 15, 8, Z_DEFAULT_STRATEGY, ver, size);
 }
 #define DISPATCH_DEF(call_nx, call_sw, err) do { init(); if (is_nx(s, MAGIC_DEF)) return call_nx; return sw.deflate ? call_sw : err; } while (0)
-EXPORT int deflate(z_streamp s, int flush) { DISPATCH_DEF(nx_deflate(s, flush), sw.deflate(s, flush), Z_STREAM_ERROR); }
-EXPORT int deflateEnd(z_streamp s) { DISPATCH_DEF(nx_deflateEnd(s), sw.deflateEnd(s), Z_STREAM_ERROR); }
+EXPORT int deflate(z_streamp s, int flush)
+{
+	init();
+	const bool nx = is_nx(s, MAGIC_DEF);
+	if (!nx && !sw.deflate) return Z_STREAM_ERROR;
+	if (!nxz_stats_enabled()) return nx ? nx_deflate(s, flush) : sw.deflate(s, flush);
+	const unsigned ai = s ? s->avail_in : 0, ao = s ? s->avail_out : 0;
+	const uint64_t t0 = now_ns();
+	int rc = nx ? nx_deflate(s, flush) : sw.deflate(s, flush);
+	nxz_stats_call(0, nx, ai, ao, now_ns() - t0, rc == Z_OK || rc == Z_STREAM_END);
+	return rc;
+}
+EXPORT int deflateEnd(z_streamp s) { init(); nxz_stats_inc("deflateEnd"); DISPATCH_DEF(nx_deflateEnd(s), sw.deflateEnd(s), Z_STREAM_ERROR); }
 EXPORT int deflateReset(z_streamp s) { DISPATCH_DEF(nx_deflateReset(s), sw.deflateReset(s), Z_STREAM_ERROR); }
 EXPORT int deflateResetKeep(z_streamp s) { DISPATCH_DEF(nx_deflateResetKeep(s), sw.deflateResetKeep(s), Z_STREAM_ERROR); }
 EXPORT int deflateSetHeader(z_streamp s, gz_headerp h) { DISPATCH_DEF(nx_deflateSetHeader(s, h), sw.deflateSetHeader(s, h), Z_STREAM_ERROR); }
@@ -148,16 +171,29 @@ EXPORT uLong deflateBound(z_streamp s, uLong n)
 // ---- inflate ----
 EXPORT int inflateInit2_(z_streamp s, int wbits, const char *ver, int size)
 {
-	if (want_nx()) {
+	const bool nx = want_nx_inf();
+	nxz_stats_inc("inflateInit");
+	if (nx) {
 		int rc = nx_inflateInit2_(s, wbits, ver, size);
-		if (rc == Z_OK || g_mode == MODE_NX || !sw.inflateInit2_) return rc;
+		if (rc == Z_OK || g_mode_inf == MODE_NX || !sw.inflateInit2_) return rc;
 	}
 	return sw.inflateInit2_ ? sw.inflateInit2_(s, wbits, ver, size) : Z_STREAM_ERROR;
 }
 EXPORT int inflateInit_(z_streamp s, const char *ver, int size) { return inflateInit2_(s, 15, ver, size); }
 #define DISPATCH_INF(call_nx, call_sw) do { init(); if (is_nx(s, MAGIC_INF)) return call_nx; return sw.inflate ? call_sw : Z_STREAM_ERROR; } while (0)
-EXPORT int inflate(z_streamp s, int flush) { DISPATCH_INF(nx_inflate(s, flush), sw.inflate(s, flush)); }
-EXPORT int inflateEnd(z_streamp s) { DISPATCH_INF(nx_inflateEnd(s), sw.inflateEnd(s)); }
+EXPORT int inflate(z_streamp s, int flush)
+{
+	init();
+	const bool nx = is_nx(s, MAGIC_INF);
+	if (!nx && !sw.inflate) return Z_STREAM_ERROR;
+	if (!nxz_stats_enabled()) return nx ? nx_inflate(s, flush) : sw.inflate(s, flush);
+	const unsigned ai = s ? s->avail_in : 0, ao = s ? s->avail_out : 0;
+	const uint64_t t0 = now_ns();
+	int rc = nx ? nx_inflate(s, flush) : sw.inflate(s, flush);
+	nxz_stats_call(1, nx, ai, ao, now_ns() - t0, rc == Z_OK || rc == Z_STREAM_END);
+	return rc;
+}
+EXPORT int inflateEnd(z_streamp s) { init(); nxz_stats_inc("inflateEnd"); DISPATCH_INF(nx_inflateEnd(s), sw.inflateEnd(s)); }
 EXPORT int inflateReset(z_streamp s) { DISPATCH_INF(nx_inflateReset(s), sw.inflateReset(s)); }
 EXPORT int inflateReset2(z_streamp s, int w) { DISPATCH_INF(nx_inflateReset2(s, w), sw.inflateReset2(s, w)); }
 EXPORT int inflateSetDictionary(z_streamp s, const Bytef *d, uInt n) { DISPATCH_INF(nx_inflateSetDictionary(s, d, n), sw.inflateSetDictionary(s, d, n)); }
@@ -170,7 +206,8 @@ EXPORT int inflateResetKeep(z_streamp s) { DISPATCH_INF(nx_inflateResetKeep(s), 
 EXPORT int compress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen, int level)
 {
 	init();
-	bool nx = g_mode == MODE_NX || (g_mode == MODE_AUTO && g_engine && sourceLen > 1024);
+	nxz_stats_inc("compress");
+	bool nx = g_mode_def == MODE_NX || (g_mode_def == MODE_AUTO && g_engine && sourceLen > 1024);
 	if (nx) return nx_compress2(dest, destLen, source, sourceLen, level);
 	return sw.compress2 ? sw.compress2(dest, destLen, source, sourceLen, level) : Z_STREAM_ERROR;
 }
@@ -187,7 +224,8 @@ EXPORT uLong compressBound(uLong n)
 EXPORT int uncompress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong *sourceLen)
 {
 	init();
-	bool nx = g_mode == MODE_NX || (g_mode == MODE_AUTO && g_engine && *sourceLen > 1024);
+	nxz_stats_inc("uncompress");
+	bool nx = g_mode_inf == MODE_NX || (g_mode_inf == MODE_AUTO && g_engine && *sourceLen > 1024);
 	if (nx) return nx_uncompress2(dest, destLen, source, sourceLen);
 	if (sw.uncompress2) return sw.uncompress2(dest, destLen, source, sourceLen);
 	return sw.uncompress ? sw.uncompress(dest, destLen, source, *sourceLen) : Z_STREAM_ERROR;
@@ -213,15 +251,21 @@ std::mutex g_gz_mu;
 std::set<void *> g_gz_nx;
 bool gz_is_nx(void *f) { std::lock_guard<std::mutex> l(g_gz_mu); return g_gz_nx.count(f) != 0; }
 void *gz_track(void *f) { if (f) { std::lock_guard<std::mutex> l(g_gz_mu); g_gz_nx.insert(f); } return f; }
+// a file opened for writing follows the deflate mode, one opened for reading the inflate mode
+int gz_mode_of(const char *mode) { return mode && (strchr(mode, 'w') || strchr(mode, 'a')) ? g_mode_def : g_mode_inf; }
 }
 EXPORT gzFile gzopen(const char *path, const char *mode)
 {
-	if (want_nx()) { void *f = gz_track(nx_gzopen(path, mode)); if (f || g_mode == MODE_NX || !sw.gzopen) return (gzFile)f; }
+	init();
+	const int m = gz_mode_of(mode);
+	if (want_nx(m)) { void *f = gz_track(nx_gzopen(path, mode)); if (f || m == MODE_NX || !sw.gzopen) return (gzFile)f; }
 	return sw.gzopen ? sw.gzopen(path, mode) : nullptr;
 }
 EXPORT gzFile gzdopen(int fd, const char *mode)
 {
-	if (want_nx()) { void *f = gz_track(nx_gzdopen(fd, mode)); if (f || g_mode == MODE_NX || !sw.gzdopen) return (gzFile)f; }
+	init();
+	const int m = gz_mode_of(mode);
+	if (want_nx(m)) { void *f = gz_track(nx_gzdopen(fd, mode)); if (f || m == MODE_NX || !sw.gzdopen) return (gzFile)f; }
 	return sw.gzdopen ? sw.gzdopen(fd, mode) : nullptr;
 }
 EXPORT int gzread(gzFile f, voidp buf, unsigned len) { init(); return gz_is_nx(f) ? nx_gzread(f, buf, len) : sw.gzread ? sw.gzread(f, buf, len) : -1; }

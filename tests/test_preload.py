@@ -96,3 +96,27 @@ def test_one_shot_engine_mode(tmp_path):
     comp = run_one_shot(tmp_path, data, 2)
     assert comp[:2] == b"\x78\x01" and zlib.decompress(comp) == data      # FLEVEL 0 header of the engine layer (Q3)
     assert len(comp) < 0.55 * len(data)
+
+
+@pytest.mark.gpu
+def test_mixed_mode_engine_deflate_software_inflate_with_statistics(tmp_path):
+    # NX_GZIP_TYPE_SELECTOR=3: the engine compresses, zlib decompresses (lib/nx_zlib.c:1197-1200);
+    # NX_GZIP_TRACE=8 prints where each call went when the process ends (lib/nx_zlib.c:876-955)
+    import re
+    data = ALICE_LIKE(200000, seed=5)
+    f = tmp_path / "in.bin"
+    f.write_bytes(data)
+    log = tmp_path / "nx.log"
+    env = dict(os.environ, NX_GZIP_TYPE_SELECTOR="3", NX_GZIP_TRACE="8", NX_GZIP_LOGFILE=str(log), LD_PRELOAD=PRELOAD)
+    subprocess.run([sys.executable, "-c", PY_ZLIB, str(f), str(zlib.crc32(data)), str(zlib.adler32(data))],
+                   env=env, check=True, capture_output=True, text=True)
+    text = log.read_text()
+    count = lambda k: int(re.search(r"^%s: (\d+)$" % re.escape(k), text, re.M).group(1))
+    assert count("\tdeflate(nx)") >= 1 and count("\tdeflate(sw)") == 0
+    assert count("\tinflate(sw)") >= 1 and count("\tinflate(nx)") == 0
+    # a fixed-Huffman override reaches the engine layer: the stream starts with a type-01 block
+    env = dict(os.environ, NX_GZIP_TYPE_SELECTOR="2", NX_GZIP_STRATEGY="0", LD_PRELOAD=PRELOAD)
+    out = subprocess.run([sys.executable, "-c", "import sys,zlib;d=open(sys.argv[1],'rb').read();"
+                          "c=zlib.compress(d,6);assert zlib.decompress(c)==d;sys.stdout.write(c[:3].hex())", str(f)],
+                         env=env, check=True, capture_output=True, text=True).stdout
+    assert (bytes.fromhex(out)[2] >> 1) & 3 == 1
