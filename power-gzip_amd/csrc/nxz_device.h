@@ -25,7 +25,7 @@ int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_dht_prepare
 int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 		       nxz_batch_dht_t *dht_io, hipStream_t stream);
-size_t nxz_inflate_lanes_workspace(void);
+size_t nxz_inflate_lanes_workspace(size_t n);
 int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 			     nxz_batch_dht_t *dht_io, uint8_t *workspace, int init_fixed, hipStream_t stream);
 }

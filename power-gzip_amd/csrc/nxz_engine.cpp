@@ -18,6 +18,7 @@
 #include <time.h>
 #include <unistd.h>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <vector>
 #include "nxz_device.h"
@@ -62,10 +63,15 @@ struct nxz_ctx {
 	std::mutex mtx;
 	std::condition_variable cv;
 	Slot slots[SLOTS];
-	// batch scratch
-	nxz_dht_prepared_t *d_prepared = nullptr;
-	size_t prepared_cap = 0;
-	uint8_t *d_lanes_ws = nullptr;                // per-lane decode tables of the batched inflate kernel
+	// batch scratch, one set per stream the caller launches on: launches on different streams may
+	// run at the same time, so they must not share the prepared tables or the decode workspace
+	struct Scratch {
+		nxz_dht_prepared_t *d_prepared = nullptr;
+		size_t prepared_cap = 0;
+		uint8_t *d_lanes_ws = nullptr;            // per-lane decode tables of the batched inflate kernel
+		size_t lanes_cap = 0;
+	};
+	std::map<hipStream_t, Scratch> scratch;
 	uint32_t *d_job_counters = nullptr;           // job counters of the batched deflate launches (ring)
 	unsigned next_counter = 0;
 };
@@ -142,8 +148,10 @@ extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 	if (--c->refs > 0) return;
 	(void)hipSetDevice(c->device);
 	for (auto &s : c->slots) if (s.stream) slot_free(s);
-	if (c->d_prepared) (void)hipFree(c->d_prepared);
-	if (c->d_lanes_ws) (void)hipFree(c->d_lanes_ws);
+	for (auto &kv : c->scratch) {
+		if (kv.second.d_prepared) (void)hipFree(kv.second.d_prepared);
+		if (kv.second.d_lanes_ws) (void)hipFree(kv.second.d_lanes_ws);
+	}
 	if (c->d_job_counters) (void)hipFree(c->d_job_counters);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	g_ctx[c->device] = nullptr;
@@ -169,18 +177,21 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 	if (count && !counts) return -EINVAL;
 	if (isdht && (!dht || !ntables)) return -EINVAL;
 	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
+	nxz_dht_prepared_t *prepared = nullptr;
 	if (isdht) {
 		{
 			std::lock_guard<std::mutex> g(c->mtx);
-			if (c->prepared_cap < ntables) {
+			nxz_ctx::Scratch &sc = c->scratch[s];
+			if (sc.prepared_cap < ntables) {
 				// grows only: warm up once with the largest batch before timing a loop
-				if (c->d_prepared) { (void)hipStreamSynchronize(s); (void)hipFree(c->d_prepared); }
-				c->d_prepared = nullptr; c->prepared_cap = 0;
-				HIPCHK(hipMalloc((void **)&c->d_prepared, ntables * sizeof(nxz_dht_prepared_t)), return -ENOMEM);
-				c->prepared_cap = ntables;
+				if (sc.d_prepared) { (void)hipStreamSynchronize(s); (void)hipFree(sc.d_prepared); }
+				sc.d_prepared = nullptr; sc.prepared_cap = 0;
+				HIPCHK(hipMalloc((void **)&sc.d_prepared, ntables * sizeof(nxz_dht_prepared_t)), return -ENOMEM);
+				sc.prepared_cap = ntables;
 			}
+			prepared = sc.d_prepared;
 		}
-		int rc = nxz_launch_dht_prepare(dht, ntables, c->d_prepared, s);
+		int rc = nxz_launch_dht_prepare(dht, ntables, prepared, s);
 		if (rc) { set_err("dht prepare launch", (hipError_t)rc); return -EIO; }
 	}
 	uint32_t *jc = nullptr;
@@ -189,7 +200,7 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 		if (!c->d_job_counters && hipMalloc((void **)&c->d_job_counters, JOB_COUNTERS * sizeof(uint32_t)) != hipSuccess) c->d_job_counters = nullptr;
 		if (c->d_job_counters) jc = c->d_job_counters + (c->next_counter++ % JOB_COUNTERS);
 	}
-	int rc = nxz_launch_deflate(isdht, count, jobs, n, c->d_prepared, results, counts, jc, s);
+	int rc = nxz_launch_deflate(isdht, count, jobs, n, prepared, results, counts, jc, s);
 	if (rc) { set_err("deflate launch", (hipError_t)rc); return -EIO; }
 	return 0;
 }
@@ -203,14 +214,22 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 	if (n >= 32) {
 		// many streams: one stream per lane (nxz_inflate_lanes.hip); the table workspace is made once
 		int init = 0;
+		uint8_t *ws;
 		{
 			std::lock_guard<std::mutex> g(c->mtx);
-			if (!c->d_lanes_ws) {
-				HIPCHK(hipMalloc((void **)&c->d_lanes_ws, nxz_inflate_lanes_workspace()), return -ENOMEM);
+			nxz_ctx::Scratch &sc = c->scratch[s];
+			const size_t need = nxz_inflate_lanes_workspace(n);
+			if (sc.lanes_cap < need) {
+				// grows only (3.6 KiB per lane in flight, 0.9 GiB for the largest grid)
+				if (sc.d_lanes_ws) { (void)hipStreamSynchronize(s); (void)hipFree(sc.d_lanes_ws); }
+				sc.d_lanes_ws = nullptr; sc.lanes_cap = 0;
+				HIPCHK(hipMalloc((void **)&sc.d_lanes_ws, need), return -ENOMEM);
+				sc.lanes_cap = need;
 				init = 1;
 			}
+			ws = sc.d_lanes_ws;
 		}
-		rc = nxz_launch_inflate_lanes(jobs, n, results, dht_io, c->d_lanes_ws, init, s);
+		rc = nxz_launch_inflate_lanes(jobs, n, results, dht_io, ws, init, s);
 	} else {
 		rc = nxz_launch_inflate(jobs, n, results, dht_io, s);
 	}

@@ -580,9 +580,12 @@ __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__res
 
 #define NXZ_LANES_MAX_GRID 4096u
 
-extern "C" size_t nxz_inflate_lanes_workspace(void)
+// workspace bytes a batch of n streams needs (grows with n up to the largest grid)
+extern "C" size_t nxz_inflate_lanes_workspace(size_t n)
 {
-	return ((size_t)NXZ_LANES_MAX_GRID * 64 + 1) * nxzl::WS_BYTES;
+	size_t groups = (n + 63) / 64;
+	size_t grid = groups < NXZ_LANES_MAX_GRID ? groups : NXZ_LANES_MAX_GRID;
+	return (grid * 64 + 1) * nxzl::WS_BYTES;
 }
 
 extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,

@@ -428,6 +428,74 @@ def test_batches_on_two_streams_at_once(eng):
                 assert a1[i, :len(exp)].tobytes() == exp
 
 
+def test_dynamic_and_inflate_batches_on_two_streams_at_once(eng):
+    """Launches on different streams may overlap on the device: each stream has its own prepared
+    tables and its own decode workspace, so two dynamic-Huffman batches with different tables, and
+    two inflate batches of different dynamic streams, give what they give alone."""
+    import torch
+    n = 1500
+    kinds = ("alice", "lz", "text33", "periodic")
+    blocks_a = [make_block(kinds[i % 4], 65536, seed=900 + i % 7) for i in range(n)]
+    blocks_b = [make_block(kinds[(i + 1) % 4], 65536, seed=950 + i % 5) for i in range(n)]
+
+    def table_for(b):
+        tok, nt = O.lz77(b)
+        ll, d = O.counts(tok, nt)
+        for i in range(286):
+            ll[i] = max(ll[i], 1)                   # a universal table: every symbol has a code
+        for i in range(30):
+            d[i] = max(d[i], 1)
+        return O.dhtgen(ll, d)
+    ta, tb = table_for(blocks_a[0]), table_for(blocks_b[1])
+    lens = np.full(n, 65536, np.uint32)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    sets = []
+    for blocks, tab in ((blocks_a, ta), (blocks_b, tb)):
+        src = pack_blocks(eng, blocks, STRIDE_IN)
+        dst = torch.zeros((n, STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+        jobs = eng.jobs_strided(src, STRIDE_IN, lens, dst, STRIDE_OUT, STRIDE_OUT, dht_index=np.zeros(n, np.uint32))
+        res = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
+        sets.append((blocks, tab, src, dst, jobs, res, eng.to_device(_dht_array([tab]))))
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for st, (blocks, tab, src, dst, jobs, res, dht) in zip((s1, s2), sets):
+            with torch.cuda.stream(st):
+                eng.compress(pkg.FC_COMPRESS_DHT, jobs, n, results=res, dht=dht, ntables=1)
+    torch.cuda.synchronize()
+    comp = []
+    for blocks, tab, src, dst, jobs, res, dht in sets:
+        r = eng.results_to_host(res).copy()
+        out = dst.cpu().numpy()
+        # CC 64: complete output that is larger than the source (33-symbol noise under a table made from text)
+        assert ((r["cc"] == 0) | (r["cc"] == 64)).all(), np.unique(r["cc"], return_counts=True)
+        for i in (0, 1, 2, 3, n // 2, n - 1):
+            exp, nbits = O.deflate_dynamic(blocks[i], tab[0], tab[1])
+            assert out[i, :len(exp)].tobytes() == exp, i
+        for i in range(0, n, 97):
+            dz = zlib.decompressobj(-15)
+            assert dz.decompress(out[i, :r["tpbc"][i]].tobytes()) == blocks[i] and dz.eof, i
+        comp.append((dst, r))
+    # inflate both outputs at the same time on the two streams
+    back = []
+    for (dst, r), st in zip(comp, (s1, s2)):
+        o = torch.zeros((n, 65536), dtype=torch.uint8, device=eng.dev)
+        j = eng.jobs_strided(dst, STRIDE_OUT, r["tpbc"].astype(np.uint32), o, 65536, 65536)
+        rr = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
+        back.append((o, j, rr))
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for st, (o, j, rr) in zip((s1, s2), back):
+            with torch.cuda.stream(st):
+                eng.decompress(j, n, results=rr)
+    torch.cuda.synchronize()
+    for (o, j, rr), (blocks, *_), (dst, r) in zip(back, sets, comp):
+        r2 = eng.results_to_host(rr)
+        assert (r2["cc"] == 0).all() and (r2["crc"] == r["crc"]).all()
+        got = o.cpu().numpy()
+        for i in range(0, n, 41):
+            assert got[i].tobytes() == blocks[i], i
+
+
 def test_seeded_fuzz_against_oracle(eng):
     """1500 blocks of random kind, random size (0 .. 64 KiB, many at tile / piece / chunk edges) and
     random history (multiple of 16, window + block <= 64 KiB), checked bit for bit and by checksum."""
