@@ -263,6 +263,31 @@ int nxz_batch_decompress(nxz_ctx_t *ctx,
 int nxz_batch_wrap(nxz_ctx_t *ctx, const nxz_batch_job_t *jobs, size_t n,
 		   nxz_batch_result_t *results, void *stream);
 
+/* Gzip members (RFC 1952) from the results of a compress batch, written back to back into
+ * `packed` (device): member i = 18-byte header carrying the "BC" extra subfield with the
+ * member's own size - 1 (the BGZF layout: readers can find every member without inflating),
+ * job i's output -- or, when the job failed or did not shrink (CC != 0 or tpbc >= length + 5), a
+ * stored block of its source, the per-job fallback of lib/nx_deflate.c:1292-1400 --, CRC32 and
+ * ISIZE.  jobs[].dst must be 16-byte aligned as the compress batch requires; source blocks of
+ * at most 65 280 bytes keep every member within BGZF's 64 KiB.  offsets (device, n + 1
+ * uint64): start of each member in `packed`; offsets[n] = total bytes.  `packed` needs
+ * n * 26 + sum(max(tpbc, length + 5)) bytes at most.  Asynchronous on `stream`. */
+int nxz_batch_pack_gzip(nxz_ctx_t *ctx, const nxz_batch_job_t *jobs, const nxz_batch_result_t *results,
+			size_t n, uint64_t *offsets, uint8_t *packed, void *stream);
+
+/* Device memory, pinned host memory, streams and asynchronous copies, for callers that hold
+ * host buffers and do not link the HIP runtime themselves.  A stream made here is passed as
+ * the `stream` argument of the batch calls; nxz_stream_destroy also releases the per-stream
+ * scratch the batch calls keep. */
+void *nxz_dev_malloc(nxz_ctx_t *ctx, size_t bytes);
+void  nxz_dev_free(nxz_ctx_t *ctx, void *p);
+void *nxz_pinned_malloc(nxz_ctx_t *ctx, size_t bytes);
+void  nxz_pinned_free(nxz_ctx_t *ctx, void *p);
+void *nxz_stream_create(nxz_ctx_t *ctx);
+void  nxz_stream_destroy(nxz_ctx_t *ctx, void *stream);
+int   nxz_copy_to_device(nxz_ctx_t *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int   nxz_copy_to_host(nxz_ctx_t *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
+
 /* Block until everything queued on `stream` by this context has finished. */
 int nxz_ctx_sync(nxz_ctx_t *ctx, void *stream);
 

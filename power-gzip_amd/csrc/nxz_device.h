@@ -26,6 +26,8 @@ int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *r
 int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 		       nxz_batch_dht_t *dht_io, hipStream_t stream);
 size_t nxz_inflate_lanes_workspace(size_t n);
+int nxz_launch_pack_members(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n,
+			    uint64_t *offsets, uint8_t *packed, hipStream_t stream);
 int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 			     nxz_batch_dht_t *dht_io, uint8_t *workspace, int init_fixed, hipStream_t stream);
 }

@@ -76,6 +76,11 @@ struct nxz_ctx {
 	unsigned next_counter = 0;
 };
 static constexpr unsigned JOB_COUNTERS = 256;
+// Batches of fewer streams than this go to the wave-per-stream inflate kernel: a stream per lane
+// takes 60-80 ms for 64 KiB streams however few there are, a stream per wave 14 ms per 768 streams
+// (profiles/r01c_inflate_by_batch_size.txt); they cross at about 4096 streams.  The wave kernel
+// needs 16-byte aligned sources, as the batch interface demands.
+#define NXZ_LANES_MIN 4096
 
 static std::mutex g_mtx;
 static nxz_ctx *g_ctx[64];
@@ -211,7 +216,9 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 	if (!c) return -EINVAL;
 	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
 	int rc;
-	if (n >= 32) {
+	const char *lm = getenv("NXZ_INFLATE_LANES_MIN");                    // tuning / test knob
+	const size_t lanes_min = lm ? (size_t)strtoull(lm, nullptr, 0) : (size_t)NXZ_LANES_MIN;
+	if (n >= lanes_min) {
 		// many streams: one stream per lane (nxz_inflate_lanes.hip); the table workspace is made once
 		int init = 0;
 		uint8_t *ws;
@@ -244,6 +251,74 @@ extern "C" int nxz_batch_wrap(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t 
 	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
 	int rc = nxz_launch_wrap(jobs, n, results, s);
 	if (rc) { set_err("wrap launch", (hipError_t)rc); return -EIO; }
+	return 0;
+}
+
+
+// Gzip members from the results of a compress batch (nxz_misc.hip): offsets[n + 1] and `packed`
+// are device memory; offsets[n] is the number of bytes written to `packed`.
+extern "C" int nxz_batch_pack_gzip(nxz_ctx_t *c, const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n,
+				   uint64_t *offsets, uint8_t *packed, void *stream)
+{
+	if (!c || !jobs || !results || !offsets || !packed || n > 0xffffffffu) return -EINVAL;
+	int rc = nxz_launch_pack_members(jobs, results, n, offsets, packed, (hipStream_t)stream);
+	if (rc) { set_err("pack launch", (hipError_t)rc); return -EIO; }
+	return 0;
+}
+
+// Device memory, pinned host memory, streams and copies for callers that hold HOST buffers and do
+// not link the HIP runtime themselves (cgo / JNI / ctypes hosts; libnxz_amd.so's blocked-gzip layer).
+extern "C" void *nxz_dev_malloc(nxz_ctx_t *c, size_t bytes)
+{
+	void *p = nullptr;
+	if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;
+	HIPCHK(hipMalloc(&p, bytes ? bytes : 16), return nullptr);
+	return p;
+}
+extern "C" void nxz_dev_free(nxz_ctx_t *c, void *p) { if (c && p) { (void)hipSetDevice(c->device); (void)hipFree(p); } }
+extern "C" void *nxz_pinned_malloc(nxz_ctx_t *c, size_t bytes)
+{
+	void *p = nullptr;
+	if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;
+	HIPCHK(hipHostMalloc(&p, bytes ? bytes : 16), return nullptr);
+	return p;
+}
+extern "C" void nxz_pinned_free(nxz_ctx_t *c, void *p) { if (c && p) { (void)hipSetDevice(c->device); (void)hipHostFree(p); } }
+extern "C" void *nxz_stream_create(nxz_ctx_t *c)
+{
+	hipStream_t s = nullptr;
+	if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;
+	HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), return nullptr);
+	return (void *)s;
+}
+extern "C" void nxz_stream_destroy(nxz_ctx_t *c, void *stream)
+{
+	if (!c || !stream) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize((hipStream_t)stream);
+	{
+		std::lock_guard<std::mutex> g(c->mtx);
+		auto it = c->scratch.find((hipStream_t)stream);
+		if (it != c->scratch.end()) {
+			if (it->second.d_prepared) (void)hipFree(it->second.d_prepared);
+			if (it->second.d_lanes_ws) (void)hipFree(it->second.d_lanes_ws);
+			c->scratch.erase(it);
+		}
+	}
+	(void)hipStreamDestroy((hipStream_t)stream);
+}
+extern "C" int nxz_copy_to_device(nxz_ctx_t *c, void *dst_dev, const void *src_host, size_t bytes, void *stream)
+{
+	if (!c) return -EINVAL;
+	if (!bytes) return 0;
+	HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream), return -EIO);
+	return 0;
+}
+extern "C" int nxz_copy_to_host(nxz_ctx_t *c, void *dst_host, const void *src_dev, size_t bytes, void *stream)
+{
+	if (!c) return -EINVAL;
+	if (!bytes) return 0;
+	HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), return -EIO);
 	return 0;
 }
 

@@ -7,6 +7,11 @@
 //   oracle/nxz_huff.c nxo_dht_parse (what lib/nx_dht_decomp.c:255-653 models).
 // wrap: GZIP_FC_WRAP (lib/nx_deflate.c:1774, lib/nx_zlib.c:1398-1443): copy
 //   source to target and return CRC-32/Adler-32 from the initial values.
+// member_offsets / pack_members: turn the outputs of a compress batch into a contiguous run of
+//   gzip members, one per job (RFC 1952; each carries the 6-byte "BC" extra subfield with its own
+//   size, the BGZF layout, so a reader can hop from member to member and inflate them in
+//   parallel).  A job that did not shrink is written as a stored block, the fallback the reference
+//   applies per job (lib/nx_deflate.c:1292-1400, append_btype00_header :175-201).
 #include <hip/hip_runtime.h>
 #include "nxz_device.h"
 
@@ -191,6 +196,103 @@ __global__ __launch_bounds__(256) void wrap_kernel(const nxz_batch_job_t *__rest
 	}
 }
 
+
+// ---- gzip members from a compress batch -------------------------------------------------------
+#define NXZ_MEMBER_OVERHEAD 26u      /* 18-byte header with the BC subfield + CRC32 + ISIZE */
+
+__device__ inline bool member_stored(const nxz_batch_job_t &job, const nxz_batch_result_t &r)
+{
+	const uint32_t len = job.src_len - job.hist_len;
+	return r.cc != 0 || r.tpbc >= len + 5;
+}
+
+// offsets[0..n]: exclusive prefix sum of the member sizes; one workgroup
+__global__ __launch_bounds__(1024) void member_offsets_kernel(const nxz_batch_job_t *__restrict__ jobs, const nxz_batch_result_t *__restrict__ results,
+							      uint32_t n, uint64_t *__restrict__ offsets)
+{
+	__shared__ uint64_t part[1024];
+	const uint32_t t = threadIdx.x;
+	const uint32_t per = (n + 1023) / 1024;
+	const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+	uint64_t sum = 0;
+	for (uint32_t i = lo; i < hi; i++) {
+		const nxz_batch_job_t job = jobs[i];
+		const nxz_batch_result_t r = results[i];
+		sum += NXZ_MEMBER_OVERHEAD + (member_stored(job, r) ? 5 + (job.src_len - job.hist_len) : r.tpbc);
+	}
+	part[t] = sum;
+	__syncthreads();
+	for (uint32_t d = 1; d < 1024; d <<= 1) {
+		uint64_t v = t >= d ? part[t - d] : 0;
+		__syncthreads();
+		part[t] += v;
+		__syncthreads();
+	}
+	uint64_t off = part[t] - sum;
+	for (uint32_t i = lo; i < hi; i++) {
+		const nxz_batch_job_t job = jobs[i];
+		const nxz_batch_result_t r = results[i];
+		offsets[i] = off;
+		off += NXZ_MEMBER_OVERHEAD + (member_stored(job, r) ? 5 + (job.src_len - job.hist_len) : r.tpbc);
+	}
+	if (t == 1023) offsets[n] = part[1023];
+}
+
+// one workgroup per member: header, payload (the job's output, or 5 bytes of stored-block header and
+// the source), trailer.  Whole dwords of the packed buffer are stored at once where the member
+// covers them; the payload bytes of such a dword come from two aligned dword loads.
+__global__ __launch_bounds__(256) void pack_members_kernel(const nxz_batch_job_t *__restrict__ jobs, const nxz_batch_result_t *__restrict__ results,
+							   const uint64_t *__restrict__ offsets, uint8_t *__restrict__ packed)
+{
+	const uint32_t t = threadIdx.x;
+	const nxz_batch_job_t job = jobs[blockIdx.x];
+	const nxz_batch_result_t r = results[blockIdx.x];
+	const uint64_t off = offsets[blockIdx.x];
+	const uint32_t len = job.src_len - job.hist_len;
+	const bool stored = member_stored(job, r);
+	const uint32_t paylen = stored ? 5 + len : r.tpbc;
+	const uint32_t size = NXZ_MEMBER_OVERHEAD + paylen;
+	const uint32_t d0 = stored ? 23 : 18;                         // first member byte that comes from `data`
+	const uint32_t dn = stored ? len : r.tpbc;
+	const uint8_t *data = stored ? job.src + job.hist_len : job.dst;
+	const uint32_t bsize = size - 1;
+	auto byte_at = [&](uint32_t j) -> uint32_t {
+		if (j < 18) {
+			// ID1 ID2 CM FLG=FEXTRA MTIME(4) XFL OS=unknown XLEN=6 'B' 'C' SLEN=2 BSIZE
+			const uint32_t h0 = 0x04088b1fu, h2 = 0x0006ff00u, h3 = 0x00024342u;
+			return j < 4 ? (h0 >> (8 * j)) & 0xff : j < 8 ? 0 : j < 12 ? (h2 >> (8 * (j - 8))) & 0xff :
+			       j < 16 ? (h3 >> (8 * (j - 12))) & 0xff : (bsize >> (8 * (j - 16))) & 0xff;
+		}
+		if (j < d0) {                                           // stored block: BFINAL=1 BTYPE=00, LEN, NLEN
+			const uint32_t k = j - 18;
+			return k == 0 ? 1 : k < 3 ? (len >> (8 * (k - 1))) & 0xff : (~len >> (8 * (k - 3))) & 0xff;
+		}
+		if (j < d0 + dn) return data[j - d0];
+		const uint32_t k = j - d0 - dn;                         // CRC32, ISIZE
+		return k < 4 ? (r.crc >> (8 * k)) & 0xff : (len >> (8 * (k - 4))) & 0xff;
+	};
+	uint8_t *o = packed + off;
+	const uint32_t head = (uint32_t)((4 - ((uintptr_t)o & 3)) & 3);      // bytes before the first aligned dword
+	const uint32_t nd = size > head ? (size - head) >> 2 : 0;            // whole dwords
+	if (t < head && t < size) o[t] = (uint8_t)byte_at(t);
+	for (uint32_t k = head + nd * 4 + t; k < size; k += 256) o[k] = (uint8_t)byte_at(k);
+	uint32_t *od = (uint32_t *)(o + head);
+	for (uint32_t w = t; w < nd; w += 256) {
+		const uint32_t j = head + w * 4;
+		uint32_t v;
+		if (j >= d0 && j + 4 <= d0 + dn) {
+			const uintptr_t a = (uintptr_t)data + (j - d0);
+			const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
+			const uint32_t bo = (uint32_t)a & 3;
+			const uint32_t lo = q[0], hi = bo ? q[1] : 0;
+			v = __builtin_amdgcn_alignbyte(hi, lo, bo);
+		} else {
+			v = byte_at(j) | byte_at(j + 1) << 8 | byte_at(j + 2) << 16 | byte_at(j + 3) << 24;
+		}
+		od[w] = v;
+	}
+}
+
 } // namespace nxz
 
 extern "C" int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_dht_prepared_t *out, hipStream_t stream)
@@ -204,5 +306,14 @@ extern "C" int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_
 {
 	if (!n) return 0;
 	hipLaunchKernelGGL(nxz::wrap_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
+	return (int)hipGetLastError();
+}
+
+extern "C" int nxz_launch_pack_members(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n,
+				       uint64_t *offsets, uint8_t *packed, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL(nxz::member_offsets_kernel, dim3(1), dim3(1024), 0, stream, jobs, results, (uint32_t)n, offsets);
+	hipLaunchKernelGGL(nxz::pack_members_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, results, offsets, packed);
 	return (int)hipGetLastError();
 }

@@ -23,9 +23,21 @@ STRIDE_OUT = 73856  # nxz_compress_bound(65536) rounded up
 
 @pytest.fixture(scope="module")
 def eng():
+    # batches of >= 32 streams go to the stream-per-lane inflate kernel in these tests (the engine's
+    # own switch-over is at 4096 streams); `inflate_kernel` below runs a test under both kernels
+    os.environ["NXZ_INFLATE_LANES_MIN"] = "32"
     e = pkg.Engine(0)
     yield e
     e.close()
+    os.environ.pop("NXZ_INFLATE_LANES_MIN", None)
+
+
+@pytest.fixture(params=["lanes", "waves"])
+def inflate_kernel(request):
+    old = os.environ.get("NXZ_INFLATE_LANES_MIN")
+    os.environ["NXZ_INFLATE_LANES_MIN"] = "32" if request.param == "lanes" else "1000000000"
+    yield request.param
+    os.environ["NXZ_INFLATE_LANES_MIN"] = old if old is not None else "32"
 
 
 def pack_blocks(eng, blocks, stride):
@@ -189,7 +201,7 @@ def _zstreams():
 
 
 @pytest.mark.parametrize("copies", [1, 3])          # 31 streams: wave-per-stream kernel; 93: lane-per-stream kernel
-def test_inflate_zlib_streams_bit_exact(eng, copies):
+def test_inflate_zlib_streams_bit_exact(eng, copies, inflate_kernel):
     import torch
     streams = _zstreams() * copies
     cstride = max(len(c) for _, c in streams) + 64
@@ -208,7 +220,7 @@ def test_inflate_zlib_streams_bit_exact(eng, copies):
         assert r["subc"][i] // 8 == 8, i
 
 
-def test_inflate_suspend_state_matches_oracle(eng):
+def test_inflate_suspend_state_matches_oracle(eng, inflate_kernel):
     """cut streams at arbitrary bytes: CC 3, SFBT/SUBC/rembytecnt/tpbc/dht must equal the CPU model."""
     import random
     import torch
@@ -534,7 +546,7 @@ def test_seeded_fuzz_against_oracle(eng):
         assert r["crc"][i] == zlib.crc32(b[hl:], 0x1234abcd) and r["adler"][i] == zlib.adler32(b[hl:], 0x00010001), i
 
 
-def test_seeded_inflate_fuzz(eng):
+def test_seeded_inflate_fuzz(eng, inflate_kernel):
     """600 zlib-made raw deflate streams (levels 0-9, default / fixed / Huffman-only / RLE strategies,
     sizes 0 .. 64 KiB, several blocks per stream through Z_FULL_FLUSH) through the batched inflate:
     output, length and both checksums."""
