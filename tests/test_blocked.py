@@ -32,8 +32,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        C.CDLL(os.path.join(ROOT, "power-gzip_amd", "libnxz_engine.so"), mode=C.RTLD_GLOBAL)
-        L = C.CDLL(LIB)
+        L = C.CDLL(LIB)          # finds libnxz_engine.so through its run path; nothing is made global
         L.nxz_blocked_deflate.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Opts), SINK, C.c_void_p, C.POINTER(C.c_uint64)]
         L.nxz_blocked_inflate.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Opts), SINK, C.c_void_p, C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_size_t)]
