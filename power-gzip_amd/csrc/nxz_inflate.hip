@@ -15,11 +15,25 @@
 //     (lane per 256-byte slice, GF(2) tree combine)
 // The 32 KiB circular output window in LDS is also the history, so match
 // sources never touch HBM.
+//
+// Inside a coded block the common case runs through a multi-token step: the next 96 bits of the
+// source are kept wave-uniform (taken with v_readlane from two 256-byte blocks of the source that
+// the lanes hold in registers, so the bit reader needs no LDS), every lane looks up BOTH decode
+// tables at its own bit offset (one LDS round trip for all 64 offsets), and a uniform walk then
+// follows the chain of real token starts through those answers with v_readlane: 5-7 tokens per
+// round trip instead of one token per 2-6.  Anything unusual (codes longer than the fast tables,
+// end of block, errors, the last bytes of the source, a full target) is left to the one-token
+// path below it, which keeps the suspend/error semantics exactly as before.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "nxz_device.h"
 
 namespace nxzi {
+
+// Diagnostic only (tools/bench_inflate_kinds.py): cycle sums of lane 0 of every stream.
+__device__ unsigned long long *prof_buf = nullptr;
+#define IPROF(idx) do { if (prof) { unsigned long long now_ = clock64(); pacc[idx] += now_ - tprev; tprev = now_; } } while (0)
+#define ICOUNT(idx, v) do { if (prof) pacc[idx] += (unsigned long long)(v); } while (0)
 
 constexpr uint32_t WIN = 32768, WMASK = WIN - 1;
 constexpr uint32_t FLUSH = 16384;
@@ -277,6 +291,9 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	const uint8_t *src = job.src + hist;
 	uint8_t *dst = job.dst;
 	const uint32_t cap = job.dst_cap;
+	unsigned long long *prof = prof_buf;
+	unsigned long long tprev = prof ? clock64() : 0;
+	unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 	for (int i = lane; i < 256; i += 64) {
 		uint32_t c = i;
@@ -307,6 +324,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 
 	// flush window bytes [flushed, upto) to dst and fold them into the checksums
 	auto flush = [&](uint32_t upto) {
+		IPROF(0);
 		while (flushed < upto) {
 			uint32_t n = upto - flushed < FLUSH ? upto - flushed : FLUSH;
 			// right-aligned frame of 64 x 256 B slices
@@ -345,6 +363,19 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			flushed += n;
 			__syncthreads();
 		}
+		IPROF(1);
+	};
+
+	// two 256-byte blocks of the source in registers (lane k: dword k), for the multi-token step
+	const bool fast_ok = ((uintptr_t)src & 3) == 0;
+	uint32_t W0 = 0, W1 = 0, wblk = 0xffffffffu;
+	auto load_block = [&](uint32_t blk) -> uint32_t {
+		const uint32_t idx = blk * 64 + lane;
+		const uint64_t byte = (uint64_t)idx * 4;
+		uint32_t w = 0;
+		if (byte + 4 <= srclen) w = ((const uint32_t *)src)[idx];
+		else for (uint32_t k = 0; byte + k < srclen; k++) w |= (uint32_t)src[byte + k] << (8 * k);
+		return w;
 	};
 
 	// resume state
@@ -444,6 +475,94 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			if (bfinal) { final_eob = true; break; }
 			state = 0;
 		} else {
+			// ---- multi-token step (see the header) ----
+			if (fast_ok && b.pos + 192 <= b.total_bits) {
+				IPROF(0);
+				const uint32_t q = (uint32_t)(b.pos >> 5), sh = (uint32_t)b.pos & 31;
+				if (wblk == 0xffffffffu || q < wblk * 64 || q >= wblk * 64 + 128) {
+					wblk = q >> 6;
+					W0 = load_block(wblk); W1 = load_block(wblk + 1);
+				} else if (q >= wblk * 64 + 64) {
+					wblk++;
+					W0 = W1; W1 = load_block(wblk + 1);
+				}
+				const uint32_t qi = q - wblk * 64;                              // 0..63: dwords qi..qi+3 are in W0/W1
+				auto word = [&](uint32_t i) -> uint32_t {
+					i = __builtin_amdgcn_readfirstlane(i);
+					return i < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)i) : (uint32_t)__builtin_amdgcn_readlane((int)W1, (int)(i - 64));
+				};
+				const uint32_t s0 = word(qi), s1 = word(qi + 1), s2 = word(qi + 2), s3 = word(qi + 3);
+				uint64_t lo = ((uint64_t)s1 << 32) | s0, hi = ((uint64_t)s2 << 32) | s1;   // bits [0,64) and [32,96) from pos
+				if (sh) { lo = (lo >> sh) | ((uint64_t)s2 << (64 - sh)); hi = (hi >> sh) | ((uint64_t)s3 << (64 - sh)); }
+				const uint32_t v = lane < 32 ? (uint32_t)(lo >> lane) : (uint32_t)(hi >> (lane - 32));
+				const uint32_t el = sm.hl.fast[v & ((1u << LBITS) - 1)];
+				const uint32_t ed = sm.hd.fast[v & ((1u << DBITS) - 1)];
+				auto bits_at = [&](uint32_t o) -> uint32_t { return o < 32 ? (uint32_t)(lo >> o) : (uint32_t)(hi >> (o - 32)); };
+				// bits of a literal token at this lane's offset, 0 when something else starts here
+				const uint32_t nbl = (el && (el & 0xfff) < 256) ? el >> 12 : 0;
+				IPROF(2);
+				const uint32_t out0 = out;
+				uint32_t off = 0;
+				for (;;) {
+					// a run of literals: follow the chain of token starts without branching (each step
+					// stays put once it meets a non-literal), then all of them are written at once
+					uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)nbl, (int)__builtin_amdgcn_readfirstlane(off));
+					if (e0) {
+						uint64_t starts = 0;
+						uint32_t o = off;
+#pragma unroll
+						for (int k = 0; k < 8; k++) {
+							const uint32_t ol = o < 63 ? o : 63;
+							uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)nbl, (int)__builtin_amdgcn_readfirstlane(ol));
+							e = o < 64 ? e : 0;
+							starts |= (uint64_t)(e != 0) << ol;
+							o += e;
+						}
+						const uint32_t nlit = (uint32_t)__builtin_popcountll(starts);
+						if (nlit > cap - out) break;                                // target nearly full: one-token path
+						if ((starts >> lane) & 1) {
+							const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0));
+							sm.win[(out + rank) & WMASK] = (uint8_t)el;
+						}
+						out += nlit; off = o;
+						if (off > 47 || out - flushed >= FLUSH) break;
+					}
+					const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)el, (int)__builtin_amdgcn_readfirstlane(off));
+					if (!e) break;                                              // a long code: one-token path
+					const uint32_t nb = e >> 12, sym = e & 0xfff;
+					if (sym < 256) continue;                                    // the run above stopped at its step limit
+					if (sym == 256 || sym >= 257 + 29) break;                   // end of block / bad symbol
+					uint32_t lbase, eb, dbase, ebd;
+					len_params(sym - 257, lbase, eb);
+					const uint32_t o1 = off + nb;
+					const uint32_t len = lbase + (bits_at(o1) & ((1u << eb) - 1));
+					const uint32_t o2 = o1 + eb;                                // <= 47 + 11 + 5
+					const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)ed, (int)__builtin_amdgcn_readfirstlane(o2));
+					if (!d) break;
+					const uint32_t ds = d & 0xfff;
+					if (ds >= 30) break;
+					dist_params(ds, dbase, ebd);
+					const uint32_t o3 = o2 + (d >> 12);
+					const uint32_t dist = dbase + (bits_at(o3) & ((1u << ebd) - 1));
+					if (dist > out + hist || dist > WIN || len > cap - out) break;
+					if (dist >= len) {
+						for (uint32_t i = lane; i < len; i += 64) sm.win[(out + i) & WMASK] = sm.win[(out - dist + i) & WMASK];
+					} else {
+						for (uint32_t i = lane; i < len; i += 64) sm.win[(out + i) & WMASK] = sm.win[(out - dist + i % dist) & WMASK];
+					}
+					out += len; off = o3 + ebd;                                 // <= 63 + 9 + 13 < 96
+					if (off > 47 || out - flushed >= FLUSH) break;
+				}
+				IPROF(3);
+				ICOUNT(4, 1); ICOUNT(5, out - out0); ICOUNT(6, off);
+				if (off) {
+					b.pos += off;
+					if (out - flushed >= FLUSH) { __syncthreads(); flush(flushed + FLUSH); }
+					continue;
+				}
+			}
+			b.bb_sync();
+			ICOUNT(7, 1);
 			const uint64_t sym_start = b.pos;
 			const uint32_t sfbt = (btype == 1 ? 0xa : 0xc) | bfinal;
 			uint32_t nb;
@@ -501,6 +620,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 done:
 	__syncthreads();
 	if (cc == 0) flush(out);
+	IPROF(0);
+	if (prof && lane == 0) for (int k = 0; k < 8; k++) __hip_atomic_fetch_add(&prof[k], pacc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	if (lane == 0) {
 		nxz_batch_result_t r;
 		uint32_t spbc = job.src_len, subc = o_subc;
@@ -518,6 +639,11 @@ done:
 }
 
 } // namespace nxzi
+
+extern "C" int nxz_inflate_prof_set(unsigned long long *buf)
+{
+	return (int)hipMemcpyToSymbol(HIP_SYMBOL(nxzi::prof_buf), &buf, sizeof(buf));
+}
 
 extern "C" int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 				  nxz_batch_dht_t *dht_io, hipStream_t stream)
