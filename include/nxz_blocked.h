@@ -25,7 +25,7 @@ typedef struct nxz_blocked_opts {
 	int      device;        /* -1: NX_GZIP_DEV_NUM / current device */
 	int      fixed;         /* 1: fixed Huffman (FC 0x00); 0: dynamic Huffman, one table per `group` blocks */
 	uint32_t block_size;    /* 0 = NXZ_BLOCKED_BLOCK; multiple of 16, <= 65280 */
-	uint32_t chunk_blocks;  /* blocks per batch (0 = 4096 for deflate, 16384 for inflate); two batches are in flight */
+	uint32_t chunk_blocks;  /* blocks per batch (0 = 4096 for deflate, 8192 for inflate); two batches are in flight */
 	uint32_t group;         /* dynamic: blocks per table (0 = 64); the table comes from the group's first block */
 	uint32_t reserved[3];
 } nxz_blocked_opts_t;

@@ -274,9 +274,9 @@ extern "C" int nxz_blocked_inflate(const void *src_, size_t len, const nxz_block
 	if (mem.empty()) return 1;
 	if (consumed) *consumed = used;
 
-	// batches of at most `chunk` members; staging sized for the largest batch.  Large batches: the
-	// stream-per-lane kernel takes 60-80 ms however few streams it is given
-	const size_t chunk = std::min<size_t>(o.chunk_blocks ? o.chunk_blocks : 16384, mem.size());
+	// batches of at most `chunk` members; staging sized for the largest batch (8192 members take
+	// the stream-per-wave kernel about 45 ms)
+	const size_t chunk = std::min<size_t>(o.chunk_blocks ? o.chunk_blocks : 8192, mem.size());
 	size_t max_in = 0, max_out = 0;
 	for (size_t f = 0; f < mem.size(); f += chunk) {
 		size_t in = 0, out = 0;

@@ -32,8 +32,13 @@ namespace nxzi {
 
 // Diagnostic only (tools/bench_inflate_kinds.py): cycle sums of lane 0 of every stream.
 __device__ unsigned long long *prof_buf = nullptr;
+#ifdef NXZ_INFLATE_PROF        /* build with -DNXZ_INFLATE_PROF to use tools/bench_inflate_kinds.py's cycle sums */
 #define IPROF(idx) do { if (prof) { unsigned long long now_ = clock64(); pacc[idx] += now_ - tprev; tprev = now_; } } while (0)
 #define ICOUNT(idx, v) do { if (prof) pacc[idx] += (unsigned long long)(v); } while (0)
+#else
+#define IPROF(idx) do { } while (0)
+#define ICOUNT(idx, v) do { } while (0)
+#endif
 
 constexpr uint32_t WIN = 32768, WMASK = WIN - 1;
 constexpr uint32_t FLUSH = 16384;
@@ -291,9 +296,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	const uint8_t *src = job.src + hist;
 	uint8_t *dst = job.dst;
 	const uint32_t cap = job.dst_cap;
+#ifdef NXZ_INFLATE_PROF
 	unsigned long long *prof = prof_buf;
 	unsigned long long tprev = prof ? clock64() : 0;
 	unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
 	for (int i = lane; i < 256; i += 64) {
 		uint32_t c = i;
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			state = 0;
 		} else {
 			// ---- multi-token step (see the header) ----
-			if (fast_ok && b.pos + 192 <= b.total_bits) {
+			while (fast_ok && b.pos + 192 <= b.total_bits) {
 				IPROF(0);
 				const uint32_t q = (uint32_t)(b.pos >> 5), sh = (uint32_t)b.pos & 31;
 				if (wblk == 0xffffffffu || q < wblk * 64 || q >= wblk * 64 + 128) {
@@ -501,7 +508,9 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 				// bits of a literal token at this lane's offset, 0 when something else starts here
 				const uint32_t nbl = (el && (el & 0xfff) < 256) ? el >> 12 : 0;
 				IPROF(2);
+#ifdef NXZ_INFLATE_PROF
 				const uint32_t out0 = out;
+#endif
 				uint32_t off = 0;
 				for (;;) {
 					// a run of literals: follow the chain of token starts without branching (each step
@@ -512,10 +521,9 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 						uint32_t o = off;
 #pragma unroll
 						for (int k = 0; k < 8; k++) {
-							const uint32_t ol = o < 63 ? o : 63;
-							uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)nbl, (int)__builtin_amdgcn_readfirstlane(ol));
+							uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)nbl, (int)__builtin_amdgcn_readfirstlane(o & 63));
 							e = o < 64 ? e : 0;
-							starts |= (uint64_t)(e != 0) << ol;
+							starts |= (uint64_t)((e + 15) >> 4) << (o & 63);      // e is 0..15: 1 for a literal, in scalar arithmetic
 							o += e;
 						}
 						const uint32_t nlit = (uint32_t)__builtin_popcountll(starts);
@@ -555,12 +563,12 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 				}
 				IPROF(3);
 				ICOUNT(4, 1); ICOUNT(5, out - out0); ICOUNT(6, off);
-				if (off) {
-					b.pos += off;
-					if (out - flushed >= FLUSH) { __syncthreads(); flush(flushed + FLUSH); }
-					continue;
-				}
+				if (!off) break;
+				b.pos += off;
+				if (out - flushed >= FLUSH) break;
 			}
+			if (out - flushed >= FLUSH) { __syncthreads(); flush(flushed + FLUSH); continue; }
+			// the step stopped at a token it leaves to the one-token path (or never ran)
 			b.bb_sync();
 			ICOUNT(7, 1);
 			const uint64_t sym_start = b.pos;
@@ -621,7 +629,9 @@ done:
 	__syncthreads();
 	if (cc == 0) flush(out);
 	IPROF(0);
+#ifdef NXZ_INFLATE_PROF
 	if (prof && lane == 0) for (int k = 0; k < 8; k++) __hip_atomic_fetch_add(&prof[k], pacc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 	if (lane == 0) {
 		nxz_batch_result_t r;
 		uint32_t spbc = job.src_len, subc = o_subc;
