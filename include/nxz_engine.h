@@ -296,6 +296,11 @@ int nxz_ctx_sync(nxz_ctx_t *ctx, void *stream);
  * store granularity). */
 size_t nxz_compress_bound(size_t src_len);
 
+/* 0 in a process that was forked after a context was created (the HIP runtime does not survive
+ * fork(); such a child gets ENODEV / CC 254 from every entry point and should use software zlib,
+ * which is what libnxz_preload.so does), else 1. */
+int nxz_engine_usable(void);
+
 /* Library version string. */
 const char *nxz_engine_version(void);
 

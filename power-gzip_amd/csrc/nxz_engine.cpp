@@ -84,6 +84,11 @@ static constexpr unsigned JOB_COUNTERS = 256;
 
 static std::mutex g_mtx;
 static nxz_ctx *g_ctx[64];
+// The HIP runtime does not survive fork(): a child that inherits contexts must not touch them (the
+// reference re-opens its device in the child, lib/nx_zlib.c:529-551; here the child is refused and
+// the dispatch layer sends its streams to software zlib).
+static pid_t g_creator_pid = 0;
+static bool forked_child() { return g_creator_pid != 0 && getpid() != g_creator_pid; }
 
 static bool slot_init(Slot &s)
 {
@@ -114,8 +119,15 @@ static void slot_free(Slot &s)
 	s = Slot();
 }
 
+extern "C" int nxz_engine_usable(void) { return forked_child() ? 0 : 1; }
+
 extern "C" nxz_ctx_t *nxz_ctx_create(int device)
 {
+	if (forked_child()) {
+		snprintf(g_err, sizeof(g_err), "this process was forked after the engine was opened: the HIP runtime does not survive fork()");
+		errno = ENODEV;
+		return nullptr;
+	}
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
 		snprintf(g_err, sizeof(g_err), "no HIP device: the DEFLATE engine needs a gfx950 GPU (no CPU fallback)");
@@ -141,6 +153,7 @@ extern "C" nxz_ctx_t *nxz_ctx_create(int device)
 	nxz_ctx *c = new nxz_ctx();
 	c->device = device;
 	c->refs = 1;
+	g_creator_pid = getpid();
 	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), { delete c; errno = ENODEV; return nullptr; });
 	g_ctx[device] = c;
 	return c;
@@ -148,7 +161,7 @@ extern "C" nxz_ctx_t *nxz_ctx_create(int device)
 
 extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 {
-	if (!c) return;
+	if (!c || forked_child()) return;                     // the parent owns the device objects
 	std::lock_guard<std::mutex> g(g_mtx);
 	if (--c->refs > 0) return;
 	(void)hipSetDevice(c->device);
@@ -178,6 +191,7 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 				  uint32_t *counts, void *stream)
 {
 	if (!c || !nxz_fc_is_compress((uint32_t)fc) || (fc & 1)) return -EINVAL;
+	if (forked_child()) return -ENODEV;
 	const bool isdht = nxz_fc_is_dht((uint32_t)fc), count = nxz_fc_has_count((uint32_t)fc);
 	if (count && !counts) return -EINVAL;
 	if (isdht && (!dht || !ntables)) return -EINVAL;
@@ -214,6 +228,7 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 				    nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, void *stream)
 {
 	if (!c) return -EINVAL;
+	if (forked_child()) return -ENODEV;
 	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
 	int rc;
 	const char *lm = getenv("NXZ_INFLATE_LANES_MIN");                    // tuning / test knob
@@ -605,7 +620,7 @@ extern "C" int nxu_run_job(nxz_crb_cpb_t *j, void *handle)
 	nxz_dev_t *h = (nxz_dev_t *)handle;
 	nxz_ctx *c = h ? (nxz_ctx *)h->paste_addr : nullptr;
 	if (!j) return -EINVAL;
-	if (!c) { nxz_csb_complete(j, NXZ_CC_NO_HW, NXZ_CE_TERMINATE, 0); return 0; }
+	if (!c || forked_child()) { nxz_csb_complete(j, NXZ_CC_NO_HW, NXZ_CE_TERMINATE, 0); return 0; }
 	uint32_t fc = nxz_fc(j);
 	Slot *s = slot_acquire(c);
 	if (!s) { nxz_csb_complete(j, NXZ_CC_NO_HW, NXZ_CE_TERMINATE, 0); return 0; }

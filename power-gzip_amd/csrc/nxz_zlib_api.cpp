@@ -107,7 +107,8 @@ void init_once()
 }
 
 inline void init() { std::call_once(g_once, init_once); }
-inline bool want_nx(int mode) { return mode == MODE_NX || (mode == MODE_AUTO && g_engine); }
+// a forked child cannot use the parent's engine: its new streams go to software zlib
+inline bool want_nx(int mode) { return nxz_engine_usable() && (mode == MODE_NX || (mode == MODE_AUTO && g_engine)); }
 inline bool want_nx_def() { init(); return want_nx(g_mode_def); }
 inline bool want_nx_inf() { init(); return want_nx(g_mode_inf); }
 inline bool is_nx(z_streamp s, uint64_t magic) { return s && s->state && *(const uint64_t *)s->state == magic; }
@@ -207,7 +208,7 @@ EXPORT int compress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong so
 {
 	init();
 	nxz_stats_inc("compress");
-	bool nx = g_mode_def == MODE_NX || (g_mode_def == MODE_AUTO && g_engine && sourceLen > 1024);
+	bool nx = nxz_engine_usable() && (g_mode_def == MODE_NX || (g_mode_def == MODE_AUTO && g_engine && sourceLen > 1024));
 	if (nx) return nx_compress2(dest, destLen, source, sourceLen, level);
 	return sw.compress2 ? sw.compress2(dest, destLen, source, sourceLen, level) : Z_STREAM_ERROR;
 }
@@ -225,7 +226,7 @@ EXPORT int uncompress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong 
 {
 	init();
 	nxz_stats_inc("uncompress");
-	bool nx = g_mode_inf == MODE_NX || (g_mode_inf == MODE_AUTO && g_engine && *sourceLen > 1024);
+	bool nx = nxz_engine_usable() && (g_mode_inf == MODE_NX || (g_mode_inf == MODE_AUTO && g_engine && *sourceLen > 1024));
 	if (nx) return nx_uncompress2(dest, destLen, source, sourceLen);
 	if (sw.uncompress2) return sw.uncompress2(dest, destLen, source, sourceLen);
 	return sw.uncompress ? sw.uncompress(dest, destLen, source, *sourceLen) : Z_STREAM_ERROR;

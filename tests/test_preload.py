@@ -120,3 +120,56 @@ def test_mixed_mode_engine_deflate_software_inflate_with_statistics(tmp_path):
                           "c=zlib.compress(d,6);assert zlib.decompress(c)==d;sys.stdout.write(c[:3].hex())", str(f)],
                          env=env, check=True, capture_output=True, text=True).stdout
     assert (bytes.fromhex(out)[2] >> 1) & 3 == 1
+
+
+FORK_PROG = r'''
+import ctypes as C, os, sys, zlib
+sys.path.insert(0, sys.argv[2])
+import zstream as Z
+d = open(sys.argv[1], "rb").read()
+c1 = zlib.compress(d, 6)                      # parent: the engine (opens the HIP runtime)
+assert zlib.decompress(c1) == d
+r, w = os.pipe()
+pid = os.fork()
+if pid == 0:
+    rc = 1
+    try:
+        c2 = zlib.compress(d, 6)              # child: must not touch the parent's HIP state
+        ok = zlib.decompress(c2) == d and zlib.decompress(c1) == d
+        L = C.CDLL(sys.argv[3])               # the nx_* layer itself refuses cleanly instead of hanging
+        zs = Z.ZStream()
+        L.nx_deflateInit_.argtypes = [C.POINTER(Z.ZStream), C.c_int, C.c_char_p, C.c_int]
+        ok = ok and L.nx_deflateInit_(C.byref(zs), 6, b"1.2.11", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR
+        os.write(w, len(c2).to_bytes(8, "little") + c2)
+        rc = 0 if ok else 2
+    finally:
+        os._exit(rc)
+os.close(w)
+buf = b""
+while True:
+    b = os.read(r, 1 << 20)
+    if not b: break
+    buf += b
+_, st = os.waitpid(pid, 0)
+assert os.WIFEXITED(st) and os.WEXITSTATUS(st) == 0, st
+c3 = zlib.compress(d, 6)                      # parent: the engine still works
+assert c3 == c1
+n = int.from_bytes(buf[:8], "little")
+sys.stdout.write(buf[8:8 + n].hex() + " " + c1.hex())
+'''
+
+
+@pytest.mark.gpu
+def test_forked_child_falls_back_to_software(tmp_path):
+    # the HIP runtime does not survive fork(): the child's streams go to zlib (the reference re-opens
+    # its device in the child, lib/nx_zlib.c:529-551; test/test_pid_reuse.c forks with a window open)
+    data = ALICE_LIKE(150000, seed=9)
+    f = tmp_path / "in.bin"
+    f.write_bytes(data)
+    env = dict(os.environ, NX_GZIP_TYPE_SELECTOR="0", LD_PRELOAD=PRELOAD)
+    out = subprocess.run([sys.executable, "-c", FORK_PROG, str(f), os.path.join(ROOT, "tests"),
+                          os.path.join(ROOT, "power-gzip_amd", "libnxz_amd.so")],
+                         env=env, check=True, capture_output=True, text=True, timeout=300).stdout
+    child, parent = (bytes.fromhex(x) for x in out.split())
+    assert child == zlib.compress(data, 6)                   # the child's bytes are software zlib's
+    assert parent != child and zlib.decompress(parent) == data
