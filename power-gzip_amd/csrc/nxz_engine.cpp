@@ -77,10 +77,10 @@ struct nxz_ctx {
 };
 static constexpr unsigned JOB_COUNTERS = 256;
 // Batches of fewer streams than this go to the wave-per-stream inflate kernel: a stream per lane
-// takes 60-80 ms for 64 KiB streams however few there are, a stream per wave 3.7-4.4 ms per 768
-// streams (profiles/r01c_inflate_by_batch_size.txt); they cross at about 16 000 streams.  The wave kernel
+// takes 60-80 ms for 64 KiB streams however few there are, a stream per wave 3.7-4.4 ms per 1024
+// streams (profiles/r01c_inflate_by_batch_size.txt); they cross at about 24 000 streams.  The wave kernel
 // needs 16-byte aligned sources, as the batch interface demands.
-#define NXZ_LANES_MIN 16384
+#define NXZ_LANES_MIN 24576
 
 static std::mutex g_mtx;
 static nxz_ctx *g_ctx[64];

@@ -5,8 +5,8 @@
 // inc_nx/nxu.h:296-393, outputs :403-541, consumer lib/nx_inflate.c:1308-1609).
 // Same decisions as the CPU restatement oracle/nxz_inflate.c.
 //
-// One wavefront per stream (workgroup = 64 lanes, 43 KiB LDS -> 3 streams per
-// CU, 768 per chip): a deflate stream is serial by construction, so the
+// One wavefront per stream (workgroup = 64 lanes, 39.5 KiB LDS -> 4 streams per
+// CU, one per SIMD, 1024 per chip): a deflate stream is serial by construction, so the
 // symbol loop is wave-uniform and the lanes are used where there is width:
 //   - coalesced 16 B/lane staging of the compressed input into LDS
 //   - decode-table construction (lane per symbol)
@@ -42,7 +42,7 @@ __device__ unsigned long long *prof_buf = nullptr;
 
 constexpr uint32_t WIN = 32768, WMASK = WIN - 1;
 constexpr uint32_t FLUSH = 16384;
-constexpr uint32_t STAGE = 4096;             // staged compressed bytes
+constexpr uint32_t STAGE = 512;              // staged compressed bytes (one-token path and headers only)
 constexpr int LBITS = 11, DBITS = 9;
 
 struct Huff {
@@ -62,7 +62,6 @@ struct Smem {
 	Huff hl;
 	HuffD hd;
 	uint8_t lens[320];
-	uint32_t red[3 * 64];
 	uint32_t crctab[256];
 };
 
