@@ -252,6 +252,60 @@ def test_inflate_suspend_state_matches_oracle(eng, inflate_kernel):
             assert dio["dht"][i, :nb].tobytes() == bytes(st.out_dht)[:nb], i
 
 
+def test_damaged_streams_match_the_oracle(eng, inflate_kernel):
+    """Bit flips, byte swaps, cuts and garbage: both inflate kernels take the oracle's decision
+    (error code, or where the stream suspends and what was produced before), never write past the
+    target and never hang."""
+    import random
+    import torch
+    rnd = random.Random(11)
+    base = _zstreams()[:24]
+    cases = []
+    for k in range(420):
+        d, c = base[k % len(base)]
+        b = bytearray(c)
+        how = k % 5
+        if how == 0 and b:                                # one to three flipped bits
+            for _ in range(rnd.randrange(1, 4)):
+                i = rnd.randrange(len(b)); b[i] ^= 1 << rnd.randrange(8)
+        elif how == 1 and len(b) > 8:                     # a damaged header region
+            for i in range(rnd.randrange(1, 6)):
+                b[rnd.randrange(0, min(len(b), 48))] = rnd.randrange(256)
+        elif how == 2 and len(b) > 4:                     # cut and flipped
+            del b[rnd.randrange(1, len(b)):]
+            b[rnd.randrange(len(b))] ^= 0x40
+        elif how == 3:                                    # pure noise
+            b = bytearray(rnd.randbytes(rnd.randrange(1, 3000)))
+        elif b:                                           # a zeroed or saturated span
+            i = rnd.randrange(len(b)); n = rnd.randrange(1, 64)
+            b[i:i + n] = bytes([rnd.choice([0, 0xff])]) * len(b[i:i + n])
+        cases.append(bytes(b))
+    cap = 65536 + 4096                                    # damaged streams may also run long: CC 13 is a valid verdict
+    cstride = (max(map(len, cases)) + 31) & ~15
+    ostride = cap + 64
+    src = pack_blocks(eng, cases, cstride)
+    dst = torch.full((len(cases), ostride), 0xAA, dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, cstride, np.array([len(c) for c in cases], np.uint32), dst, ostride, cap)
+    r = eng.results_to_host(eng.decompress(jobs, len(cases)))
+    out = dst.cpu().numpy()
+    verdicts = {}
+    for i, c in enumerate(cases):
+        exp, st = O.inflate(c, cap)
+        assert (out[i, cap:] == 0xAA).all(), i           # nothing beyond the target
+        if st.err:
+            assert r["cc"][i] == st.err, (i, r["cc"][i], st.err)
+        else:
+            assert r["cc"][i] in (0, 3), (i, r["cc"][i])
+            assert r["tpbc"][i] == st.tpbc and out[i, :st.tpbc].tobytes() == exp, i
+            subc = st.out_subc
+            if st.final_eob and subc > 0xfff8:            # SUBC is a 16-bit field: whole excess bytes stay unread
+                subc -= 8 * ((subc - 0xfff8 + 7) // 8)
+            assert (r["sfbt"][i] & 0xf) == st.out_sfbt and r["subc"][i] == subc, i
+            assert bool(r["sfbt"][i] & 0x100) == bool(st.final_eob), i
+        verdicts[int(r["cc"][i])] = verdicts.get(int(r["cc"][i]), 0) + 1
+    assert len(verdicts) >= 4, verdicts                   # the set really exercises the error paths
+
+
 def test_inflate_resume_chain(eng):
     """feed a stream in pieces through resume jobs with history, like lib/nx_inflate.c:1464-1609 does."""
     import torch
