@@ -76,11 +76,14 @@ struct nxz_ctx {
 	unsigned next_counter = 0;
 };
 static constexpr unsigned JOB_COUNTERS = 256;
-// Batches of fewer streams than this go to the wave-per-stream inflate kernel: a stream per lane
-// takes 60-80 ms for 64 KiB streams however few there are, a stream per wave 3.7-4.4 ms per 1024
-// streams (profiles/r01c_inflate_by_batch_size.txt); they cross at about 24 000 streams.  The wave kernel
-// needs 16-byte aligned sources, as the batch interface demands.
-#define NXZ_LANES_MIN 24576
+// Which inflate kernel a batch gets (profiles/r01c_inflate_by_batch_size.txt, 64 KiB streams):
+//   up to NXZ_WINDOW_LDS_MAX streams   a stream per wave, window in LDS (4 per CU): 3.7-4.4 ms a round
+//   below NXZ_LANES_MIN streams        a stream per wave, the target as window (20 per CU): 7.5 ms for
+//                                      4096 streams, 40 GiB/s at 65 536
+//   from NXZ_LANES_MIN streams on      a stream per lane: 60-80 ms however few streams, 80 GiB/s at 262 144
+// The wave kernels need 16-byte aligned sources, as the batch interface demands.
+#define NXZ_LANES_MIN 81920
+#define NXZ_WINDOW_LDS_MAX 1024
 
 static std::mutex g_mtx;
 static nxz_ctx *g_ctx[64];
@@ -253,7 +256,9 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 		}
 		rc = nxz_launch_inflate_lanes(jobs, n, results, dht_io, ws, init, s);
 	} else {
-		rc = nxz_launch_inflate(jobs, n, results, dht_io, s);
+		const char *wm = getenv("NXZ_INFLATE_LDS_MAX");                 // tuning / test knob
+		const size_t lds_max = wm ? (size_t)strtoull(wm, nullptr, 0) : (size_t)NXZ_WINDOW_LDS_MAX;
+		rc = nxz_launch_inflate(jobs, n, results, dht_io, n <= lds_max, s);
 	}
 	if (rc) { set_err("inflate launch", (hipError_t)rc); return -EIO; }
 	return 0;
@@ -581,7 +586,7 @@ static int run_decompress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 	}
 	HIPCHK(hipMemcpyAsync(s->d_in, s->h_in, got, hipMemcpyHostToDevice, s->stream), return -EIO);
 	HIPCHK(hipMemcpyAsync(s->d_job, bj, sizeof(*bj), hipMemcpyHostToDevice, s->stream), return -EIO);
-	if (nxz_launch_inflate(s->d_job, 1, s->d_res, s->d_dht, s->stream)) return -EIO;
+	if (nxz_launch_inflate(s->d_job, 1, s->d_res, s->d_dht, 1, s->stream)) return -EIO;
 	HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
 	HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
 	nxz_batch_result_t r = *s->h_res;

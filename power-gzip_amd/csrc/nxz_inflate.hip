@@ -56,8 +56,11 @@ struct HuffD {
 	uint16_t count[16];
 };
 
-struct Smem {
-	uint8_t win[WIN];
+// GW: the window is the target itself (and the history in front of the source) in global memory,
+// for batches: 7.6 KiB of LDS per stream instead of 39.5, so 16 streams per CU instead of 4.
+template <bool GW>
+struct SmemT {
+	uint8_t win[GW ? 16 : WIN];
 	uint32_t stage[STAGE / 4 + 4];
 	Huff hl;
 	HuffD hd;
@@ -218,6 +221,7 @@ __device__ __forceinline__ int decode_sym(const H &h, uint32_t bits, uint32_t &n
 
 // Parse a dynamic block header at b.pos (after the 3 header bits).  Returns
 // 0 ok (lens filled, b.pos advanced, *tbits = table bits), 1 out of source, <0 invalid.
+template <typename Smem>
 __device__ __forceinline__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist, uint32_t &tbits)
 {
 	const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
@@ -283,11 +287,12 @@ __device__ __forceinline__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist
 }
 
 // job.resume: rembytecnt | sfbt << 16 | subc << 20.  results: tebc field carries out_rembytecnt.
+template <bool GW>
 __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__restrict__ jobs,
 						     nxz_batch_result_t *__restrict__ results,
 						     nxz_batch_dht_t *__restrict__ dht_io)
 {
-	__shared__ __attribute__((aligned(16))) Smem sm;
+	__shared__ __attribute__((aligned(16))) SmemT<GW> sm;
 	const int lane = threadIdx.x;
 	const nxz_batch_job_t job = jobs[blockIdx.x];
 	const uint32_t hist = job.hist_len < job.src_len ? job.hist_len : job.src_len;
@@ -295,6 +300,14 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	const uint8_t *src = job.src + hist;
 	uint8_t *dst = job.dst;
 	const uint32_t cap = job.dst_cap;
+	// window access: position p counts output bytes, negative positions (as uint32) are history
+	const uint8_t *hist_end = job.src + hist;
+	auto wr = [&](uint32_t p, uint32_t v) { if (GW) dst[p] = (uint8_t)v; else sm.win[p & WMASK] = (uint8_t)v; };
+	uint32_t out = 0, flushed = 0;             // bytes produced / bytes already written to dst
+	auto rd = [&](uint32_t p) -> uint32_t {    // p is 1..32768 bytes behind `out`
+		if (GW) { const uint32_t back = out - p; return back > out ? hist_end[-(ptrdiff_t)(back - out)] : dst[p]; }
+		return sm.win[p & WMASK];
+	};
 #ifdef NXZ_INFLATE_PROF
 	unsigned long long *prof = prof_buf;
 	unsigned long long tprev = prof ? clock64() : 0;
@@ -310,7 +323,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	{
 		uint32_t h = hist > WIN ? WIN : hist;
 		const uint8_t *hp = job.src + (hist - h);
-		for (uint32_t i = lane; i < h; i += 64) sm.win[(0u - h + i) & WMASK] = hp[i];
+		if (!GW) for (uint32_t i = lane; i < h; i += 64) sm.win[(0u - h + i) & WMASK] = hp[i];
 	}
 	__syncthreads();
 
@@ -320,7 +333,6 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	uint32_t in_subc = (job.resume >> 20) & 7, in_sfbt = (job.resume >> 16) & 15, in_rem = job.resume & 0xffff;
 	if (srclen && in_subc) b.pos = 8 - in_subc;
 
-	uint32_t out = 0, flushed = 0;             // bytes produced / bytes already written to dst
 	uint32_t crc_state = job.in_crc ^ 0xffffffffu;
 	uint32_t ad1 = job.in_adler & 0xffff, ad2 = job.in_adler >> 16;
 	int state = 0;                             // 0 header, 1 stored, 2 coded
@@ -331,6 +343,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	// flush window bytes [flushed, upto) to dst and fold them into the checksums
 	auto flush = [&](uint32_t upto) {
 		IPROF(0);
+		if (GW) { flushed = upto; return; }              // the bytes are in place; nxzl::cksum_kernel sums them afterwards
 		while (flushed < upto) {
 			uint32_t n = upto - flushed < FLUSH ? upto - flushed : FLUSH;
 			// right-aligned frame of 64 x 256 B slices
@@ -471,7 +484,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			while (n) {
 				uint32_t room = FLUSH - (out - flushed);
 				uint32_t k = n < room ? n : room;
-				for (uint32_t i = lane; i < k; i += 64) sm.win[(out + i) & WMASK] = src[sp + i];
+				for (uint32_t i = lane; i < k; i += 64) wr(out + i, src[sp + i]);
 				out += k; sp += k; n -= k; rem -= k;
 				__syncthreads();
 				if (out - flushed == FLUSH) flush(out);
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 						if (nlit > cap - out) break;                                // target nearly full: one-token path
 						if ((starts >> lane) & 1) {
 							const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0));
-							sm.win[(out + rank) & WMASK] = (uint8_t)el;
+							wr(out + rank, el);
 						}
 						out += nlit; off = o;
 						if (off > 47 || out - flushed >= FLUSH) break;
@@ -553,9 +566,9 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 					const uint32_t dist = dbase + (bits_at(o3) & ((1u << ebd) - 1));
 					if (dist > out + hist || dist > WIN || len > cap - out) break;
 					if (dist >= len) {
-						for (uint32_t i = lane; i < len; i += 64) sm.win[(out + i) & WMASK] = sm.win[(out - dist + i) & WMASK];
+						for (uint32_t i = lane; i < len; i += 64) wr(out + i, rd(out - dist + i));
 					} else {
-						for (uint32_t i = lane; i < len; i += 64) sm.win[(out + i) & WMASK] = sm.win[(out - dist + i % dist) & WMASK];
+						for (uint32_t i = lane; i < len; i += 64) wr(out + i, rd(out - dist + i % dist));
 					}
 					out += len; off = o3 + ebd;                                 // <= 63 + 9 + 13 < 96
 					if (off > 47 || out - flushed >= FLUSH) break;
@@ -582,7 +595,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			b.bb_drop(nb);
 			if (sym < 256) {
 				if (out >= cap) { cc = NXZ_CC_TARGET_SPACE; break; }
-				if (lane == 0) sm.win[out & WMASK] = (uint8_t)sym;
+				if (lane == 0) wr(out, (uint32_t)sym);
 				out++;
 			} else if (sym == 256) {
 				if (bfinal) { final_eob = true; break; }
@@ -616,7 +629,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 				// lane per byte; source pattern repeats with period dist
 				for (uint32_t i = lane; i < len; i += 64) {
 					uint32_t k = dist >= len ? i : i % dist;
-					sm.win[(out + i) & WMASK] = sm.win[(out - dist + k) & WMASK];
+					wr(out + i, rd(out - dist + k));
 				}
 				out += len;
 			}
@@ -654,10 +667,18 @@ extern "C" int nxz_inflate_prof_set(unsigned long long *buf)
 	return (int)hipMemcpyToSymbol(HIP_SYMBOL(nxzi::prof_buf), &buf, sizeof(buf));
 }
 
+// window_in_lds != 0: the 39.5 KiB variant (4 streams per CU, matches never leave LDS: the lower latency
+// for one job or one round of jobs); 0: the window is the target itself (16 streams per CU), checksums
+// by nxzl::cksum_kernel afterwards.
 extern "C" int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
-				  nxz_batch_dht_t *dht_io, hipStream_t stream)
+				  nxz_batch_dht_t *dht_io, int window_in_lds, hipStream_t stream)
 {
 	if (!n) return 0;
-	hipLaunchKernelGGL(nxzi::inflate_kernel, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
-	return (int)hipGetLastError();
+	if (window_in_lds) {
+		hipLaunchKernelGGL(nxzi::inflate_kernel<false>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
+		return (int)hipGetLastError();
+	}
+	hipLaunchKernelGGL(nxzi::inflate_kernel<true>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
+	int rc = (int)hipGetLastError();
+	return rc ? rc : nxz_launch_cksum(jobs, n, results, stream);
 }

@@ -588,6 +588,13 @@ extern "C" size_t nxz_inflate_lanes_workspace(size_t n)
 	return (grid * 64 + 1) * nxzl::WS_BYTES;
 }
 
+extern "C" int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL(nxzl::cksum_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
+	return (int)hipGetLastError();
+}
+
 extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 					nxz_batch_dht_t *dht_io, uint8_t *workspace, int init_fixed, hipStream_t stream)
 {

@@ -32,12 +32,17 @@ def eng():
     os.environ.pop("NXZ_INFLATE_LANES_MIN", None)
 
 
-@pytest.fixture(params=["lanes", "waves"])
+@pytest.fixture(params=["lanes", "waves", "waves-global-window"])
 def inflate_kernel(request):
+    """the three inflate kernels: a stream per lane, a stream per wave with its window in LDS, and
+    with the target buffer as its window (what mid-size batches get)"""
     old = os.environ.get("NXZ_INFLATE_LANES_MIN")
     os.environ["NXZ_INFLATE_LANES_MIN"] = "32" if request.param == "lanes" else "1000000000"
+    if request.param == "waves-global-window":
+        os.environ["NXZ_INFLATE_LDS_MAX"] = "0"
     yield request.param
     os.environ["NXZ_INFLATE_LANES_MIN"] = old if old is not None else "32"
+    os.environ.pop("NXZ_INFLATE_LDS_MAX", None)
 
 
 def pack_blocks(eng, blocks, stride):
@@ -306,7 +311,7 @@ def test_damaged_streams_match_the_oracle(eng, inflate_kernel):
     assert len(verdicts) >= 4, verdicts                   # the set really exercises the error paths
 
 
-def test_inflate_resume_chain(eng):
+def test_inflate_resume_chain(eng, inflate_kernel):
     """feed a stream in pieces through resume jobs with history, like lib/nx_inflate.c:1464-1609 does."""
     import torch
     d, c = _zstreams()[-1]

@@ -42,6 +42,9 @@ for n in (32, 128, 512, 1024, 2048, 4096, 8192, 16384, 65536):
         out.append("%s %7.2f GiB/s (%7.2f ms)" % (name, n * 65536 / dt / 2**30, dt * 1e3))
     print("%6d streams: %s" % (n, "   ".join(out)), flush=True)
 '''
-for label, thr in (("a stream per lane", "1"), ("a stream per wave", "1000000000")):
+for label, thr, lds in (("a stream per lane", "1", "0"), ("a stream per wave, window in LDS", "1000000000", "1000000000"),
+                        ("a stream per wave, the target as window", "1000000000", "0")):
+    if len(sys.argv) > 1 and sys.argv[1] not in label:
+        continue
     print("--- " + label, flush=True)
-    subprocess.run([sys.executable, "-c", CHILD, ROOT], env=dict(os.environ, NXZ_INFLATE_LANES_MIN=thr), check=True)
+    subprocess.run([sys.executable, "-c", CHILD, ROOT], env=dict(os.environ, NXZ_INFLATE_LANES_MIN=thr, NXZ_INFLATE_LDS_MAX=lds), check=True)
