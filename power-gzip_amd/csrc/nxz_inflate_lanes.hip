@@ -18,7 +18,7 @@
 
 namespace nxzl {
 
-constexpr int LB = 10, DB = 8;                       // fast-table index bits
+constexpr int LB = 9, DB = 7;                        // fast-table index bits
 constexpr uint32_t WS_LIT = 0, WS_DIST = 2048, WS_LCNT = 2560, WS_LSYM = 2592, WS_DCNT = 3168, WS_DSYM = 3200;
 constexpr uint32_t WS_LENS = 320;                     // code lengths of the block being set up (last part of a slot)
 constexpr uint32_t WS_BYTES = 3328 + WS_LENS;
