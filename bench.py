@@ -309,7 +309,7 @@ def main():
             raise SystemExit("ROUND TRIP FAILURE at full size (inflate of the deflate output != source)")
         inflate_info = {"value": round(float(n) * BLOCK / (inf_ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out",
                         "ms_per_pass": round(inf_ms, 3), "kernel": "nxzl::inflate_lanes_kernel + cksum_kernel",
-                        "roundtrip_bit_exact": True}
+                        "scope": "one GPU (rank 0)", "roundtrip_bit_exact": True}
         del back
     u_bytes = float(n) * BLOCK
     c_bytes = float(res["tpbc"].astype(np.float64).sum())
