@@ -249,6 +249,19 @@ def test_cli_round_trips_and_reads_ordinary_gzip(tmp_path):
     # blocked members followed by an ordinary one
     r4 = run_cli(["-dc"], stdin=r.stdout[:-28] + gzip.compress(b"tail"))
     assert r4.returncode == 0 and r4.stdout == data[:300000] + b"tail"
+    # an empty input is one empty member (the end marker) and comes back empty
+    e = run_cli(["-c"], stdin=b"")
+    assert e.returncode == 0 and e.stdout == EOF_MARKER and gzip.decompress(e.stdout) == b""
+    e2 = run_cli(["-dc"], stdin=e.stdout)
+    assert e2.returncode == 0 and e2.stdout == b""
+    # several files in one call
+    a, b = tmp_path / "a.txt", tmp_path / "b.txt"
+    a.write_bytes(data[:70000]); b.write_bytes(data[70000:70001])
+    assert run_cli([str(a), str(b)]).returncode == 0
+    assert gzip.decompress((tmp_path / "a.txt.gz").read_bytes()) == data[:70000]
+    assert gzip.decompress((tmp_path / "b.txt.gz").read_bytes()) == data[70000:70001]
+    assert run_cli(["-d", str(tmp_path / "a.txt.gz"), str(tmp_path / "b.txt.gz")]).returncode == 0
+    assert a.read_bytes() == data[:70000] and b.read_bytes() == data[70000:70001]
     # damage is reported
     bad = bytearray(image)
     bad[5000] ^= 1
