@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr uint32_t MEMBER_HDR = 18, MEMBER_OVERHEAD = 26;
+constexpr uint32_t MEMBER_OVERHEAD = 26;       // 18-byte header with the BC subfield + CRC32 + ISIZE
 
 struct Ctx {
 	nxz_ctx_t *c = nullptr;
@@ -245,7 +245,6 @@ struct InflateSet : Set {
 	nxz_batch_job_t *h_jobs = nullptr, *d_jobs = nullptr;
 	nxz_batch_result_t *d_res = nullptr, *h_res = nullptr;
 	size_t first = 0, n = 0;
-	uint64_t out_bytes = 0;
 };
 
 } // namespace
@@ -319,7 +318,7 @@ extern "C" int nxz_blocked_inflate(const void *src_, size_t len, const nxz_block
 			in += up16(m.paylen) + 16; out += up16(m.isize);
 		}
 		t_stage.out();
-		S.first = first; S.n = jobs; S.out_bytes = out;
+		S.first = first; S.n = jobs;
 		if (!jobs) return 0;
 		int rc = nxz_copy_to_device(ctx.c, S.d_in, S.h_in, in, S.stream);
 		if (!rc) rc = nxz_copy_to_device(ctx.c, S.d_jobs, S.h_jobs, jobs * sizeof(nxz_batch_job_t), S.stream);
@@ -338,13 +337,11 @@ extern "C" int nxz_blocked_inflate(const void *src_, size_t len, const nxz_block
 		if (rc) return rc;
 		t_sink.in();
 		struct Done { Phase &p; ~Done() { p.out(); } } done{t_sink};
-		size_t out = 0;
 		for (size_t q = 0; q < jobs; q++) {
 			const Member &m = mem[S.first + S.h_jobs[q].reserved];
 			const nxz_batch_result_t &r = S.h_res[q];
 			// the whole payload is one deflate stream that ends with its final block
 			if (r.cc != 0 || !(r.sfbt & 0x100) || r.tpbc != m.isize || r.crc != m.crc) return -EILSEQ;
-			out += up16(m.isize);
 		}
 		// runs of outputs that sit back to back (blocks of a multiple of 16 bytes) go out in one piece
 		size_t pos = 0, run0 = 0, runlen = 0;
@@ -355,7 +352,6 @@ extern "C" int nxz_blocked_inflate(const void *src_, size_t len, const nxz_block
 			pos += up16(isize);
 		}
 		if (runlen && sink(user, S.h_out + run0, runlen)) return -EIO;
-		(void)out;
 		return 0;
 	};
 
