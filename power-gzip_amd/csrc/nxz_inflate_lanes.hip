@@ -119,9 +119,13 @@ __global__ __launch_bounds__(64, 4) void inflate_lanes_kernel(const nxz_batch_jo
 							   nxz_batch_dht_t *__restrict__ dht_io,
 							   uint8_t *__restrict__ workspace, const uint8_t *__restrict__ fixed_ws)
 {
-	__shared__ uint8_t lens_s[320];
+	__shared__ __attribute__((aligned(16))) uint8_t lens_s[320];
 	const int lane = threadIdx.x;
-	uint8_t *myws = workspace + ((size_t)blockIdx.x * 64 + lane + 1) * WS_BYTES;   // slot 0 = fixed tables
+	// slot 0 = fixed tables; then 65 slots per wave: one per lane and a spare that lanes with identical
+	// dynamic tables share (blocks compressed with one table, as this engine and the reference's table
+	// reuse produce them: one construction instead of 64, and lookups that hit the same cache lines)
+	uint8_t *myws = workspace + ((size_t)blockIdx.x * 65 + lane + 1) * WS_BYTES;
+	uint8_t *shared_ws = workspace + ((size_t)blockIdx.x * 65 + 64 + 1) * WS_BYTES;
 
 	for (size_t g = blockIdx.x; g * 64 < n; g += gridDim.x) {
 		const size_t jid = g * 64 + lane;
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(64, 4) void inflate_lanes_kernel(const nxz_batch_jo
 		Tab T = tab_at(fixed_ws);
 		uint64_t tstart = 0;                                     // where the dynamic table bits start
 		bool table_from_slot = false;
+		bool using_shared = false;                               // T is the wave's spare slot
 
 		if (active && (in_sfbt & 8)) {
 			uint32_t kind = (in_sfbt >> 1) & 7;
@@ -271,23 +276,42 @@ __global__ __launch_bounds__(64, 4) void inflate_lanes_kernel(const nxz_batch_jo
 				const int owner = __builtin_ctzll(need);
 				need &= need - 1;
 				const int orc = __shfl(rc, owner, 64), ohlit = __shfl(hlit, owner, 64), ohdist = __shfl(hdist, owner, 64);
-				uint8_t *ows = workspace + ((size_t)blockIdx.x * 64 + owner + 1) * WS_BYTES;
+				uint8_t *ows = workspace + ((size_t)blockIdx.x * 65 + owner + 1) * WS_BYTES;
+				uint8_t *target = ows;
+				unsigned long long sharers = 0;
 				if (orc == 0) {
 					const uint8_t *olens = ows + WS_BYTES - WS_LENS;
 					__syncthreads();
 					for (int i = lane; i < ohlit + ohdist; i += 64) lens_s[i] = olens[i];
 					__syncthreads();
-					build_tables(ows, lens_s, ohlit, ohdist, lane);
+					// waiting lanes whose code lengths equal the owner's take the same table: built once, into
+					// the spare slot, when no lane is still decoding with what that slot held before
+					bool same = state == 4 && lane != owner && ((need >> lane) & 1) && rc == 0 && hlit == ohlit && hdist == ohdist;
+					if (same) {
+						const uint32_t nl = (uint32_t)(ohlit + ohdist);
+						const uint8_t *mine = myws + WS_BYTES - WS_LENS;
+						const uint32_t *a = (const uint32_t *)mine, *q = (const uint32_t *)lens_s;
+						for (uint32_t i = 0; same && i < nl / 4; i++) same = a[i] == q[i];
+						for (uint32_t i = nl & ~3u; same && i < nl; i++) same = mine[i] == lens_s[i];
+					}
+					sharers = __ballot(same);
+					const bool spare_busy = __ballot(using_shared && state == 2) != 0;
+					if (sharers && !spare_busy) target = shared_ws; else sharers = 0;
+					build_tables(target, lens_s, ohlit, ohdist, lane);
 				}
 				__syncthreads();
 				if (lane == owner) {
-					if (orc == 0) { T = tab_at(myws); state = 2; }
+					if (orc == 0) { T = tab_at(target); using_shared = target == shared_ws; state = 2; }
 					else if (orc == 1 && !table_from_slot) {       // ran out of source inside the header
 						uint64_t hdr = tstart - 3;
 						o_sfbt = 0xe | bfinal; o_subc = (uint32_t)(b.total() - hdr); state = 3;
 					} else { cc = NXZ_CC_INVALID_DHT; state = 3; }
 					table_from_slot = false;
+				} else if ((sharers >> lane) & 1) {
+					T = tab_at(target); using_shared = true; state = 2;
+					table_from_slot = false;
 				}
+				need &= ~sharers;
 			}
 			if (!__any(state != 3)) break;
 
@@ -305,7 +329,7 @@ __global__ __launch_bounds__(64, 4) void inflate_lanes_kernel(const nxz_batch_jo
 						uint32_t lo = b.take(16), hi = b.take(16);
 						if ((lo ^ hi) != 0xffff) { cc = NXZ_CC_INVALID_DHT; state = 3; break; }
 						rem = lo; state = 1;
-					} else if (btype == 1) { T = tab_at(fixed_ws); state = 2; }
+					} else if (btype == 1) { T = tab_at(fixed_ws); using_shared = false; state = 2; }
 					else if (btype == 2) { state = 4; }
 					else { cc = NXZ_CC_INVALID_DHT; state = 3; }
 				} else if (state == 1) {
@@ -585,7 +609,7 @@ extern "C" size_t nxz_inflate_lanes_workspace(size_t n)
 {
 	size_t groups = (n + 63) / 64;
 	size_t grid = groups < NXZ_LANES_MAX_GRID ? groups : NXZ_LANES_MAX_GRID;
-	return (grid * 64 + 1) * nxzl::WS_BYTES;
+	return (grid * 65 + 1) * nxzl::WS_BYTES;
 }
 
 extern "C" int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream)

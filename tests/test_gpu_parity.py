@@ -311,6 +311,39 @@ def test_damaged_streams_match_the_oracle(eng, inflate_kernel):
     assert len(verdicts) >= 4, verdicts                   # the set really exercises the error paths
 
 
+def test_lanes_with_equal_tables_share_one_and_others_do_not(eng, inflate_kernel):
+    """Streams with identical dynamic tables sit next to streams with other tables and with several
+    dynamic blocks each (the wave's spare table slot is taken, busy, free again): every output is its
+    own stream's data."""
+    import torch
+    datas = [make_block(k, 65536, seed=400 + i) for i, k in enumerate(("alice", "lz", "text33", "alice"))]
+    whole = []
+    for d in datas:
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        whole.append(co.compress(d) + co.flush())
+    pieces = []
+    for d in datas[:2]:                                   # three dynamic blocks per stream
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        pieces.append(co.compress(d[:20000]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(d[20000:45000]) +
+                      co.flush(zlib.Z_SYNC_FLUSH) + co.compress(d[45000:]) + co.flush())
+    streams = []
+    for i in range(64 * 5 + 17):                          # the last wave is not full
+        k = (i * 7 + i // 64) % 6
+        streams.append((datas[k], whole[k]) if k < 4 else (datas[k - 4], pieces[k - 4]))
+    streams[64:128] = [(datas[0], whole[0])] * 64         # a wave whose lanes all hold the same table
+    cstride = (max(len(c) for _, c in streams) + 31) & ~15
+    src = pack_blocks(eng, [c for _, c in streams], cstride)
+    dst = torch.zeros((len(streams), 65536), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, cstride, np.array([len(c) for _, c in streams], np.uint32), dst, 65536, 65536)
+    for rep in range(2):
+        r = eng.results_to_host(eng.decompress(jobs, len(streams)))
+        out = dst.cpu().numpy()
+        for i, (d, c) in enumerate(streams):
+            assert r["cc"][i] == 0 and r["tpbc"][i] == 65536 and r["crc"][i] == zlib.crc32(d), i
+            assert out[i].tobytes() == d, i
+        dst.zero_()
+
+
 def test_inflate_resume_chain(eng, inflate_kernel):
     """feed a stream in pieces through resume jobs with history, like lib/nx_inflate.c:1464-1609 does."""
     import torch
