@@ -49,6 +49,23 @@ __device__ __forceinline__ int decode(const uint16_t *fast, const uint16_t *cnt,
 	return -2;
 }
 
+// The fixed code (RFC1951 3.2.6) needs no table: the symbol follows from the first 9 bits by
+// arithmetic, which takes the lookup (and its latency) out of every token of a type-1 block.
+__device__ __forceinline__ int decode_fixed_ll(uint32_t bits, uint32_t &nb)
+{
+	const uint32_t r9 = __builtin_bitreverse32(bits) >> 23;       // the first 9 bits, first bit most significant
+	const uint32_t r8 = r9 >> 1, r7 = r9 >> 2;
+	const bool a = r7 < 24, b8 = r8 < 0xC0, c = r8 < 0xC8;         // 7-bit lengths 256..279 | literals 0..143 | 280..287 | literals 144..255
+	nb = a ? 7 : c ? 8 : 9;
+	return (int)(a ? 256 + r7 : b8 ? r8 - 0x30 : c ? 280 + (r8 - 0xC0) : 144 + (r9 - 0x190));
+}
+__device__ __forceinline__ int decode_fixed_d(uint32_t bits, uint32_t &nb)
+{
+	const uint32_t d = __builtin_bitreverse32(bits) >> 27;        // 5 bits; 30 and 31 are no codes: same answer as the
+	nb = d < 30 ? 5 : 16;                                         // table walk gives for them (decode() above)
+	return d < 30 ? (int)d : -2;
+}
+
 __device__ __forceinline__ void len_params(uint32_t s, uint32_t &base, uint32_t &extra)
 {
 	extra = s < 8 || s == 28 ? 0 : (s - 4) >> 2;
@@ -348,7 +365,7 @@ __global__ __launch_bounds__(64, 4) void inflate_lanes_kernel(const nxz_batch_jo
 					const uint32_t sfbt = (btype == 1 ? 0xa : 0xc) | bfinal;
 					uint32_t nb;
 					b.fill();
-					int sym = decode<LB>(T.lit, T.lcnt, T.lsym, (uint32_t)b.bb, nb);
+					int sym = btype == 1 ? decode_fixed_ll((uint32_t)b.bb, nb) : decode<LB>(T.lit, T.lcnt, T.lsym, (uint32_t)b.bb, nb);
 					if (sym < 0 || !b.have(nb)) {
 						if (!b.have(sym < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); }
 						else cc = NXZ_CC_MISSING_CODE;
@@ -371,7 +388,7 @@ __global__ __launch_bounds__(64, 4) void inflate_lanes_kernel(const nxz_batch_jo
 						uint32_t len = lbase + ((uint32_t)b.bb & ((1u << eb) - 1));
 						b.drop(eb);
 						b.fill();
-						int ds = decode<DB>(T.dist, T.dcnt, T.dsym, (uint32_t)b.bb, nb);
+						int ds = btype == 1 ? decode_fixed_d((uint32_t)b.bb, nb) : decode<DB>(T.dist, T.dcnt, T.dsym, (uint32_t)b.bb, nb);
 						if (ds < 0 || !b.have(nb)) {
 							if (!b.have(ds < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); }
 							else cc = NXZ_CC_INVALID_DIST;
