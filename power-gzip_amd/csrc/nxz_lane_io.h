@@ -110,7 +110,22 @@ struct OutWr {
 				const uint32_t *sw = (const uint32_t *)(sa & ~(uintptr_t)3);
 				const uint32_t bo = (uint32_t)sa & 3;
 				uint32_t lo = sw[0];
-				for (uint32_t k = 1; i + 4 <= len; i += 4, k++) {
+				uint32_t k = 1;
+				// a source at least 20 bytes behind: four loads in flight per wait instead of one
+				if (dist >= 20) {
+					for (; i + 16 <= len; i += 16, k += 4) {
+						const uint32_t a = sw[k], b = sw[k + 1], c = sw[k + 2], e = sw[k + 3];
+						uint32_t *o = (uint32_t *)(d + i);
+						if (bo) {
+							o[0] = NXZ_LANE_ALIGNBYTE(a, lo, bo); o[1] = NXZ_LANE_ALIGNBYTE(b, a, bo);
+							o[2] = NXZ_LANE_ALIGNBYTE(c, b, bo); o[3] = NXZ_LANE_ALIGNBYTE(e, c, bo);
+						} else {
+							o[0] = lo; o[1] = a; o[2] = b; o[3] = c;
+						}
+						lo = e;
+					}
+				}
+				for (; i + 4 <= len; i += 4, k++) {
 					uint32_t v = lo;
 					if (bo) { const uint32_t hi = sw[k]; v = NXZ_LANE_ALIGNBYTE(hi, lo, bo); lo = hi; }
 					*(uint32_t *)(d + i) = v;
