@@ -111,7 +111,22 @@ struct OutWr {
 				const uint32_t bo = (uint32_t)sa & 3;
 				uint32_t lo = sw[0];
 				uint32_t k = 1;
-				// a source at least 20 bytes behind: four loads in flight per wait instead of one
+				// a source at least 36 / 20 bytes behind: eight / four loads in flight per wait instead of one
+				if (dist >= 36) {
+					for (; i + 32 <= len; i += 32, k += 8) {
+						uint32_t w[8];
+						for (int j = 0; j < 8; j++) w[j] = sw[k + j];
+						uint32_t *o = (uint32_t *)(d + i);
+						if (bo) {
+							o[0] = NXZ_LANE_ALIGNBYTE(w[0], lo, bo);
+							for (int j = 1; j < 8; j++) o[j] = NXZ_LANE_ALIGNBYTE(w[j], w[j - 1], bo);
+						} else {
+							o[0] = lo;
+							for (int j = 1; j < 8; j++) o[j] = w[j - 1];
+						}
+						lo = w[7];
+					}
+				}
 				if (dist >= 20) {
 					for (; i + 16 <= len; i += 16, k += 4) {
 						const uint32_t a = sw[k], b = sw[k + 1], c = sw[k + 2], e = sw[k + 3];
