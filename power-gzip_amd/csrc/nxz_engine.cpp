@@ -80,9 +80,10 @@ static constexpr unsigned JOB_COUNTERS = 256;
 //   up to NXZ_WINDOW_LDS_MAX streams   a stream per wave, window in LDS (4 per CU): 3.7-4.4 ms a round
 //   below NXZ_LANES_MIN streams        a stream per wave, the target as window (20 per CU): 7.5 ms for
 //                                      4096 streams, 40 GiB/s at 65 536
-//   from NXZ_LANES_MIN streams on      a stream per lane: 60-80 ms however few streams, 80 GiB/s at 262 144
+//   from NXZ_LANES_MIN streams on      a stream per lane: 55-60 ms however few streams, 51 GiB/s at 65 536,
+//                                      110 at 262 144
 // The wave kernels need 16-byte aligned sources, as the batch interface demands.
-#define NXZ_LANES_MIN 81920
+#define NXZ_LANES_MIN 57344
 #define NXZ_WINDOW_LDS_MAX 1024
 
 static std::mutex g_mtx;

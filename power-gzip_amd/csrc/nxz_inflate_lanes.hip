@@ -355,8 +355,8 @@ __global__ __launch_bounds__(64, 4) void inflate_lanes_kernel(const nxz_batch_jo
 					uint32_t k = rem < srcleft ? rem : srcleft;
 					if (k > cap - w.out) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
 					w.flush();
-					for (uint32_t i = 0; i < k; i++) dst[w.out + i] = b.src[sp + i];
-					w.out += k; rem -= k; b.pos = (uint64_t)(sp + k) * 8; b.sync();
+					w.copy_in(b.src + sp, k);
+					rem -= k; b.pos = (uint64_t)(sp + k) * 8; b.sync();
 					if (rem) { o_sfbt = 0x8 | bfinal; o_subc = 0; o_rem = rem; state = 3; break; }
 					if (bfinal) { final_eob = true; state = 3; break; }
 					state = 0;

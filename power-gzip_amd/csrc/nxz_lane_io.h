@@ -96,6 +96,48 @@ struct OutWr {
 		const uint32_t lo = NXZ_LANE_ALIGNBYTE(w1, w0, bo), hi = NXZ_LANE_ALIGNBYTE(w2, w1, bo);
 		append(((uint64_t)hi << 32) | lo, len);
 	}
+	// append n bytes of another buffer (stored blocks), pending bytes flushed by the caller: dword
+	// stores once the destination is aligned, the source dwords from aligned loads, eight in flight
+	NXZ_LANE_FN void copy_in(const uint8_t *s, uint32_t n)
+	{
+		uint8_t *d = dst + out;
+		uint32_t i = 0;
+		if (al && n >= 8) {
+			for (; (out + i) & 3; i++) d[i] = s[i];
+			const uintptr_t sa = (uintptr_t)(s + i);
+			const uint32_t *sw = (const uint32_t *)(sa & ~(uintptr_t)3);
+			const uint32_t bo = (uint32_t)sa & 3;
+			uint32_t k = 0;
+			if (bo == 0) {
+				for (; i + 32 <= n; i += 32, k += 8) {
+					uint32_t w[8];
+					for (int j = 0; j < 8; j++) w[j] = sw[k + j];
+					for (int j = 0; j < 8; j++) ((uint32_t *)(d + i))[j] = w[j];
+				}
+				for (; i + 4 <= n; i += 4, k++) *(uint32_t *)(d + i) = sw[k];
+			} else {
+				// every output dword takes bytes of two source dwords; the second one holds a byte of the
+				// source as long as at least 4 bytes are left
+				uint32_t lo = sw[0];
+				k = 1;
+				for (; i + 32 <= n; i += 32, k += 8) {
+					uint32_t w[8];
+					for (int j = 0; j < 8; j++) w[j] = sw[k + j];
+					uint32_t *o = (uint32_t *)(d + i);
+					o[0] = NXZ_LANE_ALIGNBYTE(w[0], lo, bo);
+					for (int j = 1; j < 8; j++) o[j] = NXZ_LANE_ALIGNBYTE(w[j], w[j - 1], bo);
+					lo = w[7];
+				}
+				for (; i + 4 <= n; i += 4, k++) {
+					const uint32_t hi = sw[k];
+					*(uint32_t *)(d + i) = NXZ_LANE_ALIGNBYTE(hi, lo, bo);
+					lo = hi;
+				}
+			}
+		}
+		for (; i < n; i++) d[i] = s[i];
+		out += n;
+	}
 	// copy len bytes from distance dist (1 <= dist <= out), pending bytes flushed by the caller
 	NXZ_LANE_FN void copy(uint32_t len, uint32_t dist)
 	{

@@ -57,6 +57,19 @@ int main()
 		w.flush();
 		if (w.out != rout || memcmp(m1.data() + off, ref, rout)) { printf("output mismatch, case %d\n", it); return 1; }
 	}
+	// copy_in: bytes of another buffer (stored blocks), all alignments of both sides
+	for (int it = 0; it < 60000; it++) {
+		uint32_t n = rand() % 200, soff = rand() % 8, doff = (rand() % 2) ? 0 : rand() % 4, pre = rand() % 9;
+		std::vector<uint8_t> sb((soff + n + 3) & ~3u ? (soff + n + 3) & ~3u : 4), m1((doff + pre + n + 3) & ~3u ? (doff + pre + n + 3) & ~3u : 4);
+		for (auto &x : sb) x = (uint8_t)rand();
+		OutWr w{ m1.data() + doff, 0, 0, 0, (((uintptr_t)(m1.data() + doff)) & 3) == 0 };
+		std::vector<uint8_t> ref;
+		for (uint32_t k = 0; k < pre; k++) { uint8_t c = (uint8_t)rand(); w.lit(c); ref.push_back(c); }
+		w.flush();
+		w.copy_in(sb.data() + soff, n);
+		ref.insert(ref.end(), sb.begin() + soff, sb.begin() + soff + n);
+		if (w.out != ref.size() || memcmp(m1.data() + doff, ref.data(), ref.size())) { printf("copy_in mismatch, case %d\n", it); return 1; }
+	}
 	printf("ok\n");
 	return 0;
 }
