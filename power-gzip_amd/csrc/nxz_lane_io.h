@@ -141,6 +141,18 @@ struct OutWr {
 	// copy len bytes from distance dist (1 <= dist <= out), pending bytes flushed by the caller
 	NXZ_LANE_FN void copy(uint32_t len, uint32_t dist)
 	{
+		// A long run of a short period (4 <= dist < 36): what follows the first few periods is also found
+		// m periods back, and from 36 bytes back or more the copy keeps eight loads in flight.
+		if (al && dist >= 4 && dist < 36 && len >= 96) {
+			const uint32_t m = (35 + dist) / dist, first = (m - 1) * dist;
+			copy1(first, dist);
+			copy1(len - first, m * dist);
+			return;
+		}
+		copy1(len, dist);
+	}
+	NXZ_LANE_FN void copy1(uint32_t len, uint32_t dist)
+	{
 		uint8_t *d = dst + out;
 		const uint8_t *s = d - dist;
 		uint32_t i = 0;
@@ -192,6 +204,16 @@ struct OutWr {
 				// period 1 or 2: one dword pattern
 				const uint32_t v = dist == 1 ? s[i] * 0x01010101u : ((uint32_t)s[i] | (uint32_t)s[i + 1] << 8) * 0x00010001u;   // the bytes at distance 1 / 2
 				for (; i + 4 <= len; i += 4) *(uint32_t *)(d + i) = v;
+			}
+		}
+		else if (al && len >= 8) {
+			// period 3: three dwords that repeat every 12 bytes
+			for (; (out + i) & 3; i++) d[i] = s[i];
+			const uint32_t p0 = s[i], p1 = s[i + 1], p2 = s[i + 2];
+			uint32_t w0 = p0 | p1 << 8 | p2 << 16 | p0 << 24, w1 = p1 | p2 << 8 | p0 << 16 | p1 << 24, w2 = p2 | p0 << 8 | p1 << 16 | p2 << 24;
+			for (; i + 4 <= len; i += 4) {
+				*(uint32_t *)(d + i) = w0;
+				const uint32_t t = w0; w0 = w1; w1 = w2; w2 = t;
 			}
 		}
 		for (; i < len; i++) d[i] = s[i];
