@@ -266,3 +266,15 @@ def test_cli_round_trips_and_reads_ordinary_gzip(tmp_path):
     bad = bytearray(image)
     bad[5000] ^= 1
     assert run_cli(["-tc"], stdin=bytes(bad)).returncode == 1
+
+
+@pytest.mark.gpu
+def test_plain_c_host_of_the_batch_interface(tmp_path):
+    # the boundary is a C ABI: a C program with host buffers and no HIP of its own (tests/native/batch_host.c)
+    exe = tmp_path / "batch_host"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-O1", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "native", "batch_host.c"), "-o", str(exe),
+                    "-L", os.path.join(ROOT, "power-gzip_amd"), "-lnxz_engine",
+                    "-Wl,-rpath," + os.path.join(ROOT, "power-gzip_amd")], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout + r.stderr
