@@ -272,6 +272,9 @@ extern "C" int nxz_blocked_inflate(const void *src_, size_t len, const nxz_block
 	const size_t used = scan(src, len, &mem, nullptr, nullptr);
 	if (mem.empty()) return 1;
 	if (consumed) *consumed = used;
+	// deflate cannot expand by more than 1032 : 1 (258 bytes from a 2-bit match): an ISIZE beyond that
+	// is damage, not a reason to allocate gigabytes
+	for (const Member &m : mem) if ((uint64_t)m.isize > (uint64_t)m.paylen * 1032 + 64) return -EILSEQ;
 
 	// batches of at most `chunk` members; staging sized for the largest batch (8192 members take
 	// the stream-per-wave kernel about 45 ms)

@@ -206,6 +206,10 @@ def test_inflate_of_foreign_blocked_files_and_damage():
         bad = bytearray(image)
         bad[pos] ^= 0x10
         assert inflate(bytes(bad))[0] == -84, what              # -EILSEQ
+    # an absurd ISIZE is refused before anything is allocated for it
+    bad = bytearray(image)
+    bad[off + size - 1] = 0x7f
+    assert inflate(bytes(bad))[0] == -84
     # ordinary gzip data is not ours to decode here
     assert inflate(gzip.compress(data[:100000]))[0] == 1
     # whole members only: a cut-off tail is reported through `consumed`
@@ -278,3 +282,47 @@ def test_plain_c_host_of_the_batch_interface(tmp_path):
                     "-Wl,-rpath," + os.path.join(ROOT, "power-gzip_amd")], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout + r.stderr
+
+
+def test_scan_survives_garbage():
+    """random bytes and mutated images: the walker never reads outside the buffer it was given
+    (exact-size ctypes buffers), never reports more than it was given, and stays consistent"""
+    import random
+    rnd = random.Random(5)
+    L = lib()
+    good = b"".join(py_member(make_block("alice", 3000 + 500 * i, i)) for i in range(6)) + EOF_MARKER
+    m, u, used = C.c_uint64(), C.c_uint64(), C.c_size_t()
+    for it in range(3000):
+        if it % 3 == 0:
+            buf = bytearray(rnd.randbytes(rnd.randrange(0, 200)))
+        else:
+            buf = bytearray(good[:rnd.randrange(0, len(good) + 1)])
+            for _ in range(rnd.randrange(0, 4)):
+                if buf:
+                    buf[rnd.randrange(len(buf))] = rnd.randrange(256)
+        if it % 5 == 0:
+            buf[:0] = b"\x1f\x8b\x08\x04" + bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 30)))
+        raw = bytes(buf)
+        cbuf = C.create_string_buffer(raw, len(raw)) if raw else C.create_string_buffer(1)
+        assert L.nxz_blocked_scan(cbuf, len(raw), C.byref(m), C.byref(u), C.byref(used)) == 0
+        assert used.value <= len(raw)
+        if used.value:
+            assert len(members_of_prefix(raw[:used.value])) == m.value
+
+
+def members_of_prefix(image):
+    out, pos = [], 0
+    while pos < len(image):
+        xlen = struct.unpack_from("<H", image, pos + 10)[0]
+        q, size = 0, None
+        while q + 4 <= xlen:
+            si, slen = image[pos + 12 + q:pos + 14 + q], struct.unpack_from("<H", image, pos + 14 + q)[0]
+            if si == b"BC" and slen == 2:
+                size = struct.unpack_from("<H", image, pos + 16 + q)[0] + 1
+                break
+            q += 4 + slen
+        assert size
+        out.append((pos, size))
+        pos += size
+    assert pos == len(image)
+    return out
