@@ -20,7 +20,7 @@
  * Wire format of a job (CRB + CPB + CSB + DDE), function codes and completion
  * codes: inc_nx/nxu.h:155-202, 286-616, 803-857.  The structures below are
  * declared from the byte layout (all multi-byte fields BIG-ENDIAN); their
- * offsets are checked against the reference header in tests/test_abi_layout.py.
+ * offsets are checked against the reference header in tests/test_abi.py.
  *
  * No torch / HIP types appear in any signature: plain pointers and sizes.
  */
@@ -124,7 +124,15 @@ enum {
 	NXZ_FC_DECOMPRESS_SINGLE_BLK      = 0x12,
 	NXZ_FC_DECOMPRESS_RESUME          = 0x14,
 	NXZ_FC_DECOMPRESS_RESUME_SINGLE_BLK = 0x16,
-	NXZ_FC_WRAP                       = 0x1e
+	NXZ_FC_WRAP                       = 0x1e,
+	/* Additive (not in the reference): bit 0x20 on a DHT compress code = the engine generates the
+	 * table itself, from the LZ symbol counts of this very job, exactly as the reference's dhtgen()
+	 * would (lib/nx_dhtgen.c:945-1034; EOB counted once, unused symbols get no code), and encodes
+	 * the job with it.  in_dht / dht[] are ignored. */
+	NXZ_FC_COMPRESS_DHTGEN              = 0x22,
+	NXZ_FC_COMPRESS_DHTGEN_COUNT        = 0x26,
+	NXZ_FC_COMPRESS_RESUME_DHTGEN       = 0x2a,
+	NXZ_FC_COMPRESS_RESUME_DHTGEN_COUNT = 0x2e
 };
 
 /* Completion codes written to CSB.CC (inc_nx/nxu.h:823-857). */
@@ -239,8 +247,8 @@ const char *nxz_last_error(void);
 
 /* Batched compress: jobs[n], results[n] (and dht[], counts[]) are DEVICE
  * arrays.  fc is one of the NXZ_FC_COMPRESS_* codes and applies to every job.
- * dht[ntables] (DHT function codes only) are the tables jobs[].dht_index
- * refers to.  counts (may be NULL unless fc has the COUNT bit): n x 316 uint32
+ * dht[ntables] (DHT function codes only; not the DHTGEN codes, where the engine makes a table
+ * per job) are the tables jobs[].dht_index refers to.  counts (may be NULL unless fc has the COUNT bit): n x 316 uint32
  * (host byte order), LL then D, EOB counted once.
  * Asynchronous on `stream`; returns 0 or a negative errno. */
 int nxz_batch_compress(nxz_ctx_t *ctx, int fc,
@@ -248,6 +256,13 @@ int nxz_batch_compress(nxz_ctx_t *ctx, int fc,
 		       const nxz_batch_dht_t *dht, size_t ntables,
 		       nxz_batch_result_t *results, uint32_t *counts,
 		       void *stream);
+
+/* The reference's dhtgen() (lib/nx_dhtgen.c:945-1034) on the device: counts[n][316] (286
+ * literal/length + 30 distance counts, host byte order, as the COUNT function codes return them;
+ * they are taken as they are -- raise zero counts first if the table is to serve other data,
+ * lib/nx_dhtgen.c:235) -> tables[n].  Bit for bit what nxz_dhtgen() / the reference produce.
+ * Asynchronous on `stream`. */
+int nxz_batch_dhtgen(nxz_ctx_t *ctx, const uint32_t *counts, size_t n, nxz_batch_dht_t *tables, void *stream);
 
 /* Batched decompress of raw-deflate streams (FC 0x10, or 0x14 when
  * jobs[].resume / hist_len are set): each job inflates until final EOB, end

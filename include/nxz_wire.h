@@ -87,6 +87,7 @@ static inline void nxz_csb_complete(nxz_crb_cpb_t *j, uint32_t cc, uint32_t ce3,
 static inline int nxz_fc_is_compress(uint32_t fc) { return (fc & 0x10) == 0; }
 static inline int nxz_fc_has_count(uint32_t fc) { return (fc & 0x10) == 0 && (fc & 0x4); }
 static inline int nxz_fc_is_dht(uint32_t fc) { return (fc & 0x10) == 0 && (fc & 0x2); }
+static inline int nxz_fc_is_dhtgen(uint32_t fc) { return (fc & 0x30) == 0x20; }   /* additive: NXZ_FC_COMPRESS_*_DHTGEN */
 static inline int nxz_fc_is_resume(uint32_t fc) { return (fc & 0x10) ? (fc & 0x4) != 0 : (fc & 0x8) != 0; }
 
 #endif

@@ -15,9 +15,28 @@ typedef struct nxz_dht_prepared {
 	uint32_t d[32];
 } nxz_dht_prepared_t;
 
+// What the LZ77 kernel hands to the entropy stage, per job (device scratch, NXZ_TOK_STRIDE bytes apart):
+// two bitmaps over the positions of the block (bit p of the first: a literal token starts at
+// position p; of the second: a match token starts there) and the match tokens in parse order,
+// one dword each: length - 3 | (distance - 1) << 8.
+#define NXZ_TOK_LITBITS    0u
+#define NXZ_TOK_MATCHBITS  8192u
+#define NXZ_TOK_RECORDS    16384u
+#define NXZ_TOK_STRIDE     106496u     /* 16 KiB of bitmaps + 65536 / 3 records at most */
+#define NXZ_TOK_MAXREC     ((NXZ_TOK_STRIDE - NXZ_TOK_RECORDS) / 4u)
+
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
+// Pointers into device memory are used through address space 1: generic ("flat") accesses make
+// the compiler drain the LDS queue completely at every wait that follows them.
+#define NXZ_GLOBAL_AS __attribute__((address_space(1)))
 extern "C" {
+int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n, uint8_t *tokens, nxz_batch_result_t *results,
+		    uint32_t *counts, uint32_t *job_counter, hipStream_t stream);
+int nxz_launch_encode(int dht, int table_per_job, const nxz_batch_job_t *jobs, size_t n, const uint8_t *tokens,
+		      const nxz_dht_prepared_t *tables, nxz_batch_result_t *results, hipStream_t stream);
+int nxz_launch_dhtgen(const uint32_t *counts, size_t n, nxz_dht_prepared_t *prepared,
+		      nxz_batch_dht_t *tables, hipStream_t stream);   /* device dhtgen: counts[n][316] -> tables (either output may be NULL) */
 int nxz_launch_deflate(int dht, int count, const nxz_batch_job_t *jobs, size_t n,
 		       const nxz_dht_prepared_t *tables, nxz_batch_result_t *results,
 		       uint32_t *counts, uint32_t *job_counter, hipStream_t stream);   /* job_counter: one device word per launch in flight, or NULL */

@@ -49,6 +49,7 @@ struct Slot {
 	nxz_batch_dht_t *h_dht = nullptr, *d_dht = nullptr;
 	nxz_dht_prepared_t *d_prep = nullptr;
 	uint32_t *h_cnt = nullptr, *d_cnt = nullptr;
+	uint8_t *d_tok = nullptr;                       // one job's tokens between the LZ77 and the entropy kernel
 	bool busy = false;
 };
 
@@ -70,6 +71,19 @@ struct nxz_ctx {
 		size_t prepared_cap = 0;
 		uint8_t *d_lanes_ws = nullptr;            // per-lane decode tables of the batched inflate kernel
 		size_t lanes_cap = 0;
+		// compress: what the LZ77 kernel hands to the entropy kernel, for one chunk of jobs
+		uint8_t *d_tokens = nullptr;              // chunk x NXZ_TOK_STRIDE
+		nxz_dht_prepared_t *d_gen = nullptr;      // tables the device generated, one per job of the chunk
+		uint32_t *d_counts = nullptr;             // symbol counts when the caller did not ask for them
+		size_t chunk_cap = 0;
+		void release() {
+			if (d_prepared) (void)hipFree(d_prepared);
+			if (d_lanes_ws) (void)hipFree(d_lanes_ws);
+			if (d_tokens) (void)hipFree(d_tokens);
+			if (d_gen) (void)hipFree(d_gen);
+			if (d_counts) (void)hipFree(d_counts);
+			*this = Scratch();
+		}
 	};
 	std::map<hipStream_t, Scratch> scratch;
 	uint32_t *d_job_counters = nullptr;           // job counters of the batched deflate launches (ring)
@@ -110,6 +124,7 @@ static bool slot_init(Slot &s)
 	HIPCHK(hipMalloc((void **)&s.d_prep, sizeof(nxz_dht_prepared_t)), return false);
 	HIPCHK(hipHostMalloc((void **)&s.h_cnt, 316 * 4), return false);
 	HIPCHK(hipMalloc((void **)&s.d_cnt, 316 * 4), return false);
+	HIPCHK(hipMalloc((void **)&s.d_tok, NXZ_TOK_STRIDE), return false);
 	return true;
 }
 
@@ -119,7 +134,7 @@ static void slot_free(Slot &s)
 	(void)hipHostFree(s.h_in); (void)hipHostFree(s.h_out); (void)hipFree(s.d_in); (void)hipFree(s.d_out);
 	(void)hipHostFree(s.h_job); (void)hipFree(s.d_job); (void)hipHostFree(s.h_res); (void)hipFree(s.d_res);
 	(void)hipHostFree(s.h_dht); (void)hipFree(s.d_dht); (void)hipFree(s.d_prep);
-	(void)hipHostFree(s.h_cnt); (void)hipFree(s.d_cnt);
+	(void)hipHostFree(s.h_cnt); (void)hipFree(s.d_cnt); (void)hipFree(s.d_tok);
 	s = Slot();
 }
 
@@ -170,10 +185,7 @@ extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 	if (--c->refs > 0) return;
 	(void)hipSetDevice(c->device);
 	for (auto &s : c->slots) if (s.stream) slot_free(s);
-	for (auto &kv : c->scratch) {
-		if (kv.second.d_prepared) (void)hipFree(kv.second.d_prepared);
-		if (kv.second.d_lanes_ws) (void)hipFree(kv.second.d_lanes_ws);
-	}
+	for (auto &kv : c->scratch) kv.second.release();
 	if (c->d_job_counters) (void)hipFree(c->d_job_counters);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	g_ctx[c->device] = nullptr;
@@ -190,41 +202,96 @@ extern "C" int nxz_ctx_sync(nxz_ctx_t *c, void *stream)
 // ---------------------------------------------------------------------------
 // batched, device-resident interface
 // ---------------------------------------------------------------------------
+// Jobs per launch of the three compress kernels: bounds the token scratch (104 KiB per job) and
+// keeps a chunk's tokens (about the size of its input) inside the 256 MiB Infinity Cache between the
+// LZ77 kernel that writes them and the entropy kernel that reads them.
+static constexpr size_t COMPRESS_CHUNK = 2048;
+
+// The compress function codes: LZ77 kernel (tokens, counts, checksums) -> [table generator] ->
+// entropy kernel, chunk after chunk on the caller's stream.
 extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *jobs, size_t n,
 				  const nxz_batch_dht_t *dht, size_t ntables, nxz_batch_result_t *results,
 				  uint32_t *counts, void *stream)
 {
-	if (!c || !nxz_fc_is_compress((uint32_t)fc) || (fc & 1)) return -EINVAL;
+	if (!c || !nxz_fc_is_compress((uint32_t)fc) || (fc & 1) || (fc & ~0x2e)) return -EINVAL;
 	if (forked_child()) return -ENODEV;
+	const bool gen = nxz_fc_is_dhtgen((uint32_t)fc);
 	const bool isdht = nxz_fc_is_dht((uint32_t)fc), count = nxz_fc_has_count((uint32_t)fc);
+	if (gen && !isdht) return -EINVAL;
 	if (count && !counts) return -EINVAL;
-	if (isdht && (!dht || !ntables)) return -EINVAL;
+	if (isdht && !gen && (!dht || !ntables)) return -EINVAL;
+	if (n == 0) return 0;
 	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
+	(void)hipSetDevice(c->device);
 	nxz_dht_prepared_t *prepared = nullptr;
-	if (isdht) {
-		{
-			std::lock_guard<std::mutex> g(c->mtx);
-			nxz_ctx::Scratch &sc = c->scratch[s];
-			if (sc.prepared_cap < ntables) {
-				// grows only: warm up once with the largest batch before timing a loop
-				if (sc.d_prepared) { (void)hipStreamSynchronize(s); (void)hipFree(sc.d_prepared); }
-				sc.d_prepared = nullptr; sc.prepared_cap = 0;
-				HIPCHK(hipMalloc((void **)&sc.d_prepared, ntables * sizeof(nxz_dht_prepared_t)), return -ENOMEM);
-				sc.prepared_cap = ntables;
-			}
-			prepared = sc.d_prepared;
+	nxz_ctx::Scratch sc;
+	{
+		std::lock_guard<std::mutex> g(c->mtx);
+		nxz_ctx::Scratch &r = c->scratch[s];
+		const size_t chunk = n < COMPRESS_CHUNK ? n : COMPRESS_CHUNK;
+		if (r.chunk_cap < chunk) {
+			// grows only: warm up once with the largest batch before timing a loop
+			if (r.d_tokens) { (void)hipStreamSynchronize(s); (void)hipFree(r.d_tokens); (void)hipFree(r.d_gen); (void)hipFree(r.d_counts); }
+			r.d_tokens = nullptr; r.d_gen = nullptr; r.d_counts = nullptr; r.chunk_cap = 0;
+			HIPCHK(hipMalloc((void **)&r.d_tokens, chunk * (size_t)NXZ_TOK_STRIDE), return -ENOMEM);
+			HIPCHK(hipMalloc((void **)&r.d_gen, chunk * sizeof(nxz_dht_prepared_t)), return -ENOMEM);
+			HIPCHK(hipMalloc((void **)&r.d_counts, chunk * 316 * sizeof(uint32_t)), return -ENOMEM);
+			r.chunk_cap = chunk;
 		}
+		if (isdht && !gen && r.prepared_cap < ntables) {
+			if (r.d_prepared) { (void)hipStreamSynchronize(s); (void)hipFree(r.d_prepared); }
+			r.d_prepared = nullptr; r.prepared_cap = 0;
+			HIPCHK(hipMalloc((void **)&r.d_prepared, ntables * sizeof(nxz_dht_prepared_t)), return -ENOMEM);
+			r.prepared_cap = ntables;
+		}
+		if (!c->d_job_counters && hipMalloc((void **)&c->d_job_counters, JOB_COUNTERS * sizeof(uint32_t)) != hipSuccess) c->d_job_counters = nullptr;
+		sc = r;
+	}
+	if (isdht && !gen) {
+		prepared = sc.d_prepared;
 		int rc = nxz_launch_dht_prepare(dht, ntables, prepared, s);
 		if (rc) { set_err("dht prepare launch", (hipError_t)rc); return -EIO; }
 	}
-	uint32_t *jc = nullptr;
-	{
-		std::lock_guard<std::mutex> g(c->mtx);
-		if (!c->d_job_counters && hipMalloc((void **)&c->d_job_counters, JOB_COUNTERS * sizeof(uint32_t)) != hipSuccess) c->d_job_counters = nullptr;
-		if (c->d_job_counters) jc = c->d_job_counters + (c->next_counter++ % JOB_COUNTERS);
+	// (measurement knob: the single-kernel path of round 1, for comparison runs)
+	static const bool fused = getenv("NXZ_FUSED") && atoi(getenv("NXZ_FUSED"));
+	if (fused && !gen) {
+		uint32_t *jc = nullptr;
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			if (c->d_job_counters) jc = c->d_job_counters + (c->next_counter++ % JOB_COUNTERS);
+		}
+		int rc = nxz_launch_deflate(isdht, count, jobs, n, prepared, results, counts, jc, s);
+		if (rc) { set_err("deflate launch", (hipError_t)rc); return -EIO; }
+		return 0;
 	}
-	int rc = nxz_launch_deflate(isdht, count, jobs, n, prepared, results, counts, jc, s);
-	if (rc) { set_err("deflate launch", (hipError_t)rc); return -EIO; }
+	for (size_t off = 0; off < n; off += COMPRESS_CHUNK) {
+		const size_t m = n - off < COMPRESS_CHUNK ? n - off : COMPRESS_CHUNK;
+		uint32_t *jc = nullptr;
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			if (c->d_job_counters) jc = c->d_job_counters + (c->next_counter++ % JOB_COUNTERS);
+		}
+		uint32_t *cnt = count ? counts + off * 316 : gen ? sc.d_counts : nullptr;
+		int rc = nxz_launch_lz77(cnt != nullptr, jobs + off, m, sc.d_tokens, results + off, cnt, jc, s);
+		if (rc) { set_err("lz77 launch", (hipError_t)rc); return -EIO; }
+		if (gen) {
+			rc = nxz_launch_dhtgen(cnt, m, sc.d_gen, nullptr, s);
+			if (rc) { set_err("dhtgen launch", (hipError_t)rc); return -EIO; }
+		}
+		rc = nxz_launch_encode(isdht, gen, jobs + off, m, sc.d_tokens, gen ? sc.d_gen : prepared, results + off, s);
+		if (rc) { set_err("encode launch", (hipError_t)rc); return -EIO; }
+	}
+	return 0;
+}
+
+// The reference's dhtgen() (lib/nx_dhtgen.c:945-1034) for a batch of count arrays on the device.
+extern "C" int nxz_batch_dhtgen(nxz_ctx_t *c, const uint32_t *counts, size_t n, nxz_batch_dht_t *tables, void *stream)
+{
+	if (!c || !counts || !tables) return -EINVAL;
+	if (forked_child()) return -ENODEV;
+	(void)hipSetDevice(c->device);
+	int rc = nxz_launch_dhtgen(counts, n, nullptr, tables, (hipStream_t)stream);
+	if (rc) { set_err("dhtgen launch", (hipError_t)rc); return -EIO; }
 	return 0;
 }
 
@@ -321,8 +388,7 @@ extern "C" void nxz_stream_destroy(nxz_ctx_t *c, void *stream)
 		std::lock_guard<std::mutex> g(c->mtx);
 		auto it = c->scratch.find((hipStream_t)stream);
 		if (it != c->scratch.end()) {
-			if (it->second.d_prepared) (void)hipFree(it->second.d_prepared);
-			if (it->second.d_lanes_ws) (void)hipFree(it->second.d_lanes_ws);
+			it->second.release();
 			c->scratch.erase(it);
 		}
 	}
@@ -495,14 +561,17 @@ static int run_compress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 	bj->dst_cap = dcap; bj->in_crc = nxz_in_crc(&j->cpb); bj->in_adler = nxz_in_adler(&j->cpb); bj->dht_index = 0;
 	HIPCHK(hipMemcpyAsync(s->d_in, s->h_in, h + n, hipMemcpyHostToDevice, s->stream), return -EIO);
 	HIPCHK(hipMemcpyAsync(s->d_job, bj, sizeof(*bj), hipMemcpyHostToDevice, s->stream), return -EIO);
-	if (dht) {
+	if (dht && !nxz_fc_is_dhtgen(fc)) {
 		uint32_t dhtlen = nxz_in_dhtlen(&j->cpb);
 		s->h_dht->dhtlen = dhtlen;
 		memcpy(s->h_dht->dht, j->cpb.in_dht, NXZ_DHT_MAXSZ);
 		HIPCHK(hipMemcpyAsync(s->d_dht, s->h_dht, sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s->stream), return -EIO);
 		if (nxz_launch_dht_prepare(s->d_dht, 1, s->d_prep, s->stream)) return -EIO;
 	}
-	if (nxz_launch_deflate(dht, count, s->d_job, 1, s->d_prep, s->d_res, s->d_cnt, nullptr, s->stream)) return -EIO;
+	const bool gen = nxz_fc_is_dhtgen(fc);
+	if (nxz_launch_lz77(count || gen, s->d_job, 1, s->d_tok, s->d_res, s->d_cnt, nullptr, s->stream)) return -EIO;
+	if (gen && nxz_launch_dhtgen(s->d_cnt, 1, s->d_prep, nullptr, s->stream)) return -EIO;
+	if (nxz_launch_encode(dht, 0, s->d_job, 1, s->d_tok, s->d_prep, s->d_res, s->stream)) return -EIO;
 	HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
 	if (count) HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, 316 * 4, hipMemcpyDeviceToHost, s->stream), return -EIO);
 	HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
@@ -633,7 +702,7 @@ extern "C" int nxu_run_job(nxz_crb_cpb_t *j, void *handle)
 	(void)hipSetDevice(c->device);
 	int rc;
 	if (fc == NXZ_FC_WRAP) rc = run_wrap(c, s, j);
-	else if (nxz_fc_is_compress(fc) && !(fc & 1)) rc = run_compress(c, s, j, fc);
+	else if (nxz_fc_is_compress(fc) && !(fc & 1) && !(fc & ~0x2eu) && (!nxz_fc_is_dhtgen(fc) || nxz_fc_is_dht(fc))) rc = run_compress(c, s, j, fc);
 	else if (fc == NXZ_FC_DECOMPRESS || fc == NXZ_FC_DECOMPRESS_RESUME) rc = run_decompress(c, s, j, fc);
 	else { nxz_csb_complete(j, NXZ_CC_INVALID_OP, NXZ_CE_TERMINATE, 0); rc = 0; }
 	slot_release(c, s);

@@ -1,17 +1,21 @@
-// nxz_deflate.hip -- DEFLATE compression engine for MI355X (gfx950, wave64).
+// nxz_lz77.hip -- LZ77 stage of the DEFLATE compression engine for MI355X (gfx950, wave64).
 //
-// Replaces the POWER NX accelerator's COMPRESS function codes
+// First half of the POWER NX accelerator's COMPRESS function codes
 // (GZIP_FC_COMPRESS_[RESUME_]{FHT,DHT}[_COUNT], issued at
 // /root/reference lib/nx_deflate.c:1808,1841; contract inc_nx/nxu.h:286-616 and
 // the consumer code lib/nx_deflate.c:969-1078).  One workgroup (1024 threads =
-// 16 wavefronts, one per CU: the working set is 159 KiB of LDS) turns one
-// sub-block of <= 64 KiB (history window included) into one deflate block; the grid is one
+// 16 wavefronts, one per CU: the working set is 158 KiB of LDS) turns one
+// sub-block of <= 64 KiB (history window included) into its LZ77 token sequence; the grid is one
 // persistent workgroup per CU that draws job after job from a counter.
 // The algorithm is the position-parallel LZ77 defined in oracle/nxz_lz77.c;
-// this kernel must reproduce that restatement bit for bit.
+// this kernel must reproduce that restatement's tokens exactly.  What leaves the kernel
+// (nxz_device.h, NXZ_TOK_*): a bitmap of the positions where a literal token starts, a bitmap of
+// the positions where a match token starts, the (length, distance) records of the matches in
+// parse order, the LZ symbol counts (286 + 30, the COUNT function codes' out_lzcount and the
+// input of the table generator nxz_dhtgen.hip) and the checksums.  The entropy stage
+// (nxz_encode.hip) makes the deflate block from them.
 //
-// Phases per sub-block (all data stays in LDS between load and the coalesced
-// output flush; HBM traffic is the algorithmic U + C bytes):
+// Phases per sub-block (the block stays in LDS from load to the last tile):
 //   load     coalesced 16 B/lane global loads of [window|block] into LDS
 //   cksum    CRC-32 (64-byte slices, slice-by-4, GF(2) weights, XOR reduce) and Adler-32 (v_dot4)
 //   seed     window positions -> head[] by LDS atomicMax (order free)
@@ -28,24 +32,22 @@
 //            evaluated from the flag bitmap (M3)
 //     parse  lane per 16-byte segment: speculative greedy/lazy walk -> exit X[s];
 //            pointer jumping marks the chain of entered segments; entered segments re-walk
-//            [entry, X[s]) and assemble their Huffman codes in a register bit string
-//     encode workgroup prefix sum of the bit counts, shifted dword emission into a 10 KiB LDS
-//            window, coalesced dword flush
+//            [entry, X[s]) and mark their tokens in the two bitmaps (register masks, one LDS
+//            atomic per lane)
+//     out    lane per 16 positions: match records to the job's record array at the rank a
+//            workgroup prefix sum of the match counts gives; symbol counts by LDS atomics;
+//            the two bitmaps as coalesced dwords
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
 #include "nxz_device.h"
 
-// Debug aid (tests/debug_tokens.py): when set, workgroup 0 dumps its per-position arrays.
-__device__ uint32_t *nxz_debug_buf = nullptr;
 // Diagnostic only (tools/phase_profile.py): per-phase cycle sums of every workgroup's thread 0.
-__device__ unsigned long long *nxz_prof_buf = nullptr;
-// Pointers into device memory are used through address space 1: generic ("flat") accesses make
-// the compiler drain the LDS queue completely at every wait that follows them.
-#define NXZ_GLOBAL __attribute__((address_space(1)))
+__device__ unsigned long long *nxz_lz77_prof_buf = nullptr;
+#define NXZ_GLOBAL NXZ_GLOBAL_AS
 #define PROF(idx) do { if (prof) { if (t == 0) { unsigned long long now_ = clock64(); __hip_atomic_fetch_add(&prof[idx], now_ - tprev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tprev = now_; } } } while (0)
 
-namespace nxz {
+namespace nxzl77 {
 
 constexpr int NT = 1024;                 // threads per workgroup
 constexpr int HBITS = 13;
@@ -65,11 +67,11 @@ constexpr uint32_t OFF_IN    = 0;                        // 65536 + 32 pad
 constexpr uint32_t OFF_HEAD  = 65536 + 32;               // 8192 x u32
 constexpr uint32_t OFF_CAND  = OFF_HEAD + HSIZE * 4 + 256; // 16384 x u16 (head[HSIZE + lane]: one dummy slot per lane of the chain wave)
 constexpr uint32_t OFF_MLEN  = OFF_CAND + PTILE * 2;     // 16384 x u8
-constexpr uint32_t OFF_SBITS = OFF_MLEN + PTILE;         // 512 x u32   (aliased: MARK u8[1024] during chain marking)
-constexpr uint32_t OFF_MBITS = OFF_SBITS + PTILE / 8;    // 512 x u32   (aliased: JUMP u16[1024])
-constexpr uint32_t OFF_X     = OFF_MBITS + PTILE / 8;    // 1024 x u16  } dead after the parse: together with
-constexpr uint32_t OFF_ENTRY = OFF_X + NSEG * 2;         // 1024 x u16  } BITS they form the bit-pack window
-constexpr uint32_t OFF_BITS  = OFF_ENTRY + NSEG * 2;     // 4096 + 64 bytes (aliased: CRC tables before the first tile)
+constexpr uint32_t OFF_SBITS = OFF_MLEN + PTILE;         // 512 x u32   (aliased: MARK u8[1024] during chain marking; match-token bitmap of the final walk)
+constexpr uint32_t OFF_MBITS = OFF_SBITS + PTILE / 8;    // 512 x u32   (aliased: JUMP u16[1024]; literal-token bitmap of the final walk)
+constexpr uint32_t OFF_X     = OFF_MBITS + PTILE / 8;    // 1024 x u16
+constexpr uint32_t OFF_ENTRY = OFF_X + NSEG * 2;         // 1024 x u16
+constexpr uint32_t OFF_BITS  = OFF_ENTRY + NSEG * 2;     // 4096 + 64 bytes: the CRC tables before the first tile, match-phase queues later
 constexpr uint32_t BITS_BYTES = ETILE * 2 + 64;
 // during the match phase the window region holds: 16 x 96 queue entries (long positions), 16 x 80
 // (tails beyond LCAP) and the e-flag bitmap (PTILE + 288 bits)
@@ -78,22 +80,14 @@ constexpr uint32_t OFF_XQ    = OFF_LQ + 16 * 96 * 2;
 constexpr uint32_t OFF_EB    = OFF_XQ + 16 * 80 * 2;     // 2096 bytes; bit EBO + i = flag of tile position i
 constexpr uint32_t EBO       = 32;                       // flags of the 32 positions in front of the tile come first
 static_assert(OFF_EB % 16 == 0 && OFF_EB + 2096 <= OFF_BITS + BITS_BYTES, "match-phase carve");
-// bit-pack window of the encode phase: MBITS, X, ENTRY and BITS together (the token bitmap of the
-// final walk lives in SBITS): WWORDS dwords + 16 dwords of spill.  10 KiB hold a whole tile's output
-// whenever the data shrinks to 5/8 or less.
-constexpr uint32_t OFF_WIN   = OFF_MBITS;
-constexpr uint32_t WWORDS    = (PTILE / 8 + NSEG * 4 + ETILE * 2) / 4;   // 2560
-static_assert(OFF_WIN + (WWORDS + 16) * 4 <= OFF_BITS + BITS_BYTES, "window");
 constexpr uint32_t OFF_SCAN  = OFF_BITS + BITS_BYTES;    // 64 x u32
-constexpr uint32_t OFF_LLTAB = OFF_SCAN + 256;           // 288 x u32
-constexpr uint32_t OFF_DTAB  = OFF_LLTAB + 288 * 4;      // 32 x u32
-constexpr uint32_t OFF_HIST  = OFF_DTAB + 32 * 4;        // 316 x u32
+constexpr uint32_t OFF_HIST  = OFF_SCAN + 256;           // 316 x u32
 constexpr uint32_t OFF_MISC  = OFF_HIST + 316 * 4;       // 16 x u32
 constexpr uint32_t LDS_BYTES = OFF_MISC + 64;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
-enum { M_ERR = 0, M_CARRY_BITS = 1, M_WORDBASE = 2, M_CARRY_WORD = 3, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7 };
+enum { M_NREC = 0, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7 };
 static_assert(M_TICKET == M_PROGRESS + 1 && M_DEFER == M_PROGRESS + 2, "cleared together");
 
 __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
@@ -214,11 +208,11 @@ __device__ __forceinline__ uint32_t walk_step(const Walk &w, uint32_t p, uint32_
 	return 1;
 }
 
-template <bool DHT, bool COUNT>
-__global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__restrict__ jobs,
-						     const nxz_dht_prepared_t *__restrict__ tables,
-						     nxz_batch_result_t *__restrict__ results,
-						     uint32_t *__restrict__ counts, uint32_t njobs, uint32_t *__restrict__ next_job)
+template <bool COUNT>
+__global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restrict__ jobs,
+						  uint8_t *__restrict__ tokens,
+						  nxz_batch_result_t *__restrict__ results,
+						  uint32_t *__restrict__ counts, uint32_t njobs, uint32_t *__restrict__ next_job)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	uint32_t *inw = (uint32_t *)(lds + OFF_IN);
@@ -230,17 +224,15 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 	uint32_t *sbits = (uint32_t *)(lds + OFF_SBITS);
 	uint32_t *mbits = (uint32_t *)(lds + OFF_MBITS);
 	uint32_t *tokbits = sbits;                           // match-token bitmap of the final walk (SBITS is free by then)
+	uint32_t *litbits = mbits;                           // literal-token bitmap (JUMP is dead by then)
 	uint8_t *mark = lds + OFF_SBITS;
 	uint16_t *jump = (uint16_t *)(lds + OFF_MBITS);
 	uint32_t *bitbuf = (uint32_t *)(lds + OFF_BITS);
 	uint32_t *scan = (uint32_t *)(lds + OFF_SCAN);
-	uint32_t *lltab = (uint32_t *)(lds + OFF_LLTAB);
-	uint32_t *dtab = (uint32_t *)(lds + OFF_DTAB);
 	uint32_t *hist = (uint32_t *)(lds + OFF_HIST);
 	uint32_t *misc = (uint32_t *)(lds + OFF_MISC);
 
-	NXZ_GLOBAL unsigned long long *prof = (NXZ_GLOBAL unsigned long long *)nxz_prof_buf;
-	NXZ_GLOBAL uint32_t *dbg = (NXZ_GLOBAL uint32_t *)nxz_debug_buf;
+	NXZ_GLOBAL unsigned long long *prof = (NXZ_GLOBAL unsigned long long *)nxz_lz77_prof_buf;
 	// The grid is one workgroup per CU (the LDS image allows no more); a workgroup starts with job
 	// blockIdx.x and then draws further jobs from a counter (or strides by the grid without one), so
 	// nothing waits for a dispatch in between and slow jobs do not pile up in one place.  The draw
@@ -279,22 +271,6 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 	for (uint32_t i = t; i < HSIZE; i += NT) head[i] = 0;
 	if (t < 316) hist[t] = 0;
 	if (t < 16 && t != M_NEXT) misc[t] = 0;
-	if (DHT) {
-		const nxz_dht_prepared_t *tb = &tables[job.dht_index];
-		if (t < 288) lltab[t] = tb->ll[t];
-		if (t < 32) dtab[t] = tb->d[t];
-	} else {
-		if (t < 288) {
-			// RFC1951 3.2.6 fixed code; entry = bit-reversed code | len << 16
-			uint32_t len, code;
-			if (t < 144) { len = 8; code = 0x30 + t; }
-			else if (t < 256) { len = 9; code = 0x190 + (t - 144); }
-			else if (t < 280) { len = 7; code = t - 256; }
-			else { len = 8; code = 0xC0 + (t - 280); }
-			lltab[t] = (__builtin_bitreverse32(code) >> (32 - len)) | (len << 16);
-		}
-		if (t < 32) dtab[t] = (__builtin_bitreverse32((uint32_t)t) >> 27) | (5u << 16);
-	}
 	// slice-by-4 CRC tables live in the (not yet used) bit buffer: T[k][i] = i advanced by k+1 zero bytes
 	{
 		uint32_t c = t & 255;
@@ -415,24 +391,11 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			if (!deep) atomicMax(&head[hash4(v)], r + 1);
 		}
 
-	// ---------------- block header ----------------
-	// misc[M_CARRY_BITS]: bits pending in bitbuf[0..]; misc[M_WORDBASE]: dwords already flushed
-	NXZ_GLOBAL uint32_t *dstw = (NXZ_GLOBAL uint32_t *)job.dst;
-	const uint32_t cap_words = job.dst_cap >> 2;
-	if (DHT) {
-		const nxz_dht_prepared_t *tb = &tables[job.dht_index];
-		uint32_t hb = tb->dhtlen + 3;                       // header bits
-		uint32_t nw = hb >> 5;                              // full words
-		for (uint32_t i = t; i <= nw; i += NT) {
-			uint32_t cur = i < 73 ? tb->dhtw[i] : 0, prev = i ? tb->dhtw[i - 1] : 0;
-			uint32_t w = (cur << 3) | (i ? prev >> 29 : 5u);
-			if (i < nw) { if (i < cap_words) dstw[i] = w; }
-			else misc[M_CARRY_WORD] = (hb & 31) ? (w & ((1u << (hb & 31)) - 1)) : 0;
-		}
-		if (t == 0) { misc[M_CARRY_BITS] = hb & 31; misc[M_WORDBASE] = nw; if (nw > cap_words) misc[M_ERR] = NXZ_CC_TARGET_SPACE; }
-	} else {
-		if (t == 0) { misc[M_CARRY_WORD] = 3u; misc[M_CARRY_BITS] = 3; misc[M_WORDBASE] = 0; }
-	}
+	// where this job's tokens go
+	NXZ_GLOBAL uint8_t *tk = (NXZ_GLOBAL uint8_t *)tokens + (size_t)bid * NXZ_TOK_STRIDE;
+	NXZ_GLOBAL uint32_t *g_lit = (NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_LITBITS);
+	NXZ_GLOBAL uint32_t *g_tok = (NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_MATCHBITS);
+	NXZ_GLOBAL uint32_t *g_rec = (NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_RECORDS);
 	__syncthreads();
 
 	Walk W{inw, mlen, cand, h, 0, end};
@@ -969,8 +932,6 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 			}
 		}
 		__syncthreads();
-		if (dbg && bid == 0)
-			for (uint32_t i = t; i < tn; i += NT) dbg[(tb0 / PTILE) * 65536 + i] = cand[i] | ((uint32_t)mlen[i] << 16);
 
 		PROF(5);
 		// ---- parse pass 1: speculative walk of segment s from its own start ----
@@ -1057,244 +1018,115 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 		if (entered && myx < tn) entry[myx / PSEG] = (uint16_t)myx;
 		__syncthreads();
 		uint32_t mye = entered ? entry[t] : 0;
-		if (dbg && bid == 0 && (uint32_t)t < nseg)
-			dbg[(tb0 / PTILE) * 65536 + 16384 + t] = myx | (mye << 16) | (entered ? 0x80000000u : 0);
-		// token bitmaps (alias mark/jump, which are dead now) are cleared
-		for (uint32_t i = t; i < PTILE / 32; i += NT) tokbits[i] = 0;
+		// token bitmaps (alias mark/jump, which are dead now: every thread has its entry) are cleared
+		sbits[t] = 0;                                           // tokbits and litbits (adjacent, 2 x 512 words)
 		__syncthreads();
-		// ... and so is the bit-pack window of the encode phase: MBITS / X / ENTRY / BITS are all dead
-		// now (every thread has its entry), the final walk does not touch them
-		for (uint32_t i = t; i < WWORDS + 16; i += NT) ((uint32_t *)(lds + OFF_WIN))[i] = 0;
 
 		PROF(7);
 		// ---- parse pass 2: entered segments walk [entry, X[s]) for real ----
-		// The walk assembles the Huffman codes of its tokens right away into a lane-private bit
-		// string held in registers (8 dwords + a partial one; longer ranges fall back to a second
-		// walk in the encode phase), sums their bits for the encoder's prefix sum and feeds the LZ
-		// histogram; match tokens are flagged in a bitmap and get their final length.
-		uint32_t mine = 0;
-		uint32_t lw0 = 0, lw1 = 0, lw2 = 0, lw3 = 0, lw4 = 0, lw5 = 0, lw6 = 0, lw7 = 0, lpart = 0;
-		bool loverflow = false;
+		// The walk only decides: literal and match token starts are collected in two register masks
+		// (32 positions from the segment start; beyond that -- a walk that runs on behind a long
+		// match of its neighbours -- bit by bit) and a match gets its final, possibly truncated length.
 		if (entered) {
-			uint32_t p = mye, lim = myx;
-			uint64_t acc = 0; uint32_t accn = 0, nwords = 0;
-			auto put = [&](uint32_t part, uint32_t nbits) {
-				acc |= (uint64_t)part << accn;
-				accn += nbits;
-				if (accn >= 32) {
-					uint32_t wv = (uint32_t)acc;
-					// predicated register file write: a dynamically indexed array would live in scratch
-					lw0 = nwords == 0 ? wv : lw0; lw1 = nwords == 1 ? wv : lw1; lw2 = nwords == 2 ? wv : lw2; lw3 = nwords == 3 ? wv : lw3;
-					lw4 = nwords == 4 ? wv : lw4; lw5 = nwords == 5 ? wv : lw5; lw6 = nwords == 6 ? wv : lw6; lw7 = nwords == 7 ? wv : lw7;
-					loverflow |= nwords >= 8;
-					nwords++;
-					acc >>= 32; accn -= 32;
-				}
-			};
+			uint32_t p = mye;
+			const uint32_t lim = myx;
+			uint32_t lm = 0, mm = 0;
 			while (p < lim) {
-				const uint32_t k = p - p0;
-				// all literal step (wave uniform): no lane of this wave has a match in its next
-				// positions, so up to four literals per lane go out with one input load
-				const uint32_t rest = k < 16 ? seg_nz >> k : 1;
-				uint32_t run = rest ? (uint32_t)__builtin_ctz(rest) : 16 - k;
-				if (run > lim - p) run = lim - p;
-				if (!__ballot(run == 0)) {
-					if (run > 4) run = 4;
-					const uint32_t v = lds_ld32(inw, h + tb0 + p);
-					const uint32_t b0 = v & 0xff, b1 = (v >> 8) & 0xff, b2 = (v >> 16) & 0xff, b3 = v >> 24;
-					const uint32_t t0 = lltab[b0], t1 = run > 1 ? lltab[b1] : 0, t2 = run > 2 ? lltab[b2] : 0, t3 = run > 3 ? lltab[b3] : 0;
-					if (DHT && ((t0 >> 16) == 0 || (run > 1 && (t1 >> 16) == 0) || (run > 2 && (t2 >> 16) == 0) || (run > 3 && (t3 >> 16) == 0)))
-						misc[M_ERR] = NXZ_CC_MISSING_CODE;
-					put((t0 & 0xffff) | (t1 & 0xffff) << (t0 >> 16), (t0 >> 16) + (t1 >> 16));       // <= 30 bits
-					put((t2 & 0xffff) | (t3 & 0xffff) << (t2 >> 16), (t2 >> 16) + (t3 >> 16));
-					mine += (t0 >> 16) + (t1 >> 16) + (t2 >> 16) + (t3 >> 16);
-					if (COUNT) {
-						atomicAdd(&hist[b0], 1u);
-						if (run > 1) atomicAdd(&hist[b1], 1u);
-						if (run > 2) atomicAdd(&hist[b2], 1u);
-						if (run > 3) atomicAdd(&hist[b3], 1u);
-					}
-					p += run;
-					continue;
+				uint32_t k = p - p0;
+				if (k < 16) {
+					// literals in front of the next stored match of my segment
+					const uint32_t rest = seg_nz >> k;
+					uint32_t run = rest ? (uint32_t)__builtin_ctz(rest) : 16 - k;
+					if (run > lim - p) run = lim - p;
+					lm |= ((1u << run) - 1) << k;
+					p += run; k += run;
+					if (p >= lim) break;
 				}
-				// one token per lane -- or two, if both are literals; literal and match share one
-				// (select based) code path so that a wave with both kinds does not execute two
-				// divergent branches: a match fills both puts, a literal pair one each
 				bool m;
 				uint32_t l;
 				if (k < 16) l = seg_step(p, lim, m);
-				else l = walk_step(W, p, lim, m);                 // beyond my segment (unsynchronised range): LDS data
-				const bool two = !m && k < 15 && !((seg_nz >> (k + 1)) & 1) && p + 1 < lim;   // the next position is a literal for sure
-				const uint32_t byte = lds[OFF_IN + h + tb0 + p], byte2 = lds[OFF_IN + h + tb0 + p + 1], d = cand[p];
-				const uint32_t l3 = l - 3;
-				uint32_t le = l3 < 8 ? 0 : (29 - __builtin_clz(l3 | 8));
-				const uint32_t ls = l3 == 255 ? 28 : (le << 2) + (l3 >> le);
-				if (l3 == 255) le = 0;
-				uint32_t de = d < 4 ? 0 : (30 - __builtin_clz(d | 4));
-				const uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
-				if (!m) { le = 0; de = 0; }
-				const uint32_t lt = lltab[m ? 257 + ls : byte];
-				const uint32_t dt = m ? dtab[ds & 31] : two ? lltab[byte2] : 0;   // second put: distance code or second literal
-				const uint32_t ll = lt >> 16, dl = dt >> 16;
-				if (DHT && (ll == 0 || ((m || two) && dl == 0))) misc[M_ERR] = NXZ_CC_MISSING_CODE;
-				put((lt & 0xffff) | ((l3 & ((1u << le) - 1)) << ll), ll + le);               // <= 20 bits
-				put((dt & 0xffff) | ((d & ((1u << de) - 1)) << dl), dl + de);                // <= 28 bits (0 for a single literal)
-				mine += ll + le + dl + de;
-				if (m) {
-					atomicOr(&tokbits[p >> 5], 1u << (p & 31));
-					mlen[p] = (uint8_t)l3;
+				else l = walk_step(W, p, lim, m);                 // beyond my segment (nobody else's range): LDS data
+				if (k < 32) {
+					lm |= (m ? 0u : 1u) << k;
+					mm |= (m ? 1u : 0u) << k;
+				} else {
+					atomicOr(m ? &tokbits[p >> 5] : &litbits[p >> 5], 1u << (p & 31));
 				}
-				if (COUNT) {
-					atomicAdd(&hist[m ? 257 + ls : byte], 1u);
-					if (m) atomicAdd(&hist[286 + ds], 1u);
-					if (two) atomicAdd(&hist[byte2], 1u);
-				}
-				p += l + (uint32_t)two;
+				if (m) mlen[p] = (uint8_t)(l - 3);
+				p += l;
 			}
-			lpart = (uint32_t)acc;
-			loverflow |= nwords > 8 || (nwords == 8 && accn != 0);
+			// 32 positions from p0 = 16 t: bit 16 (t & 1) of word t / 2 onwards
+			const uint32_t sh = 16 * ((uint32_t)t & 1), wi = (uint32_t)t >> 1;
+			const uint64_t lv = (uint64_t)lm << sh, mv = (uint64_t)mm << sh;
+			if ((uint32_t)lv) atomicOr(&litbits[wi], (uint32_t)lv);
+			if (lv >> 32) atomicOr(&litbits[wi + 1], (uint32_t)(lv >> 32));
+			if ((uint32_t)mv) atomicOr(&tokbits[wi], (uint32_t)mv);
+			if (mv >> 32) atomicOr(&tokbits[wi + 1], (uint32_t)(mv >> 32));
 		}
-		uint32_t incl = wave_incl_scan(mine, lane);
-		if (lane == 63) scan[wave] = incl;
-		__syncthreads();                                       // X/ENTRY are dead from here on
+		__syncthreads();
 		PROF(8);
 
-		// ---- encode ----
-		// An entered lane owns the tokens of its range [entry, X[s]); the workgroup prefix sum of
-		// the bit counts gives it a bit offset.  Codes are assembled in a 64-bit register and leave
-		// as whole dwords: plain stores for the dwords a lane owns entirely, atomicOr for the shared
-		// first/last ones.  The 8 KiB LDS window (X/ENTRY/BITS regions) is flushed as coalesced
-		// dwords, window after window.
+		// ---- out: records, counts, bitmaps ----
 		{
-			uint32_t *win = (uint32_t *)(lds + OFF_WIN);
-			uint32_t carry = misc[M_CARRY_BITS], wordbase = misc[M_WORDBASE], carryword = misc[M_CARRY_WORD];
-			uint32_t woff = 0, tot = 0;
+			const uint32_t tok16 = p0 < tn ? ((const uint16_t *)tokbits)[t] : 0;
+			const uint32_t nm = (uint32_t)__popc(tok16);
+			uint32_t incl = wave_incl_scan(nm, lane);
+			if (lane == 63) scan[wave] = incl;
+			const uint32_t recbase = misc[M_NREC];
+			__syncthreads();
+			uint32_t rank = recbase + incl - nm, tot = 0;
 #pragma unroll
 			for (int w = 0; w < 16; w++) {
-				uint32_t sc = scan[w];
-				if (w < wave) woff += sc;
+				const uint32_t sc = scan[w];
+				if (w < wave) rank += sc;
 				tot += sc;
 			}
-			const uint32_t total = carry + tot;                // bits of this tile's stream incl. the carried partial word
-			uint32_t bitpos = carry + woff + incl - mine;      // my first token, in that stream
-			const uint32_t bend = bitpos + mine;
-			if (t == 0 && carryword) atomicOr(&win[0], carryword);    // the window was cleared before the final walk
-			PROF(13);
-			uint32_t p = mye;
-			const uint32_t plim = (entered && loverflow) ? myx : 0;
-			bool done = !entered || loverflow || mine == 0;
-			for (uint32_t wlo = 0;; wlo += WWORDS * 32) {
-				const uint32_t whi = wlo + WWORDS * 32;
-				if (!done && bitpos < whi) {
-					// my whole range (<= 8 dwords + partial) goes out in one go, shifted to its bit offset
-					const uint32_t sh = bitpos & 31, w0i = (bitpos - wlo) >> 5;
-					const uint32_t nfull = mine >> 5, npart = mine & 31;            // source dwords
-					uint32_t prev = 0;
-#pragma unroll
-					for (uint32_t k = 0; k <= 9; k++) {
-						uint32_t cur = k == 0 ? lw0 : k == 1 ? lw1 : k == 2 ? lw2 : k == 3 ? lw3 : k == 4 ? lw4 : k == 5 ? lw5
-							     : k == 6 ? lw6 : k == 7 ? lw7 : 0;
-						if (k == nfull) cur = npart ? lpart & ((1u << npart) - 1) : 0;
-						if (k > nfull) cur = 0;
-						uint32_t o = sh ? (cur << sh) | (prev >> (32 - sh)) : cur;
-						prev = cur;
-						// output dword k covers stream bits [32*(w0i+k)+wlo, +32)
-						const uint32_t wbit = wlo + 32 * (w0i + k);
-						if (wbit < bend) {
-							if (k == 0 || wbit + 32 > bend) atomicOr(&win[w0i + k], o);
-							else win[w0i + k] = o;
-						}
-					}
-					done = true;
+			for (uint32_t mbits_ = tok16; mbits_; mbits_ &= mbits_ - 1) {
+				const uint32_t p = p0 + (uint32_t)__builtin_ctz(mbits_);
+				const uint32_t l3 = mlen[p], d = cand[p];
+				if (rank < NXZ_TOK_MAXREC) g_rec[rank] = l3 | (d << 8);
+				rank++;
+				if (COUNT) {
+					uint32_t le = l3 < 8 ? 0 : (29 - (uint32_t)__builtin_clz(l3 | 8));
+					const uint32_t ls = l3 == 255 ? 28 : (le << 2) + (l3 >> le);
+					const uint32_t de = d < 4 ? 0 : (30 - (uint32_t)__builtin_clz(d | 4));
+					const uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
+					atomicAdd(&hist[257 + ls], 1u);
+					atomicAdd(&hist[286 + ds], 1u);
 				}
-				if (p < plim && bitpos < whi) {
-					// fallback for ranges that did not fit the register bit string: second walk
-					uint64_t acc = 0;
-					uint32_t accn = (bitpos - wlo) & 31, accw = (bitpos - wlo) >> 5;
-					bool firstword = true;
-					auto put = [&](uint32_t part, uint32_t nbits) {
-						acc |= (uint64_t)part << accn;
-						accn += nbits;
-						if (accn >= 32) {
-							if (firstword || wlo + 32 * accw + 32 > bend) atomicOr(&win[accw], (uint32_t)acc);
-							else win[accw] = (uint32_t)acc;
-							firstword = false;
-							acc >>= 32; accn -= 32; accw++;
-						}
-					};
-					while (p < plim && bitpos < whi) {
-						uint32_t adv;
-						if (tokbits[p >> 5] >> (p & 31) & 1) {
-							uint32_t l = mlen[p], d = cand[p];            // len-3, dist-1
-							uint32_t le = l < 8 ? 0 : (29 - __builtin_clz(l));
-							uint32_t ls = l == 255 ? 28 : (le << 2) + (l >> le);
-							if (l == 255) le = 0;
-							uint32_t de = d < 4 ? 0 : (30 - __builtin_clz(d));
-							uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
-							uint32_t lt = lltab[257 + ls], dt = dtab[ds];
-							uint32_t ll = lt >> 16, dl = dt >> 16;
-							put((lt & 0xffff) | ((l & ((1u << le) - 1)) << ll), ll + le);
-							put((dt & 0xffff) | ((d & ((1u << de) - 1)) << dl), dl + de);
-							bitpos += ll + le + dl + de;
-							adv = l + 3;
-						} else {
-							uint32_t lt = lltab[lds[OFF_IN + h + tb0 + p]];
-							put(lt & 0xffff, lt >> 16);
-							bitpos += lt >> 16;
-							adv = 1;
-						}
-						p += adv;
-					}
-					if (accn) atomicOr(&win[accw], (uint32_t)acc);
-				}
-				__syncthreads();
-				PROF(14);
-				const bool lastw = total <= whi;
-				const uint32_t nw = lastw ? (total - wlo) >> 5 : WWORDS;
-				for (uint32_t i = t; i < nw; i += NT)
-					if (wordbase + i < cap_words) dstw[wordbase + i] = win[i];
-				// what stays: the partial last dword, or the spill of tokens that crossed the window end
-				uint32_t keep = 0;
-				if (t < 16) keep = lastw ? (t == 0 ? win[nw] : 0) : win[WWORDS + t];
-				__syncthreads();
-				wordbase += nw;
-				if (lastw) {
-					if (t == 0) {
-						misc[M_CARRY_BITS] = total & 31;
-						misc[M_CARRY_WORD] = keep;
-						misc[M_WORDBASE] = wordbase;
-						if (wordbase > cap_words) misc[M_ERR] = NXZ_CC_TARGET_SPACE;
-					}
-					break;
-				}
-				for (uint32_t i = t; i < WWORDS + 16; i += NT) win[i] = (i < 16) ? keep : 0;
-				__syncthreads();
 			}
-			PROF(15);                                          // (the loop is left right behind a barrier)
+			if (COUNT && p0 < tn) {
+				const uint32_t lit16 = ((const uint16_t *)litbits)[t];
+				if (lit16) {
+					const uint4 bv = *(const uint4 *)(lds + OFF_IN + h + tb0 + p0);      // 16-byte aligned: h, tb0, p0 are
+					for (uint32_t lb = lit16; lb; lb &= lb - 1) {
+						const uint32_t k = (uint32_t)__builtin_ctz(lb);
+						const uint32_t a = (k & 8) ? bv.z : bv.x, b = (k & 8) ? bv.w : bv.y;
+						const uint32_t w = (k & 4) ? b : a;
+						atomicAdd(&hist[(w >> (8 * (k & 3))) & 0xff], 1u);
+					}
+				}
+			}
+			// the bitmaps of this tile, coalesced: the first 512 threads the literal bits, the others the match bits
+			{
+				const uint32_t nwords = (tn + 31) >> 5, i = (uint32_t)t & 511;
+				if (i < nwords) {
+					if (t < 512) g_lit[(tb0 >> 5) + i] = litbits[i];
+					else g_tok[(tb0 >> 5) + i] = tokbits[i];
+				}
+			}
+			__syncthreads();                                       // scan[] and the bitmaps are reused by the next tile
+			if (t == 0) misc[M_NREC] = recbase + tot;
 		}
+		PROF(9);
 	}
 
-	PROF(9);
-	// ---------------- EOB + tail ----------------
+	// ---------------- result: checksums and counts (the entropy stage adds cc, tpbc, tebc) ----------------
 	if (t == 0) {
-		uint32_t carry = misc[M_CARRY_BITS], wordbase = misc[M_WORDBASE];
-		uint32_t lt = lltab[256];
-		uint32_t cc = misc[M_ERR];
-		if (DHT && (lt >> 16) == 0) cc = NXZ_CC_MISSING_CODE;
-		if (DHT && tables[job.dht_index].status) cc = NXZ_CC_INVALID_DHT;
-		uint64_t acc = (uint64_t)misc[M_CARRY_WORD] | ((uint64_t)(lt & 0xffff) << carry);
-		uint32_t bits = carry + (lt >> 16);
-		uint64_t totbits = (uint64_t)wordbase * 32 + bits;
-		uint32_t tpbc = (uint32_t)((totbits + 7) >> 3);
-		if (tpbc > job.dst_cap) cc = cc ? cc : NXZ_CC_TARGET_SPACE;
-		if (cc != NXZ_CC_TARGET_SPACE) {
-			NXZ_GLOBAL uint8_t *o = (NXZ_GLOBAL uint8_t *)job.dst + (size_t)wordbase * 4;
-			for (uint32_t k = 0; k < (bits + 7) / 8; k++) o[k] = (uint8_t)(acc >> (8 * k));
-		}
-		if (cc == 0 && tpbc > total) cc = NXZ_CC_TPBC_GT_SPBC;
 		nxz_batch_result_t r;
-		r.cc = cc; r.tpbc = cc == NXZ_CC_TARGET_SPACE ? 0 : tpbc; r.tebc = (uint32_t)(totbits & 7);
-		r.spbc = total; r.crc = out_crc; r.adler = out_adler; r.subc = 0; r.sfbt = 0;
+		r.cc = 0; r.tpbc = 0; r.tebc = 0;
+		r.spbc = total; r.crc = out_crc; r.adler = out_adler; r.subc = 0;
+		r.sfbt = misc[M_NREC];                                  // match tokens (diagnostic; the entropy stage checks it against the record array's size)
 		results[bid] = r;
 	}
 	if (COUNT) {
@@ -1308,45 +1140,38 @@ __global__ __launch_bounds__(NT) void deflate_kernel(const nxz_batch_job_t *__re
 	}
 }
 
-} // namespace nxz
+} // namespace nxzl77
 
-extern "C" int nxz_debug_set(uint32_t *buf)
+extern "C" int nxz_lz77_prof_set(unsigned long long *buf)
 {
-	return (int)hipMemcpyToSymbol(HIP_SYMBOL(nxz_debug_buf), &buf, sizeof(buf));
+	return (int)hipMemcpyToSymbol(HIP_SYMBOL(nxz_lz77_prof_buf), &buf, sizeof(buf));
 }
 
-extern "C" int nxz_prof_set(unsigned long long *buf)
+// One persistent workgroup per CU; job_counter: one device word per launch in flight (or NULL:
+// workgroups stride over the jobs).  tokens: n x NXZ_TOK_STRIDE bytes of device scratch.
+extern "C" int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n, uint8_t *tokens, nxz_batch_result_t *results,
+			       uint32_t *counts, uint32_t *job_counter, hipStream_t stream)
 {
-	return (int)hipMemcpyToSymbol(HIP_SYMBOL(nxz_prof_buf), &buf, sizeof(buf));
-}
-
-extern "C" int nxz_launch_deflate(int dht, int count, const nxz_batch_job_t *jobs, size_t n,
-				  const nxz_dht_prepared_t *tables, nxz_batch_result_t *results,
-				  uint32_t *counts, uint32_t *job_counter, hipStream_t stream)
-{
-	using namespace nxz;
-	static bool attr_done = false;
-	void (*k)(const nxz_batch_job_t *, const nxz_dht_prepared_t *, nxz_batch_result_t *, uint32_t *, uint32_t, uint32_t *);
-	if (dht) k = count ? deflate_kernel<true, true> : deflate_kernel<true, false>;
-	else     k = count ? deflate_kernel<false, true> : deflate_kernel<false, false>;
-	if (!attr_done) {
-		(void)hipFuncSetAttribute((const void *)deflate_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-		(void)hipFuncSetAttribute((const void *)deflate_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-		(void)hipFuncSetAttribute((const void *)deflate_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-		(void)hipFuncSetAttribute((const void *)deflate_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-		attr_done = true;
-	}
+	using namespace nxzl77;
 	if (n == 0) return 0;
-	static int ncu = 0;
+	void (*k)(const nxz_batch_job_t *, uint8_t *, nxz_batch_result_t *, uint32_t *, uint32_t, uint32_t *);
+	k = count ? lz77_kernel<true> : lz77_kernel<false>;
+	// per device: the attribute belongs to the loaded code object of a device, and so does the CU count
+	static int ncu_of[64];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+	int ncu = __atomic_load_n(&ncu_of[dev], __ATOMIC_ACQUIRE);
 	if (!ncu) {
-		int dev = 0;
+		(void)hipFuncSetAttribute((const void *)lz77_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+		(void)hipFuncSetAttribute((const void *)lz77_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 		hipDeviceProp_t prop;
-		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+		if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
 		if (ncu <= 0) ncu = 256;
+		__atomic_store_n(&ncu_of[dev], ncu, __ATOMIC_RELEASE);
 	}
 	const unsigned grid = (unsigned)(n < (size_t)ncu ? n : (size_t)ncu);
 	if (n <= grid) job_counter = nullptr;                      // one job per workgroup: nothing to draw
 	if (job_counter && hipMemsetAsync(job_counter, 0, sizeof(uint32_t), stream) != hipSuccess) job_counter = nullptr;
-	hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS_BYTES, stream, jobs, tables, results, counts, (uint32_t)n, job_counter);
+	hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS_BYTES, stream, jobs, tokens, results, counts, (uint32_t)n, job_counter);
 	return (int)hipGetLastError();
 }

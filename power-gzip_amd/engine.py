@@ -16,6 +16,9 @@ FC_COMPRESS_FHT_COUNT = 0x04
 FC_COMPRESS_DHT_COUNT = 0x06
 FC_COMPRESS_RESUME_FHT = 0x08
 FC_COMPRESS_RESUME_DHT_COUNT = 0x0E
+FC_COMPRESS_DHTGEN = 0x22           # additive: the engine builds the job's own table (include/nxz_engine.h)
+FC_COMPRESS_DHTGEN_COUNT = 0x26
+FC_COMPRESS_RESUME_DHTGEN = 0x2A
 FC_DECOMPRESS = 0x10
 FC_DECOMPRESS_RESUME = 0x14
 FC_WRAP = 0x1E
@@ -61,6 +64,7 @@ def load_library():
         L.nxz_compress_bound.argtypes = [C.c_size_t]
         L.nxz_batch_compress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nxz_batch_dhtgen.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.nxz_batch_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.nxz_batch_wrap.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.nxz_ctx_sync.argtypes = [C.c_void_p, C.c_void_p]
@@ -138,6 +142,15 @@ class Engine:
                                        self.stream_handle())
         self._check(rc, "nxz_batch_compress")
         return results, counts
+
+    def dhtgen(self, counts, n, tables=None):
+        """device dhtgen: counts = int32/uint32 tensor [n * 316] -> uint8 tensor of n nxz_batch_dht_t"""
+        t = self.torch
+        if tables is None:
+            tables = t.zeros(n * DHT_DTYPE.itemsize, dtype=t.uint8, device=self.dev)
+        self._check(self.L.nxz_batch_dhtgen(self.ctx, counts.data_ptr(), n, tables.data_ptr(), self.stream_handle()),
+                    "nxz_batch_dhtgen")
+        return tables
 
     def decompress(self, jobs, n, results=None, dht_io=None):
         t = self.torch
