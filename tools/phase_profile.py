@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase cycle shares of the deflate kernel (thread 0 of every workgroup)."""
+"""Diagnostic: per-phase cycle shares of the LZ77 kernel (thread 0 of every workgroup)."""
 import ctypes as C, importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench
 pkg = importlib.import_module("power-gzip_amd")
-NAMES = ["load", "cksum", "seed+hdr", "hash", "chain (wave 0)", "M3b dist-1 runs", "pass1", "mark", "pass2", "(tail)", "e-flags + piece links", "M3a members", "match after the chain", "enc-clear", "enc-emit", "enc-flush"]
+NAMES = ["load", "cksum", "seed", "hash", "chain (wave 0)", "M3b dist-1 runs", "pass1", "mark", "pass2 (token walk)", "out (records, counts, bitmaps)", "e-flags + piece links", "M3a members", "match after the chain", "-", "-", "-"]
+FC = {"fht": pkg.FC_COMPRESS_FHT, "dhtgen": pkg.FC_COMPRESS_DHTGEN}[os.environ.get("FC", "fht")]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = pkg.Engine(0)
 src = bench.gen_blocks(torch, eng.dev, n, 0)
@@ -18,16 +19,15 @@ dst = torch.empty((n, 73856), dtype=torch.uint8, device=eng.dev)
 size = int(sys.argv[3]) if len(sys.argv) > 3 else 65536             # bytes of each block that are compressed
 jobs = eng.jobs_strided(src, 65536, np.full(n, size, np.uint32), dst, 73856, 73856)
 prof = torch.zeros(64, dtype=torch.int64, device=eng.dev)
-eng.L.nxz_prof_set.argtypes = [C.c_void_p]
-eng.compress(pkg.FC_COMPRESS_FHT, jobs, n)
+eng.L.nxz_lz77_prof_set.argtypes = [C.c_void_p]
+eng.compress(FC, jobs, n)
 torch.cuda.synchronize()
-assert eng.L.nxz_prof_set(prof.data_ptr()) == 0
-eng.compress(pkg.FC_COMPRESS_FHT, jobs, n)
+assert eng.L.nxz_lz77_prof_set(prof.data_ptr()) == 0
+eng.compress(FC, jobs, n)
 torch.cuda.synchronize()
-eng.L.nxz_prof_set(None)
+eng.L.nxz_lz77_prof_set(None)
 p = prof.cpu().numpy().astype(np.float64) / n
 tot = p[:16].sum()
-print("pass2 wave-steps per block: literal-only %.0f, general %.0f (avg active lanes %.1f)" % (p[16], p[17], p[18] / max(p[17], 1)))
 for i, name in enumerate(NAMES):
     print("%-20s %10.0f cycles/block  %5.1f%%" % (name, p[i], 100 * p[i] / tot))
 print("total %.0f cycles/block (s_memtime ticks = 100 MHz? see guide)" % tot)
