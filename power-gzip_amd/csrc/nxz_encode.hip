@@ -22,42 +22,87 @@
 namespace nxze {
 
 constexpr int NT = 256;
-constexpr uint32_t RPOS = 4096;                 // positions per round
-constexpr uint32_t LANE_BITS_MAX = 288;         // six 48-bit match tokens in 16 positions
+constexpr uint32_t RPOS = 2048;                 // positions per round: 8 per lane, two quads of 4
+constexpr uint32_t LANE_BITS_MAX = 144;         // three 48-bit match tokens in 8 positions
 constexpr uint32_t HDR_WORDS = 74;              // 3 + 2283 bits of a dynamic header at most
-constexpr uint32_t WWORDS = NT * LANE_BITS_MAX / 32 + HDR_WORDS + 2;   // 2380
+constexpr uint32_t WWORDS = NT * LANE_BITS_MAX / 32 + HDR_WORDS + 2;   // 1228
+constexpr uint32_t RECMAX = RPOS / 3 + 6;       // match tokens that can start in one round
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 
-struct Tok {
-	uint32_t lit16, tok16;
-	v4u bytes;
-	uint32_t rec[6];
-};
+// The tokens that start in four consecutive positions, as one bit string (<= 96 bits: a match at
+// the first position and one at the fourth).  Straight-line code, the same for every lane.
+struct Quad { uint32_t a0, a1, a2, nb; };
 
-__device__ __forceinline__ uint32_t byte_at(const v4u &q, uint32_t k)
+template <bool DHT>
+__device__ __forceinline__ Quad encode_quad(const uint32_t *lltab, const uint32_t *dtab, const uint32_t *rec, uint32_t &ri,
+					    uint32_t b, uint32_t lit4, uint32_t tok4, bool &missing)
 {
-	const uint32_t a = (k & 8) ? q.z : q.x, b = (k & 8) ? q.w : q.y;
-	const uint32_t w = (k & 4) ? b : a;
-	return (w >> (8 * (k & 3))) & 0xff;
+	// literals: four look-ups whether or not a literal starts there (a covered position adds no bits)
+	const uint32_t e0 = lltab[b & 0xff], e1 = lltab[(b >> 8) & 0xff], e2 = lltab[(b >> 16) & 0xff], e3 = lltab[b >> 24];
+	uint64_t v[4] = { e0 & 0xffff, e1 & 0xffff, e2 & 0xffff, e3 & 0xffff };
+	uint32_t nbk[4] = { (lit4 & 1) ? e0 >> 16 : 0, (lit4 & 2) ? e1 >> 16 : 0, (lit4 & 4) ? e2 >> 16 : 0, (lit4 & 8) ? e3 >> 16 : 0 };
+	if (DHT) missing |= ((lit4 & 1) && !(e0 >> 16)) || ((lit4 & 2) && !(e1 >> 16)) || ((lit4 & 4) && !(e2 >> 16)) || ((lit4 & 8) && !(e3 >> 16));
+	// matches: at most two start in four positions (they are at least three bytes long), the second
+	// one only at the fourth position behind one at the first
+	if (__ballot(tok4 != 0)) {
+		auto one = [&](uint32_t r, uint64_t &mv, uint32_t &mn) {
+			const uint32_t l3 = r & 0xff, d = (r >> 8) & 0x7fff;
+			uint32_t le = l3 < 8 ? 0 : (29 - (uint32_t)__builtin_clz(l3 | 8));
+			const uint32_t ls = l3 == 255 ? 28 : (le << 2) + (l3 >> le);
+			if (l3 == 255) le = 0;
+			const uint32_t de = d < 4 ? 0 : (30 - (uint32_t)__builtin_clz(d | 4));
+			const uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
+			const uint32_t lt = lltab[257 + ls], dt = dtab[ds];
+			const uint32_t ll = lt >> 16, dl = dt >> 16;
+			if (DHT) missing |= ll == 0 || dl == 0;
+			const uint32_t lo = (lt & 0xffff) | ((l3 & ((1u << le) - 1)) << ll);          // <= 20 bits
+			const uint32_t hi = (dt & 0xffff) | ((d & ((1u << de) - 1)) << dl);           // <= 28 bits
+			mv = (uint64_t)lo | ((uint64_t)hi << (ll + le));
+			mn = ll + le + dl + de;
+		};
+		const uint32_t k1 = (uint32_t)__builtin_ctz(tok4 | 16);                  // 4 = none
+		uint64_t mv; uint32_t mn;
+		const bool miss0 = missing;
+		one(rec[ri], mv, mn);
+		if (!tok4) missing = miss0;
+		ri += tok4 ? 1 : 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) if (k1 == (uint32_t)k) { v[k] = mv; nbk[k] = mn; }
+		if (__ballot(tok4 == 9)) {
+			const bool miss1 = missing;
+			one(rec[ri], mv, mn);
+			if (tok4 != 9) missing = miss1;
+			else { v[3] = mv; nbk[3] = mn; ri++; }
+		}
+	}
+	// one string: token k at the sum of the lengths before it
+	uint64_t lo = nbk[0] ? v[0] : 0, hi = 0;
+	uint32_t off = nbk[0];
+#pragma unroll
+	for (int k = 1; k < 4; k++) {
+		const uint64_t x = nbk[k] ? v[k] : 0;
+		// off <= 48 + 45 here, x < 2^48
+		if (off < 64) { lo |= x << off; hi |= off ? x >> (64 - off) : 0; }
+		else hi |= x << (off - 64);
+		off += nbk[k];
+	}
+	Quad q;
+	q.a0 = (uint32_t)lo; q.a1 = (uint32_t)(lo >> 32); q.a2 = (uint32_t)hi; q.nb = off;
+	return q;
 }
 
-// length / distance symbol of a match record (len - 3 | (dist - 1) << 8), RFC 1951 3.2.5
-struct MatchSym { uint32_t ls, le, lx, ds, de, dx; };
-__device__ __forceinline__ MatchSym match_sym(uint32_t rec)
+// ORs a quad's bits into the window at bit position bitpos
+__device__ __forceinline__ void emit_quad(uint32_t *w, const Quad &q, uint32_t bitpos)
 {
-	MatchSym m;
-	const uint32_t l3 = rec & 0xff, d = (rec >> 8) & 0x7fff;
-	uint32_t le = l3 < 8 ? 0 : (29 - (uint32_t)__builtin_clz(l3 | 8));
-	m.ls = l3 == 255 ? 28 : (le << 2) + (l3 >> le);
-	if (l3 == 255) le = 0;
-	m.le = le;
-	m.lx = l3 & ((1u << le) - 1);
-	const uint32_t de = d < 4 ? 0 : (30 - (uint32_t)__builtin_clz(d | 4));
-	m.ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
-	m.de = de;
-	m.dx = d & ((1u << de) - 1);
-	return m;
+	if (!q.nb) return;
+	const uint32_t sh = bitpos & 31, wi = bitpos >> 5, endw = (sh + q.nb + 31) >> 5;   // dwords touched: 1..4
+	const uint64_t s0 = (uint64_t)q.a0 << sh, s1 = (uint64_t)q.a1 << sh, s2 = (uint64_t)q.a2 << sh;
+	atomicOr(&w[wi], (uint32_t)s0);
+	if (endw > 1) atomicOr(&w[wi + 1], (uint32_t)(s0 >> 32) | (uint32_t)s1);
+	if (endw > 2) atomicOr(&w[wi + 2], (uint32_t)(s1 >> 32) | (uint32_t)s2);
+	if (endw > 3) atomicOr(&w[wi + 3], (uint32_t)(s2 >> 32));
 }
 
 template <bool DHT>
@@ -67,9 +112,10 @@ __global__ __launch_bounds__(NT) void encode_kernel(const nxz_batch_job_t *__res
 {
 	__shared__ uint32_t lltab[288];
 	__shared__ uint32_t dtab[32];
-	__shared__ __attribute__((aligned(16))) uint32_t win[WWORDS + 2];
-	__shared__ uint16_t rankpre[2048];
-	__shared__ uint32_t wsum[8];
+	__shared__ __attribute__((aligned(16))) uint32_t win[2][WWORDS + 2];   // two windows: one fills while the other leaves
+	__shared__ uint32_t recbuf[2][RECMAX + 2];                             // the match records of this round and of the next
+	__shared__ uint16_t rankpre[2048 + 2];                                 // matches in front of every 32 positions; [2048] = all
+	__shared__ uint32_t wsum[2][NT / 64];
 	__shared__ uint32_t errflag;
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const uint32_t bid = blockIdx.x;
@@ -80,33 +126,81 @@ __global__ __launch_bounds__(NT) void encode_kernel(const nxz_batch_job_t *__res
 	const uint32_t n = total - h;
 	const uint8_t NXZ_GLOBAL_AS *src = (const uint8_t NXZ_GLOBAL_AS *)job.src + h;
 	const uint8_t NXZ_GLOBAL_AS *tk = (const uint8_t NXZ_GLOBAL_AS *)tokens_ + (size_t)bid * NXZ_TOK_STRIDE;
-	const uint16_t NXZ_GLOBAL_AS *litb = (const uint16_t NXZ_GLOBAL_AS *)(tk + NXZ_TOK_LITBITS);
-	const uint16_t NXZ_GLOBAL_AS *tokb = (const uint16_t NXZ_GLOBAL_AS *)(tk + NXZ_TOK_MATCHBITS);
+	const uint32_t NXZ_GLOBAL_AS *litb = (const uint32_t NXZ_GLOBAL_AS *)(tk + NXZ_TOK_LITBITS);
+	const uint32_t NXZ_GLOBAL_AS *tokb = (const uint32_t NXZ_GLOBAL_AS *)(tk + NXZ_TOK_MATCHBITS);
 	const uint32_t NXZ_GLOBAL_AS *recs = (const uint32_t NXZ_GLOBAL_AS *)(tk + NXZ_TOK_RECORDS);
 	uint32_t NXZ_GLOBAL_AS *dstw = (uint32_t NXZ_GLOBAL_AS *)job.dst;
 	const uint32_t cap_words = job.dst_cap >> 2;
 	const nxz_dht_prepared_t NXZ_GLOBAL_AS *tb = DHT ? (const nxz_dht_prepared_t NXZ_GLOBAL_AS *)tables_ + (table_per_job ? bid : job.dht_index) : nullptr;
+	const uint32_t nwords = (n + 31) >> 5;
 
-	// ---- tables, window, block header ----
-	for (uint32_t i = t; i < WWORDS + 2; i += NT) win[i] = 0;
-	if (t == 0) errflag = 0;
-	if (DHT) {
-		for (int i = t; i < 288; i += NT) lltab[i] = tb->ll[i];
-		if (t < 32) dtab[t] = tb->d[t];
-	} else {
-		for (int i = t; i < 288; i += NT) {
-			// RFC1951 3.2.6 fixed code; entry = bit-reversed code | len << 16
-			uint32_t len, code;
-			if (i < 144) { len = 8; code = 0x30 + i; }
-			else if (i < 256) { len = 9; code = 0x190 + (i - 144); }
-			else if (i < 280) { len = 7; code = i - 256; }
-			else { len = 8; code = 0xC0 + (i - 280); }
-			lltab[i] = (__builtin_bitreverse32(code) >> (32 - len)) | (len << 16);
+	// What a lane needs of a round is asked for a round ahead, so that the loads' latency hides
+	// behind the work on the round before: its 8 source bytes, the two bitmap words that hold its
+	// 8 positions, and its share of the round's match records (for the LDS copy).
+	struct Fetch { v2u bytes; uint32_t litw, tokw, rec[3]; };
+	auto fetch = [&](uint32_t r0, Fetch &f) {
+		const uint32_t p0 = r0 + 8 * t;
+		f.bytes = (v2u){ 0, 0 }; f.litw = 0; f.tokw = 0;
+		if (p0 < n) {
+			f.litw = litb[p0 >> 5];
+			f.tokw = tokb[p0 >> 5];
+			if (p0 + 8 <= n) f.bytes = *(const v2u NXZ_GLOBAL_AS *)(src + p0);
+			else {
+				// ragged end: nothing is read past the source
+				uint64_t v = 0;
+				for (uint32_t i = 0; i < 8; i++) if (p0 + i < n) v |= (uint64_t)src[p0 + i] << (8 * i);
+				f.bytes = (v2u){ (uint32_t)v, (uint32_t)(v >> 32) };
+			}
 		}
-		if (t < 32) dtab[t] = (__builtin_bitreverse32((uint32_t)t) >> 27) | (5u << 16);
+	};
+	auto fetch_recs = [&](uint32_t r0, Fetch &f) {                // needs rankpre
+		const uint32_t ra = rankpre[r0 >> 5], rb = rankpre[(r0 + RPOS) >> 5 < 2048 ? (r0 + RPOS) >> 5 : 2048];
+#pragma unroll
+		for (int j = 0; j < 3; j++) f.rec[j] = ra + t + 256 * j < rb ? recs[ra + t + 256 * j] : 0;
+	};
+	Fetch nx;
+	fetch(0, nx);                                                // round 0's bytes travel while the tables are set up
+
+	// ---- tables, windows, ranks ----
+	for (uint32_t i = t; i < 2 * (WWORDS + 2); i += NT) (&win[0][0])[i] = 0;
+	if (t == 0) errflag = 0;
+	{
+		const v4u NXZ_GLOBAL_AS *tw = (const v4u NXZ_GLOBAL_AS *)tokb;
+		v4u a = { 0, 0, 0, 0 }, b = a;
+		if (8u * t < nwords) { a = tw[2 * t]; b = tw[2 * t + 1]; }
+		const uint32_t w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+		uint32_t c[8], s = 0;
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			c[k] = s;
+			s += 8u * t + k < nwords ? (uint32_t)__popc(w[k]) : 0;  // (what lies behind the block's last word is not the kernel's)
+		}
+		uint32_t incl = s;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+		if (lane == 63) wsum[0][wave] = incl;
+		if (DHT) {
+			for (int i = t; i < 288; i += NT) lltab[i] = tb->ll[i];
+			if (t < 32) dtab[t] = tb->d[t];
+		} else {
+			for (int i = t; i < 288; i += NT) {
+				// RFC1951 3.2.6 fixed code; entry = bit-reversed code | len << 16
+				uint32_t len, code;
+				if (i < 144) { len = 8; code = 0x30 + i; }
+				else if (i < 256) { len = 9; code = 0x190 + (i - 144); }
+				else if (i < 280) { len = 7; code = i - 256; }
+				else { len = 8; code = 0xC0 + (i - 280); }
+				lltab[i] = (__builtin_bitreverse32(code) >> (32 - len)) | (len << 16);
+			}
+			if (t < 32) dtab[t] = (__builtin_bitreverse32((uint32_t)t) >> 27) | (5u << 16);
+		}
+		__syncthreads();
+		uint32_t off = incl - s;
+		for (int k = 0; k < wave; k++) off += wsum[0][k];
+#pragma unroll
+		for (int k = 0; k < 8; k++) rankpre[8 * t + k] = (uint16_t)(off + c[k]);
+		if (t == NT - 1) rankpre[2048] = (uint16_t)(off + s);
 	}
-	__syncthreads();
-	uint32_t base_bits;                                          // bits already in the window (uniform)
+	uint32_t base_bits;                                          // bits already in the current window (uniform)
 	if (DHT) {
 		const uint32_t hb = tb->dhtlen + 3;                      // BFINAL = 1 as emitted (the host rewrites it, lib/nx_deflate.c:158), BTYPE = 10
 		const uint32_t nw = (hb + 31) >> 5;
@@ -114,137 +208,82 @@ __global__ __launch_bounds__(NT) void encode_kernel(const nxz_batch_job_t *__res
 			const uint32_t cur = i < 74 ? tb->dhtw[i] : 0, prev = i ? tb->dhtw[i - 1] : 0;
 			uint32_t w = (cur << 3) | (i ? prev >> 29 : 5u);
 			if (i == (hb >> 5)) w &= (1u << (hb & 31)) - 1;       // the last, partial dword
-			win[i] = w;
+			win[0][i] = w;
 		}
 		base_bits = hb;
 	} else {
-		if (t == 0) win[0] = 3u;                                 // BFINAL = 1, BTYPE = 01
+		if (t == 0) win[0][0] = 3u;                              // BFINAL = 1, BTYPE = 01
 		base_bits = 3;
 	}
-	// ---- rank of the first match of every 32 positions (exclusive prefix sum of the match bitmap) ----
+	__syncthreads();
+	// round 0's records: no round in front to hide behind
 	{
-		const uint32_t nwords = (n + 31) >> 5;
-		const v4u NXZ_GLOBAL_AS *tw = (const v4u NXZ_GLOBAL_AS *)tokb;
-		v4u a = { 0, 0, 0, 0 }, b = a;
-		if (8u * t < nwords) { a = tw[2 * t]; b = tw[2 * t + 1]; }
-		const uint32_t w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
-		uint32_t c[8], s = 0;
+		fetch_recs(0, nx);
 #pragma unroll
-		for (int k = 0; k < 8; k++) { c[k] = s; s += (uint32_t)__popc(w[k]); }
-		uint32_t incl = s;
-		for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-		if (lane == 63) wsum[wave] = incl;
-		__syncthreads();
-		uint32_t off = incl - s;
-		for (int k = 0; k < wave; k++) off += wsum[k];
-#pragma unroll
-		for (int k = 0; k < 8; k++) rankpre[8 * t + k] = (uint16_t)(off + c[k]);
+		for (int j = 0; j < 3; j++) if (t + 256 * j < RECMAX) recbuf[0][t + 256 * j] = nx.rec[j];
 	}
 	__syncthreads();
 
-	uint32_t wordbase = 0;
+	uint32_t wordbase = 0, par = 0;
 	bool missing = false;
-	for (uint32_t r0 = 0; r0 < n; r0 += RPOS) {
-		const uint32_t p0 = r0 + 16 * t;
-		Tok k{};
-		uint32_t nbits = 0;
-		if (p0 < n) {
-			k.lit16 = litb[p0 >> 4];
-			k.tok16 = tokb[p0 >> 4];
-			if (p0 + 16 <= n) k.bytes = *(const v4u NXZ_GLOBAL_AS *)(src + p0);
-			else {
-				// ragged end: nothing is read past the source
-				uint64_t lo = 0, hi = 0;
-				for (uint32_t i = 0; i < 8; i++) {
-					if (p0 + i < n) lo |= (uint64_t)src[p0 + i] << (8 * i);
-					if (p0 + 8 + i < n) hi |= (uint64_t)src[p0 + 8 + i] << (8 * i);
-				}
-				k.bytes = (v4u){ (uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32) };
-			}
-			uint32_t rank = rankpre[p0 >> 5];
-			if (p0 & 16) rank += (uint32_t)__popc(tokb[(p0 >> 4) - 1]);
-			const uint32_t nm = (uint32_t)__popc(k.tok16);
-#pragma unroll
-			for (int j = 0; j < 6; j++) k.rec[j] = (uint32_t)j < nm ? recs[rank + j] : 0;
-			// pass 1: code lengths
-			uint32_t m = k.lit16;
-			while (m) {
-				const uint32_t kk = (uint32_t)__builtin_ctz(m);
-				m &= m - 1;
-				const uint32_t e = lltab[byte_at(k.bytes, kk)];
-				missing |= DHT && (e >> 16) == 0;
-				nbits += e >> 16;
-			}
-#pragma unroll
-			for (int j = 0; j < 6; j++) {
-				if ((uint32_t)j < nm) {
-					const MatchSym s = match_sym(k.rec[j]);
-					const uint32_t lt = lltab[257 + s.ls], dt = dtab[s.ds];
-					missing |= DHT && ((lt >> 16) == 0 || (dt >> 16) == 0);
-					nbits += (lt >> 16) + s.le + (dt >> 16) + s.de;
-				}
-			}
+	for (uint32_t r0 = 0; r0 < n; r0 += RPOS, par ^= 1) {
+		const Fetch k = nx;
+		const bool more = r0 + RPOS < n;
+		if (more) { fetch(r0 + RPOS, nx); fetch_recs(r0 + RPOS, nx); }
+		uint32_t *w_ = win[par];
+		const uint32_t p0 = r0 + 8 * t;
+		const uint32_t sh8 = p0 & 24;
+		const uint32_t lit8 = (k.litw >> sh8) & 0xff, tok8 = (k.tokw >> sh8) & 0xff;
+		Quad q0{0, 0, 0, 0}, q1{0, 0, 0, 0};
+		if (__ballot((lit8 | tok8) != 0)) {
+			// my first record: matches of the round in front of my positions
+			uint32_t ri = (uint32_t)rankpre[p0 >> 5 < 2048 ? p0 >> 5 : 2048] + (uint32_t)__popc(k.tokw & ((1u << (p0 & 31)) - 1)) - (uint32_t)rankpre[r0 >> 5];
+			if (p0 >= n) ri = 0;
+			q0 = encode_quad<DHT>(lltab, dtab, recbuf[par], ri, k.bytes.x, lit8 & 15, tok8 & 15, missing);
+			q1 = encode_quad<DHT>(lltab, dtab, recbuf[par], ri, k.bytes.y, lit8 >> 4, tok8 >> 4, missing);
 		}
+		const uint32_t nbits = q0.nb + q1.nb;
 		uint32_t incl = nbits;
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-		if (lane == 63) wsum[wave] = incl;
+		if (lane == 63) wsum[par][wave] = incl;
 		__syncthreads();
 		uint32_t bitpos = base_bits + incl - nbits, roundbits = 0;
 #pragma unroll
-		for (int w = 0; w < NT / 64; w++) { const uint32_t s = wsum[w]; if (w < wave) bitpos += s; roundbits += s; }
-		// pass 2: codes into the window, tokens in position order
-		if (nbits) {
-			uint64_t acc = 0;
-			uint32_t accn = bitpos & 31, accw = bitpos >> 5;
-			bool first = true;
-			auto put = [&](uint32_t v, uint32_t nb) {
-				acc |= (uint64_t)v << accn;
-				accn += nb;
-				if (accn >= 32) {
-					if (first) atomicOr(&win[accw], (uint32_t)acc); else win[accw] = (uint32_t)acc;
-					first = false;
-					acc >>= 32; accn -= 32; accw++;
-				}
-			};
-			uint32_t m = k.lit16 | k.tok16, j = 0;
-			while (m) {
-				const uint32_t kk = (uint32_t)__builtin_ctz(m);
-				m &= m - 1;
-				if ((k.tok16 >> kk) & 1) {
-					const uint32_t rec = j == 0 ? k.rec[0] : j == 1 ? k.rec[1] : j == 2 ? k.rec[2] : j == 3 ? k.rec[3] : j == 4 ? k.rec[4] : k.rec[5];
-					j++;
-					const MatchSym s = match_sym(rec);
-					const uint32_t lt = lltab[257 + s.ls], dt = dtab[s.ds];
-					put((lt & 0xffff) | (s.lx << (lt >> 16)), (lt >> 16) + s.le);         // <= 20 bits
-					put((dt & 0xffff) | (s.dx << (dt >> 16)), (dt >> 16) + s.de);         // <= 28 bits
-				} else {
-					const uint32_t e = lltab[byte_at(k.bytes, kk)];
-					put(e & 0xffff, e >> 16);
-				}
-			}
-			if (accn) atomicOr(&win[accw], (uint32_t)acc);
+		for (int w = 0; w < NT / 64; w++) { const uint32_t s = wsum[par][w]; if (w < wave) bitpos += s; roundbits += s; }
+		emit_quad(w_, q0, bitpos);
+		emit_quad(w_, q1, bitpos + q0.nb);
+		// the next round's records (asked for at the top of this round) into their LDS copy
+		if (more) {
+#pragma unroll
+			for (int j = 0; j < 3; j++) if (t + 256 * j < RECMAX) recbuf[par ^ 1][t + 256 * j] = nx.rec[j];
 		}
 		__syncthreads();
+		// this window leaves (whole dwords) and is cleared; its last, partial dword opens the other
+		// window, which the next round fills (atomicOr: that round's lanes may be there already)
 		const uint32_t tot = base_bits + roundbits, nfull = tot >> 5;
-		for (uint32_t i = t; i < nfull; i += NT)
-			if (wordbase + i < cap_words) dstw[wordbase + i] = win[i];
-		const uint32_t keep = win[nfull];
-		__syncthreads();
-		for (uint32_t i = t; i <= nfull; i += NT) win[i] = i == 0 ? keep : 0;
+		for (uint32_t i = t; i < nfull; i += NT) {
+			if (wordbase + i < cap_words) dstw[wordbase + i] = w_[i];
+			w_[i] = 0;
+		}
+		if (t == 0) {
+			const uint32_t keep = w_[nfull];
+			if (keep) atomicOr(&win[par ^ 1][0], keep);
+			w_[nfull] = 0;
+		}
 		wordbase += nfull;
 		base_bits = tot & 31;
-		__syncthreads();
 	}
 	if (missing) errflag = 1;
 	__syncthreads();
+	uint32_t *w_ = win[par];
 	// a job without any round (n == 0) still has its header in the window
 	if (base_bits >= 32) {
 		const uint32_t nfull = base_bits >> 5;
 		for (uint32_t i = t; i < nfull; i += NT)
-			if (wordbase + i < cap_words) dstw[wordbase + i] = win[i];
-		const uint32_t keep = win[nfull];
+			if (wordbase + i < cap_words) dstw[wordbase + i] = w_[i];
+		const uint32_t keep = w_[nfull];
 		__syncthreads();
-		if (t == 0) win[0] = keep;
+		if (t == 0) w_[0] = keep;
 		wordbase += nfull;
 		base_bits &= 31;
 		__syncthreads();
@@ -256,12 +295,12 @@ __global__ __launch_bounds__(NT) void encode_kernel(const nxz_batch_job_t *__res
 		if (wordbase > cap_words) cc = NXZ_CC_TARGET_SPACE;
 		if (DHT && (errflag || (lt >> 16) == 0)) cc = NXZ_CC_MISSING_CODE;
 		if (DHT && tb->status) cc = NXZ_CC_INVALID_DHT;
-		const uint64_t acc = (uint64_t)win[0] | ((uint64_t)(lt & 0xffff) << base_bits);
+		const uint64_t acc = (uint64_t)w_[0] | ((uint64_t)(lt & 0xffff) << base_bits);
 		const uint32_t bits = base_bits + (lt >> 16);
 		const uint64_t totbits = (uint64_t)wordbase * 32 + bits;
 		const uint32_t tpbc = (uint32_t)((totbits + 7) >> 3);
 		if (tpbc > job.dst_cap) cc = cc ? cc : NXZ_CC_TARGET_SPACE;
-		if (cc != NXZ_CC_TARGET_SPACE) {
+		if (cc != NXZ_CC_TARGET_SPACE && (uint64_t)wordbase * 4 + (bits + 7) / 8 <= job.dst_cap) {
 			uint8_t NXZ_GLOBAL_AS *o = (uint8_t NXZ_GLOBAL_AS *)job.dst + (size_t)wordbase * 4;
 			for (uint32_t b = 0; b < (bits + 7) / 8; b++) o[b] = (uint8_t)(acc >> (8 * b));
 		}
