@@ -5,7 +5,7 @@
  * The reference has no LZ77 source (POWER NX silicon; its output is not even
  * reproducible run to run: doc/power_nx_gzip_um.pdf 2.5.9.5, mirrored by
  * lib/nx_dhtgen.c:252-256).  PARITY UNPINNED: this file DEFINES the token
- * choice that the HIP kernel (power-gzip_amd/csrc/nxz_deflate.hip) must
+ * choice that the HIP kernel (power-gzip_amd/csrc/nxz_lz77.hip) must
  * reproduce bit-for-bit.  The definition is position-parallel by construction
  * so that a 64-lane-wavefront implementation gives identical results:
  *
@@ -14,16 +14,33 @@
  *     history + earlier source).  Sub-blocks are matched independently.
  *  2. Every position p with >= 4 bytes left hashes its next 4 bytes
  *     (little-endian load * 0x9E3779B1 >> (32-HBITS)).
- *  3. head[h] holds the LARGEST position inserted so far with hash h.
- *     Window bytes are inserted first.  Block positions are handled in
- *     chunks of CHUNK positions: all positions of a chunk look up head[]
- *     (state before the chunk), then all are inserted (max wins).
+ *  3. Every hash value owns a bucket of two entries: the NEWEST position
+ *     inserted so far with that hash and the one that was the newest before
+ *     it (2-way, oldest out).  Window bytes are inserted first, in order.
+ *     Block positions are handled in chunks of CHUNK positions: all
+ *     positions of a chunk look their bucket up (state before the chunk),
+ *     then all are inserted: the largest position of the chunk with that
+ *     hash becomes the newest entry (other positions of the same chunk with
+ *     the same hash leave no trace).  The second entries follow a PIECE of
+ *     512 positions late (pieces are counted from the start of the PTILE
+ *     tile; the tile's last piece may be shorter): chunk after chunk of a
+ *     piece, a bucket that a chunk inserted into is noted with what was its
+ *     newest entry before that chunk; the notes of piece c become the second
+ *     entries after the lookups of piece c + 1 (all notes at the end of a
+ *     tile).  So lookups of piece c see the second entries as the inserts
+ *     up to piece c - 2 left them: the kernel's chain wave must not wait
+ *     for a lookup before it inserts, and its second entries live in device
+ *     memory, a piece of latency away.
  *     Positions deep inside a byte run (the 12 bytes p-8 .. p+3 all equal)
  *     take no part in the table, neither lookup nor insert.
- *  4. A candidate q is a match if dist = p-q <= 32768 and >= 4 bytes agree;
- *     it is extended to at most 258 bytes / end of sub-block.  A second
- *     candidate at distance 1 is tried when load32(p-1) == load32(p)
- *     (byte runs); the longer wins, ties go to the smaller distance.
+ *  4. A bucket entry q is a candidate if dist = p-q <= 32768 and >= 4 bytes
+ *     agree.  Of two candidates the one with more equal bytes among the
+ *     first 8 is taken, the newest on a tie (8 bytes decide: what a lane can
+ *     compare in one step); it is extended to at most 258 bytes / end of
+ *     sub-block.  Another candidate at distance 1 is tried when
+ *     load32(p-1) == load32(p) (byte runs); the longer wins, ties go to the
+ *     smaller distance.  (Single entry per bucket: 0.911 x zlib -1 on
+ *     repetitive tables, 0.945 x Z_FIXED on the bench blocks; two: 0.99 / 0.98.)
  *  5. Parsing is greedy inside segments of PSEG bytes (relative to the
  *     sub-block start): a match is truncated at the segment end and dropped
  *     if fewer than 3 bytes remain.  One-step lazy evaluation: a match of
@@ -50,6 +67,9 @@
 #endif
 #ifndef NXO_RLE
 #define NXO_RLE 1
+#endif
+#ifndef NXO_PIECE
+#define NXO_PIECE 512
 #endif
 #define MINMATCH 4
 #define MAXMATCH 258
@@ -106,7 +126,7 @@ static uint32_t walk(const uint8_t *w, uint32_t h, const uint16_t *mlen, const u
 	return p;
 }
 
-/* debug taps (tools/debug_tokens.py) */
+/* debug taps */
 uint16_t *nxo_dbg_mlen, *nxo_dbg_mdist; uint32_t *nxo_dbg_x;
 
 /* one sub-block: w[0..h) window, w[h..h+n) block.  n <= NXO_SUBBLOCK, h <= NXO_WINDOW */
@@ -126,20 +146,26 @@ static inline int deep_in_run(const uint8_t *w, uint32_t r)
 
 static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *tok)
 {
-	static __thread uint32_t head[1u << NXO_HBITS];
+	static __thread uint32_t head[1u << NXO_HBITS];    /* newest entry (position + 1; 0 == empty) */
+	static __thread uint32_t head2[1u << NXO_HBITS];   /* the one before it */
+	static __thread uint16_t pend_h[2][NXO_PIECE], pend_v[2][NXO_PIECE];   /* notes of the current piece [0] and of the one before [1] */
+	uint32_t npend[2] = { 0, 0 };
 	static __thread uint16_t mlen[NXO_SUBBLOCK];
 	static __thread uint16_t mdist[NXO_SUBBLOCK];
 	const uint32_t end = h + n;
 	uint32_t c, r, ntok = 0;
 
 	memset(head, 0, sizeof(head));
+	memset(head2, 0, sizeof(head2));
 	/* 3. window seeding (entries are position+1; 0 == empty) */
 	for (r = 0; r < h && r + 4 <= end; r++) {
 		uint32_t hv = hash4(ld32(w + r));
 		if (deep_in_run(w, r))
 			continue;
-		if (head[hv] < r + 1)
+		if (head[hv] < r + 1) {
+			head2[hv] = head[hv];
 			head[hv] = r + 1;
+		}
 	}
 	/* 2-4. match finding per chunk */
 	for (c = 0; c < n; c += NXO_CHUNK) {
@@ -150,10 +176,17 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 			r = h + j;
 			if (r + 4 <= end) {
 				uint32_t v = ld32(w + r);
-				uint32_t cand = deep_in_run(w, r) ? 0 : head[hash4(v)];
+				int deep = deep_in_run(w, r);
+				uint32_t cand = deep ? 0 : head[hash4(v)], cand2 = deep ? 0 : head2[hash4(v)];
 				uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-				if (cand != 0 && r - (cand - 1) <= NXO_WINDOW &&
-				    ld32(w + cand - 1) == v) {
+				uint32_t cap8 = maxlen < 8 ? maxlen : 8, a1 = 0, a2 = 0;
+				if (cand != 0 && r - (cand - 1) <= NXO_WINDOW && ld32(w + cand - 1) == v)
+					a1 = match_len(w + cand - 1, w + r, cap8);
+				if (cand2 != 0 && r - (cand2 - 1) <= NXO_WINDOW && ld32(w + cand2 - 1) == v)
+					a2 = match_len(w + cand2 - 1, w + r, cap8);
+				if (a2 > a1)
+					cand = cand2;
+				if (a1 || a2) {
 					len = match_len(w + cand - 1, w + r, maxlen);
 					dist = r - (cand - 1);
 				}
@@ -174,9 +207,30 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 			r = h + j;
 			if (r + 4 <= end && !deep_in_run(w, r)) {
 				uint32_t hv = hash4(ld32(w + r));
-				if (head[hv] < r + 1)
+				if (head[hv] < r + 1) {
+					if (head[hv] < h + c + 1) {   /* the newest entry from before this chunk: second entry, later */
+						pend_h[0][npend[0]] = (uint16_t)hv;
+						pend_v[0][npend[0]++] = (uint16_t)head[hv];
+					}
 					head[hv] = r + 1;
+				}
 			}
+		}
+		/* end of a piece: the notes of the piece before become second entries; end of the tile
+		 * (or of the data): those of this piece too */
+		if ((cend % NXO_PTILE) % NXO_PIECE == 0 || cend == n) {
+			int tile_end = cend % NXO_PTILE == 0 || cend == n;
+			for (j = 0; j < npend[1]; j++)
+				head2[pend_h[1][j]] = pend_v[1][j];
+			if (tile_end) {
+				for (j = 0; j < npend[0]; j++)
+					head2[pend_h[0][j]] = pend_v[0][j];
+				npend[0] = 0;
+			}
+			memcpy(pend_h[1], pend_h[0], npend[0] * sizeof(uint16_t));
+			memcpy(pend_v[1], pend_v[0], npend[0] * sizeof(uint16_t));
+			npend[1] = npend[0];
+			npend[0] = 0;
 		}
 	}
 	if (nxo_dbg_mlen) { memcpy(nxo_dbg_mlen, mlen, n * 2); memcpy(nxo_dbg_mdist, mdist, n * 2); }

@@ -31,15 +31,14 @@ typedef struct nxz_dht_prepared {
 // the compiler drain the LDS queue completely at every wait that follows them.
 #define NXZ_GLOBAL_AS __attribute__((address_space(1)))
 extern "C" {
-int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n, uint8_t *tokens, nxz_batch_result_t *results,
+#define NXZ_LZ77_MAX_GRID 512          /* workgroups of one LZ77 launch (one per CU) */
+size_t nxz_lz77_cand2_bytes(void);     /* scratch of a launch: the second bucket entries in transit */
+int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n, uint8_t *tokens, uint16_t *cand2, nxz_batch_result_t *results,
 		    uint32_t *counts, uint32_t *job_counter, hipStream_t stream);
 int nxz_launch_encode(int dht, int table_per_job, const nxz_batch_job_t *jobs, size_t n, const uint8_t *tokens,
 		      const nxz_dht_prepared_t *tables, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_dhtgen(const uint32_t *counts, size_t n, nxz_dht_prepared_t *prepared,
 		      nxz_batch_dht_t *tables, hipStream_t stream);   /* device dhtgen: counts[n][316] -> tables (either output may be NULL) */
-int nxz_launch_deflate(int dht, int count, const nxz_batch_job_t *jobs, size_t n,
-		       const nxz_dht_prepared_t *tables, nxz_batch_result_t *results,
-		       uint32_t *counts, uint32_t *job_counter, hipStream_t stream);   /* job_counter: one device word per launch in flight, or NULL */
 int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_dht_prepared_t *out, hipStream_t stream);
 int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,

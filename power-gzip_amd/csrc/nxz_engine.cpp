@@ -1,5 +1,5 @@
 // nxz_engine.cpp -- host side of libnxz_engine.so: the C ABI of include/nxz_engine.h
-// on top of the HIP kernels (nxz_deflate.hip, nxz_inflate.hip, nxz_misc.hip).
+// on top of the HIP kernels (nxz_lz77.hip, nxz_dhtgen.hip, nxz_encode.hip, nxz_inflate*.hip, nxz_misc.hip).
 //
 // What it replaces in the reference (paths relative to the libnxz tree):
 //   lib/gzip_vas.c  -- open /dev/crypto/nx-gzip, VAS window, copy/paste of the
@@ -50,6 +50,7 @@ struct Slot {
 	nxz_dht_prepared_t *d_prep = nullptr;
 	uint32_t *h_cnt = nullptr, *d_cnt = nullptr;
 	uint8_t *d_tok = nullptr;                       // one job's tokens between the LZ77 and the entropy kernel
+	uint16_t *d_cand2 = nullptr;                    // LZ77 scratch (one workgroup's worth is used)
 	bool busy = false;
 };
 
@@ -75,6 +76,7 @@ struct nxz_ctx {
 		uint8_t *d_tokens = nullptr;              // chunk x NXZ_TOK_STRIDE
 		nxz_dht_prepared_t *d_gen = nullptr;      // tables the device generated, one per job of the chunk
 		uint32_t *d_counts = nullptr;             // symbol counts when the caller did not ask for them
+		uint16_t *d_cand2 = nullptr;              // LZ77 kernel: second bucket entries in transit, 32 KiB per workgroup
 		size_t chunk_cap = 0;
 		void release() {
 			if (d_prepared) (void)hipFree(d_prepared);
@@ -82,6 +84,7 @@ struct nxz_ctx {
 			if (d_tokens) (void)hipFree(d_tokens);
 			if (d_gen) (void)hipFree(d_gen);
 			if (d_counts) (void)hipFree(d_counts);
+			if (d_cand2) (void)hipFree(d_cand2);
 			*this = Scratch();
 		}
 	};
@@ -125,6 +128,7 @@ static bool slot_init(Slot &s)
 	HIPCHK(hipHostMalloc((void **)&s.h_cnt, 316 * 4), return false);
 	HIPCHK(hipMalloc((void **)&s.d_cnt, 316 * 4), return false);
 	HIPCHK(hipMalloc((void **)&s.d_tok, NXZ_TOK_STRIDE), return false);
+	HIPCHK(hipMalloc((void **)&s.d_cand2, nxz_lz77_cand2_bytes() / NXZ_LZ77_MAX_GRID), return false);
 	return true;
 }
 
@@ -134,7 +138,7 @@ static void slot_free(Slot &s)
 	(void)hipHostFree(s.h_in); (void)hipHostFree(s.h_out); (void)hipFree(s.d_in); (void)hipFree(s.d_out);
 	(void)hipHostFree(s.h_job); (void)hipFree(s.d_job); (void)hipHostFree(s.h_res); (void)hipFree(s.d_res);
 	(void)hipHostFree(s.h_dht); (void)hipFree(s.d_dht); (void)hipFree(s.d_prep);
-	(void)hipHostFree(s.h_cnt); (void)hipFree(s.d_cnt); (void)hipFree(s.d_tok);
+	(void)hipHostFree(s.h_cnt); (void)hipFree(s.d_cnt); (void)hipFree(s.d_tok); (void)hipFree(s.d_cand2);
 	s = Slot();
 }
 
@@ -202,10 +206,16 @@ extern "C" int nxz_ctx_sync(nxz_ctx_t *c, void *stream)
 // ---------------------------------------------------------------------------
 // batched, device-resident interface
 // ---------------------------------------------------------------------------
-// Jobs per launch of the three compress kernels: bounds the token scratch (104 KiB per job) and
-// keeps a chunk's tokens (about the size of its input) inside the 256 MiB Infinity Cache between the
-// LZ77 kernel that writes them and the entropy kernel that reads them.
-static constexpr size_t COMPRESS_CHUNK = 2048;
+// Jobs per launch of the three compress kernels: bounds the token scratch (104 KiB per job, 832 MiB
+// for 8192).  Larger chunks cost memory, smaller ones time: the LZ77 kernel is one persistent
+// workgroup per CU, and at the end of a launch CUs idle until the last job is done (65536 synthetic
+// blocks: 124 GiB/s with 2048 jobs per launch, 129 with 4096, 131 with 8192, 133 with 16384).
+static size_t compress_chunk()
+{
+	static const size_t v = [] { const char *e = getenv("NXZ_COMPRESS_CHUNK"); size_t x = e ? (size_t)strtoull(e, nullptr, 0) : 0; return x >= 256 ? x : (size_t)8192; }();
+	return v;
+}
+#define COMPRESS_CHUNK compress_chunk()
 
 // The compress function codes: LZ77 kernel (tokens, counts, checksums) -> [table generator] ->
 // entropy kernel, chunk after chunk on the caller's stream.
@@ -238,6 +248,7 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 			HIPCHK(hipMalloc((void **)&r.d_counts, chunk * 316 * sizeof(uint32_t)), return -ENOMEM);
 			r.chunk_cap = chunk;
 		}
+		if (!r.d_cand2) HIPCHK(hipMalloc((void **)&r.d_cand2, nxz_lz77_cand2_bytes()), return -ENOMEM);
 		if (isdht && !gen && r.prepared_cap < ntables) {
 			if (r.d_prepared) { (void)hipStreamSynchronize(s); (void)hipFree(r.d_prepared); }
 			r.d_prepared = nullptr; r.prepared_cap = 0;
@@ -252,18 +263,6 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 		int rc = nxz_launch_dht_prepare(dht, ntables, prepared, s);
 		if (rc) { set_err("dht prepare launch", (hipError_t)rc); return -EIO; }
 	}
-	// (measurement knob: the single-kernel path of round 1, for comparison runs)
-	static const bool fused = getenv("NXZ_FUSED") && atoi(getenv("NXZ_FUSED"));
-	if (fused && !gen) {
-		uint32_t *jc = nullptr;
-		{
-			std::lock_guard<std::mutex> g(c->mtx);
-			if (c->d_job_counters) jc = c->d_job_counters + (c->next_counter++ % JOB_COUNTERS);
-		}
-		int rc = nxz_launch_deflate(isdht, count, jobs, n, prepared, results, counts, jc, s);
-		if (rc) { set_err("deflate launch", (hipError_t)rc); return -EIO; }
-		return 0;
-	}
 	for (size_t off = 0; off < n; off += COMPRESS_CHUNK) {
 		const size_t m = n - off < COMPRESS_CHUNK ? n - off : COMPRESS_CHUNK;
 		uint32_t *jc = nullptr;
@@ -272,7 +271,7 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 			if (c->d_job_counters) jc = c->d_job_counters + (c->next_counter++ % JOB_COUNTERS);
 		}
 		uint32_t *cnt = count ? counts + off * 316 : gen ? sc.d_counts : nullptr;
-		int rc = nxz_launch_lz77(cnt != nullptr, jobs + off, m, sc.d_tokens, results + off, cnt, jc, s);
+		int rc = nxz_launch_lz77(cnt != nullptr, jobs + off, m, sc.d_tokens, sc.d_cand2, results + off, cnt, jc, s);
 		if (rc) { set_err("lz77 launch", (hipError_t)rc); return -EIO; }
 		if (gen) {
 			rc = nxz_launch_dhtgen(cnt, m, sc.d_gen, nullptr, s);
@@ -569,7 +568,7 @@ static int run_compress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 		if (nxz_launch_dht_prepare(s->d_dht, 1, s->d_prep, s->stream)) return -EIO;
 	}
 	const bool gen = nxz_fc_is_dhtgen(fc);
-	if (nxz_launch_lz77(count || gen, s->d_job, 1, s->d_tok, s->d_res, s->d_cnt, nullptr, s->stream)) return -EIO;
+	if (nxz_launch_lz77(count || gen, s->d_job, 1, s->d_tok, s->d_cand2, s->d_res, s->d_cnt, nullptr, s->stream)) return -EIO;
 	if (gen && nxz_launch_dhtgen(s->d_cnt, 1, s->d_prep, nullptr, s->stream)) return -EIO;
 	if (nxz_launch_encode(dht, 0, s->d_job, 1, s->d_tok, s->d_prep, s->d_res, s->stream)) return -EIO;
 	HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s->stream), return -EIO);

@@ -491,7 +491,7 @@ __device__ const PowTab CRC_POW = make_pow();
 // those into 64-byte slices: a thread feeds its slices through a slice-by-4 table (16-byte
 // loads, v_dot4 for the Adler sums), weighs a slice's raw CRC by x^(8 * bytes that follow it in
 // the chunk), and the XOR of all of them is the chunk's raw CRC (same scheme as the deflate
-// kernel, nxz_deflate.hip).  Outputs that are not 16-byte aligned take the bytewise path.
+// kernel of round 1).  Outputs that are not 16-byte aligned take the bytewise path.
 __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__restrict__ jobs, nxz_batch_result_t *__restrict__ results)
 {
 	__shared__ uint32_t T[1024];            // T[k*256 + i] = i advanced by k+1 zero bytes

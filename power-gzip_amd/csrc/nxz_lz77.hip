@@ -61,6 +61,9 @@ constexpr uint32_t MAXMATCH = 258;
 constexpr uint32_t WINDOW = 32768;
 constexpr uint32_t LCAP = 40;            // lane-serial tail extension stops here; 16 lanes per tail beyond
 constexpr uint32_t NOHASH = 0xFFFFu;
+// device scratch of a workgroup (16-bit units): carries a tile's second bucket entries from the chain
+// wave to the match waves (+ room for a piece past the end)
+constexpr uint32_t C2_STRIDE = PTILE + 1024;
 
 // ---- LDS carve (bytes) ----
 constexpr uint32_t OFF_IN    = 0;                        // 65536 + 32 pad
@@ -210,7 +213,7 @@ __device__ __forceinline__ uint32_t walk_step(const Walk &w, uint32_t p, uint32_
 
 template <bool COUNT>
 __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restrict__ jobs,
-						  uint8_t *__restrict__ tokens,
+						  uint8_t *__restrict__ tokens, uint16_t *__restrict__ cand2,
 						  nxz_batch_result_t *__restrict__ results,
 						  uint32_t *__restrict__ counts, uint32_t njobs, uint32_t *__restrict__ next_job)
 {
@@ -384,18 +387,38 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	PROF(1);
 
 	// ---------------- seed head[] with the window ----------------
-	for (uint32_t r = t; r < h; r += NT)
-		if (r + 4 <= end) {
-			const uint32_t v = lds_ld32(inw, r);
-			const bool deep = r >= 8 && lds_ld32(inw, r - 8) == v && lds_ld32(inw, r - 4) == v && v == __builtin_amdgcn_alignbyte(v, v, 1);
-			if (!deep) atomicMax(&head[hash4(v)], r + 1);
-		}
+	// A bucket is one dword of head[]: the newest position with that hash (+ 1; 0 = empty;
+	// positions are below 65533) in the lower half, the entry that was the newest before it in the
+	// upper half.  Of the window the two largest positions of a bucket are wanted: first the largest
+	// (atomic max, order free; collected in cand[], which is free until the first tile), then the
+	// largest of the others (in head[] itself, still whole dwords), then both packed.
+	if (h) {
+		uint32_t *top = (uint32_t *)cand;
+		for (uint32_t i = t; i < HSIZE; i += NT) top[i] = 0;
+		__syncthreads();
+		for (uint32_t r = t; r < h; r += NT)
+			if (r + 4 <= end) {
+				const uint32_t v = lds_ld32(inw, r);
+				const bool deep = r >= 8 && lds_ld32(inw, r - 8) == v && lds_ld32(inw, r - 4) == v && v == __builtin_amdgcn_alignbyte(v, v, 1);
+				if (!deep) atomicMax(&top[hash4(v)], r + 1);
+			}
+		__syncthreads();
+		for (uint32_t r = t; r < h; r += NT)
+			if (r + 4 <= end) {
+				const uint32_t v = lds_ld32(inw, r);
+				const bool deep = r >= 8 && lds_ld32(inw, r - 8) == v && lds_ld32(inw, r - 4) == v && v == __builtin_amdgcn_alignbyte(v, v, 1);
+				if (!deep && top[hash4(v)] != r + 1) atomicMax(&head[hash4(v)], r + 1);
+			}
+		__syncthreads();
+		for (uint32_t i = t; i < HSIZE; i += NT) head[i] = top[i] | (head[i] << 16);
+	}
 
 	// where this job's tokens go
 	NXZ_GLOBAL uint8_t *tk = (NXZ_GLOBAL uint8_t *)tokens + (size_t)bid * NXZ_TOK_STRIDE;
 	NXZ_GLOBAL uint32_t *g_lit = (NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_LITBITS);
 	NXZ_GLOBAL uint32_t *g_tok = (NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_MATCHBITS);
 	NXZ_GLOBAL uint32_t *g_rec = (NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_RECORDS);
+	NXZ_GLOBAL uint16_t *g_c2 = (NXZ_GLOBAL uint16_t *)cand2 + (size_t)blockIdx.x * C2_STRIDE;   // the second bucket entries of the tile in work
 	__syncthreads();
 
 	Walk W{inw, mlen, cand, h, 0, end};
@@ -490,55 +513,79 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 			// for a result inside a piece.  The slot offsets of the next piece are fetched ahead and
 			// the candidate positions of the previous piece (16 bit) are written one piece late, so no LDS round trip is exposed.
 			// Publishing needs no wait either: the flag store follows the data stores in LDS order.
-			const uint8_t *headb = (const uint8_t *)head;
+			uint8_t *headb = (uint8_t *)head;
 			__builtin_amdgcn_s_setprio(3);                    // the chain is the critical path of this phase
-			// Four pieces per loop trip in straight-line code (the compiler drains the LDS queue at a
-			// loop back edge); pieces past the end work on the dummy slot.
-			auto steps = [&](auto half, const uint4 pk, uint32_t piece, uint32_t (&old)[8]) {
-				constexpr int U0 = decltype(half)::value * 4;
-				const uint32_t off[8] = { pk.x & 0xffff, pk.x >> 16, pk.y & 0xffff, pk.y >> 16, pk.z & 0xffff, pk.z >> 16, pk.w & 0xffff, pk.w >> 16 };
+			// Per 64-position step: read the bucket (both entries), store my position + 1 over its
+			// newest entry -- a plain 16-bit store: of the lanes of one store instruction that hit the
+			// same bucket the highest, i.e. the largest position, lands last (tools/micro/
+			// lds_write_order.hip) -- so nothing in a step waits for a result; the LDS executes one
+			// wave's operations in order, lookup(k + 1) only has to be ISSUED after insert(k).  What the
+			// steps of a piece read (the newest entries before each chunk) is stored as the second
+			// entry of their buckets once the NEXT piece has done its lookups (oracle/nxz_lz77.c step
+			// 3); by then it has long arrived, and so the piece is handed over at that point too: the
+			// newest entries into cand[] (transposed, 16 bytes per lane), the second entries -- no room
+			// in LDS -- through this workgroup's ring in device scratch (same layout, one store per
+			// piece, it stays in L2); a piece is published when the store of the piece behind it has
+			// been issued and its own has been acknowledged.
+			auto unpack = [](const uint4 pk, uint32_t (&off)[8]) {
+				off[0] = pk.x & 0xffff; off[1] = pk.x >> 16; off[2] = pk.y & 0xffff; off[3] = pk.y >> 16;
+				off[4] = pk.z & 0xffff; off[5] = pk.z >> 16; off[6] = pk.w & 0xffff; off[7] = pk.w >> 16;
+			};
+			auto steps = [&](const uint4 pk, uint32_t piece, uint32_t (&old)[8]) {
+				uint32_t off[8]; unpack(pk, off);
 #pragma unroll
-				for (int u = U0; u < U0 + 4; u++) {
+				for (int u = 0; u < 8; u++) {
 					uint32_t *slot = (uint32_t *)(headb + off[u]);
 					old[u] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					__builtin_amdgcn_wave_barrier();
-					atomicMax(slot, h + tb0 + (piece << 9) + 64 * u + lane + 1);
+					*(uint16_t *)slot = (uint16_t)(h + tb0 + (piece << 9) + 64 * u + lane + 1);
 					__builtin_amdgcn_wave_barrier();
 				}
 			};
-			auto emit = [&](uint32_t (&o)[8], uint32_t piece) {
-				// position + 1 (0 = empty slot), 16 bits each; the consumer subtracts the 1
+			auto note = [&](const uint4 pk, const uint32_t (&old)[8]) {
+				uint32_t off[8]; unpack(pk, off);
+#pragma unroll
+				for (int u = 0; u < 8; u++) *(uint16_t *)(headb + off[u] + 2) = (uint16_t)old[u];
+				__builtin_amdgcn_wave_barrier();
+			};
+			auto hand = [&](const uint32_t (&o)[8], uint32_t piece) {
+				// position + 1 (0 = empty), 16 bits each; the consumer subtracts the 1
+				typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 				((uint4 *)cand)[(piece << 6) + lane] = make_uint4(__builtin_amdgcn_perm(o[1], o[0], 0x05040100), __builtin_amdgcn_perm(o[3], o[2], 0x05040100),
 										  __builtin_amdgcn_perm(o[5], o[4], 0x05040100), __builtin_amdgcn_perm(o[7], o[6], 0x05040100));
+				((NXZ_GLOBAL v4u *)g_c2)[(piece << 6) + lane] = (v4u){ __builtin_amdgcn_perm(o[1], o[0], 0x07060302), __builtin_amdgcn_perm(o[3], o[2], 0x07060302),
+										    __builtin_amdgcn_perm(o[5], o[4], 0x07060302), __builtin_amdgcn_perm(o[7], o[6], 0x07060302) };
 				__builtin_amdgcn_wave_barrier();
-				if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__builtin_amdgcn_s_waitcnt(0x0F71);                // vmcnt(1): all but this piece's store
+				__builtin_amdgcn_wave_barrier();
+				if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // pieces below `piece`
 				__builtin_amdgcn_wave_barrier();
 			};
 			const uint32_t dm = (HSIZE + lane) * 4 | ((HSIZE + lane) * 4) << 16;
 			const uint4 dummy = make_uint4(dm, dm, dm, dm);
-			for (uint32_t base = 0; base < npieces; base += 4) {
+			// two pieces per loop trip (two register sets, no moves); a piece past the end works on the dummy slots
+			uint4 pkB = dummy;
+			uint32_t oA[8], oB[8];
+			for (uint32_t base = 0; base < npieces; base += 2) {
 				const uint4 *cp = (const uint4 *)cand + (base << 6) + lane;
-				// (unconditional 16-byte loads of an existing piece, then a select: a branch would split
-				// them into dword loads)
-				const uint32_t last = npieces - 1 - base;              // >= 0
-				const uint4 l1 = cp[64 * (last < 1 ? last : 1)], l2 = cp[64 * (last < 2 ? last : 2)], l3 = cp[64 * (last < 3 ? last : 3)];
-				const uint4 pk0 = cp[0];
-				const uint4 pk1 = last >= 1 ? l1 : dummy, pk2 = last >= 2 ? l2 : dummy, pk3 = last >= 3 ? l3 : dummy;
-				uint32_t o0[8], o1[8], o2[8], o3[8];
-				// a piece's results are packed and published half a piece later: the wait for them
-				// then leaves the younger operations in flight
-				const std::integral_constant<int, 0> H0; const std::integral_constant<int, 1> H1;
-				steps(H0, pk0, base, o0); steps(H1, pk0, base, o0);
-				steps(H0, pk1, base + 1, o1);
-				emit(o0, base);
-				steps(H1, pk1, base + 1, o1);
-				steps(H0, pk2, base + 2, o2);
-				emit(o1, base + 1);
-				steps(H1, pk2, base + 2, o2);
-				steps(H0, pk3, base + 3, o3);
-				emit(o2, base + 2);
-				steps(H1, pk3, base + 3, o3);
-				emit(o3, base + 3);
+				const bool two = base + 1 < npieces;
+				const uint4 l1 = cp[two ? 64 : 0];                     // (unconditional 16-byte load of an existing piece, then a select)
+				const uint4 pkA = cp[0];
+				steps(pkA, base, oA);
+				if (base) { note(pkB, oB); hand(oB, base - 1); }
+				pkB = two ? l1 : dummy;
+				steps(pkB, base + 1, oB);
+				note(pkA, oA);
+				hand(oA, base);
+			}
+			// the tile's last piece (its notes too: nothing is pending across tiles)
+			{
+				const uint32_t lastp = ((npieces + 1) & ~1u) - 1;
+				note(pkB, oB);
+				hand(oB, lastp);
+				__builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+				__builtin_amdgcn_wave_barrier();
+				if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], npieces, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 			__builtin_amdgcn_s_setprio(0);
 		}
@@ -735,6 +782,13 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 					auto quad = [&](auto fullt) {
 						// FULL: far enough from the end of the tile and of the data, no clamps needed
 						constexpr bool FULL = decltype(fullt)::value;
+						// the second bucket entries of my four positions: device scratch, written by the chain
+						// wave (this CU's L1 may hold the previous tile's: read past it)
+						// (transposed like cand[] before it is turned back: position w of the piece at 8 (w % 64) + w / 64)
+						uint32_t q2[4];
+#pragma unroll
+						for (int j = 0; j < 4; j++)
+							q2[j] = __hip_atomic_load(g_c2 + (piece << 9) + (4 * (lane & 15) + j) * 8 + 4 * it + (lane >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						const uint2 qq = *(const uint2 *)(cand + i4);
 						// deep-in-run positions took no part in the table (what the chain wave left
 						// in their place is meaningless): flags i-7 .. i+3 all set
@@ -745,20 +799,32 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 						uint32_t dA[4];
 #pragma unroll
 						for (int j = 0; j < 4; j++) {
-							const uint32_t qc = (uint16_t)((uint16_t)((j & 2 ? qq.y : qq.x) >> (16 * (j & 1))) - 1);   // candidate position from the chain (0xffff = none)
 							const uint32_t i = i4 + j, r = r4 + j;
 							const bool ok = (FULL || (i < tn && r + 4 <= end)) && ((w14 >> j) & 0x7ff) != 0x7ff;
 							const uint32_t maxlen = FULL || end - r >= MAXMATCH ? MAXMATCH : end - r;
-							dA[j] = r - qc - 1;                         // distance - 1; wraps to something huge if qc >= r
-							const bool qok = ok && dA[j] < WINDOW;
-							const uint32_t q = FULL || qok ? qc : 0;
 							const uint32_t v = j ? __builtin_amdgcn_alignbyte(d1, d0, j) : d0, v4 = j ? __builtin_amdgcn_alignbyte(d2, d1, j) : d1;
-							const uint32_t qa = q >> 2, u0 = inw[qa], u1 = inw[qa + 1], u2 = inw[qa + 2];
-							const uint32_t qv = __builtin_amdgcn_alignbyte(u1, u0, q & 3), qv4 = __builtin_amdgcn_alignbyte(u2, u1, q & 3);
-							okA[j] = qok && qv == v;
-							const uint32_t x = qv4 ^ v4;
-							uint32_t lenA = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
-							if (!FULL && lenA > maxlen) lenA = maxlen;
+							// a bucket entry (position + 1 from the chain, 0 = none): valid if inside the
+							// window with four equal bytes; n = equal bytes among the first eight
+							auto probe = [&](uint32_t entry, uint32_t &dist1, uint32_t &n8) -> bool {
+								const uint32_t qc = (uint16_t)(entry - 1);      // 0xffff = none
+								dist1 = r - qc - 1;                             // distance - 1; wraps to something huge if qc >= r
+								const bool qok = ok && dist1 < WINDOW;
+								const uint32_t q = FULL || qok ? qc : 0;
+								const uint32_t qa = q >> 2, u0 = inw[qa], u1 = inw[qa + 1], u2 = inw[qa + 2];
+								const uint32_t qv = __builtin_amdgcn_alignbyte(u1, u0, q & 3), qv4 = __builtin_amdgcn_alignbyte(u2, u1, q & 3);
+								const uint32_t x = qv4 ^ v4;
+								n8 = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
+								if (!FULL && n8 > maxlen) n8 = maxlen;
+								return qok && qv == v;
+							};
+							uint32_t d1st, n1st, d2nd, n2nd;
+							const bool ok1 = probe((j & 2 ? qq.y : qq.x) >> (16 * (j & 1)), d1st, n1st);
+							const bool ok2 = probe(q2[j], d2nd, n2nd);
+							// the older entry only if it has more of the first eight bytes (oracle/nxz_lz77.c step 4)
+							const bool second = ok2 && (!ok1 || n2nd > n1st);
+							okA[j] = ok1 || ok2;
+							dA[j] = second ? d2nd : d1st;
+							const uint32_t lenA = second ? n2nd : n1st;
 							raw8[j] = okA[j] && lenA == 8;              // at least 8 bytes
 							lng[j] = raw8[j] && (FULL || maxlen > 8);   // ... and possibly more
 							mw |= (okA[j] ? lenA - 3 : 0) << (8 * j);
@@ -1149,12 +1215,15 @@ extern "C" int nxz_lz77_prof_set(unsigned long long *buf)
 
 // One persistent workgroup per CU; job_counter: one device word per launch in flight (or NULL:
 // workgroups stride over the jobs).  tokens: n x NXZ_TOK_STRIDE bytes of device scratch.
-extern "C" int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n, uint8_t *tokens, nxz_batch_result_t *results,
+// Device scratch a launch needs for the second bucket entries in transit (one tile per workgroup).
+extern "C" size_t nxz_lz77_cand2_bytes(void) { return (size_t)NXZ_LZ77_MAX_GRID * nxzl77::C2_STRIDE * sizeof(uint16_t); }
+
+extern "C" int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n, uint8_t *tokens, uint16_t *cand2, nxz_batch_result_t *results,
 			       uint32_t *counts, uint32_t *job_counter, hipStream_t stream)
 {
 	using namespace nxzl77;
 	if (n == 0) return 0;
-	void (*k)(const nxz_batch_job_t *, uint8_t *, nxz_batch_result_t *, uint32_t *, uint32_t, uint32_t *);
+	void (*k)(const nxz_batch_job_t *, uint8_t *, uint16_t *, nxz_batch_result_t *, uint32_t *, uint32_t, uint32_t *);
 	k = count ? lz77_kernel<true> : lz77_kernel<false>;
 	// per device: the attribute belongs to the loaded code object of a device, and so does the CU count
 	static int ncu_of[64];
@@ -1167,11 +1236,12 @@ extern "C" int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n,
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
 		if (ncu <= 0) ncu = 256;
+		if (ncu > NXZ_LZ77_MAX_GRID) ncu = NXZ_LZ77_MAX_GRID;
 		__atomic_store_n(&ncu_of[dev], ncu, __ATOMIC_RELEASE);
 	}
 	const unsigned grid = (unsigned)(n < (size_t)ncu ? n : (size_t)ncu);
 	if (n <= grid) job_counter = nullptr;                      // one job per workgroup: nothing to draw
 	if (job_counter && hipMemsetAsync(job_counter, 0, sizeof(uint32_t), stream) != hipSuccess) job_counter = nullptr;
-	hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS_BYTES, stream, jobs, tokens, results, counts, (uint32_t)n, job_counter);
+	hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS_BYTES, stream, jobs, tokens, cand2, results, counts, (uint32_t)n, job_counter);
 	return (int)hipGetLastError();
 }

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Deflate pipeline by function code on bench.py's synthetic blocks: fixed Huffman through the
-three-kernel pipeline (LZ77 -> entropy), the same through round 1's single kernel (NXZ_FUSED=1 in a
-child process), and the DHTGEN code (LZ77 + counts -> device dhtgen -> entropy)."""
+"""Deflate pipeline by function code on bench.py's synthetic blocks: fixed Huffman (LZ77 kernel ->
+entropy kernel) and the DHTGEN code (LZ77 + counts -> device dhtgen -> entropy)."""
 import importlib, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -20,8 +19,6 @@ def run(n):
     res = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     out = {}
     for name, fc in (("fht", pkg.FC_COMPRESS_FHT), ("dhtgen", pkg.FC_COMPRESS_DHTGEN)):
-        if os.environ.get("NXZ_FUSED") and name != "fht":
-            continue
         eng.compress(fc, jobs, n, results=res)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,7 +32,7 @@ def run(n):
         assert ((r["cc"] == 0) | (r["cc"] == 64)).all(), np.unique(r["cc"])
         out[name] = {"GiB_s": round(n * 65536 / ms / 1e-3 / 2 ** 30, 2), "ms": round(ms, 3),
                      "ratio": round(n * 65536.0 / float(r["tpbc"].astype(np.float64).sum()), 4)}
-    print(json.dumps({"blocks": n, "fused": bool(os.environ.get("NXZ_FUSED")), **out}))
+    print(json.dumps({"blocks": n, **out}))
 
 
 if __name__ == "__main__":
