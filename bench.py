@@ -1,17 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the DEFLATE hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W [--blocks B] [--no-inflate] [--no-cpu-baseline] [--no-dht]
+  python bench.py --gpus N --steps K --warmup W [--blocks B] [--config c2|c5]
+                  [--no-corpus] [--no-inflate] [--no-cpu-baseline]
 
-A *step* is one pass of the fixed-Huffman deflate engine (LZ77 + bit-pack kernel, function
-code COMPRESS_FHT) over one batch of B synthetic 64 KiB blocks that are already resident in
-HBM (BASELINE.json configs[1]: "Fixed-Huffman deflate (level 1), 1xMI355X, 1 M synthetic
-64 KiB blocks").  Every rank owns its own B blocks (independent units, no data-path
-collective: weak scaling); the only collectives are the barrier and the reductions of
-{bytes, elapsed}.  Rank 0 prints ONE JSON line.
+config c2 (default; BASELINE.json configs[1], the configuration the metric is quoted on):
+  a *step* is one pass of the fixed-Huffman deflate engine (function code COMPRESS_FHT: LZ77 kernel +
+  entropy kernel) over one batch of B synthetic 64 KiB blocks that are already resident in HBM.  Every
+  rank owns its own B blocks (independent units, no data-path collective: weak scaling); the only
+  collectives are the barrier and the reductions of {bytes, elapsed}.  Rank 0 prints ONE JSON line.
+  Beside the headline the line carries (N = 1 only, outside the timed region):
+    "corpus"   the metric's kind of data: Silesia from $SILESIA_DIR (sha256-checked against the pins
+               of the reference's oct/silesia-*.source) or the recorded real-data fallback
+               (tests/corpus.py), cut at 64 KiB, replicated to >= 65536 jobs, compressed with an exact
+               dynamic-Huffman table per block built on the device (COMPRESS_DHTGEN), its own roofline,
+               ratio per class against zlib -1 and its own cpu_baseline (zlib -1, T = 1 and T = all)
+    "inflate"  the inflate engine on the deflate output (full size, bit-exact round trip) and on
+               zlib -6 streams of the corpus, with roofline and zlib's inflate on the host cores
+config c5 (BASELINE.json configs[4]): 10 GiB of mixed-entropy 64 KiB blocks (index mod 4: zeros /
+  33-symbol text / makedata-style LZ copies / random bytes), cut into contiguous shards over the N
+  ranks (strong scaling).  A step = compress (FHT; what does not shrink is stored through the WRAP
+  function code, inside the timed region) + decompress + compare on the device.
 
-Inside the timed region: the engine launches only (kernel + tiny result buffer).  Outside:
-data generation, zlib verification of a sample, the CPU baseline (with the oracle parity check).
+Inside the timed region: the engine launches only.  Outside: data generation, zlib verification of
+a sample, the CPU baselines (with the oracle parity check).
 """
 import argparse
 import ctypes as C
@@ -28,6 +40,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BLOCK = 65536
+STRIDE_OUT = 73856
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -35,6 +48,13 @@ def shard(nblocks_per_rank, rank, world):
     """Block index range of a rank (contiguous); weak scaling: every rank gets B."""
     lo = rank * nblocks_per_rank
     return lo, lo + nblocks_per_rank
+
+
+def shard_strong(total_blocks, rank, world):
+    """Contiguous shard of a fixed total (config c5): the first `total % world` ranks get one more."""
+    per, extra = divmod(total_blocks, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
 
 
 def reduce_totals(torch, dist, dev, u_bytes, c_bytes, wall, distributed):
@@ -77,12 +97,34 @@ def gen_blocks(torch, dev, n, first_index, chunk=4096):
     return out
 
 
-def pmc_traffic(n_blocks):
-    """HBM bytes per launch from the committed PMC pass (profiles/*pmc_traffic.json, collected with
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload and corrected as
-    MI355X_MICROARCH.md prescribes), scaled to this launch's block count; None if absent."""
+def gen_mixed(torch, dev, n, first_index):
+    """config c5: block i (global index) is zeros / 33-symbol text / text + LZ copies / random bytes
+    by i mod 4."""
+    out = gen_blocks(torch, dev, n, first_index)
+    idx = torch.arange(first_index, first_index + n, device=dev)
+    kind = idx % 4
+    out[kind == 0] = 0
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED ^ first_index)
+    alphabet = torch.tensor(list(b"abcdefghijklmnopqrstuvwxyz .,;!?\n"), dtype=torch.uint8, device=dev)
+    for c0 in range(0, n, 8192):
+        m = min(8192, n - c0)
+        k = kind[c0:c0 + m]
+        sub = out[c0:c0 + m]
+        n1, n3 = int((k == 1).sum()), int((k == 3).sum())
+        if n1:
+            sub[k == 1] = alphabet[torch.randint(0, 33, (n1, BLOCK), device=dev, generator=g)]
+        if n3:
+            sub[k == 3] = torch.randint(0, 256, (n3, BLOCK), device=dev, dtype=torch.uint8, generator=g)
+    return out
+
+
+def pmc_traffic(n_blocks, which="fht"):
+    """HBM bytes per step from the committed PMC pass (profiles/*pmc_traffic_<which>.json, collected
+    with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload and corrected as
+    MI355X_MICROARCH.md prescribes), scaled to this step's block count; None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*pmc_traffic_%s.json" % which)))
     if not files:
         return None
     try:
@@ -106,116 +148,324 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(blocks_host, budget_s=12.0):
-    """oracle ('port') timed on all host cores on a bounded sample; zlib -1 Z_FIXED beside it."""
+def _cpu_run(bufs, mode, threads, budget_s):
+    """oracle/nxz_bench.c harness on a list of byte strings: calibrates on a few, then runs a sample
+    sized for about budget_s.  Returns (GiB/s of the bytes that matter, bytes in, bytes out, items)."""
     import oracle_lib as O
     L = O.lib()
-    L.nxo_bench_deflate.restype = C.c_double
-    L.nxo_bench_deflate.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    L.nxo_bench_run.restype = C.c_double
+    L.nxo_bench_run.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+
+    def run(items):
+        buf = b"".join(items)
+        lens = np.array([len(b) for b in items], np.uint32)
+        off = np.zeros(len(items), np.uint64)
+        off[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+        ob, bad = C.c_uint64(), C.c_int()
+        t = L.nxo_bench_run(buf, off.ctypes.data, lens.ctypes.data, len(items), threads, mode, C.byref(ob), C.byref(bad))
+        if bad.value:
+            raise SystemExit("cpu baseline: zlib reported %d errors" % bad.value)
+        return t, int(lens.sum()), ob.value
+
+    ncal = min(len(bufs), 4 * threads)
+    t, _, _ = run(bufs[:ncal])
+    n = int(max(ncal, ncal * budget_s / max(t, 1e-4)))
+    items = [bufs[i % len(bufs)] for i in range(n)]
+    t, nin, nout = run(items)
+    moved = nout if mode == 2 else nin                       # inflate: uncompressed bytes OUT
+    return moved / t / 2.0 ** 30, nin, nout, n
+
+
+def cpu_baseline_deflate(blocks, strategy, budget_s):
+    """The reference's CPU path for this call is system zlib (lib/sw_zlib.c:283-324 dlopens it):
+    deflate level 1, raw, fixed or default strategy, per 64 KiB block with deflateReset between
+    blocks, T = 1 and T = all usable cores; the oracle port as a side key."""
     cores = usable_cores()
-    buf = blocks_host.tobytes()
-    nmax = len(buf) // BLOCK
-    ob = C.c_uint64()
-    # calibrate on a few blocks, then size the sample for ~budget_s/2 per library
-    ncal = min(nmax, 8 * cores)
-    t = L.nxo_bench_deflate(buf, ncal, BLOCK, cores, 0, C.byref(ob))
-    n = int(max(ncal, min(nmax, ncal * (budget_s / 2) / max(t, 1e-3))))
-    t_port = L.nxo_bench_deflate(buf, n, BLOCK, cores, 0, C.byref(ob))
-    port_out = ob.value
-    t_z = L.nxo_bench_deflate(buf, n, BLOCK, cores, 1, C.byref(ob))
-    z_out = ob.value
-    gib = n * BLOCK / 2.0 ** 30
+    zmode = 1 if strategy == "fixed" else 3
+    pmode = 0 if strategy == "fixed" else 4
+    z1, _, _, n1 = _cpu_run(blocks, zmode, 1, budget_s / 4)
+    zt, nin, nout, nt = _cpu_run(blocks, zmode, cores, budget_s / 4)
+    pt, pin, pout, npt = _cpu_run(blocks, pmode, cores, budget_s / 2)
     return {
-        "value": round(gib / t_port, 4), "unit": "GiB/s", "cores": cores, "kind": "port",
-        "sample": "%d of the same 64 KiB blocks, oracle/nxz_lz77.c fixed-Huffman deflate, %d pthreads" % (n, cores),
-        "ratio": round(n * BLOCK / port_out, 4),
-        "zlib1_fixed_GiB_s": round(gib / t_z, 4), "zlib1_fixed_ratio": round(n * BLOCK / z_out, 4),
+        "value": round(zt, 4), "unit": "GiB/s", "cores": cores, "kind": "reference",
+        "what": "system zlib 1.2.11 deflate level 1 (%s strategy), raw, deflateReset per block: the library the "
+                "reference's software path dlopens (lib/sw_zlib.c:283-324)" % strategy,
+        "sample": "%d of the same blocks on %d pthreads (oracle/nxz_bench.c)" % (nt, cores),
+        "one_thread_GiB_s": round(z1, 4), "zlib_ratio": round(nin / nout, 4),
+        "oracle_port_GiB_s": round(pt, 4), "oracle_port_ratio": round(pin / pout, 4),
+        "oracle_port_sample": "%d blocks, oracle/nxz_lz77.c + %s" % (npt, "fixed code" if strategy == "fixed" else "nxo_dhtgen per block"),
     }
 
 
-def verify_sample(eng, pkg, src, dst, res_host, stride_out, k=48):
-    """zlib inflates the first k outputs to the inputs (outside the timed region; the bit-for-bit
-    comparison with the oracle is part of the cpu_baseline leg, the only place bench.py uses it)."""
+def verify_sample(src_rows, out_rows, tpbc, k=48):
+    """zlib inflates the first k outputs to the inputs (outside the timed region)."""
     import zlib
-    k = min(k, src.shape[0])
-    s = src[:k].cpu().numpy()
-    d = dst[:k].cpu().numpy()
-    for i in range(k):
-        b = s[i].tobytes()
-        got = d[i, :res_host["tpbc"][i]].tobytes()
+    for i in range(min(k, len(src_rows))):
         z = zlib.decompressobj(-15)
-        if z.decompress(got) != b or not z.eof:
+        if z.decompress(out_rows[i][:tpbc[i]].tobytes()) != src_rows[i] or not z.eof:
             raise SystemExit("ROUND TRIP FAILURE: block %d" % i)
 
 
-def oracle_parity(blocks_host, dst, res_host, k=48):
+def oracle_parity(blocks, out_rows, tpbc, dynamic, k=32):
     """cpu_baseline leg: the engine's first k outputs equal the oracle's, byte for byte."""
     import oracle_lib as O
-    k = min(k, blocks_host.shape[0])
-    d = dst[:k].cpu().numpy()
+    k = min(k, len(blocks))
     for i in range(k):
-        exp, bits = O.deflate_fixed(blocks_host[i].tobytes())
-        if d[i, :res_host["tpbc"][i]].tobytes() != exp:
+        b = blocks[i]
+        if dynamic:
+            tok, nt = O.lz77(b)
+            ll, d = O.counts(tok, nt)
+            dht, dhtlen = O.dhtgen(ll, d)
+            exp, bits = O.deflate_dynamic(b, dht, dhtlen)
+        else:
+            exp, bits = O.deflate_fixed(b)
+        if out_rows[i][:tpbc[i]].tobytes() != exp:
             raise SystemExit("PARITY FAILURE: block %d differs from the oracle" % i)
     return k
 
 
-def dht_leg(torch, eng, pkg, src, dst, n, stride_out, group=64, sample=256):
-    """Dynamic-Huffman leg (BASELINE configs[2] shape, same blocks): one table per `group` consecutive
-    blocks, built by the host generator (nxz_dhtgen_batch in libnxz_amd.so, the part the reference
-    also keeps on the host, lib/nx_dhtgen.c) from the LZ77 symbol counts of the group's first block;
-    then every block is encoded with its group's table.  Timed end to end (count pass + copy of the
-    counts + host tables + copy of the tables + encode pass); ratio next to zlib -1 (default
-    strategy) on a sample whose outputs zlib inflates back to the input."""
+def stage_times(eng):
+    ms = (C.c_double * 3)()
+    n = C.c_uint()
+    eng.L.nxz_ctx_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint)]
+    eng.L.nxz_ctx_stage_ms(eng.ctx, ms, C.byref(n))
+    return [ms[0], ms[1], ms[2]], n.value
+
+
+def timed_compress(torch, eng, fc, jobs, n, results, steps, warmup):
+    """(ms per step by torch events, [lz77, dhtgen, entropy] ms per step by the engine's own HIP events
+    on the launch stream, launches per step)"""
+    eng.L.nxz_ctx_stage_timing.argtypes = [C.c_void_p, C.c_int]
+    for _ in range(warmup):
+        eng.compress(fc, jobs, n, results=results)
+    torch.cuda.synchronize(eng.dev)
+    eng.L.nxz_ctx_stage_timing(eng.ctx, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        eng.compress(fc, jobs, n, results=results)
+    e1.record()
+    torch.cuda.synchronize(eng.dev)
+    eng.L.nxz_ctx_stage_timing(eng.ctx, 0)
+    st, launches = stage_times(eng)
+    return e0.elapsed_time(e1) / steps, [x / steps for x in st], launches // max(steps, 1)
+
+
+def roofline(u_bytes, c_bytes, stage_ms, launches, traffic, kernel):
+    """algorithmic bytes U + C over the time of the dominant kernel (the LZ77 kernel:
+    it reads U; the entropy kernel writes C and is accounted with it: both are needed to move U + C),
+    so achieved = (U + C) / (lz77 + dhtgen + entropy kernel time), measured by HIP events on the
+    launch stream around every launch of the timed region."""
+    kern_ms = sum(stage_ms)
+    achieved = (u_bytes + c_bytes) / (kern_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kernel,
+            "kernel_ms": round(kern_ms, 3), "lz77_ms": round(stage_ms[0], 3), "dhtgen_ms": round(stage_ms[1], 3),
+            "entropy_ms": round(stage_ms[2], 3), "launches_per_step": launches,
+            "avg_lz77_launch_ms": round(stage_ms[0] / max(launches, 1), 4),
+            "algorithmic_bytes_per_step": u_bytes + c_bytes}
+
+
+def corpus_leg(torch, eng, pkg, args):
+    """Real data, exact dynamic-Huffman table per block (the metric's Silesia leg)."""
     import zlib
-    H = C.CDLL(os.path.join(ROOT, "power-gzip_amd", "libnxz_amd.so"))
-    H.nxz_dhtgen_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
-    H.nxz_dhtgen_batch.restype = C.c_int
-    nthreads = usable_cores()
-    ng = (n + group - 1) // group
-    lens = np.full(n, BLOCK, np.uint32)
-    jobs_lead = eng.jobs_strided(src, BLOCK * group, np.full(ng, BLOCK, np.uint32), dst, stride_out * group, stride_out)
-    jobs_all = eng.jobs_strided(src, BLOCK, lens, dst, stride_out, stride_out,
-                                dht_index=(np.arange(n) // group).astype(np.uint32))
-    counts = torch.empty(ng * 316, dtype=torch.int32, device=eng.dev)
-    tables = np.zeros(ng, pkg.DHT_DTYPE)
+    import corpus
+    name, blocks, report = corpus.load(BLOCK)
+    uniq = len(blocks)
+    rep = max(1, -(-args.corpus_jobs // uniq))
+    n = uniq * rep
+    host = np.zeros((uniq, BLOCK), np.uint8)
+    lens_u = np.array([len(b) for _, _, b in blocks], np.uint32)
+    for i, (_, _, b) in enumerate(blocks):
+        host[i, :len(b)] = np.frombuffer(b, np.uint8)
+    src_u = torch.from_numpy(host).to(eng.dev)
+    src = src_u.repeat(rep, 1)
+    lens = np.tile(lens_u, rep)
+    dst = torch.empty((n, STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, BLOCK, lens, dst, STRIDE_OUT, STRIDE_OUT)
     res = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
-
-    def one_pass():
-        eng.compress(pkg.FC_COMPRESS_FHT_COUNT, jobs_lead, ng, counts=counts)
-        c = counts.cpu().numpy().view(np.uint32)
-        if H.nxz_dhtgen_batch(c.ctypes.data, ng, tables.ctypes.data, nthreads) != 0:
-            raise SystemExit("nxz_dhtgen_batch failed")
-        eng.compress(pkg.FC_COMPRESS_DHT, jobs_all, n, results=res, dht=eng.to_device(tables), ntables=ng)
-
-    one_pass()
-    torch.cuda.synchronize(eng.dev)
-    reps = 2
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        one_pass()
-    torch.cuda.synchronize(eng.dev)
-    dt = (time.perf_counter() - t0) / reps
+    ms, st, launches = timed_compress(torch, eng, pkg.FC_COMPRESS_DHTGEN, jobs, n, res, max(2, args.steps), 1)
     r = eng.results_to_host(res)
-    if not (r["cc"] == 0).all():
-        raise SystemExit("dynamic-Huffman leg: engine reported errors %s" % np.unique(r["cc"]))
-    m = min(n, sample)
-    hs = src[:m].cpu().numpy()
-    out = dst[:m].cpu().numpy()
-    z1 = 0
-    for i in range(m):
-        b = hs[i].tobytes()
-        z = zlib.decompressobj(-15)
-        if z.decompress(out[i, :r["tpbc"][i]].tobytes()) != b or not z.eof:
-            raise SystemExit("ROUND TRIP FAILURE (dynamic Huffman): block %d" % i)
+    if not ((r["cc"] == 0) | (r["cc"] == 64)).all():
+        raise SystemExit("corpus leg: engine reported errors %s" % np.unique(r["cc"]))
+    u_bytes, c_bytes = float(lens.astype(np.float64).sum()), float(r["tpbc"].astype(np.float64).sum())
+    # every output inflates back (on the device, full size) and a sample through zlib
+    back = torch.zeros((n, BLOCK), dtype=torch.uint8, device=eng.dev)
+    jobs2 = eng.jobs_strided(dst, STRIDE_OUT, r["tpbc"].astype(np.uint32), back, BLOCK, BLOCK)
+    r2 = eng.results_to_host(eng.decompress(jobs2, n))
+    okrt = bool((r2["cc"] == 0).all()) and bool((r2["tpbc"] == lens).all()) and bool(torch.equal(back, src))
+    if not okrt:
+        raise SystemExit("corpus leg: ROUND TRIP FAILURE (inflate of the deflate output != source)")
+    out_u = dst[:uniq].cpu().numpy()
+    raw = [b for _, _, b in blocks]
+    verify_sample(raw, out_u, r["tpbc"], k=uniq if uniq <= 400 else 400)
+    # ratio per class against zlib -1 (default strategy), on the unique blocks
+    per = {}
+    for i, (cls, _, b) in enumerate(blocks):
         c = zlib.compressobj(1, zlib.DEFLATED, -15)
-        z1 += len(c.compress(b) + c.flush())
-    ours = int(r["tpbc"][:m].sum())
-    return {"value": round(n * BLOCK / dt / 2.0 ** 30, 3), "unit": "GiB/s uncompressed in, end to end",
-            "ms_per_pass": round(dt * 1e3, 3), "ratio": round(n * float(BLOCK) / float(r["tpbc"].astype(np.float64).sum()), 4),
-            "zlib1_ratio_sample": round(m * BLOCK / z1, 4), "ratio_vs_zlib1": round(z1 / ours, 4),
-            "tables": "one per %d blocks from the first block's counts, %d host threads" % (group, nthreads),
-            "sample": "%d blocks inflated with zlib and compressed with zlib -1" % m}
+        z = len(c.compress(b) + c.flush())
+        a = per.setdefault(cls, [0, 0, 0])
+        a[0] += len(b); a[1] += int(r["tpbc"][i]); a[2] += z
+    classes = {k: {"bytes": v[0], "ratio": round(v[0] / v[1], 4), "zlib1_ratio": round(v[0] / v[2], 4),
+                   "vs_zlib1": round(v[2] / v[1], 4)} for k, v in sorted(per.items())}
+    tot = [sum(v[i] for v in per.values()) for i in range(3)]
+    out = {
+        "metric": "GiB/s uncompressed in (deflate), exact dynamic-Huffman table per block built on the device (COMPRESS_DHTGEN)",
+        "value": round(u_bytes / (ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s", "ms_per_step": round(ms, 3),
+        "corpus": name, "corpus_files": report, "unique_blocks": uniq, "jobs": n, "block_bytes": BLOCK,
+        "ratio": round(tot[0] / tot[1], 4), "zlib1_ratio": round(tot[0] / tot[2], 4), "ratio_vs_zlib1": round(tot[2] / tot[1], 4),
+        "min_class_vs_zlib1": min(v["vs_zlib1"] for v in classes.values()), "classes": classes,
+        "roundtrip_bit_exact": True, "zlib_inflated_sample": min(uniq, 400),
+        "roofline": roofline(u_bytes, c_bytes, st, launches, pmc_traffic(n, "dhtgen"),
+                             "nxzl77::lz77_kernel<true> + nxzd::dhtgen_kernel + nxze::encode_kernel<true>"),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_deflate(raw, "default", 10.0)
+        out["cpu_baseline"]["parity_checked_blocks"] = oracle_parity(raw, out_u, r["tpbc"], True)
+    # inflate of zlib -6 streams of the same corpus (what configs[3] feeds the inflate engine)
+    if not args.no_inflate:
+        out["inflate_zlib6"] = inflate_leg(torch, eng, pkg, raw, rep, args)
+    return out
+
+
+def inflate_leg(torch, eng, pkg, raw, rep, args):
+    """zlib -6 raw streams of the corpus blocks through the batched inflate engine."""
+    import zlib
+    streams = []
+    for b in raw:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        streams.append(c.compress(b) + c.flush())
+    uniq = len(raw)
+    cstride = (max(len(s) for s in streams) + 64 + 15) & ~15
+    host = np.zeros((uniq, cstride), np.uint8)
+    for i, s in enumerate(streams):
+        host[i, :len(s)] = np.frombuffer(s, np.uint8)
+    n = uniq * rep
+    src = torch.from_numpy(host).to(eng.dev).repeat(rep, 1)
+    clen = np.tile(np.array([len(s) for s in streams], np.uint32), rep)
+    ulen = np.tile(np.array([len(b) for b in raw], np.uint32), rep)
+    dst = torch.zeros((n, BLOCK), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, cstride, clen, dst, BLOCK, BLOCK)
+    res = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
+    eng.decompress(jobs, n, results=res)
+    torch.cuda.synchronize(eng.dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(2, args.steps // 2)
+    e0.record()
+    for _ in range(reps):
+        eng.decompress(jobs, n, results=res)
+    e1.record()
+    torch.cuda.synchronize(eng.dev)
+    ms = e0.elapsed_time(e1) / reps
+    r = eng.results_to_host(res)
+    got = dst[:uniq].cpu().numpy()
+    ok = bool((r["cc"] == 0).all()) and bool((r["tpbc"] == ulen).all())
+    for i, b in enumerate(raw):
+        ok = ok and got[i, :len(b)].tobytes() == b and int(r["crc"][i]) == zlib.crc32(b)
+    if not ok:
+        raise SystemExit("inflate leg: zlib -6 streams did not inflate to their sources")
+    u, cb = float(ulen.astype(np.float64).sum()), float(clen.astype(np.float64).sum())
+    out = {"value": round(u / (ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out", "ms_per_pass": round(ms, 3),
+           "streams": n, "made_by": "zlib level 6, raw deflate, one stream per 64 KiB block", "bit_exact": True,
+           "roofline": {"bound": "hbm", "achieved": round((u + cb) / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round((u + cb) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "kernel": "batched inflate (stream per lane / per wave by batch size) + cksum_kernel",
+                        "kernel_ms": round(ms, 3)}}
+    if not args.no_cpu_baseline:
+        cores = usable_cores()
+        z1, _, _, _ = _cpu_run(streams, 2, 1, 2.0)
+        zt, _, _, nt = _cpu_run(streams, 2, cores, 2.0)
+        out["cpu_baseline"] = {"value": round(zt, 4), "unit": "GiB/s uncompressed out", "cores": cores, "kind": "reference",
+                               "what": "system zlib inflate of the same streams (the reference's software path)",
+                               "sample": "%d streams on %d pthreads" % (nt, cores), "one_thread_GiB_s": round(z1, 4)}
+    return out
+
+
+def run_c5(torch, dist, args, rank, world, dev, distributed, pkg, eng):
+    """BASELINE configs[4]: 10 GiB mixed entropy, contiguous strong-scaled shards."""
+    total = args.blocks if args.blocks else 163840
+    lo, hi = shard_strong(total, rank, world)
+    n = hi - lo
+    src = gen_mixed(torch, dev, n, lo)
+    comp = torch.empty((n, STRIDE_OUT), dtype=torch.uint8, device=dev)
+    back = torch.empty((n, BLOCK), dtype=torch.uint8, device=dev)
+    lens = np.full(n, BLOCK, np.uint32)
+    jobs = eng.jobs_strided(src, BLOCK, lens, comp, STRIDE_OUT, STRIDE_OUT)
+    res = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    # blocks that do not shrink (every fourth: random bytes) complete with CC 64; they are stored
+    # through the WRAP function code, the fallback the library applies per job
+    # (lib/nx_deflate.c:1274-1282,1763-1790).  Which ones: known after the first pass, the job
+    # arrays of the wrap and of the decompress pass are built once (outside the timed region)
+    eng.compress(pkg.FC_COMPRESS_FHT, jobs, n, results=res)
+    r = eng.results_to_host(res)
+    if not ((r["cc"] == 0) | (r["cc"] == 64)).all():
+        raise SystemExit("engine reported errors: %s" % np.unique(r["cc"]))
+    stored = np.nonzero(r["cc"] == 64)[0]
+    ok = np.nonzero(r["cc"] == 0)[0]
+    base_s, base_c, base_b = src.data_ptr(), comp.data_ptr(), back.data_ptr()
+
+    def jobs_at(idx, a_base, a_stride, a_len, b_base, b_stride, b_cap):
+        j = np.zeros(len(idx), pkg.JOB_DTYPE)
+        j["src"] = np.uint64(a_base) + idx.astype(np.uint64) * np.uint64(a_stride)
+        j["dst"] = np.uint64(b_base) + idx.astype(np.uint64) * np.uint64(b_stride)
+        j["src_len"] = a_len
+        j["dst_cap"] = b_cap
+        j["in_adler"] = 1
+        return eng.to_device(j)
+    jw = jobs_at(stored, base_s, BLOCK, BLOCK, base_c, STRIDE_OUT, STRIDE_OUT) if len(stored) else None
+    jd = jobs_at(ok, base_c, STRIDE_OUT, r["tpbc"][ok], base_b, BLOCK, BLOCK)
+    ju = jobs_at(stored, base_c, STRIDE_OUT, BLOCK, base_b, BLOCK, BLOCK) if len(stored) else None   # stored blocks come back by WRAP too
+    resw = torch.empty(max(1, len(stored)) * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    resd = torch.empty(max(1, len(ok)) * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def step():
+        eng.compress(pkg.FC_COMPRESS_FHT, jobs, n, results=res)
+        if jw is not None:
+            eng.wrap(jw, len(stored), results=resw)
+        eng.decompress(jd, len(ok), results=resd)
+        if ju is not None:
+            eng.wrap(ju, len(stored), results=resw)
+        flag.add_((back != src).any().to(torch.int32))           # compare on the device
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    flag.zero_()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    if int(flag.item()) != 0:
+        raise SystemExit("ROUND TRIP FAILURE (c5): decompressed data != source on rank %d" % rank)
+    u_bytes = float(n) * BLOCK
+    c_bytes = float(r["tpbc"][ok].astype(np.float64).sum()) + len(stored) * float(BLOCK + 5)
+    tot_u, tot_c, wall_max = reduce_totals(torch, dist, dev, u_bytes, c_bytes, wall, distributed)
+    if rank == 0:
+        value = 2.0 * tot_u * args.steps / wall_max / 2.0 ** 30
+        line = {
+            "metric": "GiB/s uncompressed in (deflate) + out (inflate), 10 GiB mixed-entropy 64 KiB blocks",
+            "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: %d x 64 KiB blocks (zeros / 33-symbol text / text + LZ copies / random by "
+                                   "index mod 4), contiguous shards over %d GPUs; step = FHT compress + WRAP of what does not "
+                                   "shrink + decompress + compare, device resident" % (total, world),
+                       "total_blocks": total, "block_bytes": BLOCK, "ratio": round(tot_u / tot_c, 4),
+                       "stored_blocks_rank0": int(len(stored)), "parallelism": "shard%d" % world},
+            "roofline": {"bound": "hbm", "achieved": round(2 * (tot_u + tot_c) * args.steps / wall_max / 1e9, 2), "peak": HBM_PEAK_GBS * world,
+                         "unit": "GB/s", "frac": round(2 * (tot_u + tot_c) * args.steps / wall_max / 1e9 / (HBM_PEAK_GBS * world), 5),
+                         "traffic": None, "kernel": "whole step (deflate + wrap + inflate kernels), wall clock"},
+        }
+        print(json.dumps(line), flush=True)
 
 
 def main():
@@ -223,10 +473,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=1 << 20, help="64 KiB blocks per GPU (default 2^20 = 64 GiB)")
+    ap.add_argument("--config", choices=["c2", "c5"], default="c2")
+    ap.add_argument("--blocks", type=int, default=0, help="c2: 64 KiB blocks per GPU (default 2^20 = 64 GiB); c5: total blocks (default 163840 = 10 GiB)")
+    ap.add_argument("--corpus-jobs", type=int, default=65536, help="jobs of the real-data leg (the corpus is replicated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-inflate", action="store_true", help="skip the inflate leg (round trip of the output)")
-    ap.add_argument("--no-dht", action="store_true", help="skip the dynamic-Huffman leg (N=1 only)")
+    ap.add_argument("--no-inflate", action="store_true", help="skip the inflate legs")
+    ap.add_argument("--no-corpus", action="store_true", help="skip the real-data leg (N=1 only anyway)")
     args = ap.parse_args()
 
     import torch
@@ -249,14 +501,22 @@ def main():
     pkg = importlib.import_module("power-gzip_amd")
     eng = pkg.Engine(local_rank)
 
-    n = args.blocks
+    if args.config == "c5":
+        run_c5(torch, dist, args, rank, world, dev, distributed, pkg, eng)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        eng.close()
+        return
+
+    n = args.blocks or (1 << 20)
     lo, hi = shard(n, rank, world)
-    stride_out = 73856
     src = gen_blocks(torch, dev, n, lo)
-    dst = torch.empty((n, stride_out), dtype=torch.uint8, device=dev)
+    dst = torch.empty((n, STRIDE_OUT), dtype=torch.uint8, device=dev)
     lens = np.full(n, BLOCK, np.uint32)
-    jobs = eng.jobs_strided(src, BLOCK, lens, dst, stride_out, stride_out)
+    jobs = eng.jobs_strided(src, BLOCK, lens, dst, STRIDE_OUT, STRIDE_OUT)
     results = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    eng.L.nxz_ctx_stage_timing.argtypes = [C.c_void_p, C.c_int]
 
     def step():
         eng.compress(pkg.FC_COMPRESS_FHT, jobs, n, results=results)
@@ -268,19 +528,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
 
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
+    eng.L.nxz_ctx_stage_timing(eng.ctx, 1)                 # HIP events on the launch stream around every kernel
     t0 = time.perf_counter()
-    ev0.record()
     for _ in range(args.steps):
         step()
-    ev1.record()
     torch.cuda.synchronize(dev)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps          # the engine kernel is the only work on the stream
+    eng.L.nxz_ctx_stage_timing(eng.ctx, 0)
+    st, launches = stage_times(eng)
+    st = [x / args.steps for x in st]
+    launches //= args.steps
 
     res = results.cpu().numpy().view(pkg.RESULT_DTYPE)
     if not ((res["cc"] == 0) | (res["cc"] == 64)).all():
@@ -292,7 +552,7 @@ def main():
     inflate_info = None
     if not args.no_inflate:
         back = torch.empty((n, BLOCK), dtype=torch.uint8, device=dev)
-        jobs2 = eng.jobs_strided(dst, stride_out, res["tpbc"].astype(np.uint32), back, BLOCK, BLOCK)
+        jobs2 = eng.jobs_strided(dst, STRIDE_OUT, res["tpbc"].astype(np.uint32), back, BLOCK, BLOCK)
         res2 = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
         eng.decompress(jobs2, n, results=res2)
         torch.cuda.synchronize(dev)
@@ -307,9 +567,12 @@ def main():
         ok = bool(torch.equal(back, src)) and bool((r2["cc"] == 0).all()) and bool((r2["crc"] == res["crc"]).all())
         if not ok:
             raise SystemExit("ROUND TRIP FAILURE at full size (inflate of the deflate output != source)")
-        inflate_info = {"value": round(float(n) * BLOCK / (inf_ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out",
+        ub, cb = float(n) * BLOCK, float(res["tpbc"].astype(np.float64).sum())
+        inflate_info = {"value": round(ub / (inf_ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out",
                         "ms_per_pass": round(inf_ms, 3), "kernel": "nxzl::inflate_lanes_kernel + cksum_kernel",
-                        "scope": "one GPU (rank 0)", "roundtrip_bit_exact": True}
+                        "what": "the fixed-Huffman output of the timed region", "scope": "one GPU (rank 0)", "roundtrip_bit_exact": True,
+                        "roofline": {"bound": "hbm", "achieved": round((ub + cb) / (inf_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": round((ub + cb) / (inf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
         del back
     u_bytes = float(n) * BLOCK
     c_bytes = float(res["tpbc"].astype(np.float64).sum())
@@ -317,9 +580,11 @@ def main():
     tot_u, tot_c, wall_max = reduce_totals(torch, dist, dev, u_bytes, c_bytes, wall, distributed)
 
     if rank == 0:
-        verify_sample(eng, pkg, src, dst, res, stride_out)
+        k = min(n, 48)
+        src_rows = [row.tobytes() for row in src[:k].cpu().numpy()]
+        out_rows = dst[:k].cpu().numpy()
+        verify_sample(src_rows, out_rows, res["tpbc"], k)
         value = tot_u * args.steps / wall_max / 2.0 ** 30
-        achieved = (u_bytes + c_bytes) / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "GiB/s uncompressed in (deflate), fixed-Huffman level 1, synthetic 64 KiB blocks",
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -329,19 +594,20 @@ def main():
                                    "per GPU (33-symbol text + makedata-style LZ copies), device resident" % n,
                        "blocks_per_gpu": n, "block_bytes": BLOCK, "ratio": round(tot_u / tot_c, 4),
                        "parallelism": "shard%d" % world},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(n),
-                         "kernel": "nxz::deflate_kernel<false,false>", "kernel_ms": round(kern_ms, 3),
-                         "algorithmic_bytes_per_launch": u_bytes + c_bytes},
+            "roofline": roofline(u_bytes, c_bytes, st, launches, pmc_traffic(n, "fht"),
+                                 "nxzl77::lz77_kernel<false> (dominant) + nxze::encode_kernel<false>"),
         }
         if inflate_info:
             line["inflate"] = inflate_info
         if world == 1 and not args.no_cpu_baseline:
-            sample = src[:min(n, 32768)].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(sample)
-            line["cpu_baseline"]["parity_checked_blocks"] = oracle_parity(sample, dst, res)
-        if world == 1 and not args.no_dht:
-            line["dht"] = dht_leg(torch, eng, pkg, src, dst, n, stride_out)      # overwrites dst: last leg
+            sample = [row.tobytes() for row in src[:min(n, 2048)].cpu().numpy()]
+            line["cpu_baseline"] = cpu_baseline_deflate(sample, "fixed", 10.0)
+            line["cpu_baseline"]["parity_checked_blocks"] = oracle_parity(src_rows, out_rows, res["tpbc"], False)
+            line["config"]["ratio_vs_zlib1_fixed"] = round(line["cpu_baseline"]["zlib_ratio"] and line["config"]["ratio"] / line["cpu_baseline"]["zlib_ratio"], 4)
+        if world == 1 and not args.no_corpus:
+            del src, dst
+            torch.cuda.empty_cache()
+            line["corpus"] = corpus_leg(torch, eng, pkg, args)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

@@ -303,6 +303,12 @@ void  nxz_stream_destroy(nxz_ctx_t *ctx, void *stream);
 int   nxz_copy_to_device(nxz_ctx_t *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int   nxz_copy_to_host(nxz_ctx_t *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
 
+/* Measurement aid (bench.py's roofline): with timing on, every compress batch records events
+ * around its kernels; nxz_ctx_stage_ms waits for them and returns the milliseconds spent in the
+ * LZ77, table generator and entropy kernels since the last call, and how many launches of each. */
+void nxz_ctx_stage_timing(nxz_ctx_t *ctx, int on);
+int  nxz_ctx_stage_ms(nxz_ctx_t *ctx, double ms[3], unsigned *launches);
+
 /* Block until everything queued on `stream` by this context has finished. */
 int nxz_ctx_sync(nxz_ctx_t *ctx, void *stream);
 

@@ -91,6 +91,9 @@ struct nxz_ctx {
 	std::map<hipStream_t, Scratch> scratch;
 	uint32_t *d_job_counters = nullptr;           // job counters of the batched deflate launches (ring)
 	unsigned next_counter = 0;
+	// measurement aid (nxz_ctx_stage_timing): events around every kernel of the compress batches
+	bool timing = false;
+	std::vector<hipEvent_t> tev;                  // per chunk: before LZ77, after it, after dhtgen, after the entropy kernel
 };
 static constexpr unsigned JOB_COUNTERS = 256;
 // Which inflate kernel a batch gets (profiles/r01c_inflate_by_batch_size.txt, 64 KiB streams):
@@ -234,11 +237,13 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
 	(void)hipSetDevice(c->device);
 	nxz_dht_prepared_t *prepared = nullptr;
+	// equal chunks (a last chunk of a few jobs would cost three launches for nothing)
+	const size_t nchunks = (n + COMPRESS_CHUNK - 1) / COMPRESS_CHUNK;
+	const size_t chunk = (n + nchunks - 1) / nchunks;
 	nxz_ctx::Scratch sc;
 	{
 		std::lock_guard<std::mutex> g(c->mtx);
 		nxz_ctx::Scratch &r = c->scratch[s];
-		const size_t chunk = n < COMPRESS_CHUNK ? n : COMPRESS_CHUNK;
 		if (r.chunk_cap < chunk) {
 			// grows only: warm up once with the largest batch before timing a loop
 			if (r.d_tokens) { (void)hipStreamSynchronize(s); (void)hipFree(r.d_tokens); (void)hipFree(r.d_gen); (void)hipFree(r.d_counts); }
@@ -263,23 +268,66 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 		int rc = nxz_launch_dht_prepare(dht, ntables, prepared, s);
 		if (rc) { set_err("dht prepare launch", (hipError_t)rc); return -EIO; }
 	}
-	for (size_t off = 0; off < n; off += COMPRESS_CHUNK) {
-		const size_t m = n - off < COMPRESS_CHUNK ? n - off : COMPRESS_CHUNK;
+	for (size_t off = 0; off < n; off += chunk) {
+		const size_t m = n - off < chunk ? n - off : chunk;
 		uint32_t *jc = nullptr;
 		{
 			std::lock_guard<std::mutex> g(c->mtx);
 			if (c->d_job_counters) jc = c->d_job_counters + (c->next_counter++ % JOB_COUNTERS);
 		}
 		uint32_t *cnt = count ? counts + off * 316 : gen ? sc.d_counts : nullptr;
+		auto stamp = [&]() {
+			if (!c->timing) return;
+			hipEvent_t e;
+			if (hipEventCreate(&e) != hipSuccess) return;
+			(void)hipEventRecord(e, s);
+			std::lock_guard<std::mutex> g(c->mtx);
+			c->tev.push_back(e);
+		};
+		stamp();
 		int rc = nxz_launch_lz77(cnt != nullptr, jobs + off, m, sc.d_tokens, sc.d_cand2, results + off, cnt, jc, s);
 		if (rc) { set_err("lz77 launch", (hipError_t)rc); return -EIO; }
+		stamp();
 		if (gen) {
 			rc = nxz_launch_dhtgen(cnt, m, sc.d_gen, nullptr, s);
 			if (rc) { set_err("dhtgen launch", (hipError_t)rc); return -EIO; }
 		}
+		stamp();
 		rc = nxz_launch_encode(isdht, gen, jobs + off, m, sc.d_tokens, gen ? sc.d_gen : prepared, results + off, s);
 		if (rc) { set_err("encode launch", (hipError_t)rc); return -EIO; }
+		stamp();
 	}
+	return 0;
+}
+
+// Measurement aid: with timing on, every compress batch records events around its kernels;
+// nxz_ctx_stage_ms waits for them and returns the milliseconds spent in the LZ77, dhtgen and
+// entropy kernels since the last call (and the number of launches of each).
+extern "C" void nxz_ctx_stage_timing(nxz_ctx_t *c, int on)
+{
+	if (!c) return;
+	std::lock_guard<std::mutex> g(c->mtx);
+	c->timing = on != 0;
+}
+
+extern "C" int nxz_ctx_stage_ms(nxz_ctx_t *c, double ms[3], unsigned *launches)
+{
+	if (!c || !ms) return -EINVAL;
+	std::vector<hipEvent_t> ev;
+	{
+		std::lock_guard<std::mutex> g(c->mtx);
+		ev.swap(c->tev);
+	}
+	ms[0] = ms[1] = ms[2] = 0;
+	if (launches) *launches = (unsigned)(ev.size() / 4);
+	for (size_t i = 0; i + 3 < ev.size(); i += 4) {
+		(void)hipEventSynchronize(ev[i + 3]);
+		for (int k = 0; k < 3; k++) {
+			float f = 0;
+			if (hipEventElapsedTime(&f, ev[i + k], ev[i + k + 1]) == hipSuccess) ms[k] += f;
+		}
+	}
+	for (auto e : ev) (void)hipEventDestroy(e);
 	return 0;
 }
 

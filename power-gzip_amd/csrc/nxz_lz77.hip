@@ -45,7 +45,11 @@
 // Diagnostic only (tools/phase_profile.py): per-phase cycle sums of every workgroup's thread 0.
 __device__ unsigned long long *nxz_lz77_prof_buf = nullptr;
 #define NXZ_GLOBAL NXZ_GLOBAL_AS
-#define PROF(idx) do { if (prof) { if (t == 0) { unsigned long long now_ = clock64(); __hip_atomic_fetch_add(&prof[idx], now_ - tprev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tprev = now_; } } } while (0)
+#define WPROF_BEGIN() unsigned long long wp_ = prof ? clock64() : 0
+#define WPROF_END(idx) do { if (prof) { const unsigned long long now_ = clock64(); wacc[(idx) - 16] += now_ - wp_; wp_ = now_; } } while (0)
+// (phase sums are collected in LDS and leave with one atomic per counter and job: the chain wave
+// waits on its own vector-memory counter, an atomic in flight there would be timed as chain)
+#define PROF(idx) do { if (prof) { if (t == 0) { unsigned long long now_ = clock64(); profacc[idx] += (uint32_t)(now_ - tprev); tprev = now_; } } } while (0)
 
 namespace nxzl77 {
 
@@ -86,7 +90,8 @@ static_assert(OFF_EB % 16 == 0 && OFF_EB + 2096 <= OFF_BITS + BITS_BYTES, "match
 constexpr uint32_t OFF_SCAN  = OFF_BITS + BITS_BYTES;    // 64 x u32
 constexpr uint32_t OFF_HIST  = OFF_SCAN + 256;           // 316 x u32
 constexpr uint32_t OFF_MISC  = OFF_HIST + 316 * 4;       // 16 x u32
-constexpr uint32_t LDS_BYTES = OFF_MISC + 64;
+constexpr uint32_t OFF_PROF  = OFF_MISC + 64;            // 20 x u32 (diagnostic)
+constexpr uint32_t LDS_BYTES = OFF_PROF + 80;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
@@ -234,6 +239,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	uint32_t *scan = (uint32_t *)(lds + OFF_SCAN);
 	uint32_t *hist = (uint32_t *)(lds + OFF_HIST);
 	uint32_t *misc = (uint32_t *)(lds + OFF_MISC);
+	uint32_t *profacc = (uint32_t *)(lds + OFF_PROF);
 
 	NXZ_GLOBAL unsigned long long *prof = (NXZ_GLOBAL unsigned long long *)nxz_lz77_prof_buf;
 	// The grid is one workgroup per CU (the LDS image allows no more); a workgroup starts with job
@@ -248,6 +254,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	asm volatile("" : "+v"(tid_));
 	const int t = tid_, lane = t & 63, wave = t >> 6;
 	unsigned long long tprev = prof ? clock64() : 0;
+	unsigned long long wacc[4] = { 0, 0, 0, 0 };               // diagnostic: this wave's cycles in sections of the match phase
 	const nxz_batch_job_t job = jobs[bid];
 	const uint32_t total = job.src_len;                  // window + block
 	const uint32_t h = job.hist_len < total ? job.hist_len : total;
@@ -274,6 +281,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	for (uint32_t i = t; i < HSIZE; i += NT) head[i] = 0;
 	if (t < 316) hist[t] = 0;
 	if (t < 16 && t != M_NEXT) misc[t] = 0;
+	if (t < 20) profacc[t] = 0;
 	// slice-by-4 CRC tables live in the (not yet used) bit buffer: T[k][i] = i advanced by k+1 zero bytes
 	{
 		uint32_t c = t & 255;
@@ -758,9 +766,11 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 				if (lane == 0) piece = atomicAdd(&misc[M_TICKET], 1u);
 				piece = __builtin_amdgcn_readfirstlane(piece);
 				if (piece >= npieces) break;
+				WPROF_BEGIN();
 				while (__hip_atomic_load(&misc[M_PROGRESS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= piece)
 					__builtin_amdgcn_s_sleep(4);
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				WPROF_END(16);                                         // waiting for the chain
 				// back to the natural order: position i of the piece at cand[i]
 				{
 					const uint4 pk = ((const uint4 *)cand)[(piece << 6) + lane];
@@ -878,13 +888,19 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 						if (bits) lq[lqn + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((i4 >> 2) | bits << 12);
 						lqn += (uint32_t)__popcll(m);
 						__builtin_amdgcn_wave_barrier();
+						WPROF_END(17);                                 // M1
 						while (lqn >= 32) { stage2(lqn); lqn = lqn > 64 ? lqn - 64 : 0; }
+						WPROF_END(18);                                 // M2 (classification, tails)
 						rest &= rest - 1;
 					}
 				}
 			}
-			if (lqn) stage2(lqn);
-			if (xqn) longext(xqn);
+			{
+				WPROF_BEGIN();
+				if (lqn) stage2(lqn);
+				if (xqn) longext(xqn);
+				WPROF_END(19);                                         // M2, what was left in the queues
+			}
 		}
 		__syncthreads();
 		PROF(12);
@@ -1194,6 +1210,13 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		r.spbc = total; r.crc = out_crc; r.adler = out_adler; r.subc = 0;
 		r.sfbt = misc[M_NREC];                                  // match tokens (diagnostic; the entropy stage checks it against the record array's size)
 		results[bid] = r;
+	}
+	if (prof) {
+		// (one atomic per counter and job: thousands of waves adding to four addresses would stall every
+		// wave's next loads behind them)
+		if (lane == 0) for (int k = 0; k < 4; k++) atomicAdd(&profacc[16 + k], (uint32_t)wacc[k]);
+		__syncthreads();
+		if (t < 20) __hip_atomic_fetch_add(&prof[t], (unsigned long long)profacc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	if (COUNT) {
 		__syncthreads();

@@ -57,3 +57,46 @@ def test_generator_is_deterministic_per_block_index():
     import zlib
     blk = a[1].numpy().tobytes()
     assert len(zlib.compress(blk, 1)) < 0.7 * len(blk)
+
+
+def _worker_c5(rank, world, port, q):
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = 11                                                       # odd on purpose: shards of 6 and 5
+    lo, hi = bench.shard_strong(total, rank, world)
+    blocks = bench.gen_mixed(torch, torch.device("cpu"), hi - lo, lo)
+    kinds = [int(b.sum() == 0) for b in blocks]                      # zeros at global index % 4 == 0
+    tot_u, _, wall_max = bench.reduce_totals(torch, dist, torch.device("cpu"), float(blocks.numel()), 1.0, 1.0 + rank, True)
+    q.put((rank, lo, hi, kinds, tot_u, wall_max))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_strong_scaled_shards_of_the_mixed_batch():
+    """config c5 (BASELINE configs[4]): one fixed batch, contiguous shards, every block index once"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_c5, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, k0, u0, w0), (r1, lo1, hi1, k1, u1, w1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 6, 6, 11)
+    assert k0 == [1, 0, 0, 0, 1, 0] and k1 == [0, 0, 1, 0, 0]        # global index mod 4 decides the kind
+    assert u0 == u1 == 11 * 65536 and w0 == w1 == 2.0
+
+
+def test_mixed_batch_kinds():
+    import bench
+    import zlib
+    b = bench.gen_mixed(torch, torch.device("cpu"), 8, 0).numpy()
+    sizes = [len(zlib.compress(row.tobytes(), 1)) for row in b]
+    assert sizes[0] < 400 and sizes[4] < 400                         # zeros
+    assert sizes[3] > 65536 and sizes[7] > 65536                     # random bytes: stored path
+    assert 30000 < sizes[1] < 50000 and 20000 < sizes[2] < 50000     # 33-symbol text; text + LZ copies

@@ -11,7 +11,13 @@ FC = {"fht": pkg.FC_COMPRESS_FHT, "dhtgen": pkg.FC_COMPRESS_DHTGEN}[os.environ.g
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = pkg.Engine(0)
 src = bench.gen_blocks(torch, eng.dev, n, 0)
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and sys.argv[2] == "corpus":
+    import corpus
+    _, blocks, _ = corpus.load(65536)
+    full = [np.frombuffer(b, np.uint8) for _, _, b in blocks if len(b) == 65536]
+    host = np.stack([full[i % len(full)] for i in range(n)])
+    src = torch.from_numpy(host).to(eng.dev)
+elif len(sys.argv) > 2:
     from datagen import make_block
     b = np.frombuffer(make_block(sys.argv[2], 65536, 1), np.uint8)
     src[:] = torch.from_numpy(b.copy()).to(eng.dev)
@@ -30,4 +36,5 @@ p = prof.cpu().numpy().astype(np.float64) / n
 tot = p[:16].sum()
 for i, name in enumerate(NAMES):
     print("%-20s %10.0f cycles/block  %5.1f%%" % (name, p[i], 100 * p[i] / tot))
+print("match waves, wave-cycles per block: waiting for the chain %.0f, M1 %.0f, M2 in the loop %.0f, M2 leftovers %.0f" % (p[16], p[17], p[18], p[19]))
 print("total %.0f cycles/block (s_memtime ticks = 100 MHz? see guide)" % tot)
