@@ -274,6 +274,20 @@ int nxz_batch_decompress(nxz_ctx_t *ctx,
 			 nxz_batch_result_t *results,
 			 nxz_batch_dht_t *dht_io, void *stream);
 
+/* ONE long raw-deflate stream, decoded in parallel by block-boundary speculation (additive; the
+ * reference inflates a stream job after job, lib/nx_inflate.c:1060-1762).  src (DEVICE, src_len
+ * bytes) holds the stream from bit first_bit on and must reach its final block; hist (DEVICE or
+ * NULL): up to 32 KiB that precede the output (dictionary / earlier output); dst (DEVICE).
+ * Synchronous.  Returns 0: *out_len bytes at dst, *crc / *adler of exactly those bytes (combine
+ * them with yours), *end_bit = first bit behind the final block, *pieces / *rounds for the curious.
+ * -ENOTSUP: the stream does not lend itself to it (shorter than 1 MiB, hardly any dynamic blocks, no
+ * final block inside src, ...): use nxz_batch_decompress / nxu_run_job's resume loop.  -E2BIG:
+ * dst_cap too small (*out_len = bytes needed).  -EILSEQ: not a deflate stream. */
+int nxz_inflate_stream(nxz_ctx_t *ctx, const uint8_t *src, uint64_t src_len, uint64_t first_bit,
+		       const uint8_t *hist, uint32_t hist_len, uint8_t *dst, uint64_t dst_cap,
+		       uint64_t *out_len, uint32_t *crc, uint32_t *adler, uint64_t *end_bit,
+		       uint32_t *pieces, uint32_t *rounds, void *stream);
+
 /* Batched wrap (FC 0x1e): copy + crc32 + adler32 from the initial values. */
 int nxz_batch_wrap(nxz_ctx_t *ctx, const nxz_batch_job_t *jobs, size_t n,
 		   nxz_batch_result_t *results, void *stream);

@@ -1,0 +1,347 @@
+// nxz_blockfind.hip -- block-boundary speculation for ONE long deflate stream (gfx950, wave64).
+//
+// A deflate stream is serial: the reference's inflate loop (/root/reference lib/nx_inflate.c:1060-1762)
+// feeds the accelerator job after job, each resuming where the last one stopped, and relies on
+// an engine that is fast on a single stream (7 GB/s on POWER9, samples/simpleapi/README:27-30).
+// A GPU gets there by decoding many pieces of the stream at once, and for that it must know
+// where deflate blocks start inside it.  find_blocks_kernel scans every bit position of every
+// 8 KiB segment of the compressed stream for a plausible header of a non-final dynamic-Huffman
+// block (RFC 1951 3.2.7) and reports the first one per segment:
+//   BFINAL = 0, BTYPE = 10, HLIT <= 29, HDIST <= 29,
+//   the code-length code complete (Kraft sum exactly 1),
+//   the HLIT + 257 + HDIST + 1 code lengths decode without a bad repeat or an overrun,
+//   end-of-block has a code, the literal/length code is complete, the distance code is
+//   complete, empty or a single code of one bit (what zlib's inflate_table accepts).
+// Nothing but a real header passes all of that in practice (a wrong guess would be caught later:
+// the piece in front of it then does not end at a block header, and the stream's CRC-32 is
+// checked at the end).  Stored and fixed blocks are not searched for (a stored header is only
+// LEN == ~NLEN, one position in 65536 passes by chance): a stretch of such blocks is decoded as
+// part of the piece in front of it.
+//
+// The other kernels here move data between the rounds of the speculative decode (nxz_engine.cpp,
+// nxz_inflate_stream): copy_items_kernel (a list of byte ranges, workgroup per item).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nxz_device.h"
+
+namespace nxzb {
+
+constexpr int NT = 256;
+constexpr uint32_t SEG = 8192;                  // bytes of the stream per workgroup
+constexpr uint32_t LOOK = 320;                  // a header is at most 17 + 19 * 3 + 316 * 7 + ... bits: < 300 bytes
+constexpr uint32_t MAXCAND = 1024;
+
+__device__ __forceinline__ uint32_t peek(const uint8_t *s, uint32_t bit, uint32_t n)   // n <= 25
+{
+	const uint32_t by = bit >> 3;
+	const uint32_t w = (uint32_t)s[by] | (uint32_t)s[by + 1] << 8 | (uint32_t)s[by + 2] << 16 | (uint32_t)s[by + 3] << 24;
+	return (w >> (bit & 7)) & ((1u << n) - 1);
+}
+
+// the full check of a candidate (one lane); `limit` = first bit that is not part of the stream
+__device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
+{
+	if (bit + 17 > limit) return false;
+	uint32_t v = peek(s, bit, 17);
+	const uint32_t hlit = ((v >> 3) & 31) + 257, hdist = ((v >> 8) & 31) + 1, hclen = ((v >> 13) & 15) + 4;
+	uint32_t pos = bit + 17;
+	if (pos + 3 * hclen > limit) return false;
+	const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+	// code-length code: lengths packed 3 bits per symbol, counts per length
+	uint64_t cll = 0;
+	uint32_t cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	for (uint32_t i = 0; i < hclen; i++) {
+		const uint32_t l = peek(s, pos, 3);
+		pos += 3;
+		cll |= (uint64_t)l << (3 * order[i]);
+		cnt[l]++;
+	}
+	// canonical decode by counts (first code / first symbol index per length), symbols in order
+	uint8_t symtab[19];
+	{
+		uint32_t offs[8], o = 0;
+		for (int l = 1; l < 8; l++) { offs[l] = o; o += cnt[l]; }
+		for (uint32_t sy = 0; sy < 19; sy++) {
+			const uint32_t l = (uint32_t)(cll >> (3 * sy)) & 7;
+			if (l) symtab[offs[l]++] = (uint8_t)sy;
+		}
+	}
+	uint32_t n = 0, prev = 0, kraft_ll = 0, kraft_d = 0, nd = 0, maxd = 0, eob = 0;
+	const uint32_t total = hlit + hdist;
+	while (n < total) {
+		// one code-length symbol, bit by bit
+		uint32_t code = 0, first = 0, index = 0, sym = 0xff;
+		for (uint32_t l = 1; l <= 7; l++) {
+			if (pos >= limit) return false;
+			code |= (s[pos >> 3] >> (pos & 7)) & 1u;
+			pos++;
+			const uint32_t c = cnt[l];
+			if (code < first + c) { sym = symtab[index + (code - first)]; break; }
+			index += c; first = (first + c) << 1; code <<= 1;
+		}
+		if (sym == 0xff) return false;
+		uint32_t rep = 1, val = sym;
+		if (sym == 16) {
+			if (n == 0 || pos + 2 > limit) return false;
+			rep = 3 + peek(s, pos, 2); pos += 2; val = prev;
+		} else if (sym == 17) {
+			if (pos + 3 > limit) return false;
+			rep = 3 + peek(s, pos, 3); pos += 3; val = 0;
+		} else if (sym == 18) {
+			if (pos + 7 > limit) return false;
+			rep = 11 + peek(s, pos, 7); pos += 7; val = 0;
+		}
+		if (n + rep > total) return false;
+		if (sym < 16) prev = sym; else if (sym != 16) prev = 0;
+		if (val) {
+			for (uint32_t k = 0; k < rep; k++) {
+				const uint32_t i = n + k;
+				if (i < hlit) { kraft_ll += 1u << (15 - val); if (i == 256) eob = 1; }
+				else { kraft_d += 1u << (15 - val); nd++; if (val > maxd) maxd = val; }
+			}
+		}
+		n += rep;
+	}
+	if (!eob || kraft_ll != (1u << 15)) return false;
+	if (!(kraft_d == (1u << 15) || nd == 0 || (nd == 1 && maxd == 1))) return false;
+	return true;
+}
+
+// first[seg] = bit position (in the whole stream) of the first plausible dynamic block header that
+// starts inside segment seg, or 0xffffffffffffffff
+__global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restrict__ src, uint64_t srclen, uint64_t first_bit,
+							   uint64_t *__restrict__ first, uint32_t nseg)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t s[SEG + LOOK + 16];
+	__shared__ uint32_t cand[MAXCAND];
+	__shared__ uint32_t ncand, best;
+	const int t = threadIdx.x;
+	const uint32_t seg = blockIdx.x;
+	if (seg >= nseg) return;
+	const uint64_t base = (uint64_t)seg * SEG;
+	const uint32_t have = (uint32_t)(srclen - base < SEG + LOOK ? srclen - base : SEG + LOOK);
+	for (uint32_t i = t; i < SEG + LOOK + 16; i += NT) s[i] = i < have ? src[base + i] : 0;
+	if (t == 0) { ncand = 0; best = 0xffffffffu; }
+	__syncthreads();
+	const uint32_t limit = have * 8;
+	const uint32_t nbits = (have < SEG ? have : SEG) * 8;
+	// phase 1: the cheap part of the test at every bit position of the segment
+	for (uint32_t p = t; p < nbits; p += NT) {
+		if (base * 8 + p < first_bit) continue;
+		if (p + 17 > limit) break;
+		const uint32_t v = peek(s, p, 17);
+		// BFINAL 0, BTYPE 10 (bits 1..2 = 0b10 -> value 2), HLIT <= 29, HDIST <= 29
+		if ((v & 7) != 4 || ((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) continue;
+		const uint32_t hclen = ((v >> 13) & 15) + 4;
+		if (p + 17 + 3 * hclen > limit) continue;
+		uint32_t kraft = 0, q = p + 17;
+		for (uint32_t i = 0; i < hclen; i++, q += 3) {
+			const uint32_t l = peek(s, q, 3);
+			kraft += l ? 128u >> l : 0;
+		}
+		if (kraft != 128) continue;
+		const uint32_t k = atomicAdd(&ncand, 1u);
+		if (k < MAXCAND) cand[k] = p;
+	}
+	__syncthreads();
+	// phase 2: the whole header, a lane per survivor
+	const uint32_t nc = ncand < MAXCAND ? ncand : MAXCAND;
+	for (uint32_t k = t; k < nc; k += NT) {
+		const uint32_t p = cand[k];
+		if (p < best && header_ok(s, p, limit)) atomicMin(&best, p);
+	}
+	__syncthreads();
+	if (t == 0) first[seg] = best == 0xffffffffu ? ~0ull : base * 8 + best;
+}
+
+// items[i] = { src, dst, bytes }: dst <- src (any alignment; a workgroup per item)
+struct CopyItem { const uint8_t *src; uint8_t *dst; uint64_t bytes; };
+
+__global__ __launch_bounds__(NT) void copy_items_kernel(const CopyItem *__restrict__ items, uint32_t n)
+{
+	const uint32_t i = blockIdx.x;
+	if (i >= n) return;
+	const CopyItem it = items[i];
+	const uint8_t NXZ_GLOBAL_AS *sp = (const uint8_t NXZ_GLOBAL_AS *)it.src;
+	uint8_t NXZ_GLOBAL_AS *dp = (uint8_t NXZ_GLOBAL_AS *)it.dst;
+	uint64_t nbytes = it.bytes;
+	const int t = threadIdx.x;
+	if (!nbytes) return;
+	if ((uintptr_t)it.src < 16) {
+		// fills: 0 zeros; 1, 2, 3 the three probe windows of the speculative decode (a window byte at
+		// index k -- k counted from the item's first byte -- is k's low byte, its high byte, or 255 - low byte)
+		const uint32_t mode = (uint32_t)(uintptr_t)it.src;
+		for (uint64_t k = t; k < nbytes; k += NT)
+			dp[k] = mode == 0 ? 0 : mode == 1 ? (uint8_t)k : mode == 2 ? (uint8_t)(k >> 8) : (uint8_t)(255 - (k & 255));
+		return;
+	}
+	if ((((uintptr_t)it.src ^ (uintptr_t)it.dst) & 15) == 0 && nbytes >= 64) {
+		// same alignment: bytes up to a 16-byte boundary, then 16 bytes per lane
+		const uint32_t head = (uint32_t)((16 - ((uintptr_t)it.dst & 15)) & 15);
+		if ((uint32_t)t < head) dp[t] = sp[t];
+		typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+		const v4u NXZ_GLOBAL_AS *s4 = (const v4u NXZ_GLOBAL_AS *)(sp + head);
+		v4u NXZ_GLOBAL_AS *d4 = (v4u NXZ_GLOBAL_AS *)(dp + head);
+		const uint64_t nv = (nbytes - head) >> 4;
+		for (uint64_t k = t; k < nv; k += NT) d4[k] = s4[k];
+		const uint64_t done = head + (nv << 4);
+		if (done + t < nbytes) dp[done + t] = sp[done + t];
+	} else {
+		for (uint64_t k = t; k < nbytes; k += NT) dp[k] = sp[k];
+	}
+}
+
+// flags[i] = 1 when the two byte ranges of item i differ
+__global__ __launch_bounds__(NT) void differ_items_kernel(const CopyItem *__restrict__ items, uint32_t n, uint32_t *__restrict__ flags)
+{
+	const uint32_t i = blockIdx.x;
+	if (i >= n) return;
+	const CopyItem it = items[i];
+	const uint8_t NXZ_GLOBAL_AS *a = (const uint8_t NXZ_GLOBAL_AS *)it.src;
+	const uint8_t NXZ_GLOBAL_AS *b = (const uint8_t NXZ_GLOBAL_AS *)it.dst;
+	bool d = false;
+	for (uint64_t k = threadIdx.x; k < it.bytes; k += NT) d |= a[k] != b[k];
+	if (__syncthreads_or(d) && threadIdx.x == 0) flags[i] = 1;
+}
+
+// ---- resolving what the pieces copied out of their unknown histories ----
+// A piece (but the first) is decoded three times, with the probe windows above as its 32 KiB of
+// history.  Which history byte an output byte is a copy of -- if of any -- does not depend on what
+// the history holds, so for every output byte either all three decodes agree (the byte itself) or
+// they show the low byte, the high byte and 255 - low byte of the window index it comes from:
+// a + c == 255 exactly then (two equal bytes sum to an even number).
+struct Piece { const uint8_t *a, *b, *c; uint64_t len, place; };
+
+__device__ __forceinline__ uint32_t resolve(uint32_t a, uint32_t b, uint32_t c, const uint8_t *win)
+{
+	return a + c == 255 ? win[(b << 8) | a] : a;
+}
+
+// The window behind a piece as a function of the window in front of it: entry k of the piece's
+// tail map is the byte itself (0..255) or 0x8000 | index into the window in front.  A workgroup per
+// piece, all pieces at once.
+__global__ __launch_bounds__(256) void tailmap_kernel(const Piece *__restrict__ pieces, uint32_t n, uint16_t *__restrict__ maps)
+{
+	const uint32_t i = blockIdx.x;
+	if (i >= n) return;
+	const Piece p = pieces[i];
+	const uint64_t L = p.len;
+	uint16_t *m = maps + (size_t)i * 32768;
+	for (uint32_t k = threadIdx.x; k < 32768; k += 256) {
+		uint32_t v;
+		if (L < 32768 && k < 32768 - L) v = 0x8000u | (uint32_t)(k + L);         // still the old window, moved up
+		else {
+			const uint64_t o = L >= 32768 ? L - 32768 + k : k - (32768 - L);
+			const uint32_t a = p.a[o], b = p.b[o], c = p.c[o];
+			v = a + c == 255 ? 0x8000u | (b << 8) | a : a;
+		}
+		m[k] = (uint16_t)v;
+	}
+}
+
+// One workgroup walks the pieces in order and writes, for each, the 32 KiB window BEHIND it
+// (= the history of the next one): windows[i * 32768 ..].  win0 = the window in front of piece 0.
+// A thread owns 32 consecutive entries; the next piece's map is on its way while this one is applied.
+__global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__restrict__ maps, uint32_t n, const uint8_t *__restrict__ win0,
+							     uint8_t *__restrict__ windows)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t w[2][32768];
+	typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+	const int t = threadIdx.x;
+	for (uint32_t k = t; k < 32768 / 16; k += 1024) ((uint4 *)w[0])[k] = ((const uint4 *)win0)[k];
+	__syncthreads();
+	uint32_t cur = 0;
+	const v4u NXZ_GLOBAL_AS *mp = (const v4u NXZ_GLOBAL_AS *)maps;
+	v4u nx[4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) nx[q] = mp[(size_t)0 * 4096 + t * 4 + q];
+	for (uint32_t i = 0; i < n; i++) {
+		v4u m[4];
+#pragma unroll
+		for (int q = 0; q < 4; q++) m[q] = nx[q];
+		if (i + 1 < n) {
+#pragma unroll
+			for (int q = 0; q < 4; q++) nx[q] = mp[(size_t)(i + 1) * 4096 + t * 4 + q];
+		}
+		const uint8_t *wi = w[cur];
+		uint32_t out[8];
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const uint32_t d[4] = { m[q].x, m[q].y, m[q].z, m[q].w };
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				const uint32_t lo = d[e] & 0xffff, hi = d[e] >> 16;
+				const uint32_t b0 = (lo & 0x8000) ? wi[lo & 0x7fff] : lo, b1 = (hi & 0x8000) ? wi[hi & 0x7fff] : hi;
+				const uint32_t idx = q * 8 + e * 2;              // entry pair within my 32
+				out[idx >> 2] = (idx & 2) ? out[idx >> 2] | b0 << 16 | b1 << 24 : b0 | b1 << 8;
+			}
+		}
+		uint4 *wo = (uint4 *)(w[cur ^ 1] + 32 * t);
+		wo[0] = make_uint4(out[0], out[1], out[2], out[3]);
+		wo[1] = make_uint4(out[4], out[5], out[6], out[7]);
+		v4u NXZ_GLOBAL_AS *g = (v4u NXZ_GLOBAL_AS *)(windows + (size_t)i * 32768 + 32 * t);
+		g[0] = (v4u){ out[0], out[1], out[2], out[3] };
+		g[1] = (v4u){ out[4], out[5], out[6], out[7] };
+		__syncthreads();
+		cur ^= 1;
+	}
+}
+
+// every piece to its place: final[place + o] = the byte, or the byte of its history it is a copy of
+__global__ __launch_bounds__(256) void resolve_kernel(const Piece *__restrict__ pieces, uint32_t n, const uint8_t *__restrict__ win0,
+						       const uint8_t *__restrict__ windows, uint8_t *__restrict__ dst, uint32_t blocks_per_piece)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t w[32768];
+	const uint32_t i = blockIdx.x / blocks_per_piece, part = blockIdx.x % blocks_per_piece;
+	if (i >= n) return;
+	const Piece p = pieces[i];
+	const uint64_t per = (p.len + blocks_per_piece - 1) / blocks_per_piece;
+	const uint64_t lo = (uint64_t)part * per, hi = lo + per < p.len ? lo + per : p.len;
+	if (lo >= hi) return;
+	const uint8_t *win = i ? windows + (size_t)(i - 1) * 32768 : win0;
+	for (uint32_t k = threadIdx.x; k < 32768 / 16; k += 256) ((uint4 *)w)[k] = ((const uint4 *)win)[k];
+	__syncthreads();
+	uint8_t *out = dst + p.place;
+	for (uint64_t o = lo + threadIdx.x; o < hi; o += 256) out[o] = (uint8_t)resolve(p.a[o], p.b[o], p.c[o], w);
+}
+
+} // namespace nxzb
+
+extern "C" uint32_t nxz_blockfind_segment(void) { return nxzb::SEG; }
+
+extern "C" int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, hipStream_t stream)
+{
+	if (!nseg) return 0;
+	hipLaunchKernelGGL(nxzb::find_blocks_kernel, dim3(nseg), dim3(nxzb::NT), 0, stream, src, srclen, first_bit, first, nseg);
+	return (int)hipGetLastError();
+}
+
+extern "C" int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL(nxzb::copy_items_kernel, dim3(n), dim3(nxzb::NT), 0, stream, (const nxzb::CopyItem *)items, n);
+	return (int)hipGetLastError();
+}
+
+extern "C" int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint16_t *maps, uint8_t *windows, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL(nxzb::tailmap_kernel, dim3(n), dim3(256), 0, stream, (const nxzb::Piece *)pieces, n, maps);
+	hipLaunchKernelGGL(nxzb::window_chain_kernel, dim3(1), dim3(1024), 0, stream, (const uint16_t *)maps, n, win0, windows);
+	return (int)hipGetLastError();
+}
+
+extern "C" int nxz_launch_resolve(const void *pieces, uint32_t n, const uint8_t *win0, const uint8_t *windows, uint8_t *dst, hipStream_t stream)
+{
+	if (!n) return 0;
+	const uint32_t bpp = 4;
+	hipLaunchKernelGGL(nxzb::resolve_kernel, dim3(n * bpp), dim3(256), 0, stream, (const nxzb::Piece *)pieces, n, win0, windows, dst, bpp);
+	return (int)hipGetLastError();
+}
+
+extern "C" int nxz_launch_differ_items(const void *items, uint32_t n, uint32_t *flags, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL(nxzb::differ_items_kernel, dim3(n), dim3(nxzb::NT), 0, stream, (const nxzb::CopyItem *)items, n, flags);
+	return (int)hipGetLastError();
+}

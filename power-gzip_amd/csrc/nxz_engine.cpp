@@ -103,7 +103,7 @@ static constexpr unsigned JOB_COUNTERS = 256;
 //   from NXZ_LANES_MIN streams on      a stream per lane: 55-60 ms however few streams, 51 GiB/s at 65 536,
 //                                      110 at 262 144
 // The wave kernels need 16-byte aligned sources, as the batch interface demands.
-#define NXZ_LANES_MIN 57344
+#define NXZ_LANES_MIN 131072
 #define NXZ_WINDOW_LDS_MAX 1024
 
 static std::mutex g_mtx;

@@ -308,6 +308,23 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 		if (GW) { const uint32_t back = out - p; return back > out ? hist_end[-(ptrdiff_t)(back - out)] : dst[p]; }
 		return sm.win[p & WMASK];
 	};
+	// A match, lane per byte (the source pattern repeats with period dist when dist < len).  Every
+	// source byte lies in front of `out`, so all the loads (five at most: len <= 258) are issued
+	// before the first store: one round trip to the window per match instead of one per 64 bytes --
+	// what counts when the window is the target in device memory and the data is mostly long matches.
+	auto copy_match = [&](uint32_t dist, uint32_t len) {
+		uint32_t v[5];
+#pragma unroll
+		for (int k = 0; k < 5; k++) {
+			const uint32_t i = lane + 64 * k;
+			v[k] = i < len ? rd(out - dist + (dist >= len ? i : i % dist)) : 0;
+		}
+#pragma unroll
+		for (int k = 0; k < 5; k++) {
+			const uint32_t i = lane + 64 * k;
+			if (i < len) wr(out + i, v[k]);
+		}
+	};
 #ifdef NXZ_INFLATE_PROF
 	unsigned long long *prof = prof_buf;
 	unsigned long long tprev = prof ? clock64() : 0;
@@ -565,11 +582,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 					const uint32_t o3 = o2 + (d >> 12);
 					const uint32_t dist = dbase + (bits_at(o3) & ((1u << ebd) - 1));
 					if (dist > out + hist || dist > WIN || len > cap - out) break;
-					if (dist >= len) {
-						for (uint32_t i = lane; i < len; i += 64) wr(out + i, rd(out - dist + i));
-					} else {
-						for (uint32_t i = lane; i < len; i += 64) wr(out + i, rd(out - dist + i % dist));
-					}
+					copy_match(dist, len);
 					out += len; off = o3 + ebd;                                 // <= 63 + 9 + 13 < 96
 					if (off > 47 || out - flushed >= FLUSH) break;
 				}
@@ -626,11 +639,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 				b.bb_drop(eb);
 				if (dist > out + hist || dist > WIN) { cc = NXZ_CC_INVALID_DIST; break; }
 				if (len > cap - out) { cc = NXZ_CC_TARGET_SPACE; break; }
-				// lane per byte; source pattern repeats with period dist
-				for (uint32_t i = lane; i < len; i += 64) {
-					uint32_t k = dist >= len ? i : i % dist;
-					wr(out + i, rd(out - dist + k));
-				}
+				copy_match(dist, len);
 				out += len;
 			}
 			if (out - flushed >= FLUSH) { __syncthreads(); flush(flushed + FLUSH); }

@@ -1,0 +1,332 @@
+// nxz_pinflate.cpp -- one long deflate stream decoded in parallel: block-boundary speculation.
+//
+// The reference inflates a stream job after job (/root/reference lib/nx_inflate.c:1060-1762:
+// every job resumes where the last one stopped, with the last 32 KiB of output as its history),
+// which is fast on an engine that is fast on ONE stream (7.16 GB/s for silesia.tar on POWER9,
+// samples/simpleapi/README:27-30).  A wavefront decodes one stream at 15-18 MB/s; the GPU is fast
+// on MANY streams.  So the stream is cut where deflate blocks start (nxz_blockfind.hip finds
+// the headers of dynamic blocks by trying every bit position), and the pieces -- about one deflate
+// block each -- are decoded side by side with the engine's ordinary batched decompress jobs
+// (DECOMPRESS_RESUME: source bit offset in in_subc, 32 KiB history in front of the source).
+// What a piece does not know is its history: the 32 KiB of output in front of it.  But which
+// history byte an output byte is a copy of (directly or through copies of copies) does not depend
+// on what the history holds.  So every piece but the first is decoded THREE times in the same
+// batch, with three probe histories -- byte k of the window = k's low byte, k's high byte,
+// 255 - low byte -- and for every output byte the three results either agree (the byte itself:
+// two equal bytes never sum to 255) or spell the window index it comes from.  Then
+//   - every piece's length, hence its place in the output, is known, and so is whether the piece
+//     in front of it ends exactly at its header (a wrong guess of a block start shows here: the
+//     boundary is dropped, the pieces are merged, the batch is run again);
+//   - one workgroup walks the pieces in order and makes the true 32 KiB window behind each
+//     (32 KiB of look-ups per piece);
+//   - all pieces are resolved into place at once: final byte = the byte, or window[index].
+// The CRC-32 / Adler-32 of the output are computed over 256 KiB slices and combined (zlib's
+// crc32_combine idea); the caller checks them against the trailer as for any stream.
+#include <hip/hip_runtime.h>
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <algorithm>
+#include <mutex>
+#include <vector>
+#include "nxz_device.h"
+
+extern "C" {
+uint32_t nxz_blockfind_segment(void);
+int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, hipStream_t stream);
+int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);
+int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint16_t *maps, uint8_t *windows, hipStream_t stream);
+int nxz_launch_resolve(const void *pieces, uint32_t n, const uint8_t *win0, const uint8_t *windows, uint8_t *dst, hipStream_t stream);
+}
+
+namespace {
+
+struct CopyItem { const uint8_t *src; uint8_t *dst; uint64_t bytes; };      // src below 16: a fill (nxz_blockfind.hip)
+struct Piece { const uint8_t *a, *b, *c; uint64_t len, place; };
+
+constexpr uint32_t WINDOW = 32768;
+constexpr uint64_t SLICE = 256 << 10;            // checksum slices
+
+// GF(2) helpers for crc32_combine: multiply modulo the reflected CRC-32 polynomial
+uint32_t gf_mul(uint32_t a, uint32_t b)
+{
+	uint32_t r = 0;
+	for (int i = 0; i < 32; i++) {
+		if (b & 0x80000000u) r ^= a;
+		a = (a >> 1) ^ ((a & 1) ? 0xedb88320u : 0);
+		b <<= 1;
+	}
+	return r;
+}
+uint32_t gf_xpow8(uint64_t n)            // x^(8n)
+{
+	uint32_t r = 0x80000000u, sq = 0x00800000u;
+	for (; n; n >>= 1) { if (n & 1) r = gf_mul(r, sq); sq = gf_mul(sq, sq); }
+	return r;
+}
+uint32_t crc_combine(uint32_t c1, uint32_t c2, uint64_t len2) { return gf_mul(c1, gf_xpow8(len2)) ^ c2; }
+uint32_t adler_combine(uint32_t a1, uint32_t a2, uint64_t len2)
+{
+	const uint32_t BASE = 65521;
+	const uint32_t rem = (uint32_t)(len2 % BASE);
+	uint32_t s1 = a1 & 0xffff, s2 = (uint32_t)(((uint64_t)rem * s1) % BASE);
+	s1 += (a2 & 0xffff) + BASE - 1;
+	s2 += (a1 >> 16) + (a2 >> 16) + BASE - rem;
+	if (s1 >= BASE) s1 -= BASE;
+	if (s1 >= BASE) s1 -= BASE;
+	if (s2 >= (BASE << 1)) s2 -= (BASE << 1);
+	if (s2 >= BASE) s2 -= BASE;
+	return s1 | (s2 << 16);
+}
+
+// grow-only device/pinned workspace per context call (guarded by a mutex: one long stream at a time per context)
+struct Workspace {
+	void *dev = nullptr; size_t dev_cap = 0;
+	void *pin = nullptr; size_t pin_cap = 0;
+	std::mutex mtx;
+	bool need(size_t d, size_t p)
+	{
+		if (d > dev_cap) {
+			if (dev) (void)hipFree(dev);
+			dev = nullptr; dev_cap = 0;
+			if (hipMalloc(&dev, d) != hipSuccess) return false;
+			dev_cap = d;
+		}
+		if (p > pin_cap) {
+			if (pin) (void)hipHostFree(pin);
+			pin = nullptr; pin_cap = 0;
+			if (hipHostMalloc(&pin, p) != hipSuccess) return false;
+			pin_cap = p;
+		}
+		return true;
+	}
+};
+Workspace g_ws[64];
+
+inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace
+
+// Raw deflate stream at src (DEVICE memory, src_len bytes; it starts at bit first_bit and must run
+// to a final block) -> dst (DEVICE).  hist (may be NULL): up to 32 KiB of DEVICE bytes that precede
+// the output (a preset dictionary or what was inflated before).  Synchronous.
+//   0        done: *out_len bytes, checksums of them continued from 0 / 1 style initial values
+//            (crc of the data alone, adler of the data alone: combine with yours), *end_bit = first
+//            bit behind the final block
+//   -ENOTSUP the stream does not lend itself to this (too short, too few dynamic blocks, a piece that
+//            blows its buffer, no final block inside src): use the ordinary resume loop
+//   -E2BIG   dst_cap is too small (*out_len = bytes needed)        -EILSEQ  the data is not deflate
+extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, uint64_t first_bit,
+				  const uint8_t *hist, uint32_t hist_len,
+				  uint8_t *dst, uint64_t dst_cap, uint64_t *out_len, uint32_t *crc, uint32_t *adler,
+				  uint64_t *end_bit, uint32_t *pieces, uint32_t *rounds, void *stream_)
+{
+	if (!c || !src || !dst || !out_len) return -EINVAL;
+	hipStream_t s = (hipStream_t)stream_;
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if (dev < 0 || dev >= 64) dev = 0;
+	Workspace &ws = g_ws[dev];
+	std::lock_guard<std::mutex> guard(ws.mtx);
+	if (hist_len > WINDOW) { hist += hist_len - WINDOW; hist_len = WINDOW; }
+	if (src_len < (1u << 20) || first_bit / 8 >= src_len) return -ENOTSUP;
+
+	static const bool trace = getenv("NXZ_PINFLATE_TRACE") != nullptr;
+	struct timespec ts0;
+	clock_gettime(CLOCK_MONOTONIC, &ts0);
+	auto lap = [&](const char *what) {
+		if (!trace) return;
+		(void)hipStreamSynchronize(s);
+		struct timespec t1;
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		fprintf(stderr, "nxz_inflate_stream: %-28s %8.3f ms\n", what, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6);
+		ts0 = t1;
+	};
+	const uint32_t SEG = nxz_blockfind_segment();
+	const uint32_t nseg = (uint32_t)((src_len + SEG - 1) / SEG);
+	// ---- block starts ----
+	if (!ws.need(nseg * sizeof(uint64_t), nseg * sizeof(uint64_t))) return -ENOMEM;
+	if (nxz_launch_find_blocks(src, src_len, first_bit, (uint64_t *)ws.dev, nseg, s)) return -EIO;
+	if (hipMemcpyAsync(ws.pin, ws.dev, nseg * sizeof(uint64_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+	if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+	lap("block starts");
+	std::vector<uint64_t> B;
+	B.push_back(first_bit);
+	for (uint32_t i = 0; i < nseg; i++) {
+		const uint64_t p = ((const uint64_t *)ws.pin)[i];
+		if (p != ~0ull && p > first_bit + 64) B.push_back(p);
+	}
+	if (B.size() < 8) return -ENOTSUP;
+
+	std::vector<nxz_batch_result_t> res;                  // per piece (of its first decode)
+	std::vector<uint64_t> stage_off, out_off, cap, cbytes, cstart;
+	size_t n = 0;
+	uint8_t *d_stage = nullptr, *d_out = nullptr, *d_windows = nullptr;
+	uint16_t *d_maps = nullptr;
+	nxz_batch_job_t *d_jobs = nullptr;
+	nxz_batch_result_t *d_res = nullptr;
+	CopyItem *d_items = nullptr;
+	Piece *d_pieces = nullptr;
+	size_t pin_jobs = 0, pin_res = 0, pin_items = 0, pin_pieces = 0;
+
+	std::vector<uint64_t> capmul(B.size(), 100);        // a piece's buffer: 100 x its compressed size, 2 MiB at least
+	for (int attempt = 0; ; attempt++) {
+		n = B.size();
+		const size_t njobs = 3 * n - 2;                       // piece 0 once (its history is known), the others three times
+		stage_off.assign(n, 0); out_off.assign(n, 0); cap.assign(n, 0); cbytes.assign(n, 0); cstart.assign(n, 0);
+		size_t stage_total = 0, out_total = 0;
+		for (size_t i = 0; i < n; i++) {
+			const size_t copies = i ? 3 : 1;
+			cstart[i] = B[i] >> 3;
+			const uint64_t cend = i + 1 < n ? (B[i + 1] + 7) >> 3 : src_len;
+			cbytes[i] = cend - cstart[i];
+			if (cbytes[i] + WINDOW + 64 > 0xfffffff0ull) return -ENOTSUP;
+			stage_off[i] = stage_total;
+			stage_total += copies * up(WINDOW + cbytes[i] + 16, 256);
+			uint64_t cp = std::max<uint64_t>(cbytes[i] * capmul[i], 2u << 20);
+			if (cp > 0xfff00000ull) return -ENOTSUP;
+			cap[i] = up(cp, 256);
+			out_off[i] = out_total;
+			out_total += copies * cap[i];
+		}
+		const size_t o_jobs = 0, o_res = o_jobs + up(njobs * sizeof(nxz_batch_job_t), 256), o_items = o_res + up(njobs * sizeof(nxz_batch_result_t), 256),
+			     o_pieces = o_items + up((2 * njobs + 2) * sizeof(CopyItem), 256), o_windows = o_pieces + up(n * sizeof(Piece), 256),
+			     o_maps = o_windows + n * (size_t)WINDOW, o_stage = o_maps + n * (size_t)WINDOW * 2, o_out = o_stage + up(stage_total, 256);
+		const size_t dev_total = o_out + out_total;
+		if (dev_total > (128ull << 30)) return -ENOTSUP;
+		pin_jobs = 0; pin_res = pin_jobs + up(njobs * sizeof(nxz_batch_job_t), 256); pin_items = pin_res + up(njobs * sizeof(nxz_batch_result_t), 256);
+		pin_pieces = pin_items + up((2 * njobs + 2) * sizeof(CopyItem), 256);
+		if (!ws.need(dev_total, pin_pieces + up(n * sizeof(Piece), 256))) return -ENOMEM;
+		uint8_t *D = (uint8_t *)ws.dev, *P = (uint8_t *)ws.pin;
+		d_jobs = (nxz_batch_job_t *)(D + o_jobs); d_res = (nxz_batch_result_t *)(D + o_res); d_items = (CopyItem *)(D + o_items);
+		d_pieces = (Piece *)(D + o_pieces); d_windows = D + o_windows; d_maps = (uint16_t *)(D + o_maps); d_stage = D + o_stage; d_out = D + o_out;
+		nxz_batch_job_t *h_jobs = (nxz_batch_job_t *)(P + pin_jobs);
+		nxz_batch_result_t *h_res = (nxz_batch_result_t *)(P + pin_res);
+		CopyItem *h_items = (CopyItem *)(P + pin_items);
+		// staging: [history: the caller's (behind zeros) for piece 0, the three probe windows for the others][the piece's bytes of the stream]
+		size_t nj = 0, ni = 0;
+		for (size_t i = 0; i < n; i++) {
+			const size_t copies = i ? 3 : 1, sstride = up(WINDOW + cbytes[i] + 16, 256);
+			for (size_t k = 0; k < copies; k++) {
+				uint8_t *st = d_stage + stage_off[i] + k * sstride;
+				h_items[ni++] = CopyItem{ (const uint8_t *)(uintptr_t)(i ? k + 1 : 0), st, (i == 0) ? WINDOW - hist_len : WINDOW };
+				h_items[ni++] = CopyItem{ src + cstart[i], st + WINDOW, cbytes[i] };
+				nxz_batch_job_t &j = h_jobs[nj++];
+				memset(&j, 0, sizeof(j));
+				j.src = st; j.src_len = (uint32_t)(WINDOW + cbytes[i]); j.hist_len = WINDOW;
+				j.dst = d_out + out_off[i] + k * cap[i]; j.dst_cap = (uint32_t)cap[i];
+				j.in_crc = 0; j.in_adler = 1;
+				const uint32_t sub = (uint32_t)(B[i] & 7);
+				j.resume = (0xeu << 16) | ((sub ? 8 - sub : 0) << 20);
+			}
+		}
+		if (hipMemcpyAsync(d_items, h_items, ni * sizeof(CopyItem), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+		if (hipMemcpyAsync(d_jobs, h_jobs, nj * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+		if (nxz_launch_copy_items(d_items, (uint32_t)ni, s)) return -EIO;
+		if (hist_len) {                                       // behind the zero fill of piece 0's window
+			h_items[ni] = CopyItem{ hist, d_stage + stage_off[0] + (WINDOW - hist_len), hist_len };
+			if (hipMemcpyAsync(d_items + ni, h_items + ni, sizeof(CopyItem), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+			if (nxz_launch_copy_items(d_items + ni, 1, s)) return -EIO;
+		}
+		lap("staging");
+		if (nxz_batch_decompress(c, d_jobs, nj, d_res, nullptr, s)) return -EIO;
+		lap("decode (all pieces x 3)");
+		if (hipMemcpyAsync(h_res, d_res, nj * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+		if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+		// every piece but the last must stop at the header of the next one; the last at the final block's end
+		bool again = false;
+		std::vector<uint64_t> B2, mul2;
+		B2.push_back(B[0]); mul2.push_back(capmul[0]);
+		res.resize(n);
+		for (size_t i = 0; i < n; i++) {
+			const nxz_batch_result_t &r = h_res[i ? 3 * i - 2 : 0];
+			res[i] = r;
+			if (i && (h_res[3 * i - 1].tpbc != r.tpbc || h_res[3 * i].tpbc != r.tpbc || h_res[3 * i - 1].cc != r.cc || h_res[3 * i].cc != r.cc)) return -EIO;
+			if (r.cc == NXZ_CC_TARGET_SPACE) {
+				if (capmul[i] >= 1032 * 2) return -ENOTSUP;
+				mul2.back() = capmul[i] * 8; again = true;
+			} else if (i + 1 < n) {
+				const uint64_t used = cbytes[i] * 8 - r.subc, want = B[i + 1] - cstart[i] * 8;
+				const uint32_t kind = r.sfbt & 0xe;
+				const bool at_header = r.cc == NXZ_CC_DATA_LENGTH && ((kind == 0xe && used == want) || (kind == 0xa && used == want + 3));
+				if (!at_header) {
+					if (trace) fprintf(stderr, "nxz_inflate_stream: piece %zu (bit %llu, %llu bytes in, %u out) cc %u sfbt %#x subc %u: used %llu bits, next header thought at %llu\n",
+							   i, (unsigned long long)B[i], (unsigned long long)cbytes[i], r.tpbc, r.cc, r.sfbt, r.subc, (unsigned long long)used, (unsigned long long)want);
+					// the piece did not end where the next was thought to start: that start is wrong
+					// (or the data is bad, which the merged piece will report again)
+					if (r.cc != NXZ_CC_DATA_LENGTH && r.cc != 0 && i + 2 >= n) return -EILSEQ;
+					again = true;
+					continue;                               // B[i + 1] is dropped
+				}
+			}
+			if (i + 1 < n) { B2.push_back(B[i + 1]); mul2.push_back(capmul[i + 1]); }
+		}
+		if (!again) break;
+		if (attempt >= 11 || B2.size() < 4) return -ENOTSUP;
+		B.swap(B2); capmul.swap(mul2);
+	}
+	// the last piece must have seen the final block
+	{
+		const nxz_batch_result_t &r = res[n - 1];
+		if (r.cc != 0 && r.cc != NXZ_CC_DATA_LENGTH) return -EILSEQ;
+		if (!(r.sfbt & 0x100)) return -ENOTSUP;
+		if (end_bit) *end_bit = src_len * 8 - r.subc;
+	}
+	// ---- places, true windows, resolution ----
+	uint8_t *P = (uint8_t *)ws.pin;
+	Piece *h_pieces = (Piece *)(P + pin_pieces);
+	uint64_t total = 0;
+	for (size_t i = 0; i < n; i++) {
+		const uint8_t *a = d_out + out_off[i];
+		h_pieces[i] = Piece{ a, i ? a + cap[i] : a, i ? a + 2 * cap[i] : a, res[i].tpbc, total };
+		total += res[i].tpbc;
+	}
+	*out_len = total;
+	if (total > dst_cap) return -E2BIG;
+	if (hipMemcpyAsync(d_pieces, h_pieces, n * sizeof(Piece), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+	const uint8_t *win0 = d_stage + stage_off[0];
+	if (nxz_launch_window_chain(d_pieces, (uint32_t)n, win0, d_maps, d_windows, s)) return -EIO;
+	lap("tail maps + window chain");
+	if (nxz_launch_resolve(d_pieces, (uint32_t)n, win0, d_windows, dst, s)) return -EIO;
+	lap("resolve");
+	// ---- checksums: 256 KiB slices of the output (the job / result arrays are free again) ----
+	const size_t nsl = (size_t)((total + SLICE - 1) / SLICE);
+	std::vector<nxz_batch_result_t> sres(nsl);
+	for (size_t o = 0; o < nsl; o += 3 * n - 2) {
+		const size_t m = std::min(nsl - o, 3 * n - 2);
+		nxz_batch_job_t *h_jobs = (nxz_batch_job_t *)(P + pin_jobs);
+		nxz_batch_result_t *h_res = (nxz_batch_result_t *)(P + pin_res);
+		for (size_t k = 0; k < m; k++) {
+			memset(&h_jobs[k], 0, sizeof(nxz_batch_job_t));
+			memset(&h_res[k], 0, sizeof(nxz_batch_result_t));
+			h_jobs[k].dst = dst + (o + k) * SLICE;
+			h_jobs[k].in_crc = 0; h_jobs[k].in_adler = 1;
+			h_res[k].tpbc = (uint32_t)std::min<uint64_t>(SLICE, total - (o + k) * SLICE);
+		}
+		if (hipMemcpyAsync(d_jobs, h_jobs, m * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+		if (hipMemcpyAsync(d_res, h_res, m * sizeof(nxz_batch_result_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+		if (nxz_launch_cksum(d_jobs, m, d_res, s)) return -EIO;
+		if (hipMemcpyAsync(h_res, d_res, m * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+		if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+		memcpy(&sres[o], h_res, m * sizeof(nxz_batch_result_t));
+	}
+	lap("checksums");
+	if (trace) {
+		uint64_t mx = 0;
+		for (size_t i = 0; i < n; i++) mx = std::max<uint64_t>(mx, res[i].tpbc);
+		fprintf(stderr, "nxz_inflate_stream: %zu pieces, largest %llu bytes out, mean %llu\n", n, (unsigned long long)mx, (unsigned long long)(total / n));
+	}
+	const uint32_t nround = 1;
+	uint32_t cr = 0, ad = 1;
+	for (size_t k = 0; k < nsl; k++) {
+		cr = k ? crc_combine(cr, sres[k].crc, sres[k].tpbc) : sres[k].crc;
+		ad = k ? adler_combine(ad, sres[k].adler, sres[k].tpbc) : sres[k].adler;
+	}
+	if (crc) *crc = cr;
+	if (adler) *adler = ad;
+	if (pieces) *pieces = (uint32_t)n;
+	if (rounds) *rounds = nround;
+	return 0;
+}

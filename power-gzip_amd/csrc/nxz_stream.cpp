@@ -592,10 +592,68 @@ void publish(Inflate *s)
 	else if (s->wrap == HDR_ZLIB) s->z->adler = s->adler;
 }
 
+// A caller that hands over megabytes of deflate data at once (nx_uncompress, inflate(Z_FINISH) on a
+// whole file) gets the engine's parallel decode of ONE stream (nxz_inflate_stream: block starts are
+// found by speculation, the pieces are inflated side by side) instead of the job-after-job loop
+// below, which is what the reference runs (lib/nx_inflate.c:1143-1744) and is only as fast as one
+// wavefront.  Everything the engine declines (short input, stream not complete inside avail_in,
+// output does not fit avail_out, hardly any dynamic blocks) falls through to that loop.
+// (Weak references: the CPU model of the test suite has no such entry points.)
+extern "C" {
+int nxz_inflate_stream(nxz_ctx_t *, const uint8_t *, uint64_t, uint64_t, const uint8_t *, uint32_t, uint8_t *, uint64_t,
+		       uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, void *) __attribute__((weak));
+void *nxz_dev_malloc(nxz_ctx_t *, size_t) __attribute__((weak));
+void nxz_dev_free(nxz_ctx_t *, void *) __attribute__((weak));
+int nxz_copy_to_device(nxz_ctx_t *, void *, const void *, size_t, void *) __attribute__((weak));
+int nxz_copy_to_host(nxz_ctx_t *, void *, const void *, size_t, void *) __attribute__((weak));
+int nxz_ctx_sync(nxz_ctx_t *, void *) __attribute__((weak));
+}
+constexpr size_t PARALLEL_INFLATE_MIN = 4u << 20;
+
+bool parallel_inflate(Inflate *s)
+{
+	z_streamp z = s->z;
+	if (!nxz_inflate_stream || !nxz_dev_malloc || !nxz_dev_free || !nxz_copy_to_device || !nxz_copy_to_host || !nxz_ctx_sync) return false;
+	if (s->resuming || !s->carry.empty() || s->pending() || !s->eng.open) return false;
+	if (z->avail_in < PARALLEL_INFLATE_MIN || z->avail_out < z->avail_in) return false;
+	nxz_ctx_t *ctx = (nxz_ctx_t *)s->eng.dev.paste_addr;
+	if (!ctx) return false;
+	const size_t nin = z->avail_in, cap = z->avail_out, nh = s->hist.size();
+	uint8_t *d_src = (uint8_t *)nxz_dev_malloc(ctx, nin + 64), *d_dst = (uint8_t *)nxz_dev_malloc(ctx, cap + 64);
+	uint8_t *d_hist = nh ? (uint8_t *)nxz_dev_malloc(ctx, nh) : nullptr;
+	bool ok = d_src && d_dst && (!nh || d_hist);
+	uint64_t out_len = 0, end_bit = 0;
+	uint32_t crc = 0, adler = 1;
+	if (ok) ok = nxz_copy_to_device(ctx, d_src, z->next_in, nin, nullptr) == 0 && (!nh || nxz_copy_to_device(ctx, d_hist, s->hist.data(), nh, nullptr) == 0);
+	if (ok) ok = nxz_inflate_stream(ctx, d_src, nin, 0, d_hist, (uint32_t)nh, d_dst, cap, &out_len, &crc, &adler, &end_bit, nullptr, nullptr, nullptr) == 0;
+	if (ok) ok = nxz_copy_to_host(ctx, z->next_out, d_dst, out_len, nullptr) == 0 && nxz_ctx_sync(ctx, nullptr) == 0;
+	if (d_src) nxz_dev_free(ctx, d_src);
+	if (d_dst) nxz_dev_free(ctx, d_dst);
+	if (d_hist) nxz_dev_free(ctx, d_hist);
+	if (!ok) return false;
+	const size_t consumed = (size_t)((end_bit + 7) / 8);
+	const uint8_t *outp = z->next_out;
+	z->next_in += consumed; z->avail_in -= (uInt)consumed; z->total_in += consumed;
+	z->next_out += out_len; z->avail_out -= (uInt)out_len; z->total_out += out_len;
+	s->crc = (uint32_t)nx_crc32_combine(s->crc, crc, (off_t)out_len);
+	s->adler = (uint32_t)nx_adler32_combine(s->adler, adler, (off_t)out_len);
+	s->total_out += out_len;
+	if (out_len >= WINDOW) s->hist.assign(outp + out_len - WINDOW, outp + out_len);
+	else {
+		const size_t drop = s->hist.size() + out_len > WINDOW ? s->hist.size() + out_len - WINDOW : 0;
+		s->hist.erase(s->hist.begin(), s->hist.begin() + drop);
+		s->hist.insert(s->hist.end(), outp, outp + out_len);
+	}
+	s->st = Inflate::TRAILER;
+	publish(s);
+	return true;
+}
+
 // one engine job (nx_inflate_, lib/nx_inflate.c:1143-1744).  Returns Z_OK / error.
 int inflate_job(Inflate *s)
 {
 	z_streamp z = s->z;
+	if (parallel_inflate(s)) return Z_OK;
 	// source = [history rounded up to 16 B][carry][part of next_in]; size it from the last ratio
 	uint32_t want_out = (uint32_t)std::min<size_t>((size_t)z->avail_out + WINDOW + (WINDOW >> 2), 1u << 20);
 	uint32_t src_want = (uint32_t)(((uint64_t)want_out * s->ratio + 1000) / 1000);

@@ -67,6 +67,9 @@ def load_library():
         L.nxz_batch_dhtgen.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.nxz_batch_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.nxz_batch_wrap.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.nxz_inflate_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p]
         L.nxz_ctx_sync.argtypes = [C.c_void_p, C.c_void_p]
         L.nx_function_begin.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.nx_function_end.argtypes = [C.c_void_p]
@@ -160,6 +163,18 @@ class Engine:
                                          dht_io.data_ptr() if dht_io is not None else None, self.stream_handle())
         self._check(rc, "nxz_batch_decompress")
         return results
+
+    def inflate_stream(self, src, src_len, dst, first_bit=0, hist=None):
+        """one long raw-deflate stream (uint8 device tensor) -> dst (uint8 device tensor), in parallel by
+        block-boundary speculation.  Returns (rc, dict): rc 0 / -errno as nxz_inflate_stream."""
+        out_len, end_bit = C.c_uint64(), C.c_uint64()
+        crc, adler, pieces, rounds = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rc = self.L.nxz_inflate_stream(self.ctx, src.data_ptr(), src_len, first_bit,
+                                       hist.data_ptr() if hist is not None else None, hist.numel() if hist is not None else 0,
+                                       dst.data_ptr(), dst.numel(), C.byref(out_len), C.byref(crc), C.byref(adler),
+                                       C.byref(end_bit), C.byref(pieces), C.byref(rounds), self.stream_handle())
+        return rc, {"out_len": out_len.value, "crc": crc.value, "adler": adler.value, "end_bit": end_bit.value,
+                    "pieces": pieces.value, "rounds": rounds.value}
 
     def wrap(self, jobs, n, results=None):
         t = self.torch

@@ -1,0 +1,128 @@
+"""GPU tests of the parallel decode of ONE long deflate stream (nxz_inflate_stream: block-boundary
+speculation, -m gpu): zlib-made streams of several levels and strategies, stored / fixed stretches
+in between, a history in front, damage, streams the engine must decline; and the same through the
+zlib-style API (nx_uncompress / nx_inflate on a whole .gz), where it replaces the job-after-job loop."""
+import ctypes as C
+import importlib
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import corpus
+import zstream as Z
+
+pytestmark = pytest.mark.gpu
+pkg = importlib.import_module("power-gzip_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = pkg.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def data():
+    _, blocks, _ = corpus.load(65536)
+    raw = b"".join(b for _, _, b in blocks)
+    return (raw * 2)[:24 << 20]
+
+
+def _run(eng, comp, cap, first_bit=0, hist=None):
+    import torch
+    src = torch.from_numpy(np.frombuffer(comp, np.uint8).copy()).to(eng.dev)
+    dst = torch.zeros(cap, dtype=torch.uint8, device=eng.dev)
+    h = torch.from_numpy(np.frombuffer(hist, np.uint8).copy()).to(eng.dev) if hist else None
+    rc, info = eng.inflate_stream(src, len(comp), dst, first_bit=first_bit, hist=h)
+    torch.cuda.synchronize()
+    return rc, info, dst
+
+
+@pytest.mark.parametrize("level,strategy", [(1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                            (6, zlib.Z_FILTERED), (6, zlib.Z_HUFFMAN_ONLY)])
+def test_one_stream_bit_exact(eng, data, level, strategy):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    comp = c.compress(data) + c.flush()
+    rc, info, dst = _run(eng, comp, len(data) + 4096)
+    assert rc == 0, (rc, info)
+    assert info["out_len"] == len(data) and info["crc"] == zlib.crc32(data) and info["adler"] == zlib.adler32(data)
+    assert dst[:len(data)].cpu().numpy().tobytes() == data
+    assert info["pieces"] >= 16 and (info["end_bit"] + 7) // 8 == len(comp)
+
+
+def test_stored_and_fixed_stretches_and_flush_points(eng, data):
+    """random bytes (stored blocks), a Z_FIXED stretch and full-flush points inside one stream: block
+    starts that the search does not look for are decoded as part of the piece in front"""
+    rnd = np.random.default_rng(5).integers(0, 256, 3 << 20, dtype=np.uint8).tobytes()
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts = [data[:6 << 20], rnd, data[6 << 20:12 << 20]]
+    comp = b""
+    for p in parts:
+        comp += c.compress(p) + c.flush(zlib.Z_FULL_FLUSH)
+    # a fixed-Huffman stretch: a second compressor continues the same raw stream (Z_FULL_FLUSH left it byte aligned)
+    f = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+    tailpart = data[12 << 20:14 << 20]
+    comp += f.compress(tailpart) + f.flush()
+    plain = b"".join(parts) + tailpart
+    rc, info, dst = _run(eng, comp, len(plain) + 4096)
+    assert rc == 0, (rc, info)
+    assert info["out_len"] == len(plain) and info["crc"] == zlib.crc32(plain)
+    assert dst[:len(plain)].cpu().numpy().tobytes() == plain
+
+
+def test_history_in_front_and_bit_offset(eng, data):
+    """a stream that starts in the middle of a byte and refers to a preset dictionary"""
+    dic = data[100000:100000 + 32768]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15, zdict=dic)
+    comp = c.compress(data[:8 << 20]) + c.flush()
+    # shift the whole stream by 3 bits
+    v = int.from_bytes(comp, "little") << 3
+    shifted = v.to_bytes(len(comp) + 1, "little")
+    rc, info, dst = _run(eng, shifted, (8 << 20) + 4096, first_bit=3, hist=dic)
+    assert rc == 0, (rc, info)
+    assert dst[:8 << 20].cpu().numpy().tobytes() == data[:8 << 20] and info["crc"] == zlib.crc32(data[:8 << 20])
+
+
+def test_declined_and_damaged(eng, data):
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(data[:8 << 20]) + c.flush()
+    # too short a stream: the ordinary loop is the right tool
+    rc, _, _ = _run(eng, comp[:500000], 8 << 20)
+    assert rc == -95                                   # ENOTSUP
+    # no final block inside the source
+    rc, _, _ = _run(eng, comp[:len(comp) - 4000], 9 << 20)
+    assert rc in (-95, -84)                            # ENOTSUP / EILSEQ
+    # target too small: says how much it needs
+    rc, info, _ = _run(eng, comp, 1 << 20)
+    assert rc == -7 and info["out_len"] == 8 << 20     # E2BIG
+    # damage in the middle: either refused or caught by the checksum the caller compares
+    bad = bytearray(comp)
+    for k in range(len(bad) // 2, len(bad) // 2 + 64):
+        bad[k] ^= 0x5a
+    rc, info, _ = _run(eng, bytes(bad), 9 << 20)
+    assert rc != 0 or info["crc"] != zlib.crc32(data[:8 << 20])
+
+
+def test_through_the_zlib_style_api(data):
+    """nx_uncompress on a whole zlib stream and nx_inflate(Z_FINISH) on a whole .gz: megabytes of input
+    at once take the parallel path (NX_GZIP_TRACE-free check: the result and the trailer verification)"""
+    L = Z.load("gpu")
+    plain = data[:16 << 20]
+    z = zlib.compress(plain, 6)
+    out = C.create_string_buffer(len(plain) + 64)
+    n = C.c_ulong(len(out))
+    assert L.nx_uncompress(out, C.byref(n), z, len(z)) == 0
+    assert n.value == len(plain) and out.raw[:n.value] == plain
+    # gzip wrapper through the streaming call, everything at once
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz = co.compress(plain) + co.flush()
+    got, rc, total_in, _ = Z.inflate_all(L, gz, wbits=31, cap=len(plain) + 64)
+    assert got == plain and rc == Z.Z_STREAM_END and total_in == len(gz)
+    # a damaged trailer is still a data error
+    badgz = gz[:-5] + bytes([gz[-5] ^ 1]) + gz[-4:]
+    got, rc, _, _ = Z.inflate_all(L, badgz, wbits=31, cap=len(plain) + 64)
+    assert rc == Z.Z_DATA_ERROR
