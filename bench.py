@@ -326,6 +326,45 @@ def corpus_leg(torch, eng, pkg, args):
     # inflate of zlib -6 streams of the same corpus (what configs[3] feeds the inflate engine)
     if not args.no_inflate:
         out["inflate_zlib6"] = inflate_leg(torch, eng, pkg, raw, rep, args)
+        out["inflate_stream"] = stream_leg(torch, eng, raw, args)
+    return out
+
+
+def stream_leg(torch, eng, raw, args, mib=64):
+    """BASELINE configs[3]: ONE zlib-made deflate stream (the corpus repeated to `mib` MiB, zlib -6),
+    inflated by block-boundary speculation (nxz_inflate_stream), bit-exact check; zlib on one host
+    thread beside it (a single stream does not spread over threads there either)."""
+    import zlib
+    data = (b"".join(raw) * ((mib << 20) // sum(len(b) for b in raw) + 1))[:mib << 20]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    src = torch.from_numpy(np.frombuffer(comp, np.uint8).copy()).to(eng.dev)
+    dst = torch.zeros(len(data) + 4096, dtype=torch.uint8, device=eng.dev)
+    rc, info = eng.inflate_stream(src, len(comp), dst)
+    if rc != 0:
+        return {"error": "nxz_inflate_stream declined the stream (%d)" % rc}
+    torch.cuda.synchronize(eng.dev)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc, info = eng.inflate_stream(src, len(comp), dst)
+        torch.cuda.synchronize(eng.dev)
+        best = min(best, time.perf_counter() - t0)
+    ok = rc == 0 and info["out_len"] == len(data) and info["crc"] == zlib.crc32(data) and bool(
+        torch.equal(dst[:len(data)], torch.from_numpy(np.frombuffer(data, np.uint8).copy()).to(eng.dev)))
+    if not ok:
+        raise SystemExit("inflate_stream leg: the stream did not inflate to its source")
+    out = {"value": round(len(data) / best / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out, one stream, device resident",
+           "ms": round(best * 1e3, 2), "stream": "%d MiB of the corpus as ONE raw deflate stream, zlib level 6 (%.1f MiB compressed)" % (mib, len(comp) / 2.0 ** 20),
+           "pieces": info["pieces"], "bit_exact": True,
+           "roofline": {"bound": "hbm", "achieved": round((len(data) + len(comp)) / best / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round((len(data) + len(comp)) / best / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                        "kernel": "find_blocks + batched inflate (3 probe decodes per piece) + window chain + resolve, wall clock"}}
+    if not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        zlib.decompress(comp, -15)
+        out["cpu_baseline"] = {"value": round(len(data) / (time.perf_counter() - t0) / 2.0 ** 30, 4), "unit": "GiB/s uncompressed out", "cores": 1,
+                               "kind": "reference", "what": "system zlib inflate of the same stream, one thread"}
     return out
 
 

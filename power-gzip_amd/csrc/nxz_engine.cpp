@@ -167,7 +167,7 @@ extern "C" nxz_ctx_t *nxz_ctx_create(int device)
 	}
 	if (device >= ndev || device >= 64) { errno = ENODEV; snprintf(g_err, sizeof(g_err), "device %d out of range", device); return nullptr; }
 	std::lock_guard<std::mutex> g(g_mtx);
-	if (g_ctx[device]) { g_ctx[device]->refs++; return g_ctx[device]; }
+	if (g_ctx[device]) { g_ctx[device]->refs++; (void)hipSetDevice(device); return g_ctx[device]; }
 	hipDeviceProp_t prop;
 	HIPCHK(hipGetDeviceProperties(&prop, device), { errno = ENODEV; return nullptr; });
 	if (!strstr(prop.gcnArchName, "gfx950")) {
@@ -347,6 +347,7 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 {
 	if (!c) return -EINVAL;
 	if (forked_child()) return -ENODEV;
+	(void)hipSetDevice(c->device);         // scratch is allocated on, and kernels go to, the context's device
 	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
 	int rc;
 	const char *lm = getenv("NXZ_INFLATE_LANES_MIN");                    // tuning / test knob
@@ -383,6 +384,7 @@ extern "C" int nxz_batch_wrap(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t 
 			      nxz_batch_result_t *results, void *stream)
 {
 	if (!c) return -EINVAL;
+	(void)hipSetDevice(c->device);
 	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
 	int rc = nxz_launch_wrap(jobs, n, results, s);
 	if (rc) { set_err("wrap launch", (hipError_t)rc); return -EIO; }
@@ -396,6 +398,7 @@ extern "C" int nxz_batch_pack_gzip(nxz_ctx_t *c, const nxz_batch_job_t *jobs, co
 				   uint64_t *offsets, uint8_t *packed, void *stream)
 {
 	if (!c || !jobs || !results || !offsets || !packed || n > 0xffffffffu) return -EINVAL;
+	(void)hipSetDevice(c->device);
 	int rc = nxz_launch_pack_members(jobs, results, n, offsets, packed, (hipStream_t)stream);
 	if (rc) { set_err("pack launch", (hipError_t)rc); return -EIO; }
 	return 0;
@@ -514,6 +517,7 @@ static Slot *slot_acquire(nxz_ctx *c)
 					g.unlock();
 					(void)hipSetDevice(c->device);
 					bool ok = slot_init(s);
+					if (!ok) slot_free(s);                        // nothing half built stays behind (the next caller starts over)
 					g.lock();
 					if (!ok) { s.busy = false; return nullptr; }
 				}
@@ -752,6 +756,7 @@ extern "C" int nxu_run_job(nxz_crb_cpb_t *j, void *handle)
 	else if (nxz_fc_is_compress(fc) && !(fc & 1) && !(fc & ~0x2eu) && (!nxz_fc_is_dhtgen(fc) || nxz_fc_is_dht(fc))) rc = run_compress(c, s, j, fc);
 	else if (fc == NXZ_FC_DECOMPRESS || fc == NXZ_FC_DECOMPRESS_RESUME) rc = run_decompress(c, s, j, fc);
 	else { nxz_csb_complete(j, NXZ_CC_INVALID_OP, NXZ_CE_TERMINATE, 0); rc = 0; }
+	if (rc) (void)hipStreamSynchronize(s->stream);            // nothing of a failed job may still be in flight when the slot is reused
 	slot_release(c, s);
 	if (rc) { fprintf(stderr, "nxz: job failed: %s\n", g_err); return -EAGAIN; }
 	return 0;

@@ -26,6 +26,8 @@ struct GzState {
 	unsigned char *buf = nullptr;      // reader: source buffer
 	unsigned used = 0;                 // reader: bytes of buf not yet consumed
 	unsigned char *cur = nullptr;
+	bool eof = false;                  // reader: the file has been read to its end
+	bool done = false;                 // reader: ... and everything in it has been handed out
 };
 constexpr unsigned RBUF = 65536, CHUNK = 65536;
 
@@ -98,29 +100,54 @@ extern "C" int nx_gzread(void *file, void *buf, unsigned len)
 {
 	GzState *g = (GzState *)file;
 	if (!g || g->writer || g->err != Z_OK || len == 0) return 0;
-	const uLong before = g->strm.total_out;
+	if (g->done) return 0;
+	uLong before = g->strm.total_out, produced = 0;
 	g->strm.next_out = (Bytef *)buf;
 	g->strm.avail_out = len;
 	while (g->strm.avail_out) {
-		if (g->used == 0) {
+		if (g->used == 0 && !g->eof) {
 			ssize_t r;
 			do r = read(g->fd, g->buf, RBUF); while (r < 0 && errno == EINTR);
 			if (r < 0) { g->err = Z_ERRNO; break; }
 			g->cur = g->buf; g->used = (unsigned)r;
-			if (r == 0) {                                   // end of file: let the stream finish
-				g->strm.next_in = g->buf; g->strm.avail_in = 0;
-				int rc = nx_inflate(&g->strm, Z_FINISH);
-				if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) g->err = rc;
-				break;
-			}
+			if (r == 0) g->eof = true;
+		}
+		if (g->used == 0) {                                 // end of file: let the stream finish (it may hold output yet)
+			const uInt had = g->strm.avail_out;
+			g->strm.next_in = g->buf; g->strm.avail_in = 0;
+			int rc = nx_inflate(&g->strm, Z_FINISH);
+			if (rc == Z_STREAM_END) { g->done = true; break; }
+			if (rc != Z_OK && rc != Z_BUF_ERROR) { g->err = rc; g->done = true; break; }
+			if (g->strm.avail_out == had) { g->done = true; break; }     // nothing more to come: a truncated file
+			continue;
 		}
 		g->strm.next_in = g->cur; g->strm.avail_in = g->used;
 		int rc = nx_inflate(&g->strm, Z_NO_FLUSH);
 		g->cur = (unsigned char *)g->strm.next_in; g->used = g->strm.avail_in;
-		if (rc == Z_STREAM_END) break;
+		if (rc == Z_STREAM_END) {
+			// a gzip file is a sequence of members (RFC 1952 2.2; this library's own nxz_gzip and bgzip
+			// write one per block): go on with the next one, as zlib's gzread does.  Zero bytes between
+			// or behind members are padding.
+			produced += g->strm.total_out - before;
+			while (g->used && *g->cur == 0) { g->cur++; g->used--; }
+			if (g->used == 0) {
+				ssize_t r;
+				do r = read(g->fd, g->buf, RBUF); while (r < 0 && errno == EINTR);
+				if (r < 0) { g->err = Z_ERRNO; break; }
+				g->cur = g->buf; g->used = (unsigned)r;
+				while (g->used && *g->cur == 0) { g->cur++; g->used--; }
+				if (r == 0) g->eof = true;
+			}
+			Bytef *no = g->strm.next_out; uInt ao = g->strm.avail_out;
+			if (nx_inflateReset(&g->strm) != Z_OK) { g->err = Z_STREAM_ERROR; break; }
+			g->strm.next_out = no; g->strm.avail_out = ao;
+			before = 0;
+			if (g->eof && g->used == 0) { g->done = true; break; }
+			continue;
+		}
 		if (rc != Z_OK && rc != Z_BUF_ERROR) { g->err = rc; return 0; }
 	}
-	return (int)(g->strm.total_out - before);
+	return (int)(produced + g->strm.total_out - before);
 }
 
 extern "C" int nx_gzclose(void *file)
@@ -136,12 +163,14 @@ extern "C" int nx_gzclose(void *file)
 		do {
 			g->strm.next_out = out; g->strm.avail_out = CHUNK;
 			r = nx_deflate(&g->strm, Z_FINISH);
-			if (!write_all(g->fd, out, CHUNK - g->strm.avail_out)) break;
+			if (!write_all(g->fd, out, CHUNK - g->strm.avail_out)) { g->err = Z_ERRNO; break; }
 		} while (r == Z_OK || r == Z_BUF_ERROR);
 		free(out);
 		rc = nx_deflateEnd(&g->strm);
+		if (r != Z_STREAM_END && g->err == Z_OK) g->err = r < 0 ? r : Z_BUF_ERROR;
 	} else rc = nx_inflateEnd(&g->strm);
-	if (g->fp) fclose(g->fp); else close(g->fd);
+	if ((g->fp ? fclose(g->fp) : close(g->fd)) != 0 && g->err == Z_OK) g->err = Z_ERRNO;
+	if (g->err != Z_OK && rc == Z_OK) rc = g->writer ? g->err : rc;         // a failed write / close is the caller's to know
 	free(g->buf);
 	delete g;
 	return rc;

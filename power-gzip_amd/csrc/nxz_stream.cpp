@@ -78,6 +78,17 @@ uint32_t sw_adler32(uint32_t adler, const uint8_t *p, size_t n)
 	return (b << 16) | a;
 }
 
+// header bytes only (a few dozen): bitwise
+uint32_t sw_crc32(uint32_t crc, const uint8_t *p, size_t n)
+{
+	crc = ~crc;
+	while (n--) {
+		crc ^= *p++;
+		for (int k = 0; k < 8; k++) crc = (crc >> 1) ^ ((crc & 1) ? 0xedb88320u : 0);
+	}
+	return ~crc;
+}
+
 uint32_t gf2_mul(uint32_t a, uint32_t b)
 {
 	uint32_t r = 0;
@@ -536,6 +547,8 @@ struct Inflate {
 	std::vector<uint8_t> pend; size_t pend_off = 0;    // produced bytes waiting for next_out
 	std::vector<uint8_t> hist;                         // last <= 32 KiB of output
 	std::vector<uint8_t> carry;                        // source bytes taken from next_in but not yet consumed by the engine
+	std::vector<uint8_t> unget;                        // bytes taken from next_in that lie BEHIND the stream's trailer (the next member's):
+							   // read first by whatever follows, and kept across inflateReset
 	uint32_t sfbt = 0, subc = 0, rem = 0, dhtlen = 0; uint8_t dht[NXZ_DHT_MAXSZ]; bool resuming = false;
 	uint32_t crc = 0, adler = 1;
 	uint64_t total_out = 0;
@@ -577,12 +590,17 @@ Inflate *istate(z_streamp strm)
 	return s->magic == MAGIC_INF ? s : nullptr;
 }
 
-// next header byte: from the carry buffer first (never used for headers), then next_in
+// next header / trailer byte: what an earlier call took beyond its stream's end first (already
+// counted in total_in), then next_in.  Gzip header bytes run through the header CRC (FHCRC, RFC 1952).
 bool get_byte(Inflate *s, uint32_t &c)
 {
-	if (s->z->avail_in == 0) return false;
-	c = *s->z->next_in++;
-	s->z->avail_in--; s->z->total_in++;
+	if (!s->unget.empty()) { c = s->unget.front(); s->unget.erase(s->unget.begin()); }
+	else {
+		if (s->z->avail_in == 0) return false;
+		c = *s->z->next_in++;
+		s->z->avail_in--; s->z->total_in++;
+	}
+	if (s->st >= Inflate::GZ_ID2 && s->st <= Inflate::GZ_COMMENT) { const uint8_t b = (uint8_t)c; s->hcrc = sw_crc32(s->hcrc, &b, 1); }
 	return true;
 }
 
@@ -697,6 +715,7 @@ int inflate_job(Inflate *s)
 		uint32_t tpbc = nxz_csb_tpbc(j), spbc = nxz_rd32(&j->cpb.u.d.out_spbc_decomp_be);
 		uint32_t sfbt = nxz_out_sfbt(&j->cpb), subc = nxz_out_subc(&j->cpb);
 		uint32_t given = from_carry + from_next;
+		if (spbc < pad + histlen) spbc = pad + histlen;           // (an engine that reports less than the history it was given)
 		uint32_t used = spbc - (pad + histlen);                   // source bytes the engine looked at
 		uint32_t consumed;
 		s->crc = nxz_out_crc(&j->cpb); s->adler = nxz_out_adler(&j->cpb);
@@ -741,6 +760,7 @@ int inflate_reset(z_streamp strm)
 	Inflate *s = istate(strm);
 	if (!s) return Z_STREAM_ERROR;
 	strm->total_in = strm->total_out = 0; strm->msg = Z_NULL;
+	if (s->st != Inflate::DONE) s->unget.clear();           // (behind a finished stream: the next member's first bytes stay)
 	s->st = Inflate::HEADER; s->held = s->nheld = 0; s->gzflags = 0; s->pend.clear(); s->pend_off = 0;
 	s->hist.clear(); s->carry.clear(); s->resuming = false; s->sfbt = s->subc = s->rem = s->dhtlen = 0;
 	s->crc = 0; s->adler = 1; s->total_out = 0; s->ntrailer = 0; s->sync_point = false; s->have_dict = false; s->ratio = 250;
@@ -767,7 +787,7 @@ extern "C" int nx_inflateCopy(z_streamp dest, z_streamp source)
 	d->z = dest; d->wrap = s->wrap; d->window_bits = s->window_bits; d->st = s->st;
 	d->held = s->held; d->nheld = s->nheld; d->gzflags = s->gzflags; d->xlen = s->xlen; d->zcmf = s->zcmf; d->dictid = s->dictid;
 	d->gzhead = s->gzhead; d->hcrc = s->hcrc;
-	d->pend = s->pend; d->pend_off = s->pend_off; d->hist = s->hist; d->carry = s->carry;
+	d->pend = s->pend; d->pend_off = s->pend_off; d->hist = s->hist; d->carry = s->carry; d->unget = s->unget;
 	d->sfbt = s->sfbt; d->subc = s->subc; d->rem = s->rem; d->dhtlen = s->dhtlen; memcpy(d->dht, s->dht, sizeof(d->dht));
 	d->resuming = s->resuming; d->crc = s->crc; d->adler = s->adler; d->total_out = s->total_out;
 	memcpy(d->trailer, s->trailer, sizeof(d->trailer)); d->ntrailer = s->ntrailer;
@@ -868,13 +888,13 @@ extern "C" int nx_inflate(z_streamp strm, int flush)
 		case Inflate::HEADER:
 			if (s->wrap == (HDR_ZLIB | HDR_GZIP)) {
 				NEEDBYTE();
-				if (c == 0x1f) { s->wrap = HDR_GZIP; NEXT(GZ_ID2); }
+				if (c == 0x1f) { s->wrap = HDR_GZIP; const uint8_t b = 0x1f; s->hcrc = sw_crc32(0, &b, 1); NEXT(GZ_ID2); }
 				else if ((c & 0x0f) == 0x08 && ((c >> 4) & 0x0f) < 8) { s->wrap = HDR_ZLIB; s->zcmf = c; NEXT(ZL_FLG); }
 				else { strm->msg = (char *)"incorrect header"; NEXT(BAD); }
 			} else if (s->wrap == HDR_ZLIB) NEXT(ZL_CMF);
 			else if (s->wrap == HDR_GZIP) {
 				NEEDBYTE();
-				if (c != 0x1f) { strm->msg = (char *)"incorrect gzip header"; NEXT(BAD); } else NEXT(GZ_ID2);
+				if (c != 0x1f) { strm->msg = (char *)"incorrect gzip header"; NEXT(BAD); } else { const uint8_t b = 0x1f; s->hcrc = sw_crc32(0, &b, 1); NEXT(GZ_ID2); }
 			} else { s->crc = 0; s->adler = 1; NEXT(BODY); }
 			break;
 		case Inflate::GZ_ID2: NEEDBYTE(); if (c != 0x8b) { strm->msg = (char *)"incorrect gzip header"; NEXT(BAD); } else NEXT(GZ_CM); break;
@@ -913,7 +933,10 @@ extern "C" int nx_inflate(z_streamp strm, int flush)
 			} else if (s->gzhead) s->gzhead->comment = Z_NULL;
 			s->nheld = 0; NEXT(GZ_HCRC); break;
 		case Inflate::GZ_HCRC:
-			if (s->gzflags & 2) { while (s->nheld < 2) { NEEDBYTE(); s->nheld++; } }
+			if (s->gzflags & 2) {
+				while (s->nheld < 2) { NEEDBYTE(); s->held = s->nheld ? s->held | c << 8 : c; s->nheld++; }
+				if (s->held != (s->hcrc & 0xffff)) { strm->msg = (char *)"header crc mismatch"; NEXT(BAD); break; }
+			}
 			if (s->gzhead) { s->gzhead->hcrc = (s->gzflags >> 1) & 1; s->gzhead->done = 1; }
 			s->crc = 0; s->adler = 1; strm->adler = 0; NEXT(BODY); break;
 		case Inflate::ZL_CMF:
@@ -936,6 +959,7 @@ extern "C" int nx_inflate(z_streamp strm, int flush)
 			if (!s->have_dict) { rc = Z_NEED_DICT; goto out; }
 			NEXT(BODY); break;
 		case Inflate::BODY:
+			if (!s->unget.empty()) { s->carry.insert(s->carry.begin(), s->unget.begin(), s->unget.end()); s->unget.clear(); }
 			s->drain();
 			if (s->pending()) goto out;
 			if (strm->avail_out == 0) goto out;
@@ -970,6 +994,9 @@ extern "C" int nx_inflate(z_streamp strm, int flush)
 				ok = ck == s->adler;
 			}
 			if (!ok) { strm->msg = (char *)"incorrect data check"; NEXT(BAD); break; }
+			// what was taken from the caller beyond this stream (small inputs are gathered before the engine
+			// sees them) is the start of whatever follows: kept for it
+			if (!s->carry.empty()) { s->unget.insert(s->unget.end(), s->carry.begin(), s->carry.end()); s->carry.clear(); }
 			NEXT(DONE);
 			break;
 		}

@@ -114,3 +114,81 @@ def test_combine64_aliases(L):
     a, b = make_block("random", 1000, 1), make_block("random", 3333, 2)
     assert L.nx_crc32_combine64(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
     assert L.nx_adler32_combine64(zlib.adler32(a), zlib.adler32(b), len(b)) == zlib.adler32(a + b)
+
+
+def test_gzread_reads_every_member_of_a_multi_member_file(L, tmp_path):
+    """RFC 1952 2.2: a gzip file is a sequence of members (nxz_gzip and bgzip write one per block,
+    `cat a.gz b.gz` makes them too); zero padding between and behind members is skipped.  gzread
+    must not stop behind the first member (zlib's gzread does not either)."""
+    parts = [os.urandom(70000), b"hello world\n" * 5000, b"", b"x" * 100000, bytes(range(256)) * 300]
+    path = tmp_path / "multi.gz"
+    with open(path, "wb") as f:
+        for i, p in enumerate(parts):
+            f.write(gzip.compress(p, 6))
+            if i == 1:
+                f.write(b"\0" * 37)                              # padding between members
+        f.write(b"\0" * 512)                                     # ... and behind the last one
+    want = b"".join(parts)
+    L.nx_gzopen.restype = C.c_void_p
+    L.nx_gzopen.argtypes = [C.c_char_p, C.c_char_p]
+    L.nx_gzread.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    L.nx_gzclose.argtypes = [C.c_void_p]
+    for step in (1 << 20, 4097, 100):
+        g = L.nx_gzopen(str(path).encode(), b"rb")
+        assert g
+        got = b""
+        buf = C.create_string_buffer(step)
+        while True:
+            k = L.nx_gzread(g, buf, step)
+            if k <= 0:
+                break
+            got += buf.raw[:k]
+        assert L.nx_gzclose(g) == 0
+        assert got == want, (step, len(got), len(want))
+
+
+def test_small_feeds_do_not_lose_the_next_member(L):
+    """inflate() with fewer than 1024 bytes per call gathers its input before the engine sees it; what
+    it has taken beyond the end of a member belongs to the next one (after inflateReset) and must not
+    be lost.  Also: a gzip header CRC (FHCRC) is checked."""
+    a, b = b"first member " * 20, b"second member " * 30
+    blob = gzip.compress(a, 6) + gzip.compress(b, 6)
+    st = Z.ZStream()
+    assert L.nx_inflateInit2_(C.byref(st), 31, Z.VERSION, C.sizeof(Z.ZStream)) == Z.Z_OK
+    src = C.create_string_buffer(blob, len(blob))
+    dst = C.create_string_buffer(1 << 16)
+    st.next_in = C.addressof(src)
+    st.next_out = C.addressof(dst)
+    st.avail_out = 1 << 16
+    fed, outs, members = 0, [], 0
+    for _ in range(100000):
+        if st.avail_in == 0 and fed < len(blob):
+            k = min(7, len(blob) - fed)
+            st.avail_in = k
+            fed += k
+        rc = L.nx_inflate(C.byref(st), Z.Z_NO_FLUSH)
+        if rc == Z.Z_STREAM_END:
+            outs.append(dst.raw[:st.total_out])
+            members += 1
+            if members == 2:
+                break
+            assert L.nx_inflateReset(C.byref(st)) == Z.Z_OK
+            st.next_out = C.addressof(dst)
+            st.avail_out = 1 << 16
+            continue
+        assert rc in (Z.Z_OK, Z.Z_BUF_ERROR), rc
+    L.nx_inflateEnd(C.byref(st))
+    assert outs == [a, b]
+    # header CRC: a gzip member with FHCRC, good and damaged
+    hdr = bytearray(b"\x1f\x8b\x08\x02\0\0\0\0\0\x03")
+    import zlib
+    hc = zlib.crc32(bytes(hdr)) & 0xffff
+    body = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw = body.compress(a) + body.flush()
+    tail = zlib.crc32(a).to_bytes(4, "little") + len(a).to_bytes(4, "little")
+    good = bytes(hdr) + hc.to_bytes(2, "little") + raw + tail
+    bad = bytes(hdr) + ((hc ^ 1).to_bytes(2, "little")) + raw + tail
+    got, rc, _, _ = Z.inflate_all(L, good, wbits=31)
+    assert rc == Z.Z_STREAM_END and got == a
+    got, rc, _, _ = Z.inflate_all(L, bad, wbits=31)
+    assert rc == Z.Z_DATA_ERROR
