@@ -18,7 +18,8 @@
  *   NX_GZIP_LOGFILE          logfile         default /tmp/nx.log (opened only when something is logged)
  *   NX_GZIP_DEV_NUM          dev_num         device ordinal, -1 = current/default (NXZ_DEVICE still works)
  *   NX_GZIP_DEF_BUF_SIZE     def_buf_size    accepted (64 KiB..8 MiB, KiB/MiB/GiB suffixes); the stream layer sizes its buffers on demand
- *   (keys of the POWER transport -- mlock_csb, timeout_pgfaults, *_delay, max_vas_reuse_count,
+ *   file only                compress_delay, decompress_delay, delay_threshold (both): AUTO mode's "device is slow" rule
+ *   (keys of the POWER transport -- mlock_csb, timeout_pgfaults, max_vas_reuse_count,
  *    soft_copy_threshold -- are read and ignored; cache_threshold is honoured, <= one page)
  */
 #ifndef NXZ_CONFIG_H
@@ -39,6 +40,8 @@ typedef struct nxz_config {
 	int      mode_deflate, mode_inflate;
 	uint32_t def_buf_size;
 	uint32_t cache_threshold;
+	uint64_t compress_delay, decompress_delay;   /* AUTO mode: average job delay (512 MHz ticks) above which new
+						      * streams go to software zlib (lib/nx_zlib.c:1121-1122,1306-1318) */
 	char     logfile[256];
 	char     cfgfile[256];
 	int      cfgfile_loaded;      /* 1 when the file was read and had at least one key */
@@ -56,6 +59,14 @@ typedef struct nxz_stats {
 const nxz_config_t *nxz_config(void);          /* parsed once, on first use */
 void     nxz_config_reload(void);               /* parse environment and file again (tests) */
 uint64_t nxz_str_to_num(const char *s);         /* "64KiB" -> 65536; UINT64_MAX when the suffix is unknown */
+
+/* the engine's average job delay, in 512 MHz ticks (lib/nx_zlib.c:1487-1511 nx_device_stats: exponential
+ * moving average, decay 4; lib/nx_zlib.h:443-449 decrease_delay: streams served in software let it fade) */
+void     nxz_device_stats(uint64_t start_ticks, uint64_t end_ticks);
+uint64_t nxz_avg_delay(void);
+void     nxz_decrease_delay(void);
+void     nxz_set_avg_delay(uint64_t ticks);     /* tests */
+uint64_t nxz_ticks(void);                       /* the 512 MHz timebase the thresholds are written for */
 
 int      nxz_stats_enabled(void);               /* trace & 0x8 */
 void     nxz_stats_get(nxz_stats_t *out);

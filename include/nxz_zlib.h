@@ -53,6 +53,7 @@ int nx_uncompress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong *sou
 /* checksums (lib/nx_crc.c:215-446, lib/nx_adler32.c:81-177) */
 unsigned long nx_crc32(unsigned long crc, const unsigned char *buf, size_t len);
 unsigned long nx_adler32(unsigned long adler, const unsigned char *buf, size_t len);
+unsigned long nx_adler32_z(unsigned long adler, const unsigned char *buf, size_t len);      /* lib/nx_adler32.c:150 */
 unsigned long nx_crc32_combine(unsigned long crc1, unsigned long crc2, off_t len2);
 unsigned long nx_adler32_combine(unsigned long adler1, unsigned long adler2, off_t len2);
 unsigned long nx_crc32_combine64(unsigned long crc1, unsigned long crc2, off_t len2);

@@ -55,6 +55,8 @@ void load_locked()
 	c.def_buf_size = 1u << 20;                     // lib/nx_zlib.c:1115
 	c.cache_threshold = 8192;                      // :1116
 	c.mode_deflate = c.mode_inflate = NXZ_MODE_AUTO;
+	c.decompress_delay = 17000000;                 // lib/nx_zlib.c:1121-1122 (timebase ticks)
+	c.compress_delay = 100000000;
 
 	const char *cfgfile = getenv("NX_GZIP_CONFIG");
 	if (!cfgfile) cfgfile = "./nx-zlib.conf";
@@ -100,6 +102,11 @@ void load_locked()
 		long pg = sysconf(_SC_PAGESIZE);
 		if (v > (uint64_t)pg) v = (uint64_t)pg;
 		c.cache_threshold = (uint32_t)v;
+	}
+	if (const char *d = get(nullptr, "delay_threshold")) c.compress_delay = c.decompress_delay = nxz_str_to_num(d);   // :1306-1318
+	else {
+		if (const char *d = get(nullptr, "decompress_delay")) c.decompress_delay = nxz_str_to_num(d);
+		if (const char *d = get(nullptr, "compress_delay")) c.compress_delay = nxz_str_to_num(d);
 	}
 	g_cfg = c;
 	g_cfg_ready = true;
@@ -249,3 +256,29 @@ extern "C" void nxz_stats_print(void)
 	fprintf(f, "inflate rate: %1.2f MiB/s\n", is > 0 ? (double)(s.inflate_len / (1024 * 1024)) / is : 0.0);
 	fflush(f);
 }
+
+// ---- the engine's average job delay (AUTO mode's "is the device slow" input) ----
+#include <atomic>
+#include <time.h>
+static std::atomic<uint64_t> g_avg_delay{0};
+extern "C" uint64_t nxz_ticks(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (uint64_t)ts.tv_sec * 512000000ull + (uint64_t)ts.tv_nsec * 512ull / 1000ull;
+}
+extern "C" void nxz_device_stats(uint64_t start, uint64_t end)
+{
+	const uint64_t tps = 512000000ull, last = end - start;
+	if (last > tps || last < tps / 10000000ull) return;           // the process slept, or the clock is broken (:1493-1497)
+	uint64_t d = g_avg_delay.load(std::memory_order_relaxed);
+	if (d == 0) d = last;
+	g_avg_delay.store((last + 4 * d) / 5, std::memory_order_relaxed);
+}
+extern "C" uint64_t nxz_avg_delay(void) { return g_avg_delay.load(std::memory_order_relaxed); }
+extern "C" void nxz_decrease_delay(void)
+{
+	const uint64_t d = g_avg_delay.load(std::memory_order_relaxed);
+	g_avg_delay.store(d - d / 4, std::memory_order_relaxed);
+}
+extern "C" void nxz_set_avg_delay(uint64_t t) { g_avg_delay.store(t, std::memory_order_relaxed); }

@@ -162,9 +162,33 @@ extern "C" int nxz_dhtgen(uint32_t *lhist, int num_lhist, uint32_t *dhist, int n
 // ---------------------------------------------------------------------------
 // selection policy
 // ---------------------------------------------------------------------------
+// The reference's 35 canned tables (lib/nx_dht_builtin.c:104-840), carried as data: tables made
+// from typical inputs that serve a job whose two most frequent literal/length symbols are a
+// table's keys (dht_search_builtin, lib/nx_dht.c:401-432); entry 0 is the default of a stream's
+// first job (lib/nx_dht.c:578-583).
+namespace {
+struct Builtin { uint32_t dhtlen; int key[3]; uint8_t dht[NXZ_DHT_MAXSZ]; };
+const Builtin kBuiltin[] = {
+#include "nxz_dht_builtin.inc"
+};
+constexpr int kNumBuiltin = (int)(sizeof(kBuiltin) / sizeof(kBuiltin[0]));
+static_assert(kNumBuiltin == 35, "lib/nx_dht_builtin.c has 35 tables");
+}
+
+extern "C" int nxz_dht_builtin_count(void) { return kNumBuiltin; }
+extern "C" int nxz_dht_builtin_get(int i, uint8_t *dht_out, uint32_t *dhtlen_out, int key[3])
+{
+	if (i < 0 || i >= kNumBuiltin) return -1;
+	if (dht_out) memcpy(dht_out, kBuiltin[i].dht, (kBuiltin[i].dhtlen + 7) / 8);
+	if (dhtlen_out) *dhtlen_out = kBuiltin[i].dhtlen;
+	if (key) memcpy(key, kBuiltin[i].key, sizeof(kBuiltin[i].key));
+	return 0;
+}
+
 struct nxz_dht_state {
 	struct Entry { bool valid = false; int accessed = 0; int key[3] = {-1, -1, -1}; uint32_t dhtlen = 0; uint8_t dht[NXZ_DHT_MAXSZ]; };
-	Entry builtin0;
+	Entry builtin[kNumBuiltin];
+	int last_builtin = 0;                          // where the next search of the canned tables starts (:408-411)
 	Entry cache[128];
 	int clock = 0;
 	const Entry *last = nullptr;
@@ -191,17 +215,14 @@ extern "C" void nxz_dht_top_keys(const uint32_t *ll, int lit_and_len, int key[3]
 extern "C" nxz_dht_state *nxz_dht_begin(void)
 {
 	auto *s = new nxz_dht_state();
-	// default table for the first job: what dhtgen makes of a flat "every literal equally likely,
-	// short matches more likely than long ones" profile -- close to the fixed code, complete
-	uint32_t ll[286], d[30];
-	for (int i = 0; i < 256; i++) ll[i] = 8 + (i >= 32 && i < 127 ? 24 : 0);
-	ll[256] = 1;
-	for (int i = 257; i < 286; i++) ll[i] = (uint32_t)std::max(1, 64 >> ((i - 257) / 4));
-	for (int i = 0; i < 30; i++) d[i] = (uint32_t)(4 + i);
-	int nb = 0, vb = 0;
-	nxz_dhtgen(ll, 286, d, 30, s->builtin0.dht, &nb, &vb);
-	s->builtin0.dhtlen = (uint32_t)(nb * 8 - (vb ? 8 - vb : 0));
-	s->builtin0.valid = true;
+	for (int i = 0; i < kNumBuiltin; i++) {
+		auto &e = s->builtin[i];
+		e.valid = true;
+		e.dhtlen = kBuiltin[i].dhtlen;
+		memcpy(e.key, kBuiltin[i].key, sizeof(e.key));
+		memset(e.dht, 0, sizeof(e.dht));
+		memcpy(e.dht, kBuiltin[i].dht, (e.dhtlen + 7) / 8);
+	}
 	return s;
 }
 
@@ -210,7 +231,10 @@ extern "C" void nxz_dht_end(nxz_dht_state *s) { delete s; }
 extern "C" nxz_dht_state *nxz_dht_copy(const nxz_dht_state *s)
 {
 	auto *c = new nxz_dht_state(*s);
-	if (s->last) c->last = s->last == &s->builtin0 ? &c->builtin0 : &c->cache[s->last - s->cache];
+	if (s->last) {
+		if (s->last >= s->builtin && s->last < s->builtin + kNumBuiltin) c->last = &c->builtin[s->last - s->builtin];
+		else c->last = &c->cache[s->last - s->cache];
+	}
 	return c;
 }
 
@@ -221,7 +245,7 @@ extern "C" void nxz_dht_lookup(nxz_dht_state *s, const uint32_t *counts, long so
 {
 	const nxz_dht_state::Entry *e = nullptr;
 	if (!counts) {
-		e = &s->builtin0;
+		e = &s->builtin[0];                                // the first canned table is the default (lib/nx_dht.c:578-583)
 		s->bytes_since_refresh = 0;
 	} else {
 		s->bytes_since_refresh += source_bytes;
@@ -234,6 +258,14 @@ extern "C" void nxz_dht_lookup(nxz_dht_state *s, const uint32_t *counts, long so
 			// a cached table serves when its two top symbols are the job's (dht_search_cache, :434-478)
 			for (auto &c : s->cache)
 				if (c.valid && c.key[0] == key[0] && c.key[1] == key[1]) { c.accessed = 1; e = &c; break; }
+			// ... or a canned one with the job's two top symbols (dht_search_builtin, :401-432), the search
+			// starting at the table that served last
+			if (!e) {
+				for (int i = 0, k = s->last_builtin % kNumBuiltin; i < kNumBuiltin; i++, k = (k + 1) % kNumBuiltin) {
+					auto &b = s->builtin[k];
+					if (b.valid && b.key[0] == key[0] && b.key[1] == key[1]) { e = &b; s->last_builtin = k; break; }
+				}
+			}
 			if (!e) {
 				// clock replacement, then generate a universal table (no missing codes)
 				for (;;) {

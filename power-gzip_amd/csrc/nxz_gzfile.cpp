@@ -15,6 +15,10 @@
 #include <unistd.h>
 #include "../../include/nxz_zlib.h"
 
+// The reference's gz layer keeps this flag in a global that ends up in its ABI (lib/nx_gzlib.c:55,
+// test/libnxz.abi): set once a file has been opened for writing.
+extern "C" { bool is_deflate = false; }
+
 namespace {
 
 struct GzState {
@@ -49,6 +53,7 @@ GzState *gz_open(const char *path, int fd, const char *mode)
 		int level = digit ? *digit - '0' : Z_DEFAULT_COMPRESSION;
 		rc = nx_deflateInit2_(&g->strm, level, Z_DEFLATED, 31, 8, strategy, ZLIB_VERSION, (int)sizeof(z_stream));
 		g->writer = true;
+		is_deflate = true;
 	} else {
 		rc = nx_inflateInit2_(&g->strm, 47, ZLIB_VERSION, (int)sizeof(z_stream));
 		if (rc == Z_OK && !(g->buf = (unsigned char *)malloc(RBUF))) { nx_inflateEnd(&g->strm); rc = Z_MEM_ERROR; }

@@ -17,6 +17,8 @@ int  nxz_dhtgen_batch(const uint32_t *counts, size_t n, nxz_batch_dht_t *tables,
 int  nxz_dhtgen(uint32_t *lhist, int num_lhist, uint32_t *dhist, int num_dhist,
 		uint8_t *dht, int *dht_num_bytes, int *dht_num_valid_bits);
 void nxz_dht_top_keys(const uint32_t *ll, int lit_and_len, int key[3]);
+int  nxz_dht_builtin_count(void);                                   /* 35: lib/nx_dht_builtin.c */
+int  nxz_dht_builtin_get(int i, uint8_t *dht_out, uint32_t *dhtlen_out, int key[3]);
 nxz_dht_state *nxz_dht_begin(void);
 void nxz_dht_end(nxz_dht_state *s);
 nxz_dht_state *nxz_dht_copy(const nxz_dht_state *s);

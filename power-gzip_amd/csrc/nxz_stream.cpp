@@ -61,7 +61,9 @@ struct Engine {
 		memset((void *)&j->crb.csb, 0, sizeof(j->crb.csb));
 		nxz_wr64(&j->crb.csb_address_be, (uint64_t)(uintptr_t)&j->crb.csb & ~15ull);
 		j->cpb.u.out_spbc_be = 0; j->cpb.out_spbc_with_count_be = 0; j->cpb.u.d.out_spbc_decomp_be = 0;
+		const uint64_t t0 = nxz_ticks();
 		if (nxu_run_job(j, &dev)) return -1;
+		nxz_device_stats(t0, nxz_ticks());                 // lib/nx_zlib.c:493-499: the job delay feeds AUTO mode
 		return (int)nxz_csb_cc(j);
 	}
 };
@@ -1093,6 +1095,8 @@ extern "C" unsigned long nx_adler32(unsigned long adler, const unsigned char *bu
 	return sw_adler32((uint32_t)adler, buf, len);
 }
 
+// lib/nx_adler32.c:150 (lib/Versions:29)
+extern "C" unsigned long nx_adler32_z(unsigned long adler, const unsigned char *buf, size_t len) { return nx_adler32(adler, buf, len); }
 extern "C" unsigned long nx_crc32_combine64(unsigned long crc1, unsigned long crc2, off_t len2) { return nx_crc32_combine(crc1, crc2, len2); }
 extern "C" unsigned long nx_adler32_combine64(unsigned long a1, unsigned long a2, off_t len2) { return nx_adler32_combine(a1, a2, len2); }
 

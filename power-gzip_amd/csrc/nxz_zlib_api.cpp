@@ -109,8 +109,18 @@ void init_once()
 inline void init() { std::call_once(g_once, init_once); }
 // a forked child cannot use the parent's engine: its new streams go to software zlib
 inline bool want_nx(int mode) { return nxz_engine_usable() && (mode == MODE_NX || (mode == MODE_AUTO && g_engine)); }
-inline bool want_nx_def() { init(); return want_nx(g_mode_def); }
-inline bool want_nx_inf() { init(); return want_nx(g_mode_inf); }
+// AUTO also looks at how the engine has been doing (lib/nx_deflate.c:714, lib/nx_inflate.c: s->use_nx =
+// avg_delay <= nx_config.[de]compress_delay; lib/nx_zlib.h:376-422): a stream that is opened while the
+// average job delay is above the threshold is served by software zlib, which lets the average fade
+// (decrease_delay, :443-449) until the engine is tried again.
+inline bool slow(int mode, uint64_t threshold)
+{
+	if (mode != MODE_AUTO || nxz_avg_delay() <= threshold) return false;
+	nxz_decrease_delay();
+	return true;
+}
+inline bool want_nx_def() { init(); return want_nx(g_mode_def) && !slow(g_mode_def, nxz_config()->compress_delay); }
+inline bool want_nx_inf() { init(); return want_nx(g_mode_inf) && !slow(g_mode_inf, nxz_config()->decompress_delay); }
 inline bool is_nx(z_streamp s, uint64_t magic) { return s && s->state && *(const uint64_t *)s->state == magic; }
 inline uint64_t now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
 

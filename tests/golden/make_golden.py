@@ -200,5 +200,20 @@ def main():
     dump("alice29_zlib.json", alice())
 
 
+def abi_symbols():
+    """names, version nodes and kinds of the ELF symbols of the reference's library (test/libnxz.abi)"""
+    import re
+    abi = open(os.path.join(REF, "test", "libnxz.abi")).read()
+    syms = []
+    for m in re.finditer(r"<elf-symbol name='([^']*)'([^>]*)>", abi):
+        name, rest = m.group(1), m.group(2)
+        v = re.search(r"version='([^']*)'", rest)
+        t = re.search(r"type='([^']*)'", rest).group(1)
+        syms.append({"name": name, "version": v.group(1) if v else "", "type": "object" if t.startswith("object") else "func"})
+    json.dump({"source": "/root/reference/test/libnxz.abi (elf-symbol entries: name, version node, kind)", "soname": "libnxz.so.0",
+               "symbols": syms}, open(os.path.join(HERE, "libnxz_abi_symbols.json"), "w"), indent=0)
+
+
 if __name__ == "__main__":
     main()
+    abi_symbols()

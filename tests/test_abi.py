@@ -77,3 +77,27 @@ def test_engine_refuses_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(pkg.EngineError):
         pkg.Engine(0)
+
+
+def test_preload_library_exports_the_references_versioned_abi():
+    """f1: libnxz_preload.so (the nx_* layer and the unprefixed zlib names in one library, like the
+    reference's libnxz.so) defines exactly the symbols of the reference's ABI dump (test/libnxz.abi, carried
+    as tests/golden/libnxz_abi_symbols.json), each under the version node lib/Versions gives it -- plus
+    deflateParams, which the reference leaves to real zlib (test/zlib.supp) and this library answers itself."""
+    import json
+    import subprocess
+    want = {(s["name"], s["version"]) for s in json.load(open(os.path.join(ROOT, "tests", "golden", "libnxz_abi_symbols.json")))["symbols"]}
+    assert len(want) == 76
+    out = subprocess.run(["readelf", "--dyn-syms", "-W", os.path.join(ROOT, "power-gzip_amd", "libnxz_preload.so")],
+                         capture_output=True, text=True, check=True).stdout
+    got = set()
+    for line in out.splitlines():
+        f = line.split()
+        if len(f) < 8 or f[6] == "UND" or f[4] != "GLOBAL" or f[3] not in ("FUNC", "OBJECT"):
+            continue
+        name, _, ver = f[7].partition("@@")
+        if f[3] == "OBJECT" and name.startswith(("LIBNXZ_", "ZLIB_")):
+            continue                                       # the version nodes themselves
+        got.add((name, ver))
+    assert got - want == {("deflateParams", "")}, sorted(got - want)
+    assert want - got == set(), sorted(want - got)

@@ -24,6 +24,7 @@ class Config(C.Structure):
     _fields_ = [("verbose", C.c_int), ("trace", C.c_int), ("dht", C.c_int), ("strategy_override", C.c_int),
                 ("dev_num", C.c_int), ("mode_deflate", C.c_int), ("mode_inflate", C.c_int),
                 ("def_buf_size", C.c_uint32), ("cache_threshold", C.c_uint32),
+                ("compress_delay", C.c_uint64), ("decompress_delay", C.c_uint64),
                 ("logfile", C.c_char * 256), ("cfgfile", C.c_char * 256), ("cfgfile_loaded", C.c_int)]
 
 
@@ -256,3 +257,40 @@ def test_config_symbols_are_exported():
     exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
     for n in sorted(names):
         assert n in exported, "missing export: " + n
+
+
+def test_delay_thresholds_and_the_average_job_delay(tmp_path, monkeypatch):
+    """AUTO mode's "the device is slow" input (lib/nx_zlib.c:1121-1122,1306-1318,1487-1511; lib/nx_zlib.h:443-449):
+    thresholds from the config file, the exponential moving average of the job delay, its fading."""
+    L = lib()
+    L.nxz_avg_delay.restype = C.c_uint64
+    L.nxz_set_avg_delay.argtypes = [C.c_uint64]
+    L.nxz_device_stats.argtypes = [C.c_uint64, C.c_uint64]
+    monkeypatch.delenv("NX_GZIP_CONFIG", raising=False)
+    L.nxz_config_reload()
+    c = L.nxz_config().contents
+    assert (c.compress_delay, c.decompress_delay) == (100000000, 17000000)
+    cfg = tmp_path / "nx.conf"
+    cfg.write_text("delay_threshold = 5000\n")
+    monkeypatch.setenv("NX_GZIP_CONFIG", str(cfg))
+    L.nxz_config_reload()
+    c = L.nxz_config().contents
+    assert (c.compress_delay, c.decompress_delay) == (5000, 5000)
+    cfg.write_text("compress_delay = 7\ndecompress_delay = 9\n")
+    L.nxz_config_reload()
+    c = L.nxz_config().contents
+    assert (c.compress_delay, c.decompress_delay) == (7, 9)
+    monkeypatch.delenv("NX_GZIP_CONFIG")
+    L.nxz_config_reload()
+    L.nxz_set_avg_delay(0)
+    L.nxz_device_stats(1000, 1000 + 51200)                   # 100 us: the first sample is the average
+    assert L.nxz_avg_delay() == 51200
+    L.nxz_device_stats(0, 512000)                            # 1 ms: (last + 4 * avg) / 5
+    assert L.nxz_avg_delay() == (512000 + 4 * 51200) // 5
+    a = L.nxz_avg_delay()
+    L.nxz_device_stats(0, 10)                                # too short to be real: ignored
+    L.nxz_device_stats(0, 600000000)                         # longer than a second: the process slept
+    assert L.nxz_avg_delay() == a
+    L.nxz_decrease_delay()
+    assert L.nxz_avg_delay() == a - a // 4
+    L.nxz_set_avg_delay(0)

@@ -672,3 +672,32 @@ def test_seeded_inflate_fuzz(eng, inflate_kernel):
         assert r["tpbc"][i] == len(d), i
         assert out[i, :len(d)].tobytes() == d, i
         assert r["crc"][i] == zlib.crc32(d) and r["adler"][i] == zlib.adler32(d), i
+
+
+def test_all_35_canned_tables_encode_bit_exact(eng):
+    """a11: every canned table of the reference (lib/nx_dht_builtin.c:104-840; all of them code every
+    symbol) through COMPRESS_DHT on a block each of four kinds: bytes == the oracle's with the same table"""
+    import torch
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "builtin_dht.json")))
+    tables = [(bytes.fromhex(e["dht"]), int(e["dhtlen"])) for e in g]
+    assert len(tables) == 35
+    kinds = ["alice", "binary", "lz", "sparse"]
+    blocks, use = [], []
+    for ti in range(len(tables)):
+        for k in kinds:
+            blocks.append(make_block(k, 65536 if k != "binary" else 40000, seed=900 + ti))
+            use.append(ti)
+    dht = eng.to_device(_dht_array(tables))
+    src = pack_blocks(eng, blocks, STRIDE_IN)
+    dst = torch.zeros((len(blocks), STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, STRIDE_IN, np.array([len(b) for b in blocks], np.uint32), dst, STRIDE_OUT,
+                            STRIDE_OUT, dht_index=np.array(use, np.uint32))
+    res, _ = eng.compress(pkg.FC_COMPRESS_DHT, jobs, len(blocks), dht=dht, ntables=len(tables))
+    r = eng.results_to_host(res)
+    out = dst.cpu().numpy()
+    for i, b in enumerate(blocks):
+        bits, n = tables[use[i]]
+        exp, nbits = O.deflate_dynamic(b, bits, n)
+        assert exp is not None, (i, use[i])
+        assert r["cc"][i] in (0, 64) and r["tpbc"][i] == len(exp) and r["tebc"][i] == nbits % 8, (i, use[i], r["cc"][i])
+        assert out[i, :len(exp)].tobytes() == exp, (i, use[i])

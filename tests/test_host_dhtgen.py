@@ -72,3 +72,41 @@ def test_batched_dhtgen_equals_single_calls():
             exp, bits = _gen(L, ll, d, 286, 30)
             assert tables["dhtlen"][i] == bits, i
             assert tables["dht"][i, :len(exp)].tobytes() == exp, i
+
+
+def test_canned_tables_are_the_references_and_serve_as_in_dht_lookup():
+    """a11: the 35 canned tables (lib/nx_dht_builtin.c:104-840) are carried as data; the first one is a
+    stream's default table (lib/nx_dht.c:578-583); a job whose two most frequent literal/length symbols are
+    a canned table's keys gets that table (dht_search_builtin, lib/nx_dht.c:401-432)."""
+    import ctypes as C
+    L = _lib()
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "builtin_dht.json")))
+    L.nxz_dht_builtin_get.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int * 3)]
+    assert L.nxz_dht_builtin_count() == len(gold) == 35
+    for i, g in enumerate(gold):
+        buf = C.create_string_buffer(320)
+        n = C.c_uint32()
+        key = (C.c_int * 3)()
+        assert L.nxz_dht_builtin_get(i, buf, C.byref(n), C.byref(key)) == 0
+        assert n.value == int(g["dhtlen"]) and list(key) == [int(x) for x in g["litlen"]]
+        assert buf.raw[:(n.value + 7) // 8].hex() == g["dht"][:2 * ((n.value + 7) // 8)]
+    L.nxz_dht_begin.restype = C.c_void_p
+    L.nxz_dht_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_char_p, C.POINTER(C.c_uint32)]
+    L.nxz_dht_end.argtypes = [C.c_void_p]
+    st = L.nxz_dht_begin()
+    out = C.create_string_buffer(320)
+    n = C.c_uint32()
+    L.nxz_dht_lookup(st, None, 0, out, C.byref(n))                  # first job: entry 0
+    assert n.value == int(gold[0]["dhtlen"]) and out.raw[:(n.value + 7) // 8].hex() == gold[0]["dht"][:2 * ((n.value + 7) // 8)]
+    # counts whose top two literals are the keys of canned table 2 (0 and 1): served by it, not generated
+    k0, k1 = [int(x) for x in gold[2]["litlen"][:2]]
+    counts = np.ones(316, np.uint32)
+    counts[k0], counts[k1] = 5000, 4000
+    L.nxz_dht_lookup(st, counts.ctypes.data, 1 << 20, out, C.byref(n))
+    assert n.value == int(gold[2]["dhtlen"]) and out.raw[:(n.value + 7) // 8].hex() == gold[2]["dht"][:2 * ((n.value + 7) // 8)]
+    # other top symbols: a generated table (no canned table has these keys)
+    counts = np.ones(316, np.uint32)
+    counts[200], counts[201] = 5000, 4000
+    L.nxz_dht_lookup(st, counts.ctypes.data, 1 << 20, out, C.byref(n))
+    assert all(out.raw[:(n.value + 7) // 8].hex() != g["dht"][:2 * ((n.value + 7) // 8)] for g in gold)
+    L.nxz_dht_end(st)

@@ -173,3 +173,39 @@ def test_forked_child_falls_back_to_software(tmp_path):
     child, parent = (bytes.fromhex(x) for x in out.split())
     assert child == zlib.compress(data, 6)                   # the child's bytes are software zlib's
     assert parent != child and zlib.decompress(parent) == data
+
+
+AUTO_SLOW = r'''
+import ctypes as C, sys, zlib
+L = C.CDLL(sys.argv[1])
+L.compressBound.restype = C.c_ulong; L.compressBound.argtypes = [C.c_ulong]
+L.compress.argtypes = [C.c_char_p, C.POINTER(C.c_ulong), C.c_char_p, C.c_ulong]
+data = open(sys.argv[2], "rb").read()
+outs = []
+for k in range(6):
+    n = L.compressBound(len(data)); dst = C.create_string_buffer(n); dl = C.c_ulong(n)
+    assert L.compress(dst, C.byref(dl), data, len(data)) == 0
+    assert zlib.decompress(dst.raw[:dl.value]) == data
+    outs.append(dst.raw[:dl.value] == zlib.compress(data, -1))
+sys.stdout.write(" ".join("sw" if o else "nx" for o in outs))
+'''
+
+
+@pytest.mark.gpu
+def test_auto_mode_leaves_a_slow_engine_and_comes_back(tmp_path):
+    """AUTO (lib/nx_zlib.h:376-422, lib/nx_deflate.c:714): a stream opened while the engine's average job
+    delay is above compress_delay is served by software zlib; streams served in software let the average fade
+    (decrease_delay), so the engine is tried again.  With a threshold no real job can meet: the first call
+    goes to the engine (no measurement yet), the following ones to zlib."""
+    data = make_block("alice", 300000, 11)
+    f = tmp_path / "in.bin"
+    f.write_bytes(data)
+    cfg = tmp_path / "nx.conf"
+    cfg.write_text("delay_threshold = 3\n")                   # 3 ticks of 512 MHz: nothing is that fast
+    env = dict(os.environ, NX_GZIP_TYPE_SELECTOR="0", NX_GZIP_CONFIG=str(cfg))
+    out = subprocess.run([sys.executable, "-c", AUTO_SLOW, PRELOAD, str(f)], env=env, check=True, capture_output=True, text=True).stdout.split()
+    assert out[0] == "nx" and "sw" in out[1:], out
+    # the default thresholds (0.2 s / 33 ms per job) are never reached by this engine: everything stays on it
+    env = dict(os.environ, NX_GZIP_TYPE_SELECTOR="0")
+    out = subprocess.run([sys.executable, "-c", AUTO_SLOW, PRELOAD, str(f)], env=env, check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["nx"] * 6, out
