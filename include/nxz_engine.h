@@ -288,6 +288,21 @@ int nxz_inflate_stream(nxz_ctx_t *ctx, const uint8_t *src, uint64_t src_len, uin
 		       uint64_t *out_len, uint32_t *crc, uint32_t *adler, uint64_t *end_bit,
 		       uint32_t *pieces, uint32_t *rounds, void *stream);
 
+/* A long HOST buffer -> ONE raw deflate stream in a HOST buffer (additive; what nx_deflate makes of
+ * it job after job, lib/nx_deflate.c:1440-1719, for the levels that carry no history from job to job,
+ * :654-680).  The source is cut into 64 KiB blocks, compressed side by side (fc = NXZ_FC_COMPRESS_FHT,
+ * or NXZ_FC_COMPRESS_DHTGEN: an exact dynamic table per block made on the device), and laid back to
+ * back on the device the way the reference strings jobs together: a block that ends inside a byte is
+ * followed by an empty stored block (append_sync_flush, :220-243), a block that did not shrink is
+ * stored (:1274-1282); with `final` the last block carries BFINAL, otherwise the run ends on a byte
+ * boundary and more blocks may follow.  Groups of 256 blocks alternate between two HIP streams, so
+ * the host-to-device copy of one group, the kernels of another and the copy back overlap.
+ * dst_cap >= nxz_deflate_host_bound(src_len).  *crc / *adler: checksums of the source from 0 / 1
+ * (combine with yours).  Synchronous; returns 0 or a negative errno. */
+size_t nxz_deflate_host_bound(size_t src_len);
+int nxz_deflate_host(nxz_ctx_t *ctx, int fc, const uint8_t *src, size_t src_len, int final,
+		     uint8_t *dst, size_t dst_cap, size_t *out_len, uint32_t *crc, uint32_t *adler);
+
 /* Batched wrap (FC 0x1e): copy + crc32 + adler32 from the initial values. */
 int nxz_batch_wrap(nxz_ctx_t *ctx, const nxz_batch_job_t *jobs, size_t n,
 		   nxz_batch_result_t *results, void *stream);

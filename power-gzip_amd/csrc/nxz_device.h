@@ -44,6 +44,8 @@ int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *r
 int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 		       nxz_batch_dht_t *dht_io, int window_in_lds, hipStream_t stream);
 int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
+int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n, uint32_t final_index,
+			   uint64_t *offsets, uint8_t *packed, hipStream_t stream);
 size_t nxz_inflate_lanes_workspace(size_t n);
 int nxz_launch_pack_members(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n,
 			    uint64_t *offsets, uint8_t *packed, hipStream_t stream);

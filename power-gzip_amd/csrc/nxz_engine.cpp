@@ -26,7 +26,7 @@
 
 #define NXZ_VERSION "nxz-engine 0.1 (gfx950)"
 #define SUBBLOCK 65536u
-#define SLOTS 8
+#define SLOTS 32
 
 static thread_local char g_err[256];
 static void set_err(const char *what, hipError_t e)
@@ -89,6 +89,17 @@ struct nxz_ctx {
 		}
 	};
 	std::map<hipStream_t, Scratch> scratch;
+	// nxz_deflate_host: two lanes, each with its own stream, so that the copies of one group of
+	// blocks run while the other group is in the kernels
+	struct HostLane {
+		hipStream_t stream = nullptr;
+		uint8_t *d_src = nullptr, *d_dst = nullptr, *d_packed = nullptr;
+		nxz_batch_job_t *d_jobs = nullptr, *h_jobs = nullptr;
+		nxz_batch_result_t *d_res = nullptr, *h_res = nullptr;
+		uint64_t *d_off = nullptr, *h_total = nullptr;
+		size_t n = 0; uint64_t bytes = 0;
+	} lanes[2];
+	std::mutex lanes_mtx;
 	uint32_t *d_job_counters = nullptr;           // job counters of the batched deflate launches (ring)
 	unsigned next_counter = 0;
 	// measurement aid (nxz_ctx_stage_timing): events around every kernel of the compress batches
@@ -194,6 +205,19 @@ extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 	for (auto &s : c->slots) if (s.stream) slot_free(s);
 	for (auto &kv : c->scratch) kv.second.release();
 	if (c->d_job_counters) (void)hipFree(c->d_job_counters);
+	for (auto &l : c->lanes) {
+		if (!l.stream) continue;
+		(void)hipStreamSynchronize(l.stream);
+		{
+			std::lock_guard<std::mutex> g2(c->mtx);
+			auto it = c->scratch.find(l.stream);
+			if (it != c->scratch.end()) { it->second.release(); c->scratch.erase(it); }
+		}
+		(void)hipFree(l.d_src); (void)hipFree(l.d_dst); (void)hipFree(l.d_packed); (void)hipFree(l.d_jobs); (void)hipFree(l.d_res); (void)hipFree(l.d_off);
+		(void)hipHostFree(l.h_jobs); (void)hipHostFree(l.h_res); (void)hipHostFree(l.h_total);
+		(void)hipStreamDestroy(l.stream);
+		l = nxz_ctx::HostLane();
+	}
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	g_ctx[c->device] = nullptr;
 	delete c;
@@ -401,6 +425,130 @@ extern "C" int nxz_batch_pack_gzip(nxz_ctx_t *c, const nxz_batch_job_t *jobs, co
 	(void)hipSetDevice(c->device);
 	int rc = nxz_launch_pack_members(jobs, results, n, offsets, packed, (hipStream_t)stream);
 	if (rc) { set_err("pack launch", (hipError_t)rc); return -EIO; }
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// nxz_deflate_host: a long HOST buffer -> one raw deflate stream in a HOST buffer
+// ---------------------------------------------------------------------------
+#define HOST_GROUP 256u                    /* blocks per group: 16 MiB in, one launch of each kernel */
+#define HOST_SLOT 73856u                   /* room for one block's output (nxz_compress_bound(65536) rounded) */
+
+static uint32_t gf2_mul32(uint32_t a, uint32_t b)
+{
+	uint32_t p = 0;
+	for (uint32_t m = 0x80000000u; m; m >>= 1) {
+		if (a & m) p ^= b;
+		b = (b >> 1) ^ ((b & 1) ? 0xedb88320u : 0);
+	}
+	return p;
+}
+static uint32_t crc_shift_op(uint64_t nbytes)                       // x^(8 nbytes) mod P, reflected
+{
+	uint32_t r = 0x80000000u, sq = 0x00800000u;
+	for (uint64_t n = nbytes; n; n >>= 1) { if (n & 1) r = gf2_mul32(r, sq); sq = gf2_mul32(sq, sq); }
+	return r;
+}
+static uint32_t adler_join(uint32_t a1, uint32_t a2, uint64_t len2)
+{
+	const uint64_t B = 65521, rem = len2 % B, s1 = a1 & 0xffff;
+	const uint64_t sum1 = (s1 + (a2 & 0xffff) + B - 1) % B;
+	const uint64_t sum2 = (rem * s1 + (a1 >> 16) + (a2 >> 16) + B - rem) % B;
+	return (uint32_t)((sum2 << 16) | sum1);
+}
+
+extern "C" size_t nxz_deflate_host_bound(size_t src_len)
+{
+	return src_len + ((src_len + SUBBLOCK - 1) / SUBBLOCK) * 10 + 16;
+}
+
+static bool lane_init(nxz_ctx::HostLane &l)
+{
+	HIPCHK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), return false);
+	HIPCHK(hipMalloc((void **)&l.d_src, (size_t)HOST_GROUP * SUBBLOCK), return false);
+	HIPCHK(hipMalloc((void **)&l.d_dst, (size_t)HOST_GROUP * HOST_SLOT), return false);
+	HIPCHK(hipMalloc((void **)&l.d_packed, (size_t)HOST_GROUP * (SUBBLOCK + 16)), return false);
+	HIPCHK(hipMalloc((void **)&l.d_jobs, HOST_GROUP * sizeof(nxz_batch_job_t)), return false);
+	HIPCHK(hipHostMalloc((void **)&l.h_jobs, HOST_GROUP * sizeof(nxz_batch_job_t)), return false);
+	HIPCHK(hipMalloc((void **)&l.d_res, HOST_GROUP * sizeof(nxz_batch_result_t)), return false);
+	HIPCHK(hipHostMalloc((void **)&l.h_res, HOST_GROUP * sizeof(nxz_batch_result_t)), return false);
+	HIPCHK(hipMalloc((void **)&l.d_off, (HOST_GROUP + 1) * sizeof(uint64_t)), return false);
+	HIPCHK(hipHostMalloc((void **)&l.h_total, sizeof(uint64_t)), return false);
+	return true;
+}
+
+extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t src_len, int final,
+				uint8_t *dst, size_t dst_cap, size_t *out_len, uint32_t *crc, uint32_t *adler)
+{
+	if (!c || !src || !dst || !out_len || !src_len) return -EINVAL;
+	if (fc != NXZ_FC_COMPRESS_FHT && fc != NXZ_FC_COMPRESS_DHTGEN) return -EINVAL;
+	if (forked_child()) return -ENODEV;
+	if (dst_cap < nxz_deflate_host_bound(src_len)) return -E2BIG;
+	(void)hipSetDevice(c->device);
+	std::lock_guard<std::mutex> g(c->lanes_mtx);
+	for (auto &l : c->lanes)
+		if (!l.stream && !lane_init(l)) return -ENOMEM;
+	const size_t nblk = (src_len + SUBBLOCK - 1) / SUBBLOCK;
+	// groups: at least four when the input allows it, so that copies and kernels overlap
+	size_t group = std::min<size_t>(HOST_GROUP, std::max<size_t>(32, (nblk + 3) / 4));
+	const size_t ngroups = (nblk + group - 1) / group;
+	group = (nblk + ngroups - 1) / ngroups;
+	const uint32_t op_block = crc_shift_op(SUBBLOCK);
+	uint32_t run_crc = 0, run_adler = 1;
+	size_t pos = 0;
+	int rc = 0;
+
+	auto queue = [&](size_t gi) -> int {
+		nxz_ctx::HostLane &l = c->lanes[gi & 1];
+		const size_t b0 = gi * group, n = std::min(group, nblk - b0);
+		const uint64_t bytes = std::min<uint64_t>((uint64_t)n * SUBBLOCK, src_len - (uint64_t)b0 * SUBBLOCK);
+		for (size_t k = 0; k < n; k++) {
+			nxz_batch_job_t &j = l.h_jobs[k];
+			memset(&j, 0, sizeof(j));
+			j.src = l.d_src + k * SUBBLOCK; j.dst = l.d_dst + k * HOST_SLOT;
+			j.src_len = (uint32_t)std::min<uint64_t>(SUBBLOCK, bytes - (uint64_t)k * SUBBLOCK);
+			j.dst_cap = HOST_SLOT; j.in_crc = 0; j.in_adler = 1;
+		}
+		l.n = n; l.bytes = bytes;
+		HIPCHK(hipMemcpyAsync(l.d_jobs, l.h_jobs, n * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, l.stream), return -EIO);
+		HIPCHK(hipMemcpyAsync(l.d_src, src + (uint64_t)b0 * SUBBLOCK, bytes, hipMemcpyHostToDevice, l.stream), return -EIO);
+		int r = nxz_batch_compress(c, fc, l.d_jobs, n, nullptr, 0, l.d_res, nullptr, l.stream);
+		if (r) return r;
+		const uint32_t fin = final && gi == ngroups - 1 ? (uint32_t)(n - 1) : 0xffffffffu;
+		if (nxz_launch_pack_stream(l.d_jobs, l.d_res, n, fin, l.d_off, l.d_packed, l.stream)) return -EIO;
+		HIPCHK(hipMemcpyAsync(l.h_res, l.d_res, n * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, l.stream), return -EIO);
+		HIPCHK(hipMemcpyAsync(l.h_total, l.d_off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, l.stream), return -EIO);
+		return 0;
+	};
+	auto collect = [&](size_t gi) -> int {
+		nxz_ctx::HostLane &l = c->lanes[gi & 1];
+		HIPCHK(hipStreamSynchronize(l.stream), return -EIO);
+		const uint64_t total = *l.h_total;
+		if (pos + total > dst_cap) return -E2BIG;                   // cannot happen: the bound was checked
+		HIPCHK(hipMemcpyAsync(dst + pos, l.d_packed, total, hipMemcpyDeviceToHost, l.stream), return -EIO);
+		for (size_t k = 0; k < l.n; k++) {                           // meanwhile: checksums of the run
+			const uint32_t len = l.h_jobs[k].src_len;
+			const uint32_t op = len == SUBBLOCK ? op_block : crc_shift_op(len);
+			run_crc = gf2_mul32(run_crc, op) ^ l.h_res[k].crc;
+			run_adler = adler_join(run_adler, l.h_res[k].adler, len);
+		}
+		HIPCHK(hipStreamSynchronize(l.stream), return -EIO);
+		pos += total;
+		return 0;
+	};
+	size_t queued = 0, done = 0;
+	while (!rc && queued < ngroups && queued < 2) rc = queue(queued++);
+	while (!rc && done < queued) {
+		rc = collect(done++);
+		if (!rc && queued < ngroups) rc = queue(queued++);
+	}
+	if (rc) {
+		for (auto &l : c->lanes) (void)hipStreamSynchronize(l.stream);
+		return rc;
+	}
+	*out_len = pos;
+	if (crc) *crc = run_crc;
+	if (adler) *adler = run_adler;
 	return 0;
 }
 

@@ -293,7 +293,130 @@ __global__ __launch_bounds__(256) void pack_members_kernel(const nxz_batch_job_t
 	}
 }
 
+// ---- one deflate stream from a compress batch ---------------------------------------------------
+// The blocks of a batch, made independently, laid back to back as ONE raw deflate stream the way
+// the reference strings its jobs together: a block that ends inside a byte is followed by an
+// empty stored block (append_sync_flush, lib/nx_deflate.c:220-243), so every block starts on a
+// byte boundary; a block that failed or did not shrink goes out as stored blocks of its source
+// (lib/nx_deflate.c:1274-1282, append_btype00_header :175-201); block `final_index` carries BFINAL.
+struct StreamPiece {
+	bool stored;
+	uint32_t len;       // source bytes
+	uint32_t keep;      // compressed: bytes taken from the job's output
+	uint32_t size;      // bytes this block occupies in the stream
+	uint32_t pad;       // compressed: zero bytes between the output and 00 00 FF FF (the 3 header bits of the empty block may spill)
+	bool marker;
+};
+
+__device__ inline StreamPiece stream_piece(const nxz_batch_job_t &job, const nxz_batch_result_t &r, bool final)
+{
+	StreamPiece p;
+	p.len = job.src_len - job.hist_len;
+	p.stored = r.cc != 0 || r.tpbc > p.len;
+	if (p.stored) {
+		p.keep = 0; p.pad = 0; p.marker = false;
+		p.size = p.len > 65535 ? p.len + 10 : p.len + 5;
+	} else {
+		p.keep = r.tpbc;
+		p.marker = !final && r.tebc != 0;
+		p.pad = p.marker && r.tebc + 3 > 8 ? 1 : 0;
+		p.size = r.tpbc + (p.marker ? p.pad + 4 : 0);
+	}
+	return p;
+}
+
+__global__ __launch_bounds__(1024) void stream_offsets_kernel(const nxz_batch_job_t *__restrict__ jobs, const nxz_batch_result_t *__restrict__ results,
+							      uint32_t n, uint32_t final_index, uint64_t *__restrict__ offsets)
+{
+	__shared__ uint64_t part[1024];
+	const uint32_t t = threadIdx.x;
+	const uint32_t per = (n + 1023) / 1024;
+	const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+	uint64_t sum = 0;
+	for (uint32_t i = lo; i < hi; i++) sum += stream_piece(jobs[i], results[i], i == final_index).size;
+	part[t] = sum;
+	__syncthreads();
+	for (uint32_t d = 1; d < 1024; d <<= 1) {
+		uint64_t v = t >= d ? part[t - d] : 0;
+		__syncthreads();
+		part[t] += v;
+		__syncthreads();
+	}
+	uint64_t off = part[t] - sum;
+	for (uint32_t i = lo; i < hi; i++) {
+		offsets[i] = off;
+		off += stream_piece(jobs[i], results[i], i == final_index).size;
+	}
+	if (t == 1023) offsets[n] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void pack_stream_kernel(const nxz_batch_job_t *__restrict__ jobs, const nxz_batch_result_t *__restrict__ results,
+							  uint32_t final_index, const uint64_t *__restrict__ offsets, uint8_t *__restrict__ packed)
+{
+	const uint32_t t = threadIdx.x;
+	const nxz_batch_job_t job = jobs[blockIdx.x];
+	const nxz_batch_result_t r = results[blockIdx.x];
+	const bool final = blockIdx.x == final_index;
+	const StreamPiece p = stream_piece(job, r, final);
+	const uint8_t *data = p.stored ? job.src + job.hist_len : job.dst;
+	// stored: [hdr 5][first][hdr 5][rest]; compressed: [keep][pad][00 00 FF FF]
+	const uint32_t first = p.len > 65535 ? 65535 : p.len, rest = p.len - first;
+	const uint32_t d0 = p.stored ? 5 : 0;                           // first stream byte that is a plain copy of `data`
+	const uint32_t dn = p.stored ? first : p.keep;
+	const uint32_t lastmask = r.tebc ? (1u << r.tebc) - 1 : 0xff;
+	auto byte_at = [&](uint32_t j) -> uint32_t {
+		if (p.stored) {
+			auto hdr = [&](uint32_t k, uint32_t n, bool last) -> uint32_t {
+				return k == 0 ? (last ? 1u : 0u) : k < 3 ? (n >> (8 * (k - 1))) & 0xff : (~n >> (8 * (k - 3))) & 0xff;
+			};
+			if (j < 5) return hdr(j, first, final && rest == 0);
+			if (j < 5 + first) return data[j - 5];
+			if (j < 10 + first) return hdr(j - 5 - first, rest, final);
+			return data[j - 10];
+		}
+		if (j < p.keep) {
+			uint32_t v = data[j];
+			if (j == 0) v = (v & ~1u) | (final ? 1u : 0u);          // set_bfinal (lib/nx_deflate.c:1404-1413)
+			if (j == p.keep - 1) v &= lastmask;
+			return v;
+		}
+		const uint32_t k = j - p.keep - p.pad;                      // after the pad byte: LEN = 0, NLEN = ffff
+		return j < p.keep + p.pad ? 0 : k < 2 ? 0 : 0xff;
+	};
+	uint8_t *o = packed + offsets[blockIdx.x];
+	const uint32_t size = p.size;
+	const uint32_t head = (uint32_t)((4 - ((uintptr_t)o & 3)) & 3);
+	const uint32_t nd = size > head ? (size - head) >> 2 : 0;
+	if (t < head && t < size) o[t] = (uint8_t)byte_at(t);
+	for (uint32_t k = head + nd * 4 + t; k < size; k += 256) o[k] = (uint8_t)byte_at(k);
+	uint32_t *od = (uint32_t *)(o + head);
+	for (uint32_t w = t; w < nd; w += 256) {
+		const uint32_t j = head + w * 4;
+		uint32_t v;
+		// whole dwords strictly inside the copied region (not its first or last byte, which are patched)
+		if (j > d0 && j + 4 < d0 + dn) {
+			const uintptr_t a = (uintptr_t)data + (j - d0);
+			const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
+			const uint32_t bo = (uint32_t)a & 3;
+			const uint32_t lo = q[0], hi = bo ? q[1] : 0;
+			v = __builtin_amdgcn_alignbyte(hi, lo, bo);
+		} else {
+			v = byte_at(j) | byte_at(j + 1) << 8 | byte_at(j + 2) << 16 | byte_at(j + 3) << 24;
+		}
+		od[w] = v;
+	}
+}
+
 } // namespace nxz
+
+extern "C" int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n, uint32_t final_index,
+				      uint64_t *offsets, uint8_t *packed, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL(nxz::stream_offsets_kernel, dim3(1), dim3(1024), 0, stream, jobs, results, (uint32_t)n, final_index, offsets);
+	hipLaunchKernelGGL(nxz::pack_stream_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, results, final_index, offsets, packed);
+	return (int)hipGetLastError();
+}
 
 extern "C" int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_dht_prepared_t *out, hipStream_t stream)
 {

@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <new>
 #include <vector>
+#include <mutex>
+#include <chrono>
 #include "nxz_host.h"
 #include "../../include/nxz_config.h"
 #include "../../include/nxz_wire.h"
@@ -52,6 +54,15 @@ struct Engine {
 	{
 		memset(&dev, 0, sizeof(dev));
 		open = nx_function_begin(NXZ_FUNC_COMP_GZIP, nxz_config()->dev_num, &dev) == 0;   // NX_GZIP_DEV_NUM
+		// The reference opens its device once per process (nx_hw_init, lib/nx_zlib.c:1015-1090) and
+		// every stream shares that handle; here the first stream leaves one handle open for the life
+		// of the process, so that the engine context (streams, staging buffers) outlives the
+		// init/end pair of every nx_compress2 call instead of being rebuilt each time.
+		if (open) {
+			static std::once_flag once;
+			static nxz_dev_t keep;
+			std::call_once(once, [] { memset(&keep, 0, sizeof(keep)); (void)nx_function_begin(NXZ_FUNC_COMP_GZIP, nxz_config()->dev_num, &keep); });
+		}
 		return open;
 	}
 	void end() { if (open) nx_function_end(&dev); open = false; }
@@ -119,6 +130,8 @@ struct Deflate {
 	nxz_dht_state *dht = nullptr; uint32_t counts[316]; bool have_counts = false; long last_job_bytes = 0;
 	Engine eng; JobBuf jb; std::vector<uint8_t> jobout;
 	uint64_t total_in = 0;
+	// deflate_batch: its output when the caller's buffer may be too small for the whole run
+	std::vector<uint8_t> batch_tmp;
 
 	void out_bytes(const uint8_t *p, size_t n)
 	{
@@ -367,6 +380,51 @@ int deflate_job(Deflate *s, int flush)
 	return Z_OK;
 }
 
+// A caller that hands over hundreds of kilobytes at once at a level that keeps no history between
+// jobs (the default and 1..4: lib/nx_deflate.c:654-680 sets max_history_len = 0, so every job is
+// independent) gets all its full 64 KiB blocks -- with Z_FINISH everything it has -- compressed by ONE
+// engine call (nxz_deflate_host: blocks side by side, fixed code or an exact dynamic table per block,
+// strung together on the device the way deflate_job strings jobs together) instead of one nxu_run_job
+// round trip per block.  (Weak references: the CPU model of the test suite has no such entry.)
+extern "C" {
+size_t nxz_deflate_host_bound(size_t) __attribute__((weak));
+int nxz_deflate_host(nxz_ctx_t *, int, const uint8_t *, size_t, int, uint8_t *, size_t, size_t *, uint32_t *, uint32_t *) __attribute__((weak));
+}
+constexpr size_t BATCH_MIN = 4 * JOB_UNIT;
+
+// true when it took input; what it leaves (less than a block) goes the job-after-job way
+bool deflate_batch(Deflate *s, int flush)
+{
+	z_streamp z = s->z;
+	if (!nxz_deflate_host || !nxz_deflate_host_bound) return false;
+	if (!s->eng.open || s->max_history != 0 || s->used != 0 || s->dict_len != 0 || s->pending() || z->avail_in < BATCH_MIN) return false;
+	nxz_ctx_t *ctx = (nxz_ctx_t *)s->eng.dev.paste_addr;
+	if (!ctx) return false;
+	const bool final = flush == Z_FINISH;
+	const size_t take = final ? z->avail_in : (size_t)z->avail_in / JOB_UNIT * JOB_UNIT;
+	const size_t bound = nxz_deflate_host_bound(take);
+	if (s->tail_n) s->stored_header(0, 0);                          // the run starts on a byte boundary
+	// straight into the caller's buffer when it is sure to fit, else through the pending buffer
+	const bool direct = !s->pending() && z->avail_out >= bound;
+	uint8_t *out = z->next_out;
+	if (!direct) { s->batch_tmp.resize(bound); out = s->batch_tmp.data(); }
+	size_t produced = 0;
+	uint32_t crc = 0, adler = 1;
+	const uint64_t t0 = nxz_ticks();
+	if (nxz_deflate_host(ctx, s->strategy == Z_FIXED ? NXZ_FC_COMPRESS_FHT : 0x22 /* NXZ_FC_COMPRESS_DHTGEN */, z->next_in, take, final,
+			     out, bound, &produced, &crc, &adler))
+		return false;                                               // nothing consumed: the ordinary path takes over
+	nxz_device_stats(t0, t0 + (nxz_ticks() - t0) / ((take + JOB_UNIT - 1) / JOB_UNIT));   // per job, as AUTO mode's average counts
+	if (direct) { z->next_out += produced; z->avail_out -= (uInt)produced; z->total_out += produced; }
+	else s->out_bytes(out, produced);
+	deflate_consume(s, take);
+	combine_cksum(s, crc, adler, (uint32_t)take);
+	publish_cksum(s);
+	if (final) s->st = Deflate::BFINAL;
+	s->have_counts = false;                                          // (the next single job starts from the default table again)
+	return true;
+}
+
 int deflate_end_of_stream(Deflate *s)
 {
 	if (s->st == Deflate::BUSY) {                         // :1594-1604: final empty stored block
@@ -518,8 +576,10 @@ extern "C" int nx_deflate(z_streamp strm, int flush)
 			return Z_OK;
 		}
 		if (avail) {
-			int rc = deflate_job(s, flush);
-			if (rc != Z_OK) return rc;
+			if (!deflate_batch(s, flush)) {
+				int rc = deflate_job(s, flush);
+				if (rc != Z_OK) return rc;
+			}
 			s->dict_len = 0;
 		}
 		const bool more_in = s->used + strm->avail_in != 0;

@@ -1,0 +1,97 @@
+"""nx_deflate / nx_compress2 with hundreds of kilobytes available at once: at the levels that keep no
+history between jobs (lib/nx_deflate.c:654-680) all full 64 KiB blocks of a call go to the engine as
+ONE batch (nxz_stream.cpp deflate_batch).  What comes out must be an ordinary zlib/gzip/raw stream:
+zlib reads it back, checksums and totals agree, every flush mode and every framing still works, and a
+block that does not shrink is stored."""
+import ctypes as C
+import os
+import zlib
+
+import pytest
+
+import zstream as Z
+from datagen import make_block
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    return Z.load("gpu")
+
+
+def mixed(n, seed):
+    kinds = ["alice", "lz", "random", "zeros", "text33", "alice"]
+    out = bytearray()
+    i = 0
+    while len(out) < n:
+        out += make_block(kinds[i % len(kinds)], 65536 + (i % 3) * 4096, seed + i)
+        i += 1
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("wbits", [15, 31, -15])
+@pytest.mark.parametrize("strategy", [Z.Z_DEFAULT_STRATEGY, Z.Z_FIXED])
+def test_one_shot_deflate_of_megabytes(L, wbits, strategy):
+    data = mixed((3 << 20) + 12345, 7)
+    out, rcs, adler = Z.deflate_all(L, data, level=-1, wbits=wbits, strategy=strategy)
+    assert zlib.decompress(out, wbits) == data
+    if wbits == 15:
+        assert adler == zlib.adler32(data)
+    if wbits == 31:
+        assert adler == zlib.crc32(data)
+    # few calls: the whole input went in batches, not in one call per 64 KiB job
+    assert len(rcs) <= 4, len(rcs)
+    assert len(out) < 0.8 * len(data)
+
+
+def test_exact_multiple_of_the_block_size_ends_in_a_final_block(L):
+    data = mixed(16 * 65536, 3)
+    out, _, _ = Z.deflate_all(L, data, level=1, wbits=-15)
+    d = zlib.decompressobj(-15)
+    assert d.decompress(out) == data and d.eof and d.unused_data == b""
+
+
+@pytest.mark.parametrize("step_out", [4096, 1 << 20])
+@pytest.mark.parametrize("flush", [Z.Z_NO_FLUSH, Z.Z_SYNC_FLUSH, Z.Z_FULL_FLUSH])
+def test_streaming_with_large_feeds_and_small_outputs(L, step_out, flush):
+    data = mixed((2 << 20) + 777, 11)
+    out, _, adler = Z.deflate_all(L, data, level=-1, wbits=15, step_in=700000, step_out=step_out, flush=flush)
+    assert zlib.decompress(out) == data
+    assert adler == zlib.adler32(data)
+
+
+def test_incompressible_blocks_are_stored(L):
+    data = os.urandom(1 << 20)
+    out, _, _ = Z.deflate_all(L, data, level=-1, wbits=15)
+    assert zlib.decompress(out) == data
+    assert len(out) < len(data) + 16 * 10 + 64
+
+
+def test_compress2_round_trip_through_zlib_and_nx_uncompress(L):
+    data = mixed(5 << 20, 23)
+    cap = C.c_ulong(L.nx_compressBound(len(data)))
+    dst = C.create_string_buffer(cap.value)
+    assert L.nx_compress2(dst, C.byref(cap), data, len(data), 1) == Z.Z_OK
+    comp = dst.raw[:cap.value]
+    assert zlib.decompress(comp) == data
+    n = C.c_ulong(len(data))
+    back = C.create_string_buffer(len(data))
+    assert L.nx_uncompress(back, C.byref(n), comp, len(comp)) == Z.Z_OK
+    assert n.value == len(data) and back.raw == data
+
+
+def test_levels_with_history_keep_the_job_after_job_path(L):
+    # level 6 carries 32 KiB of history from job to job (lib/nx_deflate.c:654-680): matches may reach
+    # across job boundaries, which the batch of independent blocks cannot give -- same stream as before
+    data = make_block("alice", 1 << 20, 5)
+    out, _, _ = Z.deflate_all(L, data, level=6, wbits=15)
+    assert zlib.decompress(out) == data
+
+
+def test_dictionary_then_batch(L):
+    data = mixed(1 << 20, 31)
+    dic = data[:20000]
+    out, _, _ = Z.deflate_all(L, data, level=-1, wbits=15, dictionary=dic)
+    d = zlib.decompressobj(zdict=dic)
+    assert d.decompress(out) == data
