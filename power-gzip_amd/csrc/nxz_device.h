@@ -46,6 +46,7 @@ int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t
 int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n, uint32_t final_index,
 			   uint64_t *offsets, uint8_t *packed, hipStream_t stream);
+int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);   /* items: { src, dst, uint64 bytes } */
 size_t nxz_inflate_lanes_workspace(size_t n);
 int nxz_launch_pack_members(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n,
 			    uint64_t *offsets, uint8_t *packed, hipStream_t stream);

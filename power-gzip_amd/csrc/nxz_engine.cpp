@@ -19,6 +19,7 @@
 #include <unistd.h>
 #include <condition_variable>
 #include <map>
+#include <deque>
 #include <mutex>
 #include <vector>
 #include "nxz_device.h"
@@ -49,8 +50,6 @@ struct Slot {
 	nxz_batch_dht_t *h_dht = nullptr, *d_dht = nullptr;
 	nxz_dht_prepared_t *d_prep = nullptr;
 	uint32_t *h_cnt = nullptr, *d_cnt = nullptr;
-	uint8_t *d_tok = nullptr;                       // one job's tokens between the LZ77 and the entropy kernel
-	uint16_t *d_cand2 = nullptr;                    // LZ77 scratch (one workgroup's worth is used)
 	bool busy = false;
 };
 
@@ -100,6 +99,24 @@ struct nxz_ctx {
 		size_t n = 0; uint64_t bytes = 0;
 	} lanes[2];
 	std::mutex lanes_mtx;
+	// nxu_run_job, compress: callers that arrive while a launch is in flight are gathered and go out
+	// together as one launch of each kernel (run_compress / round_run)
+	struct Round {
+		hipStream_t stream = nullptr;
+		nxz_batch_job_t *h_jobs = nullptr;        // pinned, read by the kernels in place
+		nxz_batch_result_t *h_res = nullptr;      // pinned, written by the kernels in place
+		nxz_batch_dht_t *h_dht = nullptr;
+		uint32_t *h_cnt = nullptr;
+		nxz_dht_prepared_t *d_prep = nullptr;
+		uint8_t *d_tok = nullptr;
+		uint16_t *d_cand2 = nullptr;
+		uint8_t *d_src = nullptr;                 // the sources, brought over by one copy kernel (two kernels read them)
+		struct Item { const uint8_t *src; uint8_t *dst; uint64_t bytes; } *h_items = nullptr;
+		bool busy = false, ready = false;
+	} rounds[4];
+	std::mutex qm;
+	std::condition_variable qcv;
+	std::deque<struct CompressReq *> q;
 	uint32_t *d_job_counters = nullptr;           // job counters of the batched deflate launches (ring)
 	unsigned next_counter = 0;
 	// measurement aid (nxz_ctx_stage_timing): events around every kernel of the compress batches
@@ -141,8 +158,6 @@ static bool slot_init(Slot &s)
 	HIPCHK(hipMalloc((void **)&s.d_prep, sizeof(nxz_dht_prepared_t)), return false);
 	HIPCHK(hipHostMalloc((void **)&s.h_cnt, 316 * 4), return false);
 	HIPCHK(hipMalloc((void **)&s.d_cnt, 316 * 4), return false);
-	HIPCHK(hipMalloc((void **)&s.d_tok, NXZ_TOK_STRIDE), return false);
-	HIPCHK(hipMalloc((void **)&s.d_cand2, nxz_lz77_cand2_bytes() / NXZ_LZ77_MAX_GRID), return false);
 	return true;
 }
 
@@ -152,7 +167,7 @@ static void slot_free(Slot &s)
 	(void)hipHostFree(s.h_in); (void)hipHostFree(s.h_out); (void)hipFree(s.d_in); (void)hipFree(s.d_out);
 	(void)hipHostFree(s.h_job); (void)hipFree(s.d_job); (void)hipHostFree(s.h_res); (void)hipFree(s.d_res);
 	(void)hipHostFree(s.h_dht); (void)hipFree(s.d_dht); (void)hipFree(s.d_prep);
-	(void)hipHostFree(s.h_cnt); (void)hipFree(s.d_cnt); (void)hipFree(s.d_tok); (void)hipFree(s.d_cand2);
+	(void)hipHostFree(s.h_cnt); (void)hipFree(s.d_cnt);
 	s = Slot();
 }
 
@@ -217,6 +232,12 @@ extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 		(void)hipHostFree(l.h_jobs); (void)hipHostFree(l.h_res); (void)hipHostFree(l.h_total);
 		(void)hipStreamDestroy(l.stream);
 		l = nxz_ctx::HostLane();
+	}
+	for (auto &r : c->rounds) {
+		if (r.stream) { (void)hipStreamSynchronize(r.stream); (void)hipStreamDestroy(r.stream); }
+		(void)hipHostFree(r.h_jobs); (void)hipHostFree(r.h_res); (void)hipHostFree(r.h_dht); (void)hipHostFree(r.h_cnt);
+		(void)hipFree(r.d_prep); (void)hipFree(r.d_tok); (void)hipFree(r.d_cand2); (void)hipFree(r.d_src); (void)hipHostFree(r.h_items);
+		r = nxz_ctx::Round();
 	}
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	g_ctx[c->device] = nullptr;
@@ -737,6 +758,131 @@ static void put_cksums(nxz_crb_cpb_t *j, uint32_t crc, uint32_t adler)
 	j->cpb.out_crc_le = htole32(crc);
 }
 
+// NXZ_JOB_TRACE=1: where the time of the single-job interface goes, printed when the process ends
+#include <atomic>
+#include <chrono>
+static struct JobTrace {
+	std::atomic<uint64_t> jobs{0}, rounds{0}, ns_acquire{0}, ns_gather{0}, ns_wait{0}, ns_finish{0}, ns_issue{0}, ns_sync{0};
+	bool on = false;
+	JobTrace() { on = getenv("NXZ_JOB_TRACE") != nullptr; }
+	~JobTrace()
+	{
+		if (!on || !jobs) return;
+		const double j = (double)jobs, r = (double)(rounds ? rounds.load() : 1);
+		fprintf(stderr, "nxz job trace: %llu compress jobs in %llu rounds (%.1f per round); per job: slot %.1f us, gather %.1f us, in the round %.1f us, "
+			"scatter %.1f us; per round: launch calls %.1f us, synchronise %.1f us\n", (unsigned long long)jobs, (unsigned long long)rounds, j / r,
+			ns_acquire / j * 1e-3, ns_gather / j * 1e-3, ns_wait / j * 1e-3, ns_finish / j * 1e-3, ns_issue / r * 1e-3, ns_sync / r * 1e-3);
+	}
+} g_trace;
+static inline uint64_t trace_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// One caller's compress job on its way through a round.
+struct CompressReq {
+	uint32_t fc = 0;
+	nxz_batch_job_t job;                  // src / dst: the caller's slot, pinned host memory the kernels work on in place
+	const nxz_cpb_t *cpb = nullptr;       // the caller's table (DHT function codes)
+	nxz_batch_result_t res;
+	uint32_t cnt[316];
+	int rc = 0;
+	bool taken = false, done = false;
+};
+#define ROUND_MAX 32u
+
+static bool round_init(nxz_ctx::Round &r)
+{
+	if (r.ready) return true;
+	HIPCHK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking), return false);
+	HIPCHK(hipHostMalloc((void **)&r.h_jobs, ROUND_MAX * sizeof(nxz_batch_job_t)), return false);
+	HIPCHK(hipHostMalloc((void **)&r.h_res, ROUND_MAX * sizeof(nxz_batch_result_t)), return false);
+	HIPCHK(hipHostMalloc((void **)&r.h_dht, ROUND_MAX * sizeof(nxz_batch_dht_t)), return false);
+	HIPCHK(hipHostMalloc((void **)&r.h_cnt, ROUND_MAX * 316 * sizeof(uint32_t)), return false);
+	HIPCHK(hipMalloc((void **)&r.d_prep, ROUND_MAX * sizeof(nxz_dht_prepared_t)), return false);
+	HIPCHK(hipMalloc((void **)&r.d_tok, (size_t)ROUND_MAX * NXZ_TOK_STRIDE), return false);
+	HIPCHK(hipMalloc((void **)&r.d_cand2, nxz_lz77_cand2_bytes() / NXZ_LZ77_MAX_GRID * ROUND_MAX), return false);
+	HIPCHK(hipMalloc((void **)&r.d_src, (size_t)ROUND_MAX * SUBBLOCK), return false);
+	HIPCHK(hipHostMalloc((void **)&r.h_items, ROUND_MAX * sizeof(nxz_ctx::Round::Item)), return false);
+	r.ready = true;
+	return true;
+}
+
+// The jobs of one round: a launch of each kernel for all of them.  Targets, job, table and result
+// records are pinned host memory that the kernels read and write in place; the sources, which two
+// kernels read (the second one in small pieces), are first brought over by a copy kernel (one
+// workgroup per job, 16 bytes per lane straight from the callers' pinned staging).  No copy to
+// queue, one synchronisation per round.
+static int round_run(nxz_ctx *c, nxz_ctx::Round &R, std::vector<CompressReq *> &v)
+{
+	const uint32_t fc = v[0]->fc;
+	const size_t n = v.size();
+	const bool dht = nxz_fc_is_dht(fc), count = nxz_fc_has_count(fc), gen = nxz_fc_is_dhtgen(fc);
+	(void)hipSetDevice(c->device);
+	const uint64_t t0 = g_trace.on ? trace_ns() : 0;
+	for (size_t k = 0; k < n; k++) {
+		R.h_jobs[k] = v[k]->job;
+		R.h_jobs[k].dht_index = (uint32_t)k;
+		R.h_items[k].src = v[k]->job.src; R.h_items[k].dst = R.d_src + k * (size_t)SUBBLOCK; R.h_items[k].bytes = v[k]->job.src_len;
+		R.h_jobs[k].src = R.h_items[k].dst;
+		if (dht && !gen) {
+			R.h_dht[k].dhtlen = nxz_in_dhtlen(v[k]->cpb);
+			memcpy(R.h_dht[k].dht, v[k]->cpb->in_dht, NXZ_DHT_MAXSZ);
+		}
+	}
+	static const bool each = getenv("NXZ_JOB_TRACE") && atoi(getenv("NXZ_JOB_TRACE")) > 1;   // 2: time every kernel on its own
+	static std::atomic<uint64_t> kns[4];
+	auto lap = [&](int i, uint64_t from) { if (each) { (void)hipStreamSynchronize(R.stream); kns[i] += trace_ns() - from; } };
+	uint64_t k0 = each ? trace_ns() : 0;
+	if (nxz_launch_copy_items(R.h_items, (uint32_t)n, R.stream)) return -EIO;
+	if (dht && !gen && nxz_launch_dht_prepare(R.h_dht, n, R.d_prep, R.stream)) return -EIO;
+	lap(0, k0); k0 = each ? trace_ns() : 0;
+	if (nxz_launch_lz77(count || gen, R.h_jobs, n, R.d_tok, R.d_cand2, R.h_res, R.h_cnt, nullptr, R.stream)) return -EIO;
+	lap(1, k0); k0 = each ? trace_ns() : 0;
+	if (gen && nxz_launch_dhtgen(R.h_cnt, n, R.d_prep, nullptr, R.stream)) return -EIO;
+	lap(2, k0); k0 = each ? trace_ns() : 0;
+	if (nxz_launch_encode(dht, gen, R.h_jobs, n, R.d_tok, R.d_prep, R.h_res, R.stream)) return -EIO;
+	lap(3, k0);
+	if (each && (g_trace.rounds & 255) == 255)
+		fprintf(stderr, "nxz round kernels (sum so far, us): dht_prepare %.0f lz77 %.0f dhtgen %.0f encode %.0f over %llu rounds\n",
+			kns[0] * 1e-3, kns[1] * 1e-3, kns[2] * 1e-3, kns[3] * 1e-3, (unsigned long long)g_trace.rounds + 1);
+	const uint64_t t1 = g_trace.on ? trace_ns() : 0;
+	HIPCHK(hipStreamSynchronize(R.stream), return -EIO);
+	if (g_trace.on) { g_trace.rounds++; g_trace.ns_issue += t1 - t0; g_trace.ns_sync += trace_ns() - t1; }
+	for (size_t k = 0; k < n; k++) {
+		v[k]->res = R.h_res[k];
+		if (count) memcpy(v[k]->cnt, R.h_cnt + k * 316, sizeof(v[k]->cnt));
+	}
+	return 0;
+}
+
+// Queue the job; whoever finds a free round takes the job at the head of the queue and every queued
+// job with the same function code, runs them, and wakes their owners.  The first caller goes out
+// alone at once; those that arrive while it is in flight form the next round.
+static int round_submit(nxz_ctx *c, CompressReq *me)
+{
+	std::unique_lock<std::mutex> lk(c->qm);
+	c->q.push_back(me);
+	while (!me->done) {
+		nxz_ctx::Round *R = nullptr;
+		if (!me->taken) for (auto &r : c->rounds) if (!r.busy) { R = &r; break; }
+		if (!R) { c->qcv.wait(lk); continue; }
+		R->busy = true;
+		std::vector<CompressReq *> v;
+		const uint32_t fc = c->q.front()->fc;
+		for (auto it = c->q.begin(); it != c->q.end() && v.size() < ROUND_MAX; ) {
+			if ((*it)->fc == fc) { (*it)->taken = true; v.push_back(*it); it = c->q.erase(it); }
+			else ++it;
+		}
+		lk.unlock();
+		(void)hipSetDevice(c->device);
+		int rc = round_init(*R) ? round_run(c, *R, v) : -ENOMEM;
+		if (rc && R->stream) (void)hipStreamSynchronize(R->stream);   // nothing of a failed round may still be in flight
+		lk.lock();
+		for (auto *r : v) { r->rc = rc; r->done = true; }
+		R->busy = false;
+		c->qcv.notify_all();
+	}
+	return me->rc;
+}
+
 static int run_compress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 {
 	uint32_t srctotal = nxz_dde_bytes(&j->crb.source);
@@ -748,38 +894,27 @@ static int run_compress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 	uint32_t n = srctotal - hist;
 	bool partial = false;
 	if (h + n > SUBBLOCK) { n = SUBBLOCK - h; partial = true; }     // byte-count limit -> CC 3 partial
+	const uint64_t t0 = g_trace.on ? trace_ns() : 0;
 	uint32_t got = dde_gather(&j->crb.source, skip, s->h_in, h + n);
 	if (got < h) { h = got; n = 0; } else n = got - h;
 	uint32_t cap = dde_capacity(&j->crb.target);
 	uint32_t dcap = cap < OUT_CAP ? cap & ~3u : OUT_CAP;
 	if (cap < 4) dcap = 0;
-	bool dht = nxz_fc_is_dht(fc), count = nxz_fc_has_count(fc);
+	const bool count = nxz_fc_has_count(fc);
 
-	nxz_batch_job_t *bj = s->h_job;
-	bj->src = s->d_in; bj->dst = s->d_out; bj->src_len = h + n; bj->hist_len = h;
-	bj->dst_cap = dcap; bj->in_crc = nxz_in_crc(&j->cpb); bj->in_adler = nxz_in_adler(&j->cpb); bj->dht_index = 0;
-	HIPCHK(hipMemcpyAsync(s->d_in, s->h_in, h + n, hipMemcpyHostToDevice, s->stream), return -EIO);
-	HIPCHK(hipMemcpyAsync(s->d_job, bj, sizeof(*bj), hipMemcpyHostToDevice, s->stream), return -EIO);
-	if (dht && !nxz_fc_is_dhtgen(fc)) {
-		uint32_t dhtlen = nxz_in_dhtlen(&j->cpb);
-		s->h_dht->dhtlen = dhtlen;
-		memcpy(s->h_dht->dht, j->cpb.in_dht, NXZ_DHT_MAXSZ);
-		HIPCHK(hipMemcpyAsync(s->d_dht, s->h_dht, sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s->stream), return -EIO);
-		if (nxz_launch_dht_prepare(s->d_dht, 1, s->d_prep, s->stream)) return -EIO;
-	}
-	const bool gen = nxz_fc_is_dhtgen(fc);
-	if (nxz_launch_lz77(count || gen, s->d_job, 1, s->d_tok, s->d_cand2, s->d_res, s->d_cnt, nullptr, s->stream)) return -EIO;
-	if (gen && nxz_launch_dhtgen(s->d_cnt, 1, s->d_prep, nullptr, s->stream)) return -EIO;
-	if (nxz_launch_encode(dht, 0, s->d_job, 1, s->d_tok, s->d_prep, s->d_res, s->stream)) return -EIO;
-	HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
-	if (count) HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, 316 * 4, hipMemcpyDeviceToHost, s->stream), return -EIO);
-	HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
+	CompressReq req;
+	req.fc = fc;
+	req.cpb = &j->cpb;
+	memset(&req.job, 0, sizeof(req.job));
+	req.job.src = s->h_in; req.job.dst = s->h_out; req.job.src_len = h + n; req.job.hist_len = h;
+	req.job.dst_cap = dcap; req.job.in_crc = nxz_in_crc(&j->cpb); req.job.in_adler = nxz_in_adler(&j->cpb);
+	const uint64_t t1 = g_trace.on ? trace_ns() : 0;
+	int rc = round_submit(c, &req);
+	if (rc) return rc;
+	const uint64_t t2 = g_trace.on ? trace_ns() : 0;
 
-	nxz_batch_result_t r = *s->h_res;
+	const nxz_batch_result_t r = req.res;
 	uint32_t cc = r.cc, ce = 0, tpbc = 0;
-	if (dht && cc == 0) {
-		// status of the table parse travels in the prepared table; a bad table shows as missing codes
-	}
 	if (cc == NXZ_CC_TARGET_SPACE || cc == NXZ_CC_MISSING_CODE || cc == NXZ_CC_INVALID_DHT) {
 		ce = NXZ_CE_TERMINATE;
 	} else {
@@ -787,14 +922,12 @@ static int run_compress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 		if (tpbc > cap) { cc = NXZ_CC_TARGET_SPACE; ce = NXZ_CE_TERMINATE; tpbc = 0; }
 	}
 	if (ce != NXZ_CE_TERMINATE) {
-		HIPCHK(hipMemcpyAsync(s->h_out, s->d_out, tpbc, hipMemcpyDeviceToHost, s->stream), return -EIO);
-		HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
 		dde_scatter(&j->crb.target, s->h_out, tpbc);
 		nxz_putf(&j->cpb.out_w2_be, 16, 3, r.tebc);
 		put_cksums(j, r.crc, r.adler);
 		uint32_t spbc = skip + r.spbc;
 		if (count) {
-			for (int i = 0; i < 316; i++) nxz_wr32(&j->cpb.u.out_lzcount_be[i], s->h_cnt[i]);
+			for (int i = 0; i < 316; i++) nxz_wr32(&j->cpb.u.out_lzcount_be[i], req.cnt[i]);
 			nxz_wr32(&j->cpb.out_spbc_with_count_be, spbc);
 		} else {
 			nxz_wr32(&j->cpb.u.out_spbc_be, spbc);
@@ -802,6 +935,7 @@ static int run_compress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 		if (cc == 0 && partial) { cc = NXZ_CC_DATA_LENGTH; ce = NXZ_CE_PARTIAL | NXZ_CE_TPBC_VALID; }
 	}
 	nxz_csb_complete(j, cc, ce, tpbc);
+	if (g_trace.on) { g_trace.jobs++; g_trace.ns_gather += t1 - t0; g_trace.ns_wait += t2 - t1; g_trace.ns_finish += trace_ns() - t2; }
 	return 0;
 }
 
@@ -896,9 +1030,12 @@ extern "C" int nxu_run_job(nxz_crb_cpb_t *j, void *handle)
 	if (!j) return -EINVAL;
 	if (!c || forked_child()) { nxz_csb_complete(j, NXZ_CC_NO_HW, NXZ_CE_TERMINATE, 0); return 0; }
 	uint32_t fc = nxz_fc(j);
+	const uint64_t ta = g_trace.on ? trace_ns() : 0;
 	Slot *s = slot_acquire(c);
 	if (!s) { nxz_csb_complete(j, NXZ_CC_NO_HW, NXZ_CE_TERMINATE, 0); return 0; }
-	(void)hipSetDevice(c->device);
+	if (g_trace.on) g_trace.ns_acquire += trace_ns() - ta;
+	const bool comp = nxz_fc_is_compress(fc) && fc != NXZ_FC_WRAP;
+	if (!comp) (void)hipSetDevice(c->device);                 // (compress jobs: the thread that runs the round does)
 	int rc;
 	if (fc == NXZ_FC_WRAP) rc = run_wrap(c, s, j);
 	else if (nxz_fc_is_compress(fc) && !(fc & 1) && !(fc & ~0x2eu) && (!nxz_fc_is_dhtgen(fc) || nxz_fc_is_dht(fc))) rc = run_compress(c, s, j, fc);

@@ -17,103 +17,135 @@
 
 namespace nxz {
 
-struct BitR {
-	const uint8_t *p; uint32_t nbits, pos;
-	__device__ int get(int n) {
-		if (pos + n > nbits) return -1;
-		int v = 0;
-		for (int i = 0; i < n; i++, pos++) v |= ((p[pos >> 3] >> (pos & 7)) & 1) << i;
-		return v;
-	}
-};
-
-__device__ bool canon(const uint8_t *len, uint16_t *code, int n)
+// canonical codes of one alphabet by ranks: symbol i = row * 64 + lane; code = first code of its
+// length + the number of lower symbols of that length (RFC 1951 3.2.2).  out[i] = bit-reversed
+// code | length << 16, 0 for an absent symbol.  Returns false when the lengths oversubscribe.
+template <int ROWS>
+__device__ bool canon_wave(const uint8_t *len, uint32_t n, uint32_t *__restrict__ out, uint32_t n_out)
 {
-	uint32_t cnt[16], next[16], c = 0, kraft = 0;
-	for (int b = 0; b < 16; b++) cnt[b] = 0;
-	for (int i = 0; i < n; i++) cnt[len[i]]++;
-	cnt[0] = 0;
-	for (int b = 1; b <= 15; b++) {
-		c = (c + cnt[b - 1]) << 1;
-		next[b] = c;
-		kraft += cnt[b] << (15 - b);
+	const uint32_t lane = threadIdx.x;
+	const uint64_t below = (1ull << lane) - 1;
+	uint32_t l[ROWS], code[ROWS];
+#pragma unroll
+	for (int r = 0; r < ROWS; r++) { const uint32_t i = r * 64 + lane; l[r] = i < n ? len[i] : 0; code[r] = 0; }
+	uint32_t c = 0, prevcnt = 0, kraft = 0;
+	for (uint32_t b = 1; b <= 15; b++) {
+		c = (c + prevcnt) << 1;
+		uint32_t run = 0;
+#pragma unroll
+		for (int r = 0; r < ROWS; r++) {
+			const uint64_t m = __ballot(l[r] == b);
+			if (l[r] == b) code[r] = c + run + (uint32_t)__popcll(m & below);
+			run += (uint32_t)__popcll(m);
+		}
+		prevcnt = run;
+		kraft += run << (15 - b);
 	}
-	for (int i = 0; i < n; i++) {
-		uint32_t l = len[i];
-		code[i] = l ? (uint16_t)(__builtin_bitreverse32(next[l]++) >> (32 - l)) : 0;
+#pragma unroll
+	for (int r = 0; r < ROWS; r++) {
+		const uint32_t i = r * 64 + lane;
+		if (i < n_out) out[i] = l[r] ? ((__builtin_bitreverse32(code[r]) >> (32 - l[r])) | (l[r] << 16)) : 0;
 	}
 	return kraft <= (1u << 15);
 }
 
-__global__ void dht_prepare_kernel(const nxz_batch_dht_t *__restrict__ in, size_t n, nxz_dht_prepared_t *__restrict__ out)
+// One wavefront per table.  The bit string is taken into LDS in one go (it may sit in pinned host
+// memory: nxu_run_job's rounds hand it over in place), the code-length code becomes a 128-entry
+// look-up held in two registers per lane, and the run-length coded lengths are decoded by all lanes
+// in step (everything in that loop is wave-uniform: the look-up is a v_readlane).
+__global__ __launch_bounds__(64) void dht_prepare_kernel(const nxz_batch_dht_t *__restrict__ in, size_t n, nxz_dht_prepared_t *__restrict__ out)
 {
-	size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	__shared__ uint32_t bits[80];
+	__shared__ uint8_t lens[320 + 8];
+	__shared__ uint8_t cl_len[32];
+	const uint32_t lane = threadIdx.x;
+	const size_t idx = blockIdx.x;
 	if (idx >= n) return;
 	const nxz_batch_dht_t *t = &in[idx];
 	nxz_dht_prepared_t *o = &out[idx];
-	const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
-	uint8_t cl_len[19], lens[288 + 32];
-	uint16_t cl_code[19], codes[288];
-	uint32_t dhtlen = t->dhtlen;
+	const uint32_t dhtlen = t->dhtlen;
 	bool ok = dhtlen <= NXZ_DHT_MAXSZ * 8;
-	BitR b{t->dht, ok ? dhtlen : 0, 0};
-	int hlit = 0, hdist = 0, hclen = 0;
-
-	o->dhtlen = dhtlen;
-	for (int i = 0; i < 74; i++) {
+	if (lane == 0) o->dhtlen = dhtlen;
+	for (uint32_t i = lane; i < 80; i += 64) {
 		uint32_t w = 0;
-		for (int k = 0; k < 4; k++) {
-			uint32_t byte = (uint32_t)i * 4 + k;
-			uint32_t v = (ok && byte * 8 < dhtlen) ? t->dht[byte] : 0;
-			if (ok && byte * 8 + 8 > dhtlen && byte * 8 < dhtlen) v &= (1u << (dhtlen - byte * 8)) - 1;
-			w |= v << (8 * k);
+		const uint32_t bit0 = i * 32;
+		if (ok && i < 73 && bit0 < dhtlen) {
+			w = ((const uint32_t *)t->dht)[i];
+			if (bit0 + 32 > dhtlen) w &= (1u << (dhtlen - bit0)) - 1;
 		}
-		o->dhtw[i] = w;
+		bits[i] = w;
+		if (i < 74) o->dhtw[i] = w;
 	}
-	for (int i = 0; i < 19; i++) cl_len[i] = 0;
-	for (int i = 0; i < 320; i++) lens[i] = 0;
+	for (uint32_t i = lane; i < 320; i += 64) lens[i] = 0;
+	if (lane < 32) cl_len[lane] = 0;
+	__syncthreads();
+	auto peek = [&](uint32_t pos, uint32_t nb) -> uint32_t {                       // nb <= 25, pos + nb within the padded string
+		const uint32_t w = pos >> 5, sh = pos & 31;
+		const uint64_t v = (uint64_t)bits[w] | ((uint64_t)bits[w + 1] << 32);
+		return (uint32_t)(v >> sh) & ((1u << nb) - 1);
+	};
+	uint32_t hlit = 0, hdist = 0, hclen = 0;
 	if (ok) {
-		hlit = b.get(5); hdist = b.get(5); hclen = b.get(4);
-		ok = hlit >= 0 && hdist >= 0 && hclen >= 0;
-		hlit += 257; hdist += 1; hclen += 4;
-		ok = ok && hlit <= 286 && hdist <= 30;
+		ok = dhtlen >= 14;
+		const uint32_t v = peek(0, 14);
+		hlit = (v & 31) + 257; hdist = ((v >> 5) & 31) + 1; hclen = (v >> 10) + 4;
+		ok = ok && hlit <= 286 && hdist <= 30 && 14 + 3 * hclen <= dhtlen;
 	}
-	for (int i = 0; ok && i < hclen; i++) {
-		int v = b.get(3);
-		if (v < 0) ok = false; else cl_len[order[i]] = (uint8_t)v;
+	if (ok && lane < hclen) {
+		const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+		cl_len[order[lane]] = (uint8_t)peek(14 + 3 * lane, 3);
 	}
-	ok = ok && canon(cl_len, cl_code, 19);
-	int cnt = 0, prev = 0;
-	while (ok && cnt < hlit + hdist) {
-		int sym = -1, code = 0;
-		for (int len = 1; len <= 7 && sym < 0 && ok; len++) {
-			int bit = b.get(1);
-			if (bit < 0) { ok = false; break; }
-			code |= bit << (len - 1);
-			for (int i = 0; i < 19; i++)
-				if (cl_len[i] == len && cl_code[i] == code) { sym = i; break; }
-		}
-		if (!ok || sym < 0) { ok = false; break; }
-		if (sym < 16) { lens[cnt++] = (uint8_t)sym; prev = sym; }
-		else {
-			int rep, val = 0;
-			if (sym == 16) { if (cnt == 0) { ok = false; break; } rep = b.get(2); if (rep < 0) { ok = false; break; } rep += 3; val = prev; }
-			else if (sym == 17) { rep = b.get(3); if (rep < 0) { ok = false; break; } rep += 3; }
-			else { rep = b.get(7); if (rep < 0) { ok = false; break; } rep += 11; }
-			if (cnt + rep > hlit + hdist) { ok = false; break; }
-			while (rep--) lens[cnt++] = (uint8_t)val;
-			if (sym != 16) prev = 0;
+	__syncthreads();
+	// code-length code: canonical codes (19 symbols, every lane does all of it), then the look-up
+	// entry of peek values `lane` and `lane + 64`: symbol | length << 5, 0xff = no code
+	uint32_t tlo = 0xff, thi = 0xff;
+	{
+		uint32_t cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, next[8], c = 0, kraft = 0;
+		for (int i = 0; i < 19; i++) cnt[cl_len[i] & 7]++;
+		cnt[0] = 0;
+		for (int b = 1; b <= 7; b++) { c = (c + cnt[b - 1]) << 1; next[b] = c; kraft += cnt[b] << (7 - b); }
+		ok = ok && kraft <= 128;
+		for (int i = 0; i < 19; i++) {
+			const uint32_t l = cl_len[i] & 7;
+			if (!l) continue;
+			const uint32_t code = __builtin_bitreverse32(next[l]++) >> (32 - l), mask = (1u << l) - 1;
+			if ((lane & mask) == code) tlo = (uint32_t)i | (l << 5);
+			if (((lane + 64) & mask) == code) thi = (uint32_t)i | (l << 5);
 		}
 	}
-	ok = ok && b.pos == dhtlen;
-	uint8_t ll_len[288], d_len[32];
-	for (int i = 0; i < 288; i++) ll_len[i] = (ok && i < hlit) ? lens[i] : 0;
-	for (int i = 0; i < 32; i++) d_len[i] = (ok && i < hdist) ? lens[hlit + i] : 0;
-	ok = canon(ll_len, codes, 288) && ok;
-	for (int i = 0; i < 288; i++) o->ll[i] = codes[i] | ((uint32_t)ll_len[i] << 16);
-	ok = canon(d_len, codes, 32) && ok;
-	for (int i = 0; i < 32; i++) o->d[i] = codes[i] | ((uint32_t)d_len[i] << 16);
-	o->status = ok ? 0 : NXZ_CC_INVALID_DHT;
+	const uint32_t total = hlit + hdist;
+	uint32_t pos = 14 + 3 * hclen, cnt = 0, prev = 0;
+	while (ok && cnt < total) {
+		const uint32_t v = __builtin_amdgcn_readfirstlane(peek(pos, 14));
+		const uint32_t e = (v & 64) ? __builtin_amdgcn_readlane(thi, v & 63) : __builtin_amdgcn_readlane(tlo, v & 63);
+		if (e == 0xff) { ok = false; break; }
+		const uint32_t sym = e & 31, l = e >> 5;
+		pos += l;
+		if (pos > dhtlen) { ok = false; break; }
+		const uint32_t x = v >> l;                                                 // the extra bits, if any
+		if (sym < 16) {
+			if (lane == 0) lens[cnt] = (uint8_t)sym;
+			cnt++; prev = sym;
+			continue;
+		}
+		uint32_t rep, val = 0, nb;
+		if (sym == 16) { if (cnt == 0) { ok = false; break; } nb = 2; rep = (x & 3) + 3; val = prev; }
+		else if (sym == 17) { nb = 3; rep = (x & 7) + 3; }
+		else { nb = 7; rep = (x & 127) + 11; }
+		pos += nb;
+		if (pos > dhtlen || cnt + rep > total) { ok = false; break; }
+		for (uint32_t k = lane; k < rep; k += 64) lens[cnt + k] = (uint8_t)val;
+		cnt += rep;
+		if (sym != 16) prev = 0;
+	}
+	ok = ok && pos == dhtlen;
+	__syncthreads();
+	// literal/length and distance alphabets: lengths beyond hlit / hdist (and of a bad table) are zero
+	if (!ok) for (uint32_t i = lane; i < 320; i += 64) lens[i] = 0;
+	__syncthreads();
+	const bool okl = canon_wave<5>(lens, ok ? hlit : 0, o->ll, 288);
+	const bool okd = canon_wave<1>(lens + hlit, ok ? hdist : 0, o->d, 32);
+	if (lane == 0) o->status = ok && okl && okd ? 0 : NXZ_CC_INVALID_DHT;
 }
 
 // ---- wrap: one 256-thread workgroup per job ----
@@ -421,7 +453,7 @@ extern "C" int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_bat
 extern "C" int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_dht_prepared_t *out, hipStream_t stream)
 {
 	if (!n) return 0;
-	hipLaunchKernelGGL(nxz::dht_prepare_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, dht, n, out);
+	hipLaunchKernelGGL(nxz::dht_prepare_kernel, dim3((unsigned)n), dim3(64), 0, stream, dht, n, out);
 	return (int)hipGetLastError();
 }
 

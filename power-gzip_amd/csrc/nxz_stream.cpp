@@ -21,6 +21,7 @@
 #include <vector>
 #include <mutex>
 #include <chrono>
+#include <atomic>
 #include "nxz_host.h"
 #include "../../include/nxz_config.h"
 #include "../../include/nxz_wire.h"
@@ -321,6 +322,18 @@ int deflate_stored(Deflate *s, uint32_t n, bool finish)
 }
 
 // one engine job = one deflate block (nx_compress_block, lib/nx_deflate.c:1209-1412)
+// Dynamic blocks: the reference makes each job's table on the host from the symbol counts of the
+// job before (nx_deflate.c:1030-1052, nx_dht.c), because its engine cannot; this engine can make the
+// exact table of the job itself (NXZ_FC_COMPRESS_*DHTGEN), which is both smaller output and one
+// table parse less per job.  NXZ_DEVICE_DHT=0 keeps the reference's scheme (cached / canned tables,
+// nxz_dht.cpp); the CPU model of the test suite always does.
+extern "C" int nxz_deflate_host(nxz_ctx_t *, int, const uint8_t *, size_t, int, uint8_t *, size_t, size_t *, uint32_t *, uint32_t *) __attribute__((weak));
+bool device_dht()
+{
+	static const bool on = nxz_deflate_host != nullptr && !(getenv("NXZ_DEVICE_DHT") && atoi(getenv("NXZ_DEVICE_DHT")) == 0);
+	return on;
+}
+
 int deflate_job(Deflate *s, int flush)
 {
 	nxz_crb_cpb_t *j = s->jb.job;
@@ -328,13 +341,13 @@ int deflate_job(Deflate *s, int flush)
 	if (s->tail_n) s->stored_header(0, 0);            // the engine starts blocks on a byte boundary
 	uint32_t histuse, n = deflate_source(s, j, 0, &histuse);
 	if (n == 0) return Z_OK;
-	const bool dynamic = s->strategy != Z_FIXED;
-	uint32_t fc = dynamic ? NXZ_FC_COMPRESS_RESUME_DHT_COUNT : NXZ_FC_COMPRESS_RESUME_FHT;
+	const bool dynamic = s->strategy != Z_FIXED, host_table = dynamic && !device_dht();
+	uint32_t fc = host_table ? NXZ_FC_COMPRESS_RESUME_DHT_COUNT : dynamic ? NXZ_FC_COMPRESS_RESUME_DHTGEN : NXZ_FC_COMPRESS_RESUME_FHT;
 	nxz_set_fc(j, fc);
 	nxz_set_in_histlen(&j->cpb, histuse / 16);
 	nxz_set_in_crc(&j->cpb, s->crc);
 	nxz_set_in_adler(&j->cpb, s->adler);
-	if (dynamic) {
+	if (host_table) {
 		uint32_t dhtlen;
 		nxz_dht_lookup(s->dht, s->have_counts ? s->counts : nullptr, s->last_job_bytes, j->cpb.in_dht, &dhtlen);
 		nxz_set_in_dhtlen(&j->cpb, dhtlen);
@@ -342,7 +355,7 @@ int deflate_job(Deflate *s, int flush)
 	s->jobout.resize((size_t)n * 2 + 1024);
 	nxz_dde_set_direct(&j->crb.target, s->jobout.data(), (uint32_t)s->jobout.size());
 	int cc = s->eng.submit(j);
-	uint32_t spbc = dynamic ? nxz_rd32(&j->cpb.out_spbc_with_count_be) : nxz_rd32(&j->cpb.u.out_spbc_be);
+	uint32_t spbc = host_table ? nxz_rd32(&j->cpb.out_spbc_with_count_be) : nxz_rd32(&j->cpb.u.out_spbc_be);
 	uint32_t tpbc = nxz_csb_tpbc(j);
 	if (cc == NXZ_CC_TPBC_GT_SPBC || ((cc == NXZ_CC_OK || cc == NXZ_CC_DATA_LENGTH) && tpbc + histuse > spbc)) {
 		// did not shrink: re-emit the same source as stored blocks (:1274-1282, :1377-1389)
@@ -353,7 +366,7 @@ int deflate_job(Deflate *s, int flush)
 	if (spbc <= histuse) return Z_OK;                 // no progress (:981-986)
 	uint32_t took = spbc - histuse, tebc = nxz_out_tebc(&j->cpb);
 	s->crc = nxz_out_crc(&j->cpb); s->adler = nxz_out_adler(&j->cpb); s->cksum_set = true;
-	if (dynamic) {
+	if (host_table) {
 		for (int i = 0; i < 316; i++) s->counts[i] = nxz_rd32(&j->cpb.u.out_lzcount_be[i]);
 		s->have_counts = true; s->last_job_bytes = took;
 	}
@@ -1084,12 +1097,27 @@ out:
 // ---------------------------------------------------------------------------
 // one-shot (lib/nx_compress.c:26-75, lib/nx_uncompr.c:32-88)
 // ---------------------------------------------------------------------------
+namespace {
+struct ApiTrace {
+	std::atomic<uint64_t> calls{0}, ns_init{0}, ns_body{0}, ns_end{0};
+	bool on = getenv("NXZ_API_TRACE") != nullptr;
+	static uint64_t now() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+	~ApiTrace()
+	{
+		if (on && calls) fprintf(stderr, "nxz api trace: %llu nx_compress2 calls; per call: init %.1f us, deflate %.1f us, end %.1f us\n", (unsigned long long)calls,
+					 ns_init / (double)calls * 1e-3, ns_body / (double)calls * 1e-3, ns_end / (double)calls * 1e-3);
+	}
+} g_api;
+}
+
 extern "C" int nx_compress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen, int level)
 {
 	z_stream st;
 	memset(&st, 0, sizeof(st));
+	const uint64_t t0 = g_api.on ? ApiTrace::now() : 0;
 	int rc = nx_deflateInit(&st, level);
 	if (rc != Z_OK) return rc;
+	const uint64_t t1 = g_api.on ? ApiTrace::now() : 0;
 	const uInt maxu = 1u << 30;
 	uLong remaining = *destLen;
 	*destLen = 0;
@@ -1100,7 +1128,9 @@ extern "C" int nx_compress2(Bytef *dest, uLongf *destLen, const Bytef *source, u
 		rc = nx_deflate(&st, sourceLen ? Z_NO_FLUSH : Z_FINISH);
 	} while (rc == Z_OK);
 	*destLen = st.total_out;
+	const uint64_t t2 = g_api.on ? ApiTrace::now() : 0;
 	nx_deflateEnd(&st);
+	if (g_api.on) { g_api.calls++; g_api.ns_init += t1 - t0; g_api.ns_body += t2 - t1; g_api.ns_end += ApiTrace::now() - t2; }
 	return rc == Z_STREAM_END ? Z_OK : rc;
 }
 

@@ -219,6 +219,7 @@ EXPORT int compress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong so
 	init();
 	nxz_stats_inc("compress");
 	bool nx = nxz_engine_usable() && (g_mode_def == MODE_NX || (g_mode_def == MODE_AUTO && g_engine && sourceLen > 1024));
+	if (nx && slow(g_mode_def, nxz_config()->compress_delay)) nx = false;     // as deflateInit decides (lib/nx_deflate.c:714)
 	if (nx) return nx_compress2(dest, destLen, source, sourceLen, level);
 	return sw.compress2 ? sw.compress2(dest, destLen, source, sourceLen, level) : Z_STREAM_ERROR;
 }
@@ -237,6 +238,7 @@ EXPORT int uncompress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong 
 	init();
 	nxz_stats_inc("uncompress");
 	bool nx = nxz_engine_usable() && (g_mode_inf == MODE_NX || (g_mode_inf == MODE_AUTO && g_engine && *sourceLen > 1024));
+	if (nx && slow(g_mode_inf, nxz_config()->decompress_delay)) nx = false;
 	if (nx) return nx_uncompress2(dest, destLen, source, sourceLen);
 	if (sw.uncompress2) return sw.uncompress2(dest, destLen, source, sourceLen);
 	return sw.uncompress ? sw.uncompress(dest, destLen, source, *sourceLen) : Z_STREAM_ERROR;
