@@ -989,10 +989,17 @@ static int run_decompress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 	}
 	HIPCHK(hipMemcpyAsync(s->d_in, s->h_in, got, hipMemcpyHostToDevice, s->stream), return -EIO);
 	HIPCHK(hipMemcpyAsync(s->d_job, bj, sizeof(*bj), hipMemcpyHostToDevice, s->stream), return -EIO);
+	const uint64_t td0 = g_trace.on ? trace_ns() : 0;
 	if (nxz_launch_inflate(s->d_job, 1, s->d_res, s->d_dht, 1, s->stream)) return -EIO;
 	HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
 	HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
 	nxz_batch_result_t r = *s->h_res;
+	if (g_trace.on) {
+		static std::atomic<uint64_t> dj{0}, dns{0}, din{0}, dout{0};
+		dj++; dns += trace_ns() - td0; din += got; dout += r.tpbc;
+		if ((dj & 255) == 0) fprintf(stderr, "nxz decompress jobs: %llu, kernel+sync %.1f us each, %.0f source bytes in, %.0f bytes out each\n",
+					     (unsigned long long)dj, dns / (double)dj * 1e-3, din / (double)dj, dout / (double)dj);
+	}
 	uint32_t cc = r.cc, ce = 0, tpbc = 0;
 	if (cc != 0 && cc != NXZ_CC_DATA_LENGTH) {
 		ce = NXZ_CE_TERMINATE;

@@ -302,9 +302,9 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	const uint32_t cap = job.dst_cap;
 	// window access: position p counts output bytes, negative positions (as uint32) are history
 	const uint8_t *hist_end = job.src + hist;
-	auto wr = [&](uint32_t p, uint32_t v) { if (GW) dst[p] = (uint8_t)v; else sm.win[p & WMASK] = (uint8_t)v; };
+	auto wr = [&](uint32_t p, uint32_t v) __attribute__((always_inline)) { if (GW) dst[p] = (uint8_t)v; else sm.win[p & WMASK] = (uint8_t)v; };
 	uint32_t out = 0, flushed = 0;             // bytes produced / bytes already written to dst
-	auto rd = [&](uint32_t p) -> uint32_t {    // p is 1..32768 bytes behind `out`
+	auto rd = [&](uint32_t p) __attribute__((always_inline)) -> uint32_t {    // p is 1..32768 bytes behind `out`
 		if (GW) { const uint32_t back = out - p; return back > out ? hist_end[-(ptrdiff_t)(back - out)] : dst[p]; }
 		return sm.win[p & WMASK];
 	};
@@ -312,12 +312,34 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	// source byte lies in front of `out`, so all the loads (five at most: len <= 258) are issued
 	// before the first store: one round trip to the window per match instead of one per 64 bytes --
 	// what counts when the window is the target in device memory and the data is mostly long matches.
-	auto copy_match = [&](uint32_t dist, uint32_t len) {
+	auto copy_match = [&](uint32_t dist, uint32_t len) __attribute__((always_inline)) {
+		// dist and len are wave-uniform: the branches below are scalar
+		dist = __builtin_amdgcn_readfirstlane(dist); len = __builtin_amdgcn_readfirstlane(len);
+		if (len <= 64) {
+			// i % dist for i < 64 without a division: dist >= len > i needs none, and below that one
+			// multiplication by the rounded-up reciprocal is exact for these small numbers (checked for
+			// every dist < 259, i < 320, with the reciprocal off by 2 ulp either way)
+			uint32_t i = lane;
+			if (dist < len) { const uint32_t m = (uint32_t)(__builtin_amdgcn_rcpf((float)dist) * 1048576.0f) + 1; i -= ((i * m) >> 20) * dist; }
+			const uint32_t v = (uint32_t)lane < len ? rd(out - dist + i) : 0;
+			if ((uint32_t)lane < len) wr(out + lane, v);
+			return;
+		}
 		uint32_t v[5];
+		if (dist >= len) {
 #pragma unroll
-		for (int k = 0; k < 5; k++) {
-			const uint32_t i = lane + 64 * k;
-			v[k] = i < len ? rd(out - dist + (dist >= len ? i : i % dist)) : 0;
+			for (int k = 0; k < 5; k++) {
+				const uint32_t i = lane + 64 * k;
+				v[k] = i < len ? rd(out - dist + i) : 0;
+			}
+		} else {
+			const uint32_t m = (uint32_t)(__builtin_amdgcn_rcpf((float)dist) * 1048576.0f) + 1;   // i < 320, dist < 258: (i * m) >> 20 == i / dist
+#pragma unroll
+			for (int k = 0; k < 5; k++) {
+				const uint32_t i = lane + 64 * k;
+				const uint32_t r = i - ((i * m) >> 20) * dist;
+				v[k] = i < len ? rd(out - dist + r) : 0;
+			}
 		}
 #pragma unroll
 		for (int k = 0; k < 5; k++) {

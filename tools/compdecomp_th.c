@@ -1,7 +1,7 @@
 /* T threads, each compressing and decompressing its own buffers through the zlib-style API of
  * libnxz_amd.so, one call per buffer -- the shape of the reference's samples/compdecomp_th.c (a file,
  * a thread count; every thread runs compress + decompress rounds and the aggregate rate is printed).
- *   usage: compdecomp_th <file> <threads> [buffer KiB = 64] [buffers per thread = 512]
+ *   usage: compdecomp_th <file> <threads> [buffer KiB = 64] [buffers per thread = 2048]
  * build: make -C power-gzip_amd/csrc ../../tools/compdecomp_th   (or see tools/Makefile line in README) */
 #include <pthread.h>
 #include <stdint.h>
@@ -53,7 +53,7 @@ int main(int argc, char **argv)
 	if (argc < 3) { fprintf(stderr, "usage: %s <file> <threads> [buffer KiB] [buffers per thread]\n", argv[0]); return 2; }
 	int T = atoi(argv[2]);
 	g_buf = (argc > 3 ? (size_t)atoi(argv[3]) : 64) << 10;
-	g_per = argc > 4 ? (size_t)atoi(argv[4]) : 512;
+	g_per = argc > 4 ? (size_t)atoi(argv[4]) : 2048;
 	FILE *f = fopen(argv[1], "rb");
 	if (!f) { perror(argv[1]); return 2; }
 	fseek(f, 0, SEEK_END); long flen = ftell(f); fseek(f, 0, SEEK_SET);
