@@ -205,17 +205,9 @@ __global__ __launch_bounds__(NT) void differ_items_kernel(const CopyItem *__rest
 }
 
 // ---- resolving what the pieces copied out of their unknown histories ----
-// A piece (but the first) is decoded three times, with the probe windows above as its 32 KiB of
-// history.  Which history byte an output byte is a copy of -- if of any -- does not depend on what
-// the history holds, so for every output byte either all three decodes agree (the byte itself) or
-// they show the low byte, the high byte and 255 - low byte of the window index it comes from:
-// a + c == 255 exactly then (two equal bytes sum to an even number).
-struct Piece { const uint8_t *a, *b, *c; uint64_t len, place; };
-
-__device__ __forceinline__ uint32_t resolve(uint32_t a, uint32_t b, uint32_t c, const uint8_t *win)
-{
-	return a + c == 255 ? win[(b << 8) | a] : a;
-}
+// A piece is decoded with 16-bit elements (nxz_inflate.hip, W16): an element is the byte itself or
+// 0x8000 | the index of the byte of the 32 KiB in front of the piece that it is a copy of.
+struct Piece { const uint16_t *o; uint64_t len, place; };
 
 // The window behind a piece as a function of the window in front of it: entry k of the piece's
 // tail map is the byte itself (0..255) or 0x8000 | index into the window in front.  A workgroup per
@@ -230,11 +222,7 @@ __global__ __launch_bounds__(256) void tailmap_kernel(const Piece *__restrict__ 
 	for (uint32_t k = threadIdx.x; k < 32768; k += 256) {
 		uint32_t v;
 		if (L < 32768 && k < 32768 - L) v = 0x8000u | (uint32_t)(k + L);         // still the old window, moved up
-		else {
-			const uint64_t o = L >= 32768 ? L - 32768 + k : k - (32768 - L);
-			const uint32_t a = p.a[o], b = p.b[o], c = p.c[o];
-			v = a + c == 255 ? 0x8000u | (b << 8) | a : a;
-		}
+		else v = p.o[L >= 32768 ? L - 32768 + k : k - (32768 - L)];
 		m[k] = (uint16_t)v;
 	}
 }
@@ -302,7 +290,19 @@ __global__ __launch_bounds__(256) void resolve_kernel(const Piece *__restrict__ 
 	for (uint32_t k = threadIdx.x; k < 32768 / 16; k += 256) ((uint4 *)w)[k] = ((const uint4 *)win)[k];
 	__syncthreads();
 	uint8_t *out = dst + p.place;
-	for (uint64_t o = lo + threadIdx.x; o < hi; o += 256) out[o] = (uint8_t)resolve(p.a[o], p.b[o], p.c[o], w);
+	// 4 elements per thread and trip where the piece's place allows whole dwords
+	const uint64_t head = ((4 - ((uintptr_t)(out + lo) & 3)) & 3);
+	const uint64_t a0 = lo + head < hi ? lo + head : hi;
+	for (uint64_t o = lo + threadIdx.x; o < a0; o += 256) { const uint32_t v = p.o[o]; out[o] = (uint8_t)((v & 0x8000) ? w[v & 0x7fff] : v); }
+	const uint64_t nq = (hi - a0) >> 2;
+	for (uint64_t q = threadIdx.x; q < nq; q += 256) {
+		const uint64_t o = a0 + q * 4;
+		uint32_t r = 0;
+#pragma unroll
+		for (int e = 0; e < 4; e++) { const uint32_t v = p.o[o + e]; r |= ((v & 0x8000) ? (uint32_t)w[v & 0x7fff] : (v & 0xff)) << (8 * e); }
+		*(uint32_t *)(out + o) = r;
+	}
+	for (uint64_t o = a0 + nq * 4 + threadIdx.x; o < hi; o += 256) { const uint32_t v = p.o[o]; out[o] = (uint8_t)((v & 0x8000) ? w[v & 0x7fff] : v); }
 }
 
 } // namespace nxzb

@@ -287,7 +287,11 @@ __device__ __forceinline__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist
 }
 
 // job.resume: rembytecnt | sfbt << 16 | subc << 20.  results: tebc field carries out_rembytecnt.
-template <bool GW>
+// W16 (with GW; nxz_inflate_stream's pieces): the history in front of the output is not known yet.
+// The target holds 16-bit elements (job.dst_cap counts elements): a byte, or 0x8000 | k for "byte k
+// of the 32 KiB that precede this output", which is what a match that reaches back before the output
+// copies; matches copy elements, so such references travel.  No history bytes are read, no checksums.
+template <bool GW, bool W16 = false>
 __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__restrict__ jobs,
 						     nxz_batch_result_t *__restrict__ results,
 						     nxz_batch_dht_t *__restrict__ dht_io)
@@ -295,16 +299,23 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	__shared__ __attribute__((aligned(16))) SmemT<GW> sm;
 	const int lane = threadIdx.x;
 	const nxz_batch_job_t job = jobs[blockIdx.x];
-	const uint32_t hist = job.hist_len < job.src_len ? job.hist_len : job.src_len;
-	const uint32_t srclen = job.src_len - hist;
-	const uint8_t *src = job.src + hist;
+	const uint32_t hist_bytes = job.hist_len < job.src_len ? job.hist_len : job.src_len;
+	const uint32_t hist = W16 ? WIN : hist_bytes;      // how far back a match may reach before the output
+	const uint32_t srclen = job.src_len - hist_bytes;
+	const uint8_t *src = job.src + hist_bytes;
 	uint8_t *dst = job.dst;
 	const uint32_t cap = job.dst_cap;
 	// window access: position p counts output bytes, negative positions (as uint32) are history
-	const uint8_t *hist_end = job.src + hist;
-	auto wr = [&](uint32_t p, uint32_t v) __attribute__((always_inline)) { if (GW) dst[p] = (uint8_t)v; else sm.win[p & WMASK] = (uint8_t)v; };
+	const uint8_t *hist_end = job.src + hist_bytes;
+	uint16_t *dst16 = (uint16_t *)job.dst;
+	auto wr = [&](uint32_t p, uint32_t v) __attribute__((always_inline)) {
+		if (W16) dst16[p] = (uint16_t)v;
+		else if (GW) dst[p] = (uint8_t)v;
+		else sm.win[p & WMASK] = (uint8_t)v;
+	};
 	uint32_t out = 0, flushed = 0;             // bytes produced / bytes already written to dst
 	auto rd = [&](uint32_t p) __attribute__((always_inline)) -> uint32_t {    // p is 1..32768 bytes behind `out`
+		if (W16) { const uint32_t back = out - p; return back > out ? 0x8000u | (WIN - (back - out)) : dst16[p]; }
 		if (GW) { const uint32_t back = out - p; return back > out ? hist_end[-(ptrdiff_t)(back - out)] : dst[p]; }
 		return sm.win[p & WMASK];
 	};
@@ -360,8 +371,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	}
 	// history (the last <= 32 KiB before the output) goes into the window just below position 0
 	{
-		uint32_t h = hist > WIN ? WIN : hist;
-		const uint8_t *hp = job.src + (hist - h);
+		uint32_t h = hist_bytes > WIN ? WIN : hist_bytes;
+		const uint8_t *hp = job.src + (hist_bytes - h);
 		if (!GW) for (uint32_t i = lane; i < h; i += 64) sm.win[(0u - h + i) & WMASK] = hp[i];
 	}
 	__syncthreads();
@@ -581,7 +592,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 						if (nlit > cap - out) break;                                // target nearly full: one-token path
 						if ((starts >> lane) & 1) {
 							const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0));
-							wr(out + rank, el);
+							wr(out + rank, el & 0xff);
 						}
 						out += nlit; off = o;
 						if (off > 47 || out - flushed >= FLUSH) break;
@@ -712,4 +723,12 @@ extern "C" int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_bat
 	hipLaunchKernelGGL(nxzi::inflate_kernel<true>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
 	int rc = (int)hipGetLastError();
 	return rc ? rc : nxz_launch_cksum(jobs, n, results, stream);
+}
+
+// nxz_inflate_stream's pieces: 16-bit elements, references into the unknown 32 KiB in front as 0x8000 | index
+extern "C" int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL((nxzi::inflate_kernel<true, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, (nxz_batch_dht_t *)nullptr);
+	return (int)hipGetLastError();
 }

@@ -10,16 +10,14 @@
 // (DECOMPRESS_RESUME: source bit offset in in_subc, 32 KiB history in front of the source).
 // What a piece does not know is its history: the 32 KiB of output in front of it.  But which
 // history byte an output byte is a copy of (directly or through copies of copies) does not depend
-// on what the history holds.  So every piece but the first is decoded THREE times in the same
-// batch, with three probe histories -- byte k of the window = k's low byte, k's high byte,
-// 255 - low byte -- and for every output byte the three results either agree (the byte itself:
-// two equal bytes never sum to 255) or spell the window index it comes from.  Then
+// on what the history holds.  So a piece is decoded into 16-bit elements (nxz_inflate.hip, W16): the
+// byte itself, or 0x8000 | k for "whatever byte k of the 32 KiB in front of me is".  Then
 //   - every piece's length, hence its place in the output, is known, and so is whether the piece
 //     in front of it ends exactly at its header (a wrong guess of a block start shows here: the
-//     boundary is dropped, the pieces are merged, the batch is run again);
+//     boundary is dropped and the merged piece -- only that one -- is decoded again);
 //   - one workgroup walks the pieces in order and makes the true 32 KiB window behind each
 //     (32 KiB of look-ups per piece);
-//   - all pieces are resolved into place at once: final byte = the byte, or window[index].
+//   - all pieces are resolved into place at once: final byte = the element, or window[k].
 // The CRC-32 / Adler-32 of the output are computed over 256 KiB slices and combined (zlib's
 // crc32_combine idea); the caller checks them against the trailer as for any stream.
 #include <hip/hip_runtime.h>
@@ -44,7 +42,7 @@ int nxz_launch_resolve(const void *pieces, uint32_t n, const uint8_t *win0, cons
 namespace {
 
 struct CopyItem { const uint8_t *src; uint8_t *dst; uint64_t bytes; };      // src below 16: a fill (nxz_blockfind.hip)
-struct Piece { const uint8_t *a, *b, *c; uint64_t len, place; };
+struct Piece { const uint16_t *o; uint64_t len, place; };
 
 constexpr uint32_t WINDOW = 32768;
 constexpr uint64_t SLICE = 256 << 10;            // checksum slices
@@ -160,133 +158,152 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 	}
 	if (B.size() < 8) return -ENOTSUP;
 
-	std::vector<nxz_batch_result_t> res;                  // per piece (of its first decode)
-	std::vector<uint64_t> stage_off, out_off, cap, cbytes, cstart;
-	size_t n = 0;
-	uint8_t *d_stage = nullptr, *d_out = nullptr, *d_windows = nullptr;
-	uint16_t *d_maps = nullptr;
-	nxz_batch_job_t *d_jobs = nullptr;
-	nxz_batch_result_t *d_res = nullptr;
-	CopyItem *d_items = nullptr;
-	Piece *d_pieces = nullptr;
-	size_t pin_jobs = 0, pin_res = 0, pin_items = 0, pin_pieces = 0;
-
-	std::vector<uint64_t> capmul(B.size(), 100);        // a piece's buffer: 100 x its compressed size, 2 MiB at least
+	// a piece of the stream: from a block start to the next
+	struct P {
+		uint64_t bit, cstart, cbytes;           // first bit; first byte and byte count of its part of the stream
+		size_t stage_off, out_off;              // its 16-byte aligned copy of those bytes / its 16-bit output, in the bump area
+		uint64_t cap;                           // output elements it may produce
+		uint32_t capmul;
+		nxz_batch_result_t res;
+		bool done;
+	};
+	std::vector<P> pc(B.size());
+	for (size_t i = 0; i < B.size(); i++) { pc[i] = P(); pc[i].bit = B[i]; pc[i].capmul = 100; }   // buffer: 100 x the compressed size, 2 Mi elements at least
+	const size_t n0 = pc.size();
+	// control arrays (sized for the first, longest list of pieces), then a bump area for copies and outputs
+	const size_t o_jobs = 0, o_res = o_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), o_items = o_res + up(n0 * sizeof(nxz_batch_result_t), 256),
+		     o_pieces = o_items + up((n0 + 4) * sizeof(CopyItem), 256), o_win0 = o_pieces + up(n0 * sizeof(Piece), 256),
+		     o_windows = o_win0 + WINDOW, o_maps = o_windows + n0 * (size_t)WINDOW, o_bump = o_maps + n0 * (size_t)WINDOW * 2;
+	const size_t pin_jobs = 0, pin_res = pin_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), pin_items = pin_res + up(n0 * sizeof(nxz_batch_result_t), 256),
+		     pin_pieces = pin_items + up((n0 + 4) * sizeof(CopyItem), 256), pin_total = pin_pieces + up(n0 * sizeof(Piece), 256);
+	size_t bump = 0, reserved = 0;
+	auto size_piece = [&](P &p, uint64_t next_bit) -> bool {
+		p.cstart = p.bit >> 3;
+		const uint64_t cend = next_bit ? (next_bit + 7) >> 3 : src_len;
+		p.cbytes = cend - p.cstart;
+		if (p.cbytes > 0xfffffff0ull - 64) return false;
+		const uint64_t cp = std::max<uint64_t>(p.cbytes * p.capmul, 2u << 20);
+		if (cp > 0xfff00000ull) return false;
+		p.cap = up(cp, 256);
+		p.stage_off = bump; bump += up(p.cbytes + 64, 256);
+		p.out_off = bump; bump += p.cap * 2;
+		p.done = false;
+		return true;
+	};
+	for (size_t i = 0; i < pc.size(); i++)
+		if (!size_piece(pc[i], i + 1 < pc.size() ? pc[i + 1].bit : 0)) return -ENOTSUP;
+	uint8_t *D = nullptr, *PN = nullptr;
+	bool win0_made = false;
 	for (int attempt = 0; ; attempt++) {
-		n = B.size();
-		const size_t njobs = 3 * n - 2;                       // piece 0 once (its history is known), the others three times
-		stage_off.assign(n, 0); out_off.assign(n, 0); cap.assign(n, 0); cbytes.assign(n, 0); cstart.assign(n, 0);
-		size_t stage_total = 0, out_total = 0;
-		for (size_t i = 0; i < n; i++) {
-			const size_t copies = i ? 3 : 1;
-			cstart[i] = B[i] >> 3;
-			const uint64_t cend = i + 1 < n ? (B[i + 1] + 7) >> 3 : src_len;
-			cbytes[i] = cend - cstart[i];
-			if (cbytes[i] + WINDOW + 64 > 0xfffffff0ull) return -ENOTSUP;
-			stage_off[i] = stage_total;
-			stage_total += copies * up(WINDOW + cbytes[i] + 16, 256);
-			uint64_t cp = std::max<uint64_t>(cbytes[i] * capmul[i], 2u << 20);
-			if (cp > 0xfff00000ull) return -ENOTSUP;
-			cap[i] = up(cp, 256);
-			out_off[i] = out_total;
-			out_total += copies * cap[i];
-		}
-		const size_t o_jobs = 0, o_res = o_jobs + up(njobs * sizeof(nxz_batch_job_t), 256), o_items = o_res + up(njobs * sizeof(nxz_batch_result_t), 256),
-			     o_pieces = o_items + up((2 * njobs + 2) * sizeof(CopyItem), 256), o_windows = o_pieces + up(n * sizeof(Piece), 256),
-			     o_maps = o_windows + n * (size_t)WINDOW, o_stage = o_maps + n * (size_t)WINDOW * 2, o_out = o_stage + up(stage_total, 256);
-		const size_t dev_total = o_out + out_total;
-		if (dev_total > (128ull << 30)) return -ENOTSUP;
-		pin_jobs = 0; pin_res = pin_jobs + up(njobs * sizeof(nxz_batch_job_t), 256); pin_items = pin_res + up(njobs * sizeof(nxz_batch_result_t), 256);
-		pin_pieces = pin_items + up((2 * njobs + 2) * sizeof(CopyItem), 256);
-		if (!ws.need(dev_total, pin_pieces + up(n * sizeof(Piece), 256))) return -ENOMEM;
-		uint8_t *D = (uint8_t *)ws.dev, *P = (uint8_t *)ws.pin;
-		d_jobs = (nxz_batch_job_t *)(D + o_jobs); d_res = (nxz_batch_result_t *)(D + o_res); d_items = (CopyItem *)(D + o_items);
-		d_pieces = (Piece *)(D + o_pieces); d_windows = D + o_windows; d_maps = (uint16_t *)(D + o_maps); d_stage = D + o_stage; d_out = D + o_out;
-		nxz_batch_job_t *h_jobs = (nxz_batch_job_t *)(P + pin_jobs);
-		nxz_batch_result_t *h_res = (nxz_batch_result_t *)(P + pin_res);
-		CopyItem *h_items = (CopyItem *)(P + pin_items);
-		// staging: [history: the caller's (behind zeros) for piece 0, the three probe windows for the others][the piece's bytes of the stream]
-		size_t nj = 0, ni = 0;
-		for (size_t i = 0; i < n; i++) {
-			const size_t copies = i ? 3 : 1, sstride = up(WINDOW + cbytes[i] + 16, 256);
-			for (size_t k = 0; k < copies; k++) {
-				uint8_t *st = d_stage + stage_off[i] + k * sstride;
-				h_items[ni++] = CopyItem{ (const uint8_t *)(uintptr_t)(i ? k + 1 : 0), st, (i == 0) ? WINDOW - hist_len : WINDOW };
-				h_items[ni++] = CopyItem{ src + cstart[i], st + WINDOW, cbytes[i] };
-				nxz_batch_job_t &j = h_jobs[nj++];
-				memset(&j, 0, sizeof(j));
-				j.src = st; j.src_len = (uint32_t)(WINDOW + cbytes[i]); j.hist_len = WINDOW;
-				j.dst = d_out + out_off[i] + k * cap[i]; j.dst_cap = (uint32_t)cap[i];
-				j.in_crc = 0; j.in_adler = 1;
-				const uint32_t sub = (uint32_t)(B[i] & 7);
-				j.resume = (0xeu << 16) | ((sub ? 8 - sub : 0) << 20);
+		if (bump > reserved || !ws.dev) {
+			// (first attempt, or the repeats outgrew the room left for them: everything is placed and decoded anew)
+			if (attempt) {
+				bump = 0;
+				for (size_t i = 0; i < pc.size(); i++)
+					if (!size_piece(pc[i], i + 1 < pc.size() ? pc[i + 1].bit : 0)) return -ENOTSUP;
 			}
+			reserved = bump + std::max<size_t>(bump / 4, (size_t)256 << 20);
+			if (o_bump + reserved > (200ull << 30)) return -ENOTSUP;
+			if (!ws.need(o_bump + reserved, pin_total)) return -ENOMEM;
+			win0_made = false;
+		}
+		D = (uint8_t *)ws.dev; PN = (uint8_t *)ws.pin;
+		nxz_batch_job_t *d_jobs = (nxz_batch_job_t *)(D + o_jobs), *h_jobs = (nxz_batch_job_t *)(PN + pin_jobs);
+		nxz_batch_result_t *d_res = (nxz_batch_result_t *)(D + o_res), *h_res = (nxz_batch_result_t *)(PN + pin_res);
+		CopyItem *d_items = (CopyItem *)(D + o_items), *h_items = (CopyItem *)(PN + pin_items);
+		size_t nj = 0, ni = 0;
+		std::vector<size_t> who;
+		for (size_t i = 0; i < pc.size(); i++) {
+			P &p = pc[i];
+			if (p.done) continue;
+			uint8_t *st = D + o_bump + p.stage_off;
+			h_items[ni++] = CopyItem{ src + p.cstart, st, p.cbytes };
+			nxz_batch_job_t &j = h_jobs[nj++];
+			memset(&j, 0, sizeof(j));
+			j.src = st; j.src_len = (uint32_t)p.cbytes; j.hist_len = 0;
+			j.dst = D + o_bump + p.out_off; j.dst_cap = (uint32_t)p.cap;
+			const uint32_t sub = (uint32_t)(p.bit & 7);
+			j.resume = (0xeu << 16) | ((sub ? 8 - sub : 0) << 20);
+			who.push_back(i);
+		}
+		if (!win0_made) {
+			// the window in front of the whole output: zeros, the caller's history at its end
+			h_items[ni++] = CopyItem{ (const uint8_t *)(uintptr_t)0, D + o_win0, WINDOW - hist_len };
+			if (hist_len) h_items[ni++] = CopyItem{ hist, D + o_win0 + (WINDOW - hist_len), hist_len };
+			win0_made = true;
 		}
 		if (hipMemcpyAsync(d_items, h_items, ni * sizeof(CopyItem), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 		if (hipMemcpyAsync(d_jobs, h_jobs, nj * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 		if (nxz_launch_copy_items(d_items, (uint32_t)ni, s)) return -EIO;
-		if (hist_len) {                                       // behind the zero fill of piece 0's window
-			h_items[ni] = CopyItem{ hist, d_stage + stage_off[0] + (WINDOW - hist_len), hist_len };
-			if (hipMemcpyAsync(d_items + ni, h_items + ni, sizeof(CopyItem), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
-			if (nxz_launch_copy_items(d_items + ni, 1, s)) return -EIO;
-		}
 		lap("staging");
-		if (nxz_batch_decompress(c, d_jobs, nj, d_res, nullptr, s)) return -EIO;
-		lap("decode (all pieces x 3)");
+		if (nxz_launch_inflate_w16(d_jobs, nj, d_res, s)) return -EIO;
+		lap("decode");
 		if (hipMemcpyAsync(h_res, d_res, nj * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 		if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+		for (size_t k = 0; k < nj; k++) { pc[who[k]].res = h_res[k]; pc[who[k]].done = true; }
 		// every piece but the last must stop at the header of the next one; the last at the final block's end
 		bool again = false;
-		std::vector<uint64_t> B2, mul2;
-		B2.push_back(B[0]); mul2.push_back(capmul[0]);
-		res.resize(n);
-		for (size_t i = 0; i < n; i++) {
-			const nxz_batch_result_t &r = h_res[i ? 3 * i - 2 : 0];
-			res[i] = r;
-			if (i && (h_res[3 * i - 1].tpbc != r.tpbc || h_res[3 * i].tpbc != r.tpbc || h_res[3 * i - 1].cc != r.cc || h_res[3 * i].cc != r.cc)) return -EIO;
+		std::vector<P> nx;
+		nx.reserve(pc.size());
+		bool swallow = false;
+		for (size_t i = 0; i < pc.size(); i++) {
+			if (swallow) { swallow = false; continue; }         // this piece's start was refuted: it goes into the piece in front (sized below)
+			P p = pc[i];
+			const nxz_batch_result_t &r = p.res;
 			if (r.cc == NXZ_CC_TARGET_SPACE) {
-				if (capmul[i] >= 1032 * 2) return -ENOTSUP;
-				mul2.back() = capmul[i] * 8; again = true;
-			} else if (i + 1 < n) {
-				const uint64_t used = cbytes[i] * 8 - r.subc, want = B[i + 1] - cstart[i] * 8;
+				if (p.capmul >= 1032 * 2) return -ENOTSUP;
+				p.capmul *= 8; p.done = false;                     // same piece, more room
+				again = true;
+				nx.push_back(p);
+				continue;
+			}
+			if (i + 1 < pc.size()) {
+				const uint64_t used = p.cbytes * 8 - r.subc, want = pc[i + 1].bit - p.cstart * 8;
 				const uint32_t kind = r.sfbt & 0xe;
 				const bool at_header = r.cc == NXZ_CC_DATA_LENGTH && ((kind == 0xe && used == want) || (kind == 0xa && used == want + 3));
 				if (!at_header) {
 					if (trace) fprintf(stderr, "nxz_inflate_stream: piece %zu (bit %llu, %llu bytes in, %u out) cc %u sfbt %#x subc %u: used %llu bits, next header thought at %llu\n",
-							   i, (unsigned long long)B[i], (unsigned long long)cbytes[i], r.tpbc, r.cc, r.sfbt, r.subc, (unsigned long long)used, (unsigned long long)want);
+							   i, (unsigned long long)p.bit, (unsigned long long)p.cbytes, r.tpbc, r.cc, r.sfbt, r.subc, (unsigned long long)used, (unsigned long long)want);
 					// the piece did not end where the next was thought to start: that start is wrong
 					// (or the data is bad, which the merged piece will report again)
-					if (r.cc != NXZ_CC_DATA_LENGTH && r.cc != 0 && i + 2 >= n) return -EILSEQ;
+					if (r.cc != NXZ_CC_DATA_LENGTH && r.cc != 0 && i + 2 >= pc.size()) return -EILSEQ;
+					p.done = false; swallow = true;
 					again = true;
-					continue;                               // B[i + 1] is dropped
 				}
 			}
-			if (i + 1 < n) { B2.push_back(B[i + 1]); mul2.push_back(capmul[i + 1]); }
+			nx.push_back(p);
 		}
 		if (!again) break;
-		if (attempt >= 11 || B2.size() < 4) return -ENOTSUP;
-		B.swap(B2); capmul.swap(mul2);
+		if (attempt >= 11 || nx.size() < 4) return -ENOTSUP;
+		pc.swap(nx);
+		for (size_t i = 0; i < pc.size(); i++)
+			if (!pc[i].done && !size_piece(pc[i], i + 1 < pc.size() ? pc[i + 1].bit : 0)) return -ENOTSUP;
 	}
+	const size_t n = pc.size();
 	// the last piece must have seen the final block
 	{
-		const nxz_batch_result_t &r = res[n - 1];
+		const nxz_batch_result_t &r = pc[n - 1].res;
 		if (r.cc != 0 && r.cc != NXZ_CC_DATA_LENGTH) return -EILSEQ;
 		if (!(r.sfbt & 0x100)) return -ENOTSUP;
 		if (end_bit) *end_bit = src_len * 8 - r.subc;
 	}
 	// ---- places, true windows, resolution ----
-	uint8_t *P = (uint8_t *)ws.pin;
-	Piece *h_pieces = (Piece *)(P + pin_pieces);
+	uint8_t *P_ = (uint8_t *)ws.pin;
+	Piece *h_pieces = (Piece *)(P_ + pin_pieces);
+	Piece *d_pieces = (Piece *)(D + o_pieces);
+	uint8_t *d_windows = D + o_windows;
+	uint16_t *d_maps = (uint16_t *)(D + o_maps);
+	nxz_batch_job_t *d_jobs = (nxz_batch_job_t *)(D + o_jobs);
+	nxz_batch_result_t *d_res = (nxz_batch_result_t *)(D + o_res);
 	uint64_t total = 0;
 	for (size_t i = 0; i < n; i++) {
-		const uint8_t *a = d_out + out_off[i];
-		h_pieces[i] = Piece{ a, i ? a + cap[i] : a, i ? a + 2 * cap[i] : a, res[i].tpbc, total };
-		total += res[i].tpbc;
+		h_pieces[i] = Piece{ (const uint16_t *)(D + o_bump + pc[i].out_off), pc[i].res.tpbc, total };
+		total += pc[i].res.tpbc;
 	}
 	*out_len = total;
 	if (total > dst_cap) return -E2BIG;
 	if (hipMemcpyAsync(d_pieces, h_pieces, n * sizeof(Piece), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
-	const uint8_t *win0 = d_stage + stage_off[0];
+	const uint8_t *win0 = D + o_win0;
 	if (nxz_launch_window_chain(d_pieces, (uint32_t)n, win0, d_maps, d_windows, s)) return -EIO;
 	lap("tail maps + window chain");
 	if (nxz_launch_resolve(d_pieces, (uint32_t)n, win0, d_windows, dst, s)) return -EIO;
@@ -294,10 +311,10 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 	// ---- checksums: 256 KiB slices of the output (the job / result arrays are free again) ----
 	const size_t nsl = (size_t)((total + SLICE - 1) / SLICE);
 	std::vector<nxz_batch_result_t> sres(nsl);
-	for (size_t o = 0; o < nsl; o += 3 * n - 2) {
-		const size_t m = std::min(nsl - o, 3 * n - 2);
-		nxz_batch_job_t *h_jobs = (nxz_batch_job_t *)(P + pin_jobs);
-		nxz_batch_result_t *h_res = (nxz_batch_result_t *)(P + pin_res);
+	for (size_t o = 0; o < nsl; o += n0) {
+		const size_t m = std::min(nsl - o, n0);
+		nxz_batch_job_t *h_jobs = (nxz_batch_job_t *)(P_ + pin_jobs);
+		nxz_batch_result_t *h_res = (nxz_batch_result_t *)(P_ + pin_res);
 		for (size_t k = 0; k < m; k++) {
 			memset(&h_jobs[k], 0, sizeof(nxz_batch_job_t));
 			memset(&h_res[k], 0, sizeof(nxz_batch_result_t));
@@ -315,7 +332,7 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 	lap("checksums");
 	if (trace) {
 		uint64_t mx = 0;
-		for (size_t i = 0; i < n; i++) mx = std::max<uint64_t>(mx, res[i].tpbc);
+		for (size_t i = 0; i < n; i++) mx = std::max<uint64_t>(mx, pc[i].res.tpbc);
 		fprintf(stderr, "nxz_inflate_stream: %zu pieces, largest %llu bytes out, mean %llu\n", n, (unsigned long long)mx, (unsigned long long)(total / n));
 	}
 	const uint32_t nround = 1;
