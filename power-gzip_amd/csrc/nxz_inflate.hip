@@ -314,48 +314,40 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 		else sm.win[p & WMASK] = (uint8_t)v;
 	};
 	uint32_t out = 0, flushed = 0;             // bytes produced / bytes already written to dst
-	auto rd = [&](uint32_t p) __attribute__((always_inline)) -> uint32_t {    // p is 1..32768 bytes behind `out`
-		if (W16) { const uint32_t back = out - p; return back > out ? 0x8000u | (WIN - (back - out)) : dst16[p]; }
-		if (GW) { const uint32_t back = out - p; return back > out ? hist_end[-(ptrdiff_t)(back - out)] : dst[p]; }
+	// read position p of the window for a match that writes at `at` (p is 1..32768 bytes behind `at`;
+	// what lies in front of position 0 is the history)
+	auto rd = [&](uint32_t p, uint32_t at) __attribute__((always_inline)) -> uint32_t {
+		if (W16) { const uint32_t back = at - p; return back > at ? 0x8000u | (WIN - (back - at)) : dst16[p]; }
+		if (GW) { const uint32_t back = at - p; return back > at ? hist_end[-(ptrdiff_t)(back - at)] : dst[p]; }
 		return sm.win[p & WMASK];
 	};
-	// A match, lane per byte (the source pattern repeats with period dist when dist < len).  Every
-	// source byte lies in front of `out`, so all the loads (five at most: len <= 258) are issued
-	// before the first store: one round trip to the window per match instead of one per 64 bytes --
-	// what counts when the window is the target in device memory and the data is mostly long matches.
-	auto copy_match = [&](uint32_t dist, uint32_t len) __attribute__((always_inline)) {
-		// dist and len are wave-uniform: the branches below are scalar
-		dist = __builtin_amdgcn_readfirstlane(dist); len = __builtin_amdgcn_readfirstlane(len);
+	// A match of len bytes from dist back, written at `at`: lane per byte (the source pattern repeats
+	// with period dist when dist < len).  Every source byte lies in front of `at`, so all the loads
+	// (five at most: len <= 258) are issued before the first store: one round trip to the window per
+	// match instead of one per 64 bytes.  dist and len are wave-uniform: the branches are scalar.
+	auto copy_match = [&](uint32_t at, uint32_t dist, uint32_t len) __attribute__((always_inline)) {
+		at = __builtin_amdgcn_readfirstlane(at); dist = __builtin_amdgcn_readfirstlane(dist); len = __builtin_amdgcn_readfirstlane(len);
+		// i % dist without a division: one multiplication by the rounded-up reciprocal is exact for these
+		// small numbers (checked for every dist < 259, i < 320, with the reciprocal off by 2 ulp either way)
+		const uint32_t m = dist < len ? (uint32_t)(__builtin_amdgcn_rcpf((float)dist) * 1048576.0f) + 1 : 0;
 		if (len <= 64) {
-			// i % dist for i < 64 without a division: dist >= len > i needs none, and below that one
-			// multiplication by the rounded-up reciprocal is exact for these small numbers (checked for
-			// every dist < 259, i < 320, with the reciprocal off by 2 ulp either way)
 			uint32_t i = lane;
-			if (dist < len) { const uint32_t m = (uint32_t)(__builtin_amdgcn_rcpf((float)dist) * 1048576.0f) + 1; i -= ((i * m) >> 20) * dist; }
-			const uint32_t v = (uint32_t)lane < len ? rd(out - dist + i) : 0;
-			if ((uint32_t)lane < len) wr(out + lane, v);
+			if (dist < len) i -= ((i * m) >> 20) * dist;
+			const uint32_t v = (uint32_t)lane < len ? rd(at - dist + i, at) : 0;
+			if ((uint32_t)lane < len) wr(at + lane, v);
 			return;
 		}
 		uint32_t v[5];
-		if (dist >= len) {
 #pragma unroll
-			for (int k = 0; k < 5; k++) {
-				const uint32_t i = lane + 64 * k;
-				v[k] = i < len ? rd(out - dist + i) : 0;
-			}
-		} else {
-			const uint32_t m = (uint32_t)(__builtin_amdgcn_rcpf((float)dist) * 1048576.0f) + 1;   // i < 320, dist < 258: (i * m) >> 20 == i / dist
-#pragma unroll
-			for (int k = 0; k < 5; k++) {
-				const uint32_t i = lane + 64 * k;
-				const uint32_t r = i - ((i * m) >> 20) * dist;
-				v[k] = i < len ? rd(out - dist + r) : 0;
-			}
+		for (int k = 0; k < 5; k++) {
+			const uint32_t i = lane + 64 * k;
+			const uint32_t r = dist < len ? i - ((i * m) >> 20) * dist : i;
+			v[k] = (k < 2 || len > 64u * k) && i < len ? rd(at - dist + r, at) : 0;
 		}
 #pragma unroll
 		for (int k = 0; k < 5; k++) {
 			const uint32_t i = lane + 64 * k;
-			if (i < len) wr(out + i, v[k]);
+			if ((k < 2 || len > 64u * k) && i < len) wr(at + i, v[k]);
 		}
 	};
 #ifdef NXZ_INFLATE_PROF
@@ -545,7 +537,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			state = 0;
 		} else {
 			// ---- multi-token step (see the header) ----
-			while (fast_ok && b.pos + 192 <= b.total_bits) {
+			while (fast_ok && b.pos + 256 <= b.total_bits) {
 				IPROF(0);
 				const uint32_t q = (uint32_t)(b.pos >> 5), sh = (uint32_t)b.pos & 31;
 				if (wblk == 0xffffffffu || q < wblk * 64 || q >= wblk * 64 + 128) {
@@ -555,73 +547,114 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 					wblk++;
 					W0 = W1; W1 = load_block(wblk + 1);
 				}
-				const uint32_t qi = q - wblk * 64;                              // 0..63: dwords qi..qi+3 are in W0/W1
-				auto word = [&](uint32_t i) -> uint32_t {
-					i = __builtin_amdgcn_readfirstlane(i);
+				const uint32_t qi = __builtin_amdgcn_readfirstlane(q - wblk * 64);      // 0..63: dwords qi..qi+4 are in W0/W1
+				auto word = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
 					return i < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)i) : (uint32_t)__builtin_amdgcn_readlane((int)W1, (int)(i - 64));
 				};
-				const uint32_t s0 = word(qi), s1 = word(qi + 1), s2 = word(qi + 2), s3 = word(qi + 3);
-				uint64_t lo = ((uint64_t)s1 << 32) | s0, hi = ((uint64_t)s2 << 32) | s1;   // bits [0,64) and [32,96) from pos
-				if (sh) { lo = (lo >> sh) | ((uint64_t)s2 << (64 - sh)); hi = (hi >> sh) | ((uint64_t)s3 << (64 - sh)); }
-				const uint32_t v = lane < 32 ? (uint32_t)(lo >> lane) : (uint32_t)(hi >> (lane - 32));
-				const uint32_t el = sm.hl.fast[v & ((1u << LBITS) - 1)];
-				const uint32_t ed = sm.hd.fast[v & ((1u << DBITS) - 1)];
-				auto bits_at = [&](uint32_t o) -> uint32_t { return o < 32 ? (uint32_t)(lo >> o) : (uint32_t)(hi >> (o - 32)); };
-				// bits of a literal token at this lane's offset, 0 when something else starts here
-				const uint32_t nbl = (el && (el & 0xfff) < 256) ? el >> 12 : 0;
+				const uint32_t s0 = word(qi), s1 = word(qi + 1), s2 = word(qi + 2), s3 = word(qi + 3), s4 = word(qi + 4);
+				// this lane's 64 bits of the source: [pos + lane, pos + lane + 64)
+				const uint32_t bo = sh + (uint32_t)lane, di = bo >> 5, r = bo & 31;        // di = 0..2
+				const uint32_t a0 = di == 0 ? s0 : di == 1 ? s1 : s2;
+				const uint32_t a1 = di == 0 ? s1 : di == 1 ? s2 : s3;
+				const uint32_t a2 = di == 0 ? s2 : di == 1 ? s3 : s4;
+				const uint32_t w0 = __builtin_amdgcn_alignbit(a1, a0, r), w1 = __builtin_amdgcn_alignbit(a2, a1, r);
+				// the whole token that would start at this lane's bit: literal, or length + distance
+				const uint32_t el = sm.hl.fast[w0 & ((1u << LBITS) - 1)];
+				const uint32_t nb = el >> 12, sym = el & 0xfff;
+				const bool islit = el && sym < 256;
+				const bool islen = sym > 256 && sym < 257 + 29;
+				uint32_t lbase, eb, dbase, ebd;
+				len_params(islen ? sym - 257 : 0, lbase, eb);
+				const uint32_t mlen = lbase + (__builtin_amdgcn_alignbit(w1, w0, nb) & ((1u << eb) - 1));
+				const uint32_t o2 = nb + eb;                                               // <= 11 + 5
+				const uint32_t ed = sm.hd.fast[__builtin_amdgcn_alignbit(w1, w0, o2) & ((1u << DBITS) - 1)];
+				const uint32_t ds = ed & 0xfff;
+				const bool okd = ed && ds < 30;
+				dist_params(okd ? ds : 0, dbase, ebd);
+				const uint32_t o3 = o2 + (ed >> 12);                                       // <= 16 + 9
+				const uint32_t mdist = dbase + (__builtin_amdgcn_alignbit(w1, w0, o3) & ((1u << ebd) - 1));
+				const uint32_t tl = islit ? nb : (islen && okd) ? o3 + ebd : 0;            // bits of the token; 0: not for this step
+				const uint32_t ob = islit ? 1 : mlen;                                      // bytes it makes
 				IPROF(2);
 #ifdef NXZ_INFLATE_PROF
 				const uint32_t out0 = out;
 #endif
+				// the chain of real token starts
+				// (four links at a time without a branch: a link that meets the end of the chain -- a token that is
+				// not for this step, or the end of the lanes -- stays where it is)
 				uint32_t off = 0;
+				uint64_t starts = 0;
 				for (;;) {
-					// a run of literals: follow the chain of token starts without branching (each step
-					// stays put once it meets a non-literal), then all of them are written at once
-					uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)nbl, (int)__builtin_amdgcn_readfirstlane(off));
-					if (e0) {
-						uint64_t starts = 0;
-						uint32_t o = off;
+					uint32_t t = 0;
 #pragma unroll
-						for (int k = 0; k < 8; k++) {
-							uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)nbl, (int)__builtin_amdgcn_readfirstlane(o & 63));
-							e = o < 64 ? e : 0;
-							starts |= (uint64_t)((e + 15) >> 4) << (o & 63);      // e is 0..15: 1 for a literal, in scalar arithmetic
-							o += e;
-						}
-						const uint32_t nlit = (uint32_t)__builtin_popcountll(starts);
-						if (nlit > cap - out) break;                                // target nearly full: one-token path
-						if ((starts >> lane) & 1) {
-							const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0));
-							wr(out + rank, el & 0xff);
-						}
-						out += nlit; off = o;
-						if (off > 47 || out - flushed >= FLUSH) break;
+					for (int u = 0; u < 4; u++) {
+						t = (uint32_t)__builtin_amdgcn_readlane((int)tl, (int)(off & 63));
+						t = off < 64 ? t : 0;
+						starts |= (uint64_t)(t != 0) << (off & 63);
+						off += t;
 					}
-					const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)el, (int)__builtin_amdgcn_readfirstlane(off));
-					if (!e) break;                                              // a long code: one-token path
-					const uint32_t nb = e >> 12, sym = e & 0xfff;
-					if (sym < 256) continue;                                    // the run above stopped at its step limit
-					if (sym == 256 || sym >= 257 + 29) break;                   // end of block / bad symbol
-					uint32_t lbase, eb, dbase, ebd;
-					len_params(sym - 257, lbase, eb);
-					const uint32_t o1 = off + nb;
-					const uint32_t len = lbase + (bits_at(o1) & ((1u << eb) - 1));
-					const uint32_t o2 = o1 + eb;                                // <= 47 + 11 + 5
-					const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)ed, (int)__builtin_amdgcn_readfirstlane(o2));
-					if (!d) break;
-					const uint32_t ds = d & 0xfff;
-					if (ds >= 30) break;
-					dist_params(ds, dbase, ebd);
-					const uint32_t o3 = o2 + (d >> 12);
-					const uint32_t dist = dbase + (bits_at(o3) & ((1u << ebd) - 1));
-					if (dist > out + hist || dist > WIN || len > cap - out) break;
-					copy_match(dist, len);
-					out += len; off = o3 + ebd;                                 // <= 63 + 9 + 13 < 96
-					if (off > 47 || out - flushed >= FLUSH) break;
+					if (!t || off > 63) break;
 				}
+				if (!starts) break;
+				// where each token writes: prefix sum of the byte counts over the token starts
+				bool isstart = (starts >> lane) & 1;
+				const uint32_t x = isstart ? ob : 0;
+				uint32_t incl = x;
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);   // row_shr:1
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);   // row_shr:2
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);   // row_shr:4
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);   // row_shr:8
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);   // row_bcast:15
+				incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);   // row_bcast:31
+				const uint32_t opos = incl - x;
+				// a token that does not fit the target, or a match that reaches in front of the history: the step
+				// ends before it (the one-token path says what is wrong)
+				const uint64_t bad = __ballot(isstart && (incl > cap - out || (!islit && mdist > out + opos + hist)));
+				if (bad) {
+					const uint32_t first = (uint32_t)__builtin_ctzll(bad);
+					starts &= (1ull << first) - 1;
+					off = first;
+					if (!starts) break;
+					isstart = (starts >> lane) & 1;
+				}
+				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(63 - __builtin_clzll(starts)));
+				const uint64_t lits = __ballot(islit);
+				// All literals of the step go out at once, then the matches in order.  In the circular LDS window
+				// a literal written ahead of its turn may land on the slot of a byte, nearly 32 KiB back, that a
+				// match in front of it still has to read: such a step (rare) is done token by token.
+				const bool ordered = !GW && __ballot(isstart && !islit && mdist + total > WIN) != 0;
+				if (!ordered && isstart && islit) wr(out + opos, sym);
+				uint64_t mm = ordered ? starts : starts & ~lits;
+				// up to four short matches whose sources lie in front of the whole step: all their loads, then
+				// all their stores -- one trip to the window instead of one per match
+				if (!ordered && mm && __builtin_popcountll(mm) <= 4 && !__ballot(isstart && !islit && (ob > 64 || mdist < opos + ob))) {
+					uint32_t mp[4], mn[4], mv[4];
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						mp[k] = 0; mn[k] = 0; mv[k] = 0;
+						if (mm) {
+							const uint32_t l = (uint32_t)__builtin_ctzll(mm);
+							mm &= mm - 1;
+							mp[k] = out + (uint32_t)__builtin_amdgcn_readlane((int)opos, (int)l);
+							mn[k] = (uint32_t)__builtin_amdgcn_readlane((int)ob, (int)l);
+							const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mdist, (int)l);
+							if ((uint32_t)lane < mn[k]) mv[k] = rd(mp[k] - d + lane, mp[k]);
+						}
+					}
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						if ((uint32_t)lane < mn[k]) wr(mp[k] + lane, mv[k]);
+				}
+				while (mm) {
+					const uint32_t l = (uint32_t)__builtin_ctzll(mm);
+					mm &= mm - 1;
+					if ((lits >> l) & 1) { if ((uint32_t)lane == l) wr(out + opos, sym); continue; }
+					copy_match(out + (uint32_t)__builtin_amdgcn_readlane((int)opos, (int)l), (uint32_t)__builtin_amdgcn_readlane((int)mdist, (int)l),
+						   (uint32_t)__builtin_amdgcn_readlane((int)ob, (int)l));
+				}
+				out += total;
 				IPROF(3);
 				ICOUNT(4, 1); ICOUNT(5, out - out0); ICOUNT(6, off);
-				if (!off) break;
 				b.pos += off;
 				if (out - flushed >= FLUSH) break;
 			}
@@ -672,7 +705,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 				b.bb_drop(eb);
 				if (dist > out + hist || dist > WIN) { cc = NXZ_CC_INVALID_DIST; break; }
 				if (len > cap - out) { cc = NXZ_CC_TARGET_SPACE; break; }
-				copy_match(dist, len);
+				copy_match(out, dist, len);
 				out += len;
 			}
 			if (out - flushed >= FLUSH) { __syncthreads(); flush(flushed + FLUSH); }
