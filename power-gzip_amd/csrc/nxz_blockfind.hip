@@ -125,19 +125,32 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 	__syncthreads();
 	const uint32_t limit = have * 8;
 	const uint32_t nbits = (have < SEG ? have : SEG) * 8;
-	// phase 1: the cheap part of the test at every bit position of the segment
+	// phase 1: the cheap part of the test at every bit position of the segment.  Consecutive lanes test
+	// consecutive positions, so the four dwords a lane needs (96 bits from its position: header fields
+	// and up to 19 three-bit lengths) are the same LDS words for 32 lanes: broadcast reads, no conflicts.
+	const uint32_t *s32 = (const uint32_t *)s;
 	for (uint32_t p = t; p < nbits; p += NT) {
 		if (base * 8 + p < first_bit) continue;
 		if (p + 17 > limit) break;
-		const uint32_t v = peek(s, p, 17);
+		const uint32_t wi = p >> 5, sh = p & 31;
+		const uint32_t d0 = s32[wi], d1 = s32[wi + 1], d2 = s32[wi + 2], d3 = s32[wi + 3];
+		const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), mid = __builtin_amdgcn_alignbit(d2, d1, sh), hi = __builtin_amdgcn_alignbit(d3, d2, sh);
 		// BFINAL 0, BTYPE 10 (bits 1..2 = 0b10 -> value 2), HLIT <= 29, HDIST <= 29
-		if ((v & 7) != 4 || ((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) continue;
-		const uint32_t hclen = ((v >> 13) & 15) + 4;
+		if ((lo & 7) != 4 || ((lo >> 3) & 31) > 29 || ((lo >> 8) & 31) > 29) continue;
+		const uint32_t hclen = ((lo >> 13) & 15) + 4;
 		if (p + 17 + 3 * hclen > limit) continue;
-		uint32_t kraft = 0, q = p + 17;
-		for (uint32_t i = 0; i < hclen; i++, q += 3) {
-			const uint32_t l = peek(s, q, 3);
-			kraft += l ? 128u >> l : 0;
+		const uint64_t x = (((uint64_t)mid << 32) | lo) >> 17;        // lengths 0..14 (in the order they are sent)
+		const uint32_t y = (uint32_t)((((uint64_t)hi << 32) | mid) >> 30);   // lengths 15..18
+		uint32_t kraft = 0;
+#pragma unroll
+		for (uint32_t i = 0; i < 15; i++) {
+			const uint32_t l = (uint32_t)(x >> (3 * i)) & 7;
+			kraft += (i < hclen && l) ? 128u >> l : 0;
+		}
+#pragma unroll
+		for (uint32_t i = 15; i < 19; i++) {
+			const uint32_t l = (y >> (3 * (i - 15))) & 7;
+			kraft += (i < hclen && l) ? 128u >> l : 0;
 		}
 		if (kraft != 128) continue;
 		const uint32_t k = atomicAdd(&ncand, 1u);
@@ -227,27 +240,33 @@ __global__ __launch_bounds__(256) void tailmap_kernel(const Piece *__restrict__ 
 	}
 }
 
-// One workgroup walks the pieces in order and writes, for each, the 32 KiB window BEHIND it
-// (= the history of the next one): windows[i * 32768 ..].  win0 = the window in front of piece 0.
-// A thread owns 32 consecutive entries; the next piece's map is on its way while this one is applied.
-__global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__restrict__ maps, uint32_t n, const uint8_t *__restrict__ win0,
-							     uint8_t *__restrict__ windows)
+// A workgroup walks `per` pieces in order (workgroup g: pieces g * per ...) and writes, for each, the
+// 32 KiB window BEHIND it (= the history of the next one): windows[i * 32768 ..].  The window in front
+// of workgroup g's first piece is win0 for g = 0, else front[(g - 1) * 32768 ..].  A thread owns 32
+// consecutive entries; the next piece's map is on its way while this one is applied.
+// Used three ways (nxz_launch_window_chain): one workgroup over all pieces when they are few; else
+// over the composed maps of the groups (windows behind the groups), then a workgroup per group.
+__global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__restrict__ maps, uint32_t n, uint32_t per, const uint8_t *__restrict__ win0,
+							     const uint8_t *__restrict__ front, uint8_t *__restrict__ windows)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t w[2][32768];
 	typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 	const int t = threadIdx.x;
-	for (uint32_t k = t; k < 32768 / 16; k += 1024) ((uint4 *)w[0])[k] = ((const uint4 *)win0)[k];
+	const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+	if (lo >= hi) return;
+	const uint8_t *wf = blockIdx.x ? front + (size_t)(blockIdx.x - 1) * 32768 : win0;
+	for (uint32_t k = t; k < 32768 / 16; k += 1024) ((uint4 *)w[0])[k] = ((const uint4 *)wf)[k];
 	__syncthreads();
 	uint32_t cur = 0;
 	const v4u NXZ_GLOBAL_AS *mp = (const v4u NXZ_GLOBAL_AS *)maps;
 	v4u nx[4];
 #pragma unroll
-	for (int q = 0; q < 4; q++) nx[q] = mp[(size_t)0 * 4096 + t * 4 + q];
-	for (uint32_t i = 0; i < n; i++) {
+	for (int q = 0; q < 4; q++) nx[q] = mp[(size_t)lo * 4096 + t * 4 + q];
+	for (uint32_t i = lo; i < hi; i++) {
 		v4u m[4];
 #pragma unroll
 		for (int q = 0; q < 4; q++) m[q] = nx[q];
-		if (i + 1 < n) {
+		if (i + 1 < hi) {
 #pragma unroll
 			for (int q = 0; q < 4; q++) nx[q] = mp[(size_t)(i + 1) * 4096 + t * 4 + q];
 		}
@@ -258,8 +277,8 @@ __global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__re
 			const uint32_t d[4] = { m[q].x, m[q].y, m[q].z, m[q].w };
 #pragma unroll
 			for (int e = 0; e < 4; e++) {
-				const uint32_t lo = d[e] & 0xffff, hi = d[e] >> 16;
-				const uint32_t b0 = (lo & 0x8000) ? wi[lo & 0x7fff] : lo, b1 = (hi & 0x8000) ? wi[hi & 0x7fff] : hi;
+				const uint32_t lo16 = d[e] & 0xffff, hi16 = d[e] >> 16;
+				const uint32_t b0 = (lo16 & 0x8000) ? wi[lo16 & 0x7fff] : lo16, b1 = (hi16 & 0x8000) ? wi[hi16 & 0x7fff] : hi16;
 				const uint32_t idx = q * 8 + e * 2;              // entry pair within my 32
 				out[idx >> 2] = (idx & 2) ? out[idx >> 2] | b0 << 16 | b1 << 24 : b0 | b1 << 8;
 			}
@@ -273,6 +292,45 @@ __global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__re
 		__syncthreads();
 		cur ^= 1;
 	}
+}
+
+// The maps of `per` consecutive pieces composed into one: what the window behind the group is, as a
+// function of the window in front of it (entries as in a tail map).  A workgroup per group.
+__global__ __launch_bounds__(1024) void compose_maps_kernel(const uint16_t *__restrict__ maps, uint32_t n, uint32_t per, uint16_t *__restrict__ gmaps)
+{
+	__shared__ __attribute__((aligned(16))) uint16_t c[2][32768];
+	typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+	const int t = threadIdx.x;
+	const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+	if (lo >= hi) return;
+	for (uint32_t k = t; k < 32768; k += 1024) c[0][k] = (uint16_t)(0x8000u | k);
+	__syncthreads();
+	uint32_t cur = 0;
+	const v4u NXZ_GLOBAL_AS *mp = (const v4u NXZ_GLOBAL_AS *)maps;
+	for (uint32_t i = lo; i < hi; i++) {
+		const uint16_t *ci = c[cur];
+		uint32_t out[16];
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const v4u m = mp[(size_t)i * 4096 + t * 4 + q];
+			const uint32_t d[4] = { m.x, m.y, m.z, m.w };
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				const uint32_t lo16 = d[e] & 0xffff, hi16 = d[e] >> 16;
+				const uint32_t v0 = (lo16 & 0x8000) ? ci[lo16 & 0x7fff] : lo16, v1 = (hi16 & 0x8000) ? ci[hi16 & 0x7fff] : hi16;
+				out[q * 4 + e] = v0 | v1 << 16;
+			}
+		}
+		uint4 *co = (uint4 *)(c[cur ^ 1] + 32 * t);
+#pragma unroll
+		for (int q = 0; q < 4; q++) co[q] = make_uint4(out[q * 4], out[q * 4 + 1], out[q * 4 + 2], out[q * 4 + 3]);
+		__syncthreads();
+		cur ^= 1;
+	}
+	v4u NXZ_GLOBAL_AS *g = (v4u NXZ_GLOBAL_AS *)(gmaps + (size_t)blockIdx.x * 32768);
+	const uint4 *cf = (const uint4 *)(c[cur] + 32 * t);
+#pragma unroll
+	for (int q = 0; q < 4; q++) { const uint4 v = cf[q]; g[t * 4 + q] = (v4u){ v.x, v.y, v.z, v.w }; }
 }
 
 // every piece to its place: final[place + o] = the byte, or the byte of its history it is a copy of
@@ -323,11 +381,23 @@ extern "C" int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t 
 	return (int)hipGetLastError();
 }
 
-extern "C" int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint16_t *maps, uint8_t *windows, hipStream_t stream)
+// group maps / group windows: room for nxz_window_chain_groups(n) maps (64 KiB each) and windows (32 KiB each)
+extern "C" uint32_t nxz_window_chain_group(void) { return 32; }
+extern "C" int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint16_t *maps, uint8_t *windows,
+				       uint16_t *gmaps, uint8_t *gwin, hipStream_t stream)
 {
 	if (!n) return 0;
+	const uint32_t per = nxz_window_chain_group(), ng = (n + per - 1) / per;
 	hipLaunchKernelGGL(nxzb::tailmap_kernel, dim3(n), dim3(256), 0, stream, (const nxzb::Piece *)pieces, n, maps);
-	hipLaunchKernelGGL(nxzb::window_chain_kernel, dim3(1), dim3(1024), 0, stream, (const uint16_t *)maps, n, win0, windows);
+	if (ng <= 2 || !gmaps || !gwin) {
+		hipLaunchKernelGGL(nxzb::window_chain_kernel, dim3(1), dim3(1024), 0, stream, (const uint16_t *)maps, n, n, win0, (const uint8_t *)nullptr, windows);
+		return (int)hipGetLastError();
+	}
+	// the groups' composed maps (all at once), the windows behind the groups (one walk over the groups),
+	// then every group's pieces from the window in front of the group (all groups at once)
+	hipLaunchKernelGGL(nxzb::compose_maps_kernel, dim3(ng), dim3(1024), 0, stream, (const uint16_t *)maps, n, per, gmaps);
+	hipLaunchKernelGGL(nxzb::window_chain_kernel, dim3(1), dim3(1024), 0, stream, (const uint16_t *)gmaps, ng, ng, win0, (const uint8_t *)nullptr, gwin);
+	hipLaunchKernelGGL(nxzb::window_chain_kernel, dim3(ng), dim3(1024), 0, stream, (const uint16_t *)maps, n, per, win0, (const uint8_t *)gwin, windows);
 	return (int)hipGetLastError();
 }
 

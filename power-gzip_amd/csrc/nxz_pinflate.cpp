@@ -35,7 +35,9 @@ extern "C" {
 uint32_t nxz_blockfind_segment(void);
 int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, hipStream_t stream);
 int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);
-int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint16_t *maps, uint8_t *windows, hipStream_t stream);
+uint32_t nxz_window_chain_group(void);
+int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint16_t *maps, uint8_t *windows,
+			    uint16_t *gmaps, uint8_t *gwin, hipStream_t stream);
 int nxz_launch_resolve(const void *pieces, uint32_t n, const uint8_t *win0, const uint8_t *windows, uint8_t *dst, hipStream_t stream);
 }
 
@@ -169,11 +171,12 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 	};
 	std::vector<P> pc(B.size());
 	for (size_t i = 0; i < B.size(); i++) { pc[i] = P(); pc[i].bit = B[i]; pc[i].capmul = 100; }   // buffer: 100 x the compressed size, 2 Mi elements at least
-	const size_t n0 = pc.size();
+	const size_t n0 = pc.size(), ng0 = n0 / nxz_window_chain_group() + 1;
 	// control arrays (sized for the first, longest list of pieces), then a bump area for copies and outputs
 	const size_t o_jobs = 0, o_res = o_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), o_items = o_res + up(n0 * sizeof(nxz_batch_result_t), 256),
 		     o_pieces = o_items + up((n0 + 4) * sizeof(CopyItem), 256), o_win0 = o_pieces + up(n0 * sizeof(Piece), 256),
-		     o_windows = o_win0 + WINDOW, o_maps = o_windows + n0 * (size_t)WINDOW, o_bump = o_maps + n0 * (size_t)WINDOW * 2;
+		     o_windows = o_win0 + WINDOW, o_maps = o_windows + n0 * (size_t)WINDOW, o_gmaps = o_maps + n0 * (size_t)WINDOW * 2,
+		     o_gwin = o_gmaps + ng0 * (size_t)WINDOW * 2, o_bump = o_gwin + ng0 * (size_t)WINDOW;
 	const size_t pin_jobs = 0, pin_res = pin_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), pin_items = pin_res + up(n0 * sizeof(nxz_batch_result_t), 256),
 		     pin_pieces = pin_items + up((n0 + 4) * sizeof(CopyItem), 256), pin_total = pin_pieces + up(n0 * sizeof(Piece), 256);
 	size_t bump = 0, reserved = 0;
@@ -304,7 +307,7 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 	if (total > dst_cap) return -E2BIG;
 	if (hipMemcpyAsync(d_pieces, h_pieces, n * sizeof(Piece), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 	const uint8_t *win0 = D + o_win0;
-	if (nxz_launch_window_chain(d_pieces, (uint32_t)n, win0, d_maps, d_windows, s)) return -EIO;
+	if (nxz_launch_window_chain(d_pieces, (uint32_t)n, win0, d_maps, d_windows, (uint16_t *)(D + o_gmaps), D + o_gwin, s)) return -EIO;
 	lap("tail maps + window chain");
 	if (nxz_launch_resolve(d_pieces, (uint32_t)n, win0, d_windows, dst, s)) return -EIO;
 	lap("resolve");
