@@ -327,10 +327,92 @@ def corpus_leg(torch, eng, pkg, args):
     if not args.no_inflate:
         out["inflate_zlib6"] = inflate_leg(torch, eng, pkg, raw, rep, args)
         out["inflate_stream"] = stream_leg(torch, eng, raw, args)
+    out["api"] = api_leg(raw, args)
     return out
 
 
-def stream_leg(torch, eng, raw, args, mib=64):
+def api_leg(raw, args, mib=128, nthreads=16):
+    """Through the reference's own API (libnxz_amd.so: nx_compress2 / nx_uncompress, HOST buffers, PCIe and
+    host copies inside the timed region): one call over `mib` MiB, and `nthreads` threads each compressing
+    64 KiB buffers one call after the other (the shape of the reference's samples/compdecomp_th.c)."""
+    import ctypes as C
+    import threading
+    import zlib
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import zstream as Z
+    L = Z.load("gpu")
+    base = b"".join(raw)
+    data = (base * ((mib << 20) // len(base) + 1))[:mib << 20]
+    out = {"note": "host buffers in, host buffers out; level 1 (no history between jobs, lib/nx_deflate.c:654-680)"}
+    cap = C.c_ulong(L.nx_compressBound(len(data)))
+    dst = C.create_string_buffer(cap.value)
+    best = 1e9
+    for it in range(4):
+        cap.value = len(dst)
+        t = time.perf_counter()
+        rc = L.nx_compress2(dst, C.byref(cap), data, len(data), 1)
+        dt = time.perf_counter() - t
+        if rc != 0:
+            return {"error": "nx_compress2 returned %d" % rc}
+        if it:
+            best = min(best, dt)
+    comp = dst.raw[:cap.value]
+    if zlib.decompress(comp) != data:
+        raise SystemExit("api leg: zlib does not read nx_compress2's stream back")
+    out["compress2_one_shot"] = {"value": round(len(data) / best / 2.0 ** 30, 2), "unit": "GiB/s uncompressed in", "MiB": mib,
+                                 "ms": round(best * 1e3, 2), "ratio": round(len(data) / len(comp), 3), "zlib_reads_it_back": True}
+    z6 = zlib.compress(data, 6)
+    back = C.create_string_buffer(len(data))
+    best = 1e9
+    for it in range(4):
+        n = C.c_ulong(len(data))
+        t = time.perf_counter()
+        rc = L.nx_uncompress(back, C.byref(n), z6, len(z6))
+        dt = time.perf_counter() - t
+        if rc != 0 or n.value != len(data):
+            return dict(out, error="nx_uncompress returned %d" % rc)
+        if it:
+            best = min(best, dt)
+    if back.raw != data:
+        raise SystemExit("api leg: nx_uncompress of a zlib -6 stream differs from the source")
+    out["uncompress_one_shot"] = {"value": round(len(data) / best / 2.0 ** 30, 2), "unit": "GiB/s uncompressed out", "MiB": mib,
+                                  "ms": round(best * 1e3, 2), "stream": "zlib level 6, one zlib stream"}
+    blocks = [data[i * BLOCK:(i + 1) * BLOCK] for i in range(min(1024, len(data) // BLOCK))]
+
+    def worker(res, k):
+        c = C.c_ulong()
+        d = C.create_string_buffer(L.nx_compressBound(BLOCK))
+        tot = 0
+        for b in blocks:
+            c.value = len(d)
+            if L.nx_compress2(d, C.byref(c), b, len(b), 1) != 0:
+                tot = -1
+                break
+            tot += c.value
+        res[k] = tot
+
+    for T in (1, nthreads):
+        res = [0] * T
+        th = [threading.Thread(target=worker, args=(res, k)) for k in range(T)]
+        t = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t
+        if min(res) < 0:
+            return dict(out, error="nx_compress2 failed in a thread")
+        out["threads_%d_x_64KiB" % T] = {"value": round(T * len(blocks) * BLOCK / dt / 2.0 ** 30, 3), "unit": "GiB/s uncompressed in, all threads",
+                                         "us_per_call": round(dt / len(blocks) * 1e6, 1), "calls_per_thread": len(blocks)}
+    if not args.no_cpu_baseline:
+        t = time.perf_counter()
+        zlib.compress(data[:32 << 20], 1)
+        out["cpu_baseline"] = {"value": round((32 << 20) / (time.perf_counter() - t) / 2.0 ** 30, 4), "unit": "GiB/s uncompressed in", "cores": 1,
+                               "kind": "reference", "what": "system zlib compress(level 1) of 32 MiB of the same data, one thread"}
+    return out
+
+
+def stream_leg(torch, eng, raw, args, mib=256):
     """BASELINE configs[3]: ONE zlib-made deflate stream (the corpus repeated to `mib` MiB, zlib -6),
     inflated by block-boundary speculation (nxz_inflate_stream), bit-exact check; zlib on one host
     thread beside it (a single stream does not spread over threads there either)."""
@@ -359,7 +441,7 @@ def stream_leg(torch, eng, raw, args, mib=64):
            "pieces": info["pieces"], "bit_exact": True,
            "roofline": {"bound": "hbm", "achieved": round((len(data) + len(comp)) / best / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round((len(data) + len(comp)) / best / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                        "kernel": "find_blocks + batched inflate (3 probe decodes per piece) + window chain + resolve, wall clock"}}
+                        "kernel": "find_blocks + inflate of the pieces into 16-bit elements + window chain + resolve + checksums, wall clock"}}
     if not args.no_cpu_baseline:
         t0 = time.perf_counter()
         zlib.decompress(comp, -15)

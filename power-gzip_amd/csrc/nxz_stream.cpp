@@ -712,17 +712,23 @@ bool parallel_inflate(Inflate *s)
 	nxz_ctx_t *ctx = (nxz_ctx_t *)s->eng.dev.paste_addr;
 	if (!ctx) return false;
 	const size_t nin = z->avail_in, cap = z->avail_out, nh = s->hist.size();
-	uint8_t *d_src = (uint8_t *)nxz_dev_malloc(ctx, nin + 64), *d_dst = (uint8_t *)nxz_dev_malloc(ctx, cap + 64);
-	uint8_t *d_hist = nh ? (uint8_t *)nxz_dev_malloc(ctx, nh) : nullptr;
+	// device buffers for the stream and its output: kept from call to call (grow only), one large call at a time
+	static std::mutex pool_mtx;
+	static uint8_t *pool_src = nullptr, *pool_dst = nullptr, *pool_hist = nullptr;
+	static size_t pool_src_cap = 0, pool_dst_cap = 0;
+	static nxz_ctx_t *pool_ctx = nullptr;
+	std::lock_guard<std::mutex> pool_guard(pool_mtx);
+	if (pool_ctx != ctx) { pool_src = pool_dst = pool_hist = nullptr; pool_src_cap = pool_dst_cap = 0; pool_ctx = ctx; }   // (a context that went away took its memory along)
+	if (pool_src_cap < nin + 64) { if (pool_src) nxz_dev_free(ctx, pool_src); pool_src = (uint8_t *)nxz_dev_malloc(ctx, nin + 64); pool_src_cap = pool_src ? nin + 64 : 0; }
+	if (pool_dst_cap < cap + 64) { if (pool_dst) nxz_dev_free(ctx, pool_dst); pool_dst = (uint8_t *)nxz_dev_malloc(ctx, cap + 64); pool_dst_cap = pool_dst ? cap + 64 : 0; }
+	if (!pool_hist) pool_hist = (uint8_t *)nxz_dev_malloc(ctx, WINDOW);
+	uint8_t *d_src = pool_src, *d_dst = pool_dst, *d_hist = nh ? pool_hist : nullptr;
 	bool ok = d_src && d_dst && (!nh || d_hist);
 	uint64_t out_len = 0, end_bit = 0;
 	uint32_t crc = 0, adler = 1;
 	if (ok) ok = nxz_copy_to_device(ctx, d_src, z->next_in, nin, nullptr) == 0 && (!nh || nxz_copy_to_device(ctx, d_hist, s->hist.data(), nh, nullptr) == 0);
 	if (ok) ok = nxz_inflate_stream(ctx, d_src, nin, 0, d_hist, (uint32_t)nh, d_dst, cap, &out_len, &crc, &adler, &end_bit, nullptr, nullptr, nullptr) == 0;
 	if (ok) ok = nxz_copy_to_host(ctx, z->next_out, d_dst, out_len, nullptr) == 0 && nxz_ctx_sync(ctx, nullptr) == 0;
-	if (d_src) nxz_dev_free(ctx, d_src);
-	if (d_dst) nxz_dev_free(ctx, d_dst);
-	if (d_hist) nxz_dev_free(ctx, d_hist);
 	if (!ok) return false;
 	const size_t consumed = (size_t)((end_bit + 7) / 8);
 	const uint8_t *outp = z->next_out;
