@@ -249,8 +249,11 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 		std::vector<P> nx;
 		nx.reserve(pc.size());
 		bool swallow = false;
+		uint64_t swallow_until = 0;
 		for (size_t i = 0; i < pc.size(); i++) {
-			if (swallow) { swallow = false; continue; }         // this piece's start was refuted: it goes into the piece in front (sized below)
+			// this piece's start was refuted: it goes into the piece in front (sized below); so do all starts
+			// inside a stored block that the piece in front was in the middle of
+			if (swallow || pc[i].bit < swallow_until) { swallow = false; continue; }
 			P p = pc[i];
 			const nxz_batch_result_t &r = p.res;
 			if (r.cc == NXZ_CC_TARGET_SPACE) {
@@ -271,6 +274,7 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 					// (or the data is bad, which the merged piece will report again)
 					if (r.cc != NXZ_CC_DATA_LENGTH && r.cc != 0 && i + 2 >= pc.size()) return -EILSEQ;
 					p.done = false; swallow = true;
+					if (r.cc == NXZ_CC_DATA_LENGTH && kind == 0x8) swallow_until = (p.cstart + p.cbytes) * 8 + (uint64_t)r.tebc * 8;
 					again = true;
 				}
 			}

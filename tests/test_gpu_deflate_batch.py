@@ -95,3 +95,34 @@ def test_dictionary_then_batch(L):
     out, _, _ = Z.deflate_all(L, data, level=-1, wbits=15, dictionary=dic)
     d = zlib.decompressobj(zdict=dic)
     assert d.decompress(out) == data
+
+
+def test_sixteen_threads_share_the_engine(L):
+    """T threads x one nx_compress2 / nx_uncompress call per 64 KiB buffer, all at once (the reference's
+    samples/compdecomp_th.c): callers that arrive together go out as one launch of each kernel
+    (nxz_engine.cpp round_submit); every thread must get its own bytes back."""
+    import threading
+    T, per = 16, 24
+    bufs = [[make_block(("alice", "lz", "text33", "random", "zeros")[(t + i) % 5], 65536 - 17 * i, 100 * t + i) for i in range(per)] for t in range(T)]
+    bad = []
+
+    def worker(t):
+        cap = C.c_ulong()
+        dst = C.create_string_buffer(L.nx_compressBound(65536))
+        back = C.create_string_buffer(65536)
+        for b in bufs[t]:
+            cap.value = len(dst)
+            if L.nx_compress2(dst, C.byref(cap), b, len(b), 1) != Z.Z_OK or zlib.decompress(dst.raw[:cap.value]) != b:
+                bad.append((t, "compress"))
+                return
+            n = C.c_ulong(65536)
+            if L.nx_uncompress(back, C.byref(n), dst.raw[:cap.value], cap.value) != Z.Z_OK or back.raw[:n.value] != b:
+                bad.append((t, "uncompress"))
+                return
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not bad, bad

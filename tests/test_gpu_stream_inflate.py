@@ -74,6 +74,22 @@ def test_stored_and_fixed_stretches_and_flush_points(eng, data):
     assert dst[:len(plain)].cpu().numpy().tobytes() == plain
 
 
+def test_a_block_header_that_is_not_one(eng, data):
+    """Deflate output carried as DATA inside the stream (it does not compress, so zlib stores it): the
+    stored bytes start with a perfectly good dynamic block header that is no block start.  The piece in
+    front of it does not end there, the start is dropped and only the merged piece is decoded again."""
+    c0 = zlib.compressobj(6, zlib.DEFLATED, -15)
+    inner = c0.compress(data[:1 << 20]) + c0.flush()          # a raw stream: its first bits are a dynamic block header
+    assert (inner[0] & 7) == 4                                 # BFINAL 0, BTYPE 10
+    plain = data[:5 << 20] + inner[:200000] + data[5 << 20:9 << 20] + inner[:70000] + data[9 << 20:12 << 20]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(plain) + c.flush()
+    rc, info, dst = _run(eng, comp, len(plain) + 4096)
+    assert rc == 0, (rc, info)
+    assert info["out_len"] == len(plain) and info["crc"] == zlib.crc32(plain)
+    assert dst[:len(plain)].cpu().numpy().tobytes() == plain
+
+
 def test_history_in_front_and_bit_offset(eng, data):
     """a stream that starts in the middle of a byte and refers to a preset dictionary"""
     dic = data[100000:100000 + 32768]
