@@ -40,6 +40,9 @@ __device__ unsigned long long *prof_buf = nullptr;
 #define ICOUNT(idx, v) do { } while (0)
 #endif
 
+// a value that is the same in all lanes but sits in a vector register: tell the compiler
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 constexpr uint32_t WIN = 32768, WMASK = WIN - 1;
 constexpr uint32_t FLUSH = 16384;
 constexpr uint32_t STAGE = 512;              // staged compressed bytes (one-token path and headers only)
@@ -65,7 +68,7 @@ struct SmemT {
 	Huff hl;
 	HuffD hd;
 	uint8_t lens[320];
-	uint32_t crctab[256];
+	uint8_t cl[32];
 };
 
 __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)
@@ -88,33 +91,42 @@ __device__ __forceinline__ uint32_t gf_xpow8(uint32_t n)   // x^(8n)
 }
 
 // Build the decode tables for `n` symbols with code lengths len[] (wave cooperative).
+// All of it by the whole wave: symbol i = row * 64 + lane; counts per length, first codes and the rank
+// of a symbol among those of its length come out of ballots (RFC 1951 3.2.2), every symbol then writes
+// its slots of the fast table and its place in the (length, symbol) order of the slow path.
 template <int FB, typename H>
 __device__ __forceinline__ void build(H &h, const uint8_t *len, int n, int lane)
 {
+	constexpr int ROWS = 5;                                          // n <= 288 + 32
+	const uint64_t below = (1ull << lane) - 1;
+	uint32_t l[ROWS], code[ROWS], place[ROWS];
+#pragma unroll
+	for (int r = 0; r < ROWS; r++) { const int i = r * 64 + lane; l[r] = i < n ? len[i] : 0; code[r] = 0; place[r] = 0; }
 	for (int i = lane; i < (1 << FB); i += 64) h.fast[i] = 0;
-	if (lane < 16) h.count[lane] = 0;
-	__syncthreads();
-	if (lane == 0) {
-		uint16_t offs[16];
-		for (int i = 0; i < n; i++) h.count[len[i]]++;
-		h.count[0] = 0;
-		offs[1] = 0;
-		for (int i = 1; i < 15; i++) offs[i + 1] = offs[i] + h.count[i];
-		for (int i = 0; i < n; i++) if (len[i]) h.sym[offs[len[i]]++] = (uint16_t)i;
+	uint32_t c = 0, prevcnt = 0, offs = 0;
+	for (uint32_t b = 1; b <= 15; b++) {
+		c = (c + prevcnt) << 1;
+		uint32_t run = 0;
+#pragma unroll
+		for (int r = 0; r < ROWS; r++) {
+			const uint64_t m = __ballot(l[r] == b);
+			const uint32_t k = run + (uint32_t)__popcll(m & below);
+			if (l[r] == b) { code[r] = c + k; place[r] = offs + k; }
+			run += (uint32_t)__popcll(m);
+		}
+		if (lane == 0) h.count[b] = (uint16_t)run;
+		prevcnt = run; offs += run;
 	}
+	if (lane == 0) h.count[0] = 0;
 	__syncthreads();
-	// canonical codes: next[l]; each lane recomputes (16 steps) then handles symbols lane, lane+64, ...
-	uint32_t next[16], c = 0;
-	for (int b = 1; b <= 15; b++) { c = (c + (b > 1 ? h.count[b - 1] : 0)) << 1; next[b] = c; }
-	// rank of symbol i among symbols of equal length = number of smaller symbols with that length
-	for (int i = lane; i < n; i += 64) {
-		uint32_t l = len[i];
-		if (l == 0 || l > (uint32_t)FB) continue;
-		uint32_t rank = 0;
-		for (int k = 0; k < i; k++) rank += (len[k] == l);
-		uint32_t code = next[l] + rank;
-		uint32_t rev = __builtin_bitreverse32(code) >> (32 - l);
-		for (uint32_t idx = rev; idx < (1u << FB); idx += (1u << l)) h.fast[idx] = (uint16_t)(i | (l << 12));
+#pragma unroll
+	for (int r = 0; r < ROWS; r++) {
+		const uint32_t i = r * 64 + lane;
+		if (!l[r]) continue;
+		h.sym[place[r]] = (uint16_t)i;
+		if (l[r] > (uint32_t)FB) continue;
+		const uint32_t rev = __builtin_bitreverse32(code[r]) >> (32 - l[r]);
+		for (uint32_t idx = rev; idx < (1u << FB); idx += (1u << l[r])) h.fast[idx] = (uint16_t)(i | (l[r] << 12));
 	}
 	__syncthreads();
 }
@@ -221,68 +233,116 @@ __device__ __forceinline__ int decode_sym(const H &h, uint32_t bits, uint32_t &n
 
 // Parse a dynamic block header at b.pos (after the 3 header bits).  Returns
 // 0 ok (lens filled, b.pos advanced, *tbits = table bits), 1 out of source, <0 invalid.
+// The header (at most 2283 bits) is taken into two registers per lane (lane k: dwords k and 64 + k
+// from the dword the header starts in; a copy in sm.stage for the one step where lanes read at
+// different places), so the serial part -- one code-length symbol after the other -- reads its bits
+// with v_readlane and looks the 7-bit code-length code up in two more registers: no LDS round trip
+// per symbol.  The code-length code's canonical codes come from ballots (lane = symbol).
 template <typename Smem>
 __device__ __forceinline__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist, uint32_t &tbits)
 {
-	const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
-	uint64_t start = b.pos;
+	const int lane = b.lane;
+	const uint64_t start = b.pos;
 	if (!b.have(14)) return 1;
-	uint32_t v = b.peek();
-	hlit = (v & 31) + 257; hdist = ((v >> 5) & 31) + 1;
-	int hclen = ((v >> 10) & 15) + 4;
-	b.pos += 14;
+	const uint32_t d0 = (uint32_t)(start >> 5);                       // first dword of the header
+	auto dword = [&](uint32_t idx) __attribute__((always_inline)) -> uint32_t {
+		const uint64_t byte = (uint64_t)idx * 4;
+		uint32_t w = 0;
+		if (byte + 4 <= b.srclen && ((uintptr_t)b.src & 3) == 0) w = ((const uint32_t *)b.src)[idx];
+		else for (uint32_t k = 0; k < 4 && byte + k < b.srclen; k++) w |= (uint32_t)b.src[byte + k] << (8 * k);
+		return w;
+	};
+	const uint32_t R0 = dword(d0 + lane), R1 = dword(d0 + 64 + lane);
+	__syncthreads();
+	sm.stage[lane] = R0; sm.stage[64 + lane] = R1;
+	b.stage_base = 0xffffffffu;                                       // (the stage no longer holds what Bits put there)
+	__syncthreads();
+	// up to 25 bits at bit p of the source (p >= start), wave-uniform
+	auto peek = [&](uint64_t p) __attribute__((always_inline)) -> uint32_t {
+		const uint32_t o = uni((uint32_t)(p - (uint64_t)d0 * 32)), i = o >> 5, sh = o & 31;
+		const uint32_t lo = i < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)R0, (int)i) : (uint32_t)__builtin_amdgcn_readlane((int)R1, (int)(i - 64));
+		const uint32_t j = i + 1;
+		const uint32_t hi = j < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)R0, (int)j) : (uint32_t)__builtin_amdgcn_readlane((int)R1, (int)(j & 63));
+		return (uint32_t)(((((uint64_t)hi << 32) | lo) >> sh));
+	};
+	uint32_t v = peek(start);
+	hlit = (int)(v & 31) + 257; hdist = (int)((v >> 5) & 31) + 1;
+	const int hclen = (int)((v >> 10) & 15) + 4;
+	uint64_t pos = start + 14;
 	if (hlit > 286 || hdist > 30) return -1;
-	uint8_t cl[19];
-	for (int i = 0; i < 19; i++) cl[i] = 0;
-	for (int i = 0; i < hclen; i++) {
-		if (!b.have(3)) return 1;
-		cl[order[i]] = (uint8_t)(b.peek() & 7);
-		b.pos += 3;
-	}
-	// canonical code-length code (<= 7 bits): tiny table in registers via bit-by-bit decode
-	uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kraft = 0;
-	for (int i = 0; i < 19; i++) cnt[cl[i]]++;
-	cnt[0] = 0;
-	for (int l = 1; l <= 7; l++) kraft += cnt[l] << (7 - l);
-	if (kraft > 128) return -2;
-	uint8_t sorted[19]; int ns = 0;
-	for (int l = 1; l <= 7; l++) for (int i = 0; i < 19; i++) if (cl[i] == l) sorted[ns++] = (uint8_t)i;
-	int n = 0, prev = 0;
-	while (n < hlit + hdist) {
-		if (!b.have(1)) return 1;
-		uint32_t bits = b.peek();
-		int code = 0, first = 0, index = 0, sym = -1, len;
-		for (len = 1; len <= 7; len++) {
-			code |= (int)(bits & 1); bits >>= 1;
-			int count = (int)cnt[len];
-			if (code - count < first) { sym = sorted[index + (code - first)]; break; }
-			index += count; first += count; first <<= 1; code <<= 1;
+	if (pos + 3 * (uint32_t)hclen > b.total_bits) return 1;
+	// the code-length code: lane i < hclen reads the i-th 3-bit length, which belongs to symbol order[i]
+	uint32_t myl = 0;
+	{
+		const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+		if (lane < 32) sm.cl[lane] = 0;
+		__syncthreads();
+		if (lane < hclen) {
+			const uint32_t o = (uint32_t)(pos - (uint64_t)d0 * 32) + 3 * (uint32_t)lane;
+			const uint64_t w = (uint64_t)sm.stage[o >> 5] | ((uint64_t)sm.stage[(o >> 5) + 1] << 32);
+			sm.cl[order[lane]] = (uint8_t)((w >> (o & 31)) & 7);
 		}
-		if (sym < 0) return b.have(7) ? -3 : 1;
-		if (!b.have((uint32_t)len)) return 1;
-		b.pos += len;
-		if (sym < 16) { if (b.lane == 0) sm.lens[n] = (uint8_t)sym; n++; prev = sym; }
+		__syncthreads();
+		myl = lane < 19 ? sm.cl[lane] : 0;
+	}
+	pos += 3 * (uint32_t)hclen;
+	// canonical codes by ranks (lane = symbol), then the look-up: entries `lane` and `lane + 64` of the
+	// 7-bit table, symbol | length << 5, 0xff = no code
+	uint32_t tlo = 0xff, thi = 0xff;
+	{
+		uint32_t c = 0, prevcnt = 0, kraft = 0, mycode = 0;
+		for (uint32_t bl = 1; bl <= 7; bl++) {
+			c = (c + prevcnt) << 1;
+			const uint64_t m = __ballot(myl == bl);
+			if (myl == bl) mycode = c + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+			prevcnt = (uint32_t)__popcll(m);
+			kraft += prevcnt << (7 - bl);
+		}
+		if (kraft > 128) return -2;
+		const uint32_t myrev = myl ? __builtin_bitreverse32(mycode) >> (32 - myl) : 0;
+		for (int sy = 0; sy < 19; sy++) {
+			const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)myl, sy);
+			if (!l) continue;
+			const uint32_t rev = (uint32_t)__builtin_amdgcn_readlane((int)myrev, sy), mask = (1u << l) - 1;
+			if (((uint32_t)lane & mask) == rev) tlo = (uint32_t)sy | (l << 5);
+			if ((((uint32_t)lane + 64) & mask) == rev) thi = (uint32_t)sy | (l << 5);
+		}
+	}
+	int n = 0, prev = 0;
+	const int total = hlit + hdist;
+	while (n < total) {
+		if (pos + 1 > b.total_bits) return 1;
+		const uint32_t bits = peek(pos);
+		const uint32_t k = bits & 127;
+		const uint32_t e = k < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)tlo, (int)k) : (uint32_t)__builtin_amdgcn_readlane((int)thi, (int)(k - 64));
+		if (e == 0xff) return pos + 7 <= b.total_bits ? -3 : 1;
+		const int sym = (int)(e & 31), len = (int)(e >> 5);
+		if (pos + (uint32_t)len > b.total_bits) return 1;
+		pos += (uint32_t)len;
+		if (sym < 16) { if (lane == 0) sm.lens[n] = (uint8_t)sym; n++; prev = sym; }
 		else {
-			int eb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
-			if (!b.have((uint32_t)eb)) return 1;
-			int rep = (int)(b.peek() & ((1u << eb) - 1)) + (sym == 18 ? 11 : 3);
-			b.pos += eb;
+			const int eb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
+			if (pos + (uint32_t)eb > b.total_bits) return 1;
+			const int rep = (int)((bits >> len) & ((1u << eb) - 1)) + (sym == 18 ? 11 : 3);
+			pos += (uint32_t)eb;
 			int val = 0;
 			if (sym == 16) { if (n == 0) return -4; val = prev; }
-			if (n + rep > hlit + hdist) return -5;
-			if (b.lane == 0) for (int k = 0; k < rep; k++) sm.lens[n + k] = (uint8_t)val;
+			if (n + rep > total) return -5;
+			for (int q = lane; q < rep; q += 64) sm.lens[n + q] = (uint8_t)val;
 			n += rep;
 			if (sym != 16) prev = 0;
 		}
 	}
-	tbits = (uint32_t)(b.pos - start);
+	b.pos = pos;
+	tbits = (uint32_t)(pos - start);
 	__syncthreads();
-	if (sm.lens[256] == 0) return -6;
-	// over-subscription check (lane 0 could do it; uniform loop is short enough)
+	if (uni(sm.lens[256]) == 0) return -6;
+	// over-subscription check: lane per symbol
 	uint32_t k1 = 0, k2 = 0;
-	for (int i = 0; i < hlit; i++) if (sm.lens[i]) k1 += 1u << (15 - sm.lens[i]);
-	for (int i = 0; i < hdist; i++) if (sm.lens[hlit + i]) k2 += 1u << (15 - sm.lens[hlit + i]);
-	if (k1 > (1u << 15) || k2 > (1u << 15)) return -7;
+	for (int i = lane; i < hlit; i += 64) if (sm.lens[i]) k1 += 1u << (15 - sm.lens[i]);
+	if (lane < hdist && sm.lens[hlit + lane]) k2 = 1u << (15 - sm.lens[hlit + lane]);
+	for (int o = 32; o > 0; o >>= 1) { k1 += __shfl_xor(k1, o, 64); k2 += __shfl_xor(k2, o, 64); }
+	if (uni(k1) > (1u << 15) || uni(k2) > (1u << 15)) return -7;
 	return 0;
 }
 
@@ -353,14 +413,9 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 #ifdef NXZ_INFLATE_PROF
 	unsigned long long *prof = prof_buf;
 	unsigned long long tprev = prof ? clock64() : 0;
-	unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
-	for (int i = lane; i < 256; i += 64) {
-		uint32_t c = i;
-		for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1) ? 0xedb88320u : 0);
-		sm.crctab[i] = c;
-	}
 	// history (the last <= 32 KiB before the output) goes into the window just below position 0
 	{
 		uint32_t h = hist_bytes > WIN ? WIN : hist_bytes;
@@ -385,33 +440,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	// flush window bytes [flushed, upto) to dst and fold them into the checksums
 	auto flush = [&](uint32_t upto) {
 		IPROF(0);
-		if (GW) { flushed = upto; return; }              // the bytes are in place; nxzl::cksum_kernel sums them afterwards
+		if (GW) { flushed = upto; return; }              // the bytes are in place
+		// (checksums: nxzl::cksum_kernel over the finished output, for both forms of the window -- a lane
+		// walking its 256 bytes through a table costs the wave 80 K cycles per 16 KiB, the kernel 1 K)
 		while (flushed < upto) {
 			uint32_t n = upto - flushed < FLUSH ? upto - flushed : FLUSH;
-			// right-aligned frame of 64 x 256 B slices
-			uint32_t pad = FLUSH - n, lo = lane * 256, hi = lo + 256;
-			uint32_t c = 0, s1 = 0, s2w = 0;
-			if (hi > pad) {
-				for (uint32_t f = lo > pad ? lo : pad; f < hi; f++) {
-					uint32_t i = f - pad;
-					uint32_t byte = sm.win[(flushed + i) & WMASK];
-					c = sm.crctab[(c ^ byte) & 0xff] ^ (c >> 8);
-					s1 += byte; s2w += byte * (n - i);
-				}
-			}
-			uint32_t mult = gf_xpow8(256);
-			for (int o = 1; o < 64; o <<= 1) {
-				uint32_t right = __shfl_down(c, o, 64);
-				if ((lane & (2 * o - 1)) == 0) c = gf_mul(c, mult) ^ right;
-				mult = gf_mul(mult, mult);
-			}
-			c = __shfl(c, 0, 64);
-			uint32_t t1 = s1, t2 = s2w % 65521u;
-			for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_down(t1, o, 64); t2 += __shfl_down(t2, o, 64); }
-			t1 = __shfl(t1, 0, 64); t2 = __shfl(t2, 0, 64);
-			crc_state = gf_mul(crc_state, n == FLUSH ? mult : gf_xpow8(n)) ^ c;   // mult == x^(8*16384) after the tree
-			ad2 = (uint32_t)((ad2 + (uint64_t)n * ad1 + t2) % 65521u);
-			ad1 = (ad1 + t1) % 65521u;
 			// coalesced copy out (dst + flushed is 16 B aligned when flushed is a multiple of FLUSH)
 			for (uint32_t i = lane * 16; i < n; i += 64 * 16) {
 				if (i + 16 <= n) {
@@ -596,6 +629,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 					if (!t || off > 63) break;
 				}
 				if (!starts) break;
+				IPROF(8);
 				// where each token writes: prefix sum of the byte counts over the token starts
 				bool isstart = (starts >> lane) & 1;
 				const uint32_t x = isstart ? ob : 0;
@@ -618,6 +652,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 					isstart = (starts >> lane) & 1;
 				}
 				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(63 - __builtin_clzll(starts)));
+				IPROF(9);
 				const uint64_t lits = __ballot(islit);
 				// All literals of the step go out at once, then the matches in order.  In the circular LDS window
 				// a literal written ahead of its turn may land on the slot of a byte, nearly 32 KiB back, that a
@@ -717,7 +752,7 @@ done:
 	if (cc == 0) flush(out);
 	IPROF(0);
 #ifdef NXZ_INFLATE_PROF
-	if (prof && lane == 0) for (int k = 0; k < 8; k++) __hip_atomic_fetch_add(&prof[k], pacc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (prof && lane == 0) for (int k = 0; k < 12; k++) __hip_atomic_fetch_add(&prof[k], pacc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 	if (lane == 0) {
 		nxz_batch_result_t r;
@@ -743,17 +778,14 @@ extern "C" int nxz_inflate_prof_set(unsigned long long *buf)
 }
 
 // window_in_lds != 0: the 39.5 KiB variant (4 streams per CU, matches never leave LDS: the lower latency
-// for one job or one round of jobs); 0: the window is the target itself (16 streams per CU), checksums
+// for one job or one round of jobs); 0: the window is the target itself (16 streams per CU).  Checksums
 // by nxzl::cksum_kernel afterwards.
 extern "C" int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 				  nxz_batch_dht_t *dht_io, int window_in_lds, hipStream_t stream)
 {
 	if (!n) return 0;
-	if (window_in_lds) {
-		hipLaunchKernelGGL(nxzi::inflate_kernel<false>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
-		return (int)hipGetLastError();
-	}
-	hipLaunchKernelGGL(nxzi::inflate_kernel<true>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
+	if (window_in_lds) hipLaunchKernelGGL(nxzi::inflate_kernel<false>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
+	else hipLaunchKernelGGL(nxzi::inflate_kernel<true>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
 	int rc = (int)hipGetLastError();
 	return rc ? rc : nxz_launch_cksum(jobs, n, results, stream);
 }
