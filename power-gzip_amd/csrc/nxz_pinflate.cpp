@@ -250,38 +250,53 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 		nx.reserve(pc.size());
 		bool swallow = false;
 		uint64_t swallow_until = 0;
+		// `confirmed`: the start of the piece under inspection is known to be a block start -- it is the
+		// first piece, or the piece in front is final and ends exactly there.  Only such a piece can say
+		// that the DATA is bad; an error in any other piece more likely means that its start is none
+		// (deflate output carried as data inside a stored block has block headers that fit each other).
+		bool confirmed = true;
 		for (size_t i = 0; i < pc.size(); i++) {
 			// this piece's start was refuted: it goes into the piece in front (sized below); so do all starts
 			// inside a stored block that the piece in front was in the middle of
 			if (swallow || pc[i].bit < swallow_until) { swallow = false; continue; }
 			P p = pc[i];
 			const nxz_batch_result_t &r = p.res;
+			const bool conf = confirmed;
 			if (r.cc == NXZ_CC_TARGET_SPACE) {
 				if (p.capmul >= 1032 * 2) return -ENOTSUP;
 				p.capmul *= 8; p.done = false;                     // same piece, more room
-				again = true;
+				again = true; confirmed = false;
 				nx.push_back(p);
 				continue;
 			}
+			const bool err = r.cc != NXZ_CC_DATA_LENGTH && r.cc != 0;
+			bool ends_well = !err;
 			if (i + 1 < pc.size()) {
 				const uint64_t used = p.cbytes * 8 - r.subc, want = pc[i + 1].bit - p.cstart * 8;
 				const uint32_t kind = r.sfbt & 0xe;
-				const bool at_header = r.cc == NXZ_CC_DATA_LENGTH && ((kind == 0xe && used == want) || (kind == 0xa && used == want + 3));
-				if (!at_header) {
-					if (trace) fprintf(stderr, "nxz_inflate_stream: piece %zu (bit %llu, %llu bytes in, %u out) cc %u sfbt %#x subc %u: used %llu bits, next header thought at %llu\n",
-							   i, (unsigned long long)p.bit, (unsigned long long)p.cbytes, r.tpbc, r.cc, r.sfbt, r.subc, (unsigned long long)used, (unsigned long long)want);
-					// the piece did not end where the next was thought to start: that start is wrong
-					// (or the data is bad, which the merged piece will report again)
-					if (r.cc != NXZ_CC_DATA_LENGTH && r.cc != 0 && i + 2 >= pc.size()) return -EILSEQ;
-					p.done = false; swallow = true;
-					if (r.cc == NXZ_CC_DATA_LENGTH && kind == 0x8) swallow_until = (p.cstart + p.cbytes) * 8 + (uint64_t)r.tebc * 8;
-					again = true;
-				}
+				ends_well = r.cc == NXZ_CC_DATA_LENGTH && ((kind == 0xe && used == want) || (kind == 0xa && used == want + 3));
+				if (!ends_well && trace)
+					fprintf(stderr, "nxz_inflate_stream: piece %zu (bit %llu, %llu bytes in, %u out, start %s) cc %u sfbt %#x subc %u: used %llu bits, next header thought at %llu\n",
+						i, (unsigned long long)p.bit, (unsigned long long)p.cbytes, r.tpbc, conf ? "confirmed" : "open", r.cc, r.sfbt, r.subc, (unsigned long long)used, (unsigned long long)want);
 			}
+			if (err) {
+				if (conf) return -EILSEQ;                          // a block that starts here is damaged
+				// not a block start after all: into the piece in front, which is decoded again
+				nx.back().done = false;
+				again = true; confirmed = false;
+				continue;
+			}
+			if (!ends_well) {
+				// the piece did not end where the next was thought to start: that start is wrong
+				p.done = false; swallow = true;
+				if ((r.sfbt & 0xe) == 0x8) swallow_until = (p.cstart + p.cbytes) * 8 + (uint64_t)r.tebc * 8;
+				again = true;
+			}
+			confirmed = conf && ends_well && p.done;
 			nx.push_back(p);
 		}
 		if (!again) break;
-		if (attempt >= 11 || nx.size() < 4) return -ENOTSUP;
+		if (attempt >= 23 || nx.size() < 4) return -ENOTSUP;
 		pc.swap(nx);
 		for (size_t i = 0; i < pc.size(); i++)
 			if (!pc[i].done && !size_piece(pc[i], i + 1 < pc.size() ? pc[i + 1].bit : 0)) return -ENOTSUP;

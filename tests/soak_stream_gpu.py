@@ -1,0 +1,64 @@
+"""Soak run (not collected by pytest): seeded random long deflate streams -- pieces of the corpus, of
+generated blocks, of random bytes and of nested deflate output, compressed piece after piece with
+random levels, strategies, memLevels and flush points into ONE raw stream of 2..12 MiB -- through
+nxz_inflate_stream; output and CRC-32 against zlib.  Streams the engine declines (-ENOTSUP) are
+counted, everything else must be exact.   python tests/soak_stream_gpu.py [cases]"""
+import importlib, os, random, sys, zlib
+import numpy as np
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import corpus
+from datagen import make_block
+pkg = importlib.import_module("power-gzip_amd")
+eng = pkg.Engine(0)
+_, blocks, _ = corpus.load(65536)
+raw = b"".join(b for _, _, b in blocks)
+kinds = ["zeros", "random", "text33", "alice", "lz", "periodic", "binary", "sparse"]
+strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY, zlib.Z_FIXED]
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+bad = declined = 0
+first = int(os.environ.get('SOAK_FIRST', '0'))
+for case in range(first, ncases):
+    rnd = random.Random(7919 * (case + 1))
+    target = rnd.randrange(2 << 20, 12 << 20)
+    plain, comp = [], b""
+    co = zlib.compressobj(rnd.randrange(1, 10), zlib.DEFLATED, -15, rnd.randrange(5, 10), rnd.choice(strategies))
+    size = 0
+    while size < target:
+        how = rnd.random()
+        n = rnd.randrange(1000, 900000)
+        if how < 0.55:
+            o = rnd.randrange(0, len(raw) - n)
+            d = raw[o:o + n]
+        elif how < 0.8:
+            d = b"".join(make_block(rnd.choice(kinds), min(65536, n - o), seed=case * 1000 + o) for o in range(0, n, 65536))
+        elif how < 0.9:
+            d = rnd.randbytes(n)
+        else:
+            d = zlib.compress(raw[:n * 3], 6)[:n]                      # deflate output as data: block headers that are none
+        plain.append(d); size += len(d)
+        comp += co.compress(d)
+        f = rnd.random()
+        if f < 0.15: comp += co.flush(zlib.Z_SYNC_FLUSH)
+        elif f < 0.25: comp += co.flush(zlib.Z_FULL_FLUSH)
+        elif f < 0.3:                                                   # another compressor continues the stream
+            comp += co.flush(zlib.Z_FULL_FLUSH)
+            co = zlib.compressobj(rnd.randrange(1, 10), zlib.DEFLATED, -15, rnd.randrange(5, 10), rnd.choice(strategies))
+    comp += co.flush()
+    plain = b"".join(plain)
+    src = torch.from_numpy(np.frombuffer(comp, np.uint8).copy()).to(eng.dev)
+    dst = torch.zeros(len(plain) + 4096, dtype=torch.uint8, device=eng.dev)
+    rc, info = eng.inflate_stream(src, len(comp), dst)
+    torch.cuda.synchronize()
+    if rc == -95:
+        declined += 1
+        continue
+    ok = rc == 0 and info["out_len"] == len(plain) and info["crc"] == zlib.crc32(plain) and dst[:len(plain)].cpu().numpy().tobytes() == plain
+    if not ok:
+        bad += 1
+        print("case %d: rc %d, %s, expected %d bytes" % (case, rc, info, len(plain)), flush=True)
+    if case % 10 == 9:
+        print("%d cases done: %d declined, %d bad" % (case + 1, declined, bad), flush=True)
+print("SOAK OK" if not bad else "SOAK FAILED", "(%d cases, %d declined)" % (ncases, declined))
+sys.exit(1 if bad else 0)
