@@ -331,7 +331,7 @@ def corpus_leg(torch, eng, pkg, args):
     return out
 
 
-def api_leg(raw, args, mib=128, nthreads=16):
+def api_leg(raw, args, mib=256, nthreads=16):
     """Through the reference's own API (libnxz_amd.so: nx_compress2 / nx_uncompress, HOST buffers, PCIe and
     host copies inside the timed region): one call over `mib` MiB, and `nthreads` threads each compressing
     64 KiB buffers one call after the other (the shape of the reference's samples/compdecomp_th.c)."""

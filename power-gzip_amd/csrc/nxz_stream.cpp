@@ -726,9 +726,17 @@ bool parallel_inflate(Inflate *s)
 	bool ok = d_src && d_dst && (!nh || d_hist);
 	uint64_t out_len = 0, end_bit = 0;
 	uint32_t crc = 0, adler = 1;
+	static const bool trace = getenv("NXZ_API_TRACE") != nullptr;
+	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = trace ? now() : 0;
 	if (ok) ok = nxz_copy_to_device(ctx, d_src, z->next_in, nin, nullptr) == 0 && (!nh || nxz_copy_to_device(ctx, d_hist, s->hist.data(), nh, nullptr) == 0);
+	if (ok && trace) (void)nxz_ctx_sync(ctx, nullptr);
+	const double t1 = trace ? now() : 0;
 	if (ok) ok = nxz_inflate_stream(ctx, d_src, nin, 0, d_hist, (uint32_t)nh, d_dst, cap, &out_len, &crc, &adler, &end_bit, nullptr, nullptr, nullptr) == 0;
+	const double t2 = trace ? now() : 0;
 	if (ok) ok = nxz_copy_to_host(ctx, z->next_out, d_dst, out_len, nullptr) == 0 && nxz_ctx_sync(ctx, nullptr) == 0;
+	if (trace) fprintf(stderr, "nxz parallel_inflate: %zu bytes in, copy in %.2f ms, inflate %.2f ms, copy out %.2f ms (%llu bytes)%s\n", nin, t1 - t0, t2 - t1, now() - t2,
+			   (unsigned long long)out_len, ok ? "" : " -- declined");
 	if (!ok) return false;
 	const size_t consumed = (size_t)((end_bit + 7) / 8);
 	const uint8_t *outp = z->next_out;
