@@ -66,7 +66,13 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
 			if (l) symtab[offs[l]++] = (uint8_t)sy;
 		}
 	}
-	uint32_t n = 0, prev = 0, kraft_ll = 0, kraft_d = 0, nd = 0, maxd = 0, eob = 0;
+	// every encoder trims the three counts to the last length that is not zero (zlib: build_bl_tree /
+	// send_all_trees; so do libdeflate, miniz, 7-zip, zopfli and this engine): a header whose last
+	// code-length-code length, last literal/length length or last distance length is zero although
+	// the count could have been smaller is taken for chance.  (A stream of an encoder that does not
+	// trim offers fewer starts here and is decoded in longer pieces, or job after job.)
+	if (hclen > 4 && ((cll >> (3 * order[hclen - 1])) & 7) == 0) return false;
+	uint32_t n = 0, prev = 0, kraft_ll = 0, kraft_d = 0, nd = 0, maxd = 0, eob = 0, last_ll = 0, last_d = 0;
 	const uint32_t total = hlit + hdist;
 	while (n < total) {
 		// one code-length symbol, bit by bit
@@ -96,13 +102,14 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
 		if (val) {
 			for (uint32_t k = 0; k < rep; k++) {
 				const uint32_t i = n + k;
-				if (i < hlit) { kraft_ll += 1u << (15 - val); if (i == 256) eob = 1; }
-				else { kraft_d += 1u << (15 - val); nd++; if (val > maxd) maxd = val; }
+				if (i < hlit) { kraft_ll += 1u << (15 - val); if (i == 256) eob = 1; if (i == hlit - 1) last_ll = 1; }
+				else { kraft_d += 1u << (15 - val); nd++; if (val > maxd) maxd = val; if (i == total - 1) last_d = 1; }
 			}
 		}
 		n += rep;
 	}
 	if (!eob || kraft_ll != (1u << 15)) return false;
+	if ((hlit > 257 && !last_ll) || (hdist > 1 && !last_d)) return false;
 	if (!(kraft_d == (1u << 15) || nd == 0 || (nd == 1 && maxd == 1))) return false;
 	return true;
 }

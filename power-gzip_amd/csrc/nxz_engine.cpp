@@ -211,6 +211,9 @@ extern "C" nxz_ctx_t *nxz_ctx_create(int device)
 	return c;
 }
 
+// (for the engine's other translation units: the HIP device of a context)
+extern "C" int nxz_ctx_device(nxz_ctx_t *c) { return c ? c->device : -1; }
+
 extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 {
 	if (!c || forked_child()) return;                     // the parent owns the device objects

@@ -35,6 +35,7 @@ extern "C" {
 uint32_t nxz_blockfind_segment(void);
 int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, hipStream_t stream);
 int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);
+int nxz_ctx_device(nxz_ctx_t *c);
 uint32_t nxz_window_chain_group(void);
 int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint16_t *maps, uint8_t *windows,
 			    uint16_t *gmaps, uint8_t *gwin, hipStream_t stream);
@@ -125,9 +126,8 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 {
 	if (!c || !src || !dst || !out_len) return -EINVAL;
 	hipStream_t s = (hipStream_t)stream_;
-	int dev = 0;
-	(void)hipGetDevice(&dev);
-	if (dev < 0 || dev >= 64) dev = 0;
+	int dev = nxz_ctx_device(c);                              // the context's device, whatever the calling thread's current one is
+	if (dev < 0 || dev >= 64 || hipSetDevice(dev) != hipSuccess) return -ENODEV;
 	Workspace &ws = g_ws[dev];
 	std::lock_guard<std::mutex> guard(ws.mtx);
 	if (hist_len > WINDOW) { hist += hist_len - WINDOW; hist_len = WINDOW; }
