@@ -113,10 +113,11 @@ struct nxz_ctx {
 		uint8_t *d_src = nullptr;                 // the sources, brought over by one copy kernel (two kernels read them)
 		struct Item { const uint8_t *src; uint8_t *dst; uint64_t bytes; } *h_items = nullptr;
 		bool busy = false, ready = false;
-	} rounds[4];
+	} rounds[16];
 	std::mutex qm;
 	std::condition_variable qcv;
 	std::deque<struct CompressReq *> q;
+	std::deque<struct InflateReq *> qi;           // the same for decompress jobs
 	uint32_t *d_job_counters = nullptr;           // job counters of the batched deflate launches (ring)
 	unsigned next_counter = 0;
 	// measurement aid (nxz_ctx_stage_timing): events around every kernel of the compress batches
@@ -856,6 +857,18 @@ static int round_run(nxz_ctx *c, nxz_ctx::Round &R, std::vector<CompressReq *> &
 	return 0;
 }
 
+// A round that is free, as long as fewer than NXZ_ROUNDS (default 3) are in flight: few rounds in flight
+// make the callers that arrive meanwhile wait and go out TOGETHER, which is what the device wants (it
+// runs only a handful of small launches side by side); c->qm is held.
+static nxz_ctx::Round *free_round(nxz_ctx *c)
+{
+	static const unsigned limit = [] { const char *e = getenv("NXZ_ROUNDS"); unsigned v = e ? (unsigned)atoi(e) : 3; return v < 1 ? 1u : v > 16 ? 16u : v; }();
+	unsigned busy = 0;
+	nxz_ctx::Round *f = nullptr;
+	for (auto &r : c->rounds) { if (r.busy) busy++; else if (!f) f = &r; }
+	return busy < limit ? f : nullptr;
+}
+
 // Queue the job; whoever finds a free round takes the job at the head of the queue and every queued
 // job with the same function code, runs them, and wakes their owners.  The first caller goes out
 // alone at once; those that arrive while it is in flight form the next round.
@@ -865,7 +878,7 @@ static int round_submit(nxz_ctx *c, CompressReq *me)
 	c->q.push_back(me);
 	while (!me->done) {
 		nxz_ctx::Round *R = nullptr;
-		if (!me->taken) for (auto &r : c->rounds) if (!r.busy) { R = &r; break; }
+		if (!me->taken) R = free_round(c);
 		if (!R) { c->qcv.wait(lk); continue; }
 		R->busy = true;
 		std::vector<CompressReq *> v;
@@ -964,6 +977,61 @@ static int run_wrap(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j)
 	return 0;
 }
 
+// One caller's decompress job on its way through a round (the rounds of the compress jobs, above: the
+// callers that arrive while a launch is in flight go out together -- here as one launch of the
+// stream-per-wave inflate kernel with a wavefront per job, instead of a launch per job on a stream of
+// its own, of which the device runs only a few at a time).
+struct InflateReq {
+	nxz_batch_job_t job;                  // src: the slot's device buffer (filled by the round's copy kernel from h_in); dst: the slot's pinned h_out
+	const uint8_t *h_in = nullptr;        // the slot's pinned staging of the source
+	nxz_batch_dht_t *dht = nullptr;       // the slot's pinned table: in when the job resumes inside a dynamic block, out when it suspends in one
+	nxz_batch_result_t res;
+	int rc = 0;
+	bool taken = false, done = false;
+};
+
+static int round_run_inflate(nxz_ctx *c, nxz_ctx::Round &R, std::vector<InflateReq *> &v)
+{
+	const size_t n = v.size();
+	(void)hipSetDevice(c->device);
+	for (size_t k = 0; k < n; k++) {
+		R.h_jobs[k] = v[k]->job;
+		R.h_items[k].src = v[k]->h_in; R.h_items[k].dst = (uint8_t *)v[k]->job.src; R.h_items[k].bytes = v[k]->job.src_len;
+		R.h_dht[k] = *v[k]->dht;
+	}
+	if (nxz_launch_copy_items(R.h_items, (uint32_t)n, R.stream)) return -EIO;
+	if (nxz_launch_inflate(R.h_jobs, n, R.h_res, R.h_dht, 1, R.stream)) return -EIO;
+	HIPCHK(hipStreamSynchronize(R.stream), return -EIO);
+	for (size_t k = 0; k < n; k++) {
+		v[k]->res = R.h_res[k];
+		if ((R.h_res[k].sfbt & 0xe) == 0xc) *v[k]->dht = R.h_dht[k];
+	}
+	return 0;
+}
+
+static int round_submit_inflate(nxz_ctx *c, InflateReq *me)
+{
+	std::unique_lock<std::mutex> lk(c->qm);
+	c->qi.push_back(me);
+	while (!me->done) {
+		nxz_ctx::Round *R = nullptr;
+		if (!me->taken) R = free_round(c);
+		if (!R) { c->qcv.wait(lk); continue; }
+		R->busy = true;
+		std::vector<InflateReq *> v;
+		while (!c->qi.empty() && v.size() < ROUND_MAX) { c->qi.front()->taken = true; v.push_back(c->qi.front()); c->qi.pop_front(); }
+		lk.unlock();
+		(void)hipSetDevice(c->device);
+		int rc = round_init(*R) ? round_run_inflate(c, *R, v) : -ENOMEM;
+		if (rc && R->stream) (void)hipStreamSynchronize(R->stream);
+		lk.lock();
+		for (auto *r : v) { r->rc = rc; r->done = true; }
+		R->busy = false;
+		c->qcv.notify_all();
+	}
+	return me->rc;
+}
+
 static int run_decompress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 {
 	uint32_t srctotal = nxz_dde_bytes(&j->crb.source);
@@ -976,10 +1044,12 @@ static int run_decompress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 	if (got < hist) hist = got;
 	uint32_t cap = dde_capacity(&j->crb.target);
 	uint32_t dcap = cap < INF_OUT_CAP ? cap : INF_OUT_CAP;
-	nxz_batch_job_t *bj = s->h_job;
+	InflateReq req;
+	nxz_batch_job_t *bj = &req.job;
 	memset(bj, 0, sizeof(*bj));
-	bj->src = s->d_in; bj->dst = s->d_out; bj->src_len = got; bj->hist_len = hist; bj->dst_cap = dcap;
+	bj->src = s->d_in; bj->dst = s->h_out; bj->src_len = got; bj->hist_len = hist; bj->dst_cap = dcap;
 	bj->in_crc = nxz_in_crc(&j->cpb); bj->in_adler = nxz_in_adler(&j->cpb);
+	s->h_dht->dhtlen = 0;
 	if (resume) {
 		uint32_t sfbt = nxz_in_sfbt(&j->cpb);
 		bj->resume = (sfbt << 16) | (nxz_in_subc(&j->cpb) << 20);
@@ -987,21 +1057,20 @@ static int run_decompress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 		if ((sfbt & 0xe) == 0xc) {
 			s->h_dht->dhtlen = nxz_in_dhtlen(&j->cpb);
 			memcpy(s->h_dht->dht, j->cpb.in_dht, NXZ_DHT_MAXSZ);
-			HIPCHK(hipMemcpyAsync(s->d_dht, s->h_dht, sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s->stream), return -EIO);
 		}
 	}
-	HIPCHK(hipMemcpyAsync(s->d_in, s->h_in, got, hipMemcpyHostToDevice, s->stream), return -EIO);
-	HIPCHK(hipMemcpyAsync(s->d_job, bj, sizeof(*bj), hipMemcpyHostToDevice, s->stream), return -EIO);
+	req.h_in = s->h_in; req.dht = s->h_dht;
 	const uint64_t td0 = g_trace.on ? trace_ns() : 0;
-	if (nxz_launch_inflate(s->d_job, 1, s->d_res, s->d_dht, 1, s->stream)) return -EIO;
-	HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
-	HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
-	nxz_batch_result_t r = *s->h_res;
+	{
+		const int rrc = round_submit_inflate(c, &req);
+		if (rrc) return rrc;
+	}
+	nxz_batch_result_t r = req.res;
 	if (g_trace.on) {
 		static std::atomic<uint64_t> dj{0}, dns{0}, din{0}, dout{0};
 		dj++; dns += trace_ns() - td0; din += got; dout += r.tpbc;
-		if ((dj & 255) == 0) fprintf(stderr, "nxz decompress jobs: %llu, kernel+sync %.1f us each, %.0f source bytes in, %.0f bytes out each\n",
-					     (unsigned long long)dj, dns / (double)dj * 1e-3, din / (double)dj, dout / (double)dj);
+		if ((dj & 4095) == 0) fprintf(stderr, "nxz decompress jobs: %llu, %.1f us each in the round, %.0f source bytes in, %.0f bytes out each\n",
+					      (unsigned long long)dj, dns / (double)dj * 1e-3, din / (double)dj, dout / (double)dj);
 	}
 	uint32_t cc = r.cc, ce = 0, tpbc = 0;
 	if (cc != 0 && cc != NXZ_CC_DATA_LENGTH) {
@@ -1009,12 +1078,6 @@ static int run_decompress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 	} else {
 		tpbc = r.tpbc;
 		uint32_t sfbt = r.sfbt & 0xf;
-		if (tpbc) {
-			HIPCHK(hipMemcpyAsync(s->h_out, s->d_out, tpbc, hipMemcpyDeviceToHost, s->stream), return -EIO);
-		}
-		if ((sfbt & 0xe) == 0xc)
-			HIPCHK(hipMemcpyAsync(s->h_dht, s->d_dht, sizeof(nxz_batch_dht_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
-		HIPCHK(hipStreamSynchronize(s->stream), return -EIO);
 		dde_scatter(&j->crb.target, s->h_out, tpbc);
 		put_cksums(j, r.crc, r.adler);
 		nxz_wr32(&j->cpb.out_w2_be, r.subc & 0xffff);
@@ -1044,8 +1107,7 @@ extern "C" int nxu_run_job(nxz_crb_cpb_t *j, void *handle)
 	Slot *s = slot_acquire(c);
 	if (!s) { nxz_csb_complete(j, NXZ_CC_NO_HW, NXZ_CE_TERMINATE, 0); return 0; }
 	if (g_trace.on) g_trace.ns_acquire += trace_ns() - ta;
-	const bool comp = nxz_fc_is_compress(fc) && fc != NXZ_FC_WRAP;
-	if (!comp) (void)hipSetDevice(c->device);                 // (compress jobs: the thread that runs the round does)
+	if (fc == NXZ_FC_WRAP) (void)hipSetDevice(c->device);     // (compress and decompress jobs: the thread that runs the round does)
 	int rc;
 	if (fc == NXZ_FC_WRAP) rc = run_wrap(c, s, j);
 	else if (nxz_fc_is_compress(fc) && !(fc & 1) && !(fc & ~0x2eu) && (!nxz_fc_is_dhtgen(fc) || nxz_fc_is_dht(fc))) rc = run_compress(c, s, j, fc);
