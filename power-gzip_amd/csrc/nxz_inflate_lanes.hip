@@ -12,6 +12,7 @@
 // Per-lane lookup tables live in a workspace in HBM/L2 (3.3 KiB per resident lane); the fixed
 // Huffman tables are shared.  The wave-per-stream kernel stays for single host jobs.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "nxz_device.h"
 #include "nxz_lane_io.h"
@@ -131,7 +132,10 @@ struct LaneState {
 };
 
 // results.tebc carries out_rembytecnt; results.sfbt bit 8 = final EOB, bits 16.. = dhtlen (see nxz_engine.h)
-__global__ __launch_bounds__(64, 4) void inflate_lanes_kernel(const nxz_batch_job_t *__restrict__ jobs, size_t n,
+#ifndef NXZ_LANES_WPE
+#define NXZ_LANES_WPE 4      /* wavefronts per SIMD the register budget is cut for (128 VGPRs at 4) */
+#endif
+__global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const nxz_batch_job_t *__restrict__ jobs, size_t n,
 							   nxz_batch_result_t *__restrict__ results,
 							   nxz_batch_dht_t *__restrict__ dht_io,
 							   uint8_t *__restrict__ workspace, const uint8_t *__restrict__ fixed_ws)
@@ -619,7 +623,13 @@ __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__res
 
 } // namespace nxzl
 
-#define NXZ_LANES_MAX_GRID 4096u
+#define NXZ_LANES_MAX_GRID (1024u * NXZ_LANES_WPE)
+// resident wavefronts (each works its way through groups of 64 streams): NXZ_LANES_GRID overrides, for measurements
+static unsigned lanes_max_grid(void)
+{
+	static const unsigned v = [] { const char *e = getenv("NXZ_LANES_GRID"); unsigned g = e ? (unsigned)atoi(e) : NXZ_LANES_MAX_GRID; return g < 1 ? 1u : g > NXZ_LANES_MAX_GRID ? NXZ_LANES_MAX_GRID : g; }();
+	return v;
+}
 
 // workspace bytes a batch of n streams needs (grows with n up to the largest grid)
 extern "C" size_t nxz_inflate_lanes_workspace(size_t n)
@@ -641,7 +651,7 @@ extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, n
 {
 	if (!n) return 0;
 	size_t groups = (n + 63) / 64;
-	unsigned grid = (unsigned)(groups < NXZ_LANES_MAX_GRID ? groups : NXZ_LANES_MAX_GRID);
+	unsigned grid = (unsigned)(groups < lanes_max_grid() ? groups : lanes_max_grid());
 	if (init_fixed) hipLaunchKernelGGL(nxzl::fixed_tables_kernel, dim3(1), dim3(64), 0, stream, workspace);
 	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace);
 	hipLaunchKernelGGL(nxzl::cksum_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);

@@ -11,7 +11,7 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "t
 import torch, bench
 pkg = importlib.import_module("power-gzip_amd")
 eng = pkg.Engine(0)
-N = 65536
+N = int(os.environ.get('NXZ_BENCH_N', '65536'))
 src = bench.gen_blocks(torch, eng.dev, N, 0)
 comp = torch.empty((N, 73856), dtype=torch.uint8, device=eng.dev)
 jobs = eng.jobs_strided(src, 65536, np.full(N, 65536, np.uint32), comp, 73856, 73856)
@@ -27,7 +27,7 @@ for i, c in enumerate(cs): buf[i, :len(c)] = np.frombuffer(c, np.uint8)
 zc = torch.from_numpy(buf).to(eng.dev).repeat(N // m, 1)
 zl = np.tile(np.array([len(c) for c in cs], np.uint32), N // m)
 back = torch.empty((N, 65536), dtype=torch.uint8, device=eng.dev)
-for n in (32, 128, 512, 1024, 2048, 4096, 8192, 16384, 65536):
+for n in [k for k in (32, 128, 512, 1024, 2048, 4096, 8192, 16384, 65536, 262144) if k <= N]:
     out = []
     for name, s, st, ln in (("own fixed-Huffman output", comp, 73856, r["tpbc"].astype(np.uint32)), ("zlib -6 streams", zc, stride, zl)):
         j = eng.jobs_strided(s, st, ln[:n], back, 65536, 65536)
