@@ -252,6 +252,24 @@ def timed_compress(torch, eng, fc, jobs, n, results, steps, warmup):
     return e0.elapsed_time(e1) / steps, [x / steps for x in st], launches // max(steps, 1)
 
 
+def what_binds():
+    """The path moves few bytes per instruction: what binds the LZ77 kernel is the issue of vector instructions and
+    the LDS pipe, from the committed counter passes (profiles/r02*_pmc_counters.json; tools/pmc_report.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_counters.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["nxzl77::lz77_kernel<false>"]
+        valu, cyc = k["SQ_INSTS_VALU_per_job"], k["cu_cycles_per_job"]
+        return {"kernel": "nxzl77::lz77_kernel<false>", "source": os.path.basename(files[-1]),
+                "vector_issue_frac": round(valu * 4 / 4 / cyc, 3), "lds_busy_frac": k.get("lds_busy_share_of_kernel_time"),
+                "lds_bank_conflict_share": k.get("lds_bank_conflict_share_of_lds_cycles"),
+                "note": "a wave64 vector instruction occupies one of the CU's four SIMDs for four cycles: wave-instructions x 4 / 4 SIMDs / CU-cycles per block"}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def roofline(u_bytes, c_bytes, stage_ms, launches, traffic, kernel):
     """algorithmic bytes U + C over the time of the dominant kernel (the LZ77 kernel:
     it reads U; the entropy kernel writes C and is accounted with it: both are needed to move U + C),
@@ -259,7 +277,7 @@ def roofline(u_bytes, c_bytes, stage_ms, launches, traffic, kernel):
     launch stream around every launch of the timed region."""
     kern_ms = sum(stage_ms)
     achieved = (u_bytes + c_bytes) / (kern_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "what_binds": what_binds(),
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kernel,
             "kernel_ms": round(kern_ms, 3), "lz77_ms": round(stage_ms[0], 3), "dhtgen_ms": round(stage_ms[1], 3),
             "entropy_ms": round(stage_ms[2], 3), "launches_per_step": launches,
