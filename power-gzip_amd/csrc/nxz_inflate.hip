@@ -581,8 +581,10 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 					W0 = W1; W1 = load_block(wblk + 1);
 				}
 				const uint32_t qi = __builtin_amdgcn_readfirstlane(q - wblk * 64);      // 0..63: dwords qi..qi+4 are in W0/W1
+				// (both registers are read and one result is picked: a select where a branch would be)
 				auto word = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
-					return i < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)i) : (uint32_t)__builtin_amdgcn_readlane((int)W1, (int)(i - 64));
+					const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)(i & 63)), hi = (uint32_t)__builtin_amdgcn_readlane((int)W1, (int)(i & 63));
+					return i < 64 ? lo : hi;
 				};
 				const uint32_t s0 = word(qi), s1 = word(qi + 1), s2 = word(qi + 2), s3 = word(qi + 3), s4 = word(qi + 4);
 				// this lane's 64 bits of the source: [pos + lane, pos + lane + 64)
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 					for (int u = 0; u < 4; u++) {
 						t = (uint32_t)__builtin_amdgcn_readlane((int)tl, (int)(off & 63));
 						t = off < 64 ? t : 0;
-						starts |= (uint64_t)(t != 0) << (off & 63);
+						starts |= (uint64_t)((t + 63) >> 6) << (off & 63);         // t is 0..63: 1 for a token, in scalar arithmetic
 						off += t;
 					}
 					if (!t || off > 63) break;
