@@ -132,7 +132,7 @@ __device__ __forceinline__ void build(H &h, const uint8_t *len, int n, int lane)
 }
 
 struct Bits {
-	const uint8_t *src;       // global
+	const NXZ_GLOBAL_AS uint8_t *src;   // device memory, used through address space 1 (a generic access makes the compiler drain the LDS queue at every later wait)
 	uint32_t srclen;
 	uint64_t total_bits;      // 8*srclen
 	uint64_t pos;             // next unread bit
@@ -248,7 +248,7 @@ __device__ __forceinline__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist
 	auto dword = [&](uint32_t idx) __attribute__((always_inline)) -> uint32_t {
 		const uint64_t byte = (uint64_t)idx * 4;
 		uint32_t w = 0;
-		if (byte + 4 <= b.srclen && ((uintptr_t)b.src & 3) == 0) w = ((const uint32_t *)b.src)[idx];
+		if (byte + 4 <= b.srclen && ((uintptr_t)b.src & 3) == 0) w = ((const NXZ_GLOBAL_AS uint32_t *)b.src)[idx];
 		else for (uint32_t k = 0; k < 4 && byte + k < b.srclen; k++) w |= (uint32_t)b.src[byte + k] << (8 * k);
 		return w;
 	};
@@ -362,12 +362,12 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	const uint32_t hist_bytes = job.hist_len < job.src_len ? job.hist_len : job.src_len;
 	const uint32_t hist = W16 ? WIN : hist_bytes;      // how far back a match may reach before the output
 	const uint32_t srclen = job.src_len - hist_bytes;
-	const uint8_t *src = job.src + hist_bytes;
-	uint8_t *dst = job.dst;
+	const NXZ_GLOBAL_AS uint8_t *src = (const NXZ_GLOBAL_AS uint8_t *)job.src + hist_bytes;
+	NXZ_GLOBAL_AS uint8_t *dst = (NXZ_GLOBAL_AS uint8_t *)job.dst;
 	const uint32_t cap = job.dst_cap;
 	// window access: position p counts output bytes, negative positions (as uint32) are history
-	const uint8_t *hist_end = job.src + hist_bytes;
-	uint16_t *dst16 = (uint16_t *)job.dst;
+	const NXZ_GLOBAL_AS uint8_t *hist_end = (const NXZ_GLOBAL_AS uint8_t *)job.src + hist_bytes;
+	NXZ_GLOBAL_AS uint16_t *dst16 = (NXZ_GLOBAL_AS uint16_t *)job.dst;
 	auto wr = [&](uint32_t p, uint32_t v) __attribute__((always_inline)) {
 		if (W16) dst16[p] = (uint16_t)v;
 		else if (GW) dst[p] = (uint8_t)v;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	// history (the last <= 32 KiB before the output) goes into the window just below position 0
 	{
 		uint32_t h = hist_bytes > WIN ? WIN : hist_bytes;
-		const uint8_t *hp = job.src + (hist_bytes - h);
+		const NXZ_GLOBAL_AS uint8_t *hp = (const NXZ_GLOBAL_AS uint8_t *)job.src + (hist_bytes - h);
 		if (!GW) for (uint32_t i = lane; i < h; i += 64) sm.win[(0u - h + i) & WMASK] = hp[i];
 	}
 	__syncthreads();
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			// re-parse the table handed back by the caller
 			const nxz_batch_dht_t *t = &dht_io[blockIdx.x];
 			Bits tb;
-			tb.src = t->dht; tb.srclen = (t->dhtlen + 7) / 8; tb.total_bits = t->dhtlen; tb.pos = 0;
+			tb.src = (const NXZ_GLOBAL_AS uint8_t *)t->dht; tb.srclen = (t->dhtlen + 7) / 8; tb.total_bits = t->dhtlen; tb.pos = 0;
 			tb.stage_base = 0xffffffffu; tb.stage = sm.stage; tb.lane = lane;
 			int hlit, hdist; uint32_t tbits;
 			int rc = read_dht(tb, sm, hlit, hdist, tbits);
