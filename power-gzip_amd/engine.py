@@ -70,6 +70,10 @@ def load_library():
         L.nxz_inflate_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p]
+        L.nxz_deflate_host_bound.restype = C.c_size_t
+        L.nxz_deflate_host_bound.argtypes = [C.c_size_t]
+        L.nxz_deflate_host.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.nxz_ctx_sync.argtypes = [C.c_void_p, C.c_void_p]
         L.nx_function_begin.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.nx_function_end.argtypes = [C.c_void_p]
@@ -175,6 +179,14 @@ class Engine:
                                        C.byref(end_bit), C.byref(pieces), C.byref(rounds), self.stream_handle())
         return rc, {"out_len": out_len.value, "crc": crc.value, "adler": adler.value, "end_bit": end_bit.value,
                     "pieces": pieces.value, "rounds": rounds.value}
+
+    def deflate_host(self, data, fc=FC_COMPRESS_DHTGEN, final=True, cap=None):
+        """a HOST buffer (bytes) -> one raw deflate stream (bytes), nxz_deflate_host.  Returns (rc, stream, crc, adler)."""
+        bound = self.L.nxz_deflate_host_bound(len(data)) if cap is None else cap
+        dst = C.create_string_buffer(max(bound, 1))
+        n, crc, adler = C.c_size_t(), C.c_uint32(), C.c_uint32()
+        rc = self.L.nxz_deflate_host(self.ctx, fc, data, len(data), 1 if final else 0, dst, bound, C.byref(n), C.byref(crc), C.byref(adler))
+        return rc, dst.raw[:n.value] if rc == 0 else b"", crc.value, adler.value
 
     def wrap(self, jobs, n, results=None):
         t = self.torch

@@ -126,3 +126,32 @@ def test_sixteen_threads_share_the_engine(L):
     for x in th:
         x.join()
     assert not bad, bad
+
+
+def test_deflate_host_entry_point():
+    """nxz_deflate_host itself (include/nxz_engine.h): any length, final or not, both function codes;
+    runs that are not final end on a byte boundary and are continued by the next run."""
+    import importlib
+    pkg = importlib.import_module("power-gzip_amd")
+    eng = pkg.Engine(0)
+    try:
+        data = mixed((2 << 20) + 4711, 41)
+        for fc in (pkg.FC_COMPRESS_FHT, pkg.FC_COMPRESS_DHTGEN):
+            rc, comp, crc, adler = eng.deflate_host(data, fc=fc, final=True)
+            assert rc == 0 and zlib.decompress(comp, -15) == data
+            assert crc == zlib.crc32(data) and adler == zlib.adler32(data)
+        # two runs make one stream
+        a, b = data[:1 << 20], data[1 << 20:]
+        rc1, c1, crc1, _ = eng.deflate_host(a, final=False)
+        rc2, c2, crc2, _ = eng.deflate_host(b, final=True)
+        assert rc1 == 0 and rc2 == 0
+        d = zlib.decompressobj(-15)
+        assert d.decompress(c1 + c2) == data and d.eof
+        assert crc1 == zlib.crc32(a) and crc2 == zlib.crc32(b)
+        # small inputs: a single short block; refusals
+        rc, comp, _, _ = eng.deflate_host(b"x" * 100)
+        assert rc == 0 and zlib.decompress(comp, -15) == b"x" * 100
+        assert eng.deflate_host(data, cap=1000)[0] == -7                  # E2BIG: the bound is what it asks for
+        assert eng.deflate_host(data, fc=pkg.FC_COMPRESS_DHT)[0] == -22   # EINVAL: a caller's table makes no sense here
+    finally:
+        eng.close()
