@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 
 	// two 256-byte blocks of the source in registers (lane k: dword k), for the multi-token step
 	const bool fast_ok = ((uintptr_t)src & 3) == 0;
-	uint32_t W0 = 0, W1 = 0, wblk = 0xffffffffu;
+	uint32_t W0 = 0, W1 = 0, wbase = 0x80000000u;          // wbase: dword index of W0's lane 0 (a multiple of 64; none yet)
 	auto load_block = [&](uint32_t blk) -> uint32_t {
 		const uint32_t idx = blk * 64 + lane;
 		const uint64_t byte = (uint64_t)idx * 4;
@@ -572,15 +572,12 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			// ---- multi-token step (see the header) ----
 			while (fast_ok && b.pos + 256 <= b.total_bits) {
 				IPROF(0);
-				const uint32_t q = (uint32_t)(b.pos >> 5), sh = (uint32_t)b.pos & 31;
-				if (wblk == 0xffffffffu || q < wblk * 64 || q >= wblk * 64 + 128) {
-					wblk = q >> 6;
-					W0 = load_block(wblk); W1 = load_block(wblk + 1);
-				} else if (q >= wblk * 64 + 64) {
-					wblk++;
-					W0 = W1; W1 = load_block(wblk + 1);
+				const uint32_t q = uni((uint32_t)(b.pos >> 5)), sh = (uint32_t)b.pos & 31;
+				if (q - wbase >= 64u) {                                  // (one scalar test a step; the source is below 2^31 dwords)
+					if (q - wbase < 128u) { wbase += 64; W0 = W1; W1 = load_block((wbase >> 6) + 1); }
+					else { wbase = q & ~63u; W0 = load_block(wbase >> 6); W1 = load_block((wbase >> 6) + 1); }
 				}
-				const uint32_t qi = __builtin_amdgcn_readfirstlane(q - wblk * 64);      // 0..63: dwords qi..qi+4 are in W0/W1
+				const uint32_t qi = q - wbase;                           // 0..63: dwords qi..qi+4 are in W0/W1
 				// (both registers are read and one result is picked: a select where a branch would be)
 				auto word = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
 					const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)(i & 63)), hi = (uint32_t)__builtin_amdgcn_readlane((int)W1, (int)(i & 63));
