@@ -39,10 +39,16 @@ def run_one_shot(tmp_path, data, selector):
 
 
 def test_config1_one_shot_software_path_equals_zlib(tmp_path):
-    # nx_compress()/nx_uncompress() one-shot on alice29-like text through the CPU fallback: the
-    # output is identical to system zlib compress2(level -1) because it IS zlib (SURVEY 8(d) C1)
-    data = ALICE_LIKE(152089)
+    # BASELINE configs[0] / SURVEY 8(d) C1: compress()/uncompress() one-shot on the reference's
+    # samples/alice29.txt (tests/golden/alice29.txt, sha256 pinned) through the CPU fallback: the
+    # output is identical to system zlib compress2(level -1) because it IS zlib
+    import hashlib
+    data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alice29.txt"), "rb").read()
+    assert len(data) == 152089
+    assert hashlib.sha256(data).hexdigest() == "7467306ee0feed4971260f3c87421154a05be571d944e9cb021a5713700c38f0"
     assert run_one_shot(tmp_path, data, 1) == zlib.compress(data, -1)
+    like = ALICE_LIKE(152089)
+    assert run_one_shot(tmp_path, like, 1) == zlib.compress(like, -1)
 
 
 def test_auto_mode_without_engine_falls_back_to_zlib(tmp_path):
