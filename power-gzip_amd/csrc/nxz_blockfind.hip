@@ -30,6 +30,7 @@ constexpr int NT = 256;
 constexpr uint32_t SEG = 8192;                  // bytes of the stream per workgroup
 constexpr uint32_t LOOK = 320;                  // a header is at most 17 + 19 * 3 + 316 * 7 + ... bits: < 300 bytes
 constexpr uint32_t MAXCAND = 1024;
+constexpr uint32_t QCHUNK = 8192;               // positions per pass of the first test (its survivors queue up in LDS)
 
 __device__ __forceinline__ uint32_t peek(const uint8_t *s, uint32_t bit, uint32_t n)   // n <= 25
 {
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s[SEG + LOOK + 16];
 	__shared__ uint32_t cand[MAXCAND];
-	__shared__ uint32_t ncand, best;
+	__shared__ uint16_t queue[QCHUNK];
+	__shared__ uint32_t ncand, best, nq;
 	const int t = threadIdx.x;
 	const uint32_t seg = blockIdx.x;
 	if (seg >= nseg) return;
@@ -132,36 +134,56 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 	__syncthreads();
 	const uint32_t limit = have * 8;
 	const uint32_t nbits = (have < SEG ? have : SEG) * 8;
-	// phase 1: the cheap part of the test at every bit position of the segment.  Consecutive lanes test
-	// consecutive positions, so the four dwords a lane needs (96 bits from its position: header fields
-	// and up to 19 three-bit lengths) are the same LDS words for 32 lanes: broadcast reads, no conflicts.
+	// phase 1: the cheap part of the test at every bit position of the segment, in two steps per chunk
+	// of 8192 positions so that the lanes stay busy: (a) every lane looks at the 13 bits that decide for
+	// three positions in four (BFINAL 0, BTYPE 10, HLIT <= 29, HDIST <= 29) and the survivors -- 22 % --
+	// are packed into a queue; (b) the queue, a lane per entry, gets the Kraft sum of the code-length
+	// code (up to 19 three-bit lengths from four dwords).  Consecutive lanes test consecutive
+	// positions in (a), so the dwords they read are the same LDS words for 32 lanes: broadcast reads.
 	const uint32_t *s32 = (const uint32_t *)s;
-	for (uint32_t p = t; p < nbits; p += NT) {
-		if (base * 8 + p < first_bit) continue;
-		if (p + 17 > limit) break;
-		const uint32_t wi = p >> 5, sh = p & 31;
-		const uint32_t d0 = s32[wi], d1 = s32[wi + 1], d2 = s32[wi + 2], d3 = s32[wi + 3];
-		const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), mid = __builtin_amdgcn_alignbit(d2, d1, sh), hi = __builtin_amdgcn_alignbit(d3, d2, sh);
-		// BFINAL 0, BTYPE 10 (bits 1..2 = 0b10 -> value 2), HLIT <= 29, HDIST <= 29
-		if ((lo & 7) != 4 || ((lo >> 3) & 31) > 29 || ((lo >> 8) & 31) > 29) continue;
-		const uint32_t hclen = ((lo >> 13) & 15) + 4;
-		if (p + 17 + 3 * hclen > limit) continue;
-		const uint64_t x = (((uint64_t)mid << 32) | lo) >> 17;        // lengths 0..14 (in the order they are sent)
-		const uint32_t y = (uint32_t)((((uint64_t)hi << 32) | mid) >> 30);   // lengths 15..18
-		uint32_t kraft = 0;
-#pragma unroll
-		for (uint32_t i = 0; i < 15; i++) {
-			const uint32_t l = (uint32_t)(x >> (3 * i)) & 7;
-			kraft += (i < hclen && l) ? 128u >> l : 0;
+	for (uint32_t c0 = 0; c0 < nbits; c0 += QCHUNK) {
+		if (t == 0) nq = 0;
+		__syncthreads();
+		const uint32_t c1 = c0 + QCHUNK < nbits ? c0 + QCHUNK : nbits;
+		for (uint32_t p = c0 + t; p < c1; p += NT) {
+			bool pass = base * 8 + p >= first_bit && p + 17 <= limit;
+			const uint32_t wi = p >> 5, sh = p & 31;
+			const uint32_t lo = __builtin_amdgcn_alignbit(s32[wi + 1], s32[wi], sh);
+			pass = pass && (lo & 7) == 4 && ((lo >> 3) & 31) <= 29 && ((lo >> 8) & 31) <= 29;
+			const uint64_t m = __ballot(pass);
+			if (m) {
+				uint32_t at = 0;
+				if ((t & 63) == 0) at = atomicAdd(&nq, (uint32_t)__popcll(m));
+				at = __builtin_amdgcn_readfirstlane(at);
+				if (pass) queue[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = (uint16_t)p;
+			}
 		}
+		__syncthreads();
+		const uint32_t n1 = nq;
+		for (uint32_t k = t; k < n1; k += NT) {
+			const uint32_t p = queue[k];
+			const uint32_t wi = p >> 5, sh = p & 31;
+			const uint32_t d0 = s32[wi], d1 = s32[wi + 1], d2 = s32[wi + 2], d3 = s32[wi + 3];
+			const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), mid = __builtin_amdgcn_alignbit(d2, d1, sh), hi = __builtin_amdgcn_alignbit(d3, d2, sh);
+			const uint32_t hclen = ((lo >> 13) & 15) + 4;
+			if (p + 17 + 3 * hclen > limit) continue;
+			const uint64_t x = (((uint64_t)mid << 32) | lo) >> 17;        // lengths 0..14 (in the order they are sent)
+			const uint32_t y = (uint32_t)((((uint64_t)hi << 32) | mid) >> 30);   // lengths 15..18
+			uint32_t kraft = 0;
 #pragma unroll
-		for (uint32_t i = 15; i < 19; i++) {
-			const uint32_t l = (y >> (3 * (i - 15))) & 7;
-			kraft += (i < hclen && l) ? 128u >> l : 0;
+			for (uint32_t i = 0; i < 15; i++) {
+				const uint32_t l = (uint32_t)(x >> (3 * i)) & 7;
+				kraft += (i < hclen && l) ? 128u >> l : 0;
+			}
+#pragma unroll
+			for (uint32_t i = 15; i < 19; i++) {
+				const uint32_t l = (y >> (3 * (i - 15))) & 7;
+				kraft += (i < hclen && l) ? 128u >> l : 0;
+			}
+			if (kraft != 128) continue;
+			const uint32_t kc = atomicAdd(&ncand, 1u);
+			if (kc < MAXCAND) cand[kc] = p;
 		}
-		if (kraft != 128) continue;
-		const uint32_t k = atomicAdd(&ncand, 1u);
-		if (k < MAXCAND) cand[k] = p;
 	}
 	__syncthreads();
 	// phase 2: the whole header, a lane per survivor
