@@ -397,6 +397,26 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			if ((uint32_t)lane < len) wr(at + lane, v);
 			return;
 		}
+		// device memory, source entirely inside the output and not overlapping the copy (the long matches of
+		// highly repetitive data): eight bytes per lane and load -- four 16-bit elements, or eight bytes --
+		// instead of one element; device memory takes these loads and stores at any alignment
+		if (GW && dist >= len && dist <= at) {
+			typedef uint32_t v2u_any __attribute__((ext_vector_type(2), aligned(1)));
+			constexpr uint32_t PER = W16 ? 4 : 8;                      // elements per lane and trip
+			const NXZ_GLOBAL_AS uint8_t *sp = W16 ? (const NXZ_GLOBAL_AS uint8_t *)(dst16 + (at - dist)) : dst + (at - dist);
+			NXZ_GLOBAL_AS uint8_t *dp = W16 ? (NXZ_GLOBAL_AS uint8_t *)(dst16 + at) : dst + at;
+			const uint32_t full = len / PER;                          // whole groups; <= 64 for 16-bit elements, <= 32 for bytes
+			v2u_any g0 = { 0, 0 }, g1 = { 0, 0 };
+			if ((uint32_t)lane < full) g0 = *(const NXZ_GLOBAL_AS v2u_any *)(sp + 8 * lane);
+			if (W16 && (uint32_t)lane + 64 < full) g1 = *(const NXZ_GLOBAL_AS v2u_any *)(sp + 8 * (lane + 64));
+			const uint32_t rest = len - full * PER, e = full * PER + lane;          // the last 0..7 elements, one per lane
+			uint32_t tail = 0;
+			if ((uint32_t)lane < rest) tail = W16 ? dst16[at - dist + e] : dst[at - dist + e];
+			if ((uint32_t)lane < full) *(NXZ_GLOBAL_AS v2u_any *)(dp + 8 * lane) = g0;
+			if (W16 && (uint32_t)lane + 64 < full) *(NXZ_GLOBAL_AS v2u_any *)(dp + 8 * (lane + 64)) = g1;
+			if ((uint32_t)lane < rest) { if (W16) dst16[at + e] = (uint16_t)tail; else dst[at + e] = (uint8_t)tail; }
+			return;
+		}
 		uint32_t v[5];
 #pragma unroll
 		for (int k = 0; k < 5; k++) {
