@@ -679,9 +679,44 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 				const bool ordered = !GW && __ballot(isstart && !islit && mdist + total > WIN) != 0;
 				if (!ordered && isstart && islit) wr(out + opos, sym);
 				uint64_t mm = ordered ? starts : starts & ~lits;
-				// up to four short matches whose sources lie in front of the whole step: all their loads, then
-				// all their stores -- one trip to the window instead of one per match
-				if (!ordered && mm && __builtin_popcountll(mm) <= 4 && !__ballot(isstart && !islit && (ob > 64 || mdist < opos + ob))) {
+				// Device memory: up to four matches of any length whose sources lie inside the output and in front of
+				// the whole step -- all their loads (eight bytes per lane, as in copy_match), then all their
+				// stores: one trip to memory for the step instead of one per match.
+				// (taken when a long match is among them: short ones alone are cheaper an element per lane, below)
+				if (GW && mm && __builtin_popcountll(mm) <= 4 && __ballot(isstart && !islit && ob > 64) &&
+				    !__ballot(isstart && !islit && (mdist < opos + ob || mdist > out + opos))) {
+					typedef uint32_t v2u_any __attribute__((ext_vector_type(2), aligned(1)));
+					constexpr uint32_t PER = W16 ? 4 : 8;
+					const uint32_t ES = W16 ? 2 : 1;                          // bytes per element
+					NXZ_GLOBAL_AS uint8_t *base = W16 ? (NXZ_GLOBAL_AS uint8_t *)dst16 : dst;
+					uint32_t mp[4], mn[4], tl_[4];
+					v2u_any g[4];
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						mp[k] = 0; mn[k] = 0; tl_[k] = 0; g[k] = (v2u_any){ 0, 0 };
+						if (mm) {
+							const uint32_t l = (uint32_t)__builtin_ctzll(mm);
+							mm &= mm - 1;
+							mp[k] = out + (uint32_t)__builtin_amdgcn_readlane((int)opos, (int)l);
+							mn[k] = (uint32_t)__builtin_amdgcn_readlane((int)ob, (int)l);
+							const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mdist, (int)l);
+							const NXZ_GLOBAL_AS uint8_t *sp = base + (size_t)(mp[k] - d) * ES;
+							const uint32_t full = mn[k] / PER, rest = mn[k] - full * PER;
+							if ((uint32_t)lane < full) g[k] = *(const NXZ_GLOBAL_AS v2u_any *)(sp + 8 * lane);
+							if ((uint32_t)lane < rest) tl_[k] = W16 ? ((const NXZ_GLOBAL_AS uint16_t *)sp)[full * PER + lane] : sp[full * PER + lane];
+						}
+					}
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						NXZ_GLOBAL_AS uint8_t *dp = base + (size_t)mp[k] * ES;
+						const uint32_t full = mn[k] / PER, rest = mn[k] - full * PER;
+						if ((uint32_t)lane < full) *(NXZ_GLOBAL_AS v2u_any *)(dp + 8 * lane) = g[k];
+						if ((uint32_t)lane < rest) { if (W16) ((NXZ_GLOBAL_AS uint16_t *)dp)[full * PER + lane] = (uint16_t)tl_[k]; else dp[full * PER + lane] = (uint8_t)tl_[k]; }
+					}
+				}
+				// (window in LDS) up to four short matches whose sources lie in front of the whole step: all their
+				// loads, then all their stores
+				else if (!ordered && mm && __builtin_popcountll(mm) <= 4 && !__ballot(isstart && !islit && (ob > 64 || mdist < opos + ob))) {
 					uint32_t mp[4], mn[4], mv[4];
 #pragma unroll
 					for (int k = 0; k < 4; k++) {
