@@ -108,6 +108,8 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
 			}
 		}
 		n += rep;
+		// (lengths read off chance bits oversubscribe a code within a few dozen symbols: no need to go on)
+		if (kraft_ll > (1u << 15) || kraft_d > (1u << 15)) return false;
 	}
 	if (!eob || kraft_ll != (1u << 15)) return false;
 	if ((hlit > 257 && !last_ll) || (hdist > 1 && !last_d)) return false;
@@ -145,17 +147,19 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 		if (t == 0) nq = 0;
 		__syncthreads();
 		const uint32_t c1 = c0 + QCHUNK < nbits ? c0 + QCHUNK : nbits;
-		for (uint32_t p = c0 + t; p < c1; p += NT) {
-			bool pass = base * 8 + p >= first_bit && p + 17 <= limit;
-			const uint32_t wi = p >> 5, sh = p & 31;
-			const uint32_t lo = __builtin_amdgcn_alignbit(s32[wi + 1], s32[wi], sh);
-			pass = pass && (lo & 7) == 4 && ((lo >> 3) & 31) <= 29 && ((lo >> 8) & 31) <= 29;
-			const uint64_t m = __ballot(pass);
+		// (a) 32 positions per lane at once, bitwise: position p passes when bits p, p+1, p+2 are 0, 0, 1 and
+		// neither bits p+4..p+7 (HLIT 30, 31) nor bits p+9..p+12 (HDIST 30, 31) are all ones
+		for (uint32_t w0 = (c0 >> 5) + t; w0 * 32 < c1; w0 += NT) {
+			const uint64_t w = (uint64_t)s32[w0] | ((uint64_t)s32[w0 + 1] << 32);
+			const uint64_t hl = (w >> 4) & (w >> 5) & (w >> 6) & (w >> 7), hd = (w >> 9) & (w >> 10) & (w >> 11) & (w >> 12);
+			uint32_t m = (uint32_t)(~w & ~(w >> 1) & (w >> 2) & ~hl & ~hd);
+			const uint32_t p0 = w0 * 32;
+			if (p0 + 32 > c1) m &= (1u << (c1 - p0)) - 1;                       // positions of this chunk only
+			if (base * 8 + p0 < first_bit) m &= first_bit - base * 8 - p0 >= 32 ? 0u : ~0u << (uint32_t)(first_bit - base * 8 - p0);
+			if (p0 + 32 + 17 > limit) { for (uint32_t k = 0; k < 32; k++) if (p0 + k + 17 > limit) m &= ~(1u << k); }
 			if (m) {
-				uint32_t at = 0;
-				if ((t & 63) == 0) at = atomicAdd(&nq, (uint32_t)__popcll(m));
-				at = __builtin_amdgcn_readfirstlane(at);
-				if (pass) queue[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = (uint16_t)p;
+				uint32_t at = atomicAdd(&nq, (uint32_t)__popc(m));
+				while (m) { queue[at++] = (uint16_t)(p0 + (uint32_t)__builtin_ctz(m)); m &= m - 1; }
 			}
 		}
 		__syncthreads();
