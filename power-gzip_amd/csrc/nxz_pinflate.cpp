@@ -131,7 +131,7 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 	Workspace &ws = g_ws[dev];
 	std::lock_guard<std::mutex> guard(ws.mtx);
 	if (hist_len > WINDOW) { hist += hist_len - WINDOW; hist_len = WINDOW; }
-	if (src_len < (1u << 20) || first_bit / 8 >= src_len) return -ENOTSUP;
+	if (src_len < (48u << 10) || first_bit / 8 >= src_len) return -ENOTSUP;   // (three blocks' worth: below that one wavefront is as fast)
 
 	static const bool trace = getenv("NXZ_PINFLATE_TRACE") != nullptr;
 	struct timespec ts0;
@@ -158,7 +158,7 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 		const uint64_t p = ((const uint64_t *)ws.pin)[i];
 		if (p != ~0ull && p > first_bit + 64) B.push_back(p);
 	}
-	if (B.size() < 8) return -ENOTSUP;
+	if (B.size() < 3) return -ENOTSUP;
 
 	// a piece of the stream: from a block start to the next
 	struct P {
@@ -296,7 +296,7 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 			nx.push_back(p);
 		}
 		if (!again) break;
-		if (attempt >= 23 || nx.size() < 4) return -ENOTSUP;
+		if (attempt >= 23 || nx.size() < 2) return -ENOTSUP;
 		pc.swap(nx);
 		for (size_t i = 0; i < pc.size(); i++)
 			if (!pc[i].done && !size_piece(pc[i], i + 1 < pc.size() ? pc[i + 1].bit : 0)) return -ENOTSUP;

@@ -107,8 +107,10 @@ def test_declined_and_damaged(eng, data):
     c = zlib.compressobj(6, zlib.DEFLATED, -15)
     comp = c.compress(data[:8 << 20]) + c.flush()
     # too short a stream: the ordinary loop is the right tool
-    rc, _, _ = _run(eng, comp[:500000], 8 << 20)
+    rc, _, _ = _run(eng, comp[:30000], 8 << 20)
     assert rc == -95                                   # ENOTSUP
+    rc, _, _ = _run(eng, comp[:500000], 8 << 20)       # long enough, but cut off: no final block
+    assert rc in (-95, -84)
     # no final block inside the source
     rc, _, _ = _run(eng, comp[:len(comp) - 4000], 9 << 20)
     assert rc in (-95, -84)                            # ENOTSUP / EILSEQ
@@ -142,3 +144,16 @@ def test_through_the_zlib_style_api(data):
     badgz = gz[:-5] + bytes([gz[-5] ^ 1]) + gz[-4:]
     got, rc, _, _ = Z.inflate_all(L, badgz, wbits=31, cap=len(plain) + 64)
     assert rc == Z.Z_DATA_ERROR
+
+
+@pytest.mark.parametrize("kib", [96, 200, 700, 3000])
+def test_streams_of_a_few_blocks(eng, data, kib):
+    """from three block starts on the parallel path is taken: streams of a few hundred KiB"""
+    plain = data[1 << 20:(1 << 20) + (kib << 10)]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(plain) + c.flush()
+    rc, info, dst = _run(eng, comp, len(plain) + 4096)
+    assert rc in (0, -95), (rc, info)
+    if rc == 0:
+        assert info["out_len"] == len(plain) and info["crc"] == zlib.crc32(plain)
+        assert dst[:len(plain)].cpu().numpy().tobytes() == plain
