@@ -708,7 +708,8 @@ bool parallel_inflate(Inflate *s)
 	z_streamp z = s->z;
 	if (!nxz_inflate_stream || !nxz_dev_malloc || !nxz_dev_free || !nxz_copy_to_device || !nxz_copy_to_host || !nxz_ctx_sync) return false;
 	if (s->resuming || !s->carry.empty() || s->pending() || !s->eng.open) return false;
-	if (z->avail_in < PARALLEL_INFLATE_MIN || z->avail_out < z->avail_in) return false;
+	static const bool off = getenv("NXZ_PARALLEL_INFLATE") && atoi(getenv("NXZ_PARALLEL_INFLATE")) == 0;   // 0: always job after job
+	if (off || z->avail_in < PARALLEL_INFLATE_MIN || z->avail_out < z->avail_in) return false;
 	nxz_ctx_t *ctx = (nxz_ctx_t *)s->eng.dev.paste_addr;
 	if (!ctx) return false;
 	const size_t nin = z->avail_in, cap = z->avail_out, nh = s->hist.size();
@@ -763,7 +764,10 @@ int inflate_job(Inflate *s)
 	if (parallel_inflate(s)) return Z_OK;
 	// source = [history rounded up to 16 B][carry][part of next_in]; size it from the last ratio
 	uint32_t want_out = (uint32_t)std::min<size_t>((size_t)z->avail_out + WINDOW + (WINDOW >> 2), 1u << 20);
-	uint32_t src_want = (uint32_t)(((uint64_t)want_out * s->ratio + 1000) / 1000);
+	// (a job that overflows its target is run again with a quarter of the source -- the engine reports no
+	// state to resume from then, as the reference's does not, lib/nx_inflate.c:1399-1424 -- so the source is
+	// cut for 5/8 of the room: the last ratio is only an estimate of the next stretch)
+	uint32_t src_want = (uint32_t)(((uint64_t)want_out * s->ratio * 5 / 8 + 1000) / 1000);
 	src_want = std::max<uint32_t>(src_want, 16);
 	for (int attempt = 0; attempt < 24; attempt++) {
 		uint32_t histlen = (uint32_t)s->hist.size();
