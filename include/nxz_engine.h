@@ -215,8 +215,17 @@ typedef struct nxz_batch_job {
 	uint32_t       dht_index; /* DHT jobs: which table of the batch's dht array */
 	uint32_t       resume;    /* decompress resume state: in_rembytecnt | in_sfbt << 16 | in_subc << 20
 				   * (0 = start at a block header on a byte boundary, FC 0x10) */
-	uint32_t       reserved;
+	uint32_t       reserved;  /* flags, additive: NXZ_JOB_SUSPEND_WHEN_FULL */
 } nxz_batch_job_t;
+
+/* Decompress jobs (additive; the reference's engine has no such thing and its library runs a job
+ * that overflowed again with a quarter of the source, lib/nx_inflate.c:1399-1424): a full target is
+ * not an error (CC 13) but a place to suspend, like the end of the source -- CC 3 with the resume state
+ * in front of the token that did not fit, spbc = the source bytes used so far, subc = the unused
+ * bits of the last of them.  nxu_run_job takes the flag from bit 0 of crb.reserved1 (big-endian 1).
+ * Honoured by the stream-per-wave kernels (nxu_run_job, batches below NXZ_INFLATE_LANES_MIN streams);
+ * the stream-per-lane kernel reports CC 13 as ever. */
+#define NXZ_JOB_SUSPEND_WHEN_FULL 1u
 
 /* Per-job result, written by the device (device memory, 32 bytes). */
 typedef struct nxz_batch_result {

@@ -1049,6 +1049,7 @@ static int run_decompress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 	memset(bj, 0, sizeof(*bj));
 	bj->src = s->d_in; bj->dst = s->h_out; bj->src_len = got; bj->hist_len = hist; bj->dst_cap = dcap;
 	bj->in_crc = nxz_in_crc(&j->cpb); bj->in_adler = nxz_in_adler(&j->cpb);
+	bj->reserved = nxz_rd32(&j->crb.reserved1) & NXZ_JOB_SUSPEND_WHEN_FULL;
 	s->h_dht->dhtlen = 0;
 	if (resume) {
 		uint32_t sfbt = nxz_in_sfbt(&j->cpb);

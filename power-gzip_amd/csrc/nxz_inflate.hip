@@ -456,6 +456,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	uint32_t bfinal = 0, btype = 0, rem = 0;
 	uint32_t cc = 0, o_sfbt = 0, o_subc = 0, o_rem = 0, dhtbits = 0;
 	bool final_eob = false, have_dht = false;
+	// job.reserved bit 0 (NXZ_JOB_SUSPEND_WHEN_FULL, additive): a full target is no error (CC 13) but a place
+	// to suspend, like the end of the source: the job reports the state in front of the token that did
+	// not fit, and how much of the source it has used, and is resumed with the rest
+	const bool stop_full = (job.reserved & 1) != 0;
+	uint64_t stop_bits = ~0ull;                    // source position (bits) of such a suspension
 
 	// flush window bytes [flushed, upto) to dst and fold them into the checksums
 	auto flush = [&](uint32_t upto) {
@@ -574,7 +579,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			// stored bytes: byte aligned; copy through the window
 			uint32_t srcleft = (uint32_t)((b.total_bits - b.pos) >> 3);
 			uint32_t n = rem < srcleft ? rem : srcleft;
-			if (n > cap - out) { cc = NXZ_CC_TARGET_SPACE; break; }
+			bool full_stop = false;
+			if (n > cap - out) {
+				if (!stop_full) { cc = NXZ_CC_TARGET_SPACE; break; }
+				n = cap - out; full_stop = true;                   // what fits, then suspend inside the stored block
+			}
 			uint32_t sp = (uint32_t)(b.pos >> 3);
 			while (n) {
 				uint32_t room = FLUSH - (out - flushed);
@@ -585,6 +594,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 				if (out - flushed == FLUSH) flush(out);
 			}
 			b.pos = (uint64_t)sp * 8;
+			if (full_stop) { o_sfbt = 0x8 | bfinal; o_subc = 0; o_rem = rem; stop_bits = b.pos; break; }
 			if (rem) { o_sfbt = 0x8 | bfinal; o_subc = 0; o_rem = rem; break; }
 			if (bfinal) { final_eob = true; break; }
 			state = 0;
@@ -762,7 +772,10 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			}
 			b.bb_drop(nb);
 			if (sym < 256) {
-				if (out >= cap) { cc = NXZ_CC_TARGET_SPACE; break; }
+				if (out >= cap) {
+					if (stop_full) { o_sfbt = sfbt; stop_bits = sym_start; break; }   // suspend in front of this token
+					cc = NXZ_CC_TARGET_SPACE; break;
+				}
 				if (lane == 0) wr(out, (uint32_t)sym);
 				out++;
 			} else if (sym == 256) {
@@ -793,7 +806,10 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 				uint32_t dist = dbase + ((uint32_t)b.bb & ((1u << eb) - 1));
 				b.bb_drop(eb);
 				if (dist > out + hist || dist > WIN) { cc = NXZ_CC_INVALID_DIST; break; }
-				if (len > cap - out) { cc = NXZ_CC_TARGET_SPACE; break; }
+				if (len > cap - out) {
+					if (stop_full) { o_sfbt = sfbt; stop_bits = sym_start; break; }
+					cc = NXZ_CC_TARGET_SPACE; break;
+				}
 				copy_match(out, dist, len);
 				out += len;
 			}
@@ -811,6 +827,10 @@ done:
 	if (lane == 0) {
 		nxz_batch_result_t r;
 		uint32_t spbc = job.src_len, subc = o_subc;
+		if (stop_bits != ~0ull) {                      // the source bytes touched, and the bits of the last one that are not used yet
+			const uint32_t touched = (uint32_t)((stop_bits + 7) >> 3);
+			spbc = hist_bytes + touched; subc = touched * 8 - (uint32_t)stop_bits;
+		}
 		if (final_eob && subc > 0xfff8) {              // 16-bit SUBC: leave the excess unread
 			uint32_t drop = (subc - 0xfff8 + 7) / 8;
 			spbc -= drop; subc -= drop * 8;

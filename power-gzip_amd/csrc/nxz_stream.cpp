@@ -328,6 +328,7 @@ int deflate_stored(Deflate *s, uint32_t n, bool finish)
 // table parse less per job.  NXZ_DEVICE_DHT=0 keeps the reference's scheme (cached / canned tables,
 // nxz_dht.cpp); the CPU model of the test suite always does.
 extern "C" int nxz_deflate_host(nxz_ctx_t *, int, const uint8_t *, size_t, int, uint8_t *, size_t, size_t *, uint32_t *, uint32_t *) __attribute__((weak));
+bool device_dht_available() { return nxz_deflate_host != nullptr; }     // (the device engine, not the CPU model of the tests)
 bool device_dht()
 {
 	static const bool on = nxz_deflate_host != nullptr && !(getenv("NXZ_DEVICE_DHT") && atoi(getenv("NXZ_DEVICE_DHT")) == 0);
@@ -769,6 +770,10 @@ int inflate_job(Inflate *s)
 	// cut for 5/8 of the room: the last ratio is only an estimate of the next stretch)
 	uint32_t src_want = (uint32_t)(((uint64_t)want_out * s->ratio * 5 / 8 + 1000) / 1000);
 	src_want = std::max<uint32_t>(src_want, 16);
+	// This engine can do better (NXZ_JOB_SUSPEND_WHEN_FULL, include/nxz_engine.h): a job whose target fills
+	// up suspends there and is resumed, nothing is decoded twice, so the source need not be rationed.
+	const bool suspend_when_full = device_dht_available();
+	if (suspend_when_full) src_want = 1u << 20;
 	for (int attempt = 0; attempt < 24; attempt++) {
 		uint32_t histlen = (uint32_t)s->hist.size();
 		uint32_t pad = (16 - (histlen & 15)) & 15;                 // history prefix is given in 16-byte units
@@ -786,6 +791,7 @@ int inflate_job(Inflate *s)
 		memset(j, 0, sizeof(*j));
 		const bool resume = s->resuming || histlen;
 		nxz_set_fc(j, resume ? NXZ_FC_DECOMPRESS_RESUME : NXZ_FC_DECOMPRESS);
+		if (suspend_when_full) nxz_wr32(&j->crb.reserved1, NXZ_JOB_SUSPEND_WHEN_FULL);
 		nxz_set_in_histlen(&j->cpb, (pad + histlen) / 16);
 		nxz_set_in_crc(&j->cpb, s->crc); nxz_set_in_adler(&j->cpb, s->adler);
 		if (s->resuming) {
