@@ -297,6 +297,25 @@ int nxz_inflate_stream(nxz_ctx_t *ctx, const uint8_t *src, uint64_t src_len, uin
 		       uint64_t *out_len, uint32_t *crc, uint32_t *adler, uint64_t *end_bit,
 		       uint32_t *pieces, uint32_t *rounds, void *stream);
 
+/* The same for a PART of a stream -- what a caller of inflate() holds at one time (additive).  *state
+ * in: where the stream stands at first_bit -- all zero at a block header (or the stream's start), else
+ * the fields a suspended decompress job reported (out_sfbt with bit 3 set, out_rembytecnt, out_dhtlen /
+ * out_dht; first_bit = 8 - in_subc of the partly used first byte); out: the same for *end_bit, which
+ * is the end of src unless state->final (the final block ended at *end_bit) or the output of the
+ * pieces further on did not fit dst_cap (then *end_bit is a block header before the end of src, state
+ * all zero).  -E2BIG only when not even the first piece fits.  Everything else as above. */
+typedef struct nxz_stream_resume {
+	uint32_t sfbt;                 /* 0, or 0x8 | BFINAL inside a stored block, 0xa | fixed, 0xc | dynamic, 0xe | in a header */
+	uint32_t rem;                  /* stored: bytes of the block still to come */
+	uint32_t dhtlen;               /* dynamic: bits of the table in dht */
+	uint32_t final;                /* out: the final block ended at *end_bit */
+	uint8_t  dht[NXZ_DHT_MAXSZ];
+} nxz_stream_resume_t;
+int nxz_inflate_stream_part(nxz_ctx_t *ctx, const uint8_t *src, uint64_t src_len, uint64_t first_bit,
+			    const uint8_t *hist, uint32_t hist_len, uint8_t *dst, uint64_t dst_cap,
+			    uint64_t *out_len, uint32_t *crc, uint32_t *adler, uint64_t *end_bit,
+			    nxz_stream_resume_t *state, uint32_t *pieces, void *stream);
+
 /* A long HOST buffer -> ONE raw deflate stream in a HOST buffer (additive; what nx_deflate makes of
  * it job after job, lib/nx_deflate.c:1440-1719, for the levels that carry no history from job to job,
  * :654-680).  The source is cut into 64 KiB blocks, compressed side by side (fc = NXZ_FC_COMPRESS_FHT,

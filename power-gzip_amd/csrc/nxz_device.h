@@ -43,7 +43,7 @@ int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_dht_prepare
 int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 		       nxz_batch_dht_t *dht_io, int window_in_lds, hipStream_t stream);
-int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
+int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, hipStream_t stream);
 int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n, uint32_t final_index,
 			   uint64_t *offsets, uint8_t *packed, hipStream_t stream);

@@ -13,7 +13,9 @@
 #include <new>
 #include <cstring>
 #include <unistd.h>
+#include <algorithm>
 #include "../../include/nxz_zlib.h"
+#include "nxz_host.h"
 
 // The reference's gz layer keeps this flag in a global that ends up in its ABI (lib/nx_gzlib.c:55,
 // test/libnxz.abi): set once a file has been opened for writing.
@@ -117,25 +119,38 @@ extern "C" int nx_gzread(void *file, void *buf, unsigned len)
 			g->cur = g->buf; g->used = (unsigned)r;
 			if (r == 0) g->eof = true;
 		}
-		if (g->used == 0) {                                 // end of file: let the stream finish (it may hold output yet)
+		int rc;
+		if (g->used == 0) {                                 // end of file: let the stream finish (it may hold output, and source, yet)
 			const uInt had = g->strm.avail_out;
 			g->strm.next_in = g->buf; g->strm.avail_in = 0;
-			int rc = nx_inflate(&g->strm, Z_FINISH);
-			if (rc == Z_STREAM_END) { g->done = true; break; }
-			if (rc != Z_OK && rc != Z_BUF_ERROR) { g->err = rc; g->done = true; break; }
-			if (g->strm.avail_out == had) { g->done = true; break; }     // nothing more to come: a truncated file
-			continue;
+			rc = nx_inflate(&g->strm, Z_FINISH);
+			if (rc != Z_STREAM_END) {
+				if (rc != Z_OK && rc != Z_BUF_ERROR) { g->err = rc; g->done = true; break; }
+				if (g->strm.avail_out == had) { g->done = true; break; }     // nothing more to come: a truncated file
+				continue;
+			}
+		} else {
+			g->strm.next_in = g->cur; g->strm.avail_in = g->used;
+			rc = nx_inflate(&g->strm, Z_NO_FLUSH);
+			g->cur = (unsigned char *)g->strm.next_in; g->used = g->strm.avail_in;
 		}
-		g->strm.next_in = g->cur; g->strm.avail_in = g->used;
-		int rc = nx_inflate(&g->strm, Z_NO_FLUSH);
-		g->cur = (unsigned char *)g->strm.next_in; g->used = g->strm.avail_in;
 		if (rc == Z_STREAM_END) {
 			// a gzip file is a sequence of members (RFC 1952 2.2; this library's own nxz_gzip and bgzip
 			// write one per block): go on with the next one, as zlib's gzread does.  Zero bytes between
 			// or behind members are padding.
 			produced += g->strm.total_out - before;
+			// what the stream took beyond its own end (it gathers small inputs, and hands the engine more than one
+			// member's worth) comes back in front of what we still hold
+			if (const size_t ung = nxz_inflate_unget_size(&g->strm)) {
+				unsigned char *nb = (unsigned char *)malloc(std::max<size_t>(RBUF, ung + g->used));
+				if (!nb) { g->err = Z_MEM_ERROR; break; }
+				nxz_inflate_take_unget(&g->strm, nb);
+				if (g->used) memcpy(nb + ung, g->cur, g->used);
+				free(g->buf);
+				g->buf = g->cur = nb; g->used += (unsigned)ung;
+			}
 			while (g->used && *g->cur == 0) { g->cur++; g->used--; }
-			if (g->used == 0) {
+			if (g->used == 0 && !g->eof) {
 				ssize_t r;
 				do r = read(g->fd, g->buf, RBUF); while (r < 0 && errno == EINTR);
 				if (r < 0) { g->err = Z_ERRNO; break; }

@@ -25,6 +25,12 @@ nxz_dht_state *nxz_dht_copy(const nxz_dht_state *s);
 void nxz_dht_lookup(nxz_dht_state *s, const uint32_t *counts, long source_bytes,
 		    uint8_t *dht_out, uint32_t *dhtlen_out);
 
+
+/* a finished inflate stream: the bytes it took from next_in that lie behind its trailer (nxz_stream.cpp) */
+struct z_stream_s;
+size_t nxz_inflate_unget_size(struct z_stream_s *strm);
+void   nxz_inflate_take_unget(struct z_stream_s *strm, unsigned char *dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@
 // end of block, errors, the last bytes of the source, a full target) is left to the one-token
 // path below it, which keeps the suspend/error semantics exactly as before.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include "nxz_device.h"
 
@@ -61,9 +62,12 @@ struct HuffD {
 
 // GW: the window is the target itself (and the history in front of the source) in global memory,
 // for batches: 7.6 KiB of LDS per stream instead of 39.5, so 16 streams per CU instead of 4.
-template <bool GW>
+// (W16 without GW: a window of 16-bit elements in LDS, 64 KiB -- two streams per CU, for the few pieces of a
+// short stretch of a stream, where one wavefront's latency is all that counts)
+template <bool GW, bool W16 = false>
 struct SmemT {
-	uint8_t win[GW ? 16 : WIN];
+	typedef typename std::conditional<W16, uint16_t, uint8_t>::type elem_t;
+	elem_t win[GW ? 16 : WIN];
 	uint32_t stage[STAGE / 4 + 4];
 	Huff hl;
 	HuffD hd;
@@ -356,7 +360,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 						     nxz_batch_result_t *__restrict__ results,
 						     nxz_batch_dht_t *__restrict__ dht_io)
 {
-	__shared__ __attribute__((aligned(16))) SmemT<GW> sm;
+	__shared__ __attribute__((aligned(16))) SmemT<GW, W16> sm;
+	typedef typename SmemT<GW, W16>::elem_t elem_t;
 	const int lane = threadIdx.x;
 	const nxz_batch_job_t job = jobs[blockIdx.x];
 	const uint32_t hist_bytes = job.hist_len < job.src_len ? job.hist_len : job.src_len;
@@ -369,15 +374,15 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	const NXZ_GLOBAL_AS uint8_t *hist_end = (const NXZ_GLOBAL_AS uint8_t *)job.src + hist_bytes;
 	NXZ_GLOBAL_AS uint16_t *dst16 = (NXZ_GLOBAL_AS uint16_t *)job.dst;
 	auto wr = [&](uint32_t p, uint32_t v) __attribute__((always_inline)) {
-		if (W16) dst16[p] = (uint16_t)v;
+		if (W16 && GW) dst16[p] = (uint16_t)v;
 		else if (GW) dst[p] = (uint8_t)v;
-		else sm.win[p & WMASK] = (uint8_t)v;
+		else sm.win[p & WMASK] = (elem_t)v;
 	};
 	uint32_t out = 0, flushed = 0;             // bytes produced / bytes already written to dst
 	// read position p of the window for a match that writes at `at` (p is 1..32768 bytes behind `at`;
 	// what lies in front of position 0 is the history)
 	auto rd = [&](uint32_t p, uint32_t at) __attribute__((always_inline)) -> uint32_t {
-		if (W16) { const uint32_t back = at - p; return back > at ? 0x8000u | (WIN - (back - at)) : dst16[p]; }
+		if (W16 && GW) { const uint32_t back = at - p; return back > at ? 0x8000u | (WIN - (back - at)) : dst16[p]; }
 		if (GW) { const uint32_t back = at - p; return back > at ? hist_end[-(ptrdiff_t)(back - at)] : dst[p]; }
 		return sm.win[p & WMASK];
 	};
@@ -440,7 +445,9 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	{
 		uint32_t h = hist_bytes > WIN ? WIN : hist_bytes;
 		const NXZ_GLOBAL_AS uint8_t *hp = (const NXZ_GLOBAL_AS uint8_t *)job.src + (hist_bytes - h);
-		if (!GW) for (uint32_t i = lane; i < h; i += 64) sm.win[(0u - h + i) & WMASK] = hp[i];
+		if (!GW && !W16) for (uint32_t i = lane; i < h; i += 64) sm.win[(0u - h + i) & WMASK] = hp[i];
+		// (16-bit elements: what lies in front of the output is unknown -- byte k of those 32 KiB is the element 0x8000 | k)
+		if (!GW && W16) for (uint32_t i = lane; i < WIN; i += 64) sm.win[i] = (elem_t)(0x8000u | i);
 	}
 	__syncthreads();
 
@@ -471,12 +478,14 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 		while (flushed < upto) {
 			uint32_t n = upto - flushed < FLUSH ? upto - flushed : FLUSH;
 			// coalesced copy out (dst + flushed is 16 B aligned when flushed is a multiple of FLUSH)
-			for (uint32_t i = lane * 16; i < n; i += 64 * 16) {
-				if (i + 16 <= n) {
+			constexpr uint32_t EPV = 16 / sizeof(elem_t);             // elements per 16 bytes
+			NXZ_GLOBAL_AS elem_t *de = (NXZ_GLOBAL_AS elem_t *)job.dst;
+			for (uint32_t i = lane * EPV; i < n; i += 64 * EPV) {
+				if (i + EPV <= n) {
 					uint4 v = *(const uint4 *)&sm.win[(flushed + i) & WMASK];
-					*(uint4 *)(dst + flushed + i) = v;
+					*(uint4 *)(de + flushed + i) = v;
 				} else {
-					for (uint32_t k = i; k < n; k++) dst[flushed + k] = sm.win[(flushed + k) & WMASK];
+					for (uint32_t k = i; k < n; k++) de[flushed + k] = sm.win[(flushed + k) & WMASK];
 				}
 			}
 			flushed += n;
@@ -865,9 +874,13 @@ extern "C" int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_bat
 }
 
 // nxz_inflate_stream's pieces: 16-bit elements, references into the unknown 32 KiB in front as 0x8000 | index
-extern "C" int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream)
+extern "C" int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, hipStream_t stream)
 {
 	if (!n) return 0;
-	hipLaunchKernelGGL((nxzi::inflate_kernel<true, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, (nxz_batch_dht_t *)nullptr);
+	// a few pieces (all of them resident at two per CU): the window in LDS, where a match costs one wavefront
+	// a fraction of the trip to device memory
+	static const unsigned lds_max = getenv("NXZ_INFLATE_W16_LDS_MAX") ? (unsigned)atoi(getenv("NXZ_INFLATE_W16_LDS_MAX")) : 512;
+	if (n <= lds_max) hipLaunchKernelGGL((nxzi::inflate_kernel<false, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
+	else hipLaunchKernelGGL((nxzi::inflate_kernel<true, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
 	return (int)hipGetLastError();
 }

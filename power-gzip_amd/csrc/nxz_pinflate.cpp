@@ -110,8 +110,8 @@ inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 } // namespace
 
-// Raw deflate stream at src (DEVICE memory, src_len bytes; it starts at bit first_bit and must run
-// to a final block) -> dst (DEVICE).  hist (may be NULL): up to 32 KiB of DEVICE bytes that precede
+// Raw deflate stream at src (DEVICE memory, src_len bytes; it starts at bit first_bit and, unless
+// `st` is given, must run to a final block) -> dst (DEVICE).  hist (may be NULL): up to 32 KiB of DEVICE bytes that precede
 // the output (a preset dictionary or what was inflated before).  Synchronous.
 //   0        done: *out_len bytes, checksums of them continued from 0 / 1 style initial values
 //            (crc of the data alone, adler of the data alone: combine with yours), *end_bit = first
@@ -119,10 +119,14 @@ inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 //   -ENOTSUP the stream does not lend itself to this (too short, too few dynamic blocks, a piece that
 //            blows its buffer, no final block inside src): use the ordinary resume loop
 //   -E2BIG   dst_cap is too small (*out_len = bytes needed)        -EILSEQ  the data is not deflate
-extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, uint64_t first_bit,
-				  const uint8_t *hist, uint32_t hist_len,
-				  uint8_t *dst, uint64_t dst_cap, uint64_t *out_len, uint32_t *crc, uint32_t *adler,
-				  uint64_t *end_bit, uint32_t *pieces, uint32_t *rounds, void *stream_)
+// st (nxz_inflate_stream_part): a PART of a stream -- what a caller of inflate() holds at one time.  In:
+// where the stream stands at first_bit (inside a block: the resume fields a suspended job reported);
+// out: where it stands at *end_bit, which is the end of src -- the last piece simply runs out of source
+// like any suspended job -- or the header of the first piece whose output no longer fits dst_cap.
+static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, uint64_t first_bit,
+			  const uint8_t *hist, uint32_t hist_len,
+			  uint8_t *dst, uint64_t dst_cap, uint64_t *out_len, uint32_t *crc, uint32_t *adler,
+			  uint64_t *end_bit, nxz_stream_resume_t *st, uint32_t *pieces, uint32_t *rounds, void *stream_)
 {
 	if (!c || !src || !dst || !out_len) return -EINVAL;
 	hipStream_t s = (hipStream_t)stream_;
@@ -176,9 +180,11 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 	const size_t o_jobs = 0, o_res = o_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), o_items = o_res + up(n0 * sizeof(nxz_batch_result_t), 256),
 		     o_pieces = o_items + up((n0 + 4) * sizeof(CopyItem), 256), o_win0 = o_pieces + up(n0 * sizeof(Piece), 256),
 		     o_windows = o_win0 + WINDOW, o_maps = o_windows + n0 * (size_t)WINDOW, o_gmaps = o_maps + n0 * (size_t)WINDOW * 2,
-		     o_gwin = o_gmaps + ng0 * (size_t)WINDOW * 2, o_bump = o_gwin + ng0 * (size_t)WINDOW;
+		     o_gwin = o_gmaps + ng0 * (size_t)WINDOW * 2, o_dht = o_gwin + ng0 * (size_t)WINDOW,
+		     o_bump = o_dht + up(n0 * sizeof(nxz_batch_dht_t), 256);
 	const size_t pin_jobs = 0, pin_res = pin_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), pin_items = pin_res + up(n0 * sizeof(nxz_batch_result_t), 256),
-		     pin_pieces = pin_items + up((n0 + 4) * sizeof(CopyItem), 256), pin_total = pin_pieces + up(n0 * sizeof(Piece), 256);
+		     pin_pieces = pin_items + up((n0 + 4) * sizeof(CopyItem), 256), pin_dht = pin_pieces + up(n0 * sizeof(Piece), 256),
+		     pin_total = pin_dht + up(2 * sizeof(nxz_batch_dht_t), 256);          // (first piece's table in, last piece's out)
 	size_t bump = 0, reserved = 0;
 	auto size_piece = [&](P &p, uint64_t next_bit) -> bool {
 		p.cstart = p.bit >> 3;
@@ -197,6 +203,8 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 		if (!size_piece(pc[i], i + 1 < pc.size() ? pc[i + 1].bit : 0)) return -ENOTSUP;
 	uint8_t *D = nullptr, *PN = nullptr;
 	bool win0_made = false;
+	nxz_batch_dht_t last_dht;                       // the table in force where the last piece stopped
+	last_dht.dhtlen = 0;
 	for (int attempt = 0; ; attempt++) {
 		if (bump > reserved || !ws.dev) {
 			// (first attempt, or the repeats outgrew the room left for them: everything is placed and decoded anew)
@@ -219,14 +227,15 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 		for (size_t i = 0; i < pc.size(); i++) {
 			P &p = pc[i];
 			if (p.done) continue;
-			uint8_t *st = D + o_bump + p.stage_off;
-			h_items[ni++] = CopyItem{ src + p.cstart, st, p.cbytes };
+			uint8_t *stg = D + o_bump + p.stage_off;
+			h_items[ni++] = CopyItem{ src + p.cstart, stg, p.cbytes };
 			nxz_batch_job_t &j = h_jobs[nj++];
 			memset(&j, 0, sizeof(j));
-			j.src = st; j.src_len = (uint32_t)p.cbytes; j.hist_len = 0;
+			j.src = stg; j.src_len = (uint32_t)p.cbytes; j.hist_len = 0;
 			j.dst = D + o_bump + p.out_off; j.dst_cap = (uint32_t)p.cap;
 			const uint32_t sub = (uint32_t)(p.bit & 7);
 			j.resume = (0xeu << 16) | ((sub ? 8 - sub : 0) << 20);
+			if (i == 0 && st && (st->sfbt & 8)) j.resume = (st->rem & 0xffff) | ((st->sfbt & 0xf) << 16) | ((sub ? 8 - sub : 0) << 20);
 			who.push_back(i);
 		}
 		if (!win0_made) {
@@ -237,12 +246,23 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 		}
 		if (hipMemcpyAsync(d_items, h_items, ni * sizeof(CopyItem), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 		if (hipMemcpyAsync(d_jobs, h_jobs, nj * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+		// tables: in for a first piece that resumes inside a dynamic block, out for a last piece that stops inside one
+		nxz_batch_dht_t *d_dht = st ? (nxz_batch_dht_t *)(D + o_dht) : nullptr, *h_dht = (nxz_batch_dht_t *)(PN + pin_dht);
+		if (st && nj && who[0] == 0 && (st->sfbt & 0xe) == 0xc) {
+			memset(&h_dht[0], 0, sizeof(h_dht[0]));
+			h_dht[0].dhtlen = st->dhtlen;
+			memcpy(h_dht[0].dht, st->dht, NXZ_DHT_MAXSZ);
+			if (hipMemcpyAsync(d_dht, &h_dht[0], sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+		}
 		if (nxz_launch_copy_items(d_items, (uint32_t)ni, s)) return -EIO;
 		lap("staging");
-		if (nxz_launch_inflate_w16(d_jobs, nj, d_res, s)) return -EIO;
+		if (nxz_launch_inflate_w16(d_jobs, nj, d_res, d_dht, s)) return -EIO;
 		lap("decode");
 		if (hipMemcpyAsync(h_res, d_res, nj * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+		const bool last_ran = st && nj && who[nj - 1] == pc.size() - 1;
+		if (last_ran && hipMemcpyAsync(&h_dht[1], d_dht + (nj - 1), sizeof(nxz_batch_dht_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 		if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+		if (last_ran) last_dht = h_dht[1];
 		for (size_t k = 0; k < nj; k++) { pc[who[k]].res = h_res[k]; pc[who[k]].done = true; }
 		// every piece but the last must stop at the header of the next one; the last at the final block's end
 		bool again = false;
@@ -270,8 +290,11 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 				continue;
 			}
 			const bool err = r.cc != NXZ_CC_DATA_LENGTH && r.cc != 0;
+			// the final block ended in this piece: what lies behind it (a trailer, another gzip member, anything)
+			// is not this stream's, and block starts seen there are no concern of ours
+			const bool fin = !err && (r.sfbt & 0x100);
 			bool ends_well = !err;
-			if (i + 1 < pc.size()) {
+			if (!fin && i + 1 < pc.size()) {
 				const uint64_t used = p.cbytes * 8 - r.subc, want = pc[i + 1].bit - p.cstart * 8;
 				const uint32_t kind = r.sfbt & 0xe;
 				ends_well = r.cc == NXZ_CC_DATA_LENGTH && ((kind == 0xe && used == want) || (kind == 0xa && used == want + 3));
@@ -294,20 +317,45 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 			}
 			confirmed = conf && ends_well && p.done;
 			nx.push_back(p);
+			if (fin) break;
 		}
-		if (!again) break;
-		if (attempt >= 23 || nx.size() < 2) return -ENOTSUP;
 		pc.swap(nx);
+		if (!again) break;
+		if (attempt >= 23 || pc.size() < 2) return -ENOTSUP;
 		for (size_t i = 0; i < pc.size(); i++)
 			if (!pc[i].done && !size_piece(pc[i], i + 1 < pc.size() ? pc[i + 1].bit : 0)) return -ENOTSUP;
 	}
-	const size_t n = pc.size();
-	// the last piece must have seen the final block
+	size_t n = pc.size();
+	if (!n) return -ENOTSUP;
+	// where the decoded part ends: the last piece must have seen the final block, or (a part of a stream)
+	// stopped at the end of the source like any suspended job; pieces whose output no longer fits are left
+	// for the next call, which then starts at a block header
 	{
-		const nxz_batch_result_t &r = pc[n - 1].res;
+		uint64_t sum = 0;
+		size_t m = 0;
+		while (m < n && sum + pc[m].res.tpbc <= dst_cap) sum += pc[m++].res.tpbc;
+		if (m < n && (!st || m == 0)) {
+			for (sum = 0, m = 0; m < n; m++) sum += pc[m].res.tpbc;
+			*out_len = sum;
+			return -E2BIG;
+		}
+		const bool cut = m < n;
+		const P &lp = pc[m - 1];
+		const nxz_batch_result_t &r = lp.res;
 		if (r.cc != 0 && r.cc != NXZ_CC_DATA_LENGTH) return -EILSEQ;
-		if (!(r.sfbt & 0x100)) return -ENOTSUP;
-		if (end_bit) *end_bit = src_len * 8 - r.subc;
+		const bool fin = (r.sfbt & 0x100) != 0;
+		if (!fin && !st) return -ENOTSUP;
+		const uint64_t stop = cut ? pc[m].bit : (lp.cstart + r.spbc) * 8 - r.subc;
+		if (end_bit) *end_bit = stop;
+		if (st) {
+			memset(st, 0, sizeof(*st));
+			st->final = fin && !cut;
+			if (!fin && !cut) {
+				st->sfbt = r.sfbt & 0xf; st->rem = r.tebc;
+				if ((r.sfbt & 0xe) == 0xc) { st->dhtlen = (r.sfbt >> 16) & 0xfff; memcpy(st->dht, last_dht.dht, NXZ_DHT_MAXSZ); }
+			}
+		}
+		n = m;
 	}
 	// ---- places, true windows, resolution ----
 	uint8_t *P_ = (uint8_t *)ws.pin;
@@ -333,6 +381,7 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 	// ---- checksums: 256 KiB slices of the output (the job / result arrays are free again) ----
 	const size_t nsl = (size_t)((total + SLICE - 1) / SLICE);
 	std::vector<nxz_batch_result_t> sres(nsl);
+	if (!nsl) { if (crc) *crc = 0; if (adler) *adler = 1; }
 	for (size_t o = 0; o < nsl; o += n0) {
 		const size_t m = std::min(nsl - o, n0);
 		nxz_batch_job_t *h_jobs = (nxz_batch_job_t *)(P_ + pin_jobs);
@@ -359,6 +408,7 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 	}
 	const uint32_t nround = 1;
 	uint32_t cr = 0, ad = 1;
+	if (!nsl) return 0;
 	for (size_t k = 0; k < nsl; k++) {
 		cr = k ? crc_combine(cr, sres[k].crc, sres[k].tpbc) : sres[k].crc;
 		ad = k ? adler_combine(ad, sres[k].adler, sres[k].tpbc) : sres[k].adler;
@@ -368,4 +418,22 @@ extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src
 	if (pieces) *pieces = (uint32_t)n;
 	if (rounds) *rounds = nround;
 	return 0;
+}
+
+extern "C" int nxz_inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, uint64_t first_bit,
+				  const uint8_t *hist, uint32_t hist_len,
+				  uint8_t *dst, uint64_t dst_cap, uint64_t *out_len, uint32_t *crc, uint32_t *adler,
+				  uint64_t *end_bit, uint32_t *pieces, uint32_t *rounds, void *stream)
+{
+	return inflate_stream(c, src, src_len, first_bit, hist, hist_len, dst, dst_cap, out_len, crc, adler, end_bit, nullptr, pieces, rounds, stream);
+}
+
+// A part of a stream (include/nxz_engine.h): what inflate() holds at one time.
+extern "C" int nxz_inflate_stream_part(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, uint64_t first_bit,
+				       const uint8_t *hist, uint32_t hist_len,
+				       uint8_t *dst, uint64_t dst_cap, uint64_t *out_len, uint32_t *crc, uint32_t *adler,
+				       uint64_t *end_bit, nxz_stream_resume_t *state, uint32_t *pieces, void *stream)
+{
+	if (!state) return -EINVAL;
+	return inflate_stream(c, src, src_len, first_bit, hist, hist_len, dst, dst_cap, out_len, crc, adler, end_bit, state, pieces, nullptr, stream);
 }

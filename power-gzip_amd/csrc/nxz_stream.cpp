@@ -630,6 +630,7 @@ struct Inflate {
 	uint64_t total_out = 0;
 	uint8_t trailer[8]; uint32_t ntrailer = 0;
 	bool sync_point = false, have_dict = false;
+	uint32_t par_skip = 0;                             // calls for which the parallel decode is not tried again
 	uint32_t ratio = 250;                              // last compressed/uncompressed per mille (:1234-1250)
 	Engine eng; JobBuf jb; std::vector<uint8_t> src, out;
 
@@ -686,16 +687,18 @@ void publish(Inflate *s)
 	else if (s->wrap == HDR_ZLIB) s->z->adler = s->adler;
 }
 
-// A caller that hands over megabytes of deflate data at once (nx_uncompress, inflate(Z_FINISH) on a
-// whole file) gets the engine's parallel decode of ONE stream (nxz_inflate_stream: block starts are
-// found by speculation, the pieces are inflated side by side) instead of the job-after-job loop
-// below, which is what the reference runs (lib/nx_inflate.c:1143-1744) and is only as fast as one
-// wavefront.  Everything the engine declines (short input, stream not complete inside avail_in,
-// output does not fit avail_out, hardly any dynamic blocks) falls through to that loop.
+// A caller that hands over a good deal of deflate data at once (nx_uncompress, inflate() on a whole file
+// or with buffers of a megabyte) gets the engine's parallel decode of ONE stream (nxz_inflate_stream_part:
+// block starts are found by speculation, the pieces are inflated side by side) instead of the
+// job-after-job loop below, which is what the reference runs (lib/nx_inflate.c:1143-1744) and is only
+// as fast as one wavefront.  What the caller holds need not be the whole stream: the part may begin
+// inside a block (the resume fields of whatever ran before) and ends where the source ends, with the
+// same resume fields a suspended job reports; output beyond avail_out waits in `pend` like a job's.
+// Everything the engine declines (short input, hardly any dynamic blocks) falls through to that loop.
 // (Weak references: the CPU model of the test suite has no such entry points.)
 extern "C" {
-int nxz_inflate_stream(nxz_ctx_t *, const uint8_t *, uint64_t, uint64_t, const uint8_t *, uint32_t, uint8_t *, uint64_t,
-		       uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, void *) __attribute__((weak));
+int nxz_inflate_stream_part(nxz_ctx_t *, const uint8_t *, uint64_t, uint64_t, const uint8_t *, uint32_t, uint8_t *, uint64_t,
+			    uint64_t *, uint32_t *, uint32_t *, uint64_t *, nxz_stream_resume_t *, uint32_t *, void *) __attribute__((weak));
 void *nxz_dev_malloc(nxz_ctx_t *, size_t) __attribute__((weak));
 void nxz_dev_free(nxz_ctx_t *, void *) __attribute__((weak));
 int nxz_copy_to_device(nxz_ctx_t *, void *, const void *, size_t, void *) __attribute__((weak));
@@ -707,13 +710,20 @@ constexpr size_t PARALLEL_INFLATE_MIN = 48u << 10;
 bool parallel_inflate(Inflate *s)
 {
 	z_streamp z = s->z;
-	if (!nxz_inflate_stream || !nxz_dev_malloc || !nxz_dev_free || !nxz_copy_to_device || !nxz_copy_to_host || !nxz_ctx_sync) return false;
-	if (s->resuming || !s->carry.empty() || s->pending() || !s->eng.open) return false;
+	if (!nxz_inflate_stream_part || !nxz_dev_malloc || !nxz_dev_free || !nxz_copy_to_device || !nxz_copy_to_host || !nxz_ctx_sync) return false;
+	if (s->pending() || !s->eng.open) return false;
 	static const bool off = getenv("NXZ_PARALLEL_INFLATE") && atoi(getenv("NXZ_PARALLEL_INFLATE")) == 0;   // 0: always job after job
-	if (off || z->avail_in < PARALLEL_INFLATE_MIN || z->avail_out < z->avail_in) return false;
+	const size_t nc = s->carry.size();
+	if (off || nc + z->avail_in < PARALLEL_INFLATE_MIN) return false;
+	if (s->par_skip) { s->par_skip--; return false; }           // (declined a moment ago: this stream is not the kind)
 	nxz_ctx_t *ctx = (nxz_ctx_t *)s->eng.dev.paste_addr;
 	if (!ctx) return false;
-	const size_t nin = z->avail_in, cap = z->avail_out, nh = s->hist.size();
+	// all of next_in when the target can take what it makes; otherwise about a megabyte at a time (the surplus
+	// output waits in `pend`)
+	size_t take = z->avail_in;
+	if (z->avail_out < 2 * (nc + take)) take = std::min<size_t>(take, std::max<size_t>(1u << 20, z->avail_out));
+	const size_t nin = nc + take, nh = s->hist.size();
+	const size_t cap = z->avail_out >= 2 * nin ? (size_t)z->avail_out : std::max<size_t>(z->avail_out, 8 * nin);
 	// device buffers for the stream and its output: kept from call to call (grow only), one large call at a time
 	static std::mutex pool_mtx;
 	static uint8_t *pool_src = nullptr, *pool_dst = nullptr, *pool_hist = nullptr;
@@ -731,29 +741,76 @@ bool parallel_inflate(Inflate *s)
 	static const bool trace = getenv("NXZ_API_TRACE") != nullptr;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t0 = trace ? now() : 0;
-	if (ok) ok = nxz_copy_to_device(ctx, d_src, z->next_in, nin, nullptr) == 0 && (!nh || nxz_copy_to_device(ctx, d_hist, s->hist.data(), nh, nullptr) == 0);
+	if (ok) ok = (!nc || nxz_copy_to_device(ctx, d_src, s->carry.data(), nc, nullptr) == 0) && (!take || nxz_copy_to_device(ctx, d_src + nc, z->next_in, take, nullptr) == 0) &&
+		     (!nh || nxz_copy_to_device(ctx, d_hist, s->hist.data(), nh, nullptr) == 0);
 	if (ok && trace) (void)nxz_ctx_sync(ctx, nullptr);
 	const double t1 = trace ? now() : 0;
-	if (ok) ok = nxz_inflate_stream(ctx, d_src, nin, 0, d_hist, (uint32_t)nh, d_dst, cap, &out_len, &crc, &adler, &end_bit, nullptr, nullptr, nullptr) == 0;
+	// where the stream stands at the first byte: the fields of the last suspension (a job's or a part's)
+	nxz_stream_resume_t st;
+	memset(&st, 0, sizeof(st));
+	uint64_t first_bit = 0;
+	if (s->resuming) {
+		st.sfbt = s->sfbt; st.rem = s->rem; st.dhtlen = s->dhtlen; memcpy(st.dht, s->dht, NXZ_DHT_MAXSZ);
+		first_bit = s->subc ? 8 - s->subc : 0;
+	}
+	int prc = -1;
+	if (ok) prc = nxz_inflate_stream_part(ctx, d_src, nin, first_bit, d_hist, (uint32_t)nh, d_dst, cap, &out_len, &crc, &adler, &end_bit, &st, nullptr, nullptr);
+	ok = ok && prc == 0 && end_bit >= first_bit && end_bit <= (uint64_t)nin * 8 && (out_len || (end_bit >> 3));
 	const double t2 = trace ? now() : 0;
-	if (ok) ok = nxz_copy_to_host(ctx, z->next_out, d_dst, out_len, nullptr) == 0 && nxz_ctx_sync(ctx, nullptr) == 0;
-	if (trace) fprintf(stderr, "nxz parallel_inflate: %zu bytes in, copy in %.2f ms, inflate %.2f ms, copy out %.2f ms (%llu bytes)%s\n", nin, t1 - t0, t2 - t1, now() - t2,
-			   (unsigned long long)out_len, ok ? "" : " -- declined");
-	if (!ok) return false;
-	const size_t consumed = (size_t)((end_bit + 7) / 8);
-	const uint8_t *outp = z->next_out;
-	z->next_in += consumed; z->avail_in -= (uInt)consumed; z->total_in += consumed;
-	z->next_out += out_len; z->avail_out -= (uInt)out_len; z->total_out += out_len;
+	// the output: as much as the caller has room for goes straight to next_out, the rest waits; the last 32 KiB are the next history
+	const size_t direct = (size_t)std::min<uint64_t>(out_len, z->avail_out), later = ok ? (size_t)out_len - direct : 0;
+	std::vector<uint8_t> tail;
+	if (ok) {
+		s->pend.resize(later); s->pend_off = 0;
+		tail.resize((size_t)std::min<uint64_t>(out_len, WINDOW));
+		ok = (!direct || nxz_copy_to_host(ctx, z->next_out, d_dst, direct, nullptr) == 0) && (!later || nxz_copy_to_host(ctx, s->pend.data(), d_dst + direct, later, nullptr) == 0) &&
+		     (tail.empty() || nxz_copy_to_host(ctx, tail.data(), d_dst + out_len - tail.size(), tail.size(), nullptr) == 0) && nxz_ctx_sync(ctx, nullptr) == 0;
+		if (!ok) s->pend.clear();
+	}
+	if (trace) fprintf(stderr, "nxz parallel_inflate: %zu bytes in (%zu carried), copy in %.2f ms, inflate %.2f ms, copy out %.2f ms (%llu bytes, %zu wait)%s\n", nin, nc, t1 - t0, t2 - t1, now() - t2,
+			   (unsigned long long)out_len, later, ok ? (st.final ? " -- final" : "") : " -- declined");
+	if (!ok) { s->par_skip = 4; return false; }
+	// the source: [carry][next_in .. take); whole bytes used, and the byte the part stopped in (supplied again)
+	auto at = [&](size_t i) -> uint8_t { return i < nc ? s->carry[i] : z->next_in[i - nc]; };
+	const size_t consumed = st.final ? (size_t)((end_bit + 7) >> 3) : (size_t)(end_bit >> 3);
+	bool sync_point = false;
+	if (!st.final) {
+		const uint64_t subc = (uint64_t)nin * 8 - end_bit;            // bits not processed, as a suspended job counts them
+		if ((st.sfbt & 0xe) == 0xe && subc >= 3 && subc <= 10 && nin >= 2)      // right behind an empty stored block's header (lib/nx_inflate.c:1563-1583)
+			sync_point = subc <= 8 ? !(at(nin - 1) & (uint8_t)(0xff << (8 - subc))) : (at(nin - 1) == 0 && !(at(nin - 2) & (uint8_t)(0xff << (16 - subc))));
+	}
+	std::vector<uint8_t> rest;
+	rest.reserve(nin - consumed);
+	for (size_t i = consumed; i < nc; i++) rest.push_back(s->carry[i]);
+	const size_t from_next0 = consumed > nc ? consumed - nc : 0;
+	rest.insert(rest.end(), z->next_in + from_next0, z->next_in + take);
+	z->next_in += take; z->avail_in -= (uInt)take; z->total_in += take;
+	if (st.final || rest.size() > (1u << 20)) {
+		// what is not this stream's (or was left for want of room) goes back to the caller's view as far as it came from next_in
+		const size_t giveback = std::min<size_t>(rest.size(), take - from_next0);
+		z->next_in -= giveback; z->avail_in += (uInt)giveback; z->total_in -= giveback;
+		rest.resize(rest.size() - giveback);
+	}
+	s->carry.swap(rest);
+	z->next_out += direct; z->avail_out -= (uInt)direct; z->total_out += direct;
 	s->crc = (uint32_t)nx_crc32_combine(s->crc, crc, (off_t)out_len);
 	s->adler = (uint32_t)nx_adler32_combine(s->adler, adler, (off_t)out_len);
 	s->total_out += out_len;
-	if (out_len >= WINDOW) s->hist.assign(outp + out_len - WINDOW, outp + out_len);
+	if (tail.size() >= WINDOW) s->hist.swap(tail);
 	else {
-		const size_t drop = s->hist.size() + out_len > WINDOW ? s->hist.size() + out_len - WINDOW : 0;
+		const size_t drop = s->hist.size() + tail.size() > WINDOW ? s->hist.size() + tail.size() - WINDOW : 0;
 		s->hist.erase(s->hist.begin(), s->hist.begin() + drop);
-		s->hist.insert(s->hist.end(), outp, outp + out_len);
+		s->hist.insert(s->hist.end(), tail.begin(), tail.end());
 	}
-	s->st = Inflate::TRAILER;
+	if (out_len) s->ratio = std::max<uint32_t>(1, std::min<uint32_t>(1000, (uint32_t)((1000ull * (consumed + 1)) / (out_len + 1))));
+	s->sync_point = sync_point;
+	if (st.final) { s->st = Inflate::TRAILER; s->resuming = false; }
+	else {
+		const uint32_t part = (uint32_t)(end_bit & 7);
+		s->resuming = true;
+		s->sfbt = st.sfbt ? st.sfbt : 0xe; s->subc = part ? 8 - part : 0; s->rem = st.rem;
+		if ((st.sfbt & 0xe) == 0xc) { s->dhtlen = st.dhtlen; memcpy(s->dht, st.dht, NXZ_DHT_MAXSZ); }
+	}
 	publish(s);
 	return true;
 }
@@ -862,7 +919,7 @@ int inflate_reset(z_streamp strm)
 	if (s->st != Inflate::DONE) s->unget.clear();           // (behind a finished stream: the next member's first bytes stay)
 	s->st = Inflate::HEADER; s->held = s->nheld = 0; s->gzflags = 0; s->pend.clear(); s->pend_off = 0;
 	s->hist.clear(); s->carry.clear(); s->resuming = false; s->sfbt = s->subc = s->rem = s->dhtlen = 0;
-	s->crc = 0; s->adler = 1; s->total_out = 0; s->ntrailer = 0; s->sync_point = false; s->have_dict = false; s->ratio = 250;
+	s->crc = 0; s->adler = 1; s->total_out = 0; s->ntrailer = 0; s->sync_point = false; s->have_dict = false; s->ratio = 250; s->par_skip = 0;
 	s->hcrc = 0;
 	return Z_OK;
 }
@@ -870,6 +927,18 @@ int inflate_reset(z_streamp strm)
 } // namespace
 
 extern "C" int nx_inflateReset(z_streamp strm) { return inflate_reset(strm); }
+
+// (for the gz-file layer, which puts them back in front of its own buffer: nxz_gzfile.cpp)
+extern "C" size_t nxz_inflate_unget_size(z_streamp strm) { Inflate *s = istate(strm); return s && s->st == Inflate::DONE ? s->unget.size() : 0; }
+extern "C" void nxz_inflate_take_unget(z_streamp strm, unsigned char *dst)
+{
+	Inflate *s = istate(strm);
+	if (!s || s->unget.empty()) return;
+	memcpy(dst, s->unget.data(), s->unget.size());
+	// (they were counted as consumed when they were taken)
+	strm->total_in -= std::min<uLong>(strm->total_in, (uLong)s->unget.size());
+	s->unget.clear();
+}
 
 // The reference's inflateResetKeep is the same reset (lib/nx_inflate.c: resets state, totals and history).
 extern "C" int nx_inflateResetKeep(z_streamp strm) { return inflate_reset(strm); }

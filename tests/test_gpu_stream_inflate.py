@@ -157,3 +157,59 @@ def test_streams_of_a_few_blocks(eng, data, kib):
     if rc == 0:
         assert info["out_len"] == len(plain) and info["crc"] == zlib.crc32(plain)
         assert dst[:len(plain)].cpu().numpy().tobytes() == plain
+
+
+@pytest.mark.parametrize("step_in,step_out", [(1 << 20, 1 << 20), (256 << 10, 64 << 10), (100000, 1 << 20), (3 << 20, 200000), (64 << 10, 4 << 20)])
+def test_inflate_in_steps_takes_parts_of_the_stream(data, step_in, step_out):
+    """inflate() with avail_in / avail_out of 64 KiB - 3 MiB: every call hands the engine a PART
+    of the stream -- it begins wherever the last one stopped (inside a block, with the resume fields) and
+    ends where the source ends; the output beyond avail_out waits for the next call"""
+    L = Z.load("gpu")
+    plain = data[:12 << 20]
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz = co.compress(plain) + co.flush()
+    got, rc, total_in, _ = Z.inflate_all(L, gz, wbits=31, cap=len(plain) + 64, step_in=step_in, step_out=step_out)
+    assert rc == Z.Z_STREAM_END and total_in == len(gz)
+    assert got == plain
+
+
+def test_inflate_in_steps_of_a_mixed_stream(data):
+    """stored stretches, a fixed-Huffman stretch, flush points, huge and tiny blocks, a preset dictionary"""
+    L = Z.load("gpu")
+    rnd = np.random.default_rng(11).integers(0, 256, 2 << 20, dtype=np.uint8).tobytes()
+    dic = data[200000:200000 + 32768]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15, zdict=dic)
+    parts = [data[:3 << 20], rnd, data[3 << 20:5 << 20], b"\0" * (3 << 20), data[5 << 20:(5 << 20) + 70000]]
+    comp = b""
+    for k, p in enumerate(parts):
+        comp += c.compress(p) + c.flush(zlib.Z_FULL_FLUSH if k & 1 else zlib.Z_SYNC_FLUSH)
+    f = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+    more = data[6 << 20:8 << 20]
+    comp += f.compress(more) + f.flush()
+    plain = b"".join(parts) + more
+    for step_in, step_out in ((512 << 10, 512 << 10), (150000, 70000), (len(comp), len(plain) + 64)):
+        got, rc, total_in, _ = Z.inflate_all(L, comp, wbits=-15, cap=len(plain) + 64, step_in=step_in, step_out=step_out, dictionary=dic)
+        assert rc == Z.Z_STREAM_END and total_in == len(comp), (step_in, step_out, rc)
+        assert got == plain, (step_in, step_out)
+
+
+def test_inflate_in_steps_stops_at_the_end_of_the_member(data):
+    """two gzip members back to back: inflate() ends with the first; what follows stays with the caller"""
+    L = Z.load("gpu")
+    a, b = data[:5 << 20], data[5 << 20:7 << 20]
+    ga = zlib.compressobj(6, zlib.DEFLATED, 31); gza = ga.compress(a) + ga.flush()
+    gb = zlib.compressobj(9, zlib.DEFLATED, 31); gzb = gb.compress(b) + gb.flush()
+    for step_in in (len(gza) + len(gzb), 700000):
+        got, rc, total_in, _ = Z.inflate_all(L, gza + gzb, wbits=31, cap=len(a) + 64, step_in=step_in, step_out=1 << 20)
+        assert rc == Z.Z_STREAM_END and got == a and total_in == len(gza), (step_in, rc, total_in, len(gza))
+
+
+def test_damage_is_still_a_data_error_in_steps(data):
+    L = Z.load("gpu")
+    plain = data[:6 << 20]
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz = bytearray(co.compress(plain) + co.flush())
+    for k in range(len(gz) // 2, len(gz) // 2 + 48):
+        gz[k] ^= 0xa5
+    got, rc, _, _ = Z.inflate_all(L, bytes(gz), wbits=31, cap=len(plain) + (1 << 20), step_in=1 << 20, step_out=1 << 20)
+    assert rc == Z.Z_DATA_ERROR
