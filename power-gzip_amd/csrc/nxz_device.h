@@ -43,6 +43,16 @@ int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_dht_prepare
 int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 		       nxz_batch_dht_t *dht_io, int window_in_lds, hipStream_t stream);
+/* token boundaries inside dynamic blocks (nxz_inflate.hip token_sync_kernel; offsets in bits from src) */
+typedef struct nxz_sync_req {
+	const uint8_t *src;      /* at or in front of the block's header, 4-byte aligned if the stream is */
+	uint32_t srclen;         /* bytes at src */
+	uint32_t header_bit;     /* the block's header */
+	uint32_t guess_bit;      /* where to look: the boundary found lies behind this bit */
+	uint32_t limit_bit;      /* ... and no token looked at reaches this bit (the next block's header) */
+} nxz_sync_req_t;
+typedef struct nxz_sync_res { uint32_t bit; uint32_t lanes; } nxz_sync_res_t;   /* bit 0xffffffff: none found */
+int nxz_launch_token_sync(const nxz_sync_req_t *reqs, uint32_t n, nxz_sync_res_t *res, nxz_batch_dht_t *tables, hipStream_t stream);
 int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, hipStream_t stream);
 int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n, uint32_t final_index,

@@ -456,6 +456,12 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 	b.stage_base = 0xffffffffu; b.stage = sm.stage; b.lane = lane;
 	uint32_t in_subc = (job.resume >> 20) & 7, in_sfbt = (job.resume >> 16) & 15, in_rem = job.resume & 0xffff;
 	if (srclen && in_subc) b.pos = 8 - in_subc;
+	// (pieces of a stream, which carry no checksums: in_adler, when not 0, is the bit of the source where the next
+	// piece begins -- no token that starts there or reaches beyond it is decoded, so a piece that is in step
+	// with the next one suspends exactly there; the number of block headers read comes back in its place)
+	if (W16 && job.in_adler && job.in_adler < b.total_bits) b.total_bits = job.in_adler;
+	uint32_t nheaders = 0;
+	const unsigned long long t_begin = W16 ? wall_clock64() : 0;      // (pieces report how long they took, 10 ns units, where a job reports its CRC)
 
 	uint32_t crc_state = job.in_crc ^ 0xffffffffu;
 	uint32_t ad1 = job.in_adler & 0xffff, ad2 = job.in_adler >> 16;
@@ -544,6 +550,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			uint32_t v = b.peek();
 			bfinal = v & 1; btype = (v >> 1) & 3;
 			b.pos += 3;
+			nheaders++;
 			if (btype == 0) {
 				b.pos = (b.pos + 7) & ~7ull;
 				if (!b.have(32)) { o_sfbt = 0xe | bfinal; o_subc = (uint32_t)(b.total_bits - hdr); break; }
@@ -847,13 +854,146 @@ done:
 		if (cc == 0 && !(final_eob && subc < 8)) cc = NXZ_CC_DATA_LENGTH;
 		r.cc = cc; r.tpbc = (cc == 0 || cc == NXZ_CC_DATA_LENGTH) ? out : 0;
 		r.tebc = o_rem; r.spbc = spbc;
-		r.crc = crc_state ^ 0xffffffffu; r.adler = (ad2 << 16) | ad1;
+		r.crc = W16 ? (uint32_t)(wall_clock64() - t_begin) : crc_state ^ 0xffffffffu; r.adler = W16 ? nheaders : (ad2 << 16) | ad1;
 		r.subc = subc; r.sfbt = o_sfbt | (final_eob ? 0x100u : 0) | (((o_sfbt & 0xe) == 0xc && have_dht) ? (dhtbits << 16) : 0);
 		results[blockIdx.x] = r;
 	}
 }
 
+// ---- token boundaries inside a dynamic block (nxz_inflate_stream, few pieces) ----
+// A block is the unit the pieces of a stream are cut at, and a wavefront takes milliseconds for one: a
+// caller that holds a megabyte of the stream has some forty blocks, and waits for the longest.  Inside
+// a block the stream can be cut at any token boundary -- the decoder needs the block's tables and
+// nothing else -- but where the tokens begin is only known to who has decoded from the block's start.
+// Huffman-coded data synchronises itself, though: decoders that start at neighbouring bits fall in
+// step with each other within a few dozen tokens, because a wrong start soon decodes a token that
+// ends where a right one does.  So: a request names a block header and a bit somewhere in the
+// block; the wavefront reads the header (as the inflate kernel does), then its 64 lanes decode token
+// LENGTHS from the 64 bits that follow the guess -- one of them is a true token start, no token being
+// longer than 48 bits -- each on its own, from a 2 KiB copy of the source in LDS.  Lanes that meet a
+// code that does not exist, or end-of-block, drop out; when all that are left stand on the same bit
+// that bit is a token boundary, if the guess was inside the block at all.  (That it is, and that the
+// boundary is a true one, is not taken on trust: the piece in front must arrive exactly there, in
+// this block -- nxz_pinflate.cpp.)
+constexpr uint32_t SYNC_DW = 512;                 // dwords of the source a request may walk through
+constexpr uint32_t SYNC_RUN = 1024;               // bits every lane decodes before the lanes are compared
+
+__global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__restrict__ reqs, nxz_sync_res_t *__restrict__ res,
+							 nxz_batch_dht_t *__restrict__ tables)
+{
+	__shared__ __attribute__((aligned(16))) SmemT<true> sm;
+	__shared__ uint32_t region[SYNC_DW + 4];
+	const int lane = threadIdx.x;
+	const nxz_sync_req_t rq = reqs[blockIdx.x];
+	nxz_sync_res_t out;
+	out.bit = 0xffffffffu; out.lanes = 0;
+	Bits b;
+	b.src = (const NXZ_GLOBAL_AS uint8_t *)rq.src; b.srclen = rq.srclen; b.total_bits = (uint64_t)rq.srclen * 8; b.pos = rq.header_bit;
+	b.stage_base = 0xffffffffu; b.stage = sm.stage; b.lane = lane;
+	// header_bit 0xffffffff: the block's header is not in the source (the caller holds a part of a stream that begins
+	// inside the block); its table is in the request's slot of `tables`, as a suspended job handed it back
+	const bool given = rq.header_bit == 0xffffffffu;
+	bool ok = given || b.have(17);
+	uint32_t tbits = 0;
+	uint64_t tstart = 0;
+	int hlit = 0, hdist = 0;
+	if (given) {
+		const nxz_batch_dht_t *t = &tables[blockIdx.x];
+		Bits tb;
+		tb.src = (const NXZ_GLOBAL_AS uint8_t *)t->dht; tb.srclen = (t->dhtlen + 7) / 8; tb.total_bits = t->dhtlen; tb.pos = 0;
+		tb.stage_base = 0xffffffffu; tb.stage = sm.stage; tb.lane = lane;
+		ok = read_dht(tb, sm, hlit, hdist, tbits) == 0 && tbits == t->dhtlen;
+		tbits = 0;
+	} else if (ok) {
+		const uint32_t v = b.peek();
+		ok = (v & 7) == 4;                            // BFINAL 0, BTYPE 10
+		b.pos += 3;
+		tstart = b.pos;
+		if (ok) ok = read_dht(b, sm, hlit, hdist, tbits) == 0;
+	}
+	if (ok) {
+		build<LBITS>(sm.hl, sm.lens, hlit, lane);
+		build<DBITS>(sm.hd, sm.lens + hlit, hdist, lane);
+	}
+	if (ok && !given) {
+		// the table's bits, for the piece that will start inside this block (a job that resumes in a dynamic block)
+		nxz_batch_dht_t *t = &tables[blockIdx.x];
+		b.stage_base = 0xffffffffu;
+		b.ensure((uint32_t)(tstart >> 3), 320);
+		for (uint32_t i = lane; i < (tbits + 31) / 32; i += 64) {
+			b.pos = tstart + (uint64_t)i * 32;
+			uint32_t w = b.raw_peek();
+			if ((i + 1) * 32 > tbits && (tbits & 31)) w &= (1u << (tbits & 31)) - 1;
+			((uint32_t *)t->dht)[i] = w;
+		}
+		if (lane == 0) t->dhtlen = tbits;
+	}
+	ok = ok && rq.guess_bit >= tstart + tbits && rq.limit_bit > rq.guess_bit + 64;
+	if (ok) {
+		// the stretch of the source the lanes walk through
+		const uint32_t d0 = rq.guess_bit >> 5;
+		const bool aligned = ((uintptr_t)rq.src & 3) == 0;
+		for (uint32_t i = lane; i < SYNC_DW + 4; i += 64) {
+			const uint64_t byte = (uint64_t)(d0 + i) * 4;
+			uint32_t w = 0;
+			if (byte + 4 <= rq.srclen && aligned) w = ((const NXZ_GLOBAL_AS uint32_t *)b.src)[d0 + i];
+			else for (uint32_t k = 0; k < 4 && byte + k < rq.srclen; k++) w |= (uint32_t)b.src[byte + k] << (8 * k);
+			region[i] = w;
+		}
+		__syncthreads();
+		const uint32_t rbase = d0 * 32;
+		uint32_t rend = rbase + SYNC_DW * 32;                  // a token may be looked at while it starts in front of this bit
+		if (rend > rq.limit_bit) rend = rq.limit_bit;
+		uint32_t pos = rq.guess_bit + (uint32_t)lane;
+		bool alive = true;
+		auto step = [&]() __attribute__((always_inline)) {
+			const uint32_t o = pos - rbase, i = o >> 5, sh = o & 31;
+			const uint32_t a0 = region[i], a1 = region[i + 1], a2 = region[i + 2];
+			const uint32_t w0 = __builtin_amdgcn_alignbit(a1, a0, sh), w1 = __builtin_amdgcn_alignbit(a2, a1, sh);
+			uint32_t nb = 0;
+			const int sym = decode_sym<LBITS>(sm.hl, w0, nb);
+			if (sym < 0 || sym == 256 || sym >= 257 + 29) { alive = false; return; }
+			if (sym < 256) { pos += nb; return; }
+			uint32_t lbase, eb, dbase, ebd, nbd = 0;
+			len_params((uint32_t)sym - 257, lbase, eb);
+			const uint32_t o2 = nb + eb;                                      // <= 15 + 5
+			const int ds = decode_sym<DBITS>(sm.hd, __builtin_amdgcn_alignbit(w1, w0, o2), nbd);
+			if (ds < 0 || ds >= 30) { alive = false; return; }
+			dist_params((uint32_t)ds, dbase, ebd);
+			pos += o2 + nbd + ebd;
+		};
+		// every lane on its own for a good stretch ...
+		const uint32_t target = rq.guess_bit + 64 + SYNC_RUN;
+		while (__ballot(alive && pos < target && pos + 64 <= rend)) {
+			if (alive && pos < target && pos + 64 <= rend) step();
+		}
+		if (pos + 64 > rend && pos < target) alive = false;          // ran out of room
+		// ... then all of them up to the foremost, until they stand on one bit (or none is left)
+		for (int it = 0; it < 64; it++) {
+			uint32_t mx = alive ? pos : 0, mn = alive ? pos : 0xffffffffu;
+			for (int o = 32; o > 0; o >>= 1) {
+				const uint32_t x = (uint32_t)__shfl_xor((int)mx, o, 64), y = (uint32_t)__shfl_xor((int)mn, o, 64);
+				mx = x > mx ? x : mx; mn = y < mn ? y : mn;
+			}
+			if (mn == 0xffffffffu) break;                                     // no lane left
+			if (mn == mx) { out.bit = mx; out.lanes = (uint32_t)__popcll(__ballot(alive)); break; }
+			while (__ballot(alive && pos < mx)) {
+				if (alive && pos < mx) { if (pos + 64 <= rend) step(); else alive = false; }
+			}
+		}
+	}
+	if (lane == 0) res[blockIdx.x] = out;
+}
+
 } // namespace nxzi
+
+// requests for token boundaries inside dynamic blocks (see token_sync_kernel); tables[n]: the blocks' tables
+extern "C" int nxz_launch_token_sync(const nxz_sync_req_t *reqs, uint32_t n, nxz_sync_res_t *res, nxz_batch_dht_t *tables, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL(nxzi::token_sync_kernel, dim3(n), dim3(64), 0, stream, reqs, res, tables);
+	return (int)hipGetLastError();
+}
 
 extern "C" int nxz_inflate_prof_set(unsigned long long *buf)
 {

@@ -164,17 +164,99 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	}
 	if (B.size() < 3) return -ENOTSUP;
 
-	// a piece of the stream: from a block start to the next
+	// ---- a stream (or part of one) of a few hundred blocks at most: more places to cut it at ----
+	// With that few pieces the call takes as long as the longest piece, milliseconds for a block of 100 KiB.
+	// Inside a dynamic block any token boundary will do as a cut (the piece there is a job that resumes
+	// inside a dynamic block, with the block's table); token_sync_kernel finds boundaries near the bits asked for.
+	struct Sub { uint64_t bit; uint32_t tab; };
+	std::vector<Sub> subs;
+	std::vector<nxz_batch_dht_t> tabs;
+	{
+		static const int split_max = getenv("NXZ_PINFLATE_SPLIT") ? atoi(getenv("NXZ_PINFLATE_SPLIT")) : 16;      // pieces per block at most (0, 1: blocks only)
+		const uint64_t all_bits = src_len * 8 - first_bit;
+		const uint64_t sub_bits = std::max<uint64_t>(16384, all_bits / 768);
+		std::vector<nxz_sync_req_t> rq;
+		std::vector<uint64_t> rq_base;
+		// (the first piece begins wherever the caller's part of the stream does: inside a dynamic block that is not
+		// the last -- then the table is the one the last suspension handed back --, or at a header of whatever kind)
+		const bool given0 = st && (st->sfbt & 8) && (st->sfbt & 0xe) != 0xe;
+		size_t ngiven = 0;
+		for (size_t i = 0; i < B.size() && split_max > 1; i++) {
+			const uint64_t end = i + 1 < B.size() ? B[i + 1] : src_len * 8, span = end - B[i];
+			const uint64_t base = (B[i] >> 3) & ~3ull;
+			if (end - base * 8 >= 0xffffffffull) continue;
+			if (i == 0 && given0 && (st->sfbt & 0xf) != 0xc) continue;
+			const uint32_t nsub = (uint32_t)std::min<uint64_t>((uint64_t)split_max, span / sub_bits);
+			for (uint32_t k = 1; k < nsub; k++) {
+				nxz_sync_req_t r;
+				r.src = src + base;
+				r.srclen = (uint32_t)std::min<uint64_t>(src_len - base, 0x7fffffffull);
+				r.header_bit = (uint32_t)(B[i] - base * 8);
+				if (i == 0 && given0) { r.header_bit = 0xffffffffu; ngiven++; }
+				r.guess_bit = (uint32_t)(B[i] + span * k / nsub - base * 8);
+				r.limit_bit = (uint32_t)(end - base * 8);
+				rq.push_back(r); rq_base.push_back(base * 8);
+			}
+		}
+		const size_t nr = rq.size();
+		if (nr) {
+			const size_t o_rq = 0, o_rs = up(nr * sizeof(nxz_sync_req_t), 256), o_tb = o_rs + up(nr * sizeof(nxz_sync_res_t), 256),
+				     tot = o_tb + up(nr * sizeof(nxz_batch_dht_t), 256);
+			if (!ws.need(tot, tot)) return -ENOMEM;
+			uint8_t *Dv = (uint8_t *)ws.dev, *Pn = (uint8_t *)ws.pin;
+			memcpy(Pn + o_rq, rq.data(), nr * sizeof(nxz_sync_req_t));
+			if (hipMemcpyAsync(Dv + o_rq, Pn + o_rq, nr * sizeof(nxz_sync_req_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+			if (ngiven) {
+				nxz_batch_dht_t *tg = (nxz_batch_dht_t *)(Pn + o_tb);
+				for (size_t k = 0; k < ngiven; k++) {                 // (they are the first requests)
+					memset(&tg[k], 0, sizeof(tg[k]));
+					tg[k].dhtlen = st->dhtlen;
+					memcpy(tg[k].dht, st->dht, NXZ_DHT_MAXSZ);
+				}
+				if (hipMemcpyAsync(Dv + o_tb, Pn + o_tb, ngiven * sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+			}
+			if (nxz_launch_token_sync((const nxz_sync_req_t *)(Dv + o_rq), (uint32_t)nr, (nxz_sync_res_t *)(Dv + o_rs), (nxz_batch_dht_t *)(Dv + o_tb), s)) return -EIO;
+			if (hipMemcpyAsync(Pn + o_rs, Dv + o_rs, tot - o_rs, hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+			if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+			const nxz_sync_res_t *rs = (const nxz_sync_res_t *)(Pn + o_rs);
+			const nxz_batch_dht_t *tb = (const nxz_batch_dht_t *)(Pn + o_tb);
+			for (size_t k = 0; k < nr; k++) {
+				if (rs[k].bit == 0xffffffffu) continue;
+				subs.push_back(Sub{ rq_base[k] + rs[k].bit, (uint32_t)tabs.size() });
+				tabs.push_back(tb[k]);
+			}
+			if (trace) fprintf(stderr, "nxz_inflate_stream: %zu blocks, %zu token boundaries asked for, %zu found\n", B.size(), nr, subs.size());
+			lap("token boundaries");
+		}
+	}
+
+	// a piece of the stream: from a block start (or a token boundary inside a dynamic block) to the next
 	struct P {
 		uint64_t bit, cstart, cbytes;           // first bit; first byte and byte count of its part of the stream
+		uint64_t stop;                          // the next piece starts inside a block: its first bit, counted from cstart (else 0)
+		int tab;                                // starts inside a dynamic block: which table (else -1)
+		uint32_t hdr0;                          // block headers it has read while it is still in the block it began in
 		size_t stage_off, out_off;              // its 16-byte aligned copy of those bytes / its 16-bit output, in the bump area
 		uint64_t cap;                           // output elements it may produce
 		uint32_t capmul;
 		nxz_batch_result_t res;
 		bool done;
 	};
-	std::vector<P> pc(B.size());
-	for (size_t i = 0; i < B.size(); i++) { pc[i] = P(); pc[i].bit = B[i]; pc[i].capmul = 100; }   // buffer: 100 x the compressed size, 2 Mi elements at least
+	std::vector<P> pc;
+	pc.reserve(B.size() + subs.size());
+	for (size_t i = 0, k = 0; i < B.size(); i++) {
+		P p = P();
+		p.bit = B[i]; p.capmul = 100; p.tab = -1;                      // buffer: 100 x the compressed size, 2 Mi elements at least
+		p.hdr0 = i == 0 && st && (st->sfbt & 8) && (st->sfbt & 0xe) != 0xe ? 0 : 1;
+		pc.push_back(p);
+		p.hdr0 = 0;
+		const uint64_t end = i + 1 < B.size() ? B[i + 1] : src_len * 8;
+		for (; k < subs.size() && subs[k].bit < end; k++) {
+			if (subs[k].bit < pc.back().bit + 2048 || subs[k].bit + 2048 > end) continue;     // (too close to its neighbours to be worth a piece)
+			p.bit = subs[k].bit; p.tab = (int)subs[k].tab;
+			pc.push_back(p);
+		}
+	}
 	const size_t n0 = pc.size(), ng0 = n0 / nxz_window_chain_group() + 1;
 	// control arrays (sized for the first, longest list of pieces), then a bump area for copies and outputs
 	const size_t o_jobs = 0, o_res = o_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), o_items = o_res + up(n0 * sizeof(nxz_batch_result_t), 256),
@@ -184,14 +266,17 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		     o_bump = o_dht + up(n0 * sizeof(nxz_batch_dht_t), 256);
 	const size_t pin_jobs = 0, pin_res = pin_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), pin_items = pin_res + up(n0 * sizeof(nxz_batch_result_t), 256),
 		     pin_pieces = pin_items + up((n0 + 4) * sizeof(CopyItem), 256), pin_dht = pin_pieces + up(n0 * sizeof(Piece), 256),
-		     pin_total = pin_dht + up(2 * sizeof(nxz_batch_dht_t), 256);          // (first piece's table in, last piece's out)
+		     pin_total = pin_dht + up((n0 + 1) * sizeof(nxz_batch_dht_t), 256);   // (the tables the jobs start with; the last piece's, out)
 	size_t bump = 0, reserved = 0;
-	auto size_piece = [&](P &p, uint64_t next_bit) -> bool {
+	auto size_piece = [&](P &p, const P *next) -> bool {
+		const uint64_t next_bit = next ? next->bit : 0;
 		p.cstart = p.bit >> 3;
 		const uint64_t cend = next_bit ? (next_bit + 7) >> 3 : src_len;
 		p.cbytes = cend - p.cstart;
 		if (p.cbytes > 0xfffffff0ull - 64) return false;
-		const uint64_t cp = std::max<uint64_t>(p.cbytes * p.capmul, 2u << 20);
+		p.stop = next && next->tab >= 0 ? next_bit - p.cstart * 8 : 0;
+		if (p.stop > 0xffffffffull) return false;
+		const uint64_t cp = std::max<uint64_t>(p.cbytes * p.capmul, p.tab >= 0 ? 256u << 10 : 2u << 20);
 		if (cp > 0xfff00000ull) return false;
 		p.cap = up(cp, 256);
 		p.stage_off = bump; bump += up(p.cbytes + 64, 256);
@@ -200,7 +285,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		return true;
 	};
 	for (size_t i = 0; i < pc.size(); i++)
-		if (!size_piece(pc[i], i + 1 < pc.size() ? pc[i + 1].bit : 0)) return -ENOTSUP;
+		if (!size_piece(pc[i], i + 1 < pc.size() ? &pc[i + 1] : nullptr)) return -ENOTSUP;
 	uint8_t *D = nullptr, *PN = nullptr;
 	bool win0_made = false;
 	nxz_batch_dht_t last_dht;                       // the table in force where the last piece stopped
@@ -211,7 +296,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			if (attempt) {
 				bump = 0;
 				for (size_t i = 0; i < pc.size(); i++)
-					if (!size_piece(pc[i], i + 1 < pc.size() ? pc[i + 1].bit : 0)) return -ENOTSUP;
+					if (!size_piece(pc[i], i + 1 < pc.size() ? &pc[i + 1] : nullptr)) return -ENOTSUP;
 			}
 			reserved = bump + std::max<size_t>(bump / 4, (size_t)256 << 20);
 			if (o_bump + reserved > (200ull << 30)) return -ENOTSUP;
@@ -236,6 +321,8 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			const uint32_t sub = (uint32_t)(p.bit & 7);
 			j.resume = (0xeu << 16) | ((sub ? 8 - sub : 0) << 20);
 			if (i == 0 && st && (st->sfbt & 8)) j.resume = (st->rem & 0xffff) | ((st->sfbt & 0xf) << 16) | ((sub ? 8 - sub : 0) << 20);
+			if (p.tab >= 0) j.resume = (0xcu << 16) | ((sub ? 8 - sub : 0) << 20);      // inside a dynamic block that is not the last
+			j.in_adler = (uint32_t)p.stop;
 			who.push_back(i);
 		}
 		if (!win0_made) {
@@ -247,12 +334,21 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		if (hipMemcpyAsync(d_items, h_items, ni * sizeof(CopyItem), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 		if (hipMemcpyAsync(d_jobs, h_jobs, nj * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 		// tables: in for a first piece that resumes inside a dynamic block, out for a last piece that stops inside one
-		nxz_batch_dht_t *d_dht = st ? (nxz_batch_dht_t *)(D + o_dht) : nullptr, *h_dht = (nxz_batch_dht_t *)(PN + pin_dht);
-		if (st && nj && who[0] == 0 && (st->sfbt & 0xe) == 0xc) {
-			memset(&h_dht[0], 0, sizeof(h_dht[0]));
-			h_dht[0].dhtlen = st->dhtlen;
-			memcpy(h_dht[0].dht, st->dht, NXZ_DHT_MAXSZ);
-			if (hipMemcpyAsync(d_dht, &h_dht[0], sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+		const bool use_dht = st || !tabs.empty();
+		nxz_batch_dht_t *d_dht = use_dht ? (nxz_batch_dht_t *)(D + o_dht) : nullptr, *h_dht = (nxz_batch_dht_t *)(PN + pin_dht);
+		if (use_dht && nj) {
+			bool any = false;
+			for (size_t k = 0; k < nj; k++) {
+				const P &p = pc[who[k]];
+				if (p.tab >= 0) { h_dht[k] = tabs[(size_t)p.tab]; any = true; }
+				else if (who[k] == 0 && st && (st->sfbt & 0xe) == 0xc) {
+					memset(&h_dht[k], 0, sizeof(h_dht[k]));
+					h_dht[k].dhtlen = st->dhtlen;
+					memcpy(h_dht[k].dht, st->dht, NXZ_DHT_MAXSZ);
+					any = true;
+				}
+			}
+			if (any && hipMemcpyAsync(d_dht, h_dht, nj * sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 		}
 		if (nxz_launch_copy_items(d_items, (uint32_t)ni, s)) return -EIO;
 		lap("staging");
@@ -260,15 +356,15 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		lap("decode");
 		if (hipMemcpyAsync(h_res, d_res, nj * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 		const bool last_ran = st && nj && who[nj - 1] == pc.size() - 1;
-		if (last_ran && hipMemcpyAsync(&h_dht[1], d_dht + (nj - 1), sizeof(nxz_batch_dht_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+		if (last_ran && hipMemcpyAsync(&h_dht[n0], d_dht + (nj - 1), sizeof(nxz_batch_dht_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 		if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
-		if (last_ran) last_dht = h_dht[1];
+		if (last_ran) last_dht = h_dht[n0];
 		for (size_t k = 0; k < nj; k++) { pc[who[k]].res = h_res[k]; pc[who[k]].done = true; }
 		// every piece but the last must stop at the header of the next one; the last at the final block's end
 		bool again = false;
 		std::vector<P> nx;
 		nx.reserve(pc.size());
-		bool swallow = false;
+		bool swallow = false, swallow_cuts = false;
 		uint64_t swallow_until = 0;
 		// `confirmed`: the start of the piece under inspection is known to be a block start -- it is the
 		// first piece, or the piece in front is final and ends exactly there.  Only such a piece can say
@@ -278,7 +374,9 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		for (size_t i = 0; i < pc.size(); i++) {
 			// this piece's start was refuted: it goes into the piece in front (sized below); so do all starts
 			// inside a stored block that the piece in front was in the middle of
-			if (swallow || pc[i].bit < swallow_until) { swallow = false; continue; }
+			// (a piece that did not arrive at a cut inside its block: the block's other cuts go as well)
+			if (swallow || (swallow_cuts && pc[i].tab >= 0) || pc[i].bit < swallow_until) { swallow = false; continue; }
+			swallow_cuts = false;
 			P p = pc[i];
 			const nxz_batch_result_t &r = p.res;
 			const bool conf = confirmed;
@@ -295,9 +393,12 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			const bool fin = !err && (r.sfbt & 0x100);
 			bool ends_well = !err;
 			if (!fin && i + 1 < pc.size()) {
-				const uint64_t used = p.cbytes * 8 - r.subc, want = pc[i + 1].bit - p.cstart * 8;
+				const uint64_t used = (p.stop ? p.stop : p.cbytes * 8) - r.subc, want = pc[i + 1].bit - p.cstart * 8;
 				const uint32_t kind = r.sfbt & 0xe;
 				ends_well = r.cc == NXZ_CC_DATA_LENGTH && ((kind == 0xe && used == want) || (kind == 0xa && used == want + 3));
+				// a cut inside a dynamic block: this piece must stand exactly there, still in the block it began in (it has
+				// read that block's header and no other, or none if it began at a cut itself)
+				if (pc[i + 1].tab >= 0) ends_well = r.cc == NXZ_CC_DATA_LENGTH && kind == 0xc && !(r.sfbt & 1) && used == want && r.adler == p.hdr0;
 				if (!ends_well && trace)
 					fprintf(stderr, "nxz_inflate_stream: piece %zu (bit %llu, %llu bytes in, %u out, start %s) cc %u sfbt %#x subc %u: used %llu bits, next header thought at %llu\n",
 						i, (unsigned long long)p.bit, (unsigned long long)p.cbytes, r.tpbc, conf ? "confirmed" : "open", r.cc, r.sfbt, r.subc, (unsigned long long)used, (unsigned long long)want);
@@ -312,6 +413,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			if (!ends_well) {
 				// the piece did not end where the next was thought to start: that start is wrong
 				p.done = false; swallow = true;
+				if (pc[i + 1].tab >= 0) swallow_cuts = true;
 				if ((r.sfbt & 0xe) == 0x8) swallow_until = (p.cstart + p.cbytes) * 8 + (uint64_t)r.tebc * 8;
 				again = true;
 			}
@@ -323,7 +425,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		if (!again) break;
 		if (attempt >= 23 || pc.size() < 2) return -ENOTSUP;
 		for (size_t i = 0; i < pc.size(); i++)
-			if (!pc[i].done && !size_piece(pc[i], i + 1 < pc.size() ? pc[i + 1].bit : 0)) return -ENOTSUP;
+			if (!pc[i].done && !size_piece(pc[i], i + 1 < pc.size() ? &pc[i + 1] : nullptr)) return -ENOTSUP;
 	}
 	size_t n = pc.size();
 	if (!n) return -ENOTSUP;
@@ -334,6 +436,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		uint64_t sum = 0;
 		size_t m = 0;
 		while (m < n && sum + pc[m].res.tpbc <= dst_cap) sum += pc[m++].res.tpbc;
+		while (m > 0 && m < n && pc[m].tab >= 0) m--;          // (what is left for the next call starts at a block header)
 		if (m < n && (!st || m == 0)) {
 			for (sum = 0, m = 0; m < n; m++) sum += pc[m].res.tpbc;
 			*out_len = sum;
@@ -405,6 +508,14 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		uint64_t mx = 0;
 		for (size_t i = 0; i < n; i++) mx = std::max<uint64_t>(mx, pc[i].res.tpbc);
 		fprintf(stderr, "nxz_inflate_stream: %zu pieces, largest %llu bytes out, mean %llu\n", n, (unsigned long long)mx, (unsigned long long)(total / n));
+		// the pieces that took longest (the kernel reports 10 ns ticks in the CRC's place)
+		std::vector<size_t> ord(n);
+		for (size_t i = 0; i < n; i++) ord[i] = i;
+		std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return pc[a].res.crc > pc[b].res.crc; });
+		for (size_t k = 0; k < std::min<size_t>(n, 6); k++) {
+			const P &q = pc[ord[k]];
+			fprintf(stderr, "nxz_inflate_stream:   piece %zu (%s): %llu bytes in, %u out, %.1f us\n", ord[k], q.tab >= 0 ? "cut" : "block", (unsigned long long)q.cbytes, q.res.tpbc, q.res.crc * 0.01);
+		}
 	}
 	const uint32_t nround = 1;
 	uint32_t cr = 0, ad = 1;
