@@ -1,3 +1,4 @@
+"""<MiB> <out.gz>: a zlib -6 .gz of the first MiB of the test corpus (repeated as needed), for tools/inflate_steps.c"""
 import sys, zlib
 sys.path.insert(0, "tests")
 import corpus
