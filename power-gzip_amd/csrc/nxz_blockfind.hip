@@ -39,7 +39,11 @@ __device__ __forceinline__ uint32_t peek(const uint8_t *s, uint32_t bit, uint32_
 	return (w >> (bit & 7)) & ((1u << n) - 1);
 }
 
-// the full check of a candidate (one lane); `limit` = first bit that is not part of the stream
+// the full check of a candidate (one lane); `limit` = first bit that is not part of the stream.
+// Everything the lane keeps per candidate is packed into registers (the code-length code's lengths, the
+// counts per length, the symbols in canonical order: 3, 5 and 5 bits an entry) -- arrays indexed at run
+// time would live in scratch memory, a trip to the caches per symbol -- and a code-length symbol costs
+// one look at the source (14 bits: the longest code and the longest repeat count).
 __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
 {
 	if (bit + 17 > limit) return false;
@@ -47,24 +51,37 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
 	const uint32_t hlit = ((v >> 3) & 31) + 257, hdist = ((v >> 8) & 31) + 1, hclen = ((v >> 13) & 15) + 4;
 	uint32_t pos = bit + 17;
 	if (pos + 3 * hclen > limit) return false;
-	const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
-	// code-length code: lengths packed 3 bits per symbol, counts per length
+	// code-length code: lengths packed 3 bits per symbol, counts per length 5 bits per length
 	uint64_t cll = 0;
-	uint32_t cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	for (uint32_t i = 0; i < hclen; i++) {
-		const uint32_t l = peek(s, pos, 3);
-		pos += 3;
-		cll |= (uint64_t)l << (3 * order[i]);
-		cnt[l]++;
-	}
-	// canonical decode by counts (first code / first symbol index per length), symbols in order
-	uint8_t symtab[19];
+	uint64_t cnt = 0;
+	uint32_t lastl = 0;
 	{
-		uint32_t offs[8], o = 0;
-		for (int l = 1; l < 8; l++) { offs[l] = o; o += cnt[l]; }
+		const uint64_t raw = (uint64_t)peek(s, pos, 24) | ((uint64_t)peek(s, pos + 24, 24) << 24) | ((uint64_t)peek(s, pos + 48, 9) << 48);   // 19 x 3 bits
+		constexpr uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+#pragma unroll
+		for (uint32_t i = 0; i < 19; i++) {
+			const uint32_t l = i < hclen ? (uint32_t)(raw >> (3 * i)) & 7 : 0;
+			cll |= (uint64_t)l << (3 * order[i]);
+			cnt += 1ull << (5 * l);
+			if (i + 1 == hclen) lastl = l;
+		}
+		pos += 3 * hclen;
+	}
+	// canonical order: the symbols of length 1 in ascending order, then those of length 2, ... (5 bits each, 19 at most)
+	uint64_t st_lo = 0, st_hi = 0;                                 // entries 0..11, 12..18
+	{
+		uint64_t offs = 0;                                     // first entry of each length, 5 bits per length
+		uint32_t o = 0;
+#pragma unroll
+		for (uint32_t l = 1; l < 8; l++) { offs |= (uint64_t)o << (5 * l); o += (uint32_t)(cnt >> (5 * l)) & 31; }
+#pragma unroll
 		for (uint32_t sy = 0; sy < 19; sy++) {
 			const uint32_t l = (uint32_t)(cll >> (3 * sy)) & 7;
-			if (l) symtab[offs[l]++] = (uint8_t)sy;
+			if (l) {
+				const uint32_t at = (uint32_t)(offs >> (5 * l)) & 31;
+				if (at < 12) st_lo |= (uint64_t)sy << (5 * at); else st_hi |= (uint64_t)sy << (5 * (at - 12));
+				offs += 1ull << (5 * l);
+			}
 		}
 	}
 	// every encoder trims the three counts to the last length that is not zero (zlib: build_bl_tree /
@@ -72,40 +89,54 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
 	// code-length-code length, last literal/length length or last distance length is zero although
 	// the count could have been smaller is taken for chance.  (A stream of an encoder that does not
 	// trim offers fewer starts here and is decoded in longer pieces, or job after job.)
-	if (hclen > 4 && ((cll >> (3 * order[hclen - 1])) & 7) == 0) return false;
+	if (hclen > 4 && lastl == 0) return false;
 	uint32_t n = 0, prev = 0, kraft_ll = 0, kraft_d = 0, nd = 0, maxd = 0, eob = 0, last_ll = 0, last_d = 0;
 	const uint32_t total = hlit + hdist;
 	while (n < total) {
-		// one code-length symbol, bit by bit
-		uint32_t code = 0, first = 0, index = 0, sym = 0xff;
+		// one code-length symbol: its code (7 bits at most) and what follows it (7 at most)
+		if (pos >= limit) return false;
+		const uint32_t w = peek(s, pos, 14);
+		uint32_t code = 0, first = 0, index = 0, sym = 0xff, len = 0;
+#pragma unroll
 		for (uint32_t l = 1; l <= 7; l++) {
-			if (pos >= limit) return false;
-			code |= (s[pos >> 3] >> (pos & 7)) & 1u;
-			pos++;
-			const uint32_t c = cnt[l];
-			if (code < first + c) { sym = symtab[index + (code - first)]; break; }
-			index += c; first = (first + c) << 1; code <<= 1;
+			if (sym == 0xff) {
+				code |= (w >> (l - 1)) & 1u;
+				const uint32_t c = (uint32_t)(cnt >> (5 * l)) & 31;
+				if (code < first + c) {
+					const uint32_t at = index + (code - first);
+					sym = (uint32_t)(at < 12 ? st_lo >> (5 * at) : st_hi >> (5 * (at - 12))) & 31;
+					len = l;
+				}
+				index += c; first = (first + c) << 1; code <<= 1;
+			}
 		}
-		if (sym == 0xff) return false;
+		if (sym == 0xff || pos + len > limit) return false;
+		pos += len;
+		const uint32_t x = w >> len;
 		uint32_t rep = 1, val = sym;
 		if (sym == 16) {
 			if (n == 0 || pos + 2 > limit) return false;
-			rep = 3 + peek(s, pos, 2); pos += 2; val = prev;
+			rep = 3 + (x & 3); pos += 2; val = prev;
 		} else if (sym == 17) {
 			if (pos + 3 > limit) return false;
-			rep = 3 + peek(s, pos, 3); pos += 3; val = 0;
+			rep = 3 + (x & 7); pos += 3; val = 0;
 		} else if (sym == 18) {
 			if (pos + 7 > limit) return false;
-			rep = 11 + peek(s, pos, 7); pos += 7; val = 0;
+			rep = 11 + (x & 127); pos += 7; val = 0;
 		}
 		if (n + rep > total) return false;
 		if (sym < 16) prev = sym; else if (sym != 16) prev = 0;
 		if (val) {
-			for (uint32_t k = 0; k < rep; k++) {
-				const uint32_t i = n + k;
-				if (i < hlit) { kraft_ll += 1u << (15 - val); if (i == 256) eob = 1; if (i == hlit - 1) last_ll = 1; }
-				else { kraft_d += 1u << (15 - val); nd++; if (val > maxd) maxd = val; if (i == total - 1) last_d = 1; }
-			}
+			// (a run of one length: what of it is literal/length codes, what distance codes)
+			const uint32_t e = n + rep;
+			const uint32_t nl = n < hlit ? (e < hlit ? e : hlit) - n : 0, ndist = rep - nl;
+			kraft_ll += nl << (15 - val);
+			kraft_d += ndist << (15 - val);
+			nd += ndist;
+			if (ndist && val > maxd) maxd = val;
+			if (n <= 256 && e > 256) eob = 1;
+			if (nl && n + nl == hlit) last_ll = 1;
+			if (ndist && e == total) last_d = 1;
 		}
 		n += rep;
 		// (lengths read off chance bits oversubscribe a code within a few dozen symbols: no need to go on)
@@ -119,8 +150,10 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
 
 // first[seg] = bit position (in the whole stream) of the first plausible dynamic block header that
 // starts inside segment seg, or 0xffffffffffffffff
+// (seg: bytes of the stream per workgroup, <= SEG -- a short stream is cut finer, so that the search takes less
+// long and blocks of a KiB or two are not hidden behind the first of their segment)
 __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restrict__ src, uint64_t srclen, uint64_t first_bit,
-							   uint64_t *__restrict__ first, uint32_t nseg)
+							   uint64_t *__restrict__ first, uint32_t nseg, uint32_t seg_bytes)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s[SEG + LOOK + 16];
 	__shared__ uint32_t cand[MAXCAND];
@@ -129,13 +162,13 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 	const int t = threadIdx.x;
 	const uint32_t seg = blockIdx.x;
 	if (seg >= nseg) return;
-	const uint64_t base = (uint64_t)seg * SEG;
-	const uint32_t have = (uint32_t)(srclen - base < SEG + LOOK ? srclen - base : SEG + LOOK);
-	for (uint32_t i = t; i < SEG + LOOK + 16; i += NT) s[i] = i < have ? src[base + i] : 0;
+	const uint64_t base = (uint64_t)seg * seg_bytes;
+	const uint32_t have = (uint32_t)(srclen - base < seg_bytes + LOOK ? srclen - base : seg_bytes + LOOK);
+	for (uint32_t i = t; i < seg_bytes + LOOK + 16; i += NT) s[i] = i < have ? src[base + i] : 0;
 	if (t == 0) { ncand = 0; best = 0xffffffffu; }
 	__syncthreads();
 	const uint32_t limit = have * 8;
-	const uint32_t nbits = (have < SEG ? have : SEG) * 8;
+	const uint32_t nbits = (have < seg_bytes ? have : seg_bytes) * 8;
 	// phase 1: the cheap part of the test at every bit position of the segment, in two steps per chunk
 	// of 8192 positions so that the lanes stay busy: (a) every lane looks at the 13 bits that decide for
 	// three positions in four (BFINAL 0, BTYPE 10, HLIT <= 29, HDIST <= 29) and the survivors -- 22 % --
@@ -198,6 +231,41 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 	}
 	__syncthreads();
 	if (t == 0) first[seg] = best == 0xffffffffu ? ~0ull : base * 8 + best;
+}
+
+// A run of stored blocks is followed header by header (a thread per request; LEN tells where the next header
+// is): from a byte position inside a stored block with `rem` bytes of it to come, to the header of the
+// first block that is not a stored one -- or that is not whole inside the source, or whose LEN / NLEN do
+// not match, or to the end of a final stored block (flag 1).  Stored data may look like anything, block
+// headers included: a piece that stopped inside a stored block is continued behind the run in one go.
+__global__ __launch_bounds__(64) void stored_walk_kernel(const nxz_walk_req_t *__restrict__ reqs, uint32_t n, nxz_walk_res_t *__restrict__ res)
+{
+	const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= n) return;
+	const nxz_walk_req_t rq = reqs[i];
+	const uint8_t *s = rq.src;
+	const uint64_t total = rq.src_len * 8;
+	uint64_t pos = rq.bit + (uint64_t)rq.rem * 8;
+	uint32_t fin = rq.bfinal, flags = 0;
+	for (uint32_t k = 0; k < (1u << 20); k++) {
+		if (fin) { flags = 1; break; }
+		if (pos + 3 > total) break;
+		const uint32_t by = (uint32_t)(pos & 7);
+		uint32_t h = s[pos >> 3] >> by;
+		if (by > 5) h |= (uint32_t)s[(pos >> 3) + 1] << (8 - by);
+		if (((h >> 1) & 3) != 0) break;                                  // not a stored block
+		const uint64_t p2 = (pos + 3 + 7) & ~7ull;
+		if (p2 + 32 > total) break;
+		const uint8_t *q = s + (p2 >> 3);
+		const uint32_t len = q[0] | (uint32_t)q[1] << 8, nlen = q[2] | (uint32_t)q[3] << 8;
+		if ((len ^ nlen) != 0xffff) break;
+		if (p2 + 32 + (uint64_t)len * 8 > total) break;                  // (the block reaches beyond the source: the piece suspends in it)
+		fin = h & 1;
+		pos = p2 + 32 + (uint64_t)len * 8;
+	}
+	nxz_walk_res_t out;
+	out.bit = pos; out.flags = flags; out.reserved = 0;
+	res[i] = out;
 }
 
 // items[i] = { src, dst, bytes }: dst <- src (any alignment; a workgroup per item)
@@ -398,12 +466,19 @@ __global__ __launch_bounds__(256) void resolve_kernel(const Piece *__restrict__ 
 
 } // namespace nxzb
 
-extern "C" uint32_t nxz_blockfind_segment(void) { return nxzb::SEG; }
+extern "C" uint32_t nxz_blockfind_segment(uint64_t srclen) { return srclen <= (4u << 20) ? 1024 : srclen <= (32u << 20) ? 2048 : nxzb::SEG; }
 
 extern "C" int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, hipStream_t stream)
 {
 	if (!nseg) return 0;
-	hipLaunchKernelGGL(nxzb::find_blocks_kernel, dim3(nseg), dim3(nxzb::NT), 0, stream, src, srclen, first_bit, first, nseg);
+	hipLaunchKernelGGL(nxzb::find_blocks_kernel, dim3(nseg), dim3(nxzb::NT), 0, stream, src, srclen, first_bit, first, nseg, nxz_blockfind_segment(srclen));
+	return (int)hipGetLastError();
+}
+
+extern "C" int nxz_launch_stored_walk(const nxz_walk_req_t *reqs, uint32_t n, nxz_walk_res_t *res, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL(nxzb::stored_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, reqs, n, res);
 	return (int)hipGetLastError();
 }
 

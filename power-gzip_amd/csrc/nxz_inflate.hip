@@ -601,6 +601,21 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 				n = cap - out; full_stop = true;                   // what fits, then suspend inside the stored block
 			}
 			uint32_t sp = (uint32_t)(b.pos >> 3);
+			if (GW) {
+				// the target is the window: four bytes per lane and trip (device memory takes them at any alignment)
+				typedef uint32_t u32_any __attribute__((aligned(1)));
+				typedef uint32_t v2u_any __attribute__((ext_vector_type(2), aligned(1)));
+				const uint32_t quads = n >> 2;
+				for (uint32_t i = lane; i < quads; i += 64) {
+					const uint32_t w = *(const NXZ_GLOBAL_AS u32_any *)(src + sp + 4 * i);
+					if (W16) *(NXZ_GLOBAL_AS v2u_any *)(dst16 + out + 4 * i) = (v2u_any){ (w & 0xff) | ((w & 0xff00) << 8), ((w >> 16) & 0xff) | ((w >> 24) << 16) };
+					else *(NXZ_GLOBAL_AS u32_any *)(dst + out + 4 * i) = w;
+				}
+				for (uint32_t i = quads * 4 + lane; i < n; i += 64) wr(out + i, src[sp + i]);
+				out += n; sp += n; rem -= n; n = 0;
+				flushed = out;
+				__syncthreads();
+			}
 			while (n) {
 				uint32_t room = FLUSH - (out - flushed);
 				uint32_t k = n < room ? n : room;
@@ -611,7 +626,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			}
 			b.pos = (uint64_t)sp * 8;
 			if (full_stop) { o_sfbt = 0x8 | bfinal; o_subc = 0; o_rem = rem; stop_bits = b.pos; break; }
-			if (rem) { o_sfbt = 0x8 | bfinal; o_subc = 0; o_rem = rem; break; }
+			if (rem) { o_sfbt = 0x8 | bfinal; o_subc = (uint32_t)(b.total_bits - b.pos);       // (0, unless a piece was cut at a bit inside a byte)
+				 o_rem = rem; break; }
 			if (bfinal) { final_eob = true; break; }
 			state = 0;
 		} else {
@@ -1014,13 +1030,14 @@ extern "C" int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_bat
 }
 
 // nxz_inflate_stream's pieces: 16-bit elements, references into the unknown 32 KiB in front as 0x8000 | index
-extern "C" int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, hipStream_t stream)
+extern "C" int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, int few_and_even, hipStream_t stream)
 {
 	if (!n) return 0;
-	// a few pieces (all of them resident at two per CU): the window in LDS, where a match costs one wavefront
-	// a fraction of the trip to device memory
+	// a few pieces of about one size (all of them resident at two per CU): the window in LDS, where a match costs one
+	// wavefront a fraction of the trip to device memory.  (Not for the odd pieces that are decoded again: long
+	// stored stretches are among them, which the other form copies four bytes per lane.)
 	static const unsigned lds_max = getenv("NXZ_INFLATE_W16_LDS_MAX") ? (unsigned)atoi(getenv("NXZ_INFLATE_W16_LDS_MAX")) : 512;
-	if (n <= lds_max) hipLaunchKernelGGL((nxzi::inflate_kernel<false, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
+	if (few_and_even && n <= lds_max) hipLaunchKernelGGL((nxzi::inflate_kernel<false, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
 	else hipLaunchKernelGGL((nxzi::inflate_kernel<true, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
 	return (int)hipGetLastError();
 }

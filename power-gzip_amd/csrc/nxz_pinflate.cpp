@@ -32,7 +32,7 @@
 #include "nxz_device.h"
 
 extern "C" {
-uint32_t nxz_blockfind_segment(void);
+uint32_t nxz_blockfind_segment(uint64_t srclen);
 int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, hipStream_t stream);
 int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);
 int nxz_ctx_device(nxz_ctx_t *c);
@@ -48,7 +48,6 @@ struct CopyItem { const uint8_t *src; uint8_t *dst; uint64_t bytes; };      // s
 struct Piece { const uint16_t *o; uint64_t len, place; };
 
 constexpr uint32_t WINDOW = 32768;
-constexpr uint64_t SLICE = 256 << 10;            // checksum slices
 
 // GF(2) helpers for crc32_combine: multiply modulo the reflected CRC-32 polynomial
 uint32_t gf_mul(uint32_t a, uint32_t b)
@@ -67,7 +66,6 @@ uint32_t gf_xpow8(uint64_t n)            // x^(8n)
 	for (; n; n >>= 1) { if (n & 1) r = gf_mul(r, sq); sq = gf_mul(sq, sq); }
 	return r;
 }
-uint32_t crc_combine(uint32_t c1, uint32_t c2, uint64_t len2) { return gf_mul(c1, gf_xpow8(len2)) ^ c2; }
 uint32_t adler_combine(uint32_t a1, uint32_t a2, uint64_t len2)
 {
 	const uint32_t BASE = 65521;
@@ -148,7 +146,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		fprintf(stderr, "nxz_inflate_stream: %-28s %8.3f ms\n", what, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6);
 		ts0 = t1;
 	};
-	const uint32_t SEG = nxz_blockfind_segment();
+	const uint32_t SEG = nxz_blockfind_segment(src_len);
 	const uint32_t nseg = (uint32_t)((src_len + SEG - 1) / SEG);
 	// ---- block starts ----
 	if (!ws.need(nseg * sizeof(uint64_t), nseg * sizeof(uint64_t))) return -ENOMEM;
@@ -174,7 +172,9 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	{
 		static const int split_max = getenv("NXZ_PINFLATE_SPLIT") ? atoi(getenv("NXZ_PINFLATE_SPLIT")) : 16;      // pieces per block at most (0, 1: blocks only)
 		const uint64_t all_bits = src_len * 8 - first_bit;
-		const uint64_t sub_bits = std::max<uint64_t>(16384, all_bits / 768);
+		// (as many pieces as the device holds wavefronts of the decode kernel, a few times over: 768 for a part of a
+		// megabyte or two, 8192 for a long stream)
+		const uint64_t sub_bits = std::max<uint64_t>(16384, all_bits <= (64u << 20) ? all_bits / 768 : all_bits / 8192);
 		std::vector<nxz_sync_req_t> rq;
 		std::vector<uint64_t> rq_base;
 		// (the first piece begins wherever the caller's part of the stream does: inside a dynamic block that is not
@@ -236,6 +236,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		uint64_t stop;                          // the next piece starts inside a block: its first bit, counted from cstart (else 0)
 		int tab;                                // starts inside a dynamic block: which table (else -1)
 		uint32_t hdr0;                          // block headers it has read while it is still in the block it began in
+		uint32_t srem, sfin;                    // starts inside a stored block: bytes of it still to come (else 0), its BFINAL
 		size_t stage_off, out_off;              // its 16-byte aligned copy of those bytes / its 16-bit output, in the bump area
 		uint64_t cap;                           // output elements it may produce
 		uint32_t capmul;
@@ -263,10 +264,12 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		     o_pieces = o_items + up((n0 + 4) * sizeof(CopyItem), 256), o_win0 = o_pieces + up(n0 * sizeof(Piece), 256),
 		     o_windows = o_win0 + WINDOW, o_maps = o_windows + n0 * (size_t)WINDOW, o_gmaps = o_maps + n0 * (size_t)WINDOW * 2,
 		     o_gwin = o_gmaps + ng0 * (size_t)WINDOW * 2, o_dht = o_gwin + ng0 * (size_t)WINDOW,
-		     o_bump = o_dht + up(n0 * sizeof(nxz_batch_dht_t), 256);
+		     o_walk = o_dht + up(n0 * sizeof(nxz_batch_dht_t), 256),
+		     o_bump = o_walk + up(n0 * (sizeof(nxz_walk_req_t) + sizeof(nxz_walk_res_t)), 256);
 	const size_t pin_jobs = 0, pin_res = pin_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), pin_items = pin_res + up(n0 * sizeof(nxz_batch_result_t), 256),
 		     pin_pieces = pin_items + up((n0 + 4) * sizeof(CopyItem), 256), pin_dht = pin_pieces + up(n0 * sizeof(Piece), 256),
-		     pin_total = pin_dht + up((n0 + 1) * sizeof(nxz_batch_dht_t), 256);   // (the tables the jobs start with; the last piece's, out)
+		     pin_walk = pin_dht + up((n0 + 1) * sizeof(nxz_batch_dht_t), 256),    // (the tables the jobs start with; the last piece's, out)
+		     pin_total = pin_walk + up(n0 * (sizeof(nxz_walk_req_t) + sizeof(nxz_walk_res_t)), 256);
 	size_t bump = 0, reserved = 0;
 	auto size_piece = [&](P &p, const P *next) -> bool {
 		const uint64_t next_bit = next ? next->bit : 0;
@@ -322,6 +325,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			j.resume = (0xeu << 16) | ((sub ? 8 - sub : 0) << 20);
 			if (i == 0 && st && (st->sfbt & 8)) j.resume = (st->rem & 0xffff) | ((st->sfbt & 0xf) << 16) | ((sub ? 8 - sub : 0) << 20);
 			if (p.tab >= 0) j.resume = (0xcu << 16) | ((sub ? 8 - sub : 0) << 20);      // inside a dynamic block that is not the last
+			if (p.srem) j.resume = p.srem | ((0x8u | p.sfin) << 16);                     // inside a stored block (on a byte boundary)
 			j.in_adler = (uint32_t)p.stop;
 			who.push_back(i);
 		}
@@ -352,7 +356,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		}
 		if (nxz_launch_copy_items(d_items, (uint32_t)ni, s)) return -EIO;
 		lap("staging");
-		if (nxz_launch_inflate_w16(d_jobs, nj, d_res, d_dht, s)) return -EIO;
+		if (nxz_launch_inflate_w16(d_jobs, nj, d_res, d_dht, attempt == 0, s)) return -EIO;
 		lap("decode");
 		if (hipMemcpyAsync(h_res, d_res, nj * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 		const bool last_ran = st && nj && who[nj - 1] == pc.size() - 1;
@@ -360,11 +364,46 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
 		if (last_ran) last_dht = h_dht[n0];
 		for (size_t k = 0; k < nj; k++) { pc[who[k]].res = h_res[k]; pc[who[k]].done = true; }
+		if (trace) {
+			size_t slow = 0;
+			for (size_t k = 1; k < nj; k++) if (h_res[k].crc > h_res[slow].crc) slow = k;
+			const P &q = pc[who[slow]];
+			fprintf(stderr, "nxz_inflate_stream: round %d: %zu pieces; the longest took %.1f us (piece %zu, %s%s: %llu bytes in, %u out, cc %u)\n", attempt, nj, h_res[slow].crc * 0.01,
+				who[slow], q.tab >= 0 ? "cut" : "block", q.srem ? ", starts in a stored block" : "", (unsigned long long)q.cbytes, h_res[slow].tpbc, h_res[slow].cc);
+		}
+		// pieces that stopped inside a stored block: where the run of stored blocks they are in ends (stored data may
+		// hold anything, things that look like block starts included: they are continued behind the run)
+		std::vector<uint64_t> run_end(pc.size(), 0);
+		{
+			nxz_walk_req_t *h_wq = (nxz_walk_req_t *)(PN + pin_walk);
+			nxz_walk_res_t *h_wr = (nxz_walk_res_t *)(PN + pin_walk + up(n0 * sizeof(nxz_walk_req_t), 16));
+			nxz_walk_req_t *d_wq = (nxz_walk_req_t *)(D + o_walk);
+			nxz_walk_res_t *d_wr = (nxz_walk_res_t *)(D + o_walk + up(n0 * sizeof(nxz_walk_req_t), 16));
+			std::vector<size_t> wi;
+			for (size_t i = 0; i + 1 < pc.size() && wi.size() < n0; i++) {
+				const P &p = pc[i];
+				const nxz_batch_result_t &r = p.res;
+				if (!p.done || r.cc != NXZ_CC_DATA_LENGTH || (r.sfbt & 0xe) != 0x8 || !r.tebc || pc[i + 1].srem) continue;
+				nxz_walk_req_t &w = h_wq[wi.size()];
+				w.src = src; w.src_len = src_len;
+				w.bit = p.cstart * 8 + (p.stop ? p.stop : p.cbytes * 8) - r.subc;
+				w.rem = r.tebc; w.bfinal = r.sfbt & 1;
+				wi.push_back(i);
+			}
+			if (!wi.empty()) {
+				if (hipMemcpyAsync(d_wq, h_wq, wi.size() * sizeof(nxz_walk_req_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+				if (nxz_launch_stored_walk(d_wq, (uint32_t)wi.size(), d_wr, s)) return -EIO;
+				if (hipMemcpyAsync(h_wr, d_wr, wi.size() * sizeof(nxz_walk_res_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+				if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+				for (size_t k = 0; k < wi.size(); k++) run_end[wi[k]] = h_wr[k].bit;
+				lap("runs of stored blocks");
+			}
+		}
 		// every piece but the last must stop at the header of the next one; the last at the final block's end
 		bool again = false;
 		std::vector<P> nx;
 		nx.reserve(pc.size());
-		bool swallow = false, swallow_cuts = false;
+		bool swallow = false, swallow_cuts = false, drop_cuts = false;
 		uint64_t swallow_until = 0;
 		// `confirmed`: the start of the piece under inspection is known to be a block start -- it is the
 		// first piece, or the piece in front is final and ends exactly there.  Only such a piece can say
@@ -375,8 +414,10 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			// this piece's start was refuted: it goes into the piece in front (sized below); so do all starts
 			// inside a stored block that the piece in front was in the middle of
 			// (a piece that did not arrive at a cut inside its block: the block's other cuts go as well)
-			if (swallow || (swallow_cuts && pc[i].tab >= 0) || pc[i].bit < swallow_until) { swallow = false; continue; }
-			swallow_cuts = false;
+			// (and a block start that goes takes the cuts inside its block along)
+			if (drop_cuts && pc[i].tab >= 0) continue;
+			if (swallow || (swallow_cuts && pc[i].tab >= 0) || pc[i].bit < swallow_until) { if (pc[i].tab < 0) drop_cuts = true; swallow = false; continue; }
+			swallow_cuts = false; drop_cuts = false;
 			P p = pc[i];
 			const nxz_batch_result_t &r = p.res;
 			const bool conf = confirmed;
@@ -390,7 +431,14 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			const bool err = r.cc != NXZ_CC_DATA_LENGTH && r.cc != 0;
 			// the final block ended in this piece: what lies behind it (a trailer, another gzip member, anything)
 			// is not this stream's, and block starts seen there are no concern of ours
-			const bool fin = !err && (r.sfbt & 0x100);
+			const bool fin = !err && (r.sfbt & 0x100) && conf;
+			if (!err && (r.sfbt & 0x100) && !conf) {
+				// (a final block seen from a start that is not settled yet -- a whole deflate stream carried as data inside a
+				// stored block has one: like an error in such a piece below, it waits for what the pieces in front turn out to be)
+				confirmed = false;
+				nx.push_back(p);
+				continue;
+			}
 			bool ends_well = !err;
 			if (!fin && i + 1 < pc.size()) {
 				const uint64_t used = (p.stop ? p.stop : p.cbytes * 8) - r.subc, want = pc[i + 1].bit - p.cstart * 8;
@@ -398,6 +446,8 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 				ends_well = r.cc == NXZ_CC_DATA_LENGTH && ((kind == 0xe && used == want) || (kind == 0xa && used == want + 3));
 				// a cut inside a dynamic block: this piece must stand exactly there, still in the block it began in (it has
 				// read that block's header and no other, or none if it began at a cut itself)
+				// the next piece is the rest of the stored block this one stopped in (see below)
+				if (pc[i + 1].srem) ends_well = r.cc == NXZ_CC_DATA_LENGTH && kind == 0x8 && used == want && r.tebc == pc[i + 1].srem;
 				if (pc[i + 1].tab >= 0) ends_well = r.cc == NXZ_CC_DATA_LENGTH && kind == 0xc && !(r.sfbt & 1) && used == want && r.adler == p.hdr0;
 				if (!ends_well && trace)
 					fprintf(stderr, "nxz_inflate_stream: piece %zu (bit %llu, %llu bytes in, %u out, start %s) cc %u sfbt %#x subc %u: used %llu bits, next header thought at %llu\n",
@@ -405,10 +455,29 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			}
 			if (err) {
 				if (conf) return -EILSEQ;                          // a block that starts here is damaged
-				// not a block start after all: into the piece in front, which is decoded again
-				nx.back().done = false;
-				again = true; confirmed = false;
+				// Its start is not settled yet -- something in front of it is being decoded again (else `conf` would hold),
+				// and it is looked at here only because the piece in front arrived exactly at it.  It keeps its result:
+				// either the pieces in front turn out to be none and take it along, or its start is confirmed next
+				// time round and the data is bad.
+				confirmed = false;
+				nx.push_back(p);
 				continue;
+			}
+			if (!ends_well && !err && r.cc == NXZ_CC_DATA_LENGTH && (r.sfbt & 0xe) == 0x8 && r.tebc && p.done) {
+				// It stopped inside a stored block: the start it was cut at is none (stored data that looks like a
+				// header).  What it has decoded stands; what is left of the stored block, and whatever follows up to
+				// the next start behind that block, becomes a piece of its own -- a job that resumes inside a stored block.
+				P q = P();
+				q.bit = p.cstart * 8 + (p.stop ? p.stop : p.cbytes * 8) - r.subc;
+				q.capmul = 100; q.tab = -1; q.hdr0 = 0; q.srem = r.tebc; q.sfin = r.sfbt & 1; q.done = false;
+				swallow_until = std::max<uint64_t>(q.bit + (uint64_t)r.tebc * 8, run_end[i]);
+				if (q.bit > p.bit && !(q.bit & 7)) {
+					nx.push_back(p);
+					nx.push_back(q);
+					again = true; confirmed = false;
+					continue;
+				}
+				swallow_until = 0;
 			}
 			if (!ends_well) {
 				// the piece did not end where the next was thought to start: that start is wrong
@@ -482,6 +551,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	if (nxz_launch_resolve(d_pieces, (uint32_t)n, win0, d_windows, dst, s)) return -EIO;
 	lap("resolve");
 	// ---- checksums: 256 KiB slices of the output (the job / result arrays are free again) ----
+	const uint64_t SLICE = total <= (16u << 20) ? 64 << 10 : 256 << 10;       // (a workgroup per slice: short ones when there are few)
 	const size_t nsl = (size_t)((total + SLICE - 1) / SLICE);
 	std::vector<nxz_batch_result_t> sres(nsl);
 	if (!nsl) { if (crc) *crc = 0; if (adler) *adler = 1; }
@@ -520,8 +590,9 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	const uint32_t nround = 1;
 	uint32_t cr = 0, ad = 1;
 	if (!nsl) return 0;
+	const uint32_t xslice = gf_xpow8(SLICE);                 // (all slices but the last are this long)
 	for (size_t k = 0; k < nsl; k++) {
-		cr = k ? crc_combine(cr, sres[k].crc, sres[k].tpbc) : sres[k].crc;
+		cr = k ? gf_mul(cr, sres[k].tpbc == SLICE ? xslice : gf_xpow8(sres[k].tpbc)) ^ sres[k].crc : sres[k].crc;
 		ad = k ? adler_combine(ad, sres[k].adler, sres[k].tpbc) : sres[k].adler;
 	}
 	if (crc) *crc = cr;
