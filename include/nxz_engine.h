@@ -289,7 +289,7 @@ int nxz_batch_decompress(nxz_ctx_t *ctx,
  * NULL): up to 32 KiB that precede the output (dictionary / earlier output); dst (DEVICE).
  * Synchronous.  Returns 0: *out_len bytes at dst, *crc / *adler of exactly those bytes (combine
  * them with yours), *end_bit = first bit behind the final block, *pieces / *rounds for the curious.
- * -ENOTSUP: the stream does not lend itself to it (shorter than 48 KiB, hardly any dynamic blocks, no
+ * -ENOTSUP: the stream does not lend itself to it (shorter than 12 KiB, hardly any dynamic blocks, no
  * final block inside src, ...): use nxz_batch_decompress / nxu_run_job's resume loop.  -E2BIG:
  * dst_cap too small (*out_len = bytes needed).  -EILSEQ: not a deflate stream. */
 int nxz_inflate_stream(nxz_ctx_t *ctx, const uint8_t *src, uint64_t src_len, uint64_t first_bit,

@@ -5,9 +5,9 @@
 // an engine that is fast on a single stream (7 GB/s on POWER9, samples/simpleapi/README:27-30).
 // A GPU gets there by decoding many pieces of the stream at once, and for that it must know
 // where deflate blocks start inside it.  find_blocks_kernel scans every bit position of every
-// 8 KiB segment of the compressed stream for a plausible header of a non-final dynamic-Huffman
+// segment (1 - 8 KiB) of the compressed stream for a plausible header of a dynamic-Huffman
 // block (RFC 1951 3.2.7) and reports the first one per segment:
-//   BFINAL = 0, BTYPE = 10, HLIT <= 29, HDIST <= 29,
+//   BTYPE = 10 (BFINAL either way: a stream's last block is as long as any), HLIT <= 29, HDIST <= 29,
 //   the code-length code complete (Kraft sum exactly 1),
 //   the HLIT + 257 + HDIST + 1 code lengths decode without a bad repeat or an overrun,
 //   end-of-block has a code, the literal/length code is complete, the distance code is
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 	const uint32_t nbits = (have < seg_bytes ? have : seg_bytes) * 8;
 	// phase 1: the cheap part of the test at every bit position of the segment, in two steps per chunk
 	// of 8192 positions so that the lanes stay busy: (a) every lane looks at the 13 bits that decide for
-	// three positions in four (BFINAL 0, BTYPE 10, HLIT <= 29, HDIST <= 29) and the survivors -- 22 % --
+	// three positions in four (BTYPE 10, HLIT <= 29, HDIST <= 29) and the survivors -- 22 % --
 	// are packed into a queue; (b) the queue, a lane per entry, gets the Kraft sum of the code-length
 	// code (up to 19 three-bit lengths from four dwords).  Consecutive lanes test consecutive
 	// positions in (a), so the dwords they read are the same LDS words for 32 lanes: broadcast reads.
@@ -180,12 +180,12 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 		if (t == 0) nq = 0;
 		__syncthreads();
 		const uint32_t c1 = c0 + QCHUNK < nbits ? c0 + QCHUNK : nbits;
-		// (a) 32 positions per lane at once, bitwise: position p passes when bits p, p+1, p+2 are 0, 0, 1 and
+		// (a) 32 positions per lane at once, bitwise: position p passes when bits p+1, p+2 are 0, 1 and
 		// neither bits p+4..p+7 (HLIT 30, 31) nor bits p+9..p+12 (HDIST 30, 31) are all ones
 		for (uint32_t w0 = (c0 >> 5) + t; w0 * 32 < c1; w0 += NT) {
 			const uint64_t w = (uint64_t)s32[w0] | ((uint64_t)s32[w0 + 1] << 32);
 			const uint64_t hl = (w >> 4) & (w >> 5) & (w >> 6) & (w >> 7), hd = (w >> 9) & (w >> 10) & (w >> 11) & (w >> 12);
-			uint32_t m = (uint32_t)(~w & ~(w >> 1) & (w >> 2) & ~hl & ~hd);
+			uint32_t m = (uint32_t)(~(w >> 1) & (w >> 2) & ~hl & ~hd);
 			const uint32_t p0 = w0 * 32;
 			if (p0 + 32 > c1) m &= (1u << (c1 - p0)) - 1;                       // positions of this chunk only
 			if (base * 8 + p0 < first_bit) m &= first_bit - base * 8 - p0 >= 32 ? 0u : ~0u << (uint32_t)(first_bit - base * 8 - p0);

@@ -51,7 +51,7 @@ typedef struct nxz_sync_req {
 	uint32_t guess_bit;      /* where to look: the boundary found lies behind this bit */
 	uint32_t limit_bit;      /* ... and no token looked at reaches this bit (the next block's header) */
 } nxz_sync_req_t;
-typedef struct nxz_sync_res { uint32_t bit; uint32_t lanes; } nxz_sync_res_t;   /* bit 0xffffffff: none found */
+typedef struct nxz_sync_res { uint32_t bit; uint32_t lanes; } nxz_sync_res_t;   /* bit 0xffffffff: none found; lanes bit 31: the block's BFINAL */
 int nxz_launch_token_sync(const nxz_sync_req_t *reqs, uint32_t n, nxz_sync_res_t *res, nxz_batch_dht_t *tables, hipStream_t stream);
 /* runs of stored blocks (nxz_blockfind.hip stored_walk_kernel) */
 typedef struct nxz_walk_req { const uint8_t *src; uint64_t src_len; uint64_t bit; uint32_t rem, bfinal; } nxz_walk_req_t;

@@ -922,7 +922,8 @@ __global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__
 		tbits = 0;
 	} else if (ok) {
 		const uint32_t v = b.peek();
-		ok = (v & 7) == 4;                            // BFINAL 0, BTYPE 10
+		ok = (v & 6) == 4;                            // BTYPE 10
+		out.lanes = (v & 1) << 31;                    // (BFINAL goes back in the top bit)
 		b.pos += 3;
 		tstart = b.pos;
 		if (ok) ok = read_dht(b, sm, hlit, hdist, tbits) == 0;
@@ -992,7 +993,7 @@ __global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__
 				mx = x > mx ? x : mx; mn = y < mn ? y : mn;
 			}
 			if (mn == 0xffffffffu) break;                                     // no lane left
-			if (mn == mx) { out.bit = mx; out.lanes = (uint32_t)__popcll(__ballot(alive)); break; }
+			if (mn == mx) { out.bit = mx; out.lanes |= (uint32_t)__popcll(__ballot(alive)); break; }
 			while (__ballot(alive && pos < mx)) {
 				if (alive && pos < mx) { if (pos + 64 <= rend) step(); else alive = false; }
 			}

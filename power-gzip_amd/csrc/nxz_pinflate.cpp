@@ -133,7 +133,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	Workspace &ws = g_ws[dev];
 	std::lock_guard<std::mutex> guard(ws.mtx);
 	if (hist_len > WINDOW) { hist += hist_len - WINDOW; hist_len = WINDOW; }
-	if (src_len < (48u << 10) || first_bit / 8 >= src_len) return -ENOTSUP;   // (three blocks' worth: below that one wavefront is as fast)
+	if (src_len < (12u << 10) || first_bit / 8 >= src_len) return -ENOTSUP;   // (half a dozen pieces' worth: below that one wavefront is as fast)
 
 	static const bool trace = getenv("NXZ_PINFLATE_TRACE") != nullptr;
 	struct timespec ts0;
@@ -160,13 +160,12 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		const uint64_t p = ((const uint64_t *)ws.pin)[i];
 		if (p != ~0ull && p > first_bit + 64) B.push_back(p);
 	}
-	if (B.size() < 3) return -ENOTSUP;
 
 	// ---- a stream (or part of one) of a few hundred blocks at most: more places to cut it at ----
 	// With that few pieces the call takes as long as the longest piece, milliseconds for a block of 100 KiB.
 	// Inside a dynamic block any token boundary will do as a cut (the piece there is a job that resumes
 	// inside a dynamic block, with the block's table); token_sync_kernel finds boundaries near the bits asked for.
-	struct Sub { uint64_t bit; uint32_t tab; };
+	struct Sub { uint64_t bit; uint32_t tab, fin; };
 	std::vector<Sub> subs;
 	std::vector<nxz_batch_dht_t> tabs;
 	{
@@ -185,7 +184,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			const uint64_t end = i + 1 < B.size() ? B[i + 1] : src_len * 8, span = end - B[i];
 			const uint64_t base = (B[i] >> 3) & ~3ull;
 			if (end - base * 8 >= 0xffffffffull) continue;
-			if (i == 0 && given0 && (st->sfbt & 0xf) != 0xc) continue;
+			if (i == 0 && given0 && (st->sfbt & 0xe) != 0xc) continue;
 			const uint32_t nsub = (uint32_t)std::min<uint64_t>((uint64_t)split_max, span / sub_bits);
 			for (uint32_t k = 1; k < nsub; k++) {
 				nxz_sync_req_t r;
@@ -222,7 +221,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			const nxz_batch_dht_t *tb = (const nxz_batch_dht_t *)(Pn + o_tb);
 			for (size_t k = 0; k < nr; k++) {
 				if (rs[k].bit == 0xffffffffu) continue;
-				subs.push_back(Sub{ rq_base[k] + rs[k].bit, (uint32_t)tabs.size() });
+				subs.push_back(Sub{ rq_base[k] + rs[k].bit, (uint32_t)tabs.size(), k < ngiven ? (st->sfbt & 1u) : rs[k].lanes >> 31 });
 				tabs.push_back(tb[k]);
 			}
 			if (trace) fprintf(stderr, "nxz_inflate_stream: %zu blocks, %zu token boundaries asked for, %zu found\n", B.size(), nr, subs.size());
@@ -237,6 +236,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		int tab;                                // starts inside a dynamic block: which table (else -1)
 		uint32_t hdr0;                          // block headers it has read while it is still in the block it began in
 		uint32_t srem, sfin;                    // starts inside a stored block: bytes of it still to come (else 0), its BFINAL
+		uint32_t cfin;                          // starts inside a dynamic block: its BFINAL
 		size_t stage_off, out_off;              // its 16-byte aligned copy of those bytes / its 16-bit output, in the bump area
 		uint64_t cap;                           // output elements it may produce
 		uint32_t capmul;
@@ -254,10 +254,11 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		const uint64_t end = i + 1 < B.size() ? B[i + 1] : src_len * 8;
 		for (; k < subs.size() && subs[k].bit < end; k++) {
 			if (subs[k].bit < pc.back().bit + 2048 || subs[k].bit + 2048 > end) continue;     // (too close to its neighbours to be worth a piece)
-			p.bit = subs[k].bit; p.tab = (int)subs[k].tab;
+			p.bit = subs[k].bit; p.tab = (int)subs[k].tab; p.cfin = subs[k].fin;
 			pc.push_back(p);
 		}
 	}
+	if (pc.size() < 3) return -ENOTSUP;                            // (hardly anything to do side by side)
 	const size_t n0 = pc.size(), ng0 = n0 / nxz_window_chain_group() + 1;
 	// control arrays (sized for the first, longest list of pieces), then a bump area for copies and outputs
 	const size_t o_jobs = 0, o_res = o_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), o_items = o_res + up(n0 * sizeof(nxz_batch_result_t), 256),
@@ -324,7 +325,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			const uint32_t sub = (uint32_t)(p.bit & 7);
 			j.resume = (0xeu << 16) | ((sub ? 8 - sub : 0) << 20);
 			if (i == 0 && st && (st->sfbt & 8)) j.resume = (st->rem & 0xffff) | ((st->sfbt & 0xf) << 16) | ((sub ? 8 - sub : 0) << 20);
-			if (p.tab >= 0) j.resume = (0xcu << 16) | ((sub ? 8 - sub : 0) << 20);      // inside a dynamic block that is not the last
+			if (p.tab >= 0) j.resume = ((0xcu | p.cfin) << 16) | ((sub ? 8 - sub : 0) << 20);      // inside a dynamic block
 			if (p.srem) j.resume = p.srem | ((0x8u | p.sfin) << 16);                     // inside a stored block (on a byte boundary)
 			j.in_adler = (uint32_t)p.stop;
 			who.push_back(i);
@@ -448,7 +449,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 				// read that block's header and no other, or none if it began at a cut itself)
 				// the next piece is the rest of the stored block this one stopped in (see below)
 				if (pc[i + 1].srem) ends_well = r.cc == NXZ_CC_DATA_LENGTH && kind == 0x8 && used == want && r.tebc == pc[i + 1].srem;
-				if (pc[i + 1].tab >= 0) ends_well = r.cc == NXZ_CC_DATA_LENGTH && kind == 0xc && !(r.sfbt & 1) && used == want && r.adler == p.hdr0;
+				if (pc[i + 1].tab >= 0) ends_well = r.cc == NXZ_CC_DATA_LENGTH && kind == 0xc && (r.sfbt & 1) == pc[i + 1].cfin && used == want && r.adler == p.hdr0;
 				if (!ends_well && trace)
 					fprintf(stderr, "nxz_inflate_stream: piece %zu (bit %llu, %llu bytes in, %u out, start %s) cc %u sfbt %#x subc %u: used %llu bits, next header thought at %llu\n",
 						i, (unsigned long long)p.bit, (unsigned long long)p.cbytes, r.tpbc, conf ? "confirmed" : "open", r.cc, r.sfbt, r.subc, (unsigned long long)used, (unsigned long long)want);

@@ -705,7 +705,7 @@ int nxz_copy_to_device(nxz_ctx_t *, void *, const void *, size_t, void *) __attr
 int nxz_copy_to_host(nxz_ctx_t *, void *, const void *, size_t, void *) __attribute__((weak));
 int nxz_ctx_sync(nxz_ctx_t *, void *) __attribute__((weak));
 }
-constexpr size_t PARALLEL_INFLATE_MIN = 48u << 10;
+constexpr size_t PARALLEL_INFLATE_MIN = 12u << 10;
 
 bool parallel_inflate(Inflate *s)
 {
