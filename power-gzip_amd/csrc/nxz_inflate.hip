@@ -483,10 +483,14 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 		// walking its 256 bytes through a table costs the wave 80 K cycles per 16 KiB, the kernel 1 K)
 		while (flushed < upto) {
 			uint32_t n = upto - flushed < FLUSH ? upto - flushed : FLUSH;
-			// coalesced copy out (dst + flushed is 16 B aligned when flushed is a multiple of FLUSH)
+			// coalesced copy out: 16 bytes per lane from where `flushed` is a multiple of that (it is a multiple of
+			// FLUSH unless a stored stretch went straight to the target, below), single elements in front and behind
 			constexpr uint32_t EPV = 16 / sizeof(elem_t);             // elements per 16 bytes
 			NXZ_GLOBAL_AS elem_t *de = (NXZ_GLOBAL_AS elem_t *)job.dst;
-			for (uint32_t i = lane * EPV; i < n; i += 64 * EPV) {
+			uint32_t head = (EPV - (flushed & (EPV - 1))) & (EPV - 1);
+			if (head > n) head = n;
+			if ((uint32_t)lane < head) de[flushed + lane] = sm.win[(flushed + lane) & WMASK];
+			for (uint32_t i = head + lane * EPV; i < n; i += 64 * EPV) {
 				if (i + EPV <= n) {
 					uint4 v = *(const uint4 *)&sm.win[(flushed + i) & WMASK];
 					*(uint4 *)(de + flushed + i) = v;
@@ -612,6 +616,25 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 					else *(NXZ_GLOBAL_AS u32_any *)(dst + out + 4 * i) = w;
 				}
 				for (uint32_t i = quads * 4 + lane; i < n; i += 64) wr(out + i, src[sp + i]);
+				out += n; sp += n; rem -= n; n = 0;
+				flushed = out;
+				__syncthreads();
+			} else if (n >= 1024) {
+				// window in LDS: a long stored stretch goes straight to the target the same way (what the window holds
+				// is written out first), and only its last 32 KiB into the window
+				__syncthreads();
+				flush(out);
+				typedef uint32_t u32_any __attribute__((aligned(1)));
+				typedef uint32_t v2u_any __attribute__((ext_vector_type(2), aligned(1)));
+				const uint32_t quads = n >> 2;
+				for (uint32_t i = lane; i < quads; i += 64) {
+					const uint32_t w = *(const NXZ_GLOBAL_AS u32_any *)(src + sp + 4 * i);
+					if (W16) *(NXZ_GLOBAL_AS v2u_any *)(dst16 + out + 4 * i) = (v2u_any){ (w & 0xff) | ((w & 0xff00) << 8), ((w >> 16) & 0xff) | ((w >> 24) << 16) };
+					else *(NXZ_GLOBAL_AS u32_any *)(dst + out + 4 * i) = w;
+				}
+				for (uint32_t i = quads * 4 + lane; i < n; i += 64) { if (W16) dst16[out + i] = src[sp + i]; else dst[out + i] = src[sp + i]; }
+				const uint32_t keep = n < WIN ? n : WIN;
+				for (uint32_t i = n - keep + lane; i < n; i += 64) sm.win[(out + i) & WMASK] = (elem_t)src[sp + i];
 				out += n; sp += n; rem -= n; n = 0;
 				flushed = out;
 				__syncthreads();

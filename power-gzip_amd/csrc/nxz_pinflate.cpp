@@ -506,7 +506,6 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		uint64_t sum = 0;
 		size_t m = 0;
 		while (m < n && sum + pc[m].res.tpbc <= dst_cap) sum += pc[m++].res.tpbc;
-		while (m > 0 && m < n && pc[m].tab >= 0) m--;          // (what is left for the next call starts at a block header)
 		if (m < n && (!st || m == 0)) {
 			for (sum = 0, m = 0; m < n; m++) sum += pc[m].res.tpbc;
 			*out_len = sum;
@@ -526,6 +525,15 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			if (!fin && !cut) {
 				st->sfbt = r.sfbt & 0xf; st->rem = r.tebc;
 				if ((r.sfbt & 0xe) == 0xc) { st->dhtlen = (r.sfbt >> 16) & 0xfff; memcpy(st->dht, last_dht.dht, NXZ_DHT_MAXSZ); }
+			}
+			if (cut) {
+				// the first piece left out begins at a block header (all zero), or inside a block: stored, or dynamic at a cut
+				const P &np = pc[m];
+				if (np.srem) { st->sfbt = 0x8 | np.sfin; st->rem = np.srem; }
+				else if (np.tab >= 0) {
+					st->sfbt = 0xc | np.cfin; st->dhtlen = tabs[(size_t)np.tab].dhtlen;
+					memcpy(st->dht, tabs[(size_t)np.tab].dht, NXZ_DHT_MAXSZ);
+				}
 			}
 		}
 		n = m;

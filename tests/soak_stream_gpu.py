@@ -2,7 +2,9 @@
 generated blocks, of random bytes and of nested deflate output, compressed piece after piece with
 random levels, strategies, memLevels and flush points into ONE raw stream of 2..12 MiB -- through
 nxz_inflate_stream; output and CRC-32 against zlib.  Streams the engine declines (-ENOTSUP) are
-counted, everything else must be exact.   python tests/soak_stream_gpu.py [cases]"""
+counted, everything else must be exact.  Then the same stream through nx_inflate in steps of random
+sizes (parts of the stream that begin and end anywhere: nxz_inflate_stream_part), which must be exact
+whatever the engine declines.   python tests/soak_stream_gpu.py [cases]"""
 import importlib, os, random, sys, zlib
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -10,6 +12,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import corpus
 from datagen import make_block
+import zstream as Z
+ZL = Z.load("gpu")
 pkg = importlib.import_module("power-gzip_amd")
 eng = pkg.Engine(0)
 _, blocks, _ = corpus.load(65536)
@@ -58,6 +62,13 @@ for case in range(first, ncases):
     if not ok:
         bad += 1
         print("case %d: rc %d, %s, expected %d bytes" % (case, rc, info, len(plain)), flush=True)
+    # ... and in steps through the zlib-style call
+    step_in = rnd.choice([rnd.randrange(20000, 200000), rnd.randrange(200000, 3 << 20), len(comp)])
+    step_out = rnd.choice([rnd.randrange(30000, 300000), rnd.randrange(300000, 4 << 20), len(plain) + 64])
+    got, zrc, total_in, _ = Z.inflate_all(ZL, comp, wbits=-15, cap=len(plain) + 64, step_in=step_in, step_out=step_out)
+    if zrc != Z.Z_STREAM_END or got != plain or total_in != len(comp):
+        bad += 1
+        print("case %d in steps of %d / %d: rc %d, %d bytes of %d, %d of %d consumed" % (case, step_in, step_out, zrc, len(got), len(plain), total_in, len(comp)), flush=True)
     if case % 10 == 9:
         print("%d cases done: %d declined, %d bad" % (case + 1, declined, bad), flush=True)
 print("SOAK OK" if not bad else "SOAK FAILED", "(%d cases, %d declined)" % (ncases, declined))
