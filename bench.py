@@ -395,6 +395,41 @@ def api_leg(raw, args, mib=256, nthreads=16):
         raise SystemExit("api leg: nx_uncompress of a zlib -6 stream differs from the source")
     out["uncompress_one_shot"] = {"value": round(len(data) / best / 2.0 ** 30, 2), "unit": "GiB/s uncompressed out", "MiB": mib,
                                   "ms": round(best * 1e3, 2), "stream": "zlib level 6, one zlib stream"}
+    # the same data as a .gz through inflate() with avail_in / avail_out steps of 64 KiB and 1 MiB
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz = co.compress(data[:64 << 20]) + co.flush()
+    gsrc = C.create_string_buffer(gz, len(gz))
+    gdst = C.create_string_buffer(1 << 20)
+    for step in (64 << 10, 1 << 20):
+        best = 1e9
+        for it in range(2):
+            st = Z.ZStream()
+            if L.nx_inflateInit2_(C.byref(st), 31, Z.VERSION, C.sizeof(Z.ZStream)) != 0:
+                return dict(out, error="nx_inflateInit2_ failed")
+            fed = total = 0
+            crc = 0
+            rc = 0
+            t = time.perf_counter()
+            while rc != Z.Z_STREAM_END:
+                if st.avail_in == 0 and fed < len(gz):
+                    k = min(step, len(gz) - fed)
+                    st.next_in = C.addressof(gsrc) + fed
+                    st.avail_in = k
+                    fed += k
+                st.next_out = C.addressof(gdst)
+                st.avail_out = step
+                rc = L.nx_inflate(C.byref(st), Z.Z_NO_FLUSH)
+                if rc not in (Z.Z_OK, Z.Z_STREAM_END, Z.Z_BUF_ERROR) or (rc == Z.Z_BUF_ERROR and st.avail_out == step and fed == len(gz)):
+                    return dict(out, error="nx_inflate in steps returned %d" % rc)
+                total += step - st.avail_out
+            dt = time.perf_counter() - t
+            crc = st.adler
+            L.nx_inflateEnd(C.byref(st))
+            best = min(best, dt)
+        if total != (64 << 20) or crc != zlib.crc32(data[:64 << 20]):
+            raise SystemExit("api leg: nx_inflate in steps of %d made %d bytes, crc %08x" % (step, total, crc))
+        out["inflate_in_steps_%dKiB" % (step >> 10)] = {"value": round(total / best / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out", "MiB": 64,
+                                                        "ms": round(best * 1e3, 1), "stream": "zlib level 6 .gz, avail_in = avail_out = the step"}
     blocks = [data[i * BLOCK:(i + 1) * BLOCK] for i in range(min(1024, len(data) // BLOCK))]
 
     def worker(res, k):

@@ -89,7 +89,11 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
 	// code-length-code length, last literal/length length or last distance length is zero although
 	// the count could have been smaller is taken for chance.  (A stream of an encoder that does not
 	// trim offers fewer starts here and is decoded in longer pieces, or job after job.)
-	if (hclen > 4 && lastl == 0) return false;
+	// The exception is the POWER NX engine's table generator (and this engine's, which makes the same tables:
+	// /root/reference lib/nx_dhtgen.c:628-648): it always sends all 286 + 30 lengths with all 19
+	// code-length-code lengths, used or not -- that signature is taken as it comes.
+	const bool nx_made = hlit == 286 && hdist == 30 && hclen == 19;
+	if (hclen > 4 && lastl == 0 && !nx_made) return false;
 	uint32_t n = 0, prev = 0, kraft_ll = 0, kraft_d = 0, nd = 0, maxd = 0, eob = 0, last_ll = 0, last_d = 0;
 	const uint32_t total = hlit + hdist;
 	while (n < total) {
@@ -143,7 +147,7 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
 		if (kraft_ll > (1u << 15) || kraft_d > (1u << 15)) return false;
 	}
 	if (!eob || kraft_ll != (1u << 15)) return false;
-	if ((hlit > 257 && !last_ll) || (hdist > 1 && !last_d)) return false;
+	if (!nx_made && ((hlit > 257 && !last_ll) || (hdist > 1 && !last_d))) return false;
 	if (!(kraft_d == (1u << 15) || nd == 0 || (nd == 1 && maxd == 1))) return false;
 	return true;
 }

@@ -27,6 +27,7 @@
 #include <string.h>
 #include <time.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "nxz_device.h"
@@ -80,10 +81,12 @@ uint32_t adler_combine(uint32_t a1, uint32_t a2, uint64_t len2)
 	return s1 | (s2 << 16);
 }
 
-// grow-only device/pinned workspace per context call (guarded by a mutex: one long stream at a time per context)
+// grow-only device/pinned workspaces, a few per device: callers on different threads (each with a stream of
+// its own) decode side by side; a caller takes one that is free, or waits for the one its turn falls on
 struct Workspace {
 	void *dev = nullptr; size_t dev_cap = 0;
 	void *pin = nullptr; size_t pin_cap = 0;
+	hipStream_t own = nullptr;                  // for callers that name no stream
 	std::mutex mtx;
 	bool need(size_t d, size_t p)
 	{
@@ -102,7 +105,9 @@ struct Workspace {
 		return true;
 	}
 };
-Workspace g_ws[64];
+constexpr int NWS = 8;
+Workspace g_ws[64][NWS];
+std::atomic<unsigned> g_ws_turn{0};
 
 inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -130,8 +135,15 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	hipStream_t s = (hipStream_t)stream_;
 	int dev = nxz_ctx_device(c);                              // the context's device, whatever the calling thread's current one is
 	if (dev < 0 || dev >= 64 || hipSetDevice(dev) != hipSuccess) return -ENODEV;
-	Workspace &ws = g_ws[dev];
-	std::lock_guard<std::mutex> guard(ws.mtx);
+	Workspace *wsp = nullptr;
+	for (int k = 0; k < NWS && !wsp; k++) if (g_ws[dev][k].mtx.try_lock()) wsp = &g_ws[dev][k];
+	if (!wsp) { wsp = &g_ws[dev][g_ws_turn.fetch_add(1) % NWS]; wsp->mtx.lock(); }
+	Workspace &ws = *wsp;
+	std::lock_guard<std::mutex> guard(ws.mtx, std::adopt_lock);
+	if (!s) {
+		if (!ws.own && hipStreamCreateWithFlags(&ws.own, hipStreamNonBlocking) != hipSuccess) return -EIO;
+		s = ws.own;
+	}
 	if (hist_len > WINDOW) { hist += hist_len - WINDOW; hist_len = WINDOW; }
 	if (src_len < (12u << 10) || first_bit / 8 >= src_len) return -ENOTSUP;   // (half a dozen pieces' worth: below that one wavefront is as fast)
 

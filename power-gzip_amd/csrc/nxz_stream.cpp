@@ -704,6 +704,7 @@ void nxz_dev_free(nxz_ctx_t *, void *) __attribute__((weak));
 int nxz_copy_to_device(nxz_ctx_t *, void *, const void *, size_t, void *) __attribute__((weak));
 int nxz_copy_to_host(nxz_ctx_t *, void *, const void *, size_t, void *) __attribute__((weak));
 int nxz_ctx_sync(nxz_ctx_t *, void *) __attribute__((weak));
+void *nxz_stream_create(nxz_ctx_t *) __attribute__((weak));
 }
 constexpr size_t PARALLEL_INFLATE_MIN = 12u << 10;
 
@@ -724,13 +725,28 @@ bool parallel_inflate(Inflate *s)
 	if (z->avail_out < 2 * (nc + take)) take = std::min<size_t>(take, std::max<size_t>(1u << 20, z->avail_out));
 	const size_t nin = nc + take, nh = s->hist.size();
 	const size_t cap = z->avail_out >= 2 * nin ? (size_t)z->avail_out : std::max<size_t>(z->avail_out, 8 * nin);
-	// device buffers for the stream and its output: kept from call to call (grow only), one large call at a time
-	static std::mutex pool_mtx;
-	static uint8_t *pool_src = nullptr, *pool_dst = nullptr, *pool_hist = nullptr;
-	static size_t pool_src_cap = 0, pool_dst_cap = 0;
-	static nxz_ctx_t *pool_ctx = nullptr;
-	std::lock_guard<std::mutex> pool_guard(pool_mtx);
-	if (pool_ctx != ctx) { pool_src = pool_dst = pool_hist = nullptr; pool_src_cap = pool_dst_cap = 0; pool_ctx = ctx; }   // (a context that went away took its memory along)
+	// device buffers for the stream and its output and a HIP stream to work on: a few sets, kept from call to call
+	// (grow only); callers on different threads take different sets and run side by side
+	struct Slot {
+		std::mutex mtx;
+		uint8_t *src = nullptr, *dst = nullptr, *hist = nullptr;
+		size_t src_cap = 0, dst_cap = 0;
+		nxz_ctx_t *ctx = nullptr;
+		void *stream = nullptr;
+	};
+	constexpr int NSLOT = 8;
+	static Slot slots[NSLOT];
+	static std::atomic<unsigned> turn{0};
+	Slot *slot = nullptr;
+	for (int k = 0; k < NSLOT && !slot; k++) if (slots[k].mtx.try_lock()) slot = &slots[k];
+	if (!slot) { slot = &slots[turn.fetch_add(1) % NSLOT]; slot->mtx.lock(); }
+	std::lock_guard<std::mutex> pool_guard(slot->mtx, std::adopt_lock);
+	uint8_t *&pool_src = slot->src, *&pool_dst = slot->dst, *&pool_hist = slot->hist;
+	size_t &pool_src_cap = slot->src_cap, &pool_dst_cap = slot->dst_cap;
+	nxz_ctx_t *&pool_ctx = slot->ctx;
+	if (pool_ctx != ctx) { pool_src = pool_dst = pool_hist = nullptr; pool_src_cap = pool_dst_cap = 0; pool_ctx = ctx; slot->stream = nullptr; }   // (a context that went away took its memory along)
+	if (!slot->stream && nxz_stream_create) slot->stream = nxz_stream_create(ctx);
+	void *const hs = slot->stream;               // (NULL, the default stream, if none could be made)
 	if (pool_src_cap < nin + 64) { if (pool_src) nxz_dev_free(ctx, pool_src); pool_src = (uint8_t *)nxz_dev_malloc(ctx, nin + 64); pool_src_cap = pool_src ? nin + 64 : 0; }
 	if (pool_dst_cap < cap + 64) { if (pool_dst) nxz_dev_free(ctx, pool_dst); pool_dst = (uint8_t *)nxz_dev_malloc(ctx, cap + 64); pool_dst_cap = pool_dst ? cap + 64 : 0; }
 	if (!pool_hist) pool_hist = (uint8_t *)nxz_dev_malloc(ctx, WINDOW);
@@ -741,9 +757,9 @@ bool parallel_inflate(Inflate *s)
 	static const bool trace = getenv("NXZ_API_TRACE") != nullptr;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t0 = trace ? now() : 0;
-	if (ok) ok = (!nc || nxz_copy_to_device(ctx, d_src, s->carry.data(), nc, nullptr) == 0) && (!take || nxz_copy_to_device(ctx, d_src + nc, z->next_in, take, nullptr) == 0) &&
-		     (!nh || nxz_copy_to_device(ctx, d_hist, s->hist.data(), nh, nullptr) == 0);
-	if (ok && trace) (void)nxz_ctx_sync(ctx, nullptr);
+	if (ok) ok = (!nc || nxz_copy_to_device(ctx, d_src, s->carry.data(), nc, hs) == 0) && (!take || nxz_copy_to_device(ctx, d_src + nc, z->next_in, take, hs) == 0) &&
+		     (!nh || nxz_copy_to_device(ctx, d_hist, s->hist.data(), nh, hs) == 0);
+	if (ok && trace) (void)nxz_ctx_sync(ctx, hs);
 	const double t1 = trace ? now() : 0;
 	// where the stream stands at the first byte: the fields of the last suspension (a job's or a part's)
 	nxz_stream_resume_t st;
@@ -754,7 +770,7 @@ bool parallel_inflate(Inflate *s)
 		first_bit = s->subc ? 8 - s->subc : 0;
 	}
 	int prc = -1;
-	if (ok) prc = nxz_inflate_stream_part(ctx, d_src, nin, first_bit, d_hist, (uint32_t)nh, d_dst, cap, &out_len, &crc, &adler, &end_bit, &st, nullptr, nullptr);
+	if (ok) prc = nxz_inflate_stream_part(ctx, d_src, nin, first_bit, d_hist, (uint32_t)nh, d_dst, cap, &out_len, &crc, &adler, &end_bit, &st, nullptr, hs);
 	ok = ok && prc == 0 && end_bit >= first_bit && end_bit <= (uint64_t)nin * 8 && (out_len || (end_bit >> 3));
 	const double t2 = trace ? now() : 0;
 	// the output: as much as the caller has room for goes straight to next_out, the rest waits; the last 32 KiB are the next history
@@ -763,8 +779,8 @@ bool parallel_inflate(Inflate *s)
 	if (ok) {
 		s->pend.resize(later); s->pend_off = 0;
 		tail.resize((size_t)std::min<uint64_t>(out_len, WINDOW));
-		ok = (!direct || nxz_copy_to_host(ctx, z->next_out, d_dst, direct, nullptr) == 0) && (!later || nxz_copy_to_host(ctx, s->pend.data(), d_dst + direct, later, nullptr) == 0) &&
-		     (tail.empty() || nxz_copy_to_host(ctx, tail.data(), d_dst + out_len - tail.size(), tail.size(), nullptr) == 0) && nxz_ctx_sync(ctx, nullptr) == 0;
+		ok = (!direct || nxz_copy_to_host(ctx, z->next_out, d_dst, direct, hs) == 0) && (!later || nxz_copy_to_host(ctx, s->pend.data(), d_dst + direct, later, hs) == 0) &&
+		     (tail.empty() || nxz_copy_to_host(ctx, tail.data(), d_dst + out_len - tail.size(), tail.size(), hs) == 0) && nxz_ctx_sync(ctx, hs) == 0;
 		if (!ok) s->pend.clear();
 	}
 	if (trace) fprintf(stderr, "nxz parallel_inflate: %zu bytes in (%zu carried), copy in %.2f ms, inflate %.2f ms, copy out %.2f ms (%llu bytes, %zu wait)%s\n", nin, nc, t1 - t0, t2 - t1, now() - t2,
