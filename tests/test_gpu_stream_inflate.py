@@ -213,3 +213,17 @@ def test_damage_is_still_a_data_error_in_steps(data):
         gz[k] ^= 0xa5
     got, rc, _, _ = Z.inflate_all(L, bytes(gz), wbits=31, cap=len(plain) + (1 << 20), step_in=1 << 20, step_out=1 << 20)
     assert rc == Z.Z_DATA_ERROR
+
+
+def test_streams_made_by_this_engine_are_cut_at_every_block(eng, data):
+    """The NX table generator (and this engine's, which makes the same tables) sends all 286 + 30 code lengths
+    with all 19 code-length-code lengths, used or not: headers no other encoder writes.  The block search
+    takes them as they come, so a stream made by nx_deflate / the reference is decoded side by side too."""
+    plain = data[:8 << 20]
+    rc, stream, crc, _ = eng.deflate_host(plain)
+    assert rc == 0 and zlib.decompress(stream, -15) == plain
+    rc, info, dst = _run(eng, stream, len(plain) + 4096)
+    assert rc == 0, (rc, info)
+    assert info["out_len"] == len(plain) and info["crc"] == crc == zlib.crc32(plain)
+    assert dst[:len(plain)].cpu().numpy().tobytes() == plain
+    assert info["pieces"] >= len(plain) // 65536          # a piece per 64 KiB block at least (cuts inside the blocks come on top)
