@@ -181,11 +181,12 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	std::vector<Sub> subs;
 	std::vector<nxz_batch_dht_t> tabs;
 	{
-		static const int split_max = getenv("NXZ_PINFLATE_SPLIT") ? atoi(getenv("NXZ_PINFLATE_SPLIT")) : 16;      // pieces per block at most (0, 1: blocks only)
+		static const int split_max = getenv("NXZ_PINFLATE_SPLIT") ? atoi(getenv("NXZ_PINFLATE_SPLIT")) : 64;      // pieces per block at most (0, 1: blocks only)
+		static const uint64_t sub_min = getenv("NXZ_PINFLATE_PIECE_BITS") ? (uint64_t)atoll(getenv("NXZ_PINFLATE_PIECE_BITS")) : 4096;   // the shortest piece
 		const uint64_t all_bits = src_len * 8 - first_bit;
 		// (as many pieces as the device holds wavefronts of the decode kernel, a few times over: 768 for a part of a
 		// megabyte or two, 8192 for a long stream)
-		const uint64_t sub_bits = std::max<uint64_t>(16384, all_bits <= (64u << 20) ? all_bits / 768 : all_bits / 8192);
+		const uint64_t sub_bits = std::max<uint64_t>(std::max<uint64_t>(sub_min, 2048), all_bits <= (64u << 20) ? all_bits / 768 : all_bits / 8192);
 		std::vector<nxz_sync_req_t> rq;
 		std::vector<uint64_t> rq_base;
 		// (the first piece begins wherever the caller's part of the stream does: inside a dynamic block that is not
