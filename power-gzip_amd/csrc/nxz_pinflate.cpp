@@ -37,7 +37,7 @@ uint32_t nxz_blockfind_segment(uint64_t srclen);
 int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, hipStream_t stream);
 int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);
 int nxz_ctx_device(nxz_ctx_t *c);
-uint32_t nxz_window_chain_group(void);
+uint32_t nxz_window_chain_group(uint32_t n);
 int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint16_t *maps, uint8_t *windows,
 			    uint16_t *gmaps, uint8_t *gwin, hipStream_t stream);
 int nxz_launch_resolve(const void *pieces, uint32_t n, const uint8_t *win0, const uint8_t *windows, uint8_t *dst, hipStream_t stream);
@@ -272,7 +272,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		}
 	}
 	if (pc.size() < 3) return -ENOTSUP;                            // (hardly anything to do side by side)
-	const size_t n0 = pc.size(), ng0 = n0 / nxz_window_chain_group() + 1;
+	const size_t n0 = pc.size(), ng0 = n0 / nxz_window_chain_group(0) + 1;
 	// control arrays (sized for the first, longest list of pieces), then a bump area for copies and outputs
 	const size_t o_jobs = 0, o_res = o_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), o_items = o_res + up(n0 * sizeof(nxz_batch_result_t), 256),
 		     o_pieces = o_items + up((n0 + 4) * sizeof(CopyItem), 256), o_win0 = o_pieces + up(n0 * sizeof(Piece), 256),
