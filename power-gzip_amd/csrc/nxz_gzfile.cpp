@@ -35,7 +35,7 @@ struct GzState {
 	bool eof = false;                  // reader: the file has been read to its end
 	bool done = false;                 // reader: ... and everything in it has been handed out
 };
-constexpr unsigned RBUF = 65536, CHUNK = 65536;
+constexpr unsigned RBUF = 1u << 20, CHUNK = 65536;       // (reads of a MiB: nx_inflate decodes what it is handed side by side)
 
 GzState *gz_open(const char *path, int fd, const char *mode)
 {

@@ -72,7 +72,7 @@ int stream_inflate(const uint8_t *p, size_t len, Out &out)
 	z_stream s;
 	memset(&s, 0, sizeof(s));
 	if (nx_inflateInit2_(&s, 47, ZLIB_VERSION, (int)sizeof(s)) != Z_OK) { fprintf(stderr, "nxz_gzip: cannot open the engine\n"); return -1; }
-	std::vector<uint8_t> o(4u << 20);
+	std::vector<uint8_t> o(64u << 20);
 	size_t pos = 0;
 	int rc = Z_OK;
 	while (pos < len) {
