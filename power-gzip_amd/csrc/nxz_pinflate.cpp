@@ -148,6 +148,10 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	if (src_len < (12u << 10) || first_bit / 8 >= src_len) return -ENOTSUP;   // (half a dozen pieces' worth: below that one wavefront is as fast)
 
 	static const bool trace = getenv("NXZ_PINFLATE_TRACE") != nullptr;
+	// The small records the kernels are steered by and answer with (jobs, results, requests, tables, pieces) stay
+	// in pinned host memory, which the device reads and writes in place: no copy calls, a call of this function
+	// is a dozen launches and four waits.  (NXZ_PINFLATE_ZEROCOPY=0: copies to and from device memory instead.)
+	static const bool zc = !(getenv("NXZ_PINFLATE_ZEROCOPY") && atoi(getenv("NXZ_PINFLATE_ZEROCOPY")) == 0);
 	struct timespec ts0;
 	clock_gettime(CLOCK_MONOTONIC, &ts0);
 	auto lap = [&](const char *what) {
@@ -162,8 +166,8 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	const uint32_t nseg = (uint32_t)((src_len + SEG - 1) / SEG);
 	// ---- block starts ----
 	if (!ws.need(nseg * sizeof(uint64_t), nseg * sizeof(uint64_t))) return -ENOMEM;
-	if (nxz_launch_find_blocks(src, src_len, first_bit, (uint64_t *)ws.dev, nseg, s)) return -EIO;
-	if (hipMemcpyAsync(ws.pin, ws.dev, nseg * sizeof(uint64_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+	if (nxz_launch_find_blocks(src, src_len, first_bit, (uint64_t *)(zc ? ws.pin : ws.dev), nseg, s)) return -EIO;
+	if (!zc && hipMemcpyAsync(ws.pin, ws.dev, nseg * sizeof(uint64_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 	if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
 	lap("block starts");
 	std::vector<uint64_t> B;
@@ -215,9 +219,9 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			const size_t o_rq = 0, o_rs = up(nr * sizeof(nxz_sync_req_t), 256), o_tb = o_rs + up(nr * sizeof(nxz_sync_res_t), 256),
 				     tot = o_tb + up(nr * sizeof(nxz_batch_dht_t), 256);
 			if (!ws.need(tot, tot)) return -ENOMEM;
-			uint8_t *Dv = (uint8_t *)ws.dev, *Pn = (uint8_t *)ws.pin;
+			uint8_t *Pn = (uint8_t *)ws.pin, *Dv = zc ? Pn : (uint8_t *)ws.dev;
 			memcpy(Pn + o_rq, rq.data(), nr * sizeof(nxz_sync_req_t));
-			if (hipMemcpyAsync(Dv + o_rq, Pn + o_rq, nr * sizeof(nxz_sync_req_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+			if (!zc && hipMemcpyAsync(Dv + o_rq, Pn + o_rq, nr * sizeof(nxz_sync_req_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 			if (ngiven) {
 				nxz_batch_dht_t *tg = (nxz_batch_dht_t *)(Pn + o_tb);
 				for (size_t k = 0; k < ngiven; k++) {                 // (they are the first requests)
@@ -225,10 +229,10 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 					tg[k].dhtlen = st->dhtlen;
 					memcpy(tg[k].dht, st->dht, NXZ_DHT_MAXSZ);
 				}
-				if (hipMemcpyAsync(Dv + o_tb, Pn + o_tb, ngiven * sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+				if (!zc && hipMemcpyAsync(Dv + o_tb, Pn + o_tb, ngiven * sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 			}
 			if (nxz_launch_token_sync((const nxz_sync_req_t *)(Dv + o_rq), (uint32_t)nr, (nxz_sync_res_t *)(Dv + o_rs), (nxz_batch_dht_t *)(Dv + o_tb), s)) return -EIO;
-			if (hipMemcpyAsync(Pn + o_rs, Dv + o_rs, tot - o_rs, hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+			if (!zc && hipMemcpyAsync(Pn + o_rs, Dv + o_rs, tot - o_rs, hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 			if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
 			const nxz_sync_res_t *rs = (const nxz_sync_res_t *)(Pn + o_rs);
 			const nxz_batch_dht_t *tb = (const nxz_batch_dht_t *)(Pn + o_tb);
@@ -321,9 +325,9 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			win0_made = false;
 		}
 		D = (uint8_t *)ws.dev; PN = (uint8_t *)ws.pin;
-		nxz_batch_job_t *d_jobs = (nxz_batch_job_t *)(D + o_jobs), *h_jobs = (nxz_batch_job_t *)(PN + pin_jobs);
-		nxz_batch_result_t *d_res = (nxz_batch_result_t *)(D + o_res), *h_res = (nxz_batch_result_t *)(PN + pin_res);
-		CopyItem *d_items = (CopyItem *)(D + o_items), *h_items = (CopyItem *)(PN + pin_items);
+		nxz_batch_job_t *h_jobs = (nxz_batch_job_t *)(PN + pin_jobs), *d_jobs = zc ? h_jobs : (nxz_batch_job_t *)(D + o_jobs);
+		nxz_batch_result_t *h_res = (nxz_batch_result_t *)(PN + pin_res), *d_res = zc ? h_res : (nxz_batch_result_t *)(D + o_res);
+		CopyItem *h_items = (CopyItem *)(PN + pin_items), *d_items = zc ? h_items : (CopyItem *)(D + o_items);
 		size_t nj = 0, ni = 0;
 		std::vector<size_t> who;
 		for (size_t i = 0; i < pc.size(); i++) {
@@ -349,11 +353,11 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			if (hist_len) h_items[ni++] = CopyItem{ hist, D + o_win0 + (WINDOW - hist_len), hist_len };
 			win0_made = true;
 		}
-		if (hipMemcpyAsync(d_items, h_items, ni * sizeof(CopyItem), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
-		if (hipMemcpyAsync(d_jobs, h_jobs, nj * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+		if (!zc && hipMemcpyAsync(d_items, h_items, ni * sizeof(CopyItem), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+		if (!zc && hipMemcpyAsync(d_jobs, h_jobs, nj * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 		// tables: in for a first piece that resumes inside a dynamic block, out for a last piece that stops inside one
 		const bool use_dht = st || !tabs.empty();
-		nxz_batch_dht_t *d_dht = use_dht ? (nxz_batch_dht_t *)(D + o_dht) : nullptr, *h_dht = (nxz_batch_dht_t *)(PN + pin_dht);
+		nxz_batch_dht_t *h_dht = (nxz_batch_dht_t *)(PN + pin_dht), *d_dht = !use_dht ? nullptr : zc ? h_dht : (nxz_batch_dht_t *)(D + o_dht);
 		if (use_dht && nj) {
 			bool any = false;
 			for (size_t k = 0; k < nj; k++) {
@@ -366,17 +370,17 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 					any = true;
 				}
 			}
-			if (any && hipMemcpyAsync(d_dht, h_dht, nj * sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+			if (!zc && any && hipMemcpyAsync(d_dht, h_dht, nj * sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 		}
 		if (nxz_launch_copy_items(d_items, (uint32_t)ni, s)) return -EIO;
 		lap("staging");
 		if (nxz_launch_inflate_w16(d_jobs, nj, d_res, d_dht, attempt == 0, s)) return -EIO;
 		lap("decode");
-		if (hipMemcpyAsync(h_res, d_res, nj * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+		if (!zc && hipMemcpyAsync(h_res, d_res, nj * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 		const bool last_ran = st && nj && who[nj - 1] == pc.size() - 1;
-		if (last_ran && hipMemcpyAsync(&h_dht[n0], d_dht + (nj - 1), sizeof(nxz_batch_dht_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+		if (!zc && last_ran && hipMemcpyAsync(&h_dht[n0], d_dht + (nj - 1), sizeof(nxz_batch_dht_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 		if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
-		if (last_ran) last_dht = h_dht[n0];
+		if (last_ran) last_dht = zc ? h_dht[nj - 1] : h_dht[n0];
 		for (size_t k = 0; k < nj; k++) { pc[who[k]].res = h_res[k]; pc[who[k]].done = true; }
 		if (trace) {
 			size_t slow = 0;
@@ -391,8 +395,8 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		{
 			nxz_walk_req_t *h_wq = (nxz_walk_req_t *)(PN + pin_walk);
 			nxz_walk_res_t *h_wr = (nxz_walk_res_t *)(PN + pin_walk + up(n0 * sizeof(nxz_walk_req_t), 16));
-			nxz_walk_req_t *d_wq = (nxz_walk_req_t *)(D + o_walk);
-			nxz_walk_res_t *d_wr = (nxz_walk_res_t *)(D + o_walk + up(n0 * sizeof(nxz_walk_req_t), 16));
+			nxz_walk_req_t *d_wq = zc ? h_wq : (nxz_walk_req_t *)(D + o_walk);
+			nxz_walk_res_t *d_wr = zc ? h_wr : (nxz_walk_res_t *)(D + o_walk + up(n0 * sizeof(nxz_walk_req_t), 16));
 			std::vector<size_t> wi;
 			for (size_t i = 0; i + 1 < pc.size() && wi.size() < n0; i++) {
 				const P &p = pc[i];
@@ -405,9 +409,9 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 				wi.push_back(i);
 			}
 			if (!wi.empty()) {
-				if (hipMemcpyAsync(d_wq, h_wq, wi.size() * sizeof(nxz_walk_req_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+				if (!zc && hipMemcpyAsync(d_wq, h_wq, wi.size() * sizeof(nxz_walk_req_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 				if (nxz_launch_stored_walk(d_wq, (uint32_t)wi.size(), d_wr, s)) return -EIO;
-				if (hipMemcpyAsync(h_wr, d_wr, wi.size() * sizeof(nxz_walk_res_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+				if (!zc && hipMemcpyAsync(h_wr, d_wr, wi.size() * sizeof(nxz_walk_res_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 				if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
 				for (size_t k = 0; k < wi.size(); k++) run_end[wi[k]] = h_wr[k].bit;
 				lap("runs of stored blocks");
@@ -554,7 +558,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	// ---- places, true windows, resolution ----
 	uint8_t *P_ = (uint8_t *)ws.pin;
 	Piece *h_pieces = (Piece *)(P_ + pin_pieces);
-	Piece *d_pieces = (Piece *)(D + o_pieces);
+	Piece *d_pieces = zc ? h_pieces : (Piece *)(D + o_pieces);
 	uint8_t *d_windows = D + o_windows;
 	uint16_t *d_maps = (uint16_t *)(D + o_maps);
 	nxz_batch_job_t *d_jobs = (nxz_batch_job_t *)(D + o_jobs);
@@ -566,7 +570,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	}
 	*out_len = total;
 	if (total > dst_cap) return -E2BIG;
-	if (hipMemcpyAsync(d_pieces, h_pieces, n * sizeof(Piece), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+	if (!zc && hipMemcpyAsync(d_pieces, h_pieces, n * sizeof(Piece), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 	const uint8_t *win0 = D + o_win0;
 	if (nxz_launch_window_chain(d_pieces, (uint32_t)n, win0, d_maps, d_windows, (uint16_t *)(D + o_gmaps), D + o_gwin, s)) return -EIO;
 	lap("tail maps + window chain");
@@ -588,10 +592,10 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			h_jobs[k].in_crc = 0; h_jobs[k].in_adler = 1;
 			h_res[k].tpbc = (uint32_t)std::min<uint64_t>(SLICE, total - (o + k) * SLICE);
 		}
-		if (hipMemcpyAsync(d_jobs, h_jobs, m * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
-		if (hipMemcpyAsync(d_res, h_res, m * sizeof(nxz_batch_result_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
-		if (nxz_launch_cksum(d_jobs, m, d_res, s)) return -EIO;
-		if (hipMemcpyAsync(h_res, d_res, m * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+		if (!zc && hipMemcpyAsync(d_jobs, h_jobs, m * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+		if (!zc && hipMemcpyAsync(d_res, h_res, m * sizeof(nxz_batch_result_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+		if (nxz_launch_cksum(zc ? h_jobs : d_jobs, m, zc ? h_res : d_res, s)) return -EIO;
+		if (!zc && hipMemcpyAsync(h_res, d_res, m * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 		if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
 		memcpy(&sres[o], h_res, m * sizeof(nxz_batch_result_t));
 	}
