@@ -17,6 +17,7 @@
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
+#include <atomic>
 #include <condition_variable>
 #include <map>
 #include <deque>
@@ -88,8 +89,8 @@ struct nxz_ctx {
 		}
 	};
 	std::map<hipStream_t, Scratch> scratch;
-	// nxz_deflate_host: two lanes, each with its own stream, so that the copies of one group of
-	// blocks run while the other group is in the kernels
+	// nxz_deflate_host: a call works on two lanes, each with its own stream, so that the copies of one group of
+	// blocks run while the other group is in the kernels; four such pairs (made when first used), for callers on different threads
 	struct HostLane {
 		hipStream_t stream = nullptr;
 		uint8_t *d_src = nullptr, *d_dst = nullptr, *d_packed = nullptr;
@@ -97,8 +98,9 @@ struct nxz_ctx {
 		nxz_batch_result_t *d_res = nullptr, *h_res = nullptr;
 		uint64_t *d_off = nullptr, *h_total = nullptr;
 		size_t n = 0; uint64_t bytes = 0;
-	} lanes[2];
-	std::mutex lanes_mtx;
+	} lanes[8];
+	std::mutex lanes_mtx[4];
+	std::atomic<unsigned> lanes_turn{0};
 	// nxu_run_job, compress: callers that arrive while a launch is in flight are gathered and go out
 	// together as one launch of each kernel (run_compress / round_run)
 	struct Round {
@@ -510,9 +512,13 @@ extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t
 	if (forked_child()) return -ENODEV;
 	if (dst_cap < nxz_deflate_host_bound(src_len)) return -E2BIG;
 	(void)hipSetDevice(c->device);
-	std::lock_guard<std::mutex> g(c->lanes_mtx);
-	for (auto &l : c->lanes)
-		if (!l.stream && !lane_init(l)) return -ENOMEM;
+	int pair = -1;
+	for (int k = 0; k < 4 && pair < 0; k++) if (c->lanes_mtx[k].try_lock()) pair = k;
+	if (pair < 0) { pair = (int)(c->lanes_turn.fetch_add(1) % 4); c->lanes_mtx[pair].lock(); }
+	std::lock_guard<std::mutex> g(c->lanes_mtx[pair], std::adopt_lock);
+	nxz_ctx::HostLane *const lanes = c->lanes + 2 * pair;
+	for (int k = 0; k < 2; k++)
+		if (!lanes[k].stream && !lane_init(lanes[k])) return -ENOMEM;
 	const size_t nblk = (src_len + SUBBLOCK - 1) / SUBBLOCK;
 	// groups: at least four when the input allows it, so that copies and kernels overlap
 	size_t group = std::min<size_t>(HOST_GROUP, std::max<size_t>(32, (nblk + 3) / 4));
@@ -524,7 +530,7 @@ extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t
 	int rc = 0;
 
 	auto queue = [&](size_t gi) -> int {
-		nxz_ctx::HostLane &l = c->lanes[gi & 1];
+		nxz_ctx::HostLane &l = lanes[gi & 1];
 		const size_t b0 = gi * group, n = std::min(group, nblk - b0);
 		const uint64_t bytes = std::min<uint64_t>((uint64_t)n * SUBBLOCK, src_len - (uint64_t)b0 * SUBBLOCK);
 		for (size_t k = 0; k < n; k++) {
@@ -546,7 +552,7 @@ extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t
 		return 0;
 	};
 	auto collect = [&](size_t gi) -> int {
-		nxz_ctx::HostLane &l = c->lanes[gi & 1];
+		nxz_ctx::HostLane &l = lanes[gi & 1];
 		HIPCHK(hipStreamSynchronize(l.stream), return -EIO);
 		const uint64_t total = *l.h_total;
 		if (pos + total > dst_cap) return -E2BIG;                   // cannot happen: the bound was checked
@@ -568,7 +574,7 @@ extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t
 		if (!rc && queued < ngroups) rc = queue(queued++);
 	}
 	if (rc) {
-		for (auto &l : c->lanes) (void)hipStreamSynchronize(l.stream);
+		for (int k = 0; k < 2; k++) (void)hipStreamSynchronize(lanes[k].stream);
 		return rc;
 	}
 	*out_len = pos;

@@ -128,6 +128,40 @@ def test_sixteen_threads_share_the_engine(L):
     assert not bad, bad
 
 
+def test_threads_with_large_calls_work_side_by_side(L):
+    """eight threads, each nx_compress2 / nx_uncompress of buffers of 1 - 3 MiB at once: the large-call paths
+    (nxz_deflate_host on one of four pairs of lanes, nxz_inflate_stream_part on one of eight workspaces)
+    run side by side; every thread must get its own bytes back, and zlib must read what was written"""
+    import threading
+    T, per = 8, 4
+    kinds = ("alice", "lz", "text33", "random", "zeros", "binary")
+    bufs = [[b"".join(make_block(kinds[(t + i + k) % 6], 65536, 1000 * t + 10 * i + k) for k in range(16 + 8 * ((t + i) % 5))) for i in range(per)] for t in range(T)]
+    bad = []
+
+    def worker(t):
+        cap = C.c_ulong()
+        dst = C.create_string_buffer(L.nx_compressBound(4 << 20))
+        back = C.create_string_buffer(4 << 20)
+        for b in bufs[t]:
+            cap.value = len(dst)
+            if L.nx_compress2(dst, C.byref(cap), b, len(b), 1) != Z.Z_OK or zlib.decompress(dst.raw[:cap.value]) != b:
+                bad.append((t, "compress"))
+                return
+            z6 = zlib.compress(b, 6)
+            for stream in (dst.raw[:cap.value], z6):
+                n = C.c_ulong(len(back))
+                if L.nx_uncompress(back, C.byref(n), stream, len(stream)) != Z.Z_OK or back.raw[:n.value] != b:
+                    bad.append((t, "uncompress"))
+                    return
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not bad, bad
+
+
 def test_deflate_host_entry_point():
     """nxz_deflate_host itself (include/nxz_engine.h): any length, final or not, both function codes;
     runs that are not final end on a byte boundary and are continued by the next run."""
