@@ -630,7 +630,7 @@ struct Inflate {
 	uint64_t total_out = 0;
 	uint8_t trailer[8]; uint32_t ntrailer = 0;
 	bool sync_point = false, have_dict = false;
-	uint32_t par_skip = 0;                             // calls for which the parallel decode is not tried again
+	uint32_t par_skip = 0, par_declined = 0;           // calls for which the parallel decode is not tried again; declines in a row
 	uint32_t ratio = 250;                              // last compressed/uncompressed per mille (:1234-1250)
 	Engine eng; JobBuf jb; std::vector<uint8_t> src, out;
 
@@ -785,7 +785,13 @@ bool parallel_inflate(Inflate *s)
 	}
 	if (trace) fprintf(stderr, "nxz parallel_inflate: %zu bytes in (%zu carried), copy in %.2f ms, inflate %.2f ms, copy out %.2f ms (%llu bytes, %zu wait)%s\n", nin, nc, t1 - t0, t2 - t1, now() - t2,
 			   (unsigned long long)out_len, later, ok ? (st.final ? " -- final" : "") : " -- declined");
-	if (!ok) { s->par_skip = 4; return false; }
+	if (!ok) {
+		// declined: once is chance (the next part is tried again), again and again is the kind of stream
+		s->par_declined = std::min<uint32_t>(s->par_declined + 1, 4);
+		s->par_skip = (1u << (s->par_declined - 1)) - 1;
+		return false;
+	}
+	s->par_declined = 0;
 	// the source: [carry][next_in .. take); whole bytes used, and the byte the part stopped in (supplied again)
 	auto at = [&](size_t i) -> uint8_t { return i < nc ? s->carry[i] : z->next_in[i - nc]; };
 	const size_t consumed = st.final ? (size_t)((end_bit + 7) >> 3) : (size_t)(end_bit >> 3);
@@ -935,7 +941,7 @@ int inflate_reset(z_streamp strm)
 	if (s->st != Inflate::DONE) s->unget.clear();           // (behind a finished stream: the next member's first bytes stay)
 	s->st = Inflate::HEADER; s->held = s->nheld = 0; s->gzflags = 0; s->pend.clear(); s->pend_off = 0;
 	s->hist.clear(); s->carry.clear(); s->resuming = false; s->sfbt = s->subc = s->rem = s->dhtlen = 0;
-	s->crc = 0; s->adler = 1; s->total_out = 0; s->ntrailer = 0; s->sync_point = false; s->have_dict = false; s->ratio = 250; s->par_skip = 0;
+	s->crc = 0; s->adler = 1; s->total_out = 0; s->ntrailer = 0; s->sync_point = false; s->have_dict = false; s->ratio = 250; s->par_skip = 0; s->par_declined = 0;
 	s->hcrc = 0;
 	return Z_OK;
 }
