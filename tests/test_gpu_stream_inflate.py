@@ -148,7 +148,7 @@ def test_through_the_zlib_style_api(data):
 
 @pytest.mark.parametrize("kib", [96, 200, 700, 3000])
 def test_streams_of_a_few_blocks(eng, data, kib):
-    """from three block starts on the parallel path is taken: streams of a few hundred KiB"""
+    """streams of a few hundred KiB: a few blocks, cut at token boundaries inside them"""
     plain = data[1 << 20:(1 << 20) + (kib << 10)]
     c = zlib.compressobj(6, zlib.DEFLATED, -15)
     comp = c.compress(plain) + c.flush()
