@@ -69,6 +69,18 @@ for case in range(first, ncases):
     if zrc != Z.Z_STREAM_END or got != plain or total_in != len(comp):
         bad += 1
         print("case %d in steps of %d / %d: rc %d, %d bytes of %d, %d of %d consumed" % (case, step_in, step_out, zrc, len(got), len(plain), total_in, len(comp)), flush=True)
+    # ... and damaged, inside a gzip wrapper (every third case): a data error or a trailer that does not match, never
+    # wrong bytes reported as good, never a crash
+    if case % 3 == 0:
+        import struct
+        gz = bytearray(b"\x1f\x8b\x08\0\0\0\0\0\0\x03" + comp + struct.pack("<II", zlib.crc32(plain), len(plain) & 0xffffffff))
+        at = rnd.randrange(10, len(gz) - 8)
+        for k in range(at, min(at + rnd.choice([1, 3, 40, 2000]), len(gz) - 8)):
+            gz[k] ^= rnd.randrange(1, 256)
+        got, zrc, _, _ = Z.inflate_all(ZL, bytes(gz), wbits=31, cap=len(plain) * 2 + (1 << 20), step_in=step_in, step_out=step_out)
+        if not (zrc == Z.Z_DATA_ERROR or zrc == Z.Z_BUF_ERROR or (zrc == Z.Z_STREAM_END and got == plain)):
+            bad += 1
+            print("case %d damaged at %d: rc %d, %d bytes" % (case, at, zrc, len(got)), flush=True)
     if case % 10 == 9:
         print("%d cases done: %d declined, %d bad" % (case + 1, declined, bad), flush=True)
 print("SOAK OK" if not bad else "SOAK FAILED", "(%d cases, %d declined)" % (ncases, declined))
