@@ -190,7 +190,8 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		const uint64_t all_bits = src_len * 8 - first_bit;
 		// (as many pieces as the device holds wavefronts of the decode kernel, a few times over: 768 for a part of a
 		// megabyte or two, 8192 for a long stream)
-		const uint64_t sub_bits = std::max<uint64_t>(std::max<uint64_t>(sub_min, 2048), all_bits <= (64u << 20) ? all_bits / 768 : all_bits / 8192);
+		static const uint64_t many = getenv("NXZ_PINFLATE_PIECES") ? std::max<uint64_t>(1, (uint64_t)atoll(getenv("NXZ_PINFLATE_PIECES"))) : 8192;   // pieces of a long stream, about
+		const uint64_t sub_bits = std::max<uint64_t>(std::max<uint64_t>(sub_min, 2048), all_bits <= (64u << 20) ? all_bits / 768 : all_bits / many);
 		std::vector<nxz_sync_req_t> rq;
 		std::vector<uint64_t> rq_base;
 		// (the first piece begins wherever the caller's part of the stream does: inside a dynamic block that is not
