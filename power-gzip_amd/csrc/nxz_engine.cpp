@@ -489,9 +489,14 @@ extern "C" size_t nxz_deflate_host_bound(size_t src_len)
 	return src_len + ((src_len + SUBBLOCK - 1) / SUBBLOCK) * 10 + 16;
 }
 
-static bool lane_init(nxz_ctx::HostLane &l)
+// (the two lanes of a pair get streams of different priority: the runtime maps streams onto a few hardware
+// queues, and two streams of one priority may share a queue, depending on what other streams the process has
+// made before -- then the copies of one lane and the kernels of the other run one after the other)
+static bool lane_init(nxz_ctx::HostLane &l, bool high)
 {
-	HIPCHK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), return false);
+	int least = 0, greatest = 0;
+	(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+	HIPCHK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, high ? greatest : least), return false);
 	HIPCHK(hipMalloc((void **)&l.d_src, (size_t)HOST_GROUP * SUBBLOCK), return false);
 	HIPCHK(hipMalloc((void **)&l.d_dst, (size_t)HOST_GROUP * HOST_SLOT), return false);
 	HIPCHK(hipMalloc((void **)&l.d_packed, (size_t)HOST_GROUP * (SUBBLOCK + 16)), return false);
@@ -504,6 +509,7 @@ static bool lane_init(nxz_ctx::HostLane &l)
 	return true;
 }
 
+static inline uint64_t trace_ns();
 extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t src_len, int final,
 				uint8_t *dst, size_t dst_cap, size_t *out_len, uint32_t *crc, uint32_t *adler)
 {
@@ -518,7 +524,7 @@ extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t
 	std::lock_guard<std::mutex> g(c->lanes_mtx[pair], std::adopt_lock);
 	nxz_ctx::HostLane *const lanes = c->lanes + 2 * pair;
 	for (int k = 0; k < 2; k++)
-		if (!lanes[k].stream && !lane_init(lanes[k])) return -ENOMEM;
+		if (!lanes[k].stream && !lane_init(lanes[k], k == 1)) return -ENOMEM;
 	const size_t nblk = (src_len + SUBBLOCK - 1) / SUBBLOCK;
 	// groups: at least four when the input allows it, so that copies and kernels overlap
 	size_t group = std::min<size_t>(HOST_GROUP, std::max<size_t>(32, (nblk + 3) / 4));
@@ -568,11 +574,17 @@ extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t
 		return 0;
 	};
 	size_t queued = 0, done = 0;
-	while (!rc && queued < ngroups && queued < 2) rc = queue(queued++);
+	static const bool htrace = getenv("NXZ_API_TRACE") != nullptr;
+	uint64_t tq = 0, tc = 0, t_ = 0;
+	auto tick = [&]() { return htrace ? trace_ns() : 0; };
+	while (!rc && queued < ngroups && queued < 2) { t_ = tick(); rc = queue(queued++); tq += tick() - t_; }
 	while (!rc && done < queued) {
-		rc = collect(done++);
-		if (!rc && queued < ngroups) rc = queue(queued++);
+		t_ = tick(); rc = collect(done++); tc += tick() - t_;
+		if (!rc && queued < ngroups) { t_ = tick(); rc = queue(queued++); tq += tick() - t_; }
 	}
+	if (htrace && src_len >= (64u << 20))
+		fprintf(stderr, "nxz_deflate_host: %zu bytes in %zu groups on lanes %d/%d: %.2f ms queueing (copies in, launches), %.2f ms collecting (waits, copies out)\n",
+			src_len, ngroups, 2 * pair, 2 * pair + 1, tq * 1e-6, tc * 1e-6);
 	if (rc) {
 		for (int k = 0; k < 2; k++) (void)hipStreamSynchronize(lanes[k].stream);
 		return rc;

@@ -140,7 +140,8 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	if (!wsp) { wsp = &g_ws[dev][g_ws_turn.fetch_add(1) % NWS]; wsp->mtx.lock(); }
 	Workspace &ws = *wsp;
 	std::lock_guard<std::mutex> guard(ws.mtx, std::adopt_lock);
-	if (!s) {
+	static const bool own_stream = !(getenv("NXZ_PINFLATE_OWN_STREAM") && atoi(getenv("NXZ_PINFLATE_OWN_STREAM")) == 0);
+	if (!s && own_stream) {
 		if (!ws.own && hipStreamCreateWithFlags(&ws.own, hipStreamNonBlocking) != hipSuccess) return -EIO;
 		s = ws.own;
 	}
