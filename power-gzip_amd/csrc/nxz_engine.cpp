@@ -492,6 +492,17 @@ extern "C" size_t nxz_deflate_host_bound(size_t src_len)
 // (the two lanes of a pair get streams of different priority: the runtime maps streams onto a few hardware
 // queues, and two streams of one priority may share a queue, depending on what other streams the process has
 // made before -- then the copies of one lane and the kernels of the other run one after the other)
+// a non-blocking stream whose priority goes round (low, normal, high) with `turn`: streams that are to run side by
+// side -- rounds, the callers' streams of nxz_stream_create -- spread over the hardware queues of all three levels
+static hipError_t stream_create_spread(hipStream_t *s, unsigned turn)
+{
+	static const bool spread = !(getenv("NXZ_STREAM_PRIORITIES") && atoi(getenv("NXZ_STREAM_PRIORITIES")) == 0);
+	int least = 0, greatest = 0;
+	(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+	const int prio = !spread ? 0 : turn % 3 == 0 ? 0 : turn % 3 == 1 ? greatest : least;
+	return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio);
+}
+
 static bool lane_init(nxz_ctx::HostLane &l, bool high)
 {
 	int least = 0, greatest = 0;
@@ -617,7 +628,8 @@ extern "C" void *nxz_stream_create(nxz_ctx_t *c)
 {
 	hipStream_t s = nullptr;
 	if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;
-	HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), return nullptr);
+	static std::atomic<unsigned> turn{0};
+	HIPCHK(stream_create_spread(&s, turn.fetch_add(1)), return nullptr);
 	return (void *)s;
 }
 extern "C" void nxz_stream_destroy(nxz_ctx_t *c, void *stream)
@@ -813,7 +825,8 @@ struct CompressReq {
 static bool round_init(nxz_ctx::Round &r)
 {
 	if (r.ready) return true;
-	HIPCHK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking), return false);
+	static std::atomic<unsigned> round_turn{0};
+	HIPCHK(stream_create_spread(&r.stream, round_turn.fetch_add(1)), return false);
 	HIPCHK(hipHostMalloc((void **)&r.h_jobs, ROUND_MAX * sizeof(nxz_batch_job_t)), return false);
 	HIPCHK(hipHostMalloc((void **)&r.h_res, ROUND_MAX * sizeof(nxz_batch_result_t)), return false);
 	HIPCHK(hipHostMalloc((void **)&r.h_dht, ROUND_MAX * sizeof(nxz_batch_dht_t)), return false);

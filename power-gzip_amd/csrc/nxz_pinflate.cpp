@@ -142,7 +142,13 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	std::lock_guard<std::mutex> guard(ws.mtx, std::adopt_lock);
 	static const bool own_stream = !(getenv("NXZ_PINFLATE_OWN_STREAM") && atoi(getenv("NXZ_PINFLATE_OWN_STREAM")) == 0);
 	if (!s && own_stream) {
-		if (!ws.own && hipStreamCreateWithFlags(&ws.own, hipStreamNonBlocking) != hipSuccess) return -EIO;
+		if (!ws.own) {
+			// (priorities in turn: streams of one priority may share a hardware queue)
+			int least = 0, greatest = 0;
+			(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+			const int k = (int)(wsp - g_ws[dev]);
+			if (hipStreamCreateWithPriority(&ws.own, hipStreamNonBlocking, k % 3 == 0 ? 0 : k % 3 == 1 ? greatest : least) != hipSuccess) return -EIO;
+		}
 		s = ws.own;
 	}
 	if (hist_len > WINDOW) { hist += hist_len - WINDOW; hist_len = WINDOW; }
