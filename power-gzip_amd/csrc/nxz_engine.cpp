@@ -888,12 +888,12 @@ static int round_run(nxz_ctx *c, nxz_ctx::Round &R, std::vector<CompressReq *> &
 	return 0;
 }
 
-// A round that is free, as long as fewer than NXZ_ROUNDS (default 3) are in flight: few rounds in flight
+// A round that is free, as long as fewer than NXZ_ROUNDS (default 6) are in flight: few rounds in flight
 // make the callers that arrive meanwhile wait and go out TOGETHER, which is what the device wants (it
 // runs only a handful of small launches side by side); c->qm is held.
 static nxz_ctx::Round *free_round(nxz_ctx *c)
 {
-	static const unsigned limit = [] { const char *e = getenv("NXZ_ROUNDS"); unsigned v = e ? (unsigned)atoi(e) : 3; return v < 1 ? 1u : v > 16 ? 16u : v; }();
+	static const unsigned limit = [] { const char *e = getenv("NXZ_ROUNDS"); unsigned v = e ? (unsigned)atoi(e) : 6; return v < 1 ? 1u : v > 16 ? 16u : v; }();
 	unsigned busy = 0;
 	nxz_ctx::Round *f = nullptr;
 	for (auto &r : c->rounds) { if (r.busy) busy++; else if (!f) f = &r; }
