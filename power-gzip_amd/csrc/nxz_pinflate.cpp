@@ -37,6 +37,7 @@ uint32_t nxz_blockfind_segment(uint64_t srclen);
 int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, hipStream_t stream);
 int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);
 int nxz_ctx_device(nxz_ctx_t *c);
+int nxz_engine_usable(void);
 uint32_t nxz_window_chain_group(uint32_t n);
 int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint16_t *maps, uint8_t *windows,
 			    uint16_t *gmaps, uint8_t *gwin, hipStream_t stream);
@@ -132,6 +133,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			  uint64_t *end_bit, nxz_stream_resume_t *st, uint32_t *pieces, uint32_t *rounds, void *stream_)
 {
 	if (!c || !src || !dst || !out_len) return -EINVAL;
+	if (!nxz_engine_usable()) return -ENODEV;                  // (a process forked after the engine was opened: no HIP calls there)
 	hipStream_t s = (hipStream_t)stream_;
 	int dev = nxz_ctx_device(c);                              // the context's device, whatever the calling thread's current one is
 	if (dev < 0 || dev >= 64 || hipSetDevice(dev) != hipSuccess) return -ENODEV;

@@ -705,6 +705,7 @@ int nxz_copy_to_device(nxz_ctx_t *, void *, const void *, size_t, void *) __attr
 int nxz_copy_to_host(nxz_ctx_t *, void *, const void *, size_t, void *) __attribute__((weak));
 int nxz_ctx_sync(nxz_ctx_t *, void *) __attribute__((weak));
 void *nxz_stream_create(nxz_ctx_t *) __attribute__((weak));
+int nxz_engine_usable(void) __attribute__((weak));
 }
 constexpr size_t PARALLEL_INFLATE_MIN = 12u << 10;
 
@@ -713,6 +714,7 @@ bool parallel_inflate(Inflate *s)
 	z_streamp z = s->z;
 	if (!nxz_inflate_stream_part || !nxz_dev_malloc || !nxz_dev_free || !nxz_copy_to_device || !nxz_copy_to_host || !nxz_ctx_sync) return false;
 	if (s->pending() || !s->eng.open) return false;
+	if (nxz_engine_usable && !nxz_engine_usable()) return false;       // (forked after the engine was opened: the job loop reports it)
 	static const bool off = getenv("NXZ_PARALLEL_INFLATE") && atoi(getenv("NXZ_PARALLEL_INFLATE")) == 0;   // 0: always job after job
 	const size_t nc = s->carry.size();
 	if (off || nc + z->avail_in < PARALLEL_INFLATE_MIN) return false;
