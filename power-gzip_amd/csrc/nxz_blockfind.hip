@@ -44,7 +44,9 @@ __device__ __forceinline__ uint32_t peek(const uint8_t *s, uint32_t bit, uint32_
 // counts per length, the symbols in canonical order: 3, 5 and 5 bits an entry) -- arrays indexed at run
 // time would live in scratch memory, a trip to the caches per symbol -- and a code-length symbol costs
 // one look at the source (14 bits: the longest code and the longest repeat count).
-__device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
+// (max_syms: give up -- answer "may be one" -- after that many code-length symbols without a contradiction: the
+// first sieve, a lane per survivor; what it lets through goes to header_ok_wave)
+__device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit, uint32_t max_syms)
 {
 	if (bit + 17 > limit) return false;
 	uint32_t v = peek(s, bit, 17);
@@ -96,7 +98,9 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
 	if (hclen > 4 && lastl == 0 && !nx_made) return false;
 	uint32_t n = 0, prev = 0, kraft_ll = 0, kraft_d = 0, nd = 0, maxd = 0, eob = 0, last_ll = 0, last_d = 0;
 	const uint32_t total = hlit + hdist;
+	uint32_t nsym = 0;
 	while (n < total) {
+		if (nsym++ >= max_syms) return true;
 		// one code-length symbol: its code (7 bits at most) and what follows it (7 at most)
 		if (pos >= limit) return false;
 		const uint32_t w = peek(s, pos, 14);
@@ -144,6 +148,124 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit)
 		}
 		n += rep;
 		// (lengths read off chance bits oversubscribe a code within a few dozen symbols: no need to go on)
+		if (kraft_ll > (1u << 15) || kraft_d > (1u << 15)) return false;
+	}
+	if (!eob || kraft_ll != (1u << 15)) return false;
+	if (!nx_made && ((hlit > 257 && !last_ll) || (hdist > 1 && !last_d))) return false;
+	if (!(kraft_d == (1u << 15) || nd == 0 || (nd == 1 && maxd == 1))) return false;
+	return true;
+}
+
+// The same check by a whole wavefront (all lanes call it with the same candidate; the answer is the same in all):
+// a lane on its own issues an instruction every five cycles or so and needs ~150 of them per code-length symbol,
+// 100 us for a real header -- which is what the search cost when every survivor had a lane of its own and the
+// wavefront waited for its slowest lane.  Here the header's bits (at most 2283 + 17) sit in two registers per
+// lane, a symbol's bits are fetched with v_readlane, the 7-bit code-length code is looked up in two more
+// registers (as the inflate kernel reads tables: nxz_inflate.hip read_dht), and the bookkeeping is scalar.
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__device__ bool header_ok_wave(const uint32_t *s32, uint32_t ndw, uint32_t bit, uint32_t limit, int lane)
+{
+	bit = uni32(bit);
+	if (bit + 17 > limit) return false;
+	const uint32_t d0 = bit >> 5;
+	const uint32_t R0 = d0 + lane < ndw ? s32[d0 + lane] : 0, R1 = d0 + 64 + lane < ndw ? s32[d0 + 64 + lane] : 0;
+	// up to 25 bits at bit p (p >= bit), wave-uniform
+	auto peek = [&](uint32_t p) __attribute__((always_inline)) -> uint32_t {
+		const uint32_t o = uni32(p - d0 * 32), i = o >> 5, sh = o & 31;
+		const uint32_t lo = i < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)R0, (int)i) : (uint32_t)__builtin_amdgcn_readlane((int)R1, (int)(i & 63));
+		const uint32_t j = i + 1;
+		const uint32_t hi = j < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)R0, (int)j) : (uint32_t)__builtin_amdgcn_readlane((int)R1, (int)(j & 63));
+		return (uint32_t)(((((uint64_t)hi << 32) | lo) >> sh));
+	};
+	const uint32_t v = peek(bit);
+	const uint32_t hlit = ((v >> 3) & 31) + 257, hdist = ((v >> 8) & 31) + 1, hclen = ((v >> 13) & 15) + 4;
+	uint32_t pos = bit + 17;
+	if (pos + 3 * hclen > limit) return false;
+	// the code-length code: lane = symbol; its 3-bit length is the inv[symbol]-th that is sent
+	uint32_t myl = 0;
+	{
+		// position of symbol sy in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15, five bits each
+		const uint64_t inv_lo = 3ull | 17ull << 5 | 15ull << 10 | 13ull << 15 | 11ull << 20 | 9ull << 25 | 7ull << 30 | 5ull << 35 | 4ull << 40 | 6ull << 45 | 8ull << 50 | 10ull << 55;
+		const uint64_t inv_hi = 12ull | 14ull << 5 | 16ull << 10 | 18ull << 15 | 0ull << 20 | 1ull << 25 | 2ull << 30;
+		const uint32_t sy = (uint32_t)lane;
+		const uint32_t at = sy < 12 ? (uint32_t)(inv_lo >> (5 * sy)) & 31 : sy < 19 ? (uint32_t)(inv_hi >> (5 * (sy - 12))) & 31 : 31;
+		if (at < hclen) {
+			const uint32_t o = pos + 3 * at;
+			const uint64_t w = (uint64_t)s32[o >> 5] | ((uint64_t)s32[(o >> 5) + 1] << 32);
+			myl = (uint32_t)(w >> (o & 31)) & 7;
+		}
+	}
+	const bool nx_made = hlit == 286 && hdist == 30 && hclen == 19;
+	// (the last length that is sent belongs to symbol order[hclen - 1]: the lane whose `at` is hclen - 1)
+	{
+		const uint64_t inv_lo = 3ull | 17ull << 5 | 15ull << 10 | 13ull << 15 | 11ull << 20 | 9ull << 25 | 7ull << 30 | 5ull << 35 | 4ull << 40 | 6ull << 45 | 8ull << 50 | 10ull << 55;
+		const uint64_t inv_hi = 12ull | 14ull << 5 | 16ull << 10 | 18ull << 15 | 0ull << 20 | 1ull << 25 | 2ull << 30;
+		const uint32_t sy = (uint32_t)lane;
+		const uint32_t at = sy < 12 ? (uint32_t)(inv_lo >> (5 * sy)) & 31 : sy < 19 ? (uint32_t)(inv_hi >> (5 * (sy - 12))) & 31 : 31;
+		const uint64_t last_nonzero = __ballot(at == hclen - 1 && myl != 0);
+		if (hclen > 4 && !last_nonzero && !nx_made) return false;
+	}
+	pos += 3 * hclen;
+	// canonical codes by ranks (lane = symbol), then the look-up: entries `lane` and `lane + 64` of the 7-bit table,
+	// symbol | length << 5, 0xff = no code
+	uint32_t tlo = 0xff, thi = 0xff;
+	{
+		uint32_t c = 0, prevcnt = 0, kraft = 0, mycode = 0;
+		for (uint32_t bl = 1; bl <= 7; bl++) {
+			c = (c + prevcnt) << 1;
+			const uint64_t m = __ballot(myl == bl);
+			if (myl == bl) mycode = c + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+			prevcnt = (uint32_t)__popcll(m);
+			kraft += prevcnt << (7 - bl);
+		}
+		if (kraft != 128) return false;
+		const uint32_t myrev = myl ? __builtin_bitreverse32(mycode) >> (32 - myl) : 0;
+		for (int sy = 0; sy < 19; sy++) {
+			const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)myl, sy);
+			if (!l) continue;
+			const uint32_t rev = (uint32_t)__builtin_amdgcn_readlane((int)myrev, sy), mask = (1u << l) - 1;
+			if (((uint32_t)lane & mask) == rev) tlo = (uint32_t)sy | (l << 5);
+			if ((((uint32_t)lane + 64) & mask) == rev) thi = (uint32_t)sy | (l << 5);
+		}
+	}
+	uint32_t n = 0, prev = 0, kraft_ll = 0, kraft_d = 0, nd = 0, maxd = 0, eob = 0, last_ll = 0, last_d = 0;
+	const uint32_t total = hlit + hdist;
+	while (n < total) {
+		if (pos >= limit) return false;
+		const uint32_t w = peek(pos);
+		const uint32_t k = w & 127;
+		const uint32_t e = k < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)tlo, (int)k) : (uint32_t)__builtin_amdgcn_readlane((int)thi, (int)(k - 64));
+		if (e == 0xff) return false;
+		const uint32_t sym = e & 31, len = e >> 5;
+		if (pos + len > limit) return false;
+		pos += len;
+		const uint32_t x = w >> len;
+		uint32_t rep = 1, val = sym;
+		if (sym == 16) {
+			if (n == 0 || pos + 2 > limit) return false;
+			rep = 3 + (x & 3); pos += 2; val = prev;
+		} else if (sym == 17) {
+			if (pos + 3 > limit) return false;
+			rep = 3 + (x & 7); pos += 3; val = 0;
+		} else if (sym == 18) {
+			if (pos + 7 > limit) return false;
+			rep = 11 + (x & 127); pos += 7; val = 0;
+		}
+		if (n + rep > total) return false;
+		if (sym < 16) prev = sym; else if (sym != 16) prev = 0;
+		if (val) {
+			const uint32_t en = n + rep;
+			const uint32_t nl = n < hlit ? (en < hlit ? en : hlit) - n : 0, ndist = rep - nl;
+			kraft_ll += nl << (15 - val);
+			kraft_d += ndist << (15 - val);
+			nd += ndist;
+			if (ndist && val > maxd) maxd = val;
+			if (n <= 256 && en > 256) eob = 1;
+			if (nl && n + nl == hlit) last_ll = 1;
+			if (ndist && en == total) last_d = 1;
+		}
+		n += rep;
 		if (kraft_ll > (1u << 15) || kraft_d > (1u << 15)) return false;
 	}
 	if (!eob || kraft_ll != (1u << 15)) return false;
@@ -227,11 +349,34 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 		}
 	}
 	__syncthreads();
-	// phase 2: the whole header, a lane per survivor
-	const uint32_t nc = ncand < MAXCAND ? ncand : MAXCAND;
-	for (uint32_t k = t; k < nc; k += NT) {
+	// phase 2: the start of the header, a lane per survivor (lengths read off chance bits oversubscribe a code within
+	// a few dozen symbols) ...
+	const uint32_t nc0 = ncand < MAXCAND ? ncand : MAXCAND;
+	if (seg_bytes > 2048) {
+		// (long streams, long segments with hundreds of survivors each: what counts is the work, not how long one
+		// workgroup takes -- the whole header by the lane, all survivors at once)
+		for (uint32_t k = t; k < nc0; k += NT) {
+			const uint32_t p = cand[k];
+			if (p < best && header_ok(s, p, limit, 0xffffffffu)) atomicMin(&best, p);
+		}
+		__syncthreads();
+		if (t == 0) first[seg] = best == 0xffffffffu ? ~0ull : base * 8 + best;
+		return;
+	}
+	__syncthreads();
+	if (t == 0) nq = 0;
+	__syncthreads();
+	for (uint32_t k = t; k < nc0; k += NT) {
 		const uint32_t p = cand[k];
-		if (p < best && header_ok(s, p, limit)) atomicMin(&best, p);
+		if (header_ok(s, p, limit, 40)) queue[atomicAdd(&nq, 1u)] = (uint16_t)p;
+	}
+	__syncthreads();
+	// ... then the whole header, a wavefront per survivor of that
+	const uint32_t nc = nq;
+	for (uint32_t k = (uint32_t)t >> 6; k < nc; k += NT / 64) {
+		const uint32_t p = uni32(queue[k]);
+		if (p >= uni32(best)) continue;
+		if (header_ok_wave(s32, (SEG + LOOK + 16) / 4, p, limit, t & 63) && (t & 63) == 0) atomicMin(&best, p);
 	}
 	__syncthreads();
 	if (t == 0) first[seg] = best == 0xffffffffu ? ~0ull : base * 8 + best;
