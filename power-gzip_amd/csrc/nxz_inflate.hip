@@ -984,6 +984,9 @@ __global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__
 		const uint32_t rbase = d0 * 32;
 		uint32_t rend = rbase + SYNC_DW * 32;                  // a token may be looked at while it starts in front of this bit
 		if (rend > rq.limit_bit) rend = rq.limit_bit;
+		// (lanes that have not fallen in step 2048 bits behind the stretch each walked alone will hardly do so: the
+		// request is given up -- walking on to the end of the copy would make this wavefront the one the launch waits for)
+		if (rend > rq.guess_bit + 64 + SYNC_RUN + 2048) rend = rq.guess_bit + 64 + SYNC_RUN + 2048;
 		uint32_t pos = rq.guess_bit + (uint32_t)lane;
 		bool alive = true;
 		auto step = [&]() __attribute__((always_inline)) {
