@@ -52,12 +52,15 @@ typedef struct nxz_sync_req {
 	uint32_t limit_bit;      /* ... and no token looked at reaches this bit (the next block's header) */
 } nxz_sync_req_t;
 typedef struct nxz_sync_res { uint32_t bit; uint32_t lanes; } nxz_sync_res_t;   /* bit 0xffffffff: none found; lanes bit 31: the block's BFINAL */
-int nxz_launch_token_sync(const nxz_sync_req_t *reqs, uint32_t n, nxz_sync_res_t *res, nxz_batch_dht_t *tables, hipStream_t stream);
+size_t nxz_built_tables_bytes(void);
+int nxz_launch_token_sync(const nxz_sync_req_t *breqs, uint32_t nb, nxz_batch_dht_t *tables, void *built,
+			  const nxz_sync_req_t *reqs, uint32_t n, nxz_sync_res_t *res, hipStream_t stream);
 /* runs of stored blocks (nxz_blockfind.hip stored_walk_kernel) */
 typedef struct nxz_walk_req { const uint8_t *src; uint64_t src_len; uint64_t bit; uint32_t rem, bfinal; } nxz_walk_req_t;
 typedef struct nxz_walk_res { uint64_t bit; uint32_t flags, reserved; } nxz_walk_res_t;
 int nxz_launch_stored_walk(const nxz_walk_req_t *reqs, uint32_t n, nxz_walk_res_t *res, hipStream_t stream);
-int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, int few_and_even, hipStream_t stream);
+int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, const void *built,
+			   int few_and_even, hipStream_t stream);
 int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n, uint32_t final_index,
 			   uint64_t *offsets, uint8_t *packed, hipStream_t stream);

@@ -75,6 +75,26 @@ struct SmemT {
 	uint8_t cl[32];
 };
 
+// The decode tables of a dynamic block as they stand in LDS, kept in device memory: built once per block
+// (block_tables_kernel) for everything that starts inside the block -- the requests of token_sync_kernel,
+// the pieces that begin at a cut -- to load instead of reading the header and building them again.
+struct __attribute__((aligned(16))) Built {
+	Huff hl;
+	HuffD hd;
+	uint32_t ok, bfinal, end_bit, pad;         // end_bit: first bit behind the header, counted from the request's src (0: header not in the source)
+};
+static_assert(sizeof(Huff) % 16 == 0 && sizeof(HuffD) % 16 == 0 && sizeof(Built) % 16 == 0, "tables are copied 16 bytes a lane");
+
+template <typename Smem>
+__device__ __forceinline__ void load_built(Smem &sm, const Built *bt, int lane)
+{
+	const uint4 *src = (const uint4 *)bt;
+	uint4 *dl = (uint4 *)&sm.hl, *dd = (uint4 *)&sm.hd;
+	for (uint32_t i = lane; i < sizeof(Huff) / 16; i += 64) dl[i] = src[i];
+	for (uint32_t i = lane; i < sizeof(HuffD) / 16; i += 64) dd[i] = src[sizeof(Huff) / 16 + i];
+	__syncthreads();
+}
+
 __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)
 {
 	uint32_t r = 0;
@@ -358,7 +378,7 @@ __device__ __forceinline__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist
 template <bool GW, bool W16 = false>
 __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__restrict__ jobs,
 						     nxz_batch_result_t *__restrict__ results,
-						     nxz_batch_dht_t *__restrict__ dht_io)
+						     nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
 {
 	__shared__ __attribute__((aligned(16))) SmemT<GW, W16> sm;
 	typedef typename SmemT<GW, W16>::elem_t elem_t;
@@ -524,8 +544,15 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 		else if (kind == 5) { state = 2; btype = 1; }
 		else if (kind == 6) {
 			state = 2; btype = 2;
-			// re-parse the table handed back by the caller
+			// re-parse the table handed back by the caller -- or, a piece of a stream that begins at a cut inside a block
+			// whose tables were built for the whole block (in_crc, which such pieces have no use for: which): load them
 			const nxz_batch_dht_t *t = &dht_io[blockIdx.x];
+			if (W16 && built && job.in_crc) {
+				load_built(sm, &built[job.in_crc - 1], lane);
+				have_dht = true; dhtbits = t->dhtlen;
+				b.stage_base = 0xffffffffu;
+				goto tables_ready;
+			}
 			Bits tb;
 			tb.src = (const NXZ_GLOBAL_AS uint8_t *)t->dht; tb.srclen = (t->dhtlen + 7) / 8; tb.total_bits = t->dhtlen; tb.pos = 0;
 			tb.stage_base = 0xffffffffu; tb.stage = sm.stage; tb.lane = lane;
@@ -538,6 +565,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__re
 			b.stage_base = 0xffffffffu;
 		}
 	}
+tables_ready:
 	if (state == 2 && btype == 1) {
 		for (int i = lane; i < 288; i += 64) sm.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
 		if (lane < 30) sm.lens[288 + lane] = 5;
@@ -917,23 +945,22 @@ done:
 constexpr uint32_t SYNC_DW = 512;                 // dwords of the source a request may walk through
 constexpr uint32_t SYNC_RUN = 1024;               // bits every lane decodes before the lanes are compared
 
-__global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__restrict__ reqs, nxz_sync_res_t *__restrict__ res,
-							 nxz_batch_dht_t *__restrict__ tables)
+// the tables of the blocks that requests or pieces will start in, a wavefront per block.  header_bit 0xffffffff:
+// the block's header is not in the source (the caller holds a part of a stream that begins inside the block);
+// its table is in the request's slot of `tables`, as a suspended job handed it back.  Else the header's table
+// bits go into that slot, for the pieces that start inside the block (jobs that resume in a dynamic block).
+__global__ __launch_bounds__(64) void block_tables_kernel(const nxz_sync_req_t *__restrict__ reqs, nxz_batch_dht_t *__restrict__ tables,
+							   Built *__restrict__ built)
 {
 	__shared__ __attribute__((aligned(16))) SmemT<true> sm;
-	__shared__ uint32_t region[SYNC_DW + 4];
 	const int lane = threadIdx.x;
 	const nxz_sync_req_t rq = reqs[blockIdx.x];
-	nxz_sync_res_t out;
-	out.bit = 0xffffffffu; out.lanes = 0;
 	Bits b;
 	b.src = (const NXZ_GLOBAL_AS uint8_t *)rq.src; b.srclen = rq.srclen; b.total_bits = (uint64_t)rq.srclen * 8; b.pos = rq.header_bit;
 	b.stage_base = 0xffffffffu; b.stage = sm.stage; b.lane = lane;
-	// header_bit 0xffffffff: the block's header is not in the source (the caller holds a part of a stream that begins
-	// inside the block); its table is in the request's slot of `tables`, as a suspended job handed it back
 	const bool given = rq.header_bit == 0xffffffffu;
 	bool ok = given || b.have(17);
-	uint32_t tbits = 0;
+	uint32_t tbits = 0, bfinal = 0;
 	uint64_t tstart = 0;
 	int hlit = 0, hdist = 0;
 	if (given) {
@@ -946,7 +973,7 @@ __global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__
 	} else if (ok) {
 		const uint32_t v = b.peek();
 		ok = (v & 6) == 4;                            // BTYPE 10
-		out.lanes = (v & 1) << 31;                    // (BFINAL goes back in the top bit)
+		bfinal = v & 1;
 		b.pos += 3;
 		tstart = b.pos;
 		if (ok) ok = read_dht(b, sm, hlit, hdist, tbits) == 0;
@@ -956,7 +983,6 @@ __global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__
 		build<DBITS>(sm.hd, sm.lens + hlit, hdist, lane);
 	}
 	if (ok && !given) {
-		// the table's bits, for the piece that will start inside this block (a job that resumes in a dynamic block)
 		nxz_batch_dht_t *t = &tables[blockIdx.x];
 		b.stage_base = 0xffffffffu;
 		b.ensure((uint32_t)(tstart >> 3), 320);
@@ -967,6 +993,37 @@ __global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__
 			((uint32_t *)t->dht)[i] = w;
 		}
 		if (lane == 0) t->dhtlen = tbits;
+	}
+	Built *o = &built[blockIdx.x];
+	if (ok) {
+		__syncthreads();
+		uint4 *dst = (uint4 *)o;
+		const uint4 *sl = (const uint4 *)&sm.hl, *sd = (const uint4 *)&sm.hd;
+		for (uint32_t i = lane; i < sizeof(Huff) / 16; i += 64) dst[i] = sl[i];
+		for (uint32_t i = lane; i < sizeof(HuffD) / 16; i += 64) dst[sizeof(Huff) / 16 + i] = sd[i];
+	}
+	if (lane == 0) { o->ok = ok ? 1 : 0; o->bfinal = bfinal; o->end_bit = given ? 0 : (uint32_t)(tstart + tbits); o->pad = 0; }
+}
+
+// (a request's header_bit names its block's tables: the index into `built`)
+__global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__restrict__ reqs, nxz_sync_res_t *__restrict__ res,
+							 const Built *__restrict__ built)
+{
+	__shared__ __attribute__((aligned(16))) SmemT<true> sm;
+	__shared__ uint32_t region[SYNC_DW + 4];
+	const int lane = threadIdx.x;
+	const nxz_sync_req_t rq = reqs[blockIdx.x];
+	nxz_sync_res_t out;
+	out.bit = 0xffffffffu; out.lanes = 0;
+	const Built *bt = &built[rq.header_bit];
+	bool ok = bt->ok != 0;
+	const uint64_t tstart = 0;
+	const uint32_t tbits = ok ? bt->end_bit : 0;
+	struct { const NXZ_GLOBAL_AS uint8_t *src; } b;
+	b.src = (const NXZ_GLOBAL_AS uint8_t *)rq.src;
+	if (ok) {
+		load_built(sm, bt, lane);
+		out.lanes = bt->bfinal << 31;                 // (BFINAL goes back in the top bit)
 	}
 	ok = ok && rq.guess_bit >= tstart + tbits && rq.limit_bit > rq.guess_bit + 64;
 	if (ok) {
@@ -1031,10 +1088,16 @@ __global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__
 } // namespace nxzi
 
 // requests for token boundaries inside dynamic blocks (see token_sync_kernel); tables[n]: the blocks' tables
-extern "C" int nxz_launch_token_sync(const nxz_sync_req_t *reqs, uint32_t n, nxz_sync_res_t *res, nxz_batch_dht_t *tables, hipStream_t stream)
+extern "C" size_t nxz_built_tables_bytes(void) { return sizeof(nxzi::Built); }
+
+// the tables of nb blocks (breqs: src, srclen, header_bit), then n requests for token boundaries in them (reqs:
+// header_bit = which block of breqs); tables[nb]: the blocks' table bits; built: nb x nxz_built_tables_bytes() of DEVICE memory
+extern "C" int nxz_launch_token_sync(const nxz_sync_req_t *breqs, uint32_t nb, nxz_batch_dht_t *tables, void *built,
+				     const nxz_sync_req_t *reqs, uint32_t n, nxz_sync_res_t *res, hipStream_t stream)
 {
-	if (!n) return 0;
-	hipLaunchKernelGGL(nxzi::token_sync_kernel, dim3(n), dim3(64), 0, stream, reqs, res, tables);
+	if (!n || !nb) return 0;
+	hipLaunchKernelGGL(nxzi::block_tables_kernel, dim3(nb), dim3(64), 0, stream, breqs, tables, (nxzi::Built *)built);
+	hipLaunchKernelGGL(nxzi::token_sync_kernel, dim3(n), dim3(64), 0, stream, reqs, res, (const nxzi::Built *)built);
 	return (int)hipGetLastError();
 }
 
@@ -1050,21 +1113,22 @@ extern "C" int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_bat
 				  nxz_batch_dht_t *dht_io, int window_in_lds, hipStream_t stream)
 {
 	if (!n) return 0;
-	if (window_in_lds) hipLaunchKernelGGL(nxzi::inflate_kernel<false>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
-	else hipLaunchKernelGGL(nxzi::inflate_kernel<true>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
+	if (window_in_lds) hipLaunchKernelGGL(nxzi::inflate_kernel<false>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)nullptr);
+	else hipLaunchKernelGGL(nxzi::inflate_kernel<true>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)nullptr);
 	int rc = (int)hipGetLastError();
 	return rc ? rc : nxz_launch_cksum(jobs, n, results, stream);
 }
 
 // nxz_inflate_stream's pieces: 16-bit elements, references into the unknown 32 KiB in front as 0x8000 | index
-extern "C" int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, int few_and_even, hipStream_t stream)
+extern "C" int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, const void *built,
+				      int few_and_even, hipStream_t stream)
 {
 	if (!n) return 0;
 	// a few pieces of about one size (all of them resident at two per CU): the window in LDS, where a match costs one
 	// wavefront a fraction of the trip to device memory.  (Not for the odd pieces that are decoded again: long
 	// stored stretches are among them, which the other form copies four bytes per lane.)
 	static const unsigned lds_max = getenv("NXZ_INFLATE_W16_LDS_MAX") ? (unsigned)atoi(getenv("NXZ_INFLATE_W16_LDS_MAX")) : 512;
-	if (few_and_even && n <= lds_max) hipLaunchKernelGGL((nxzi::inflate_kernel<false, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
-	else hipLaunchKernelGGL((nxzi::inflate_kernel<true, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io);
+	if (few_and_even && n <= lds_max) hipLaunchKernelGGL((nxzi::inflate_kernel<false, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)built);
+	else hipLaunchKernelGGL((nxzi::inflate_kernel<true, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)built);
 	return (int)hipGetLastError();
 }

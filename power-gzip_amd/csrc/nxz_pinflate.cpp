@@ -88,6 +88,7 @@ struct Workspace {
 	void *dev = nullptr; size_t dev_cap = 0;
 	void *pin = nullptr; size_t pin_cap = 0;
 	hipStream_t own = nullptr;                  // for callers that name no stream
+	void *built = nullptr; size_t built_cap = 0; // the blocks' decode tables (nxz_inflate.hip Built), device memory
 	std::mutex mtx;
 	bool need(size_t d, size_t p)
 	{
@@ -201,57 +202,69 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		// megabyte or two, 8192 for a long stream)
 		static const uint64_t many = getenv("NXZ_PINFLATE_PIECES") ? std::max<uint64_t>(1, (uint64_t)atoll(getenv("NXZ_PINFLATE_PIECES"))) : 8192;   // pieces of a long stream, about
 		const uint64_t sub_bits = std::max<uint64_t>(std::max<uint64_t>(sub_min, 2048), all_bits <= (64u << 20) ? all_bits / 768 : all_bits / many);
-		std::vector<nxz_sync_req_t> rq;
+		std::vector<nxz_sync_req_t> rq, bq;          // requests; the blocks they lie in (bq: src, srclen, header_bit)
 		std::vector<uint64_t> rq_base;
 		// (the first piece begins wherever the caller's part of the stream does: inside a dynamic block that is not
 		// the last -- then the table is the one the last suspension handed back --, or at a header of whatever kind)
 		const bool given0 = st && (st->sfbt & 8) && (st->sfbt & 0xe) != 0xe;
-		size_t ngiven = 0;
+		bool given = false;
 		for (size_t i = 0; i < B.size() && split_max > 1; i++) {
 			const uint64_t end = i + 1 < B.size() ? B[i + 1] : src_len * 8, span = end - B[i];
 			const uint64_t base = (B[i] >> 3) & ~3ull;
 			if (end - base * 8 >= 0xffffffffull) continue;
 			if (i == 0 && given0 && (st->sfbt & 0xe) != 0xc) continue;
 			const uint32_t nsub = (uint32_t)std::min<uint64_t>((uint64_t)split_max, span / sub_bits);
+			if (nsub < 2) continue;
+			nxz_sync_req_t r;
+			r.src = src + base;
+			r.srclen = (uint32_t)std::min<uint64_t>(src_len - base, 0x7fffffffull);
+			r.header_bit = (uint32_t)(B[i] - base * 8);
+			r.guess_bit = 0; r.limit_bit = (uint32_t)(end - base * 8);
+			if (i == 0 && given0) { r.header_bit = 0xffffffffu; given = true; }
+			bq.push_back(r);
 			for (uint32_t k = 1; k < nsub; k++) {
-				nxz_sync_req_t r;
-				r.src = src + base;
-				r.srclen = (uint32_t)std::min<uint64_t>(src_len - base, 0x7fffffffull);
-				r.header_bit = (uint32_t)(B[i] - base * 8);
-				if (i == 0 && given0) { r.header_bit = 0xffffffffu; ngiven++; }
+				r.header_bit = (uint32_t)(bq.size() - 1);         // (which block's tables)
 				r.guess_bit = (uint32_t)(B[i] + span * k / nsub - base * 8);
-				r.limit_bit = (uint32_t)(end - base * 8);
 				rq.push_back(r); rq_base.push_back(base * 8);
 			}
 		}
-		const size_t nr = rq.size();
+		const size_t nr = rq.size(), nb = bq.size();
 		if (nr) {
-			const size_t o_rq = 0, o_rs = up(nr * sizeof(nxz_sync_req_t), 256), o_tb = o_rs + up(nr * sizeof(nxz_sync_res_t), 256),
-				     tot = o_tb + up(nr * sizeof(nxz_batch_dht_t), 256);
+			const size_t o_rq = 0, o_bq = up(nr * sizeof(nxz_sync_req_t), 256), o_rs = o_bq + up(nb * sizeof(nxz_sync_req_t), 256),
+				     o_tb = o_rs + up(nr * sizeof(nxz_sync_res_t), 256), tot = o_tb + up(nb * sizeof(nxz_batch_dht_t), 256);
 			if (!ws.need(tot, tot)) return -ENOMEM;
+			// the blocks' decode tables as they stand in LDS: device memory of their own, they are still wanted when the pieces are decoded
+			const size_t bbytes = nxz_built_tables_bytes() * nb;
+			if (bbytes > ws.built_cap) {
+				if (ws.built) (void)hipFree(ws.built);
+				ws.built = nullptr; ws.built_cap = 0;
+				if (hipMalloc(&ws.built, bbytes + bbytes / 2) != hipSuccess) return -ENOMEM;
+				ws.built_cap = bbytes + bbytes / 2;
+			}
 			uint8_t *Pn = (uint8_t *)ws.pin, *Dv = zc ? Pn : (uint8_t *)ws.dev;
 			memcpy(Pn + o_rq, rq.data(), nr * sizeof(nxz_sync_req_t));
-			if (!zc && hipMemcpyAsync(Dv + o_rq, Pn + o_rq, nr * sizeof(nxz_sync_req_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
-			if (ngiven) {
-				nxz_batch_dht_t *tg = (nxz_batch_dht_t *)(Pn + o_tb);
-				for (size_t k = 0; k < ngiven; k++) {                 // (they are the first requests)
-					memset(&tg[k], 0, sizeof(tg[k]));
-					tg[k].dhtlen = st->dhtlen;
-					memcpy(tg[k].dht, st->dht, NXZ_DHT_MAXSZ);
-				}
-				if (!zc && hipMemcpyAsync(Dv + o_tb, Pn + o_tb, ngiven * sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+			memcpy(Pn + o_bq, bq.data(), nb * sizeof(nxz_sync_req_t));
+			if (!zc && hipMemcpyAsync(Dv + o_rq, Pn + o_rq, o_rs, hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+			if (given) {
+				nxz_batch_dht_t *tg = (nxz_batch_dht_t *)(Pn + o_tb);            // (it is the first block)
+				memset(&tg[0], 0, sizeof(tg[0]));
+				tg[0].dhtlen = st->dhtlen;
+				memcpy(tg[0].dht, st->dht, NXZ_DHT_MAXSZ);
+				if (!zc && hipMemcpyAsync(Dv + o_tb, Pn + o_tb, sizeof(nxz_batch_dht_t), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 			}
-			if (nxz_launch_token_sync((const nxz_sync_req_t *)(Dv + o_rq), (uint32_t)nr, (nxz_sync_res_t *)(Dv + o_rs), (nxz_batch_dht_t *)(Dv + o_tb), s)) return -EIO;
+			if (nxz_launch_token_sync((const nxz_sync_req_t *)(Dv + o_bq), (uint32_t)nb, (nxz_batch_dht_t *)(Dv + o_tb), ws.built,
+						  (const nxz_sync_req_t *)(Dv + o_rq), (uint32_t)nr, (nxz_sync_res_t *)(Dv + o_rs), s)) return -EIO;
 			if (!zc && hipMemcpyAsync(Pn + o_rs, Dv + o_rs, tot - o_rs, hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 			if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
 			const nxz_sync_res_t *rs = (const nxz_sync_res_t *)(Pn + o_rs);
 			const nxz_batch_dht_t *tb = (const nxz_batch_dht_t *)(Pn + o_tb);
+			tabs.assign(tb, tb + nb);                        // (a table per block; a cut's `tab` is its block's)
 			for (size_t k = 0; k < nr; k++) {
 				if (rs[k].bit == 0xffffffffu) continue;
-				subs.push_back(Sub{ rq_base[k] + rs[k].bit, (uint32_t)tabs.size(), k < ngiven ? (st->sfbt & 1u) : rs[k].lanes >> 31 });
-				tabs.push_back(tb[k]);
+				const uint32_t blk = rq[k].header_bit;
+				subs.push_back(Sub{ rq_base[k] + rs[k].bit, blk, blk == 0 && given ? (st->sfbt & 1u) : rs[k].lanes >> 31 });
 			}
-			if (trace) fprintf(stderr, "nxz_inflate_stream: %zu blocks, %zu token boundaries asked for, %zu found\n", B.size(), nr, subs.size());
+			if (trace) fprintf(stderr, "nxz_inflate_stream: %zu blocks, %zu token boundaries asked for in %zu of them, %zu found\n", B.size(), nr, nb, subs.size());
 			lap("token boundaries");
 		}
 	}
@@ -357,6 +370,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			if (p.tab >= 0) j.resume = ((0xcu | p.cfin) << 16) | ((sub ? 8 - sub : 0) << 20);      // inside a dynamic block
 			if (p.srem) j.resume = p.srem | ((0x8u | p.sfin) << 16);                     // inside a stored block (on a byte boundary)
 			j.in_adler = (uint32_t)p.stop;
+			j.in_crc = p.tab >= 0 ? (uint32_t)p.tab + 1 : 0;                             // (which block's ready-made tables)
 			who.push_back(i);
 		}
 		if (!win0_made) {
@@ -386,7 +400,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		}
 		if (nxz_launch_copy_items(d_items, (uint32_t)ni, s)) return -EIO;
 		lap("staging");
-		if (nxz_launch_inflate_w16(d_jobs, nj, d_res, d_dht, attempt == 0, s)) return -EIO;
+		if (nxz_launch_inflate_w16(d_jobs, nj, d_res, d_dht, tabs.empty() ? nullptr : ws.built, attempt == 0, s)) return -EIO;
 		lap("decode");
 		if (!zc && hipMemcpyAsync(h_res, d_res, nj * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 		const bool last_ran = st && nj && who[nj - 1] == pc.size() - 1;
