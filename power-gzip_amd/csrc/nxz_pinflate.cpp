@@ -1,13 +1,17 @@
-// nxz_pinflate.cpp -- one long deflate stream decoded in parallel: block-boundary speculation.
+// nxz_pinflate.cpp -- one deflate stream, or the part of one a caller of inflate() holds, decoded in parallel:
+// block-boundary speculation, and cuts at token boundaries inside the blocks.
 //
 // The reference inflates a stream job after job (/root/reference lib/nx_inflate.c:1060-1762:
 // every job resumes where the last one stopped, with the last 32 KiB of output as its history),
 // which is fast on an engine that is fast on ONE stream (7.16 GB/s for silesia.tar on POWER9,
 // samples/simpleapi/README:27-30).  A wavefront decodes one stream at 15-18 MB/s; the GPU is fast
 // on MANY streams.  So the stream is cut where deflate blocks start (nxz_blockfind.hip finds
-// the headers of dynamic blocks by trying every bit position), and the pieces -- about one deflate
-// block each -- are decoded side by side with the engine's ordinary batched decompress jobs
-// (DECOMPRESS_RESUME: source bit offset in in_subc, 32 KiB history in front of the source).
+// the headers of dynamic blocks by trying every bit position) and, inside the blocks, at token
+// boundaries (nxz_inflate.hip token_sync_kernel: 64 lanes decode token lengths from neighbouring bits
+// until they fall in step), and the pieces -- a block, or a few KiB of one -- are decoded side by side
+// with the engine's ordinary decompress jobs (DECOMPRESS_RESUME: source bit offset in in_subc; a
+// piece at a cut resumes inside a dynamic block with the block's table, one behind a run of stored
+// blocks inside a stored block -- the resume states the reference's engine defines).
 // What a piece does not know is its history: the 32 KiB of output in front of it.  But which
 // history byte an output byte is a copy of (directly or through copies of copies) does not depend
 // on what the history holds.  So a piece is decoded into 16-bit elements (nxz_inflate.hip, W16): the
@@ -18,6 +22,8 @@
 //   - one workgroup walks the pieces in order and makes the true 32 KiB window behind each
 //     (32 KiB of look-ups per piece);
 //   - all pieces are resolved into place at once: final byte = the element, or window[k].
+// A part of a stream (nxz_inflate_stream_part) is the same with a resume state in and out: the first piece
+// begins wherever the last call stopped, the last one runs out of source like any suspended job.
 // The CRC-32 / Adler-32 of the output are computed over 256 KiB slices and combined (zlib's
 // crc32_combine idea); the caller checks them against the trailer as for any stream.
 #include <hip/hip_runtime.h>
