@@ -33,6 +33,11 @@ DHT_DTYPE = np.dtype([("dhtlen", "<u4"), ("dht", "u1", (292,))])
 assert JOB_DTYPE.itemsize == 48 and RESULT_DTYPE.itemsize == 32 and DHT_DTYPE.itemsize == 296
 
 
+class StreamResume(C.Structure):
+    """nxz_stream_resume_t (include/nxz_engine.h): where a deflate stream stands between two calls"""
+    _fields_ = [("sfbt", C.c_uint32), ("rem", C.c_uint32), ("dhtlen", C.c_uint32), ("final", C.c_uint32), ("dht", C.c_uint8 * 288)]
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -70,6 +75,9 @@ def load_library():
         L.nxz_inflate_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p]
+        L.nxz_inflate_stream_part.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
+                                              C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                              C.POINTER(StreamResume), C.POINTER(C.c_uint32), C.c_void_p]
         L.nxz_deflate_host_bound.restype = C.c_size_t
         L.nxz_deflate_host_bound.argtypes = [C.c_size_t]
         L.nxz_deflate_host.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
@@ -179,6 +187,20 @@ class Engine:
                                        C.byref(end_bit), C.byref(pieces), C.byref(rounds), self.stream_handle())
         return rc, {"out_len": out_len.value, "crc": crc.value, "adler": adler.value, "end_bit": end_bit.value,
                     "pieces": pieces.value, "rounds": rounds.value}
+
+    def inflate_stream_part(self, src, src_len, dst, state=None, first_bit=0, hist=None):
+        """a PART of a raw-deflate stream (uint8 device tensor) -> dst, nxz_inflate_stream_part.  `state`: None at a
+        block header / the stream's start, else the StreamResume a previous call returned.  Returns (rc, dict);
+        dict["state"] is where the stream stands at dict["end_bit"] (state.final: the final block ended there)."""
+        st = state if state is not None else StreamResume()
+        out_len, end_bit = C.c_uint64(), C.c_uint64()
+        crc, adler, pieces = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rc = self.L.nxz_inflate_stream_part(self.ctx, src.data_ptr(), src_len, first_bit,
+                                            hist.data_ptr() if hist is not None else None, hist.numel() if hist is not None else 0,
+                                            dst.data_ptr(), dst.numel(), C.byref(out_len), C.byref(crc), C.byref(adler),
+                                            C.byref(end_bit), C.byref(st), C.byref(pieces), self.stream_handle())
+        return rc, {"out_len": out_len.value, "crc": crc.value, "adler": adler.value, "end_bit": end_bit.value,
+                    "pieces": pieces.value, "state": st}
 
     def deflate_host(self, data, fc=FC_COMPRESS_DHTGEN, final=True, cap=None):
         """a HOST buffer (bytes) -> one raw deflate stream (bytes), nxz_deflate_host.  Returns (rc, stream, crc, adler)."""

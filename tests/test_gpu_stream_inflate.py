@@ -227,3 +227,42 @@ def test_streams_made_by_this_engine_are_cut_at_every_block(eng, data):
     assert info["out_len"] == len(plain) and info["crc"] == crc == zlib.crc32(plain)
     assert dst[:len(plain)].cpu().numpy().tobytes() == plain
     assert info["pieces"] >= len(plain) // 65536          # a piece per 64 KiB block at least (cuts inside the blocks come on top)
+
+
+def test_the_part_interface_walks_a_stream_on_the_device(eng, data):
+    """nxz_inflate_stream_part itself (include/nxz_engine.h), device buffers only: a stream is fed in parts of
+    odd sizes; each call gets the state the last one returned (inside a block, as a rule), the last 32 KiB of
+    output as history and the byte the last part stopped in as its first; CRCs combine to the stream's"""
+    import torch
+    plain = data[2 << 20:11 << 20]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(plain) + c.flush()
+    L = Z.load("gpu")
+    got = bytearray()
+    crc = 0
+    pos, first_bit, state = 0, 0, None
+    hist = None
+    sizes = [300000, 70000, 1 << 20, 15000, 555555]
+    k = 0
+    while True:
+        n = min(sizes[k % len(sizes)], len(comp) - pos); k += 1
+        src = torch.from_numpy(np.frombuffer(comp[pos:pos + n], np.uint8).copy()).to(eng.dev)
+        dst = torch.zeros(n * 12 + (1 << 20), dtype=torch.uint8, device=eng.dev)
+        rc, info = eng.inflate_stream_part(src, n, dst, state=state, first_bit=first_bit, hist=hist)
+        torch.cuda.synchronize()
+        assert rc == 0, (rc, pos, n, info)
+        out = dst[:info["out_len"]].cpu().numpy().tobytes()
+        assert info["crc"] == zlib.crc32(out)
+        crc = L.nx_crc32_combine(crc, info["crc"], len(out))
+        got += out
+        state = info["state"]
+        if state.final:
+            assert pos + (info["end_bit"] + 7) // 8 == len(comp)
+            break
+        assert info["end_bit"] > first_bit
+        pos += info["end_bit"] >> 3                       # whole bytes used; the byte it stopped in comes again
+        first_bit = info["end_bit"] & 7
+        tail = bytes(got[-32768:])
+        hist = torch.from_numpy(np.frombuffer(tail, np.uint8).copy()).to(eng.dev)
+        assert pos < len(comp)
+    assert bytes(got) == plain and crc == zlib.crc32(plain)
