@@ -334,21 +334,36 @@ __device__ __forceinline__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist
 	}
 	int n = 0, prev = 0;
 	const int total = hlit + hdist;
+	// (the bits at pos in a scalar window, refilled from the lanes' registers every few symbols: a symbol takes 14
+	// bits at most -- two trips through v_readlane per symbol would otherwise be the better part of the loop)
+	uint64_t win = 0;
+	uint32_t wbits = 0;
+	auto word = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)R0, (int)(i & 63)), hi = (uint32_t)__builtin_amdgcn_readlane((int)R1, (int)(i & 63));
+		return i < 64 ? lo : hi;
+	};
 	while (n < total) {
 		if (pos + 1 > b.total_bits) return 1;
-		const uint32_t bits = peek(pos);
+		if (wbits < 14) {
+			const uint32_t o = uni((uint32_t)(pos - (uint64_t)d0 * 32)), i = o >> 5, sh = o & 31;
+			win = (((uint64_t)word(i + 1) << 32) | word(i)) >> sh;
+			wbits = 64 - sh;
+		}
+		const uint32_t bits = (uint32_t)win;
 		const uint32_t k = bits & 127;
 		const uint32_t e = k < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)tlo, (int)k) : (uint32_t)__builtin_amdgcn_readlane((int)thi, (int)(k - 64));
 		if (e == 0xff) return pos + 7 <= b.total_bits ? -3 : 1;
 		const int sym = (int)(e & 31), len = (int)(e >> 5);
 		if (pos + (uint32_t)len > b.total_bits) return 1;
 		pos += (uint32_t)len;
+		win >>= len; wbits -= (uint32_t)len;
 		if (sym < 16) { if (lane == 0) sm.lens[n] = (uint8_t)sym; n++; prev = sym; }
 		else {
 			const int eb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
 			if (pos + (uint32_t)eb > b.total_bits) return 1;
 			const int rep = (int)((bits >> len) & ((1u << eb) - 1)) + (sym == 18 ? 11 : 3);
 			pos += (uint32_t)eb;
+			win >>= eb; wbits -= (uint32_t)eb;
 			int val = 0;
 			if (sym == 16) { if (n == 0) return -4; val = prev; }
 			if (n + rep > total) return -5;
@@ -375,10 +390,10 @@ __device__ __forceinline__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist
 // The target holds 16-bit elements (job.dst_cap counts elements): a byte, or 0x8000 | k for "byte k
 // of the 32 KiB that precede this output", which is what a match that reaches back before the output
 // copies; matches copy elements, so such references travel.  No history bytes are read, no checksums.
-template <bool GW, bool W16 = false>
-__global__ __launch_bounds__(64) void inflate_kernel(const nxz_batch_job_t *__restrict__ jobs,
-						     nxz_batch_result_t *__restrict__ results,
-						     nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
+template <bool GW, bool W16>
+__device__ __forceinline__ void inflate_body(const nxz_batch_job_t *__restrict__ jobs,
+					     nxz_batch_result_t *__restrict__ results,
+					     nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
 {
 	__shared__ __attribute__((aligned(16))) SmemT<GW, W16> sm;
 	typedef typename SmemT<GW, W16>::elem_t elem_t;
@@ -925,6 +940,39 @@ done:
 		r.subc = subc; r.sfbt = o_sfbt | (final_eob ? 0x100u : 0) | (((o_sfbt & 0xe) == 0xc && have_dht) ? (dhtbits << 16) : 0);
 		results[blockIdx.x] = r;
 	}
+}
+
+// The kernels.  With the target as window (GW) a stream needs 6.6 KiB of LDS and what bounds the number of
+// wavefronts per SIMD is registers: five at 96 VGPRs, four at 97 -- and the fifth is worth a tenth of the
+// throughput of a full batch (51.8 against 46.7 GiB/s at 65 536 zlib -6 streams).  The compiler is told so; left to
+// itself it takes 95 to 104 registers from one edit of this file to the next.  With the window in LDS only
+// one or two streams fit a CU anyway.
+template <bool GW, bool W16 = false>
+__global__ void inflate_kernel(const nxz_batch_job_t *__restrict__ jobs, nxz_batch_result_t *__restrict__ results,
+			       nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built);
+template <>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void inflate_kernel<true, false>(const nxz_batch_job_t *__restrict__ jobs,
+		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
+{
+	inflate_body<true, false>(jobs, results, dht_io, built);
+}
+template <>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void inflate_kernel<true, true>(const nxz_batch_job_t *__restrict__ jobs,
+		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
+{
+	inflate_body<true, true>(jobs, results, dht_io, built);
+}
+template <>
+__global__ __launch_bounds__(64) void inflate_kernel<false, false>(const nxz_batch_job_t *__restrict__ jobs,
+		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
+{
+	inflate_body<false, false>(jobs, results, dht_io, built);
+}
+template <>
+__global__ __launch_bounds__(64) void inflate_kernel<false, true>(const nxz_batch_job_t *__restrict__ jobs,
+		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
+{
+	inflate_body<false, true>(jobs, results, dht_io, built);
 }
 
 // ---- token boundaries inside a dynamic block (nxz_inflate_stream, few pieces) ----
