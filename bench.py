@@ -67,55 +67,99 @@ def reduce_totals(torch, dist, dev, u_bytes, c_bytes, wall, distributed):
     return float(tot[0].item()), float(tot[1].item()), float(tmax.item())
 
 
-def gen_blocks(torch, dev, n, first_index, chunk=4096):
-    """Seeded synthetic 64 KiB blocks, generated on the device.
+GOLD = 0x9E3779B97F4A7C15
+ALPHABET33 = b"abcdefghijklmnopqrstuvwxyz .,;!?\n"
 
-    Recipe (after the reference's generators): first half of every block =
-    uniform text over a 33-symbol alphabet (test/test_utils.c:22-28); second half = LZ copies
-    (samples/makedata.c:51-68): runs (mean length 96) copied from the first half at a per-run
-    distance of 300..32768 bytes.  Chunk c of 4096 blocks uses seed 0x9E3779B97F4A7C15 ^ index.
+
+def _i64(x):
+    """a 64-bit pattern as the signed value torch's int64 holds"""
+    x &= 0xFFFFFFFFFFFFFFFF
+    return x - (1 << 64) if x >> 63 else x
+
+
+def _mix(torch, x):
+    """splitmix64's finaliser on int64 tensors (wrapping multiplies, logical shifts): a counter-based
+    generator, so that block i depends on nothing but its own seed GOLD ^ i"""
+    x = (x ^ ((x >> 30) & 0x3FFFFFFFF)) * _i64(0xBF58476D1CE4E5B9)
+    x = (x ^ ((x >> 27) & 0x1FFFFFFFFF)) * _i64(0x94D049BB133111EB)
+    return x ^ ((x >> 31) & 0x1FFFFFFFF)
+
+
+def _rand31(torch, seed, counter):
+    """31 random bits per element: hash of (block seed, counter)"""
+    step = _i64(counter * GOLD) if isinstance(counter, int) else counter * _i64(GOLD)
+    return (_mix(torch, seed + step) >> 33) & 0x7FFFFFFF
+
+
+def block_seeds(torch, dev, n, first_index):
+    idx = torch.arange(first_index, first_index + n, device=dev, dtype=torch.int64)
+    return _mix(torch, idx ^ _i64(GOLD)).unsqueeze(1)              # (n, 1): seed 0x9E3779B97F4A7C15 ^ i, whitened
+
+
+def gen_text(torch, dev, n, first_index, length=BLOCK):
+    """uniform text over a 33-symbol alphabet (test/test_utils.c:22-28,152-161), block i from its own seed"""
+    alphabet = torch.tensor(list(ALPHABET33), dtype=torch.uint8, device=dev)
+    seed = block_seeds(torch, dev, n, first_index)
+    j = torch.arange(length, device=dev, dtype=torch.int64).unsqueeze(0)
+    return alphabet[_rand31(torch, seed, j) % 33]
+
+
+def gen_blocks(torch, dev, n, first_index, chunk=1024):
+    """Seeded synthetic 64 KiB blocks, generated on the device (SURVEY.md 8(d) C2).
+
+    Block i (global index) uses the seed 0x9E3779B97F4A7C15 ^ i and nothing else.  Recipe = the
+    reference's own generators: the first half of the block is uniform text over a 33-symbol
+    alphabet (test/test_utils.c:22-28,152-161); the rest is filled the way samples/makedata.c:51-68
+    does it: per block len_max in [10, 249] and dist_max in [1, 65536], then copy after copy of
+    len in [16, len_max + 15] bytes from dist in [1, min(dist_max, bytes so far)] bytes back, byte
+    by byte (a copy may overlap itself and may read earlier copies).  On the device a copy is a
+    source index per byte, and copies of copies are resolved by pointer doubling.
     """
     out = torch.empty((n, BLOCK), dtype=torch.uint8, device=dev)
-    alphabet = torch.tensor(list(b"abcdefghijklmnopqrstuvwxyz .,;!?\n"), dtype=torch.uint8, device=dev)
     half = BLOCK // 2
-    pos = torch.arange(half, device=dev, dtype=torch.int32).unsqueeze(0)
+    K = half // 16                                                   # copies are >= 16 bytes long
+    pos = torch.arange(BLOCK, device=dev, dtype=torch.int64).unsqueeze(0)
+    k = torch.arange(K, device=dev, dtype=torch.int64).unsqueeze(0)
     for c0 in range(0, n, chunk):
         m = min(chunk, n - c0)
-        g = torch.Generator(device=dev)
-        g.manual_seed((0x9E3779B97F4A7C15 ^ (first_index + c0)) & 0x7FFFFFFFFFFFFFFF)
-        text = alphabet[torch.randint(0, 33, (m, half), device=dev, generator=g)]
-        boundary = torch.rand((m, half), device=dev, generator=g) < (1.0 / 96)
-        boundary[:, 0] = True
-        runstart = torch.cummax(torch.where(boundary, pos, torch.zeros_like(pos)), dim=1).values
-        runid = torch.cumsum(boundary.to(torch.int32), dim=1).clamp_(max=1023).to(torch.int64)
-        frac = torch.gather(torch.rand((m, 1024), device=dev, generator=g), 1, runid)
-        off = (frac * (half - 300 - runstart).clamp_(min=0).to(torch.float32)).to(torch.int32)
-        src_idx = (pos + off).clamp_(max=half - 1).to(torch.int64)     # distance = half - off in [300, 32768]
-        out[c0:c0 + m, :half] = text
-        out[c0:c0 + m, half:] = torch.gather(text, 1, src_idx)
-        del text, boundary, runstart, runid, frac, off, src_idx
+        seed = block_seeds(torch, dev, m, first_index + c0)
+        text = gen_text(torch, dev, m, first_index + c0, half)
+        len_max = 10 + _rand31(torch, seed, 1 << 20) % 240           # (m, 1)
+        dist_max = 1 + _rand31(torch, seed, (1 << 20) + 1) % 65536
+        ln = 16 + _rand31(torch, seed, (2 << 20) + k) % len_max      # (m, K)
+        start = half + torch.cumsum(ln, dim=1) - ln                  # where copy k begins
+        dist = 1 + _rand31(torch, seed, (3 << 20) + k) % torch.minimum(dist_max, start)
+        # the copy a position belongs to: count the copies that begin at or before it
+        mark = torch.zeros((m, BLOCK + 1), dtype=torch.int32, device=dev)
+        mark.scatter_(1, start.clamp(max=BLOCK), 1)
+        run = (torch.cumsum(mark[:, :BLOCK], dim=1) - 1).clamp_(min=0).to(torch.int64)
+        s = pos - torch.gather(dist, 1, run)                         # source index of every byte ...
+        s = torch.where(pos < half, pos, s)                          # ... the text stands for itself
+        del mark, run, ln, start, dist
+        for _ in range(15):                                          # 2^15 hops: as deep as a chain of copies gets
+            s = torch.gather(s, 1, s)
+        out[c0:c0 + m] = torch.gather(text, 1, s)
+        del text, s
     return out
 
 
 def gen_mixed(torch, dev, n, first_index):
-    """config c5: block i (global index) is zeros / 33-symbol text / text + LZ copies / random bytes
-    by i mod 4."""
+    """config c5: block i (global index) is zeros / 33-symbol text / text + makedata copies / random
+    bytes by i mod 4, each from its own seed."""
     out = gen_blocks(torch, dev, n, first_index)
     idx = torch.arange(first_index, first_index + n, device=dev)
     kind = idx % 4
     out[kind == 0] = 0
-    g = torch.Generator(device=dev)
-    g.manual_seed(0x5EED ^ first_index)
-    alphabet = torch.tensor(list(b"abcdefghijklmnopqrstuvwxyz .,;!?\n"), dtype=torch.uint8, device=dev)
-    for c0 in range(0, n, 8192):
-        m = min(8192, n - c0)
+    j = torch.arange(BLOCK, device=dev, dtype=torch.int64).unsqueeze(0)
+    for c0 in range(0, n, 2048):
+        m = min(2048, n - c0)
         k = kind[c0:c0 + m]
         sub = out[c0:c0 + m]
-        n1, n3 = int((k == 1).sum()), int((k == 3).sum())
-        if n1:
-            sub[k == 1] = alphabet[torch.randint(0, 33, (n1, BLOCK), device=dev, generator=g)]
-        if n3:
-            sub[k == 3] = torch.randint(0, 256, (n3, BLOCK), device=dev, dtype=torch.uint8, generator=g)
+        if bool((k == 1).any()):
+            sub[k == 1] = gen_text(torch, dev, m, first_index + c0)[k == 1]
+        if bool((k == 3).any()):
+            seed = block_seeds(torch, dev, m, first_index + c0)[k == 3]
+            sub[k == 3] = ((_rand31(torch, seed, (5 << 20) + j) >> 7) & 0xFF).to(torch.uint8)
     return out
 
 

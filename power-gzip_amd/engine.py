@@ -43,7 +43,8 @@ class EngineError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "libnxz_engine.so")
+    # NXZ_ENGINE_LIB: another build of the engine in this directory (A/B runs of kernel variants, tools/)
+    return os.path.join(HERE, os.environ.get("NXZ_ENGINE_LIB", "libnxz_engine.so"))
 
 
 _lib = None

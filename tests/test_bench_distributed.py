@@ -48,12 +48,52 @@ def test_two_rank_sharding_and_reduction():
     assert s0 != s1                                                  # different shards -> different data
 
 
-def test_generator_is_deterministic_per_block_index():
+def _mix_py(x):
+    M = (1 << 64) - 1
+    x &= M
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+    return x ^ (x >> 31)
+
+
+def _makedata_block(i):
+    """block i of bench.gen_blocks, byte by byte the way /root/reference samples/makedata.c:51-68 fills its
+    buffer: per-block seed 0x9E3779B97F4A7C15 ^ i, 33-symbol text in the first half,
+    then copies of len in [16, len_max + 15] from dist in [1, min(dist_max, idx)] back"""
     import bench
-    a = bench.gen_blocks(torch, torch.device("cpu"), 4, 8, chunk=4)
-    b = bench.gen_blocks(torch, torch.device("cpu"), 4, 8, chunk=4)
-    assert torch.equal(a, b)
-    # makedata-style: second half copies from the first half -> compressible
+    G, M = bench.GOLD, (1 << 64) - 1
+    seed = _mix_py(i ^ G)
+
+    def r31(counter):
+        return _mix_py((seed + counter * G) & M) >> 33
+    half = 32768
+    buf = bytearray(bench.ALPHABET33[r31(j) % 33] for j in range(half))
+    len_max = 10 + r31(1 << 20) % 240
+    dist_max = 1 + r31((1 << 20) + 1) % 65536
+    k = 0
+    while len(buf) < 65536:
+        ln = 16 + r31((2 << 20) + k) % len_max
+        dist = 1 + r31((3 << 20) + k) % min(dist_max, len(buf))
+        k += 1
+        for _ in range(ln):
+            if len(buf) < 65536:
+                buf.append(buf[-dist])
+    return bytes(buf), len_max, dist_max
+
+
+def test_generator_is_the_makedata_recipe_per_block_index():
+    import bench
+    a = bench.gen_blocks(torch, torch.device("cpu"), 6, 8, chunk=4)
+    b = bench.gen_blocks(torch, torch.device("cpu"), 3, 10, chunk=2)
+    assert torch.equal(a[2:5], b)                                    # block i depends on i alone, not on the batch it is made in
+    params = set()
+    for j in range(6):
+        exp, len_max, dist_max = _makedata_block(8 + j)
+        assert a[j].numpy().tobytes() == exp, j
+        assert 10 <= len_max <= 249 and 1 <= dist_max <= 65536
+        params.add((len_max, dist_max))
+    assert len(params) == 6                                          # every block draws its own len_max / dist_max
+    # second half copies from what is in front of it -> compressible
     import zlib
     blk = a[1].numpy().tobytes()
     assert len(zlib.compress(blk, 1)) < 0.7 * len(blk)
