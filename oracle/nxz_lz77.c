@@ -41,11 +41,24 @@
  *     load32(p-1) == load32(p) (byte runs); the longer wins, ties go to the
  *     smaller distance.  (Single entry per bucket: 0.911 x zlib -1 on
  *     repetitive tables, 0.945 x Z_FIXED on the bench blocks; two: 0.99 / 0.98.)
- *  5. Parsing is greedy inside segments of PSEG bytes (relative to the
- *     sub-block start): a match is truncated at the segment end and dropped
- *     if fewer than 3 bytes remain.  One-step lazy evaluation: a match of
- *     length L < LAZY_MAX at p is replaced by a literal when position p+1
- *     has a match longer than L.
+ *  5. Parsing, per tile of PTILE positions, in two passes over segments of
+ *     PSEG positions.  Pass 1: every segment is walked greedily from its own
+ *     start until the walk leaves the segment (one-step lazy evaluation: a
+ *     match of length L < LAZY_MAX at p is replaced by a literal when
+ *     position p+1 has a match longer than L; matches are truncated at the
+ *     tile's end and dropped if fewer than 3 bytes remain); X[s] is where
+ *     it leaves.  Pass 2: the chain of ENTERED segments -- the one that holds
+ *     the tile's first position, then the one that holds X of the one before
+ *     -- is walked for real from its entry: step by step with matches
+ *     truncated at X[s] until the walk stands on a position that pass 1's
+ *     walk of this segment visited; from there on it IS pass 1's walk (its
+ *     tokens are taken as they are, they end at X[s]).  A walk that has
+ *     stepped over the start of pass 1's last match without visiting it
+ *     stands inside that match: what is left of it -- same distance, up to
+ *     X[s] -- is the last token (literals if fewer than 3 bytes are left).
+ *     So every step of pass 2 is taken inside the segment: a lane of the
+ *     kernel walks on the 16 lengths it holds in registers, keeps pass 1's
+ *     visits in a mask, and most segments cost no second walk at all.
  */
 #include <string.h>
 #include "nxz_oracle.h"
@@ -97,10 +110,15 @@ static inline uint32_t match_len(const uint8_t *a, const uint8_t *b, uint32_t ma
  * (dropped if fewer than 3 bytes remain).  Returns the exit position.  With
  * tok != NULL the tokens are appended at tok[*ntok]. */
 static uint32_t walk(const uint8_t *w, uint32_t h, const uint16_t *mlen, const uint16_t *mdist,
-		     uint32_t p, uint32_t stop, uint32_t limit, uint32_t *tok, size_t *ntok)
+		     uint32_t p, uint32_t stop, uint32_t limit, uint32_t *tok, size_t *ntok, uint32_t *visited, uint32_t vbase,
+		     uint32_t *last_match)
 {
 	while (p < stop) {
 		uint32_t len = mlen[p];
+		if (visited)
+			*visited |= 1u << (p - vbase);      /* a token starts here (stop - vbase <= 32) */
+		if (last_match)
+			*last_match = 0xffffffffu;          /* start of the walk's last token if that is a match */
 		if (len > limit - p)
 			len = limit - p;
 		if (len >= MINMATCH - 1 && mlen[p] >= MINMATCH) {
@@ -117,6 +135,7 @@ static uint32_t walk(const uint8_t *w, uint32_t h, const uint16_t *mlen, const u
 			}
 #endif
 			if (tok) tok[(*ntok)++] = NXO_TOK_MATCH | ((uint32_t)mdist[p] << 8) | (len - 3);
+			if (last_match) *last_match = p;
 			p += len;
 		} else {
 			if (tok) tok[(*ntok)++] = w[h + p];
@@ -238,22 +257,43 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 	for (c = 0; c < n; c += NXO_PTILE) {
 		uint32_t tend = c + NXO_PTILE < n ? c + NXO_PTILE : n;
 		uint32_t nseg = (tend - c + NXO_PSEG - 1) / NXO_PSEG, s;
-		static __thread uint32_t X[NXO_PTILE / NXO_PSEG];
+		static __thread uint32_t X[NXO_PTILE / NXO_PSEG], V[NXO_PTILE / NXO_PSEG], A[NXO_PTILE / NXO_PSEG];
 		uint32_t entry = c;
 		/* pass 1: speculative walk of every segment from its own start; X = exit */
 		for (s = 0; s < nseg; s++) {
 			uint32_t sb = c + s * NXO_PSEG;
 			uint32_t se = sb + NXO_PSEG < tend ? sb + NXO_PSEG : tend;
-			X[s] = walk(w, h, mlen, mdist, sb, se, tend, NULL, NULL);
+			V[s] = 0;
+			X[s] = walk(w, h, mlen, mdist, sb, se, tend, NULL, NULL, &V[s], sb, &A[s]);
 		}
 		if (nxo_dbg_x) for (s = 0; s < nseg; s++) nxo_dbg_x[c / NXO_PSEG + s] = X[s];
-		/* chain of entered segments: the segment containing `entry` is walked
-		 * for real from `entry` up to its own speculative exit (matches are
-		 * truncated there), which is the entry of the next entered segment */
+		/* chain of entered segments: the segment containing `entry` is walked for real from `entry`:
+		 * step by step (matches truncated at the segment's speculative exit) until it stands on a
+		 * position the speculative walk visited, then along that walk to its exit, which is the entry of
+		 * the next entered segment */
 		while (entry < tend) {
 			size_t k = ntok;
+			uint32_t sb, se, p = entry;
 			s = (entry - c) / NXO_PSEG;
-			walk(w, h, mlen, mdist, entry, X[s], X[s], tok, &k);
+			sb = c + s * NXO_PSEG;
+			se = sb + NXO_PSEG < tend ? sb + NXO_PSEG : tend;
+			while (p < X[s]) {
+				if (p < se && ((V[s] >> (p - sb)) & 1)) {
+					p = walk(w, h, mlen, mdist, p, se, tend, tok, &k, NULL, 0, NULL);
+					break;
+				}
+				if (A[s] != 0xffffffffu && p > A[s]) {
+					/* inside the speculative walk's last match: the rest of it */
+					if (X[s] - p >= 3)
+						tok[k++] = NXO_TOK_MATCH | ((uint32_t)mdist[A[s]] << 8) | (X[s] - p - 3);
+					else
+						while (p < X[s])
+							tok[k++] = w[h + p++];
+					p = X[s];
+					break;
+				}
+				p = walk(w, h, mlen, mdist, p, p + 1, X[s], tok, &k, NULL, 0, NULL);
+			}
 			ntok = (uint32_t)k;
 			entry = X[s];
 		}

@@ -182,40 +182,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 	return v;
 }
 
-struct Walk {
-	const uint32_t *inw;
-	uint8_t *mlen;
-	const uint16_t *cand;
-	uint32_t h, tile_base, end;   // window bytes, tile start (block relative), sub-block end (window relative)
-
-	// match length at tile position p (stored value is len-3, 0 = none; exact after run extension)
-	__device__ __forceinline__ uint32_t full_len(uint32_t p) const
-	{
-		uint32_t m = mlen[p];
-		return m ? m + 3 : 0;
-	}
-};
-
-// One greedy/lazy step at tile position p (oracle/nxz_lz77.c walk()).  Returns
-// the token length (1 = literal) and whether it is a match.
-__device__ __forceinline__ uint32_t walk_step(const Walk &w, uint32_t p, uint32_t limit, bool &is_match)
-{
-	uint32_t full = w.full_len(p);
-	uint32_t len = full < limit - p ? full : limit - p;
-	is_match = false;
-	if (full >= 4 && len >= 3) {
-		if (len < LAZY_MAX && p + 1 < limit) {
-			uint32_t m2 = w.mlen[p + 1];
-			uint32_t l2 = m2 ? m2 + 3 : 0;
-			if (l2 > limit - p - 1) l2 = limit - p - 1;
-			if (l2 > len) return 1;
-		}
-		is_match = true;
-		return len;
-	}
-	return 1;
-}
-
 template <bool COUNT>
 __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restrict__ jobs,
 						  uint8_t *__restrict__ tokens, uint16_t *__restrict__ cand2,
@@ -429,14 +395,12 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	NXZ_GLOBAL uint16_t *g_c2 = (NXZ_GLOBAL uint16_t *)cand2 + (size_t)blockIdx.x * C2_STRIDE;   // the second bucket entries of the tile in work
 	__syncthreads();
 
-	Walk W{inw, mlen, cand, h, 0, end};
 	PROF(2);
 
 	// ================= tiles =================
 	for (uint32_t tb0 = 0; tb0 < n; tb0 += PTILE) {
 		const uint32_t tn = n - tb0 < PTILE ? n - tb0 : PTILE;       // positions in this tile
 		const uint32_t nseg = (tn + PSEG - 1) / PSEG;
-		W.tile_base = tb0;
 
 		// ---- hash ----
 		// cand[i] = byte offset of the position's head[] slot (dummy slot for positions without a
@@ -935,34 +899,37 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		const uint32_t p0 = (uint32_t)t * PSEG;
 		if (p0 < tn) {
 			// members of my 16 positions, last to first: N = (end of the chain) - position; the chain
-			// ends at the first non-member behind it, whose length is final (M1, M2 or the link pass)
+			// ends at the first non-member behind it, whose length is final (M1, M2 or the link pass).
+			// Straight-line code over the 16 positions (their stored lengths in four registers, one 16-byte
+			// read and one 16-byte write): a loop over the members alone ran as long as the lane with the
+			// most members in every wave.
 			const uint32_t kb16 = ((const uint16_t *)kb)[t];
-			uint32_t kbits = kb16 & ((const uint16_t *)vb)[t], e_cur = 0, T_prev = 0xffffffffu, T_ext = 0xffffffffu;
-			// more than 258 + 16 positions away is as good as infinitely far
-			const uint32_t lim = p0 + 16 + 272 < tn ? p0 + 16 + 272 : tn;
-			while (kbits) {
-				const uint32_t j = 31 - (uint32_t)__builtin_clz(kbits);
-				kbits &= ~(1u << j);
-				const uint32_t i = p0 + j;
-				const uint32_t z = ~kb16 & (0xfffeu << j) & 0xffffu;
-				uint32_t T;
-				if (z) T = p0 + (uint32_t)__builtin_ctz(z);
-				else {
-					if (T_ext == 0xffffffffu) {
-						uint32_t s0 = p0 + 16;
-						asm volatile("" : "+v"(s0));                  // not hoisted out of the tile loop (it would be spilled)
-						T_ext = first_zero(kb, s0, lim);
-					}
-					T = T_ext;
+			const uint32_t kbits = kb16 & ((const uint16_t *)vb)[t];
+			if (kbits) {
+				const uint4 mv = *(const uint4 *)(mlen + p0);
+				uint32_t mw[4] = { mv.x, mv.y, mv.z, mv.w };
+				// the end (position + length) of the chain that runs out of my segment
+				uint32_t E = 0;
+				if (kb16 >> 15) {
+					// more than 258 + 16 positions away is as good as infinitely far
+					const uint32_t lim = p0 + 16 + 272 < tn ? p0 + 16 + 272 : tn;
+					uint32_t s0 = p0 + 16;
+					asm volatile("" : "+v"(s0));                  // not hoisted out of the tile loop (it would be spilled)
+					const uint32_t T = first_zero(kb, s0, lim);
+					E = T < lim ? T + mlen[T] + 3 : T + MAXMATCH;
 				}
-				if (T != T_prev) {
-					e_cur = T < lim ? T + mlen[T] + 3 : T + MAXMATCH;
-					T_prev = T;
+				const uint32_t room15 = end - (h + tb0 + p0 + 15);      // bytes from my last position to the end of the data
+#pragma unroll
+				for (int j = 15; j >= 0; j--) {
+					const uint32_t m = (mw[j >> 2] >> (8 * (j & 3))) & 0xff;
+					E = (kb16 >> j) & 1 ? E : p0 + j + m + 3;             // a non-member ends the chains in front of it
+					const uint32_t room = room15 + (15 - j);
+					uint32_t N = E - (p0 + j);
+					N = N < room ? N : room;
+					N = N < MAXMATCH ? N : MAXMATCH;
+					if ((kbits >> j) & 1) mw[j >> 2] = (mw[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((N - 3) & 0xff) << (8 * (j & 3));
 				}
-				const uint32_t r = h + tb0 + i;
-				const uint32_t ml = end - r < MAXMATCH ? end - r : MAXMATCH;
-				const uint32_t N = e_cur - i < ml ? e_cur - i : ml;
-				mlen[i] = (uint8_t)(N - 3);
+				*(uint4 *)(mlen + p0) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
 			}
 		}
 		__syncthreads();
@@ -1020,6 +987,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		// The 16 stored lengths of the segment (+1 for the lazy look-ahead) are fetched with one
 		// 16-byte LDS read and the walk runs out of registers.
 		uint32_t seg_next = 0, seg_nz = 0;
+		uint32_t mm1 = 0, lit1 = 0;                            // what the speculative walk visits: match / literal token starts (16 bits)
 		auto seg_m = [&](uint32_t k) -> uint32_t {              // stored length (len-3, 0 = none) of position p0+k, k <= 16
 			// two levels of 2-way selects (a 4-way select on a computed index becomes a scratch table)
 			const uint32_t a = (k & 8) ? sm2 : sm0, b = (k & 8) ? sm3 : sm1;
@@ -1027,7 +995,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 			const uint32_t v = (w >> (8 * (k & 3))) & 0xff;
 			return (k & 16) ? seg_next : v;
 		};
-		// one greedy/lazy step on register data (same decisions as walk_step)
+		// one greedy/lazy step on register data (oracle/nxz_lz77.c walk())
 		auto seg_step = [&](uint32_t p, uint32_t limit, bool &is_match) -> uint32_t {
 			const uint32_t k = p - p0, cur = seg_m(k);
 			const uint32_t full = cur ? cur + 3 : 0;
@@ -1054,14 +1022,19 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 			};
 			seg_nz = nz4(sm0) | nz4(sm1) << 4 | nz4(sm2) << 8 | nz4(sm3) << 12;
 			uint32_t p = p0, stop = p + PSEG < tn ? p + PSEG : tn;
+			uint32_t cov = 0;                                   // positions of the segment inside a match of this walk (its start too)
 			while (p < stop) {
 				// branch free: skip the literals in front of the next match, then take one step there
 				const uint32_t rest = seg_nz >> (p - p0);
 				p += rest ? (uint32_t)__builtin_ctz(rest) : stop - p;
 				bool m;
 				const uint32_t adv = seg_step(p < stop ? p : p0, tn, m);
+				const bool took = p < stop && m;
+				mm1 |= took ? 1u << (p - p0) : 0;
+				cov |= took ? (adv >= 16 ? 0xffffu : (1u << adv) - 1) << (p - p0) : 0;
 				p += p < stop ? adv : 0;
 			}
+			lit1 = ~cov & (stop - p0 >= 16 ? 0xffffu : (1u << (stop - p0)) - 1);
 			if (p > stop && stop == tn) p = tn;
 			X[t] = (uint16_t)(p < tn ? p : tn);
 			jump[t] = (uint16_t)(p >= tn ? NSEG : p / PSEG);
@@ -1113,27 +1086,55 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 			uint32_t p = mye;
 			const uint32_t lim = myx;
 			uint32_t lm = 0, mm = 0;
+			const uint32_t vis1 = lit1 | mm1;
+			// the speculative walk's last token, if that is a match: every position behind its start lies inside it
+			const uint32_t jm = mm1 ? 31 - (uint32_t)__builtin_clz(mm1) : 0;
+			const bool lastm = mm1 != 0 && (lit1 >> jm) <= 1u;     // (bit jm of lit1 is clear)
 			while (p < lim) {
-				uint32_t k = p - p0;
-				if (k < 16) {
-					// literals in front of the next stored match of my segment
-					const uint32_t rest = seg_nz >> k;
-					uint32_t run = rest ? (uint32_t)__builtin_ctz(rest) : 16 - k;
-					if (run > lim - p) run = lim - p;
+				const uint32_t k = p - p0;
+				if (k < 16 && ((vis1 >> k) & 1)) {
+					// the speculative walk passed here: from now on this IS that walk (oracle/nxz_lz77.c
+					// step 5); its tokens end at lim.  Only its last match can have been cut by the end of
+					// the tile: that one gets its final length.
+					const uint32_t ms = mm1 & (0xffffffffu << k);
+					lm |= lit1 & (0xffffffffu << k);
+					mm |= ms;
+					if (lim == tn && ms) {
+						const uint32_t j = 31 - (uint32_t)__builtin_clz(ms), pl = p0 + j;
+						if (pl + seg_m(j) + 3 > tn) mlen[pl] = (uint8_t)(tn - pl - 3);
+					}
+					break;
+				}
+				if (lastm && k > jm) {
+					// stepped over the start of the speculative walk's last match: what is left of that match
+					// (same distance, up to lim) is the last token; literals if fewer than 3 bytes are left
+					const uint32_t left = lim - p;
+					if (left >= 3) {
+						if (k < 32) mm |= 1u << k; else atomicOr(&tokbits[p >> 5], 1u << (p & 31));
+						mlen[p] = (uint8_t)(left - 3);
+						cand[p] = cand[p0 + jm];
+					} else {
+						for (uint32_t q = p; q < lim; q++) {
+							if (q - p0 < 32) lm |= 1u << (q - p0); else atomicOr(&litbits[q >> 5], 1u << (q & 31));
+						}
+					}
+					break;
+				}
+				// (here p is inside my segment: in front of the last match's start, or there is none and lim is the segment's end)
+				// literals in front of the next stored match of my segment / of the next position the
+				// speculative walk visited
+				const uint32_t rest = (seg_nz | vis1) >> k;
+				uint32_t run = rest ? (uint32_t)__builtin_ctz(rest) : 16 - k;
+				if (run > lim - p) run = lim - p;
+				if (run) {
 					lm |= ((1u << run) - 1) << k;
-					p += run; k += run;
-					if (p >= lim) break;
+					p += run;
+					continue;
 				}
 				bool m;
-				uint32_t l;
-				if (k < 16) l = seg_step(p, lim, m);
-				else l = walk_step(W, p, lim, m);                 // beyond my segment (nobody else's range): LDS data
-				if (k < 32) {
-					lm |= (m ? 0u : 1u) << k;
-					mm |= (m ? 1u : 0u) << k;
-				} else {
-					atomicOr(m ? &tokbits[p >> 5] : &litbits[p >> 5], 1u << (p & 31));
-				}
+				const uint32_t l = seg_step(p, lim, m);
+				lm |= (m ? 0u : 1u) << k;
+				mm |= (m ? 1u : 0u) << k;
 				if (m) mlen[p] = (uint8_t)(l - 3);
 				p += l;
 			}
