@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the DEFLATE hot path on MI355X (BASELINE.json metric).
+"""bench.py -- throughput of the DEFLATE hot path on MI355X (BASELINE.json metric:
+"GiB/s uncompressed in (deflate) + out (inflate), Silesia 64KiB blocks").
 
-  python bench.py --gpus N --steps K --warmup W [--blocks B] [--config c2|c5]
-                  [--no-corpus] [--no-inflate] [--no-cpu-baseline]
+  python bench.py --gpus N --steps K --warmup W [--config corpus|c2|c5] [--blocks B] [--corpus-jobs J]
+                  [--no-c2] [--no-c5] [--no-inflate] [--no-api] [--no-cpu-baseline]
 
-config c2 (default; BASELINE.json configs[1], the configuration the metric is quoted on):
-  a *step* is one pass of the fixed-Huffman deflate engine (function code COMPRESS_FHT: LZ77 kernel +
-  entropy kernel) over one batch of B synthetic 64 KiB blocks that are already resident in HBM.  Every
-  rank owns its own B blocks (independent units, no data-path collective: weak scaling); the only
-  collectives are the barrier and the reductions of {bytes, elapsed}.  Rank 0 prints ONE JSON line.
-  Beside the headline the line carries (N = 1 only, outside the timed region):
-    "corpus"   the metric's kind of data: Silesia from $SILESIA_DIR (sha256-checked against the pins
-               of the reference's oct/silesia-*.source) or the recorded real-data fallback
-               (tests/corpus.py), cut at 64 KiB, replicated to >= 65536 jobs, compressed with an exact
-               dynamic-Huffman table per block built on the device (COMPRESS_DHTGEN), its own roofline,
-               ratio per class against zlib -1 and its own cpu_baseline (zlib -1, T = 1 and T = all)
-    "inflate"  the inflate engine on the deflate output (full size, bit-exact round trip) and on
-               zlib -6 streams of the corpus, with roofline and zlib's inflate on the host cores
-config c5 (BASELINE.json configs[4]): 10 GiB of mixed-entropy 64 KiB blocks (index mod 4: zeros /
-  33-symbol text / makedata-style LZ copies / random bytes), cut into contiguous shards over the N
-  ranks (strong scaling).  A step = compress (FHT; what does not shrink is stored through the WRAP
-  function code, inside the timed region) + decompress + compare on the device.
+config corpus (default; BASELINE.json configs[2], the metric's own kind of data): the real-data corpus --
+  Silesia from $SILESIA_DIR (sha256-checked against the pins of the reference's oct/silesia-*.source) or
+  the recorded real-data fallback of this image (tests/corpus.py) -- cut at 64 KiB and replicated to J
+  jobs per GPU, resident in HBM.  A *step* is one pass of the deflate engine with an exact dynamic-Huffman
+  table per block built on the device (function code COMPRESS_DHTGEN: LZ77 kernel -> dhtgen kernel ->
+  entropy kernel).  Every rank owns its own J jobs (independent units, no data-path collective: weak
+  scaling); the only collectives are the barrier and the reductions of {bytes, elapsed}.  Rank 0 prints
+  ONE JSON line with `roofline` and `cpu_baseline` (zlib -1 on the same chunks, the reference's software
+  path) and, at N = 1, outside the timed region:
+    "inflate_zlib6", "inflate_stream"  the inflate engine on zlib -6 streams of the corpus chunks (batch)
+               and on ONE long zlib -6 stream (block-boundary speculation, BASELINE configs[3])
+    "api"      the reference's own API (nx_compress2 / nx_uncompress / inflate() in steps) on host buffers
+    "c2"       BASELINE configs[1]: fixed-Huffman deflate of synthetic 64 KiB blocks (SURVEY 8(d) C2 recipe)
+               with its own roofline / cpu_baseline, and the inflate engine on that output
+    "c5"       BASELINE configs[4]: the mixed-entropy batch, compress + stored fallback + decompress + compare
+config c2: the "c2" object as the headline (2^20 blocks per GPU by default), weak scaling over N GPUs.
+config c5: 10 GiB of mixed-entropy 64 KiB blocks (index mod 4: zeros / 33-symbol text / makedata-style
+  LZ copies / random bytes), cut into contiguous shards over the N ranks (strong scaling).  A step =
+  compress (FHT; what does not shrink is stored through the WRAP function code, inside the timed region)
+  + decompress + compare on the device.
 
 Inside the timed region: the engine launches only.  Outside: data generation, zlib verification of
 a sample, the CPU baselines (with the oracle parity check).
@@ -41,7 +45,42 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BLOCK = 65536
 STRIDE_OUT = 73856
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured there with a float4 copy)
+_copy_peak = None
+
+
+def copy_peak_gbs(torch, dev):
+    """the achievable HBM figure, measured on this box with a copy kernel (1 GiB device to
+    device, read + written bytes over the time of the copy by HIP events on the copy's stream)."""
+    global _copy_peak
+    if _copy_peak is None:
+        n = 1 << 30
+        a = torch.empty(n, dtype=torch.uint8, device=dev)
+        b = torch.empty(n, dtype=torch.uint8, device=dev)
+        a.zero_()
+        b.copy_(a)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        _copy_peak = round(2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del a, b
+    return _copy_peak
+
+
+def roof(achieved, traffic, kernel, peak_measured=None, **extra):
+    """the roofline object of the contract (+ the figure against the copy kernel's rate on this box)"""
+    out = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kernel}
+    if peak_measured:
+        out["peak_measured"] = peak_measured
+        out["frac_of_measured"] = round(achieved / peak_measured, 5)
+    out.update(extra)
+    return out
+
 
 
 def shard(nblocks_per_rank, rank, world):
@@ -168,7 +207,7 @@ def pmc_traffic(n_blocks, which="fht"):
     with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload and corrected as
     MI355X_MICROARCH.md prescribes), scaled to this step's block count; None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*pmc_traffic_%s.json" % which)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*pmc_traffic_%s.json" % which)))
     if not files:
         return None
     try:
@@ -300,7 +339,7 @@ def what_binds():
     """The path moves few bytes per instruction: what binds the LZ77 kernel is the issue of vector instructions and
     the LDS pipe, from the committed counter passes (profiles/r02*_pmc_counters.json; tools/pmc_report.py)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_counters.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_counters.json")))
     if not files:
         return None
     try:
@@ -314,54 +353,79 @@ def what_binds():
         return None
 
 
-def roofline(u_bytes, c_bytes, stage_ms, launches, traffic, kernel):
+def roofline(u_bytes, c_bytes, stage_ms, launches, traffic, kernel, peak_measured=None):
     """algorithmic bytes U + C over the time of the dominant kernel (the LZ77 kernel:
     it reads U; the entropy kernel writes C and is accounted with it: both are needed to move U + C),
     so achieved = (U + C) / (lz77 + dhtgen + entropy kernel time), measured by HIP events on the
     launch stream around every launch of the timed region."""
     kern_ms = sum(stage_ms)
     achieved = (u_bytes + c_bytes) / (kern_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "what_binds": what_binds(),
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kernel,
-            "kernel_ms": round(kern_ms, 3), "lz77_ms": round(stage_ms[0], 3), "dhtgen_ms": round(stage_ms[1], 3),
-            "entropy_ms": round(stage_ms[2], 3), "launches_per_step": launches,
-            "avg_lz77_launch_ms": round(stage_ms[0] / max(launches, 1), 4),
-            "algorithmic_bytes_per_step": u_bytes + c_bytes}
+    return roof(achieved, traffic, kernel, peak_measured, what_binds=what_binds(),
+                kernel_ms=round(kern_ms, 3), lz77_ms=round(stage_ms[0], 3), dhtgen_ms=round(stage_ms[1], 3),
+                entropy_ms=round(stage_ms[2], 3), launches_per_step=launches,
+                avg_lz77_launch_ms=round(stage_ms[0] / max(launches, 1), 4),
+                algorithmic_bytes_per_step=u_bytes + c_bytes)
 
 
-def corpus_leg(torch, eng, pkg, args):
-    """Real data, exact dynamic-Huffman table per block (the metric's Silesia leg)."""
+def run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng):
+    """The headline: real data (the metric's corpus), exact dynamic-Huffman table per block (BASELINE configs[2])."""
     import zlib
     import corpus
     name, blocks, report = corpus.load(BLOCK)
     uniq = len(blocks)
     rep = max(1, -(-args.corpus_jobs // uniq))
-    n = uniq * rep
+    n = uniq * rep                                             # jobs of THIS rank (every rank its own: weak scaling)
     host = np.zeros((uniq, BLOCK), np.uint8)
     lens_u = np.array([len(b) for _, _, b in blocks], np.uint32)
     for i, (_, _, b) in enumerate(blocks):
         host[i, :len(b)] = np.frombuffer(b, np.uint8)
-    src_u = torch.from_numpy(host).to(eng.dev)
-    src = src_u.repeat(rep, 1)
+    src = torch.from_numpy(host).to(dev).repeat(rep, 1)
     lens = np.tile(lens_u, rep)
-    dst = torch.empty((n, STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    dst = torch.empty((n, STRIDE_OUT), dtype=torch.uint8, device=dev)
     jobs = eng.jobs_strided(src, BLOCK, lens, dst, STRIDE_OUT, STRIDE_OUT)
-    res = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
-    ms, st, launches = timed_compress(torch, eng, pkg.FC_COMPRESS_DHTGEN, jobs, n, res, max(2, args.steps), 1)
+    res = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    eng.L.nxz_ctx_stage_timing.argtypes = [C.c_void_p, C.c_int]
+
+    def step():
+        eng.compress(pkg.FC_COMPRESS_DHTGEN, jobs, n, results=res)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    eng.L.nxz_ctx_stage_timing(eng.ctx, 1)                 # HIP events on the launch stream around every kernel
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    eng.L.nxz_ctx_stage_timing(eng.ctx, 0)
+    st, launches = stage_times(eng)
+    st = [x / args.steps for x in st]
+    launches //= args.steps
+
     r = eng.results_to_host(res)
     if not ((r["cc"] == 0) | (r["cc"] == 64)).all():
-        raise SystemExit("corpus leg: engine reported errors %s" % np.unique(r["cc"]))
+        raise SystemExit("corpus: engine reported errors %s" % np.unique(r["cc"]))
     u_bytes, c_bytes = float(lens.astype(np.float64).sum()), float(r["tpbc"].astype(np.float64).sum())
-    # every output inflates back (on the device, full size) and a sample through zlib
-    back = torch.zeros((n, BLOCK), dtype=torch.uint8, device=eng.dev)
+    # every output inflates back (on the device, full size) -- on every rank
+    back = torch.zeros((n, BLOCK), dtype=torch.uint8, device=dev)
     jobs2 = eng.jobs_strided(dst, STRIDE_OUT, r["tpbc"].astype(np.uint32), back, BLOCK, BLOCK)
     r2 = eng.results_to_host(eng.decompress(jobs2, n))
-    okrt = bool((r2["cc"] == 0).all()) and bool((r2["tpbc"] == lens).all()) and bool(torch.equal(back, src))
-    if not okrt:
-        raise SystemExit("corpus leg: ROUND TRIP FAILURE (inflate of the deflate output != source)")
+    if not (bool((r2["cc"] == 0).all()) and bool((r2["tpbc"] == lens).all()) and bool(torch.equal(back, src))):
+        raise SystemExit("corpus: ROUND TRIP FAILURE on rank %d (inflate of the deflate output != source)" % rank)
+    del back
+    tot_u, tot_c, wall_max = reduce_totals(torch, dist, dev, u_bytes, c_bytes, wall, distributed)
+    if rank != 0:
+        return
     out_u = dst[:uniq].cpu().numpy()
     raw = [b for _, _, b in blocks]
-    verify_sample(raw, out_u, r["tpbc"], k=uniq if uniq <= 400 else 400)
+    verify_sample(raw, out_u, r["tpbc"], k=uniq if uniq <= 400 else 400)      # ... and a sample through zlib
     # ratio per class against zlib -1 (default strategy), on the unique blocks
     per = {}
     for i, (cls, _, b) in enumerate(blocks):
@@ -372,25 +436,42 @@ def corpus_leg(torch, eng, pkg, args):
     classes = {k: {"bytes": v[0], "ratio": round(v[0] / v[1], 4), "zlib1_ratio": round(v[0] / v[2], 4),
                    "vs_zlib1": round(v[2] / v[1], 4)} for k, v in sorted(per.items())}
     tot = [sum(v[i] for v in per.values()) for i in range(3)]
-    out = {
-        "metric": "GiB/s uncompressed in (deflate), exact dynamic-Huffman table per block built on the device (COMPRESS_DHTGEN)",
-        "value": round(u_bytes / (ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s", "ms_per_step": round(ms, 3),
-        "corpus": name, "corpus_files": report, "unique_blocks": uniq, "jobs": n, "block_bytes": BLOCK,
-        "ratio": round(tot[0] / tot[1], 4), "zlib1_ratio": round(tot[0] / tot[2], 4), "ratio_vs_zlib1": round(tot[2] / tot[1], 4),
-        "min_class_vs_zlib1": min(v["vs_zlib1"] for v in classes.values()), "classes": classes,
-        "roundtrip_bit_exact": True, "zlib_inflated_sample": min(uniq, 400),
+    peak_m = copy_peak_gbs(torch, dev)
+    line = {
+        "metric": "GiB/s uncompressed in (deflate), real-data corpus in 64 KiB blocks, exact dynamic-Huffman table per block",
+        "value": round(tot_u * args.steps / wall_max / 2.0 ** 30, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(wall_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8",
+        "data": "Silesia ($SILESIA_DIR, sha256-checked)" if name == "silesia" else
+                "real files of this image (recorded fallback corpus: Silesia is not on the box), replicated",
+        "config": {"workload": "BASELINE configs[2]: dynamic-Huffman deflate (COMPRESS_DHTGEN: LZ77 + histogram, dhtgen on the device, "
+                               "entropy) of the %s corpus cut at 64 KiB, %d jobs per GPU (%d unique blocks), device resident" % (name, n, uniq),
+                   "corpus": name, "corpus_files": report, "unique_blocks": uniq, "jobs_per_gpu": n, "block_bytes": BLOCK,
+                   "ratio": round(tot[0] / tot[1], 4), "zlib1_ratio": round(tot[0] / tot[2], 4), "ratio_vs_zlib1": round(tot[2] / tot[1], 4),
+                   "min_class_vs_zlib1": min(v["vs_zlib1"] for v in classes.values()), "classes": classes,
+                   "roundtrip_bit_exact": True, "zlib_inflated_sample": min(uniq, 400), "parallelism": "shard%d" % world},
         "roofline": roofline(u_bytes, c_bytes, st, launches, pmc_traffic(n, "dhtgen"),
-                             "nxzl77::lz77_kernel<true> + nxzd::dhtgen_kernel + nxze::encode_kernel<true>"),
+                             "nxzl77::lz77_kernel<true> (dominant) + nxzd::dhtgen_kernel + nxze::encode_kernel<true>", peak_m),
     }
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_deflate(raw, "default", 10.0)
-        out["cpu_baseline"]["parity_checked_blocks"] = oracle_parity(raw, out_u, r["tpbc"], True)
-    # inflate of zlib -6 streams of the same corpus (what configs[3] feeds the inflate engine)
-    if not args.no_inflate:
-        out["inflate_zlib6"] = inflate_leg(torch, eng, pkg, raw, rep, args)
-        out["inflate_stream"] = stream_leg(torch, eng, raw, args)
-    out["api"] = api_leg(raw, args)
-    return out
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_deflate(raw, "default", 10.0)
+        line["cpu_baseline"]["parity_checked_blocks"] = oracle_parity(raw, out_u, r["tpbc"], True, k=64)
+    if world == 1:
+        del src, dst, jobs, res
+        torch.cuda.empty_cache()
+        # inflate of zlib -6 streams of the same corpus (what configs[3] feeds the inflate engine)
+        if not args.no_inflate:
+            line["inflate_zlib6"] = inflate_leg(torch, eng, pkg, raw, rep, args)
+            line["inflate_stream"] = stream_leg(torch, eng, raw, args)
+        if not args.no_api:
+            line["api"] = api_leg(raw, args)
+        if not args.no_c2:
+            torch.cuda.empty_cache()
+            line["c2"] = c2_measure(torch, dist, args, 0, 1, dev, False, pkg, eng, args.blocks or (1 << 18), max(2, args.steps // 2), 1)
+        if not args.no_c5:
+            torch.cuda.empty_cache()
+            line["c5"] = c5_measure(torch, dist, args, 0, 1, dev, False, pkg, eng, 163840, max(2, args.steps // 2), 1)
+    print(json.dumps(line), flush=True)
 
 
 def api_leg(raw, args, mib=256, nthreads=16):
@@ -536,9 +617,9 @@ def stream_leg(torch, eng, raw, args, mib=256):
     out = {"value": round(len(data) / best / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out, one stream, device resident",
            "ms": round(best * 1e3, 2), "stream": "%d MiB of the corpus as ONE raw deflate stream, zlib level 6 (%.1f MiB compressed)" % (mib, len(comp) / 2.0 ** 20),
            "pieces": info["pieces"], "bit_exact": True,
-           "roofline": {"bound": "hbm", "achieved": round((len(data) + len(comp)) / best / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round((len(data) + len(comp)) / best / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                        "kernel": "find_blocks + inflate of the pieces into 16-bit elements + window chain + resolve + checksums, wall clock"}}
+           "roofline": roof((len(data) + len(comp)) / best / 1e9, pmc_traffic(len(data) / BLOCK, "inflate_stream"),
+                            "find_blocks + inflate of the pieces into 16-bit elements + window chain + resolve + checksums, wall clock",
+                            copy_peak_gbs(torch, eng.dev))}
     if not args.no_cpu_baseline:
         t0 = time.perf_counter()
         zlib.decompress(comp, -15)
@@ -586,10 +667,9 @@ def inflate_leg(torch, eng, pkg, raw, rep, args):
     u, cb = float(ulen.astype(np.float64).sum()), float(clen.astype(np.float64).sum())
     out = {"value": round(u / (ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out", "ms_per_pass": round(ms, 3),
            "streams": n, "made_by": "zlib level 6, raw deflate, one stream per 64 KiB block", "bit_exact": True,
-           "roofline": {"bound": "hbm", "achieved": round((u + cb) / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round((u + cb) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                        "kernel": "batched inflate (stream per lane / per wave by batch size) + cksum_kernel",
-                        "kernel_ms": round(ms, 3)}}
+           "roofline": roof((u + cb) / (ms * 1e-3) / 1e9, pmc_traffic(n, "inflate_zlib6"),
+                            "batched inflate (stream per lane / per wave by batch size) + cksum_kernel", copy_peak_gbs(torch, eng.dev),
+                            kernel_ms=round(ms, 3))}
     if not args.no_cpu_baseline:
         cores = usable_cores()
         z1, _, _, _ = _cpu_run(streams, 2, 1, 2.0)
@@ -600,12 +680,13 @@ def inflate_leg(torch, eng, pkg, raw, rep, args):
     return out
 
 
-def run_c5(torch, dist, args, rank, world, dev, distributed, pkg, eng):
-    """BASELINE configs[4]: 10 GiB mixed entropy, contiguous strong-scaled shards."""
-    total = args.blocks if args.blocks else 163840
-    lo, hi = shard_strong(total, rank, world)
-    n = hi - lo
-    src = gen_mixed(torch, dev, n, lo)
+def c5_prepare(torch, eng, pkg, src):
+    """One step of BASELINE configs[4] on the mixed blocks `src` (n x 64 KiB, device): returns (step, info).
+    step() = FHT compress + WRAP of what does not shrink + decompress (WRAP back for the stored ones) +
+    compare on the device; info: buffers, the first pass' results, the indices of the stored blocks and
+    the device flag that counts mismatching passes."""
+    dev = src.device
+    n = src.shape[0]
     comp = torch.empty((n, STRIDE_OUT), dtype=torch.uint8, device=dev)
     back = torch.empty((n, BLOCK), dtype=torch.uint8, device=dev)
     lens = np.full(n, BLOCK, np.uint32)
@@ -616,7 +697,7 @@ def run_c5(torch, dist, args, rank, world, dev, distributed, pkg, eng):
     # (lib/nx_deflate.c:1274-1282,1763-1790).  Which ones: known after the first pass, the job
     # arrays of the wrap and of the decompress pass are built once (outside the timed region)
     eng.compress(pkg.FC_COMPRESS_FHT, jobs, n, results=res)
-    r = eng.results_to_host(res)
+    r = eng.results_to_host(res).copy()
     if not ((r["cc"] == 0) | (r["cc"] == 64)).all():
         raise SystemExit("engine reported errors: %s" % np.unique(r["cc"]))
     stored = np.nonzero(r["cc"] == 64)[0]
@@ -647,7 +728,19 @@ def run_c5(torch, dist, args, rank, world, dev, distributed, pkg, eng):
             eng.wrap(ju, len(stored), results=resw)
         flag.add_((back != src).any().to(torch.int32))           # compare on the device
 
-    for _ in range(args.warmup):
+    c_bytes = float(r["tpbc"][ok].astype(np.float64).sum()) + len(stored) * float(BLOCK + 5)
+    return step, {"comp": comp, "back": back, "results": r, "stored": int(len(stored)), "stored_index": stored,
+                  "flag": flag, "c_bytes": c_bytes, "keep": (jobs, res, jw, jd, ju, resw, resd)}
+
+
+def c5_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, total, steps, warmup):
+    """BASELINE configs[4]: 10 GiB mixed entropy, contiguous strong-scaled shards; the JSON line (rank 0) or None."""
+    lo, hi = shard_strong(total, rank, world)
+    n = hi - lo
+    src = gen_mixed(torch, dev, n, lo)
+    step, info = c5_prepare(torch, eng, pkg, src)
+    flag = info["flag"]
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
     if distributed:
@@ -655,7 +748,7 @@ def run_c5(torch, dist, args, rank, world, dev, distributed, pkg, eng):
     torch.cuda.synchronize(dev)
     flag.zero_()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize(dev)
     if distributed:
@@ -665,25 +758,139 @@ def run_c5(torch, dist, args, rank, world, dev, distributed, pkg, eng):
     if int(flag.item()) != 0:
         raise SystemExit("ROUND TRIP FAILURE (c5): decompressed data != source on rank %d" % rank)
     u_bytes = float(n) * BLOCK
-    c_bytes = float(r["tpbc"][ok].astype(np.float64).sum()) + len(stored) * float(BLOCK + 5)
+    tot_u, tot_c, wall_max = reduce_totals(torch, dist, dev, u_bytes, info["c_bytes"], wall, distributed)
+    if rank != 0:
+        return None
+    value = 2.0 * tot_u * steps / wall_max / 2.0 ** 30
+    return {
+        "metric": "GiB/s uncompressed in (deflate) + out (inflate), 10 GiB mixed-entropy 64 KiB blocks",
+        "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(wall_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: %d x 64 KiB blocks (zeros / 33-symbol text / text + makedata copies / random by "
+                               "index mod 4), contiguous shards over %d GPUs; step = FHT compress + WRAP of what does not "
+                               "shrink + decompress + compare, device resident" % (total, world),
+                   "total_blocks": total, "block_bytes": BLOCK, "ratio": round(tot_u / tot_c, 4),
+                   "stored_blocks_rank0": info["stored"], "roundtrip_bit_exact": True, "parallelism": "shard%d" % world},
+        "roofline": roof(2 * (tot_u + tot_c) * steps / wall_max / 1e9 / world, None,
+                         "whole step (deflate + wrap + inflate kernels), wall clock, per GPU", copy_peak_gbs(torch, dev)),
+    }
+
+
+def c2_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, n, steps, warmup):
+    """BASELINE configs[1]: fixed-Huffman deflate of n synthetic 64 KiB blocks per GPU (weak scaling); the JSON
+    line (rank 0) or None."""
+    lo, hi = shard(n, rank, world)
+    src = gen_blocks(torch, dev, n, lo)
+    dst = torch.empty((n, STRIDE_OUT), dtype=torch.uint8, device=dev)
+    lens = np.full(n, BLOCK, np.uint32)
+    jobs = eng.jobs_strided(src, BLOCK, lens, dst, STRIDE_OUT, STRIDE_OUT)
+    results = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    eng.L.nxz_ctx_stage_timing.argtypes = [C.c_void_p, C.c_int]
+
+    def step():
+        eng.compress(pkg.FC_COMPRESS_FHT, jobs, n, results=results)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+
+    eng.L.nxz_ctx_stage_timing(eng.ctx, 1)                 # HIP events on the launch stream around every kernel
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    eng.L.nxz_ctx_stage_timing(eng.ctx, 0)
+    st, launches = stage_times(eng)
+    st = [x / steps for x in st]
+    launches //= steps
+
+    res = results.cpu().numpy().view(pkg.RESULT_DTYPE)
+    if not ((res["cc"] == 0) | (res["cc"] == 64)).all():
+        raise SystemExit("engine reported errors: %s" % np.unique(res["cc"]))
+    peak_m = copy_peak_gbs(torch, dev)
+
+    # second leg of the metric (uncompressed bytes OUT of inflate), measured after the timed deflate
+    # region on the same device-resident data: the inflate engine decodes the deflate engine's output
+    # and the result is compared with the source on the device (bit-exact round trip at full size).
+    inflate_info = None
+    if not args.no_inflate and rank == 0:
+        back = torch.empty((n, BLOCK), dtype=torch.uint8, device=dev)
+        jobs2 = eng.jobs_strided(dst, STRIDE_OUT, res["tpbc"].astype(np.uint32), back, BLOCK, BLOCK)
+        res2 = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        eng.decompress(jobs2, n, results=res2)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(max(1, steps // 2)):
+            eng.decompress(jobs2, n, results=res2)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        inf_ms = e0.elapsed_time(e1) / max(1, steps // 2)
+        r2 = res2.cpu().numpy().view(pkg.RESULT_DTYPE)
+        ok = bool(torch.equal(back, src)) and bool((r2["cc"] == 0).all()) and bool((r2["crc"] == res["crc"]).all())
+        if not ok:
+            badrows = (back != src).any(dim=1)
+            nbad = int(badrows.sum().item())
+            import zlib
+            for i in torch.nonzero(badrows).flatten()[:4].tolist():
+                b = src[i].cpu().numpy().tobytes()
+                o = dst[i, :int(res["tpbc"][i])].cpu().numpy().tobytes()
+                g = back[i].cpu().numpy().tobytes()
+                try:
+                    z = zlib.decompressobj(-15)
+                    zok = z.decompress(o) == b
+                except zlib.error as e:
+                    zok = "zlib error %s" % e
+                first = next((k for k in range(BLOCK) if g[k] != b[k]), -1)
+                ndiff = sum(1 for k in range(BLOCK) if g[k] != b[k])
+                print("bad block %d: zlib inflates the deflate output to the source: %s; first differing byte %d, %d bytes differ; tpbc %d; crc deflate %08x inflate %08x zlib %08x"
+                      % (i, zok, first, ndiff, int(res["tpbc"][i]), int(res["crc"][i]), int(r2["crc"][i]), zlib.crc32(b)), file=sys.stderr)
+            raise SystemExit("ROUND TRIP FAILURE at full size (inflate of the deflate output != source): %d of %d blocks differ, cc != 0 in %d (%s), "
+                             "crc differs in %d" % (nbad, n, int((r2["cc"] != 0).sum()), np.unique(r2["cc"]), int((r2["crc"] != res["crc"]).sum())))
+        ub, cb = float(n) * BLOCK, float(res["tpbc"].astype(np.float64).sum())
+        inflate_info = {"value": round(ub / (inf_ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out",
+                        "ms_per_pass": round(inf_ms, 3), "kernel": "batched inflate (stream per lane / per wave by batch size) + cksum_kernel",
+                        "what": "the fixed-Huffman output of the timed region", "scope": "one GPU (rank 0)", "roundtrip_bit_exact": True,
+                        "roofline": roof((ub + cb) / (inf_ms * 1e-3) / 1e9, pmc_traffic(n, "inflate_own"), "nxzl::inflate_lanes_kernel + cksum_kernel", peak_m)}
+        del back
+    u_bytes = float(n) * BLOCK
+    c_bytes = float(res["tpbc"].astype(np.float64).sum())
     tot_u, tot_c, wall_max = reduce_totals(torch, dist, dev, u_bytes, c_bytes, wall, distributed)
-    if rank == 0:
-        value = 2.0 * tot_u * args.steps / wall_max / 2.0 ** 30
-        line = {
-            "metric": "GiB/s uncompressed in (deflate) + out (inflate), 10 GiB mixed-entropy 64 KiB blocks",
-            "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[4]: %d x 64 KiB blocks (zeros / 33-symbol text / text + LZ copies / random by "
-                                   "index mod 4), contiguous shards over %d GPUs; step = FHT compress + WRAP of what does not "
-                                   "shrink + decompress + compare, device resident" % (total, world),
-                       "total_blocks": total, "block_bytes": BLOCK, "ratio": round(tot_u / tot_c, 4),
-                       "stored_blocks_rank0": int(len(stored)), "parallelism": "shard%d" % world},
-            "roofline": {"bound": "hbm", "achieved": round(2 * (tot_u + tot_c) * args.steps / wall_max / 1e9, 2), "peak": HBM_PEAK_GBS * world,
-                         "unit": "GB/s", "frac": round(2 * (tot_u + tot_c) * args.steps / wall_max / 1e9 / (HBM_PEAK_GBS * world), 5),
-                         "traffic": None, "kernel": "whole step (deflate + wrap + inflate kernels), wall clock"},
-        }
-        print(json.dumps(line), flush=True)
+    if rank != 0:
+        return None
+    k = min(n, 48)
+    src_rows = [row.tobytes() for row in src[:k].cpu().numpy()]
+    out_rows = dst[:k].cpu().numpy()
+    verify_sample(src_rows, out_rows, res["tpbc"], k)
+    value = tot_u * steps / wall_max / 2.0 ** 30
+    line = {
+        "metric": "GiB/s uncompressed in (deflate), fixed-Huffman level 1, synthetic 64 KiB blocks",
+        "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(wall_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: fixed-Huffman deflate (FC 0x00), %d x 64 KiB synthetic blocks per GPU (block i from seed "
+                               "0x9E3779B97F4A7C15 ^ i: 33-symbol text, then makedata copies with per-block len_max / dist_max), device resident" % n,
+                   "blocks_per_gpu": n, "block_bytes": BLOCK, "ratio": round(tot_u / tot_c, 4),
+                   "parallelism": "shard%d" % world},
+        "roofline": roofline(u_bytes, c_bytes, st, launches, pmc_traffic(n, "fht"),
+                             "nxzl77::lz77_kernel<false> (dominant) + nxze::encode_kernel<false>", peak_m),
+    }
+    if inflate_info:
+        line["inflate"] = inflate_info
+    if world == 1 and not args.no_cpu_baseline:
+        sample = [row.tobytes() for row in src[:min(n, 2048)].cpu().numpy()]
+        line["cpu_baseline"] = cpu_baseline_deflate(sample, "fixed", 10.0)
+        line["cpu_baseline"]["parity_checked_blocks"] = oracle_parity(src_rows, out_rows, res["tpbc"], False)
+        line["config"]["ratio_vs_zlib1_fixed"] = round(line["cpu_baseline"]["zlib_ratio"] and line["config"]["ratio"] / line["cpu_baseline"]["zlib_ratio"], 4)
+    return line
 
 
 def main():
@@ -691,12 +898,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["c2", "c5"], default="c2")
-    ap.add_argument("--blocks", type=int, default=0, help="c2: 64 KiB blocks per GPU (default 2^20 = 64 GiB); c5: total blocks (default 163840 = 10 GiB)")
-    ap.add_argument("--corpus-jobs", type=int, default=65536, help="jobs of the real-data leg (the corpus is replicated)")
+    ap.add_argument("--config", choices=["corpus", "c3", "c2", "c5"], default="corpus")
+    ap.add_argument("--blocks", type=int, default=0, help="c2: 64 KiB blocks per GPU (default 2^20 = 64 GiB; as the side object of the default "
+                                                         "config 2^18); c5: total blocks (default 163840 = 10 GiB)")
+    ap.add_argument("--corpus-jobs", type=int, default=262144, help="jobs per GPU of the corpus config (the corpus is replicated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inflate", action="store_true", help="skip the inflate legs")
-    ap.add_argument("--no-corpus", action="store_true", help="skip the real-data leg (N=1 only anyway)")
+    ap.add_argument("--no-api", action="store_true", help="skip the host-buffer API leg")
+    ap.add_argument("--no-c2", action="store_true", help="corpus config: skip the c2 side object")
+    ap.add_argument("--no-c5", action="store_true", help="corpus config: skip the c5 side object")
+    ap.add_argument("--no-corpus", action="store_true", help="(kept for old command lines: no effect)")
     args = ap.parse_args()
 
     import torch
@@ -720,113 +931,15 @@ def main():
     eng = pkg.Engine(local_rank)
 
     if args.config == "c5":
-        run_c5(torch, dist, args, rank, world, dev, distributed, pkg, eng)
-        if distributed:
-            dist.barrier()
-            dist.destroy_process_group()
-        eng.close()
-        return
-
-    n = args.blocks or (1 << 20)
-    lo, hi = shard(n, rank, world)
-    src = gen_blocks(torch, dev, n, lo)
-    dst = torch.empty((n, STRIDE_OUT), dtype=torch.uint8, device=dev)
-    lens = np.full(n, BLOCK, np.uint32)
-    jobs = eng.jobs_strided(src, BLOCK, lens, dst, STRIDE_OUT, STRIDE_OUT)
-    results = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    eng.L.nxz_ctx_stage_timing.argtypes = [C.c_void_p, C.c_int]
-
-    def step():
-        eng.compress(pkg.FC_COMPRESS_FHT, jobs, n, results=results)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-
-    eng.L.nxz_ctx_stage_timing(eng.ctx, 1)                 # HIP events on the launch stream around every kernel
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    eng.L.nxz_ctx_stage_timing(eng.ctx, 0)
-    st, launches = stage_times(eng)
-    st = [x / args.steps for x in st]
-    launches //= args.steps
-
-    res = results.cpu().numpy().view(pkg.RESULT_DTYPE)
-    if not ((res["cc"] == 0) | (res["cc"] == 64)).all():
-        raise SystemExit("engine reported errors: %s" % np.unique(res["cc"]))
-
-    # second leg of the metric (uncompressed bytes OUT of inflate), measured after the timed deflate
-    # region on the same device-resident data: the inflate engine decodes the deflate engine's output
-    # and the result is compared with the source on the device (bit-exact round trip at full size).
-    inflate_info = None
-    if not args.no_inflate:
-        back = torch.empty((n, BLOCK), dtype=torch.uint8, device=dev)
-        jobs2 = eng.jobs_strided(dst, STRIDE_OUT, res["tpbc"].astype(np.uint32), back, BLOCK, BLOCK)
-        res2 = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-        eng.decompress(jobs2, n, results=res2)
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(max(1, args.steps // 2)):
-            eng.decompress(jobs2, n, results=res2)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        inf_ms = e0.elapsed_time(e1) / max(1, args.steps // 2)
-        r2 = res2.cpu().numpy().view(pkg.RESULT_DTYPE)
-        ok = bool(torch.equal(back, src)) and bool((r2["cc"] == 0).all()) and bool((r2["crc"] == res["crc"]).all())
-        if not ok:
-            raise SystemExit("ROUND TRIP FAILURE at full size (inflate of the deflate output != source)")
-        ub, cb = float(n) * BLOCK, float(res["tpbc"].astype(np.float64).sum())
-        inflate_info = {"value": round(ub / (inf_ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out",
-                        "ms_per_pass": round(inf_ms, 3), "kernel": "nxzl::inflate_lanes_kernel + cksum_kernel",
-                        "what": "the fixed-Huffman output of the timed region", "scope": "one GPU (rank 0)", "roundtrip_bit_exact": True,
-                        "roofline": {"bound": "hbm", "achieved": round((ub + cb) / (inf_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                                     "unit": "GB/s", "frac": round((ub + cb) / (inf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
-        del back
-    u_bytes = float(n) * BLOCK
-    c_bytes = float(res["tpbc"].astype(np.float64).sum())
-
-    tot_u, tot_c, wall_max = reduce_totals(torch, dist, dev, u_bytes, c_bytes, wall, distributed)
-
-    if rank == 0:
-        k = min(n, 48)
-        src_rows = [row.tobytes() for row in src[:k].cpu().numpy()]
-        out_rows = dst[:k].cpu().numpy()
-        verify_sample(src_rows, out_rows, res["tpbc"], k)
-        value = tot_u * args.steps / wall_max / 2.0 ** 30
-        line = {
-            "metric": "GiB/s uncompressed in (deflate), fixed-Huffman level 1, synthetic 64 KiB blocks",
-            "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: fixed-Huffman deflate (FC 0x00), %d x 64 KiB synthetic blocks "
-                                   "per GPU (33-symbol text + makedata-style LZ copies), device resident" % n,
-                       "blocks_per_gpu": n, "block_bytes": BLOCK, "ratio": round(tot_u / tot_c, 4),
-                       "parallelism": "shard%d" % world},
-            "roofline": roofline(u_bytes, c_bytes, st, launches, pmc_traffic(n, "fht"),
-                                 "nxzl77::lz77_kernel<false> (dominant) + nxze::encode_kernel<false>"),
-        }
-        if inflate_info:
-            line["inflate"] = inflate_info
-        if world == 1 and not args.no_cpu_baseline:
-            sample = [row.tobytes() for row in src[:min(n, 2048)].cpu().numpy()]
-            line["cpu_baseline"] = cpu_baseline_deflate(sample, "fixed", 10.0)
-            line["cpu_baseline"]["parity_checked_blocks"] = oracle_parity(src_rows, out_rows, res["tpbc"], False)
-            line["config"]["ratio_vs_zlib1_fixed"] = round(line["cpu_baseline"]["zlib_ratio"] and line["config"]["ratio"] / line["cpu_baseline"]["zlib_ratio"], 4)
-        if world == 1 and not args.no_corpus:
-            del src, dst
-            torch.cuda.empty_cache()
-            line["corpus"] = corpus_leg(torch, eng, pkg, args)
-        print(json.dumps(line), flush=True)
+        line = c5_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, args.blocks or 163840, args.steps, args.warmup)
+        if line:
+            print(json.dumps(line), flush=True)
+    elif args.config == "c2":
+        line = c2_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, args.blocks or (1 << 20), args.steps, args.warmup)
+        if line:
+            print(json.dumps(line), flush=True)
+    else:
+        run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -988,6 +988,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		// 16-byte LDS read and the walk runs out of registers.
 		uint32_t seg_next = 0, seg_nz = 0;
 		uint32_t mm1 = 0, lit1 = 0;                            // what the speculative walk visits: match / literal token starts (16 bits)
+		uint32_t lastd = 0;                                    // distance - 1 of its last match
 		auto seg_m = [&](uint32_t k) -> uint32_t {              // stored length (len-3, 0 = none) of position p0+k, k <= 16
 			// two levels of 2-way selects (a 4-way select on a computed index becomes a scratch table)
 			const uint32_t a = (k & 8) ? sm2 : sm0, b = (k & 8) ? sm3 : sm1;
@@ -1035,6 +1036,8 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 				p += p < stop ? adv : 0;
 			}
 			lit1 = ~cov & (stop - p0 >= 16 ? 0xffffu : (1u << (stop - p0)) - 1);
+			// (read now: in pass 2 another segment's walk may put the rest of ITS last match on that position)
+			lastd = mm1 ? cand[p0 + 31 - (uint32_t)__builtin_clz(mm1)] : 0;
 			if (p > stop && stop == tn) p = tn;
 			X[t] = (uint16_t)(p < tn ? p : tn);
 			jump[t] = (uint16_t)(p >= tn ? NSEG : p / PSEG);
@@ -1112,7 +1115,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 					if (left >= 3) {
 						if (k < 32) mm |= 1u << k; else atomicOr(&tokbits[p >> 5], 1u << (p & 31));
 						mlen[p] = (uint8_t)(left - 3);
-						cand[p] = cand[p0 + jm];
+						cand[p] = (uint16_t)lastd;
 					} else {
 						for (uint32_t q = p; q < lim; q++) {
 							if (q - p0 < 32) lm |= 1u << (q - p0); else atomicOr(&litbits[q >> 5], 1u << (q & 31));
