@@ -330,6 +330,17 @@ int nxz_inflate_stream_part(nxz_ctx_t *ctx, const uint8_t *src, uint64_t src_len
 size_t nxz_deflate_host_bound(size_t src_len);
 int nxz_deflate_host(nxz_ctx_t *ctx, int fc, const uint8_t *src, size_t src_len, int final,
 		     uint8_t *dst, size_t dst_cap, size_t *out_len, uint32_t *crc, uint32_t *adler);
+/* The same for the levels that carry history from job to job (5..9: lib/nx_deflate.c:654-680 sets
+ * max_history_len to 4..32 KiB; :845-862 puts that much of the earlier input in front of a job's
+ * source): every block's window is the hist_max bytes of the INPUT in front of it -- known up
+ * front, so the blocks are still compressed side by side --, the first block's the tail of `prev`
+ * (prev_len bytes the caller kept of earlier calls; may be NULL).  Blocks are 64 KiB - hist_max long
+ * (window + block <= 64 KiB; hist_max is rounded down to a multiple of 16, 32 KiB at most).
+ * dst_cap >= nxz_deflate_host_bound_hist(src_len, hist_max). */
+size_t nxz_deflate_host_bound_hist(size_t src_len, uint32_t hist_max);
+int nxz_deflate_host_hist(nxz_ctx_t *ctx, int fc, const uint8_t *src, size_t src_len, int final, uint32_t hist_max,
+			  const uint8_t *prev, size_t prev_len, uint8_t *dst, size_t dst_cap, size_t *out_len,
+			  uint32_t *crc, uint32_t *adler);
 
 /* Batched wrap (FC 0x1e): copy + crc32 + adler32 from the initial values. */
 int nxz_batch_wrap(nxz_ctx_t *ctx, const nxz_batch_job_t *jobs, size_t n,

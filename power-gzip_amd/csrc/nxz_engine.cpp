@@ -484,10 +484,19 @@ static uint32_t adler_join(uint32_t a1, uint32_t a2, uint64_t len2)
 	return (uint32_t)((sum2 << 16) | sum1);
 }
 
-extern "C" size_t nxz_deflate_host_bound(size_t src_len)
+// the source bytes a block takes when hist_max bytes of what lies in front of it are its window
+// (window + block <= 64 KiB, both multiples of 16)
+static inline size_t host_block_bytes(uint32_t hist_max)
 {
-	return src_len + ((src_len + SUBBLOCK - 1) / SUBBLOCK) * 10 + 16;
+	const uint32_t h = hist_max > 32768u ? 32768u : hist_max & ~15u;
+	return SUBBLOCK - h;
 }
+extern "C" size_t nxz_deflate_host_bound_hist(size_t src_len, uint32_t hist_max)
+{
+	const size_t B = host_block_bytes(hist_max);
+	return src_len + ((src_len + B - 1) / B) * 10 + 16;
+}
+extern "C" size_t nxz_deflate_host_bound(size_t src_len) { return nxz_deflate_host_bound_hist(src_len, 0); }
 
 // (the two lanes of a pair get streams of different priority: the runtime maps streams onto a few hardware
 // queues, and two streams of one priority may share a queue, depending on what other streams the process has
@@ -524,10 +533,24 @@ static inline uint64_t trace_ns();
 extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t src_len, int final,
 				uint8_t *dst, size_t dst_cap, size_t *out_len, uint32_t *crc, uint32_t *adler)
 {
+	return nxz_deflate_host_hist(c, fc, src, src_len, final, 0, nullptr, 0, dst, dst_cap, out_len, crc, adler);
+}
+
+// The same with a window: every block sees the hist_max bytes of the INPUT in front of it (the levels that carry
+// history from job to job, lib/nx_deflate.c:654-680,845-862: the history of a job is just the bytes in front of
+// it, known up front, so the jobs do not depend on each other); the first block's window is the tail of `prev`
+// (what the stream kept of earlier calls).  Blocks are 64 KiB - hist_max long (window + block <= 64 KiB).
+extern "C" int nxz_deflate_host_hist(nxz_ctx_t *c, int fc, const uint8_t *src, size_t src_len, int final, uint32_t hist_max,
+				     const uint8_t *prev, size_t prev_len, uint8_t *dst, size_t dst_cap, size_t *out_len, uint32_t *crc, uint32_t *adler)
+{
 	if (!c || !src || !dst || !out_len || !src_len) return -EINVAL;
 	if (fc != NXZ_FC_COMPRESS_FHT && fc != NXZ_FC_COMPRESS_DHTGEN) return -EINVAL;
 	if (forked_child()) return -ENODEV;
-	if (dst_cap < nxz_deflate_host_bound(src_len)) return -E2BIG;
+	if (dst_cap < nxz_deflate_host_bound_hist(src_len, hist_max)) return -E2BIG;
+	const uint32_t H = (uint32_t)(SUBBLOCK - host_block_bytes(hist_max));      // window bytes per block
+	const size_t B = SUBBLOCK - H;
+	if (H) fc |= 0x08;                                                  // the RESUME forms take hist_len
+	if (!prev) prev_len = 0;
 	(void)hipSetDevice(c->device);
 	int pair = -1;
 	for (int k = 0; k < 4 && pair < 0; k++) if (c->lanes_mtx[k].try_lock()) pair = k;
@@ -536,12 +559,12 @@ extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t
 	nxz_ctx::HostLane *const lanes = c->lanes + 2 * pair;
 	for (int k = 0; k < 2; k++)
 		if (!lanes[k].stream && !lane_init(lanes[k], k == 1)) return -ENOMEM;
-	const size_t nblk = (src_len + SUBBLOCK - 1) / SUBBLOCK;
+	const size_t nblk = (src_len + B - 1) / B;
 	// groups: at least four when the input allows it, so that copies and kernels overlap
-	size_t group = std::min<size_t>(HOST_GROUP, std::max<size_t>(32, (nblk + 3) / 4));
+	size_t group = std::min<size_t>(HOST_GROUP - 1, std::max<size_t>(32, (nblk + 3) / 4));   // (- 1: the window in front of a group's first block)
 	const size_t ngroups = (nblk + group - 1) / group;
 	group = (nblk + ngroups - 1) / ngroups;
-	const uint32_t op_block = crc_shift_op(SUBBLOCK);
+	const uint32_t op_block = crc_shift_op(B);
 	uint32_t run_crc = 0, run_adler = 1;
 	size_t pos = 0;
 	int rc = 0;
@@ -549,17 +572,23 @@ extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t
 	auto queue = [&](size_t gi) -> int {
 		nxz_ctx::HostLane &l = lanes[gi & 1];
 		const size_t b0 = gi * group, n = std::min(group, nblk - b0);
-		const uint64_t bytes = std::min<uint64_t>((uint64_t)n * SUBBLOCK, src_len - (uint64_t)b0 * SUBBLOCK);
+		const uint64_t first = (uint64_t)b0 * B;                      // offset of the group's first block in src
+		const uint64_t bytes = std::min<uint64_t>((uint64_t)n * B, src_len - first);
+		// the window in front of the group: from src itself, for the call's first block from `prev`
+		const uint32_t h0 = !H ? 0 : first ? (uint32_t)std::min<uint64_t>(H, first) & ~15u : (uint32_t)std::min<size_t>(H, prev_len) & ~15u;
 		for (size_t k = 0; k < n; k++) {
 			nxz_batch_job_t &j = l.h_jobs[k];
 			memset(&j, 0, sizeof(j));
-			j.src = l.d_src + k * SUBBLOCK; j.dst = l.d_dst + k * HOST_SLOT;
-			j.src_len = (uint32_t)std::min<uint64_t>(SUBBLOCK, bytes - (uint64_t)k * SUBBLOCK);
+			const uint32_t hk = (uint32_t)std::min<uint64_t>(H, h0 + (uint64_t)k * B);   // (a multiple of 16: h0, B and H are)
+			j.src = l.d_src + h0 + k * B - hk; j.dst = l.d_dst + k * HOST_SLOT;
+			j.hist_len = hk;
+			j.src_len = hk + (uint32_t)std::min<uint64_t>(B, bytes - (uint64_t)k * B);
 			j.dst_cap = HOST_SLOT; j.in_crc = 0; j.in_adler = 1;
 		}
 		l.n = n; l.bytes = bytes;
 		HIPCHK(hipMemcpyAsync(l.d_jobs, l.h_jobs, n * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, l.stream), return -EIO);
-		HIPCHK(hipMemcpyAsync(l.d_src, src + (uint64_t)b0 * SUBBLOCK, bytes, hipMemcpyHostToDevice, l.stream), return -EIO);
+		if (h0 && !first) { HIPCHK(hipMemcpyAsync(l.d_src, prev + prev_len - h0, h0, hipMemcpyHostToDevice, l.stream), return -EIO); }
+		HIPCHK(hipMemcpyAsync(l.d_src + (first ? 0 : h0), src + first - (first ? h0 : 0), bytes + (first ? h0 : 0), hipMemcpyHostToDevice, l.stream), return -EIO);
 		int r = nxz_batch_compress(c, fc, l.d_jobs, n, nullptr, 0, l.d_res, nullptr, l.stream);
 		if (r) return r;
 		const uint32_t fin = final && gi == ngroups - 1 ? (uint32_t)(n - 1) : 0xffffffffu;
@@ -575,8 +604,8 @@ extern "C" int nxz_deflate_host(nxz_ctx_t *c, int fc, const uint8_t *src, size_t
 		if (pos + total > dst_cap) return -E2BIG;                   // cannot happen: the bound was checked
 		HIPCHK(hipMemcpyAsync(dst + pos, l.d_packed, total, hipMemcpyDeviceToHost, l.stream), return -EIO);
 		for (size_t k = 0; k < l.n; k++) {                           // meanwhile: checksums of the run
-			const uint32_t len = l.h_jobs[k].src_len;
-			const uint32_t op = len == SUBBLOCK ? op_block : crc_shift_op(len);
+			const uint32_t len = l.h_jobs[k].src_len - l.h_jobs[k].hist_len;
+			const uint32_t op = len == B ? op_block : crc_shift_op(len);
 			run_crc = gf2_mul32(run_crc, op) ^ l.h_res[k].crc;
 			run_adler = adler_join(run_adler, l.h_res[k].adler, len);
 		}

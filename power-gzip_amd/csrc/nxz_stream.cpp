@@ -247,6 +247,11 @@ void deflate_consume(Deflate *s, size_t n)
 	if (s->max_history == 0) {
 		s->fifo.erase(s->fifo.begin(), s->fifo.begin() + s->hist_len + from_cache);
 		s->hist_len = 0;
+	} else if (from_next >= s->max_history) {
+		// (a large call: the new history is the tail of what was taken from next_in, nothing else moves)
+		s->fifo.erase(s->fifo.begin(), s->fifo.begin() + s->hist_len + from_cache);
+		s->fifo.insert(s->fifo.begin(), s->z->next_in + from_next - s->max_history, s->z->next_in + from_next);
+		s->hist_len = s->max_history;
 	} else {
 		// bring the consumed next_in bytes into the fifo right after the consumed cache part
 		if (from_next) s->fifo.insert(s->fifo.begin() + s->hist_len + from_cache, s->z->next_in, s->z->next_in + from_next);
@@ -401,8 +406,8 @@ int deflate_job(Deflate *s, int flush)
 // strung together on the device the way deflate_job strings jobs together) instead of one nxu_run_job
 // round trip per block.  (Weak references: the CPU model of the test suite has no such entry.)
 extern "C" {
-size_t nxz_deflate_host_bound(size_t) __attribute__((weak));
-int nxz_deflate_host(nxz_ctx_t *, int, const uint8_t *, size_t, int, uint8_t *, size_t, size_t *, uint32_t *, uint32_t *) __attribute__((weak));
+size_t nxz_deflate_host_bound_hist(size_t, uint32_t) __attribute__((weak));
+int nxz_deflate_host_hist(nxz_ctx_t *, int, const uint8_t *, size_t, int, uint32_t, const uint8_t *, size_t, uint8_t *, size_t, size_t *, uint32_t *, uint32_t *) __attribute__((weak));
 }
 constexpr size_t BATCH_MIN = 4 * JOB_UNIT;
 
@@ -410,13 +415,18 @@ constexpr size_t BATCH_MIN = 4 * JOB_UNIT;
 bool deflate_batch(Deflate *s, int flush)
 {
 	z_streamp z = s->z;
-	if (!nxz_deflate_host || !nxz_deflate_host_bound) return false;
-	if (!s->eng.open || s->max_history != 0 || s->used != 0 || s->dict_len != 0 || s->pending() || z->avail_in < BATCH_MIN) return false;
+	if (!nxz_deflate_host_hist || !nxz_deflate_host_bound_hist) return false;
+	if (!s->eng.open || s->used != 0 || s->dict_len != 0 || s->pending() || z->avail_in < BATCH_MIN) return false;
+	// At the levels that carry history (5..9, max_history 4..32 KiB) a block's window is the input in front of
+	// it: blocks of 64 KiB - max_history, still side by side (nxz_deflate_host_hist); the first block's window
+	// is what the stream kept of the calls before (the front of the fifo).
+	const uint32_t hmax = s->max_history > 32768 ? 32768u : (s->max_history & ~15u);
+	const size_t unit = JOB_UNIT - hmax;
 	nxz_ctx_t *ctx = (nxz_ctx_t *)s->eng.dev.paste_addr;
 	if (!ctx) return false;
 	const bool final = flush == Z_FINISH;
-	const size_t take = final ? z->avail_in : (size_t)z->avail_in / JOB_UNIT * JOB_UNIT;
-	const size_t bound = nxz_deflate_host_bound(take);
+	const size_t take = final ? z->avail_in : (size_t)z->avail_in / unit * unit;
+	const size_t bound = nxz_deflate_host_bound_hist(take, hmax);
 	if (s->tail_n) s->stored_header(0, 0);                          // the run starts on a byte boundary
 	// straight into the caller's buffer when it is sure to fit, else through the pending buffer
 	const bool direct = !s->pending() && z->avail_out >= bound;
@@ -425,10 +435,10 @@ bool deflate_batch(Deflate *s, int flush)
 	size_t produced = 0;
 	uint32_t crc = 0, adler = 1;
 	const uint64_t t0 = nxz_ticks();
-	if (nxz_deflate_host(ctx, s->strategy == Z_FIXED ? NXZ_FC_COMPRESS_FHT : 0x22 /* NXZ_FC_COMPRESS_DHTGEN */, z->next_in, take, final,
-			     out, bound, &produced, &crc, &adler))
+	if (nxz_deflate_host_hist(ctx, s->strategy == Z_FIXED ? NXZ_FC_COMPRESS_FHT : 0x22 /* NXZ_FC_COMPRESS_DHTGEN */, z->next_in, take, final,
+				  hmax, s->hist_len ? s->fifo.data() : nullptr, s->hist_len, out, bound, &produced, &crc, &adler))
 		return false;                                               // nothing consumed: the ordinary path takes over
-	nxz_device_stats(t0, t0 + (nxz_ticks() - t0) / ((take + JOB_UNIT - 1) / JOB_UNIT));   // per job, as AUTO mode's average counts
+	nxz_device_stats(t0, t0 + (nxz_ticks() - t0) / ((take + unit - 1) / unit));   // per job, as AUTO mode's average counts
 	if (direct) { z->next_out += produced; z->avail_out -= (uInt)produced; z->total_out += produced; }
 	else s->out_bytes(out, produced);
 	deflate_consume(s, take);
@@ -436,6 +446,18 @@ bool deflate_batch(Deflate *s, int flush)
 	publish_cksum(s);
 	if (final) s->st = Deflate::BFINAL;
 	s->have_counts = false;                                          // (the next single job starts from the default table again)
+	// A flush request is honoured by the job that takes the last input (deflate_job).  When the batch left none,
+	// the flush rules of lib/nx_deflate.c:1081-1176 are applied here: the run ends on a byte boundary (a block
+	// that ended inside a byte is followed by an empty stored block already: pack_stream_kernel), so a sync / full
+	// flush only needs its 00 00 FF FF marker when the last block did not bring one, and a partial flush its
+	// empty fixed block.
+	if (!final && z->avail_in == 0 && s->used == 0 && (flush == Z_SYNC_FLUSH || flush == Z_FULL_FLUSH || flush == Z_PARTIAL_FLUSH)) {
+		static const uint8_t marker[4] = { 0, 0, 0xff, 0xff };
+		const bool marked = produced >= 4 && !memcmp(out + produced - 4, marker, 4);
+		if (!marked) s->stored_header(0, 0);
+		if (flush == Z_PARTIAL_FLUSH) s->put_bits(2, 10);            // empty fixed block: BFINAL 0, BTYPE 01, EOB
+		if (flush == Z_FULL_FLUSH) { s->fifo.erase(s->fifo.begin(), s->fifo.begin() + s->hist_len); s->hist_len = 0; }
+	}
 	return true;
 }
 

@@ -81,12 +81,69 @@ def test_compress2_round_trip_through_zlib_and_nx_uncompress(L):
     assert n.value == len(data) and back.raw == data
 
 
-def test_levels_with_history_keep_the_job_after_job_path(L):
-    # level 6 carries 32 KiB of history from job to job (lib/nx_deflate.c:654-680): matches may reach
-    # across job boundaries, which the batch of independent blocks cannot give -- same stream as before
-    data = make_block("alice", 1 << 20, 5)
-    out, _, _ = Z.deflate_all(L, data, level=6, wbits=15)
+@pytest.mark.parametrize("level", [5, 6, 9])
+def test_levels_with_history_go_in_one_batch_with_the_input_as_window(L, level):
+    """Levels 5..9 carry 4..32 KiB of the earlier INPUT into the next job (lib/nx_deflate.c:654-680,845-862).
+    The history of a block is just the bytes in front of it, so a large call still goes to the engine as one
+    batch (nxz_deflate_host_hist: blocks of 64 KiB - history, each with its window): zlib reads the stream,
+    matches reach across block boundaries (better ratio than the level-1 batch on text), and it is fast."""
+    import time
+    data = (open(os.path.join(os.path.dirname(__file__), "golden", "alice29.txt"), "rb").read() * 120)[:16 << 20]
+    out, rcs, adler = Z.deflate_all(L, data, level=level, wbits=15)
     assert zlib.decompress(out) == data
+    assert adler == zlib.adler32(data)
+    assert len(rcs) <= 4, len(rcs)                               # one batch, not 256+ jobs
+    out1, _, _ = Z.deflate_all(L, data, level=1, wbits=15)
+    assert len(out) < len(out1)                                  # cross-block matches
+    # the first block of a later call sees the tail of the call before (the stream's history)
+    half = len(data) // 2 + 12345
+    out2, _, _ = Z.deflate_all(L, data, level=level, wbits=15, step_in=half)
+    assert zlib.decompress(out2) == data
+    # host buffer to host buffer through the one-shot call (buffers made once: the call alone is timed)
+    big = data * 4                                               # 64 MiB
+    cap = C.c_ulong(L.nx_compressBound(len(big)))
+    dst = C.create_string_buffer(cap.value)
+    best = 1e9
+    for _ in range(4):
+        cap.value = len(dst)
+        t = time.perf_counter()
+        assert L.nx_compress2(dst, C.byref(cap), big, len(big), level) == Z.Z_OK
+        best = min(best, time.perf_counter() - t)
+    assert zlib.decompress(dst.raw[:cap.value]) == big
+    rate = len(big) / best / 2 ** 30
+    print("nx_compress2 level %d, 64 MiB host to host: %.2f GiB/s (%.2f ms), ratio %.3f" % (level, rate, best * 1e3, len(big) / cap.value))
+    assert rate >= 15.0, "level %d: %.2f GiB/s host to host" % (level, rate)
+
+
+@pytest.mark.parametrize("flush,tail", [(Z.Z_SYNC_FLUSH, b"\x00\x00\xff\xff"), (Z.Z_FULL_FLUSH, b"\x00\x00\xff\xff"), (Z.Z_PARTIAL_FLUSH, None)])
+@pytest.mark.parametrize("kind", ["alice", "zeros", "mixed"])
+def test_a_flush_request_is_honoured_when_the_batch_takes_all_the_input(L, flush, tail, kind):
+    """Round-2 advisor finding: 4 x 64 KiB with Z_SYNC_FLUSH went to the batch, which consumed everything and
+    returned without the flush rules of lib/nx_deflate.c:1081-1176.  The output of the flush call must end in the
+    00 00 FF FF marker (sync / full), a partial flush in its empty fixed block; the stream goes on afterwards."""
+    n = 4 * 65536
+    data = mixed(n, 77) if kind == "mixed" else make_block(kind, n, 9)
+    st = Z.ZStream()
+    assert L.nx_deflateInit2_(C.byref(st), 1, Z.Z_DEFLATED, -15, 8, Z.Z_DEFAULT_STRATEGY, Z.VERSION, C.sizeof(Z.ZStream)) == Z.Z_OK
+    src = C.create_string_buffer(data + data[:1000], n + 1000)
+    dst = C.create_string_buffer(2 * n + 4096)
+    st.next_in = C.addressof(src); st.avail_in = n
+    st.next_out = C.addressof(dst); st.avail_out = len(dst)
+    assert L.nx_deflate(C.byref(st), flush) == Z.Z_OK
+    assert st.avail_in == 0
+    first = dst.raw[:st.total_out]
+    if tail is not None:
+        assert first.endswith(tail), first[-8:]
+    # everything fed so far is decodable from what has been written (that is what a flush promises)
+    d = zlib.decompressobj(-15)
+    assert d.decompress(first) == data
+    # and the stream continues
+    st.avail_in = 1000
+    assert L.nx_deflate(C.byref(st), Z.Z_FINISH) == Z.Z_STREAM_END
+    whole = dst.raw[:st.total_out]
+    L.nx_deflateEnd(C.byref(st))
+    d = zlib.decompressobj(-15)
+    assert d.decompress(whole) == data + data[:1000] and d.eof
 
 
 def test_dictionary_then_batch(L):
