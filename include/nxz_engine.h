@@ -342,6 +342,12 @@ int nxz_deflate_host_hist(nxz_ctx_t *ctx, int fc, const uint8_t *src, size_t src
 			  const uint8_t *prev, size_t prev_len, uint8_t *dst, size_t dst_cap, size_t *out_len,
 			  uint32_t *crc, uint32_t *adler);
 
+/* Device memory the engine keeps between calls (workspaces of nxz_inflate_stream / _part: grown on demand,
+ * a workspace above NXZ_PINFLATE_KEEP_MB -- default 8192 -- is given back when its call ends): nxz_trim()
+ * gives back what no call is using right now and returns the bytes freed.  For processes that share the
+ * device with other users (torch, another library). */
+size_t nxz_trim(void);
+
 /* Batched wrap (FC 0x1e): copy + crc32 + adler32 from the initial values. */
 int nxz_batch_wrap(nxz_ctx_t *ctx, const nxz_batch_job_t *jobs, size_t n,
 		   nxz_batch_result_t *results, void *stream);

@@ -38,6 +38,8 @@ static void set_err(const char *what, hipError_t e)
 #define HIPCHK(x, fail) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(#x, e_); fail; } } while (0)
 
 extern "C" const char *nxz_last_error(void) { return g_err; }
+extern "C" size_t nxz_pinflate_trim(void);
+extern "C" size_t nxz_trim(void) { return nxz_pinflate_trim(); }
 extern "C" const char *nxz_engine_version(void) { return NXZ_VERSION; }
 extern "C" size_t nxz_compress_bound(size_t n) { return ((n * 9 + 7) / 8 + 16 + 15) & ~(size_t)15; }
 

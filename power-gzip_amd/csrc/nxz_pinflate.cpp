@@ -115,11 +115,52 @@ struct Workspace {
 };
 constexpr int NWS = 8;
 Workspace g_ws[64][NWS];
+// Room for a piece's 16-bit output: CAPMUL0 elements per compressed byte to begin with (NXZ_PINFLATE_CAPMUL; a
+// piece that runs out of room -- CC 13 -- is decoded again from its start with 8 x as much, up to deflate's own
+// limit of 1032, and a repeated piece costs its whole decode time once more: 256 MiB of the corpus at zlib -6
+// take 11.2 ms at 100 x, 12.8 at 32 x, 15.7 at 16 x), and a floor that spares short pieces of very repetitive
+// data the repeat.  (Round 2 began at 100 x with a floor of 2 Mi elements per block piece: ~11 GB + 9 GB of
+// floors for that stream, per workspace, kept for good -- the advisor's finding.  48 x and floors of 32 / 128 Ki
+// elements: about 5 GB for it, 100 bytes of device memory per compressed byte.)
+static const uint32_t CAPMUL0 = getenv("NXZ_PINFLATE_CAPMUL") ? (uint32_t)atoi(getenv("NXZ_PINFLATE_CAPMUL")) : 48;
+constexpr uint64_t CAP_FLOOR_CUT = 32u << 10, CAP_FLOOR_BLOCK = 128u << 10;
+// A workspace that a call has grown beyond this is given back to the device when the call ends (NXZ_PINFLATE_KEEP_MB,
+// default 8192 MiB): the engine shares the device with its caller (torch, other libraries).
+inline size_t keep_bytes()
+{
+	static const size_t v = (size_t)(getenv("NXZ_PINFLATE_KEEP_MB") ? atoll(getenv("NXZ_PINFLATE_KEEP_MB")) : 8192) << 20;
+	return v;
+}
+struct TrimOnExit {
+	Workspace &w;
+	~TrimOnExit()
+	{
+		if (w.dev_cap > keep_bytes()) { (void)hipFree(w.dev); w.dev = nullptr; w.dev_cap = 0; }
+	}
+};
 std::atomic<unsigned> g_ws_turn{0};
 
 inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 } // namespace
+
+// Gives the device memory of every workspace that no call is using back to the device (include/nxz_engine.h nxz_trim).
+extern "C" size_t nxz_pinflate_trim(void)
+{
+	size_t freed = 0;
+	for (int d = 0; d < 64; d++)
+		for (int k = 0; k < NWS; k++) {
+			Workspace &w = g_ws[d][k];
+			if (!w.dev && !w.built) continue;
+			if (!w.mtx.try_lock()) continue;
+			if (hipSetDevice(d) == hipSuccess) {
+				if (w.dev) { freed += w.dev_cap; (void)hipFree(w.dev); w.dev = nullptr; w.dev_cap = 0; }
+				if (w.built) { freed += w.built_cap; (void)hipFree(w.built); w.built = nullptr; w.built_cap = 0; }
+			}
+			w.mtx.unlock();
+		}
+	return freed;
+}
 
 // Raw deflate stream at src (DEVICE memory, src_len bytes; it starts at bit first_bit and, unless
 // `st` is given, must run to a final block) -> dst (DEVICE).  hist (may be NULL): up to 32 KiB of DEVICE bytes that precede
@@ -149,6 +190,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	if (!wsp) { wsp = &g_ws[dev][g_ws_turn.fetch_add(1) % NWS]; wsp->mtx.lock(); }
 	Workspace &ws = *wsp;
 	std::lock_guard<std::mutex> guard(ws.mtx, std::adopt_lock);
+	TrimOnExit trim{ws};                                       // (destroyed before the guard: still under the lock)
 	static const bool own_stream = !(getenv("NXZ_PINFLATE_OWN_STREAM") && atoi(getenv("NXZ_PINFLATE_OWN_STREAM")) == 0);
 	if (!s && own_stream) {
 		if (!ws.own) {
@@ -293,7 +335,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	pc.reserve(B.size() + subs.size());
 	for (size_t i = 0, k = 0; i < B.size(); i++) {
 		P p = P();
-		p.bit = B[i]; p.capmul = 100; p.tab = -1;                      // buffer: 100 x the compressed size, 2 Mi elements at least
+		p.bit = B[i]; p.capmul = CAPMUL0; p.tab = -1;                  // buffer: 16 x the compressed size to begin with (x 8 per repeat), FLOOR elements at least
 		p.hdr0 = i == 0 && st && (st->sfbt & 8) && (st->sfbt & 0xe) != 0xe ? 0 : 1;
 		pc.push_back(p);
 		p.hdr0 = 0;
@@ -328,7 +370,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		if (p.cbytes > 0xfffffff0ull - 64) return false;
 		p.stop = next && next->tab >= 0 ? next_bit - p.cstart * 8 : 0;
 		if (p.stop > 0xffffffffull) return false;
-		const uint64_t cp = std::max<uint64_t>(p.cbytes * p.capmul, p.tab >= 0 ? 256u << 10 : 2u << 20);
+		const uint64_t cp = std::max<uint64_t>(p.cbytes * p.capmul, p.tab >= 0 ? CAP_FLOOR_CUT : CAP_FLOOR_BLOCK);
 		if (cp > 0xfff00000ull) return false;
 		p.cap = up(cp, 256);
 		p.stage_off = bump; bump += up(p.cbytes + 64, 256);
@@ -350,7 +392,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 				for (size_t i = 0; i < pc.size(); i++)
 					if (!size_piece(pc[i], i + 1 < pc.size() ? &pc[i + 1] : nullptr)) return -ENOTSUP;
 			}
-			reserved = bump + std::max<size_t>(bump / 4, (size_t)256 << 20);
+			reserved = bump + std::max<size_t>(bump / 4, (size_t)32 << 20);
 			if (o_bump + reserved > (200ull << 30)) return -ENOTSUP;
 			if (!ws.need(o_bump + reserved, pin_total)) return -ENOMEM;
 			win0_made = false;
@@ -519,7 +561,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 				// the next start behind that block, becomes a piece of its own -- a job that resumes inside a stored block.
 				P q = P();
 				q.bit = p.cstart * 8 + (p.stop ? p.stop : p.cbytes * 8) - r.subc;
-				q.capmul = 100; q.tab = -1; q.hdr0 = 0; q.srem = r.tebc; q.sfin = r.sfbt & 1; q.done = false;
+				q.capmul = CAPMUL0; q.tab = -1; q.hdr0 = 0; q.srem = r.tebc; q.sfin = r.sfbt & 1; q.done = false;
 				swallow_until = std::max<uint64_t>(q.bit + (uint64_t)r.tebc * 8, run_end[i]);
 				if (q.bit > p.bit && !(q.bit & 7)) {
 					nx.push_back(p);

@@ -730,6 +730,7 @@ void *nxz_stream_create(nxz_ctx_t *) __attribute__((weak));
 int nxz_engine_usable(void) __attribute__((weak));
 }
 constexpr size_t PARALLEL_INFLATE_MIN = 12u << 10;
+constexpr size_t CARRY_KEEP = 1024;                // unconsumed source kept between calls at most: a dynamic block header (<= 290 bytes) and a token
 
 bool parallel_inflate(Inflate *s)
 {
@@ -831,8 +832,11 @@ bool parallel_inflate(Inflate *s)
 	const size_t from_next0 = consumed > nc ? consumed - nc : 0;
 	rest.insert(rest.end(), z->next_in + from_next0, z->next_in + take);
 	z->next_in += take; z->avail_in -= (uInt)take; z->total_in += take;
-	if (st.final || rest.size() > (1u << 20)) {
-		// what is not this stream's (or was left for want of room) goes back to the caller's view as far as it came from next_in
+	if (st.final || rest.size() > CARRY_KEEP) {
+		// what is not this stream's, or was left for want of room in the target, goes back to the caller's view as far
+		// as it came from next_in: next_in moves only over what the engine has used (lib/nx_inflate.c:1614-1623), so at
+		// Z_STREAM_END it stands right behind the stream.  Only the few bytes of a token or header that the source
+		// ended in stay here (the caller's next call brings what follows them).
 		const size_t giveback = std::min<size_t>(rest.size(), take - from_next0);
 		z->next_in -= giveback; z->avail_in += (uInt)giveback; z->total_in -= giveback;
 		rest.resize(rest.size() - giveback);
@@ -940,8 +944,10 @@ int inflate_job(Inflate *s)
 		// what stays for the next job: unconsumed bytes taken from carry / next_in
 		std::vector<uint8_t> rest(s->src.begin() + pad + histlen + consumed, s->src.begin() + pad + histlen + given);
 		z->next_in += from_next; z->avail_in -= from_next; z->total_in += from_next;
-		if (final) {
-			// unconsumed bytes go back to the caller's view as far as they came from next_in
+		if (final || rest.size() > CARRY_KEEP) {
+			// unconsumed bytes go back to the caller's view as far as they came from next_in (all of them behind a
+			// finished stream or when the job stopped for want of room in the target; the tail of a token or header
+			// that the source ended in stays here)
 			size_t giveback = std::min<size_t>(rest.size(), from_next);
 			z->next_in -= giveback; z->avail_in += (uInt)giveback; z->total_in -= giveback;
 			rest.resize(rest.size() - giveback);

@@ -268,3 +268,49 @@ def test_software_checksums(L, golden_dir):
     a, b = make_block("random", 1000, 1), make_block("random", 70001, 2)
     assert L.nx_crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
     assert L.nx_adler32_combine(zlib.adler32(a), zlib.adler32(b), len(b)) == zlib.adler32(a + b)
+
+
+@pytest.mark.parametrize("size,step_out", [(3 << 20, 65536), (3 << 20, 1 << 20), (200000, 4096), (40000, 1000)])
+def test_next_in_stands_right_behind_the_stream_at_stream_end(L, size, step_out):
+    """zlib's contract (and lib/nx_inflate.c:1614-1623 update_stream_in: next_in moves only over what the engine
+    consumed): at Z_STREAM_END next_in / avail_in / total_in point just past the stream, so a caller that reads
+    concatenated gzip members (inflateEnd + inflateInit per member, CPython's unused_data) finds the next member.
+    Round-2 advisor finding: with a large avail_in and a small avail_out up to a megabyte of the caller's input
+    was swallowed into the stream state and the start of the next member was lost."""
+    a = make_block("alice", size, 3)
+    b = make_block("lz", 70000, 4)
+    m1 = zlib.compressobj(6, zlib.DEFLATED, 31)
+    m1 = m1.compress(a) + m1.flush()
+    m2 = zlib.compressobj(6, zlib.DEFLATED, 31)
+    m2 = m2.compress(b) + m2.flush()
+    both = m1 + m2
+    src = C.create_string_buffer(both, len(both))
+    dst = C.create_string_buffer(step_out)
+    st = Z.ZStream()
+    assert L.nx_inflateInit2_(C.byref(st), 31, Z.VERSION, C.sizeof(Z.ZStream)) == Z.Z_OK
+    st.next_in = C.addressof(src)
+    st.avail_in = len(both)                                    # everything at once: both members
+    got = bytearray()
+    rc = Z.Z_OK
+    for _ in range(1000000):
+        st.next_out = C.addressof(dst)
+        st.avail_out = step_out
+        rc = L.nx_inflate(C.byref(st), Z.Z_NO_FLUSH)
+        got += dst.raw[:step_out - st.avail_out]
+        if rc != Z.Z_OK:
+            break
+    assert rc == Z.Z_STREAM_END and bytes(got) == a
+    assert st.avail_in == len(m2) and st.total_in == len(m1)
+    assert st.next_in == C.addressof(src) + len(m1)
+    L.nx_inflateEnd(C.byref(st))
+    # the second member is read from where next_in stands
+    st2 = Z.ZStream()
+    assert L.nx_inflateInit2_(C.byref(st2), 31, Z.VERSION, C.sizeof(Z.ZStream)) == Z.Z_OK
+    st2.next_in = st.next_in
+    st2.avail_in = st.avail_in
+    out2 = C.create_string_buffer(len(b) + 64)
+    st2.next_out = C.addressof(out2)
+    st2.avail_out = len(out2)
+    assert L.nx_inflate(C.byref(st2), Z.Z_FINISH) == Z.Z_STREAM_END
+    assert out2.raw[:st2.total_out] == b and st2.avail_in == 0
+    L.nx_inflateEnd(C.byref(st2))
