@@ -348,6 +348,14 @@ int nxz_deflate_host_hist(nxz_ctx_t *ctx, int fc, const uint8_t *src, size_t src
  * device with other users (torch, another library). */
 size_t nxz_trim(void);
 
+/* The device a context is made on when the caller names none (nx_function_begin with pri = -1, i.e.
+ * NX_GZIP_DEV_NUM unset: lib/nx_zlib.c:568-576 "nx_id -1 means open any", :1281-1287): NXZ_DEVICE if set;
+ * else the calling thread's device -- the process' first thread gets the current HIP device, every further
+ * thread the next visible device in turn (NXZ_DEVICE_POLICY=current: always the current device).  The
+ * policy itself, a pure function: requested ordinal (-1 = any), visible devices, current device, index of the
+ * calling thread in order of first use, spread on / off -> device, or -1 for "no such device". */
+int nxz_pick_device(int requested, int ndev, int current, unsigned thread_index, int spread);
+
 /* Batched wrap (FC 0x1e): copy + crc32 + adler32 from the initial values. */
 int nxz_batch_wrap(nxz_ctx_t *ctx, const nxz_batch_job_t *jobs, size_t n,
 		   nxz_batch_result_t *results, void *stream);

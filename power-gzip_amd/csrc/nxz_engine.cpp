@@ -178,6 +178,30 @@ static void slot_free(Slot &s)
 
 extern "C" int nxz_engine_usable(void) { return forked_child() ? 0 : 1; }
 
+// Which device a caller that names none (NX_GZIP_DEV_NUM = -1, the default) gets.  The reference opens the
+// NX unit nearest the calling CPU, or the one NX_GZIP_DEV_NUM names (lib/nx_zlib.c:568-576,1081,1281-1287), so a
+// process with many threads uses every engine of the machine.  Here: NXZ_DEVICE names one; else the calling
+// THREAD keeps one device for all its streams -- the first thread of the process the current HIP device (what a
+// single-threaded caller has always got), every further thread the next visible device in turn -- so that T
+// threads spread over min(T, ndev) GPUs.  NXZ_DEVICE_POLICY=current: every thread the current device.
+// Pure function of its arguments (tests/test_config.py calls it with made-up device counts).
+extern "C" int nxz_pick_device(int requested, int ndev, int current, unsigned thread_index, int spread)
+{
+	if (ndev <= 0) return -1;
+	if (requested >= 0) return requested < ndev ? requested : -1;      // an explicit ordinal pins (out of range: no such device)
+	if (current < 0 || current >= ndev) current = 0;
+	if (!spread) return current;
+	return (int)(((unsigned)current + thread_index) % (unsigned)ndev);
+}
+
+static unsigned calling_thread_index()
+{
+	static std::atomic<unsigned> next{0};
+	static thread_local unsigned mine = ~0u;
+	if (mine == ~0u) mine = next.fetch_add(1);
+	return mine;
+}
+
 extern "C" nxz_ctx_t *nxz_ctx_create(int device)
 {
 	if (forked_child()) {
@@ -193,10 +217,15 @@ extern "C" nxz_ctx_t *nxz_ctx_create(int device)
 	}
 	if (device < 0) {
 		const char *e = getenv("NXZ_DEVICE");
-		device = e ? atoi(e) : 0;
-		if (!e) (void)hipGetDevice(&device);
+		if (e) device = atoi(e);
+		else {
+			static const bool spread = !(getenv("NXZ_DEVICE_POLICY") && !strcmp(getenv("NXZ_DEVICE_POLICY"), "current"));
+			int cur = 0;
+			(void)hipGetDevice(&cur);
+			device = nxz_pick_device(-1, ndev < 64 ? ndev : 64, cur, calling_thread_index(), spread);
+		}
 	}
-	if (device >= ndev || device >= 64) { errno = ENODEV; snprintf(g_err, sizeof(g_err), "device %d out of range", device); return nullptr; }
+	if (device < 0 || device >= ndev || device >= 64) { errno = ENODEV; snprintf(g_err, sizeof(g_err), "device %d out of range", device); return nullptr; }
 	std::lock_guard<std::mutex> g(g_mtx);
 	if (g_ctx[device]) { g_ctx[device]->refs++; (void)hipSetDevice(device); return g_ctx[device]; }
 	hipDeviceProp_t prop;

@@ -59,10 +59,13 @@ struct Engine {
 		// every stream shares that handle; here the first stream leaves one handle open for the life
 		// of the process, so that the engine context (streams, staging buffers) outlives the
 		// init/end pair of every nx_compress2 call instead of being rebuilt each time.
+		// (one such handle per device: with NX_GZIP_DEV_NUM = -1 the threads of a process spread over the devices)
 		if (open) {
-			static std::once_flag once;
-			static nxz_dev_t keep;
-			std::call_once(once, [] { memset(&keep, 0, sizeof(keep)); (void)nx_function_begin(NXZ_FUNC_COMP_GZIP, nxz_config()->dev_num, &keep); });
+			static std::once_flag once[64];
+			static nxz_dev_t keep[64];
+			const int d = dev.fd - 1;                                   // (the handle's fd is the device ordinal + 1)
+			if (d >= 0 && d < 64)
+				std::call_once(once[d], [d] { memset(&keep[d], 0, sizeof(keep[d])); (void)nx_function_begin(NXZ_FUNC_COMP_GZIP, d, &keep[d]); });
 		}
 		return open;
 	}
@@ -1184,12 +1187,11 @@ extern "C" int nx_inflate(z_streamp strm, int flush)
 			if (s->pending()) goto out;
 			if (strm->avail_out == 0) goto out;
 			if (strm->avail_in == 0 && s->carry.empty()) goto out;
-			if (strm->avail_in > 0 && strm->avail_in + s->carry.size() < 1024 && flush != Z_FINISH && flush != Z_SYNC_FLUSH) {
-				// tiny input: remember it, like the reference's fifo_in caching (:1197-1205)
-				s->carry.insert(s->carry.end(), strm->next_in, strm->next_in + strm->avail_in);
-				strm->total_in += strm->avail_in; strm->next_in += strm->avail_in; strm->avail_in = 0;
-				goto out;
-			}
+			// (The reference gathers inputs below its cache threshold here and returns Z_OK without decoding,
+			// lib/nx_inflate.c:1184-1205.  Not replicated: a caller in the canonical zlib loop -- zpipe.c: feed what
+			// fread() gave, stop at Z_STREAM_END, end of file otherwise means a truncated stream -- never gets the end
+			// of a stream whose last chunk, or whole length, is shorter than the threshold.  Found by the interoperability
+			// matrix, tests/test_gpu_oct.py; inflate() decodes what it is given.)
 			rc = inflate_job(s);
 			if (rc != Z_OK) { if (rc == Z_DATA_ERROR) NEXT(BAD); goto out; }
 			if (s->st == Inflate::BODY && s->pending()) goto out;

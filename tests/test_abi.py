@@ -101,3 +101,30 @@ def test_preload_library_exports_the_references_versioned_abi():
         got.add((name, ver))
     assert got - want == {("deflateParams", "")}, sorted(got - want)
     assert want - got == set(), sorted(want - got)
+
+
+def test_device_selection_policy_spreads_threads_over_the_gpus():
+    """Row (e) / verdict item 6: a caller that names no device (NX_GZIP_DEV_NUM unset: "nx_id -1 means open any",
+    /root/reference lib/nx_zlib.c:568-576,1281-1287 -- the reference takes the unit nearest the calling CPU, so an
+    N-thread process uses every engine) gets a device per THREAD: the first thread the current device, the others
+    the next devices in turn; an explicit ordinal pins.  The policy is a pure function, called here with made-up
+    device counts (no GPU needed)."""
+    import ctypes as C
+    L = pkg.engine.load_library()
+    f = L.nxz_pick_device
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int]
+    # one thread: what it always got -- the current device
+    assert f(-1, 8, 0, 0, 1) == 0 and f(-1, 8, 5, 0, 1) == 5
+    # 16 threads on 8 GPUs: every GPU gets two of them
+    got = [f(-1, 8, 0, t, 1) for t in range(16)]
+    assert sorted(got) == sorted(list(range(8)) * 2)
+    # starting from the current device, wrapping
+    assert [f(-1, 4, 2, t, 1) for t in range(5)] == [2, 3, 0, 1, 2]
+    # the policy switched off (NXZ_DEVICE_POLICY=current): everybody on the current device
+    assert {f(-1, 8, 3, t, 0) for t in range(16)} == {3}
+    # an explicit ordinal pins, whatever the thread; out of range is refused
+    assert {f(6, 8, 0, t, 1) for t in range(16)} == {6}
+    assert f(8, 8, 0, 0, 1) == -1 and f(0, 0, 0, 0, 1) == -1
+    # one GPU: everything on it
+    assert {f(-1, 1, 0, t, 1) for t in range(9)} == {0}

@@ -1,0 +1,116 @@
+"""The reference's interoperability matrix (/root/reference oct/generate-test.sh:11-58, oct/tests.mk:54-70,
+generated inputs oct/Makefile.am:36-55) on the GPU box: an UNMODIFIED zlib client (power-gzip_amd/minigz, built
+from tools/minigz.c against system zlib: the two clients of the matrix in one -- gzip files through the gz*
+calls, zlib streams through deflate()/inflate()) runs with and without LD_PRELOAD=libnxz_preload.so:
+
+    compress     engine compresses  | system zlib decompresses
+    decompress   system zlib compresses at the level | engine decompresses
+    compdecomp   engine compresses  | engine decompresses
+
+levels 1..9 x {gzip, deflate} x {corpus files, empty, random 4 KiB / 13 MiB, sparse 10 MiB, zero 4 KiB /
+13 MiB}; the sha256 of what comes out must be the source's.  (All nine levels on the short inputs, 1 / 6 / 9 on
+the long ones: every pipeline is two or three processes that open the device.)"""
+import hashlib
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MINIGZ = os.path.join(ROOT, "power-gzip_amd", "minigz")
+PRELOAD = os.path.join(ROOT, "power-gzip_amd", "libnxz_preload.so")
+
+
+def _inputs():
+    import corpus
+    rnd = __import__("random").Random(20261003)
+    files = {
+        "empty": b"",
+        "random4k": rnd.randbytes(4096),
+        "zero4k": bytes(4096),
+        "alice29": open(os.path.join(ROOT, "tests", "golden", "alice29.txt"), "rb").read(),
+        "random13M": rnd.randbytes(13 << 20),
+        "zero13M": bytes(13 << 20),
+        "sparse10M": bytes(10 << 20),
+    }
+    # two more files of the real-data corpus, whole (an ELF and XML where the fallback corpus is in use)
+    _, blocks, _ = corpus.load(65536)
+    byname = {}
+    for cls, name, b in blocks:
+        byname.setdefault((cls, name), []).append(b)
+    picked = 0
+    for (cls, name), bl in byname.items():
+        if name != "alice29.txt" and cls in ("elf", "xml", "exe", "database") and picked < 2:
+            files["corpus-" + name] = b"".join(bl)
+            picked += 1
+    return files
+
+
+SHORT = ("empty", "random4k", "zero4k", "alice29")
+
+
+def _run(cmd, data, preload):
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    if preload:
+        env["LD_PRELOAD"] = PRELOAD
+        env["NX_GZIP_TYPE_SELECTOR"] = "2"          # the engine, always: no AUTO-mode escape to software zlib
+    p = subprocess.run([MINIGZ] + cmd, input=data, env=env, capture_output=True)
+    assert p.returncode == 0, (cmd, preload, p.stderr[-300:])
+    return p.stdout
+
+
+def _combo(args):
+    name, data, level, typ, want = args
+    z = ["-z"] if typ == "deflate" else []
+    lv = ["-%d" % level]
+    failures = []
+    nx_comp = _run(z + lv, data, True)
+    if hashlib.sha256(_run(z + ["-d"], nx_comp, False)).hexdigest() != want:
+        failures.append("%s.%d.compress.%s" % (name, level, typ))
+    if hashlib.sha256(_run(z + ["-d"], nx_comp, True)).hexdigest() != want:
+        failures.append("%s.%d.compdecomp.%s" % (name, level, typ))
+    sw_comp = _run(z + lv, data, False)
+    if hashlib.sha256(_run(z + ["-d"], sw_comp, True)).hexdigest() != want:
+        failures.append("%s.%d.decompress.%s" % (name, level, typ))
+    # the engine's output is a real compression of compressible data (not a stored copy)
+    if name in ("zero13M", "sparse10M", "alice29") and len(nx_comp) > len(data) // 2:
+        failures.append("%s.%d.%s: %d bytes out of %d" % (name, level, typ, len(nx_comp), len(data)))
+    return failures
+
+
+def test_oct_matrix_under_ld_preload():
+    assert os.path.exists(MINIGZ) and os.path.exists(PRELOAD)
+    files = _inputs()
+    combos = []
+    for name, data in files.items():
+        want = hashlib.sha256(data).hexdigest()
+        for level in (range(1, 10) if name in SHORT else (1, 6, 9)):
+            for typ in ("gzip", "deflate"):
+                combos.append((name, data, level, typ, want))
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        failures = [f for fl in ex.map(_combo, combos) for f in fl]
+    assert not failures, failures
+    assert len(combos) >= 4 * 9 * 2 + 3 * 3 * 2
+
+
+def test_the_client_really_lands_in_the_engine(tmp_path):
+    """the matrix would pass with a preload that did nothing: the library's call statistics (NX_GZIP_TRACE=8, the
+    lines of the reference's print_stats, lib/nx_zlib.c:876-955) count the client's deflate / inflate calls as
+    served by the engine ("(nx)"), none by software zlib"""
+    import re
+    data = open(os.path.join(ROOT, "tests", "golden", "alice29.txt"), "rb").read() * 8
+    for cmd, key in ((["-z", "-6"], "deflate"), (["-z", "-d"], "inflate")):
+        log = tmp_path / (key + ".log")
+        env = dict(os.environ, LD_PRELOAD=PRELOAD, NX_GZIP_TYPE_SELECTOR="2", NX_GZIP_TRACE="8", NX_GZIP_LOGFILE=str(log))
+        inp = data if key == "deflate" else __import__("zlib").compress(data, 6)
+        p = subprocess.run([MINIGZ] + cmd, input=inp, env=env, capture_output=True)
+        assert p.returncode == 0, p.stderr[-300:]
+        text = log.read_text(errors="replace")
+        nx = re.search(r"%s\(nx\): (\d+)" % key, text)
+        sw = re.search(r"%s\(sw\): (\d+)" % key, text)
+        assert nx and int(nx.group(1)) > 0, text[-600:]
+        assert sw and int(sw.group(1)) == 0, text[-600:]

@@ -314,3 +314,37 @@ def test_next_in_stands_right_behind_the_stream_at_stream_end(L, size, step_out)
     assert L.nx_inflate(C.byref(st2), Z.Z_FINISH) == Z.Z_STREAM_END
     assert out2.raw[:st2.total_out] == b and st2.avail_in == 0
     L.nx_inflateEnd(C.byref(st2))
+
+
+@pytest.mark.parametrize("n", [0, 10, 4096, 300000])
+def test_canonical_zpipe_loop_sees_the_end_of_short_streams_and_short_last_chunks(L, n):
+    """The canonical client loop of zlib's zpipe.c (the reference ships it: samples/zpipe.c:100-146): feed what a
+    read gave with Z_NO_FLUSH, stop at Z_STREAM_END, treat end of input before that as a truncated stream.  A
+    stream shorter than the reference's input cache threshold, or whose last chunk is, must still end in
+    Z_STREAM_END within the call that brings its last byte (found by tests/test_gpu_oct.py)."""
+    data = make_block("alice", n, 5) if n else b""
+    comp = zlib.compress(data, 6)
+    chunk = 4096 if n < 100000 else len(comp) - 200            # the long one: a 200-byte last chunk
+    st = Z.ZStream()
+    assert L.nx_inflateInit2_(C.byref(st), 15, Z.VERSION, C.sizeof(Z.ZStream)) == Z.Z_OK
+    out = C.create_string_buffer(1 << 19)
+    got = bytearray()
+    rc = Z.Z_OK
+    pos = 0
+    while rc != Z.Z_STREAM_END:
+        piece = comp[pos:pos + chunk]
+        pos += len(piece)
+        assert piece, "end of input before Z_STREAM_END"
+        src = C.create_string_buffer(piece, len(piece))
+        st.next_in = C.addressof(src)
+        st.avail_in = len(piece)
+        while True:
+            st.next_out = C.addressof(out)
+            st.avail_out = len(out)
+            rc = L.nx_inflate(C.byref(st), Z.Z_NO_FLUSH)
+            assert rc in (Z.Z_OK, Z.Z_STREAM_END, Z.Z_BUF_ERROR), rc
+            got += out.raw[:len(out) - st.avail_out]
+            if st.avail_out != 0:
+                break
+    L.nx_inflateEnd(C.byref(st))
+    assert bytes(got) == data
