@@ -40,6 +40,10 @@ typedef struct nxz_config {
 	int      mode_deflate, mode_inflate;
 	uint32_t def_buf_size;
 	uint32_t cache_threshold;
+	uint64_t auto_comp_min, auto_dec_min;        /* AUTO mode: a one-shot call, or the first deflate() / inflate() call of a
+						      * stream, with fewer input bytes than this is served by software zlib
+						      * (NX_GZIP_AUTO_COMP_MIN / NX_GZIP_AUTO_DEC_MIN, keys auto_comp_min /
+						      * auto_dec_min; the reference's rule is a fixed 1024 bytes, lib/nx_zlib.h:88-89) */
 	uint64_t compress_delay, decompress_delay;   /* AUTO mode: average job delay (512 MHz ticks) above which new
 						      * streams go to software zlib (lib/nx_zlib.c:1121-1122,1306-1318) */
 	char     logfile[256];

@@ -55,6 +55,11 @@ void load_locked()
 	c.def_buf_size = 1u << 20;                     // lib/nx_zlib.c:1115
 	c.cache_threshold = 8192;                      // :1116
 	c.mode_deflate = c.mode_inflate = NXZ_MODE_AUTO;
+	// AUTO mode's break-even, measured on MI355X against system zlib on the host's cores with the reference's own
+	// harness shape (tools/api_sweep.py, profiles/r03_api_sweep.txt): below these sizes a call costs its fixed
+	// launches and copies (0.2 - 0.3 ms) and software zlib is faster
+	c.auto_comp_min = 128u << 10;
+	c.auto_dec_min = 1u << 20;
 	c.decompress_delay = 17000000;                 // lib/nx_zlib.c:1121-1122 (timebase ticks)
 	c.compress_delay = 100000000;
 
@@ -97,6 +102,8 @@ void load_locked()
 	}
 	if (const char *d = get("NX_GZIP_DHT_CONFIG", "dht_config")) c.dht = (int)nxz_str_to_num(d);
 	if (const char *d = get("NX_GZIP_DEV_NUM", "dev_num")) c.dev_num = atoi(d);
+	if (const char *v = get("NX_GZIP_AUTO_COMP_MIN", "auto_comp_min")) c.auto_comp_min = nxz_str_to_num(v);
+	if (const char *v = get("NX_GZIP_AUTO_DEC_MIN", "auto_dec_min")) c.auto_dec_min = nxz_str_to_num(v);
 	if (const char *t = get(nullptr, "cache_threshold")) {                     // file only (:1166, 1295-1299)
 		uint64_t v = nxz_str_to_num(t);
 		long pg = sysconf(_SC_PAGESIZE);

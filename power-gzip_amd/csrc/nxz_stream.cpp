@@ -123,6 +123,7 @@ struct Deflate {
 	uint64_t magic = MAGIC_DEF;
 	z_streamp z = nullptr;
 	int wrap = HDR_ZLIB, level = 6, strategy = Z_DEFAULT_STRATEGY;
+	int init_wbits = 15, init_level = -1;               // as the caller gave them (AUTO mode may reopen the stream in software zlib)
 	uint32_t max_history = 0;
 	enum St { INIT, BUSY, BFINAL, TRAILER } st = INIT;
 	std::vector<uint8_t> pend; size_t pend_off = 0;     // complete bytes waiting for next_out
@@ -503,6 +504,7 @@ extern "C" int nx_deflateInit2_(z_streamp strm, int level, int method, int windo
 	if (windowBits != 15 && windowBits != 31 && windowBits != -15) return Z_STREAM_ERROR;     // :609-613
 	if (method != Z_DEFLATED || (strategy != Z_FIXED && strategy != Z_DEFAULT_STRATEGY)) return Z_STREAM_ERROR;
 	uint32_t maxhist;
+	const int level_in = level;
 	switch (level) {                                                                           // :654-680
 	case 0: level = 6; maxhist = 0; break;                                                    // (Q2)
 	case Z_DEFAULT_COMPRESSION: case 1: case 2: case 3: case 4: maxhist = 0; break;
@@ -515,6 +517,7 @@ extern "C" int nx_deflateInit2_(z_streamp strm, int level, int method, int windo
 	if (!s->eng.begin()) { delete s; return Z_STREAM_ERROR; }                                  // "cannot open NX device"
 	s->z = strm;
 	s->wrap = windowBits < 0 ? HDR_RAW : windowBits > 15 ? HDR_GZIP : HDR_ZLIB;
+	s->init_wbits = windowBits; s->init_level = level_in;
 	s->level = level; s->max_history = maxhist;
 	// NX_GZIP_STRATEGY=0 forces fixed Huffman whatever the caller asked for (lib/nx_deflate.c:648-652)
 	s->strategy = (strategy == Z_FIXED || nxz_config()->strategy_override == 0) ? Z_FIXED : Z_DEFAULT_STRATEGY;
@@ -640,6 +643,7 @@ struct Inflate {
 	uint64_t magic = MAGIC_INF;
 	z_streamp z = nullptr;
 	int wrap = HDR_ZLIB | HDR_GZIP, window_bits = 15;
+	int init_wbits = 47;                               // as the caller gave it
 	enum St { HEADER, GZ_ID2, GZ_CM, GZ_FLG, GZ_MTIME, GZ_XFL, GZ_OS, GZ_XLEN, GZ_EXTRA, GZ_NAME, GZ_COMMENT, GZ_HCRC,
 		  ZL_CMF, ZL_FLG, ZL_DICTID, NEED_DICT, BODY, TRAILER, DONE, BAD } st = HEADER;
 	uint32_t held = 0, nheld = 0, gzflags = 0, xlen = 0, zcmf = 0, dictid = 0;
@@ -1046,7 +1050,24 @@ extern "C" int nx_inflateInit2_(z_streamp strm, int windowBits, const char *vers
 	strm->state = (struct internal_state *)s;
 	int rc = nx_inflateReset2(strm, windowBits);
 	if (rc != Z_OK) { s->eng.end(); delete s; strm->state = Z_NULL; }
+	else s->init_wbits = windowBits;
 	return rc;
+}
+
+// AUTO mode's switchable streams (nxz_host.h)
+extern "C" int nxz_inflate_pristine(z_streamp strm, int *wbits)
+{
+	Inflate *s = istate(strm);
+	if (!s || s->st != Inflate::HEADER || s->nheld || s->have_dict || s->gzhead || strm->total_in || strm->total_out || !s->carry.empty()) return 0;
+	*wbits = s->init_wbits;
+	return 1;
+}
+extern "C" int nxz_deflate_pristine(z_streamp strm, int *level, int *wbits, int *strategy)
+{
+	Deflate *s = dstate(strm);
+	if (!s || s->st != Deflate::INIT || s->used || s->dict_len || s->gzhead || s->hist_len || strm->total_in || strm->total_out) return 0;
+	*level = s->init_level; *wbits = s->init_wbits; *strategy = s->strategy;
+	return 1;
 }
 
 extern "C" int nx_inflateInit_(z_streamp strm, const char *version, int stream_size)

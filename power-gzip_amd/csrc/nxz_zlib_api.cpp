@@ -8,7 +8,8 @@
 //   inflate; NX_GZIP_COMP_MODE / NX_GZIP_DEC_MODE per direction; the same keys in the file named by
 //   NX_GZIP_CONFIG (lib/nx_zlib.c:1067-1217; parsed by nxz_config.cpp).  NX_GZIP_TRACE=8 gathers the
 //   reference's call statistics here, in the dispatch layer, as lib/nx_deflate.c:2472-2520 does.
-// Auto: one-shot calls of <= 1024 bytes go to zlib (lib/nx_zlib.h:88-89); everything goes to zlib
+// Auto: one-shot calls and streams whose first call brings less than the measured break-even (nxz_config
+// auto_comp_min / auto_dec_min; the reference: <= 1024 bytes, lib/nx_zlib.h:88-89) go to zlib; everything goes to zlib
 // when no engine can be opened.  A stream stays with the backend that initialised it; which one
 // that was is read from the state tag, so no stream map is needed (the reference keeps one for
 // its switchable AUTO streams, lib/nx_map.c).
@@ -22,6 +23,7 @@
 #include "../../include/nxz_engine.h"
 #include "../../include/nxz_zlib.h"
 #include "../../include/nxz_config.h"
+#include "nxz_host.h"
 #include <time.h>
 
 namespace {
@@ -147,10 +149,49 @@ EXPORT int deflateInit_(z_streamp s, int level, const char *ver, int size)
 	return deflateInit2_(s, level, Z_DEFLATED, 15, 8, Z_DEFAULT_STRATEGY, ver, size);
 }
 #define DISPATCH_DEF(call_nx, call_sw, err) do { init(); if (is_nx(s, MAGIC_DEF)) return call_nx; return sw.deflate ? call_sw : err; } while (0)
+// AUTO mode, first call of a stream: a caller that brings less than the break-even (nxz_config auto_comp_min /
+// auto_dec_min: measured, tools/api_sweep.py) is better served by software zlib -- the engine stream, to which
+// nothing has happened yet, is closed and the same z_stream reopened there with the parameters it was made with.
+// (The reference's switchable AUTO streams, lib/nx_map.c, lib/nx_zlib.h:376-422; its size rule is a fixed
+// 1024 bytes for one-shot calls only, lib/nx_zlib.h:88-89.)
+static bool auto_to_sw_deflate(z_streamp s, int flush)
+{
+	if (g_mode_def != MODE_AUTO || !sw.deflateInit2_ || !s || s->avail_in >= nxz_config()->auto_comp_min) return false;
+	if (flush != Z_FINISH && s->avail_in == 0) return false;           // (nothing to judge by yet)
+	int level, wbits, strategy;
+	if (!nxz_deflate_pristine(s, &level, &wbits, &strategy)) return false;
+	z_stream keep = *s;
+	nx_deflateEnd(s);
+	if (sw.deflateInit2_(s, level, Z_DEFLATED, wbits, 8, strategy, ZLIB_VERSION, (int)sizeof(z_stream)) != Z_OK) {
+		// (cannot happen with parameters the engine took; back to an engine stream)
+		*s = keep; s->state = Z_NULL;
+		(void)nx_deflateInit2_(s, level, Z_DEFLATED, wbits, 8, strategy, ZLIB_VERSION, (int)sizeof(z_stream));
+		return false;
+	}
+	s->next_in = keep.next_in; s->avail_in = keep.avail_in; s->next_out = keep.next_out; s->avail_out = keep.avail_out;
+	return true;
+}
+static bool auto_to_sw_inflate(z_streamp s)
+{
+	if (g_mode_inf != MODE_AUTO || !sw.inflateInit2_ || !s || s->avail_in == 0 || s->avail_in >= nxz_config()->auto_dec_min) return false;
+	int wbits;
+	if (!nxz_inflate_pristine(s, &wbits)) return false;
+	z_stream keep = *s;
+	nx_inflateEnd(s);
+	if (sw.inflateInit2_(s, wbits, ZLIB_VERSION, (int)sizeof(z_stream)) != Z_OK) {
+		*s = keep; s->state = Z_NULL;
+		(void)nx_inflateInit2_(s, wbits, ZLIB_VERSION, (int)sizeof(z_stream));
+		return false;
+	}
+	s->next_in = keep.next_in; s->avail_in = keep.avail_in; s->next_out = keep.next_out; s->avail_out = keep.avail_out;
+	return true;
+}
+
 EXPORT int deflate(z_streamp s, int flush)
 {
 	init();
-	const bool nx = is_nx(s, MAGIC_DEF);
+	bool nx = is_nx(s, MAGIC_DEF);
+	if (nx && s->total_in == 0 && auto_to_sw_deflate(s, flush)) nx = false;
 	if (!nx && !sw.deflate) return Z_STREAM_ERROR;
 	if (!nxz_stats_enabled()) return nx ? nx_deflate(s, flush) : sw.deflate(s, flush);
 	const unsigned ai = s ? s->avail_in : 0, ao = s ? s->avail_out : 0;
@@ -195,7 +236,8 @@ EXPORT int inflateInit_(z_streamp s, const char *ver, int size) { return inflate
 EXPORT int inflate(z_streamp s, int flush)
 {
 	init();
-	const bool nx = is_nx(s, MAGIC_INF);
+	bool nx = is_nx(s, MAGIC_INF);
+	if (nx && s->total_in == 0 && auto_to_sw_inflate(s)) nx = false;
 	if (!nx && !sw.inflate) return Z_STREAM_ERROR;
 	if (!nxz_stats_enabled()) return nx ? nx_inflate(s, flush) : sw.inflate(s, flush);
 	const unsigned ai = s ? s->avail_in : 0, ao = s ? s->avail_out : 0;
@@ -218,7 +260,7 @@ EXPORT int compress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong so
 {
 	init();
 	nxz_stats_inc("compress");
-	bool nx = nxz_engine_usable() && (g_mode_def == MODE_NX || (g_mode_def == MODE_AUTO && g_engine && sourceLen > 1024));
+	bool nx = nxz_engine_usable() && (g_mode_def == MODE_NX || (g_mode_def == MODE_AUTO && g_engine && sourceLen >= nxz_config()->auto_comp_min));
 	if (nx && slow(g_mode_def, nxz_config()->compress_delay)) nx = false;     // as deflateInit decides (lib/nx_deflate.c:714)
 	if (nx) return nx_compress2(dest, destLen, source, sourceLen, level);
 	return sw.compress2 ? sw.compress2(dest, destLen, source, sourceLen, level) : Z_STREAM_ERROR;
@@ -237,7 +279,7 @@ EXPORT int uncompress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong 
 {
 	init();
 	nxz_stats_inc("uncompress");
-	bool nx = nxz_engine_usable() && (g_mode_inf == MODE_NX || (g_mode_inf == MODE_AUTO && g_engine && *sourceLen > 1024));
+	bool nx = nxz_engine_usable() && (g_mode_inf == MODE_NX || (g_mode_inf == MODE_AUTO && g_engine && *sourceLen >= nxz_config()->auto_dec_min));
 	if (nx && slow(g_mode_inf, nxz_config()->decompress_delay)) nx = false;
 	if (nx) return nx_uncompress2(dest, destLen, source, sourceLen);
 	if (sw.uncompress2) return sw.uncompress2(dest, destLen, source, sourceLen);

@@ -17,13 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PRELOAD = os.path.join(ROOT, "power-gzip_amd", "libnxz_preload.so")
 KNOBS = ["NX_GZIP_CONFIG", "NX_GZIP_TYPE_SELECTOR", "NX_GZIP_COMP_MODE", "NX_GZIP_DEC_MODE", "NX_GZIP_STRATEGY",
          "NX_GZIP_DHT_CONFIG", "NX_GZIP_TRACE", "NX_GZIP_VERBOSE", "NX_GZIP_LOGFILE", "NX_GZIP_DEV_NUM",
-         "NX_GZIP_DEF_BUF_SIZE"]
+         "NX_GZIP_DEF_BUF_SIZE", "NX_GZIP_AUTO_COMP_MIN", "NX_GZIP_AUTO_DEC_MIN"]
 
 
 class Config(C.Structure):
     _fields_ = [("verbose", C.c_int), ("trace", C.c_int), ("dht", C.c_int), ("strategy_override", C.c_int),
                 ("dev_num", C.c_int), ("mode_deflate", C.c_int), ("mode_inflate", C.c_int),
                 ("def_buf_size", C.c_uint32), ("cache_threshold", C.c_uint32),
+                ("auto_comp_min", C.c_uint64), ("auto_dec_min", C.c_uint64),
                 ("compress_delay", C.c_uint64), ("decompress_delay", C.c_uint64),
                 ("logfile", C.c_char * 256), ("cfgfile", C.c_char * 256), ("cfgfile_loaded", C.c_int)]
 
@@ -74,6 +75,10 @@ def test_defaults(tmp_path):
         assert (c.mode_deflate, c.mode_inflate) == (0, 0)
         assert c.def_buf_size == 1 << 20 and c.cache_threshold == 8192
         assert c.logfile == b"/tmp/nx.log" and c.cfgfile_loaded == 0
+        # AUTO mode's break-even sizes (measured, profiles/r03_api_sweep.txt); environment and file keys
+        assert (c.auto_comp_min, c.auto_dec_min) == (128 << 10, 1 << 20)
+        c = reload(L, tmp_path, env={"NX_GZIP_AUTO_COMP_MIN": "1MiB"}, file_text="auto_dec_min = 4096\n")
+        assert (c.auto_comp_min, c.auto_dec_min) == (1 << 20, 4096)
     finally:
         reload(L, tmp_path)
 

@@ -114,3 +114,50 @@ def test_the_client_really_lands_in_the_engine(tmp_path):
         sw = re.search(r"%s\(sw\): (\d+)" % key, text)
         assert nx and int(nx.group(1)) > 0, text[-600:]
         assert sw and int(sw.group(1)) == 0, text[-600:]
+
+
+def test_auto_mode_routes_by_the_measured_break_even(tmp_path):
+    """AUTO mode (the default, NX_GZIP_TYPE_SELECTOR=0): a stream whose first call brings less than the break-even
+    (nxz_config auto_comp_min 128 KiB / auto_dec_min 1 MiB, measured against zlib on the same box:
+    profiles/r03_api_sweep.txt) is reopened in software zlib; larger calls go to the engine.  Either way the
+    bytes round-trip."""
+    import re
+    import zlib
+    alice = open(os.path.join(ROOT, "tests", "golden", "alice29.txt"), "rb").read()
+
+    def stats(cmd, inp, key):
+        log = tmp_path / ("auto_%s_%d.log" % (key, len(inp)))
+        env = dict(os.environ, LD_PRELOAD=PRELOAD, NX_GZIP_TYPE_SELECTOR="0", NX_GZIP_TRACE="8", NX_GZIP_LOGFILE=str(log))
+        p = subprocess.run([MINIGZ] + cmd, input=inp, env=env, capture_output=True)
+        assert p.returncode == 0, p.stderr[-300:]
+        text = log.read_text(errors="replace")
+        return p.stdout, int(re.search(r"%s\(nx\): (\d+)" % key, text).group(1)), int(re.search(r"%s\(sw\): (\d+)" % key, text).group(1))
+
+    small, big = alice[:40000], alice * 8                     # one call of 40 000 bytes; 256 KiB chunks
+    out, nx, sw = stats(["-z", "-6"], small, "deflate")
+    assert nx == 0 and sw > 0 and zlib.decompress(out) == small
+    out, nx, sw = stats(["-z", "-6"], big, "deflate")
+    assert nx > 0 and sw == 0 and zlib.decompress(out) == big
+    out, nx, sw = stats(["-z", "-d"], zlib.compress(small, 6), "inflate")
+    assert nx == 0 and sw > 0 and out == small
+    rnd = __import__("random").Random(7).randbytes(3 << 20)    # 3 MiB that do not compress
+    big_z = zlib.compress(rnd, 1)
+    out, nx, sw = stats(["-z", "-d"], big_z, "inflate")         # minigz feeds 256 KiB per call: below the 1 MiB break-even
+    assert nx == 0 and sw > 0 and out == rnd
+    # the one-shot call with the whole stream at hand goes to the engine
+    code = (
+        "import ctypes as C, sys, zlib\n"
+        "L = C.CDLL(None)\n"
+        "data = open(sys.argv[1], 'rb').read()\n"
+        "n = C.c_ulong(4 << 20); dst = C.create_string_buffer(4 << 20)\n"
+        "L.uncompress.argtypes = [C.c_char_p, C.POINTER(C.c_ulong), C.c_char_p, C.c_ulong]\n"
+        "assert L.uncompress(dst, C.byref(n), data, len(data)) == 0\n"
+        "sys.stdout.buffer.write(dst.raw[:n.value])\n")
+    f = tmp_path / "big.z"
+    f.write_bytes(big_z)
+    log = tmp_path / "oneshot.log"
+    env = dict(os.environ, LD_PRELOAD=PRELOAD, NX_GZIP_TYPE_SELECTOR="0", NX_GZIP_TRACE="8", NX_GZIP_LOGFILE=str(log))
+    p = subprocess.run([__import__("sys").executable, "-c", code, str(f)], env=env, capture_output=True)
+    assert p.returncode == 0 and p.stdout == rnd, p.stderr[-300:]
+    text = log.read_text(errors="replace")
+    assert int(re.search(r"inflate\(nx\): (\d+)", text).group(1)) > 0 or "uncompress: 1" in text, text[-500:]

@@ -9,7 +9,14 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#ifdef USE_ZLIB       /* the same harness on system zlib: the CPU beside it (-DUSE_ZLIB -lz) */
+#include <zlib.h>
+#define nx_compressBound compressBound
+#define nx_compress2 compress2
+#define nx_uncompress uncompress
+#else
 #include "../include/nxz_zlib.h"
+#endif
 
 static uint8_t *g_data;
 static size_t g_len, g_buf, g_per;
