@@ -1,0 +1,62 @@
+"""Register / scratch budgets of the HIP kernels, checked at build time without a GPU (hipcc cross-compiles for
+gfx950; -Rpass-analysis=kernel-resource-usage).  Round 2 lost 12 % on the zlib -6 inflate leg because the
+stream-per-wave kernel drifted from 96 to 99 VGPRs -- a wavefront per SIMD -- and only a slow bench showed it
+(housekeeping item 8).  The budgets are the occupancy steps of MI355X_MICROARCH.md's register table:
+<= 64 VGPRs: 8 waves per SIMD, 96: 5, 128: 4.  The full table of a round is kept in profiles/rNN_kernel_resource_usage.txt
+(tools/resource_usage.py)."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# kernel -> (max VGPRs, max scratch bytes per lane)
+BUDGET = {
+    "nxzl77::lz77_kernel<false>": (128, 64),          # 1024 threads per workgroup: 128 is the cap
+    "nxzl77::lz77_kernel<true>": (128, 64),
+    "nxze::encode_kernel<false>": (64, 0),            # seven workgroups of 256 threads per CU
+    "nxze::encode_kernel<true>": (64, 0),
+    "nxzd::dhtgen_kernel": (64, 0),
+    "nxzi::inflate_kernel<true, false>": (96, 0),     # a stream per wave, the target as window: five waves per SIMD
+    "nxzi::inflate_kernel<true, true>": (96, 0),
+    "nxzi::inflate_kernel<false, false>": (128, 0),   # window in LDS: LDS bounds the occupancy, not registers
+    "nxzi::inflate_kernel<false, true>": (128, 0),
+    "nxzl::inflate_lanes_kernel": (128, 32),
+    "nxzl::cksum_kernel": (96, 0),
+    "nxzb::find_blocks_kernel": (96, 0),
+    "nxzi::token_sync_kernel": (64, 0),
+    "nxzi::block_tables_kernel": (64, 0),
+    "nxzb::resolve_kernel": (64, 0),
+    "nxzb::window_chain_kernel": (64, 0),
+    "nxz::pack_stream_kernel": (64, 0),
+    "nxz::wrap_kernel": (64, 0),
+}
+
+
+@pytest.fixture(scope="module")
+def usage():
+    spec = importlib.util.spec_from_file_location("resource_usage", os.path.join(ROOT, "tools", "resource_usage.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.collect()
+
+
+def test_every_kernel_stays_inside_its_register_budget(usage):
+    over = []
+    for k, (vmax, smax) in BUDGET.items():
+        assert k in usage, (k, sorted(usage))
+        u = usage[k]
+        if u["VGPRs"] > vmax or u.get("ScratchSize", 0) > smax:
+            over.append((k, u["VGPRs"], vmax, u.get("ScratchSize", 0), smax))
+    assert not over, over
+
+
+def test_no_kernel_is_missing_from_the_recorded_table(usage):
+    """the table committed for the round lists every kernel the sources define (so a new kernel gets a line -- and,
+    if it is on the hot path, a budget)"""
+    rec = [f for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if f.endswith("_kernel_resource_usage.txt")]
+    assert rec, "run tools/resource_usage.py > profiles/rNN_kernel_resource_usage.txt"
+    text = open(os.path.join(ROOT, "profiles", rec[-1])).read()
+    missing = [k for k in usage if k[:58] not in text]
+    assert not missing, missing
