@@ -61,6 +61,7 @@ typedef struct nxz_walk_res { uint64_t bit; uint32_t flags, reserved; } nxz_walk
 int nxz_launch_stored_walk(const nxz_walk_req_t *reqs, uint32_t n, nxz_walk_res_t *res, hipStream_t stream);
 int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, const void *built,
 			   int few_and_even, hipStream_t stream);
+int nxz_launch_sample_btype(const nxz_batch_job_t *jobs, size_t n, uint32_t *out, hipStream_t stream);   /* out: pinned host word */
 int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n, uint32_t final_index,
 			   uint64_t *offsets, uint8_t *packed, hipStream_t stream);

@@ -69,6 +69,8 @@ struct nxz_ctx {
 	Slot slots[SLOTS];
 	// batch scratch, one set per stream the caller launches on: launches on different streams may
 	// run at the same time, so they must not share the prepared tables or the decode workspace
+	uint32_t *h_sample = nullptr;                 // pinned words the block-type sample of a large inflate batch lands in
+	unsigned sample_turn = 0;
 	struct Scratch {
 		nxz_dht_prepared_t *d_prepared = nullptr;
 		size_t prepared_cap = 0;
@@ -136,6 +138,11 @@ static constexpr unsigned JOB_COUNTERS = 256;
 //   from NXZ_LANES_MIN streams on      a stream per lane: 55-60 ms however few streams, 51 GiB/s at 65 536,
 //                                      110 at 262 144
 // The wave kernels need 16-byte aligned sources, as the batch interface demands.
+// Round 3 (profiles/r03_inflate_by_batch_size.txt): the lane kernel wins only on streams of fixed-Huffman (or stored)
+// blocks -- one table for all lanes -- from about 100 000 streams on (91 against 44 GiB/s at 262 144); streams that
+// bring a table each (zlib's, the engine's own exact-table output) run twice as fast a stream per wave at every batch
+// size (81 against 40).  So a batch of NXZ_LANES_MIN streams or more is sampled first: 256 of its streams, the type
+// of their first block.
 #define NXZ_LANES_MIN 131072
 #define NXZ_WINDOW_LDS_MAX 1024
 
@@ -257,6 +264,7 @@ extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 	for (auto &s : c->slots) if (s.stream) slot_free(s);
 	for (auto &kv : c->scratch) kv.second.release();
 	if (c->d_job_counters) (void)hipFree(c->d_job_counters);
+	if (c->h_sample) (void)hipHostFree(c->h_sample);
 	for (auto &l : c->lanes) {
 		if (!l.stream) continue;
 		(void)hipStreamSynchronize(l.stream);
@@ -434,7 +442,21 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 	int rc;
 	const char *lm = getenv("NXZ_INFLATE_LANES_MIN");                    // tuning / test knob
 	const size_t lanes_min = lm ? (size_t)strtoull(lm, nullptr, 0) : (size_t)NXZ_LANES_MIN;
-	if (n >= lanes_min) {
+	bool lanes = n >= lanes_min;
+	if (lanes && !lm) {
+		// what kind of streams?  (one small launch and a wait for it: nothing next to the tens of milliseconds such a batch takes)
+		uint32_t *h = nullptr;
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			if (!c->h_sample) (void)hipHostMalloc((void **)&c->h_sample, 64 * sizeof(uint32_t));
+			h = c->h_sample ? c->h_sample + (c->sample_turn++ & 63) : nullptr;
+		}
+		if (h) {
+			*h = 0;
+			if (nxz_launch_sample_btype(jobs, n, h, s) == 0 && hipStreamSynchronize(s) == hipSuccess && *h > 64) lanes = false;   // a quarter or more with tables
+		}
+	}
+	if (lanes) {
 		// many streams: one stream per lane (nxz_inflate_lanes.hip); the table workspace is made once
 		int init = 0;
 		uint8_t *ws;

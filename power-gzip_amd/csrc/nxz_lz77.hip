@@ -188,7 +188,9 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 						  nxz_batch_result_t *__restrict__ results,
 						  uint32_t *__restrict__ counts, uint32_t njobs, uint32_t *__restrict__ next_job)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	// (a static array: its address is a compile-time constant, 0; with `extern __shared__` every LDS address of the
+	// kernel carried one more vector add -- of a link-time zero --, 117 of them)
+	__shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
 	uint32_t *inw = (uint32_t *)(lds + OFF_IN);
 	uint32_t *head = (uint32_t *)(lds + OFF_HEAD);
 	uint16_t *cand = (uint16_t *)(lds + OFF_CAND);
@@ -777,9 +779,10 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 							const bool ok = (FULL || (i < tn && r + 4 <= end)) && ((w14 >> j) & 0x7ff) != 0x7ff;
 							const uint32_t maxlen = FULL || end - r >= MAXMATCH ? MAXMATCH : end - r;
 							const uint32_t v = j ? __builtin_amdgcn_alignbyte(d1, d0, j) : d0, v4 = j ? __builtin_amdgcn_alignbyte(d2, d1, j) : d1;
-							// a bucket entry (position + 1 from the chain, 0 = none): valid if inside the
-							// window with four equal bytes; n = equal bytes among the first eight
-							auto probe = [&](uint32_t entry, uint32_t &dist1, uint32_t &n8) -> bool {
+							// a bucket entry (position + 1 from the chain, 0 = none): a candidate if inside the
+							// window with four equal bytes; returns the equal bytes among the first eight (4..8),
+							// 0 if it is none
+							auto probe = [&](uint32_t entry, uint32_t &dist1) -> uint32_t {
 								const uint32_t qc = (uint16_t)(entry - 1);      // 0xffff = none
 								dist1 = r - qc - 1;                             // distance - 1; wraps to something huge if qc >= r
 								const bool qok = ok && dist1 < WINDOW;
@@ -787,21 +790,21 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 								const uint32_t qa = q >> 2, u0 = inw[qa], u1 = inw[qa + 1], u2 = inw[qa + 2];
 								const uint32_t qv = __builtin_amdgcn_alignbyte(u1, u0, q & 3), qv4 = __builtin_amdgcn_alignbyte(u2, u1, q & 3);
 								const uint32_t x = qv4 ^ v4;
-								n8 = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
-								if (!FULL && n8 > maxlen) n8 = maxlen;
-								return qok && qv == v;
+								uint32_t n8 = 4 + ((x ? (uint32_t)__builtin_ctz(x) : 32u) >> 3);
+								if (!FULL && n8 > maxlen) n8 = maxlen;          // (maxlen >= 4 where ok)
+								return qok && qv == v ? n8 : 0;
 							};
-							uint32_t d1st, n1st, d2nd, n2nd;
-							const bool ok1 = probe((j & 2 ? qq.y : qq.x) >> (16 * (j & 1)), d1st, n1st);
-							const bool ok2 = probe(q2[j], d2nd, n2nd);
+							uint32_t d1st, d2nd;
+							const uint32_t n1st = probe((j & 2 ? qq.y : qq.x) >> (16 * (j & 1)), d1st);
+							const uint32_t n2nd = probe(q2[j], d2nd);
 							// the older entry only if it has more of the first eight bytes (oracle/nxz_lz77.c step 4)
-							const bool second = ok2 && (!ok1 || n2nd > n1st);
-							okA[j] = ok1 || ok2;
-							dA[j] = second ? d2nd : d1st;
+							const bool second = n2nd > n1st;
 							const uint32_t lenA = second ? n2nd : n1st;
-							raw8[j] = okA[j] && lenA == 8;              // at least 8 bytes
+							okA[j] = lenA != 0;
+							dA[j] = second ? d2nd : d1st;
+							raw8[j] = lenA == 8;                        // at least 8 bytes
 							lng[j] = raw8[j] && (FULL || maxlen > 8);   // ... and possibly more
-							mw |= (okA[j] ? lenA - 3 : 0) << (8 * j);
+							mw |= (lenA ? lenA - 3 : 0) << (8 * j);
 							const uint32_t cj = okA[j] ? dA[j] : NOHASH;
 							if (j < 2) c01 |= cj << (16 * j); else c23 |= cj << (16 * (j - 2));
 							vbits |= (uint32_t)okA[j] << j;
@@ -1258,8 +1261,6 @@ extern "C" int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n,
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
 	int ncu = __atomic_load_n(&ncu_of[dev], __ATOMIC_ACQUIRE);
 	if (!ncu) {
-		(void)hipFuncSetAttribute((const void *)lz77_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-		(void)hipFuncSetAttribute((const void *)lz77_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
 		if (ncu <= 0) ncu = 256;
@@ -1269,6 +1270,6 @@ extern "C" int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n,
 	const unsigned grid = (unsigned)(n < (size_t)ncu ? n : (size_t)ncu);
 	if (n <= grid) job_counter = nullptr;                      // one job per workgroup: nothing to draw
 	if (job_counter && hipMemsetAsync(job_counter, 0, sizeof(uint32_t), stream) != hipSuccess) job_counter = nullptr;
-	hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS_BYTES, stream, jobs, tokens, cand2, results, counts, (uint32_t)n, job_counter);
+	hipLaunchKernelGGL(k, dim3(grid), dim3(NT), 0, stream, jobs, tokens, cand2, results, counts, (uint32_t)n, job_counter);
 	return (int)hipGetLastError();
 }

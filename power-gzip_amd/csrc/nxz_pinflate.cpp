@@ -115,15 +115,6 @@ struct Workspace {
 };
 constexpr int NWS = 8;
 Workspace g_ws[64][NWS];
-// Room for a piece's 16-bit output: CAPMUL0 elements per compressed byte to begin with (NXZ_PINFLATE_CAPMUL; a
-// piece that runs out of room -- CC 13 -- is decoded again from its start with 8 x as much, up to deflate's own
-// limit of 1032, and a repeated piece costs its whole decode time once more: 256 MiB of the corpus at zlib -6
-// take 11.2 ms at 100 x, 12.8 at 32 x, 15.7 at 16 x), and a floor that spares short pieces of very repetitive
-// data the repeat.  (Round 2 began at 100 x with a floor of 2 Mi elements per block piece: ~11 GB + 9 GB of
-// floors for that stream, per workspace, kept for good -- the advisor's finding.  48 x and floors of 32 / 128 Ki
-// elements: about 5 GB for it, 100 bytes of device memory per compressed byte.)
-static const uint32_t CAPMUL0 = getenv("NXZ_PINFLATE_CAPMUL") ? (uint32_t)atoi(getenv("NXZ_PINFLATE_CAPMUL")) : 48;
-constexpr uint64_t CAP_FLOOR_CUT = 32u << 10, CAP_FLOOR_BLOCK = 128u << 10;
 // A workspace that a call has grown beyond this is given back to the device when the call ends (NXZ_PINFLATE_KEEP_MB,
 // default 8192 MiB): the engine shares the device with its caller (torch, other libraries).
 inline size_t keep_bytes()
@@ -131,6 +122,22 @@ inline size_t keep_bytes()
 	static const size_t v = (size_t)(getenv("NXZ_PINFLATE_KEEP_MB") ? atoll(getenv("NXZ_PINFLATE_KEEP_MB")) : 8192) << 20;
 	return v;
 }
+// Room for a piece's 16-bit output: capmul elements per compressed byte to begin with (NXZ_PINFLATE_CAPMUL; a
+// piece that runs out of room -- CC 13 -- is decoded again from its start with 8 x as much, up to deflate's own
+// limit of 1032, and a repeated piece costs its whole decode time once more: 256 MiB of the corpus at zlib -6
+// take 11.2 ms at 100 x, 12.8 at 32 x, 15.7 at 16 x), and a floor that spares short pieces of very repetitive
+// data the repeat.  (Round 2 used 100 x with a floor of 2 Mi elements per block piece whatever the stream's
+// length: ~11 GB + 9 GB of floors for that stream, per workspace, kept for good -- the advisor's finding.)
+// The multiplier of a call: 100 x while the whole stream's buffers stay inside the memory a workspace may keep
+// (keep_bytes(): 200 bytes of device memory per compressed byte), less for longer streams, 32 x at least.
+static const uint32_t CAPMUL_ENV = getenv("NXZ_PINFLATE_CAPMUL") ? (uint32_t)atoi(getenv("NXZ_PINFLATE_CAPMUL")) : 0;
+static inline uint32_t capmul_for(uint64_t src_len)
+{
+	if (CAPMUL_ENV) return CAPMUL_ENV;
+	const uint64_t fit = keep_bytes() / (2 * (src_len ? src_len : 1));
+	return (uint32_t)(fit > 100 ? 100 : fit < 32 ? 32 : fit);
+}
+constexpr uint64_t CAP_FLOOR_CUT = 32u << 10, CAP_FLOOR_BLOCK = 128u << 10;
 struct TrimOnExit {
 	Workspace &w;
 	~TrimOnExit()
@@ -335,7 +342,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	pc.reserve(B.size() + subs.size());
 	for (size_t i = 0, k = 0; i < B.size(); i++) {
 		P p = P();
-		p.bit = B[i]; p.capmul = CAPMUL0; p.tab = -1;                  // buffer: 16 x the compressed size to begin with (x 8 per repeat), FLOOR elements at least
+		p.bit = B[i]; p.capmul = capmul_for(src_len); p.tab = -1;      // buffer: capmul x the compressed size to begin with (x 8 per repeat), a floor at least
 		p.hdr0 = i == 0 && st && (st->sfbt & 8) && (st->sfbt & 0xe) != 0xe ? 0 : 1;
 		pc.push_back(p);
 		p.hdr0 = 0;
@@ -561,7 +568,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 				// the next start behind that block, becomes a piece of its own -- a job that resumes inside a stored block.
 				P q = P();
 				q.bit = p.cstart * 8 + (p.stop ? p.stop : p.cbytes * 8) - r.subc;
-				q.capmul = CAPMUL0; q.tab = -1; q.hdr0 = 0; q.srem = r.tebc; q.sfin = r.sfbt & 1; q.done = false;
+				q.capmul = capmul_for(src_len); q.tab = -1; q.hdr0 = 0; q.srem = r.tebc; q.sfin = r.sfbt & 1; q.done = false;
 				swallow_until = std::max<uint64_t>(q.bit + (uint64_t)r.tebc * 8, run_end[i]);
 				if (q.bit > p.bit && !(q.bit & 7)) {
 					nx.push_back(p);

@@ -752,11 +752,13 @@ bool parallel_inflate(Inflate *s)
 	nxz_ctx_t *ctx = (nxz_ctx_t *)s->eng.dev.paste_addr;
 	if (!ctx) return false;
 	// all of next_in when the target can take what it makes; otherwise about a megabyte at a time (the surplus
-	// output waits in `pend`)
+	// output waits in `pend`: room for 32 x the part's size, so that -- whatever next_in moves over being what the
+	// engine has used -- a part is as good as always used up and the caller's next call brings a whole new part
+	// instead of the shrinking remainder of this one)
 	size_t take = z->avail_in;
 	if (z->avail_out < 2 * (nc + take)) take = std::min<size_t>(take, std::max<size_t>(1u << 20, z->avail_out));
 	const size_t nin = nc + take, nh = s->hist.size();
-	const size_t cap = z->avail_out >= 2 * nin ? (size_t)z->avail_out : std::max<size_t>(z->avail_out, 8 * nin);
+	const size_t cap = z->avail_out >= 2 * nin ? (size_t)z->avail_out : std::max<size_t>(z->avail_out, 32 * nin);
 	// device buffers for the stream and its output and a HIP stream to work on: a few sets, kept from call to call
 	// (grow only); callers on different threads take different sets and run side by side
 	struct Slot {

@@ -1,0 +1,72 @@
+"""Which batched inflate kernel for which batch: a stream per wave (the target as window) against a stream per
+lane, by batch size and by kind of stream (zlib -6 dynamic streams of the corpus blocks; the engine's own
+fixed-Huffman output of the synthetic blocks; its own exact-table output of the corpus).  Forces the kernel with
+NXZ_INFLATE_LANES_MIN; prints GiB/s of uncompressed bytes out.  -> profiles/rNN_inflate_by_batch_size.txt"""
+import importlib, os, sys, zlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import bench, corpus
+pkg = importlib.import_module("power-gzip_amd")
+B, S = 65536, 73856
+sizes = [int(x) for x in os.environ.get("SIZES", "4096,16384,65536,131072,262144").split(",")]
+_, blocks, _ = corpus.load(B)
+raw = [b for _, _, b in blocks if len(b) == B]
+
+
+def timed(eng, jobs, n):
+    eng.decompress(jobs, n)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(2):
+        res = eng.decompress(jobs, n)
+    e1.record()
+    torch.cuda.synchronize()
+    r = eng.results_to_host(res)
+    assert (r["cc"] == 0).all()
+    return e0.elapsed_time(e1) / 2
+
+
+print("%-34s %8s | %12s %12s" % ("streams", "n", "per wave", "per lane"))
+for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "own exact tables (corpus)"):
+    for n in sizes:
+        row = []
+        for kernel in ("waves", "lanes"):
+            os.environ["NXZ_INFLATE_LANES_MIN"] = "1" if kernel == "lanes" else "1000000000"
+            os.environ["NXZ_INFLATE_LDS_MAX"] = "0"
+            eng = pkg.Engine(0)
+            if kind.startswith("zlib"):
+                streams = []
+                for b in raw:
+                    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+                    streams.append(c.compress(b) + c.flush())
+                cs = (max(len(s) for s in streams) + 64 + 15) & ~15
+                host = np.zeros((len(raw), cs), np.uint8)
+                for i, s in enumerate(streams):
+                    host[i, :len(s)] = np.frombuffer(s, np.uint8)
+                rep = -(-n // len(raw))
+                src = torch.from_numpy(host).to(eng.dev).repeat(rep, 1)[:n]
+                clen = np.tile(np.array([len(s) for s in streams], np.uint32), rep)[:n]
+                dst = torch.zeros((n, B), dtype=torch.uint8, device=eng.dev)
+                jobs = eng.jobs_strided(src, cs, clen, dst, B, B)
+            else:
+                if "synthetic" in kind:
+                    data = bench.gen_blocks(torch, eng.dev, n, 0)
+                    fc = pkg.FC_COMPRESS_FHT
+                else:
+                    host = np.stack([np.frombuffer(raw[i % len(raw)], np.uint8) for i in range(n)])
+                    data = torch.from_numpy(host).to(eng.dev)
+                    fc = pkg.FC_COMPRESS_DHTGEN
+                comp = torch.empty((n, S), dtype=torch.uint8, device=eng.dev)
+                j1 = eng.jobs_strided(data, B, np.full(n, B, np.uint32), comp, S, S)
+                r = eng.results_to_host(eng.compress(fc, j1, n)[0])
+                dst = torch.zeros((n, B), dtype=torch.uint8, device=eng.dev)
+                jobs = eng.jobs_strided(comp, S, r["tpbc"].astype(np.uint32), dst, B, B)
+            ms = timed(eng, jobs, n)
+            row.append(n * B / ms / 1e-3 / 2 ** 30)
+            eng.close()
+            del jobs, dst
+            torch.cuda.empty_cache()
+        print("%-34s %8d | %12.1f %12.1f" % (kind, n, row[0], row[1]), flush=True)
