@@ -32,6 +32,7 @@ typedef struct nxz_dht_prepared {
 #define NXZ_GLOBAL_AS __attribute__((address_space(1)))
 extern "C" {
 #define NXZ_LZ77_MAX_GRID 512          /* workgroups of one LZ77 launch (one per CU) */
+#define NXZ_LZ77_FUSED_FHT 2            /* nxz_launch_lz77 count: the kernel writes the finished fixed-Huffman block itself (no entropy launch) */
 size_t nxz_lz77_cand2_bytes(void);     /* scratch of a launch: the second bucket entries in transit */
 int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n, uint8_t *tokens, uint16_t *cand2, nxz_batch_result_t *results,
 		    uint32_t *counts, uint32_t *job_counter, hipStream_t stream);

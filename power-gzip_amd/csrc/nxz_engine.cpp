@@ -328,13 +328,16 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 	(void)hipSetDevice(c->device);
 	nxz_dht_prepared_t *prepared = nullptr;
 	// equal chunks (a last chunk of a few jobs would cost three launches for nothing)
-	const size_t nchunks = (n + COMPRESS_CHUNK - 1) / COMPRESS_CHUNK;
+	// the fixed code without counts: the LZ77 kernel writes the finished block itself (no tokens in device scratch,
+	// no entropy launch, and so no reason to cut the batch into chunks: one launch, one tail)
+	const bool fused = !isdht && !count;
+	const size_t nchunks = fused ? 1 : (n + COMPRESS_CHUNK - 1) / COMPRESS_CHUNK;
 	const size_t chunk = (n + nchunks - 1) / nchunks;
 	nxz_ctx::Scratch sc;
 	{
 		std::lock_guard<std::mutex> g(c->mtx);
 		nxz_ctx::Scratch &r = c->scratch[s];
-		if (r.chunk_cap < chunk) {
+		if (!fused && r.chunk_cap < chunk) {
 			// grows only: warm up once with the largest batch before timing a loop
 			if (r.d_tokens) { (void)hipStreamSynchronize(s); (void)hipFree(r.d_tokens); (void)hipFree(r.d_gen); (void)hipFree(r.d_counts); }
 			r.d_tokens = nullptr; r.d_gen = nullptr; r.d_counts = nullptr; r.chunk_cap = 0;
@@ -375,9 +378,10 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 			c->tev.push_back(e);
 		};
 		stamp();
-		int rc = nxz_launch_lz77(cnt != nullptr, jobs + off, m, sc.d_tokens, sc.d_cand2, results + off, cnt, jc, s);
+		int rc = nxz_launch_lz77(fused ? NXZ_LZ77_FUSED_FHT : cnt != nullptr, jobs + off, m, sc.d_tokens, sc.d_cand2, results + off, cnt, jc, s);
 		if (rc) { set_err("lz77 launch", (hipError_t)rc); return -EIO; }
 		stamp();
+		if (fused) { stamp(); stamp(); continue; }
 		if (gen) {
 			rc = nxz_launch_dhtgen(cnt, m, sc.d_gen, nullptr, s);
 			if (rc) { set_err("dhtgen launch", (hipError_t)rc); return -EIO; }
@@ -951,11 +955,12 @@ static int round_run(nxz_ctx *c, nxz_ctx::Round &R, std::vector<CompressReq *> &
 	if (nxz_launch_copy_items(R.h_items, (uint32_t)n, R.stream)) return -EIO;
 	if (dht && !gen && nxz_launch_dht_prepare(R.h_dht, n, R.d_prep, R.stream)) return -EIO;
 	lap(0, k0); k0 = each ? trace_ns() : 0;
-	if (nxz_launch_lz77(count || gen, R.h_jobs, n, R.d_tok, R.d_cand2, R.h_res, R.h_cnt, nullptr, R.stream)) return -EIO;
+	const bool fused = !dht && !count && !gen;             // the fixed code: the LZ77 kernel writes the block itself
+	if (nxz_launch_lz77(fused ? NXZ_LZ77_FUSED_FHT : count || gen, R.h_jobs, n, R.d_tok, R.d_cand2, R.h_res, R.h_cnt, nullptr, R.stream)) return -EIO;
 	lap(1, k0); k0 = each ? trace_ns() : 0;
 	if (gen && nxz_launch_dhtgen(R.h_cnt, n, R.d_prep, nullptr, R.stream)) return -EIO;
 	lap(2, k0); k0 = each ? trace_ns() : 0;
-	if (nxz_launch_encode(dht, gen, R.h_jobs, n, R.d_tok, R.d_prep, R.h_res, R.stream)) return -EIO;
+	if (!fused && nxz_launch_encode(dht, gen, R.h_jobs, n, R.d_tok, R.d_prep, R.h_res, R.stream)) return -EIO;
 	lap(3, k0);
 	if (each && (g_trace.rounds & 255) == 255)
 		fprintf(stderr, "nxz round kernels (sum so far, us): dht_prepare %.0f lz77 %.0f dhtgen %.0f encode %.0f over %llu rounds\n",

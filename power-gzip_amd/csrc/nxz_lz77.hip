@@ -95,7 +95,7 @@ constexpr uint32_t LDS_BYTES = OFF_PROF + 80;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
-enum { M_NREC = 0, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7 };
+enum { M_NREC = 0, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7, M_KEEP = 8 };
 static_assert(M_TICKET == M_PROGRESS + 1 && M_DEFER == M_PROGRESS + 2, "cleared together");
 
 __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
@@ -182,7 +182,85 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 	return v;
 }
 
-template <bool COUNT>
+// ---- fixed-Huffman output inside the LZ77 kernel (FUSED: function codes 0x00 / 0x08) ----
+// The fixed code needs no table and no second pass: a tile's tokens go from LDS straight into the job's target
+// (round 2 wrote them to device scratch -- 56 KB per block -- and a second kernel read them and the source again:
+// 12 % of the step and 2.6 x the bytes, for a split that only dynamic tables require).
+// The tokens that start in four consecutive positions as one bit string (<= 96 bits: a match at the first position
+// and one at the fourth): RFC 1951 3.2.6 codes by arithmetic, bit-reversed; bit for bit oracle/nxz_lz77.c put_tokens.
+struct Quad { uint32_t a0, a1, a2, nb; };
+__device__ __forceinline__ void fx_match(uint32_t l3, uint32_t d, uint64_t &mv, uint32_t &mn)
+{
+	uint32_t le = l3 < 8 ? 0 : (29 - (uint32_t)__builtin_clz(l3 | 8));
+	const uint32_t ls = l3 == 255 ? 28 : (le << 2) + (l3 >> le);
+	if (l3 == 255) le = 0;
+	const uint32_t de = d < 4 ? 0 : (30 - (uint32_t)__builtin_clz(d | 4));
+	const uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
+	// symbol 257 + ls: 7 bits (code ls + 1) below 280, else 8 bits (0xC0 + ls - 23); distance: 5 bits
+	const bool l8 = ls >= 23;
+	const uint32_t ll = l8 ? 8 : 7;
+	const uint32_t lc = __builtin_bitreverse32(l8 ? 0xC0u + ls - 23 : ls + 1) >> (l8 ? 24 : 25);
+	const uint32_t dc = __builtin_bitreverse32(ds) >> 27;
+	const uint32_t lo = lc | ((l3 & ((1u << le) - 1)) << ll);                // <= 13 bits
+	const uint32_t hi = dc | ((d & ((1u << de) - 1)) << 5);                  // <= 18 bits
+	mv = (uint64_t)lo | ((uint64_t)hi << (ll + le));
+	mn = ll + le + 5 + de;
+}
+// b: the four bytes; lit4 / tok4: which of the positions start a literal / a match; m4: the stored lengths
+// (len - 3, a byte each); c01, c23: the distances - 1 (16 bits each)
+__device__ __forceinline__ Quad fx_quad(uint32_t b, uint32_t lit4, uint32_t tok4, uint32_t m4, uint32_t c01, uint32_t c23)
+{
+	uint64_t v[4];
+	uint32_t nbk[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const uint32_t x = (b >> (8 * k)) & 0xff;
+		const bool hi = x >= 144;
+		v[k] = __builtin_bitreverse32(x + (hi ? 0x100u : 0x30u)) >> (hi ? 23 : 24);
+		nbk[k] = (lit4 >> k) & 1 ? (hi ? 9 : 8) : 0;
+	}
+	// matches: at most two start in four positions (they are at least three bytes long), the second one only at
+	// the fourth position behind one at the first
+	if (__ballot(tok4 != 0)) {
+		const uint32_t k1 = (uint32_t)__builtin_ctz(tok4 | 16);                 // 4 = none
+		const uint32_t kk = k1 & 3;
+		uint64_t mv; uint32_t mn;
+		fx_match((m4 >> (8 * kk)) & 0xff, ((kk & 2 ? c23 : c01) >> (16 * (kk & 1))) & 0xffff, mv, mn);
+#pragma unroll
+		for (int k = 0; k < 4; k++) if (k1 == (uint32_t)k) { v[k] = mv; nbk[k] = mn; }
+		if (__ballot(tok4 == 9)) {
+			fx_match(m4 >> 24, c23 >> 16, mv, mn);
+			if (tok4 == 9) { v[3] = mv; nbk[3] = mn; }
+		}
+	}
+	// one string: token k at the sum of the lengths before it
+	uint64_t lo = nbk[0] ? v[0] : 0, hi = 0;
+	uint32_t off = nbk[0];
+#pragma unroll
+	for (int k = 1; k < 4; k++) {
+		const uint64_t x = nbk[k] ? v[k] : 0;
+		// off <= 31 + 9 + 9 here, x < 2^31
+		if (off < 64) { lo |= x << off; hi |= off ? x >> (64 - off) : 0; }
+		else hi |= x << (off - 64);
+		off += nbk[k];
+	}
+	Quad q;
+	q.a0 = (uint32_t)lo; q.a1 = (uint32_t)(lo >> 32); q.a2 = (uint32_t)hi; q.nb = off;
+	return q;
+}
+// ORs a quad's bits into the window at bit position bitpos
+__device__ __forceinline__ void fx_emit(uint32_t *w, const Quad &q, uint32_t bitpos)
+{
+	if (!q.nb) return;
+	const uint32_t sh = bitpos & 31, wi = bitpos >> 5, endw = (sh + q.nb + 31) >> 5;   // dwords touched: 1..4
+	const uint64_t s0 = (uint64_t)q.a0 << sh, s1 = (uint64_t)q.a1 << sh, s2 = (uint64_t)q.a2 << sh;
+	atomicOr(&w[wi], (uint32_t)s0);
+	if (endw > 1) atomicOr(&w[wi + 1], (uint32_t)(s0 >> 32) | (uint32_t)s1);
+	if (endw > 2) atomicOr(&w[wi + 2], (uint32_t)(s1 >> 32) | (uint32_t)s2);
+	if (endw > 3) atomicOr(&w[wi + 3], (uint32_t)(s2 >> 32));
+}
+
+template <bool COUNT, bool FUSED = false>
 __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restrict__ jobs,
 						  uint8_t *__restrict__ tokens, uint16_t *__restrict__ cand2,
 						  nxz_batch_result_t *__restrict__ results,
@@ -248,7 +326,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	}
 	for (uint32_t i = t; i < HSIZE; i += NT) head[i] = 0;
 	if (t < 316) hist[t] = 0;
-	if (t < 16 && t != M_NEXT) misc[t] = 0;
+	if (t < 16 && t != M_NEXT) misc[t] = FUSED && t == M_KEEP ? 3u : 0u;       // (FUSED: the block's header bits, BFINAL = 1, BTYPE = 01)
 	if (t < 20) profacc[t] = 0;
 	// slice-by-4 CRC tables live in the (not yet used) bit buffer: T[k][i] = i advanced by k+1 zero bytes
 	{
@@ -389,6 +467,10 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		for (uint32_t i = t; i < HSIZE; i += NT) head[i] = top[i] | (head[i] << 16);
 	}
 
+	// FUSED: where the block's bits go; dwords written so far, bits in the dword that is open (wave-uniform)
+	NXZ_GLOBAL uint32_t *dstw = (NXZ_GLOBAL uint32_t *)job.dst;
+	const uint32_t cap_words = job.dst_cap >> 2;
+	uint32_t wordbase = 0, obits = 3;
 	// where this job's tokens go
 	NXZ_GLOBAL uint8_t *tk = (NXZ_GLOBAL uint8_t *)tokens + (size_t)bid * NXZ_TOK_STRIDE;
 	NXZ_GLOBAL uint32_t *g_lit = (NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_LITBITS);
@@ -1155,6 +1237,51 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		__syncthreads();
 		PROF(8);
 
+		// ---- out (FUSED): the tile's tokens as fixed-Huffman bits, straight into the target ----
+		if constexpr (FUSED) {
+			Quad q[4] = { {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0} };
+			uint32_t nb = 0;
+			if (p0 < tn) {
+				const uint32_t tok16 = ((const uint16_t *)tokbits)[t], lit16 = ((const uint16_t *)litbits)[t];
+				if (tok16 | lit16) {
+					const uint4 bv = *(const uint4 *)(lds + OFF_IN + h + tb0 + p0);      // 16-byte aligned: h, tb0, p0 are
+					const uint4 mv = *(const uint4 *)(mlen + p0);
+					const uint4 c0 = ((const uint4 *)cand)[2 * t], c1 = ((const uint4 *)cand)[2 * t + 1];
+					q[0] = fx_quad(bv.x, lit16 & 15, tok16 & 15, mv.x, c0.x, c0.y);
+					q[1] = fx_quad(bv.y, (lit16 >> 4) & 15, (tok16 >> 4) & 15, mv.y, c0.z, c0.w);
+					q[2] = fx_quad(bv.z, (lit16 >> 8) & 15, (tok16 >> 8) & 15, mv.z, c1.x, c1.y);
+					q[3] = fx_quad(bv.w, lit16 >> 12, tok16 >> 12, mv.w, c1.z, c1.w);
+					nb = q[0].nb + q[1].nb + q[2].nb + q[3].nb;
+				}
+			}
+			const uint32_t incl = wave_incl_scan(nb, lane);
+			if (lane == 63) scan[wave] = incl;
+			__syncthreads();                                       // cand[] and mlen[] have been read: their place is the window now
+			uint32_t bitpos = obits + incl - nb, tilebits = 0;
+#pragma unroll
+			for (int w = 0; w < 16; w++) {
+				const uint32_t sc = scan[w];
+				if (w < wave) bitpos += sc;
+				tilebits += sc;
+			}
+			uint32_t *win = (uint32_t *)(lds + OFF_CAND);          // <= 16384 x 9 bits + a carried dword: 18.5 KiB of the 48 KiB
+			const uint32_t tot = obits + tilebits, nfull = tot >> 5;
+			for (uint32_t i = t; i < (nfull + 8) / 4 + 1; i += NT) ((uint4 *)win)[i] = make_uint4(0, 0, 0, 0);
+			__syncthreads();
+			if (t == 0) atomicOr(&win[0], misc[M_KEEP]);           // the partial dword the tile before left
+			fx_emit(win, q[0], bitpos);
+			fx_emit(win, q[1], bitpos + q[0].nb);
+			fx_emit(win, q[2], bitpos + q[0].nb + q[1].nb);
+			fx_emit(win, q[3], bitpos + q[0].nb + q[1].nb + q[2].nb);
+			__syncthreads();
+			// whole dwords leave; the last, partial one opens the next tile's window
+			for (uint32_t i = t; i < nfull; i += NT)
+				if (wordbase + i < cap_words) dstw[wordbase + i] = win[i];
+			if (t == 0) misc[M_KEEP] = win[nfull];
+			wordbase += nfull;
+			obits = tot & 31;
+			__syncthreads();                                       // the window is cand[] again; scan[] and the bitmaps are reused by the next tile
+		} else
 		// ---- out: records, counts, bitmaps ----
 		{
 			const uint32_t tok16 = p0 < tn ? ((const uint16_t *)tokbits)[t] : 0;
@@ -1216,6 +1343,21 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		r.cc = 0; r.tpbc = 0; r.tebc = 0;
 		r.spbc = total; r.crc = out_crc; r.adler = out_adler; r.subc = 0;
 		r.sfbt = misc[M_NREC];                                  // match tokens (diagnostic; the entropy stage checks it against the record array's size)
+		if constexpr (FUSED) {
+			// end of block (seven zero bits) behind what the tiles left, the last bytes, the completion code
+			// (as the entropy kernel sets them: nxz_encode.hip)
+			const uint64_t acc = misc[M_KEEP];
+			const uint32_t bits = obits + 7;
+			const uint64_t totbits = (uint64_t)wordbase * 32 + bits;
+			const uint32_t tpbc = (uint32_t)((totbits + 7) >> 3);
+			uint32_t cc = wordbase > cap_words || tpbc > job.dst_cap ? NXZ_CC_TARGET_SPACE : 0;
+			if (!cc) {
+				NXZ_GLOBAL uint8_t *o = (NXZ_GLOBAL uint8_t *)job.dst + (size_t)wordbase * 4;
+				for (uint32_t b = 0; b < (bits + 7) / 8; b++) o[b] = (uint8_t)(acc >> (8 * b));
+				if (tpbc > total) cc = NXZ_CC_TPBC_GT_SPBC;
+			}
+			r.cc = cc; r.tpbc = cc == NXZ_CC_TARGET_SPACE ? 0 : tpbc; r.tebc = (uint32_t)(totbits & 7); r.sfbt = 0;
+		}
 		results[bid] = r;
 	}
 	if (prof) {
@@ -1253,8 +1395,9 @@ extern "C" int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n,
 {
 	using namespace nxzl77;
 	if (n == 0) return 0;
+	// count: 0 tokens for the entropy kernel, 1 tokens + symbol counts, 2 (NXZ_LZ77_FUSED_FHT) the finished fixed-Huffman block
 	void (*k)(const nxz_batch_job_t *, uint8_t *, uint16_t *, nxz_batch_result_t *, uint32_t *, uint32_t, uint32_t *);
-	k = count ? lz77_kernel<true> : lz77_kernel<false>;
+	k = count == 2 ? lz77_kernel<false, true> : count ? lz77_kernel<true> : lz77_kernel<false>;
 	// per device: the attribute belongs to the loaded code object of a device, and so does the CU count
 	static int ncu_of[64];
 	int dev = 0;

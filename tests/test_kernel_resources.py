@@ -13,8 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel -> (max VGPRs, max scratch bytes per lane)
 BUDGET = {
-    "nxzl77::lz77_kernel<false>": (128, 64),          # 1024 threads per workgroup: 128 is the cap
-    "nxzl77::lz77_kernel<true>": (128, 64),
+    "nxzl77::lz77_kernel<false, false>": (128, 64),   # 1024 threads per workgroup: 128 is the cap
+    "nxzl77::lz77_kernel<true, false>": (128, 64),
+    "nxzl77::lz77_kernel<false, true>": (128, 64),    # the fixed-Huffman form that writes the finished block
     "nxze::encode_kernel<false>": (64, 0),            # seven workgroups of 256 threads per CU
     "nxze::encode_kernel<true>": (64, 0),
     "nxzd::dhtgen_kernel": (64, 0),
