@@ -95,7 +95,7 @@ constexpr uint32_t LDS_BYTES = OFF_PROF + 80;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
-enum { M_NREC = 0, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7, M_KEEP = 8 };
+enum { M_NREC = 0, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7, M_KEEP = 8, M_DEFER2 = 9 };
 static_assert(M_TICKET == M_PROGRESS + 1 && M_DEFER == M_PROGRESS + 2, "cleared together");
 
 __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
@@ -496,6 +496,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		const uint32_t tnpad = (tn + 511) & ~511u;
 		const uint32_t npieces = tnpad >> 9;
 		if (t < 3) misc[M_PROGRESS + t] = 0;                    // M_PROGRESS, M_TICKET, M_DEFER
+		if (t == 3) misc[M_DEFER2] = 0;
 		sbits[t] = 0;                                           // vb and kb (adjacent, 2 x 512 words)
 		for (uint32_t piece = wave; piece < npieces; piece += NT / 64) {
 #pragma unroll
@@ -607,8 +608,11 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 			auto hand = [&](const uint32_t (&o)[8], uint32_t piece) {
 				// position + 1 (0 = empty), 16 bits each; the consumer subtracts the 1
 				typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-				((uint4 *)cand)[(piece << 6) + lane] = make_uint4(__builtin_amdgcn_perm(o[1], o[0], 0x05040100), __builtin_amdgcn_perm(o[3], o[2], 0x05040100),
-										  __builtin_amdgcn_perm(o[5], o[4], 0x05040100), __builtin_amdgcn_perm(o[7], o[6], 0x05040100));
+				// (the newest entries in natural order, position i of the piece at cand[i]: eight 16-bit stores here instead of
+				// one 16-byte store and a turn by the wave that takes the piece -- the match phase draws HALF pieces, and two
+				// waves cannot turn one piece in place)
+#pragma unroll
+				for (int u = 0; u < 8; u++) cand[(piece << 9) + 64 * u + lane] = (uint16_t)o[u];
 				((NXZ_GLOBAL v4u *)g_c2)[(piece << 6) + lane] = (v4u){ __builtin_amdgcn_perm(o[1], o[0], 0x07060302), __builtin_amdgcn_perm(o[3], o[2], 0x07060302),
 										    __builtin_amdgcn_perm(o[5], o[4], 0x07060302), __builtin_amdgcn_perm(o[7], o[6], 0x07060302) };
 				__builtin_amdgcn_wave_barrier();
@@ -736,7 +740,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 					// round trip 1: my distance and the verified positions i+1 .. i+32, not looking
 					// beyond the piece (another wave's)
 					const uint32_t dA = cand[i];
-					const uint32_t pend = (i | 511) + 1 < tn ? (i | 511) + 1 : tn;
+					const uint32_t pend = (i | 255) + 1 < tn ? (i | 255) + 1 : tn;
 					uint32_t w32 = (uint32_t)((((uint64_t)vb[((i + 1) >> 5) + 1] << 32) | vb[(i + 1) >> 5]) >> ((i + 1) & 31));
 					if (pend - i <= 32) w32 &= (1u << (pend - i - 1)) - 1;
 					const uint32_t g1 = w32 ? (uint32_t)__builtin_ctz(w32) : 32, sp = w32 ? i + 1 + g1 : i;
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 						}
 					} else if (w32 == 0 && i + 1 == pend && pend < tn) {
 						// last position of the piece: settled after the barrier
-						atomicOr(&misc[M_DEFER], 1u << ((i >> 9) & 31));
+						atomicOr(&misc[(i >> 13) & 1 ? M_DEFER2 : M_DEFER], 1u << ((i >> 8) & 31));
 					} else {
 						// 24 bytes are compared by now.  A mismatch among them makes the length final.
 						// Otherwise a successor (same distance) inside those bytes makes me a member of
@@ -809,32 +813,25 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 				}
 				}
 			};
+			// The unit of work a wave draws is 256 positions (four per lane): a tile is 64 of them, so the waves finish
+			// within one unit's time of each other (with whole pieces of 512 the last ones decided the phase).  A unit is
+			// classified on its own: nothing looks beyond its last position (another wave's), whose successor is settled
+			// after the barrier.
+			const uint32_t nunits = (tn + 255) >> 8;
 			for (;;) {
-				uint32_t piece = 0;
-				if (lane == 0) piece = atomicAdd(&misc[M_TICKET], 1u);
-				piece = __builtin_amdgcn_readfirstlane(piece);
-				if (piece >= npieces) break;
+				uint32_t unit = 0;
+				if (lane == 0) unit = atomicAdd(&misc[M_TICKET], 1u);
+				unit = __builtin_amdgcn_readfirstlane(unit);
+				if (unit >= nunits) break;
+				const uint32_t piece = unit >> 1;
 				WPROF_BEGIN();
 				while (__hip_atomic_load(&misc[M_PROGRESS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= piece)
 					__builtin_amdgcn_s_sleep(4);
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				WPROF_END(16);                                         // waiting for the chain
-				// back to the natural order: position i of the piece at cand[i]
 				{
-					const uint4 pk = ((const uint4 *)cand)[(piece << 6) + lane];
-					__builtin_amdgcn_wave_barrier();
-					uint16_t *cp = cand + (piece << 9) + lane;
-					cp[0] = (uint16_t)pk.x; cp[64] = (uint16_t)(pk.x >> 16); cp[128] = (uint16_t)pk.y; cp[192] = (uint16_t)(pk.y >> 16);
-					cp[256] = (uint16_t)pk.z; cp[320] = (uint16_t)(pk.z >> 16); cp[384] = (uint16_t)pk.w; cp[448] = (uint16_t)(pk.w >> 16);
-					__builtin_amdgcn_wave_barrier();
-				}
-				// upper half first, so that a successor's entry is in place when a long position is
-				// classified
-				uint32_t upper_key0 = 0xffffffffu;                 // first position of the half piece behind the current one
-#pragma unroll 1
-				for (int it = 1; it >= 0; it--) {
-					const uint32_t ib = (piece << 9) + ((uint32_t)it << 8);
-					if (ib >= tn) continue;
+					const uint32_t it = unit & 1;
+					const uint32_t ib = unit << 8;
 					const uint32_t i4 = ib + 4 * lane, r4 = h + tb0 + i4;       // r4 is a multiple of 4
 					uint32_t qbits = 0;
 					auto quad = [&](auto fullt) {
@@ -910,13 +907,12 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 							kbits |= (g13 ? 6u : 0u) | (g02 ? 3u : 0u) | (g03 ? 7u : 0u);
 							qbits &= ~((g13 ? 2u : 0u) | (g02 || g03 ? 1u : 0u));
 						}
-						// my last position: its direct successor is the first position of the next lane (of
-						// the half piece processed before this one for lane 63; unknown at the piece end)
+						// my last position: its direct successor is the first position of the next lane
+						// (unknown at the unit's end: settled after the barrier)
 						{
 							const uint32_t key0 = okA[0] ? dA[0] | (uint32_t)raw8[0] << 16 : 0xffffffffu;
 							uint32_t skey = __shfl_down(key0, 1, 64);
-							if (lane == 63) skey = upper_key0;
-							upper_key0 = __builtin_amdgcn_readfirstlane(key0);
+							if (lane == 63) skey = 0xffffffffu;
 							const bool direct = skey != 0xffffffffu && (skey & 0xffff) == dA[3];
 							kbits |= (uint32_t)(lng[3] && direct && (skey >> 16)) << 3;
 							qbits |= (uint32_t)(lng[3] && !direct) << 3;
@@ -955,9 +951,9 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		PROF(12);
 		// the piece-last long positions: member if the first position of the next piece continues
 		// the match, tail otherwise -- extended right here by a whole wave, 256 bytes per step
-		for (uint32_t pc = wave; pc < 32; pc += NT / 64) {
-			if (!((misc[M_DEFER] >> pc) & 1)) continue;
-			const uint32_t ii = (pc << 9) + 511;
+		for (uint32_t pc = wave; pc < 64; pc += NT / 64) {
+			if (!((misc[pc & 32 ? M_DEFER2 : M_DEFER] >> (pc & 31)) & 1)) continue;
+			const uint32_t ii = (pc << 8) + 255;
 			if (cand[ii + 1] == cand[ii]) {
 				if (lane == 0 && mlen[ii + 1] >= 5) kb[ii >> 5] |= 0x80000000u;     // successor has 8 bytes or more: member
 				continue;
