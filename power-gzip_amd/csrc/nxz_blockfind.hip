@@ -22,6 +22,7 @@
 // nxz_inflate_stream): copy_items_kernel (a list of byte ranges, workgroup per item).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "nxz_device.h"
 
 namespace nxzb {
@@ -48,6 +49,7 @@ __device__ __forceinline__ uint32_t peek(const uint8_t *s, uint32_t bit, uint32_
 // first sieve, a lane per survivor; what it lets through goes to header_ok_wave)
 __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit, uint32_t max_syms)
 {
+	const uint32_t *s32 = (const uint32_t *)s;                     // (the segment starts on a 16-byte boundary of LDS)
 	if (bit + 17 > limit) return false;
 	uint32_t v = peek(s, bit, 17);
 	const uint32_t hlit = ((v >> 3) & 31) + 257, hdist = ((v >> 8) & 31) + 1, hclen = ((v >> 13) & 15) + 4;
@@ -69,13 +71,22 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit, uint32
 		}
 		pos += 3 * hclen;
 	}
-	// canonical order: the symbols of length 1 in ascending order, then those of length 2, ... (5 bits each, 19 at most)
+	// canonical order: the symbols of length 1 in ascending order, then those of length 2, ... (5 bits each, 19 at most);
+	// and per length l, eight bits each: lim -- the first 7-bit value (code bits first, left-justified) that is no code of
+	// length <= l; bas -- 128 + (place of the first symbol of length l in that order) - (first code of length l)
 	uint64_t st_lo = 0, st_hi = 0;                                 // entries 0..11, 12..18
+	uint64_t lim = 0, bas = 0;
 	{
 		uint64_t offs = 0;                                     // first entry of each length, 5 bits per length
-		uint32_t o = 0;
+		uint32_t o = 0, code = 0;
 #pragma unroll
-		for (uint32_t l = 1; l < 8; l++) { offs |= (uint64_t)o << (5 * l); o += (uint32_t)(cnt >> (5 * l)) & 31; }
+		for (uint32_t l = 1; l < 8; l++) {
+			const uint32_t c = (uint32_t)(cnt >> (5 * l)) & 31;
+			offs |= (uint64_t)o << (5 * l);
+			lim |= (uint64_t)((code + c) << (7 - l)) << (8 * l);
+			bas |= (uint64_t)((128 + o - code) & 0xff) << (8 * l);
+			o += c; code = (code + c) << 1;
+		}
 #pragma unroll
 		for (uint32_t sy = 0; sy < 19; sy++) {
 			const uint32_t l = (uint32_t)(cll >> (3 * sy)) & 7;
@@ -101,24 +112,20 @@ __device__ bool header_ok(const uint8_t *s, uint32_t bit, uint32_t limit, uint32
 	uint32_t nsym = 0;
 	while (n < total) {
 		if (nsym++ >= max_syms) return true;
-		// one code-length symbol: its code (7 bits at most) and what follows it (7 at most)
+		// one code-length symbol: its code (7 bits at most) and what follows it (7 at most).  The code's length is one
+		// more than the number of lengths whose limit the 7 bits reach (the code-length code is complete -- the Kraft
+		// sum was checked -- so there is always one); no branches, two dwords of the source.  (Round 3's first form
+		// tried the seven lengths in turn, ~280 instructions with their branches: 1 us a symbol for a lane on its own,
+		// 100-300 us for a real header -- and the search took as long as its real headers.)
 		if (pos >= limit) return false;
-		const uint32_t w = peek(s, pos, 14);
-		uint32_t code = 0, first = 0, index = 0, sym = 0xff, len = 0;
-#pragma unroll
-		for (uint32_t l = 1; l <= 7; l++) {
-			if (sym == 0xff) {
-				code |= (w >> (l - 1)) & 1u;
-				const uint32_t c = (uint32_t)(cnt >> (5 * l)) & 31;
-				if (code < first + c) {
-					const uint32_t at = index + (code - first);
-					sym = (uint32_t)(at < 12 ? st_lo >> (5 * at) : st_hi >> (5 * (at - 12))) & 31;
-					len = l;
-				}
-				index += c; first = (first + c) << 1; code <<= 1;
-			}
-		}
-		if (sym == 0xff || pos + len > limit) return false;
+		const uint32_t w = __builtin_amdgcn_alignbit(s32[(pos >> 5) + 1], s32[pos >> 5], pos & 31);
+		const uint32_t c7 = __builtin_bitreverse32(w) >> 25;
+		const uint32_t llo = (uint32_t)lim, lhi = (uint32_t)(lim >> 32);
+		const uint32_t len = 1 + (c7 >= ((llo >> 8) & 0xff)) + (c7 >= ((llo >> 16) & 0xff)) + (c7 >= (llo >> 24)) +
+				     (c7 >= (lhi & 0xff)) + (c7 >= ((lhi >> 8) & 0xff)) + (c7 >= ((lhi >> 16) & 0xff));
+		const uint32_t at = (((uint32_t)(bas >> (8 * len)) & 0xff) + (c7 >> (7 - len)) - 128) & 31;
+		const uint32_t sym = (uint32_t)((at < 12 ? st_lo : st_hi) >> (5 * (at < 12 ? at : at - 12))) & 31;
+		if (pos + len > limit) return false;
 		pos += len;
 		const uint32_t x = w >> len;
 		uint32_t rep = 1, val = sym;
@@ -279,18 +286,40 @@ __device__ bool header_ok_wave(const uint32_t *s32, uint32_t ndw, uint32_t bit, 
 // (seg: bytes of the stream per workgroup, <= SEG -- a short stream is cut finer, so that the search takes less
 // long and blocks of a KiB or two are not hidden behind the first of their segment)
 __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restrict__ src, uint64_t srclen, uint64_t first_bit,
-							   uint64_t *__restrict__ first, uint32_t nseg, uint32_t seg_bytes)
+							   uint64_t *__restrict__ first, uint32_t nseg, uint32_t seg_bytes, uint32_t diag)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s[SEG + LOOK + 16];
 	__shared__ uint32_t cand[MAXCAND];
 	__shared__ uint16_t queue[QCHUNK];
 	__shared__ uint32_t ncand, best, nq;
+	__shared__ uint8_t klut[512];                   // Kraft sum, in 1/128, of three code lengths of 3 bits each
+	__shared__ __attribute__((aligned(8))) uint32_t hmask[16][2];   // the bits of the first HCLEN (4..19) lengths
 	const int t = threadIdx.x;
 	const uint32_t seg = blockIdx.x;
 	if (seg >= nseg) return;
+	for (uint32_t i = t; i < 512; i += NT) {
+		uint32_t k = 0;
+		for (uint32_t f = 0; f < 3; f++) { const uint32_t l = (i >> (3 * f)) & 7; k += l ? 128u >> l : 0; }
+		klut[i] = (uint8_t)k;
+	}
+	if (t < 16) {
+		const uint64_t m = (1ull << (3 * (t + 4))) - 1;
+		hmask[t][0] = (uint32_t)m; hmask[t][1] = (uint32_t)(m >> 32);
+	}
 	const uint64_t base = (uint64_t)seg * seg_bytes;
 	const uint32_t have = (uint32_t)(srclen - base < seg_bytes + LOOK ? srclen - base : seg_bytes + LOOK);
-	for (uint32_t i = t; i < seg_bytes + LOOK + 16; i += NT) s[i] = i < have ? src[base + i] : 0;
+	if ((((uintptr_t)src + base) & 15) == 0) {
+		// (16 bytes a lane: a byte a lane is 34 trips to device memory, one after the other, for an 8 KiB segment)
+		const uint32_t whole = have >> 4;
+		for (uint32_t i = t; i < (seg_bytes + LOOK + 16) / 16; i += NT) {
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (i < whole) v = ((const uint4 *)(src + base))[i];
+			((uint4 *)s)[i] = v;
+		}
+		__syncthreads();
+		for (uint32_t i = whole * 16 + t; i < have; i += NT) s[i] = src[base + i];
+	} else
+		for (uint32_t i = t; i < seg_bytes + LOOK + 16; i += NT) s[i] = i < have ? src[base + i] : 0;
 	if (t == 0) { ncand = 0; best = 0xffffffffu; }
 	__syncthreads();
 	const uint32_t limit = have * 8;
@@ -302,6 +331,7 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 	// code (up to 19 three-bit lengths from four dwords).  Consecutive lanes test consecutive
 	// positions in (a), so the dwords they read are the same LDS words for 32 lanes: broadcast reads.
 	const uint32_t *s32 = (const uint32_t *)s;
+	if (diag == 3) { if (t == 0) first[seg] = ~0ull - s[have - 1]; return; }      // (timing of the load alone: tools)
 	for (uint32_t c0 = 0; c0 < nbits; c0 += QCHUNK) {
 		if (t == 0) nq = 0;
 		__syncthreads();
@@ -322,7 +352,7 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 			}
 		}
 		__syncthreads();
-		const uint32_t n1 = nq;
+		const uint32_t n1 = diag == 2 ? 0 : nq;                                    // (diag 2: without the Kraft sums)
 		for (uint32_t k = t; k < n1; k += NT) {
 			const uint32_t p = queue[k];
 			const uint32_t wi = p >> 5, sh = p & 31;
@@ -330,47 +360,57 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 			const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), mid = __builtin_amdgcn_alignbit(d2, d1, sh), hi = __builtin_amdgcn_alignbit(d3, d2, sh);
 			const uint32_t hclen = ((lo >> 13) & 15) + 4;
 			if (p + 17 + 3 * hclen > limit) continue;
-			const uint64_t x = (((uint64_t)mid << 32) | lo) >> 17;        // lengths 0..14 (in the order they are sent)
-			const uint32_t y = (uint32_t)((((uint64_t)hi << 32) | mid) >> 30);   // lengths 15..18
-			uint32_t kraft = 0;
-#pragma unroll
-			for (uint32_t i = 0; i < 15; i++) {
-				const uint32_t l = (uint32_t)(x >> (3 * i)) & 7;
-				kraft += (i < hclen && l) ? 128u >> l : 0;
-			}
-#pragma unroll
-			for (uint32_t i = 15; i < 19; i++) {
-				const uint32_t l = (y >> (3 * (i - 15))) & 7;
-				kraft += (i < hclen && l) ? 128u >> l : 0;
-			}
+			// the 3-bit lengths in the order they are sent, those beyond HCLEN masked off; their Kraft sum three
+			// lengths a look-up (19 compare-shift-select-adds cost three times as much, and this loop is what the
+			// search spends its time in)
+			const uint2 hm = ((const uint2 *)hmask)[hclen - 4];
+			const uint32_t xlo = __builtin_amdgcn_alignbit(mid, lo, 17) & hm.x, xhi = __builtin_amdgcn_alignbit(hi, mid, 17) & hm.y;
+			const uint32_t kraft = (uint32_t)klut[xlo & 511] + klut[(xlo >> 9) & 511] + klut[(xlo >> 18) & 511] +
+					       klut[__builtin_amdgcn_alignbit(xhi, xlo, 27) & 511] + klut[(xhi >> 4) & 511] + klut[(xhi >> 13) & 511] + klut[(xhi >> 22) & 7];
 			if (kraft != 128) continue;
 			const uint32_t kc = atomicAdd(&ncand, 1u);
 			if (kc < MAXCAND) cand[kc] = p;
 		}
 	}
 	__syncthreads();
-	// phase 2: the start of the header, a lane per survivor (lengths read off chance bits oversubscribe a code within
-	// a few dozen symbols) ...
+	if (diag == 1 || diag == 2) { if (t == 0) first[seg] = ~0ull - ncand; return; }          // (timing of phase 1 alone: tools)
+	// phase 2: the whole header, a lane per survivor.  Measured on 256 MiB of the corpus at zlib -6 (8 KiB segments): 55
+	// survivors a segment, and chance bits do NOT contradict themselves soon -- 42 of the 55 are still alive after 4
+	// code-length symbols, 35 after 12, 20 after 40, 9 after 80 (their code-length codes give the long lengths and the
+	// zero runs the short codes, so the Kraft sums fill up as slowly as a real header's) -- while a lane needs ~150
+	// instructions a symbol.  With the survivors spread over the workgroup's four wavefronts every wavefront had such
+	// a lane and ran its 100+ symbols at 1/64 of its width: 1.13 of the search's 1.42 ms.  So: the first 8 symbols by
+	// all lanes, then what is left (38 of 55) packed into the lanes of ONE wavefront for the whole header.
 	const uint32_t nc0 = ncand < MAXCAND ? ncand : MAXCAND;
-	if (seg_bytes > 2048) {
-		// (long streams, long segments with hundreds of survivors each: what counts is the work, not how long one
-		// workgroup takes -- the whole header by the lane, all survivors at once)
+	if (diag != 5) {
+		const uint32_t s1 = diag >= 200 ? diag - 200 : 8;
+		__syncthreads();
+		if (t == 0) nq = 0;
+		__syncthreads();
 		for (uint32_t k = t; k < nc0; k += NT) {
 			const uint32_t p = cand[k];
+			if (header_ok(s, p, limit, s1)) queue[atomicAdd(&nq, 1u)] = (uint16_t)p;
+		}
+		__syncthreads();
+		const uint32_t n2 = nq;
+		for (uint32_t k = t; k < n2; k += NT) {
+			const uint32_t p = queue[k];
 			if (p < best && header_ok(s, p, limit, 0xffffffffu)) atomicMin(&best, p);
 		}
 		__syncthreads();
 		if (t == 0) first[seg] = best == 0xffffffffu ? ~0ull : base * 8 + best;
 		return;
 	}
+	// (diag 5, tools: the form short segments had up to round 3 -- 40 symbols by the lane, then a wavefront per survivor)
 	__syncthreads();
 	if (t == 0) nq = 0;
 	__syncthreads();
 	for (uint32_t k = t; k < nc0; k += NT) {
 		const uint32_t p = cand[k];
-		if (header_ok(s, p, limit, 40)) queue[atomicAdd(&nq, 1u)] = (uint16_t)p;
+		if (header_ok(s, p, limit, diag >= 100 ? diag - 100 : 40)) queue[atomicAdd(&nq, 1u)] = (uint16_t)p;
 	}
 	__syncthreads();
+	if (diag >= 100) { if (t == 0) first[seg] = ~0ull - nq; return; }           // (how many the sieve lets through, and its time: tools)
 	// ... then the whole header, a wavefront per survivor of that
 	const uint32_t nc = nq;
 	for (uint32_t k = (uint32_t)t >> 6; k < nc; k += NT / 64) {
@@ -472,22 +512,22 @@ __global__ __launch_bounds__(NT) void differ_items_kernel(const CopyItem *__rest
 // 0x8000 | the index of the byte of the 32 KiB in front of the piece that it is a copy of.
 struct Piece { const uint16_t *o; uint64_t len, place; };
 
-// The window behind a piece as a function of the window in front of it: entry k of the piece's
-// tail map is the byte itself (0..255) or 0x8000 | index into the window in front.  A workgroup per
-// piece, all pieces at once.
-__global__ __launch_bounds__(256) void tailmap_kernel(const Piece *__restrict__ pieces, uint32_t n, uint16_t *__restrict__ maps)
+// The window behind a piece as a function of the window in front of it -- the piece's tail map: entry k is the
+// byte itself (0..255) or 0x8000 | index into the window in front.  It is the last 32 KiB of the piece's
+// elements; in front of a shorter piece, the old window moved up.  Nobody stores it: the kernels below read
+// eight entries at a time straight from the piece (round 2 wrote all maps out first: 64 KiB a piece of device
+// memory, and a third of the chain's time).
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u_any __attribute__((ext_vector_type(4), aligned(2)));
+__device__ __forceinline__ v4u tail_entries(const Piece &p, uint32_t kq)            // entries kq .. kq + 7 (kq a multiple of 8)
 {
-	const uint32_t i = blockIdx.x;
-	if (i >= n) return;
-	const Piece p = pieces[i];
-	const uint64_t L = p.len;
-	uint16_t *m = maps + (size_t)i * 32768;
-	for (uint32_t k = threadIdx.x; k < 32768; k += 256) {
-		uint32_t v;
-		if (L < 32768 && k < 32768 - L) v = 0x8000u | (uint32_t)(k + L);         // still the old window, moved up
-		else v = p.o[L >= 32768 ? L - 32768 + k : k - (32768 - L)];
-		m[k] = (uint16_t)v;
-	}
+	const uint32_t L = p.len >= 32768 ? 32768u : (uint32_t)p.len, keep = 32768 - L;
+	const uint16_t NXZ_GLOBAL_AS *o = (const uint16_t NXZ_GLOBAL_AS *)p.o + (p.len - L);         // the last L elements
+	if (kq >= keep) return *(const NXZ_GLOBAL_AS v4u_any *)(o + (kq - keep));
+	uint32_t e[8];
+#pragma unroll
+	for (uint32_t j = 0; j < 8; j++) e[j] = kq + j < keep ? 0x8000u | (kq + j + L) : (uint32_t)o[kq + j - keep];
+	return (v4u){ e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16 };
 }
 
 // A workgroup walks `per` pieces in order (workgroup g: pieces g * per ...) and writes, for each, the
@@ -495,12 +535,13 @@ __global__ __launch_bounds__(256) void tailmap_kernel(const Piece *__restrict__ 
 // of workgroup g's first piece is win0 for g = 0, else front[(g - 1) * 32768 ..].  A thread owns 32
 // consecutive entries; the next piece's map is on its way while this one is applied.
 // Used three ways (nxz_launch_window_chain): one workgroup over all pieces when they are few; else
-// over the composed maps of the groups (windows behind the groups), then a workgroup per group.
-__global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__restrict__ maps, uint32_t n, uint32_t per, const uint8_t *__restrict__ win0,
-							     const uint8_t *__restrict__ front, uint8_t *__restrict__ windows)
+// over the composed maps of the groups (windows behind the groups; PIECES false: the maps are an array),
+// then a workgroup per group.
+template <bool PIECES>
+__global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__restrict__ maps, const Piece *__restrict__ pieces, uint32_t n, uint32_t per,
+							     const uint8_t *__restrict__ win0, const uint8_t *__restrict__ front, uint8_t *__restrict__ windows)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t w[2][32768];
-	typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 	const int t = threadIdx.x;
 	const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
 	if (lo >= hi) return;
@@ -509,16 +550,20 @@ __global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__re
 	__syncthreads();
 	uint32_t cur = 0;
 	const v4u NXZ_GLOBAL_AS *mp = (const v4u NXZ_GLOBAL_AS *)maps;
+	auto fetch = [&](uint32_t i, int q) __attribute__((always_inline)) -> v4u {
+		if (PIECES) return tail_entries(pieces[i], 32 * t + 8 * q);
+		return mp[(size_t)i * 4096 + t * 4 + q];
+	};
 	v4u nx[4];
 #pragma unroll
-	for (int q = 0; q < 4; q++) nx[q] = mp[(size_t)lo * 4096 + t * 4 + q];
+	for (int q = 0; q < 4; q++) nx[q] = fetch(lo, q);
 	for (uint32_t i = lo; i < hi; i++) {
 		v4u m[4];
 #pragma unroll
 		for (int q = 0; q < 4; q++) m[q] = nx[q];
 		if (i + 1 < hi) {
 #pragma unroll
-			for (int q = 0; q < 4; q++) nx[q] = mp[(size_t)(i + 1) * 4096 + t * 4 + q];
+			for (int q = 0; q < 4; q++) nx[q] = fetch(i + 1, q);
 		}
 		const uint8_t *wi = w[cur];
 		uint32_t out[8];
@@ -546,23 +591,31 @@ __global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__re
 
 // The maps of `per` consecutive pieces composed into one: what the window behind the group is, as a
 // function of the window in front of it (entries as in a tail map).  A workgroup per group.
-__global__ __launch_bounds__(1024) void compose_maps_kernel(const uint16_t *__restrict__ maps, uint32_t n, uint32_t per, uint16_t *__restrict__ gmaps)
+__global__ __launch_bounds__(1024) void compose_maps_kernel(const Piece *__restrict__ pieces, uint32_t n, uint32_t per, uint16_t *__restrict__ gmaps)
 {
 	__shared__ __attribute__((aligned(16))) uint16_t c[2][32768];
-	typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 	const int t = threadIdx.x;
 	const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
 	if (lo >= hi) return;
 	for (uint32_t k = t; k < 32768; k += 1024) c[0][k] = (uint16_t)(0x8000u | k);
 	__syncthreads();
 	uint32_t cur = 0;
-	const v4u NXZ_GLOBAL_AS *mp = (const v4u NXZ_GLOBAL_AS *)maps;
+	v4u nx[4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) nx[q] = tail_entries(pieces[lo], 32 * t + 8 * q);
 	for (uint32_t i = lo; i < hi; i++) {
 		const uint16_t *ci = c[cur];
+		v4u mq[4];
+#pragma unroll
+		for (int q = 0; q < 4; q++) mq[q] = nx[q];
+		if (i + 1 < hi) {
+#pragma unroll
+			for (int q = 0; q < 4; q++) nx[q] = tail_entries(pieces[i + 1], 32 * t + 8 * q);
+		}
 		uint32_t out[16];
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
-			const v4u m = mp[(size_t)i * 4096 + t * 4 + q];
+			const v4u m = mq[q];
 			const uint32_t d[4] = { m.x, m.y, m.z, m.w };
 #pragma unroll
 			for (int e = 0; e < 4; e++) {
@@ -583,7 +636,11 @@ __global__ __launch_bounds__(1024) void compose_maps_kernel(const uint16_t *__re
 	for (int q = 0; q < 4; q++) { const uint4 v = cf[q]; g[t * 4 + q] = (v4u){ v.x, v.y, v.z, v.w }; }
 }
 
-// every piece to its place: final[place + o] = the byte, or the byte of its history it is a copy of
+// every piece to its place: final[place + o] = the byte, or the byte of its history it is a copy of.
+// A piece is taken in chunks of 32 Ki elements by up to blocks_per_piece workgroups (chunk c by workgroup
+// c mod blocks_per_piece; a workgroup without a chunk ends at once): each loads the piece's window once, so a
+// piece of the usual 10-40 KiB costs one or two window loads (a fixed four parts per piece cost four, as much
+// traffic as the elements themselves), and the odd piece of half a megabyte still has four workgroups.
 __global__ __launch_bounds__(256) void resolve_kernel(const Piece *__restrict__ pieces, uint32_t n, const uint8_t *__restrict__ win0,
 						       const uint8_t *__restrict__ windows, uint8_t *__restrict__ dst, uint32_t blocks_per_piece)
 {
@@ -591,36 +648,51 @@ __global__ __launch_bounds__(256) void resolve_kernel(const Piece *__restrict__ 
 	const uint32_t i = blockIdx.x / blocks_per_piece, part = blockIdx.x % blocks_per_piece;
 	if (i >= n) return;
 	const Piece p = pieces[i];
-	const uint64_t per = (p.len + blocks_per_piece - 1) / blocks_per_piece;
-	const uint64_t lo = (uint64_t)part * per, hi = lo + per < p.len ? lo + per : p.len;
-	if (lo >= hi) return;
+	constexpr uint64_t CH = 32768;
+	const uint64_t nch = (p.len + CH - 1) / CH;
+	if (part >= nch) return;
 	const uint8_t *win = i ? windows + (size_t)(i - 1) * 32768 : win0;
 	for (uint32_t k = threadIdx.x; k < 32768 / 16; k += 256) ((uint4 *)w)[k] = ((const uint4 *)win)[k];
 	__syncthreads();
 	uint8_t *out = dst + p.place;
-	// 4 elements per thread and trip where the piece's place allows whole dwords
-	const uint64_t head = ((4 - ((uintptr_t)(out + lo) & 3)) & 3);
-	const uint64_t a0 = lo + head < hi ? lo + head : hi;
-	for (uint64_t o = lo + threadIdx.x; o < a0; o += 256) { const uint32_t v = p.o[o]; out[o] = (uint8_t)((v & 0x8000) ? w[v & 0x7fff] : v); }
-	const uint64_t nq = (hi - a0) >> 2;
-	for (uint64_t q = threadIdx.x; q < nq; q += 256) {
-		const uint64_t o = a0 + q * 4;
-		uint32_t r = 0;
+	typedef uint32_t v2u_any __attribute__((ext_vector_type(2), aligned(2)));
+	for (uint64_t c = part; c < nch; c += blocks_per_piece) {
+		const uint64_t lo = c * CH, hi = lo + CH < p.len ? lo + CH : p.len;
+		// 4 elements per thread and trip where the piece's place allows whole dwords
+		const uint64_t head = ((4 - ((uintptr_t)(out + lo) & 3)) & 3);
+		const uint64_t a0 = lo + head < hi ? lo + head : hi;
+		for (uint64_t o = lo + threadIdx.x; o < a0; o += 256) { const uint32_t v = p.o[o]; out[o] = (uint8_t)((v & 0x8000) ? w[v & 0x7fff] : v); }
+		const uint64_t nq = (hi - a0) >> 2;
+		for (uint64_t q = threadIdx.x; q < nq; q += 256) {
+			const uint64_t o = a0 + q * 4;
+			const v2u_any e2 = *(const NXZ_GLOBAL_AS v2u_any *)((const uint16_t NXZ_GLOBAL_AS *)p.o + o);
+			const uint32_t v[4] = { e2.x & 0xffff, e2.x >> 16, e2.y & 0xffff, e2.y >> 16 };
+			uint32_t r = 0;
 #pragma unroll
-		for (int e = 0; e < 4; e++) { const uint32_t v = p.o[o + e]; r |= ((v & 0x8000) ? (uint32_t)w[v & 0x7fff] : (v & 0xff)) << (8 * e); }
-		*(uint32_t *)(out + o) = r;
+			for (int e = 0; e < 4; e++) r |= ((v[e] & 0x8000) ? (uint32_t)w[v[e] & 0x7fff] : (v[e] & 0xff)) << (8 * e);
+			*(uint32_t *)(out + o) = r;
+		}
+		for (uint64_t o = a0 + nq * 4 + threadIdx.x; o < hi; o += 256) { const uint32_t v = p.o[o]; out[o] = (uint8_t)((v & 0x8000) ? w[v & 0x7fff] : v); }
 	}
-	for (uint64_t o = a0 + nq * 4 + threadIdx.x; o < hi; o += 256) { const uint32_t v = p.o[o]; out[o] = (uint8_t)((v & 0x8000) ? w[v & 0x7fff] : v); }
 }
 
 } // namespace nxzb
 
-extern "C" uint32_t nxz_blockfind_segment(uint64_t srclen) { return srclen <= (4u << 20) ? 1024 : srclen <= (32u << 20) ? 2048 : nxzb::SEG; }
+extern "C" uint32_t nxz_blockfind_segment(uint64_t srclen)
+{
+	static const uint32_t env = getenv("NXZ_BLOCKFIND_SEG") ? (uint32_t)atoi(getenv("NXZ_BLOCKFIND_SEG")) : 0;
+	if (env >= 512 && env <= nxzb::SEG && !(env & (env - 1))) return env;
+	// (a workgroup per segment; what a workgroup takes longest over is the real header in its segment, if there is one,
+	// so short segments buy little: 3.7 MiB of stream: 0.36 ms at 1 KiB, 0.29 at 2 KiB, 0.24 at 4 KiB; 13 MiB: 0.48 at
+	// 4 KiB, 0.39 at 8 KiB; 53 MiB: 1.56 at 4 KiB, 1.10 at 8 KiB.  Only a part of a stream of a MiB or so is cut finer)
+	return srclen <= (1u << 20) ? 1024 : srclen <= (2u << 20) ? 2048 : srclen <= (8u << 20) ? 4096 : nxzb::SEG;
+}
 
 extern "C" int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, hipStream_t stream)
 {
 	if (!nseg) return 0;
-	hipLaunchKernelGGL(nxzb::find_blocks_kernel, dim3(nseg), dim3(nxzb::NT), 0, stream, src, srclen, first_bit, first, nseg, nxz_blockfind_segment(srclen));
+	static const uint32_t diag = getenv("NXZ_BLOCKFIND_DIAG") ? (uint32_t)atoi(getenv("NXZ_BLOCKFIND_DIAG")) : 0;
+	hipLaunchKernelGGL(nxzb::find_blocks_kernel, dim3(nseg), dim3(nxzb::NT), 0, stream, src, srclen, first_bit, first, nseg, nxz_blockfind_segment(srclen), diag);
 	return (int)hipGetLastError();
 }
 
@@ -642,21 +714,21 @@ extern "C" int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t 
 // Pieces per group: composing a group's maps takes 7.6 us a piece, a walk 2.3 us a step, so
 // 9.9 g + 2.3 n / g in all -- least at g = 0.48 sqrt(n).  (n = 0: the smallest group there is.)
 extern "C" uint32_t nxz_window_chain_group(uint32_t n) { return n == 0 || n < 400 ? 8 : n < 1600 ? 16 : 32; }
-extern "C" int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint16_t *maps, uint8_t *windows,
+extern "C" int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint8_t *windows,
 				       uint16_t *gmaps, uint8_t *gwin, hipStream_t stream)
 {
 	if (!n) return 0;
 	const uint32_t per = nxz_window_chain_group(n), ng = (n + per - 1) / per;
-	hipLaunchKernelGGL(nxzb::tailmap_kernel, dim3(n), dim3(256), 0, stream, (const nxzb::Piece *)pieces, n, maps);
+	const nxzb::Piece *pc = (const nxzb::Piece *)pieces;
 	if (ng <= 2 || !gmaps || !gwin) {
-		hipLaunchKernelGGL(nxzb::window_chain_kernel, dim3(1), dim3(1024), 0, stream, (const uint16_t *)maps, n, n, win0, (const uint8_t *)nullptr, windows);
+		hipLaunchKernelGGL(nxzb::window_chain_kernel<true>, dim3(1), dim3(1024), 0, stream, (const uint16_t *)nullptr, pc, n, n, win0, (const uint8_t *)nullptr, windows);
 		return (int)hipGetLastError();
 	}
 	// the groups' composed maps (all at once), the windows behind the groups (one walk over the groups),
 	// then every group's pieces from the window in front of the group (all groups at once)
-	hipLaunchKernelGGL(nxzb::compose_maps_kernel, dim3(ng), dim3(1024), 0, stream, (const uint16_t *)maps, n, per, gmaps);
-	hipLaunchKernelGGL(nxzb::window_chain_kernel, dim3(1), dim3(1024), 0, stream, (const uint16_t *)gmaps, ng, ng, win0, (const uint8_t *)nullptr, gwin);
-	hipLaunchKernelGGL(nxzb::window_chain_kernel, dim3(ng), dim3(1024), 0, stream, (const uint16_t *)maps, n, per, win0, (const uint8_t *)gwin, windows);
+	hipLaunchKernelGGL(nxzb::compose_maps_kernel, dim3(ng), dim3(1024), 0, stream, pc, n, per, gmaps);
+	hipLaunchKernelGGL(nxzb::window_chain_kernel<false>, dim3(1), dim3(1024), 0, stream, (const uint16_t *)gmaps, pc, ng, ng, win0, (const uint8_t *)nullptr, gwin);
+	hipLaunchKernelGGL(nxzb::window_chain_kernel<true>, dim3(ng), dim3(1024), 0, stream, (const uint16_t *)nullptr, pc, n, per, win0, (const uint8_t *)gwin, windows);
 	return (int)hipGetLastError();
 }
 

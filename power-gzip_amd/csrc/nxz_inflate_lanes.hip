@@ -489,6 +489,12 @@ constexpr PowTab make_pow()
 	return p;
 }
 __device__ const PowTab CRC_POW = make_pow();
+constexpr uint32_t cxpow8(uint32_t n)            // x^(8n) mod P, compile time
+{
+	uint32_t r = 0x80000000u, sq = 0x00800000u;
+	while (n) { if (n & 1) r = cgf_mul(r, sq); sq = cgf_mul(sq, sq); n >>= 1; }
+	return r;
+}
 
 // CRC-32 and Adler-32 of every job's output (results[].tpbc bytes at job.dst), continued from
 // job.in_crc / job.in_adler.  One workgroup per job; the output is cut into 64 KiB chunks and
@@ -607,8 +613,10 @@ __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__res
 		if (t == 0) {
 			const uint32_t full = red[0][0] ^ red[0][1] ^ red[0][2] ^ red[0][3];
 			const uint32_t tail = red[0][4] ^ red[0][5] ^ red[0][6] ^ red[0][7];
-			const uint32_t chunk = gf_mul(full, xpow8(r)) ^ tail;          // raw CRC of the chunk
-			c_run = gf_mul(c_run, xpow8(len)) ^ chunk;
+			// (whole chunks, whole slices: the two powers are constants -- computing them is 2000 instructions of one thread)
+			constexpr uint32_t X64 = cxpow8(64), X64K = cxpow8(65536);
+			const uint32_t chunk = gf_mul(full, r == 64 ? X64 : xpow8(r)) ^ tail;          // raw CRC of the chunk
+			c_run = gf_mul(c_run, len == 65536 ? X64K : xpow8(len)) ^ chunk;
 			const uint32_t b1 = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) % 65521u;
 			const uint32_t b2 = (red[2][0] + red[2][1] + red[2][2] + red[2][3]) % 65521u;
 			a2_run = (uint32_t)((a2_run + (uint64_t)len * a1_run + b2) % 65521u);

@@ -24,7 +24,7 @@
 //   - all pieces are resolved into place at once: final byte = the element, or window[k].
 // A part of a stream (nxz_inflate_stream_part) is the same with a resume state in and out: the first piece
 // begins wherever the last call stopped, the last one runs out of source like any suspended job.
-// The CRC-32 / Adler-32 of the output are computed over 256 KiB slices and combined (zlib's
+// The CRC-32 / Adler-32 of the output are computed over 64 KiB slices and combined (zlib's
 // crc32_combine idea); the caller checks them against the trailer as for any stream.
 #include <hip/hip_runtime.h>
 #include <errno.h>
@@ -45,7 +45,7 @@ int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);
 int nxz_ctx_device(nxz_ctx_t *c);
 int nxz_engine_usable(void);
 uint32_t nxz_window_chain_group(uint32_t n);
-int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint16_t *maps, uint8_t *windows,
+int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint8_t *windows,
 			    uint16_t *gmaps, uint8_t *gwin, hipStream_t stream);
 int nxz_launch_resolve(const void *pieces, uint32_t n, const uint8_t *win0, const uint8_t *windows, uint8_t *dst, hipStream_t stream);
 }
@@ -253,10 +253,16 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		static const int split_max = getenv("NXZ_PINFLATE_SPLIT") ? atoi(getenv("NXZ_PINFLATE_SPLIT")) : 64;      // pieces per block at most (0, 1: blocks only)
 		static const uint64_t sub_min = getenv("NXZ_PINFLATE_PIECE_BITS") ? (uint64_t)atoll(getenv("NXZ_PINFLATE_PIECE_BITS")) : 4096;   // the shortest piece
 		const uint64_t all_bits = src_len * 8 - first_bit;
-		// (as many pieces as the device holds wavefronts of the decode kernel, a few times over: 768 for a part of a
-		// megabyte or two, 8192 for a long stream)
-		static const uint64_t many = getenv("NXZ_PINFLATE_PIECES") ? std::max<uint64_t>(1, (uint64_t)atoll(getenv("NXZ_PINFLATE_PIECES"))) : 8192;   // pieces of a long stream, about
-		const uint64_t sub_bits = std::max<uint64_t>(std::max<uint64_t>(sub_min, 2048), all_bits <= (64u << 20) ? all_bits / 768 : all_bits / many);
+		// How many pieces: each costs its share of the window chain (64 KiB of map, 32 KiB of window) and a request for a
+		// token boundary, and a wavefront alone decodes 10-15 MB/s -- about 2.5 KiB of the stream per piece is where the
+		// two meet (16 MiB of the corpus at zlib -6: 3.2 ms with 657 pieces, 2.5 with 1414, 3.3 with 5839; 64 MiB: 6.2 ms
+		// with 7664, 5.4 with 4543, 8.1 with 15566), between 768 pieces (a part of a megabyte or two) and 8192 (a long
+		// stream: more than the device holds wavefronts of the decode kernel at one time, 5120).
+		static const uint64_t many = getenv("NXZ_PINFLATE_PIECES") ? std::max<uint64_t>(1, (uint64_t)atoll(getenv("NXZ_PINFLATE_PIECES"))) : 8192;
+		static const uint64_t few = getenv("NXZ_PINFLATE_PIECES_SHORT") ? std::max<uint64_t>(1, (uint64_t)atoll(getenv("NXZ_PINFLATE_PIECES_SHORT"))) : 768;
+		static const uint64_t per_piece = getenv("NXZ_PINFLATE_PIECE_BYTES") ? std::max<uint64_t>(256, (uint64_t)atoll(getenv("NXZ_PINFLATE_PIECE_BYTES"))) : 2560;
+		const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(few, all_bits / (8 * per_piece)), std::max<uint64_t>(few, many));
+		const uint64_t sub_bits = std::max<uint64_t>(std::max<uint64_t>(sub_min, 2048), all_bits / want);
 		std::vector<nxz_sync_req_t> rq, bq;          // requests; the blocks they lie in (bq: src, srclen, header_bit)
 		std::vector<uint64_t> rq_base;
 		// (the first piece begins wherever the caller's part of the stream does: inside a dynamic block that is not
@@ -360,7 +366,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	// control arrays (sized for the first, longest list of pieces), then a bump area for copies and outputs
 	const size_t o_jobs = 0, o_res = o_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), o_items = o_res + up(n0 * sizeof(nxz_batch_result_t), 256),
 		     o_pieces = o_items + up((n0 + 4) * sizeof(CopyItem), 256), o_win0 = o_pieces + up(n0 * sizeof(Piece), 256),
-		     o_windows = o_win0 + WINDOW, o_maps = o_windows + n0 * (size_t)WINDOW, o_gmaps = o_maps + n0 * (size_t)WINDOW * 2,
+		     o_windows = o_win0 + WINDOW, o_gmaps = o_windows + n0 * (size_t)WINDOW,
 		     o_gwin = o_gmaps + ng0 * (size_t)WINDOW * 2, o_dht = o_gwin + ng0 * (size_t)WINDOW,
 		     o_walk = o_dht + up(n0 * sizeof(nxz_batch_dht_t), 256),
 		     o_bump = o_walk + up(n0 * (sizeof(nxz_walk_req_t) + sizeof(nxz_walk_res_t)), 256);
@@ -369,9 +375,15 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		     pin_walk = pin_dht + up((n0 + 1) * sizeof(nxz_batch_dht_t), 256),    // (the tables the jobs start with; the last piece's, out)
 		     pin_total = pin_walk + up(n0 * (sizeof(nxz_walk_req_t) + sizeof(nxz_walk_res_t)), 256);
 	size_t bump = 0, reserved = 0;
+	// The pieces read the caller's stream where it lies: a piece's source starts at the 16-byte boundary in front of
+	// its first bit (the decode kernel loads 16 bytes a lane) and the job names the bit.  (A stream that does not
+	// itself start on such a boundary: every piece gets an aligned copy of its bytes, as all did up to round 3 --
+	// 0.9 ms of copies for 256 MiB.  NXZ_PINFLATE_STAGE=1 forces that.)
+	static const bool stage_env = getenv("NXZ_PINFLATE_STAGE") && atoi(getenv("NXZ_PINFLATE_STAGE")) != 0;
+	const bool direct = !stage_env && ((uintptr_t)src & 15) == 0;
 	auto size_piece = [&](P &p, const P *next) -> bool {
 		const uint64_t next_bit = next ? next->bit : 0;
-		p.cstart = p.bit >> 3;
+		p.cstart = direct ? (p.bit >> 3) & ~15ull : p.bit >> 3;
 		const uint64_t cend = next_bit ? (next_bit + 7) >> 3 : src_len;
 		p.cbytes = cend - p.cstart;
 		if (p.cbytes > 0xfffffff0ull - 64) return false;
@@ -380,7 +392,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		const uint64_t cp = std::max<uint64_t>(p.cbytes * p.capmul, p.tab >= 0 ? CAP_FLOOR_CUT : CAP_FLOOR_BLOCK);
 		if (cp > 0xfff00000ull) return false;
 		p.cap = up(cp, 256);
-		p.stage_off = bump; bump += up(p.cbytes + 64, 256);
+		p.stage_off = bump; if (!direct) bump += up(p.cbytes + 64, 256);
 		p.out_off = bump; bump += p.cap * 2;
 		p.done = false;
 		return true;
@@ -414,15 +426,15 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			P &p = pc[i];
 			if (p.done) continue;
 			uint8_t *stg = D + o_bump + p.stage_off;
-			h_items[ni++] = CopyItem{ src + p.cstart, stg, p.cbytes };
+			if (!direct) h_items[ni++] = CopyItem{ src + p.cstart, stg, p.cbytes };
 			nxz_batch_job_t &j = h_jobs[nj++];
 			memset(&j, 0, sizeof(j));
-			j.src = stg; j.src_len = (uint32_t)p.cbytes; j.hist_len = 0;
+			j.src = direct ? src + p.cstart : stg; j.src_len = (uint32_t)p.cbytes;
+			j.hist_len = (uint32_t)(p.bit - p.cstart * 8);                               // (a piece: the bit it starts at)
 			j.dst = D + o_bump + p.out_off; j.dst_cap = (uint32_t)p.cap;
-			const uint32_t sub = (uint32_t)(p.bit & 7);
-			j.resume = (0xeu << 16) | ((sub ? 8 - sub : 0) << 20);
-			if (i == 0 && st && (st->sfbt & 8)) j.resume = (st->rem & 0xffff) | ((st->sfbt & 0xf) << 16) | ((sub ? 8 - sub : 0) << 20);
-			if (p.tab >= 0) j.resume = ((0xcu | p.cfin) << 16) | ((sub ? 8 - sub : 0) << 20);      // inside a dynamic block
+			j.resume = 0xeu << 16;
+			if (i == 0 && st && (st->sfbt & 8)) j.resume = (st->rem & 0xffff) | ((st->sfbt & 0xf) << 16);
+			if (p.tab >= 0) j.resume = (0xcu | p.cfin) << 16;                            // inside a dynamic block
 			if (p.srem) j.resume = p.srem | ((0x8u | p.sfin) << 16);                     // inside a stored block (on a byte boundary)
 			j.in_adler = (uint32_t)p.stop;
 			j.in_crc = p.tab >= 0 ? (uint32_t)p.tab + 1 : 0;                             // (which block's ready-made tables)
@@ -458,14 +470,19 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		if (nxz_launch_inflate_w16(d_jobs, nj, d_res, d_dht, tabs.empty() ? nullptr : ws.built, attempt == 0, s)) return -EIO;
 		lap("decode");
 		if (!zc && hipMemcpyAsync(h_res, d_res, nj * sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
-		const bool last_ran = st && nj && who[nj - 1] == pc.size() - 1;
-		if (!zc && last_ran && hipMemcpyAsync(&h_dht[n0], d_dht + (nj - 1), sizeof(nxz_batch_dht_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+		size_t klast = nj;                          // which job the stream's last piece is, if it ran
+		for (size_t k = 0; k < nj && st; k++) if (who[k] == pc.size() - 1) klast = k;
+		const bool last_ran = klast < nj;
+		if (!zc && last_ran && hipMemcpyAsync(&h_dht[n0], d_dht + klast, sizeof(nxz_batch_dht_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 		if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
-		if (last_ran) last_dht = zc ? h_dht[nj - 1] : h_dht[n0];
+		if (last_ran) last_dht = zc ? h_dht[klast] : h_dht[n0];
 		for (size_t k = 0; k < nj; k++) { pc[who[k]].res = h_res[k]; pc[who[k]].done = true; }
 		if (trace) {
 			size_t slow = 0;
+			double sum_us = 0;
+			for (size_t k = 0; k < nj; k++) sum_us += h_res[k].crc * 0.01;
 			for (size_t k = 1; k < nj; k++) if (h_res[k].crc > h_res[slow].crc) slow = k;
+			fprintf(stderr, "nxz_inflate_stream: round %d: the pieces' decode times add up to %.0f us (%.1f us each; / 5120 wavefronts at a time: %.0f us)\n", attempt, sum_us, sum_us / nj, sum_us / 5120);
 			const P &q = pc[who[slow]];
 			fprintf(stderr, "nxz_inflate_stream: round %d: %zu pieces; the longest took %.1f us (piece %zu, %s%s: %llu bytes in, %u out, cc %u)\n", attempt, nj, h_res[slow].crc * 0.01,
 				who[slow], q.tab >= 0 ? "cut" : "block", q.srem ? ", starts in a stored block" : "", (unsigned long long)q.cbytes, h_res[slow].tpbc, h_res[slow].cc);
@@ -641,7 +658,6 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	Piece *h_pieces = (Piece *)(P_ + pin_pieces);
 	Piece *d_pieces = zc ? h_pieces : (Piece *)(D + o_pieces);
 	uint8_t *d_windows = D + o_windows;
-	uint16_t *d_maps = (uint16_t *)(D + o_maps);
 	nxz_batch_job_t *d_jobs = (nxz_batch_job_t *)(D + o_jobs);
 	nxz_batch_result_t *d_res = (nxz_batch_result_t *)(D + o_res);
 	uint64_t total = 0;
@@ -653,12 +669,14 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	if (total > dst_cap) return -E2BIG;
 	if (!zc && hipMemcpyAsync(d_pieces, h_pieces, n * sizeof(Piece), hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
 	const uint8_t *win0 = D + o_win0;
-	if (nxz_launch_window_chain(d_pieces, (uint32_t)n, win0, d_maps, d_windows, (uint16_t *)(D + o_gmaps), D + o_gwin, s)) return -EIO;
+	if (nxz_launch_window_chain(d_pieces, (uint32_t)n, win0, d_windows, (uint16_t *)(D + o_gmaps), D + o_gwin, s)) return -EIO;
 	lap("tail maps + window chain");
 	if (nxz_launch_resolve(d_pieces, (uint32_t)n, win0, d_windows, dst, s)) return -EIO;
 	lap("resolve");
 	// ---- checksums: 256 KiB slices of the output (the job / result arrays are free again) ----
-	const uint64_t SLICE = total <= (16u << 20) ? 64 << 10 : 256 << 10;       // (a workgroup per slice: short ones when there are few)
+	// (a workgroup per slice, and a workgroup takes 64 KiB at a time: 64 KiB slices fill the device up to half a GiB)
+	static const uint64_t slice_env = getenv("NXZ_PINFLATE_CKSUM_SLICE") ? (uint64_t)atoll(getenv("NXZ_PINFLATE_CKSUM_SLICE")) : 0;
+	const uint64_t SLICE = slice_env ? slice_env : total <= (512u << 20) ? 64 << 10 : 256 << 10;
 	const size_t nsl = (size_t)((total + SLICE - 1) / SLICE);
 	std::vector<nxz_batch_result_t> sres(nsl);
 	if (!nsl) { if (crc) *crc = 0; if (adler) *adler = 1; }
@@ -670,6 +688,9 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			memset(&h_jobs[k], 0, sizeof(nxz_batch_job_t));
 			memset(&h_res[k], 0, sizeof(nxz_batch_result_t));
 			h_jobs[k].dst = dst + (o + k) * SLICE;
+			// (what of the caller's buffer lies behind the slice's first byte: the kernel loads 16 bytes a lane where
+			// that stays inside it -- left at 0, as up to round 3, every byte was loaded on its own: 0.58 ms for 256 MiB)
+			h_jobs[k].dst_cap = (uint32_t)std::min<uint64_t>(dst_cap - (o + k) * SLICE, 0xffffffffull);
 			h_jobs[k].in_crc = 0; h_jobs[k].in_adler = 1;
 			h_res[k].tpbc = (uint32_t)std::min<uint64_t>(SLICE, total - (o + k) * SLICE);
 		}
