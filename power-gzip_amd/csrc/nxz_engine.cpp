@@ -60,6 +60,7 @@ struct Slot {
 #define INF_SRC_CAP (1u << 20)           /* decompress: source bytes taken per job */
 #define INF_OUT_CAP (4u << 20)
 
+constexpr int HOST_PAIRS = 16;
 struct nxz_ctx {
 	int device = 0;
 	int refs = 0;
@@ -94,7 +95,8 @@ struct nxz_ctx {
 	};
 	std::map<hipStream_t, Scratch> scratch;
 	// nxz_deflate_host: a call works on two lanes, each with its own stream, so that the copies of one group of
-	// blocks run while the other group is in the kernels; four such pairs (made when first used), for callers on different threads
+	// blocks run while the other group is in the kernels; HOST_PAIRS such pairs (made when first used, 100 MiB of device
+	// memory each), for callers on different threads (four pairs: 16 threads spent three quarters of a call waiting for one)
 	struct HostLane {
 		hipStream_t stream = nullptr;
 		uint8_t *d_src = nullptr, *d_dst = nullptr, *d_packed = nullptr;
@@ -102,8 +104,8 @@ struct nxz_ctx {
 		nxz_batch_result_t *d_res = nullptr, *h_res = nullptr;
 		uint64_t *d_off = nullptr, *h_total = nullptr;
 		size_t n = 0; uint64_t bytes = 0;
-	} lanes[8];
-	std::mutex lanes_mtx[4];
+	} lanes[2 * HOST_PAIRS];
+	std::mutex lanes_mtx[HOST_PAIRS];
 	std::atomic<unsigned> lanes_turn{0};
 	// nxu_run_job, compress: callers that arrive while a launch is in flight are gathered and go out
 	// together as one launch of each kernel (run_compress / round_run)
@@ -610,8 +612,8 @@ extern "C" int nxz_deflate_host_hist(nxz_ctx_t *c, int fc, const uint8_t *src, s
 	if (!prev) prev_len = 0;
 	(void)hipSetDevice(c->device);
 	int pair = -1;
-	for (int k = 0; k < 4 && pair < 0; k++) if (c->lanes_mtx[k].try_lock()) pair = k;
-	if (pair < 0) { pair = (int)(c->lanes_turn.fetch_add(1) % 4); c->lanes_mtx[pair].lock(); }
+	for (int k = 0; k < HOST_PAIRS && pair < 0; k++) if (c->lanes_mtx[k].try_lock()) pair = k;
+	if (pair < 0) { pair = (int)(c->lanes_turn.fetch_add(1) % HOST_PAIRS); c->lanes_mtx[pair].lock(); }
 	std::lock_guard<std::mutex> g(c->lanes_mtx[pair], std::adopt_lock);
 	nxz_ctx::HostLane *const lanes = c->lanes + 2 * pair;
 	for (int k = 0; k < 2; k++)

@@ -113,7 +113,7 @@ struct Workspace {
 		return true;
 	}
 };
-constexpr int NWS = 8;
+constexpr int NWS = 32;           // (as many callers side by side; 16 threads on 8 of them spent two thirds of a call waiting for one)
 Workspace g_ws[64][NWS];
 // A workspace that a call has grown beyond this is given back to the device when the call ends (NXZ_PINFLATE_KEEP_MB,
 // default 8192 MiB): the engine shares the device with its caller (torch, other libraries).

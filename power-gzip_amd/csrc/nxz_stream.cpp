@@ -768,7 +768,7 @@ bool parallel_inflate(Inflate *s)
 		nxz_ctx_t *ctx = nullptr;
 		void *stream = nullptr;
 	};
-	constexpr int NSLOT = 8;
+	constexpr int NSLOT = 32;
 	static Slot slots[NSLOT];
 	static std::atomic<unsigned> turn{0};
 	Slot *slot = nullptr;
