@@ -31,6 +31,7 @@ constexpr int NT = 256;
 constexpr uint32_t SEG = 8192;                  // bytes of the stream per workgroup
 constexpr uint32_t LOOK = 320;                  // a header is at most 17 + 19 * 3 + 316 * 7 + ... bits: < 300 bytes
 constexpr uint32_t MAXCAND = 1024;
+constexpr uint32_t LEFT_MAX = 126;                // positions per segment handed to check_headers_kernel
 constexpr uint32_t QCHUNK = 8192;               // positions per pass of the first test (its survivors queue up in LDS)
 
 __device__ __forceinline__ uint32_t peek(const uint8_t *s, uint32_t bit, uint32_t n)   // n <= 25
@@ -281,12 +282,31 @@ __device__ bool header_ok_wave(const uint32_t *s32, uint32_t ndw, uint32_t bit, 
 	return true;
 }
 
+// a segment of the stream (and the LOOK bytes behind it a header may reach into) into LDS, zeros behind the stream's end
+template <int THREADS>
+__device__ __forceinline__ void load_segment(uint8_t *s, const uint8_t *__restrict__ src, uint64_t base, uint32_t have, uint32_t seg_bytes, int t)
+{
+	if ((((uintptr_t)src + base) & 15) == 0) {
+		// (16 bytes a lane: a byte a lane is 34 trips to device memory, one after the other, for an 8 KiB segment)
+		const uint32_t whole = have >> 4;
+		for (uint32_t i = t; i < (seg_bytes + LOOK + 16) / 16; i += THREADS) {
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (i < whole) v = ((const uint4 *)(src + base))[i];
+			((uint4 *)s)[i] = v;
+		}
+		__syncthreads();
+		for (uint32_t i = whole * 16 + t; i < have; i += THREADS) s[i] = src[base + i];
+	} else
+		for (uint32_t i = t; i < seg_bytes + LOOK + 16; i += THREADS) s[i] = i < have ? src[base + i] : 0;
+}
+
 // first[seg] = bit position (in the whole stream) of the first plausible dynamic block header that
 // starts inside segment seg, or 0xffffffffffffffff
 // (seg: bytes of the stream per workgroup, <= SEG -- a short stream is cut finer, so that the search takes less
 // long and blocks of a KiB or two are not hidden behind the first of their segment)
 __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restrict__ src, uint64_t srclen, uint64_t first_bit,
-							   uint64_t *__restrict__ first, uint32_t nseg, uint32_t seg_bytes, uint32_t diag)
+							   uint64_t *__restrict__ first, uint32_t nseg, uint32_t seg_bytes, uint32_t diag,
+							   uint16_t *__restrict__ left)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s[SEG + LOOK + 16];
 	__shared__ uint32_t cand[MAXCAND];
@@ -308,18 +328,7 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 	}
 	const uint64_t base = (uint64_t)seg * seg_bytes;
 	const uint32_t have = (uint32_t)(srclen - base < seg_bytes + LOOK ? srclen - base : seg_bytes + LOOK);
-	if ((((uintptr_t)src + base) & 15) == 0) {
-		// (16 bytes a lane: a byte a lane is 34 trips to device memory, one after the other, for an 8 KiB segment)
-		const uint32_t whole = have >> 4;
-		for (uint32_t i = t; i < (seg_bytes + LOOK + 16) / 16; i += NT) {
-			uint4 v = make_uint4(0, 0, 0, 0);
-			if (i < whole) v = ((const uint4 *)(src + base))[i];
-			((uint4 *)s)[i] = v;
-		}
-		__syncthreads();
-		for (uint32_t i = whole * 16 + t; i < have; i += NT) s[i] = src[base + i];
-	} else
-		for (uint32_t i = t; i < seg_bytes + LOOK + 16; i += NT) s[i] = i < have ? src[base + i] : 0;
+	load_segment<NT>(s, src, base, have, seg_bytes, t);
 	if (t == 0) { ncand = 0; best = 0xffffffffu; }
 	__syncthreads();
 	const uint32_t limit = have * 8;
@@ -393,6 +402,18 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 		}
 		__syncthreads();
 		const uint32_t n2 = nq;
+		if (left) {
+			// what is left goes to check_headers_kernel: LEFT_MAX positions per segment, their number in front.
+			// (This workgroup holds 30 KiB of LDS for the search; with five of them on a CU, each down to a few lanes
+			// walking a few hundred symbols, the CU did next to nothing for 0.8 of the search's 1.1 ms.  The second kernel
+			// is a wavefront and 8.5 KiB a segment: eighteen of them on a CU.)
+			uint16_t *o = left + (size_t)seg * (LEFT_MAX + 2);
+			const uint32_t n3 = n2 < LEFT_MAX ? n2 : LEFT_MAX;
+			if (t == 0) { o[0] = (uint16_t)n3; o[1] = (uint16_t)(n2 > LEFT_MAX); }
+			for (uint32_t k = t; k < n3; k += NT) o[2 + k] = queue[k];
+			if (n2 <= LEFT_MAX) return;
+			// (more than the list holds -- data made to look like headers: this workgroup does them all, as before)
+		}
 		for (uint32_t k = t; k < n2; k += NT) {
 			const uint32_t p = queue[k];
 			if (p < best && header_ok(s, p, limit, 0xffffffffu)) atomicMin(&best, p);
@@ -417,6 +438,34 @@ __global__ __launch_bounds__(NT) void find_blocks_kernel(const uint8_t *__restri
 		const uint32_t p = uni32(queue[k]);
 		if (p >= uni32(best)) continue;
 		if (header_ok_wave(s32, (SEG + LOOK + 16) / 4, p, limit, t & 63) && (t & 63) == 0) atomicMin(&best, p);
+	}
+	__syncthreads();
+	if (t == 0) first[seg] = best == 0xffffffffu ? ~0ull : base * 8 + best;
+}
+
+// the whole header for the positions find_blocks_kernel left over, a wavefront per segment (see there)
+__global__ __launch_bounds__(64) void check_headers_kernel(const uint8_t *__restrict__ src, uint64_t srclen, uint64_t *__restrict__ first,
+							    uint32_t nseg, uint32_t seg_bytes, const uint16_t *__restrict__ left)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t s[SEG + LOOK + 16];
+	__shared__ uint32_t best;
+	const int t = threadIdx.x;
+	const uint32_t seg = blockIdx.x;
+	if (seg >= nseg) return;
+	const uint16_t *o = left + (size_t)seg * (LEFT_MAX + 2);
+	const uint32_t n = o[0];
+	if (o[1]) return;                                  // (the first kernel did this segment itself)
+	if (!n) { if (t == 0) first[seg] = ~0ull; return; }
+	const uint64_t base = (uint64_t)seg * seg_bytes;
+	const uint32_t have = (uint32_t)(srclen - base < seg_bytes + LOOK ? srclen - base : seg_bytes + LOOK);
+	// (a header reaches LOOK bytes at most: what lies behind the last candidate's is not wanted)
+	load_segment<64>(s, src, base, have, seg_bytes, t);
+	if (t == 0) best = 0xffffffffu;
+	__syncthreads();
+	const uint32_t limit = have * 8;
+	for (uint32_t k = t; k < n; k += 64) {
+		const uint32_t p = o[2 + k];
+		if (p < best && header_ok(s, p, limit, 0xffffffffu)) atomicMin(&best, p);
 	}
 	__syncthreads();
 	if (t == 0) first[seg] = best == 0xffffffffu ? ~0ull : base * 8 + best;
@@ -688,11 +737,17 @@ extern "C" uint32_t nxz_blockfind_segment(uint64_t srclen)
 	return srclen <= (1u << 20) ? 1024 : srclen <= (2u << 20) ? 2048 : srclen <= (8u << 20) ? 4096 : nxzb::SEG;
 }
 
-extern "C" int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, hipStream_t stream)
+// scratch: nxz_blockfind_scratch(nseg) bytes of DEVICE memory, or NULL (the search as one kernel)
+extern "C" size_t nxz_blockfind_scratch(uint32_t nseg) { return (size_t)nseg * (nxzb::LEFT_MAX + 2) * sizeof(uint16_t); }
+extern "C" int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, void *scratch, hipStream_t stream)
 {
 	if (!nseg) return 0;
 	static const uint32_t diag = getenv("NXZ_BLOCKFIND_DIAG") ? (uint32_t)atoi(getenv("NXZ_BLOCKFIND_DIAG")) : 0;
-	hipLaunchKernelGGL(nxzb::find_blocks_kernel, dim3(nseg), dim3(nxzb::NT), 0, stream, src, srclen, first_bit, first, nseg, nxz_blockfind_segment(srclen), diag);
+	static const bool two = !(getenv("NXZ_BLOCKFIND_TWO") && atoi(getenv("NXZ_BLOCKFIND_TWO")) == 0);
+	const uint32_t seg = nxz_blockfind_segment(srclen);
+	uint16_t *left = two && !diag ? (uint16_t *)scratch : nullptr;
+	hipLaunchKernelGGL(nxzb::find_blocks_kernel, dim3(nseg), dim3(nxzb::NT), 0, stream, src, srclen, first_bit, first, nseg, seg, diag, left);
+	if (left) hipLaunchKernelGGL(nxzb::check_headers_kernel, dim3(nseg), dim3(64), 0, stream, src, srclen, first, nseg, seg, (const uint16_t *)left);
 	return (int)hipGetLastError();
 }
 

@@ -104,6 +104,7 @@ struct nxz_ctx {
 		nxz_batch_result_t *d_res = nullptr, *h_res = nullptr;
 		uint64_t *d_off = nullptr, *h_total = nullptr;
 		size_t n = 0; uint64_t bytes = 0;
+		size_t cap = 0;                           // blocks per group the buffers hold
 	} lanes[2 * HOST_PAIRS];
 	std::mutex lanes_mtx[HOST_PAIRS];
 	std::atomic<unsigned> lanes_turn{0};
@@ -571,20 +572,37 @@ static hipError_t stream_create_spread(hipStream_t *s, unsigned turn)
 	return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio);
 }
 
-static bool lane_init(nxz_ctx::HostLane &l, bool high)
+// a lane's stream (made once) and its buffers for `blocks` blocks per group (grow only, a power of two from 32 up to
+// HOST_GROUP: a caller of megabyte-sized calls holds 2 x 6 MiB, not 2 x 50 -- with 16 pairs of lanes that is what a
+// process of many threads pays when each makes its first call)
+static bool lane_need(nxz_ctx::HostLane &l, bool high, size_t blocks)
 {
-	int least = 0, greatest = 0;
-	(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-	HIPCHK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, high ? greatest : least), return false);
-	HIPCHK(hipMalloc((void **)&l.d_src, (size_t)HOST_GROUP * SUBBLOCK), return false);
-	HIPCHK(hipMalloc((void **)&l.d_dst, (size_t)HOST_GROUP * HOST_SLOT), return false);
-	HIPCHK(hipMalloc((void **)&l.d_packed, (size_t)HOST_GROUP * (SUBBLOCK + 16)), return false);
-	HIPCHK(hipMalloc((void **)&l.d_jobs, HOST_GROUP * sizeof(nxz_batch_job_t)), return false);
-	HIPCHK(hipHostMalloc((void **)&l.h_jobs, HOST_GROUP * sizeof(nxz_batch_job_t)), return false);
-	HIPCHK(hipMalloc((void **)&l.d_res, HOST_GROUP * sizeof(nxz_batch_result_t)), return false);
-	HIPCHK(hipHostMalloc((void **)&l.h_res, HOST_GROUP * sizeof(nxz_batch_result_t)), return false);
-	HIPCHK(hipMalloc((void **)&l.d_off, (HOST_GROUP + 1) * sizeof(uint64_t)), return false);
-	HIPCHK(hipHostMalloc((void **)&l.h_total, sizeof(uint64_t)), return false);
+	if (!l.stream) {
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		HIPCHK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, high ? greatest : least), return false);
+		HIPCHK(hipHostMalloc((void **)&l.h_total, sizeof(uint64_t)), return false);
+	}
+	if (blocks <= l.cap) return true;
+	size_t cap = 32;
+	while (cap < blocks) cap <<= 1;
+	if (cap > HOST_GROUP) cap = HOST_GROUP;
+	if (l.cap) {
+		(void)hipStreamSynchronize(l.stream);
+		(void)hipFree(l.d_src); (void)hipFree(l.d_dst); (void)hipFree(l.d_packed); (void)hipFree(l.d_jobs); (void)hipFree(l.d_res); (void)hipFree(l.d_off);
+		(void)hipHostFree(l.h_jobs); (void)hipHostFree(l.h_res);
+		l.d_src = l.d_dst = l.d_packed = nullptr; l.d_jobs = l.h_jobs = nullptr; l.d_res = l.h_res = nullptr; l.d_off = nullptr;
+		l.cap = 0;
+	}
+	HIPCHK(hipMalloc((void **)&l.d_src, cap * SUBBLOCK), return false);
+	HIPCHK(hipMalloc((void **)&l.d_dst, cap * HOST_SLOT), return false);
+	HIPCHK(hipMalloc((void **)&l.d_packed, cap * (SUBBLOCK + 16)), return false);
+	HIPCHK(hipMalloc((void **)&l.d_jobs, cap * sizeof(nxz_batch_job_t)), return false);
+	HIPCHK(hipHostMalloc((void **)&l.h_jobs, cap * sizeof(nxz_batch_job_t)), return false);
+	HIPCHK(hipMalloc((void **)&l.d_res, cap * sizeof(nxz_batch_result_t)), return false);
+	HIPCHK(hipHostMalloc((void **)&l.h_res, cap * sizeof(nxz_batch_result_t)), return false);
+	HIPCHK(hipMalloc((void **)&l.d_off, (cap + 1) * sizeof(uint64_t)), return false);
+	l.cap = cap;
 	return true;
 }
 
@@ -616,13 +634,13 @@ extern "C" int nxz_deflate_host_hist(nxz_ctx_t *c, int fc, const uint8_t *src, s
 	if (pair < 0) { pair = (int)(c->lanes_turn.fetch_add(1) % HOST_PAIRS); c->lanes_mtx[pair].lock(); }
 	std::lock_guard<std::mutex> g(c->lanes_mtx[pair], std::adopt_lock);
 	nxz_ctx::HostLane *const lanes = c->lanes + 2 * pair;
-	for (int k = 0; k < 2; k++)
-		if (!lanes[k].stream && !lane_init(lanes[k], k == 1)) return -ENOMEM;
 	const size_t nblk = (src_len + B - 1) / B;
 	// groups: at least four when the input allows it, so that copies and kernels overlap
-	size_t group = std::min<size_t>(HOST_GROUP - 1, std::max<size_t>(32, (nblk + 3) / 4));   // (- 1: the window in front of a group's first block)
+	size_t group = std::min<size_t>(HOST_GROUP - 1, std::max<size_t>(31, (nblk + 3) / 4));   // (- 1: the window in front of a group's first block)
 	const size_t ngroups = (nblk + group - 1) / group;
 	group = (nblk + ngroups - 1) / ngroups;
+	for (int k = 0; k < 2; k++)
+		if (!lane_need(lanes[k], k == 1, group + 1)) return -ENOMEM;
 	const uint32_t op_block = crc_shift_op(B);
 	uint32_t run_crc = 0, run_adler = 1;
 	size_t pos = 0;

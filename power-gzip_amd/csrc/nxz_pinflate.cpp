@@ -40,7 +40,8 @@
 
 extern "C" {
 uint32_t nxz_blockfind_segment(uint64_t srclen);
-int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, hipStream_t stream);
+size_t nxz_blockfind_scratch(uint32_t nseg);
+int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint64_t first_bit, uint64_t *first, uint32_t nseg, void *scratch, hipStream_t stream);
 int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);
 int nxz_ctx_device(nxz_ctx_t *c);
 int nxz_engine_usable(void);
@@ -231,8 +232,9 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	const uint32_t SEG = nxz_blockfind_segment(src_len);
 	const uint32_t nseg = (uint32_t)((src_len + SEG - 1) / SEG);
 	// ---- block starts ----
-	if (!ws.need(nseg * sizeof(uint64_t), nseg * sizeof(uint64_t))) return -ENOMEM;
-	if (nxz_launch_find_blocks(src, src_len, first_bit, (uint64_t *)(zc ? ws.pin : ws.dev), nseg, s)) return -EIO;
+	const size_t o_left = up(nseg * sizeof(uint64_t), 256);             // (what the search's first kernel leaves for its second)
+	if (!ws.need(o_left + nxz_blockfind_scratch(nseg), nseg * sizeof(uint64_t))) return -ENOMEM;
+	if (nxz_launch_find_blocks(src, src_len, first_bit, (uint64_t *)(zc ? ws.pin : ws.dev), nseg, (uint8_t *)ws.dev + o_left, s)) return -EIO;
 	if (!zc && hipMemcpyAsync(ws.pin, ws.dev, nseg * sizeof(uint64_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 	if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
 	lap("block starts");
@@ -430,11 +432,14 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		for (size_t i = 0; i < pc.size(); i++) if (!pc[i].done) who.push_back(i);
 		static const bool lpt = !(getenv("NXZ_PINFLATE_LPT") && atoi(getenv("NXZ_PINFLATE_LPT")) == 0);
 		if (lpt && who.size() > 1024) {
-			std::vector<uint64_t> key(who.size());           // (~cbytes, place in the list): ascending = longest first, ties in order
-			for (size_t k = 0; k < who.size(); k++) key[k] = ((0xffffffffull - pc[who[k]].cbytes) << 32) | k;
-			std::sort(key.begin(), key.end());
+			// (by counting, 64 bytes a bucket: a comparison sort of 7000 pieces is a quarter of a millisecond the device waits for)
+			constexpr size_t NB = 2048;
+			std::vector<uint32_t> cnt(NB + 1, 0);
+			auto bucket = [&](size_t i) -> size_t { const uint64_t b = pc[i].cbytes >> 6; return NB - 1 - (size_t)std::min<uint64_t>(b, NB - 1); };
+			for (size_t k = 0; k < who.size(); k++) cnt[bucket(who[k]) + 1]++;
+			for (size_t b = 0; b < NB; b++) cnt[b + 1] += cnt[b];
 			std::vector<size_t> tw(who.size());
-			for (size_t k = 0; k < who.size(); k++) tw[k] = who[(size_t)(key[k] & 0xffffffffu)];
+			for (size_t k = 0; k < who.size(); k++) tw[cnt[bucket(who[k])]++] = who[k];
 			who.swap(tw);
 		}
 		for (size_t k = 0; k < who.size(); k++) {
