@@ -90,6 +90,60 @@ def test_a_block_header_that_is_not_one(eng, data):
     assert dst[:len(plain)].cpu().numpy().tobytes() == plain
 
 
+@pytest.mark.parametrize("off", [1, 3, 8, 13])
+def test_a_stream_that_does_not_start_on_a_16_byte_boundary(eng, data, off):
+    """The pieces read the caller's stream in place when it starts on a 16-byte boundary of device memory; one that
+    does not gets aligned copies of its pieces (nxz_pinflate.cpp `direct`): same bytes out either way."""
+    import torch
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    plain = data[:6 << 20]
+    comp = c.compress(plain) + c.flush()
+    buf = torch.zeros(len(comp) + 64, dtype=torch.uint8, device=eng.dev)
+    buf[off:off + len(comp)] = torch.from_numpy(np.frombuffer(comp, np.uint8).copy()).to(eng.dev)
+    src = buf[off:off + len(comp)]
+    assert src.data_ptr() % 16 == off % 16
+    dst = torch.zeros(len(plain) + 4096, dtype=torch.uint8, device=eng.dev)
+    rc, info = eng.inflate_stream(src, len(comp), dst)
+    torch.cuda.synchronize()
+    assert rc == 0, (rc, info)
+    assert info["out_len"] == len(plain) and info["crc"] == zlib.crc32(plain)
+    assert dst[:len(plain)].cpu().numpy().tobytes() == plain
+
+
+def _stream_with_headers_as_stored_data(data):
+    """data[:5 MiB] deflated | 6.5 MiB of STORED blocks that hold a 15-byte dynamic block header (zlib's own, of a
+    block of four letters) every 20 bytes | data[5 MiB:11 MiB] deflated: one raw deflate stream of > 8 MiB"""
+    rng = np.random.default_rng(3)
+    four = bytes(rng.choice([97, 98, 99, 100], size=4000, p=[.5, .25, .15, .1]).astype(np.uint8))
+    c0 = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_HUFFMAN_ONLY)
+    hdr = (c0.compress(four) + c0.flush())[:15]
+    assert (hdr[0] & 6) == 4                                    # BTYPE 10
+    junk = b"".join(hdr + rng.integers(0, 256, 5, dtype=np.uint8).tobytes() for _ in range((6500 << 10) // 20))
+    c1 = zlib.compressobj(6, zlib.DEFLATED, -15)
+    part1 = c1.compress(data[:5 << 20]) + c1.flush(zlib.Z_SYNC_FLUSH)            # ends on a byte boundary, not final
+    stored = b"".join(b"\x00" + len(ch).to_bytes(2, "little") + (len(ch) ^ 0xffff).to_bytes(2, "little") + ch
+                      for ch in (junk[o:o + 65535] for o in range(0, len(junk), 65535)))
+    c2 = zlib.compressobj(6, zlib.DEFLATED, -15)
+    part2 = c2.compress(data[5 << 20:11 << 20]) + c2.flush()
+    plain = data[:5 << 20] + junk + data[5 << 20:11 << 20]
+    comp = part1 + stored + part2
+    assert zlib.decompress(comp, -15) == plain and len(comp) > (8 << 20)
+    return comp, plain
+
+
+def test_hundreds_of_headers_that_are_none_in_one_segment(eng, data):
+    """A short, perfectly good dynamic block header every 20 bytes of stored data: 400 candidates in every 8 KiB
+    segment of the search pass every test -- more than its first kernel hands to the second (LEFT_MAX = 126: such a
+    segment is done by the first kernel itself), and every segment of 6.5 MiB reports a block start that is none.
+    The stream must still come out bit exact (the pieces in front do not end at those starts; stored_walk_kernel
+    carries the piece over the run of stored blocks)."""
+    comp, plain = _stream_with_headers_as_stored_data(data)
+    rc, info, dst = _run(eng, comp, len(plain) + 4096)
+    assert rc == 0, (rc, info)
+    assert info["out_len"] == len(plain) and info["crc"] == zlib.crc32(plain)
+    assert dst[:len(plain)].cpu().numpy().tobytes() == plain
+
+
 def test_history_in_front_and_bit_offset(eng, data):
     """a stream that starts in the middle of a byte and refers to a preset dictionary"""
     dic = data[100000:100000 + 32768]
