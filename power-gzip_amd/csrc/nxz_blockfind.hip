@@ -640,10 +640,18 @@ __global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__re
 
 // The maps of `per` consecutive pieces composed into one: what the window behind the group is, as a
 // function of the window in front of it (entries as in a tail map).  A workgroup per group.
-__global__ __launch_bounds__(1024) void compose_maps_kernel(const Piece *__restrict__ pieces, uint32_t n, uint32_t per, uint16_t *__restrict__ gmaps)
+// (PIECES false: the maps are an array -- groups of groups, for the third level of a long chain)
+template <bool PIECES>
+__global__ __launch_bounds__(1024) void compose_maps_kernel(const Piece *__restrict__ pieces, const uint16_t *__restrict__ maps, uint32_t n, uint32_t per,
+							     uint16_t *__restrict__ gmaps)
 {
 	__shared__ __attribute__((aligned(16))) uint16_t c[2][32768];
 	const int t = threadIdx.x;
+	const v4u NXZ_GLOBAL_AS *mp = (const v4u NXZ_GLOBAL_AS *)maps;
+	auto fetch = [&](uint32_t i, int q) __attribute__((always_inline)) -> v4u {
+		if (PIECES) return tail_entries(pieces[i], 32 * t + 8 * q);
+		return mp[(size_t)i * 4096 + t * 4 + q];
+	};
 	const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
 	if (lo >= hi) return;
 	for (uint32_t k = t; k < 32768; k += 1024) c[0][k] = (uint16_t)(0x8000u | k);
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(1024) void compose_maps_kernel(const Piece *__restr
 	uint32_t cur = 0;
 	v4u nx[4];
 #pragma unroll
-	for (int q = 0; q < 4; q++) nx[q] = tail_entries(pieces[lo], 32 * t + 8 * q);
+	for (int q = 0; q < 4; q++) nx[q] = fetch(lo, q);
 	for (uint32_t i = lo; i < hi; i++) {
 		const uint16_t *ci = c[cur];
 		v4u mq[4];
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(1024) void compose_maps_kernel(const Piece *__restr
 		for (int q = 0; q < 4; q++) mq[q] = nx[q];
 		if (i + 1 < hi) {
 #pragma unroll
-			for (int q = 0; q < 4; q++) nx[q] = tail_entries(pieces[i + 1], 32 * t + 8 * q);
+			for (int q = 0; q < 4; q++) nx[q] = fetch(i + 1, q);
 		}
 		uint32_t out[16];
 #pragma unroll
@@ -779,10 +787,22 @@ extern "C" int nxz_launch_window_chain(const void *pieces, uint32_t n, const uin
 		hipLaunchKernelGGL(nxzb::window_chain_kernel<true>, dim3(1), dim3(1024), 0, stream, (const uint16_t *)nullptr, pc, n, n, win0, (const uint8_t *)nullptr, windows);
 		return (int)hipGetLastError();
 	}
-	// the groups' composed maps (all at once), the windows behind the groups (one walk over the groups),
-	// then every group's pieces from the window in front of the group (all groups at once)
-	hipLaunchKernelGGL(nxzb::compose_maps_kernel, dim3(ng), dim3(1024), 0, stream, pc, n, per, gmaps);
-	hipLaunchKernelGGL(nxzb::window_chain_kernel<false>, dim3(1), dim3(1024), 0, stream, (const uint16_t *)gmaps, pc, ng, ng, win0, (const uint8_t *)nullptr, gwin);
+	// the groups' composed maps (all at once), the windows behind the groups, then every group's pieces from the
+	// window in front of the group (all groups at once).  The windows behind the groups: one walk over the groups
+	// when they are few (1.7 us a step); else the same again one level up -- groups of 16 groups composed, one
+	// walk over those, then every group of groups side by side (214 groups: 0.37 ms -> under 0.1)
+	hipLaunchKernelGGL(nxzb::compose_maps_kernel<true>, dim3(ng), dim3(1024), 0, stream, pc, (const uint16_t *)nullptr, n, per, gmaps);
+	static const uint32_t two_max = getenv("NXZ_CHAIN_TWO_LEVELS_MAX") ? (uint32_t)atoi(getenv("NXZ_CHAIN_TWO_LEVELS_MAX")) : 64;
+	if (ng <= two_max)
+		hipLaunchKernelGGL(nxzb::window_chain_kernel<false>, dim3(1), dim3(1024), 0, stream, (const uint16_t *)gmaps, pc, ng, ng, win0, (const uint8_t *)nullptr, gwin);
+	else {
+		const uint32_t per2 = 16, ng2 = (ng + per2 - 1) / per2;
+		uint16_t *gmaps2 = gmaps + (size_t)ng * 32768;                  // (room: see nxz_pinflate.cpp, n / 8 + 1 maps and windows)
+		uint8_t *gwin2 = gwin + (size_t)ng * 32768;
+		hipLaunchKernelGGL(nxzb::compose_maps_kernel<false>, dim3(ng2), dim3(1024), 0, stream, pc, (const uint16_t *)gmaps, ng, per2, gmaps2);
+		hipLaunchKernelGGL(nxzb::window_chain_kernel<false>, dim3(1), dim3(1024), 0, stream, (const uint16_t *)gmaps2, pc, ng2, ng2, win0, (const uint8_t *)nullptr, gwin2);
+		hipLaunchKernelGGL(nxzb::window_chain_kernel<false>, dim3(ng2), dim3(1024), 0, stream, (const uint16_t *)gmaps, pc, ng, per2, win0, (const uint8_t *)gwin2, gwin);
+	}
 	hipLaunchKernelGGL(nxzb::window_chain_kernel<true>, dim3(ng), dim3(1024), 0, stream, (const uint16_t *)nullptr, pc, n, per, win0, (const uint8_t *)gwin, windows);
 	return (int)hipGetLastError();
 }

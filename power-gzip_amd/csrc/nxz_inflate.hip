@@ -710,12 +710,17 @@ tables_ready:
 			// ---- multi-token step (see the header) ----
 			while (fast_ok && b.pos + 256 <= b.total_bits) {
 				IPROF(0);
-				const uint32_t q = uni((uint32_t)(b.pos >> 5)), sh = (uint32_t)b.pos & 31;
-				if (q - wbase >= 64u) {                                  // (one scalar test a step; the source is below 2^31 dwords)
-					if (q - wbase < 128u) { wbase += 64; W0 = W1; W1 = load_block((wbase >> 6) + 1); }
-					else { wbase = q & ~63u; W0 = load_block(wbase >> 6); W1 = load_block((wbase >> 6) + 1); }
+				// (the position and the window's base are the same in all lanes: said so, or the compiler keeps them in
+				// vector registers and every word of the five below costs eight vector instructions instead of two)
+				const uint32_t q = uni((uint32_t)(b.pos >> 5)), sh = uni((uint32_t)b.pos & 31);
+				uint32_t wb = uni(wbase);
+				if (q - wb >= 64u) {                                     // (one scalar test a step; the source is below 2^31 dwords)
+					if (q - wb < 128u) { wb += 64; W0 = W1; W1 = load_block((wb >> 6) + 1); }
+					else { wb = q & ~63u; W0 = load_block(wb >> 6); W1 = load_block((wb >> 6) + 1); }
+					wbase = wb;
 				}
-				const uint32_t qi = q - wbase;                           // 0..63: dwords qi..qi+4 are in W0/W1
+				wb = uni(wb);
+				const uint32_t qi = q - wb;                              // 0..63: dwords qi..qi+4 are in W0/W1
 				// (both registers are read and one result is picked: a select where a branch would be)
 				auto word = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
 					const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)(i & 63)), hi = (uint32_t)__builtin_amdgcn_readlane((int)W1, (int)(i & 63));

@@ -31,7 +31,9 @@ BUDGET = {
     "nxzb::resolve_kernel": (64, 0),
     "nxzb::window_chain_kernel<true>": (128, 0),      # 1024 threads and 64 KiB of LDS per workgroup: two per CU whatever the registers
     "nxzb::window_chain_kernel<false>": (128, 0),
-    "nxzb::compose_maps_kernel": (128, 0),
+    "nxzb::compose_maps_kernel<true>": (128, 0),
+    "nxzb::compose_maps_kernel<false>": (128, 0),
+    "nxzb::check_headers_kernel": (96, 0),
     "nxz::pack_stream_kernel": (64, 0),
     "nxz::wrap_kernel": (64, 0),
 }
