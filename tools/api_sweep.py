@@ -9,7 +9,7 @@ threads = [int(x) for x in os.environ.get("SWEEP_THREADS", "1,16,64").split(",")
 print("%8s %4s | %10s %10s | %10s %10s | %9s %9s" % ("KiB", "T", "nx comp", "nx decomp", "zlib comp", "zlib dec", "comp x", "decomp x"))
 for kib in sizes:
     for T in threads:
-        per = max(32, min(1024, (48 << 10) // kib // max(1, T // 8)))      # (32 at least: a thread's first calls make its buffer set)
+        per = max(32, min(1024, (192 << 10) // kib // max(1, T // 8), (8 << 20) // (kib * T)))   # (long enough that a thread's first calls, which make its buffer set, do not decide; 8 GiB of buffers at most)
         row = {}
         for name, exe in (("nx", "compdecomp_th"), ("zlib", "compdecomp_th_zlib")):
             p = subprocess.run([os.path.join(ROOT, "power-gzip_amd", exe), f, str(T), str(kib), str(per)], capture_output=True, text=True)
