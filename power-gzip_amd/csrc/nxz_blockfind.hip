@@ -712,23 +712,37 @@ __global__ __launch_bounds__(256) void resolve_kernel(const Piece *__restrict__ 
 	for (uint32_t k = threadIdx.x; k < 32768 / 16; k += 256) ((uint4 *)w)[k] = ((const uint4 *)win)[k];
 	__syncthreads();
 	uint8_t *out = dst + p.place;
-	typedef uint32_t v2u_any __attribute__((ext_vector_type(2), aligned(2)));
 	for (uint64_t c = part; c < nch; c += blocks_per_piece) {
 		const uint64_t lo = c * CH, hi = lo + CH < p.len ? lo + CH : p.len;
 		// 4 elements per thread and trip where the piece's place allows whole dwords
 		const uint64_t head = ((4 - ((uintptr_t)(out + lo) & 3)) & 3);
 		const uint64_t a0 = lo + head < hi ? lo + head : hi;
 		for (uint64_t o = lo + threadIdx.x; o < a0; o += 256) { const uint32_t v = p.o[o]; out[o] = (uint8_t)((v & 0x8000) ? w[v & 0x7fff] : v); }
-		const uint64_t nq = (hi - a0) >> 2;
-		for (uint64_t q = threadIdx.x; q < nq; q += 256) {
-			const uint64_t o = a0 + q * 4;
-			const v2u_any e2 = *(const NXZ_GLOBAL_AS v2u_any *)((const uint16_t NXZ_GLOBAL_AS *)p.o + o);
-			const uint32_t v[4] = { e2.x & 0xffff, e2.x >> 16, e2.y & 0xffff, e2.y >> 16 };
-			uint32_t r = 0;
+		// (eight elements a lane and trip -- one 16-byte load at any alignment, one 8-byte store on a dword boundary --,
+		// two trips in flight: with four elements and one trip a workgroup spent its time waiting for its loads)
+		typedef uint32_t v2u_st __attribute__((ext_vector_type(2), aligned(4)));
+		const uint64_t no = (hi - a0) >> 3;
+		const uint16_t NXZ_GLOBAL_AS *eo = (const uint16_t NXZ_GLOBAL_AS *)p.o;
+		auto eight = [&](uint64_t o, const v4u e4) __attribute__((always_inline)) {
+			const uint32_t d[4] = { e4.x, e4.y, e4.z, e4.w };
+			uint32_t r[2] = { 0, 0 };
 #pragma unroll
-			for (int e = 0; e < 4; e++) r |= ((v[e] & 0x8000) ? (uint32_t)w[v[e] & 0x7fff] : (v[e] & 0xff)) << (8 * e);
-			*(uint32_t *)(out + o) = r;
+			for (int k = 0; k < 4; k++) {
+				const uint32_t v0 = d[k] & 0xffff, v1 = d[k] >> 16;
+				const uint32_t b0 = (v0 & 0x8000) ? (uint32_t)w[v0 & 0x7fff] : (v0 & 0xff), b1 = (v1 & 0x8000) ? (uint32_t)w[v1 & 0x7fff] : (v1 & 0xff);
+				r[k >> 1] |= (b0 | b1 << 8) << (16 * (k & 1));
+			}
+			*(NXZ_GLOBAL_AS v2u_st *)(out + o) = (v2u_st){ r[0], r[1] };
+		};
+		uint64_t q = threadIdx.x;
+		for (; q + 256 < no; q += 512) {
+			const uint64_t o0 = a0 + q * 8, o1 = o0 + 256 * 8;
+			const v4u ea = *(const NXZ_GLOBAL_AS v4u_any *)(eo + o0), ebb = *(const NXZ_GLOBAL_AS v4u_any *)(eo + o1);
+			eight(o0, ea);
+			eight(o1, ebb);
 		}
+		if (q < no) { const uint64_t o0 = a0 + q * 8; eight(o0, *(const NXZ_GLOBAL_AS v4u_any *)(eo + o0)); }
+		const uint64_t nq = no * 2;                               // (what follows counts in fours, as before)
 		for (uint64_t o = a0 + nq * 4 + threadIdx.x; o < hi; o += 256) { const uint32_t v = p.o[o]; out[o] = (uint8_t)((v & 0x8000) ? w[v & 0x7fff] : v); }
 	}
 }

@@ -94,6 +94,7 @@ struct nxz_ctx {
 		}
 	};
 	std::map<hipStream_t, Scratch> scratch;
+	std::map<hipStream_t, std::mutex> scratch_use;   // held by a batch call from sizing its stream's scratch to its last launch
 	// nxz_deflate_host: a call works on two lanes, each with its own stream, so that the copies of one group of
 	// blocks run while the other group is in the kernels; HOST_PAIRS such pairs (made when first used, 100 MiB of device
 	// memory each), for callers on different threads (four pairs: 16 threads spent three quarters of a call waiting for one)
@@ -337,6 +338,15 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 	const size_t nchunks = fused ? 1 : (n + COMPRESS_CHUNK - 1) / COMPRESS_CHUNK;
 	const size_t chunk = (n + nchunks - 1) / nchunks;
 	nxz_ctx::Scratch sc;
+	// Calls on ONE stream share that stream's scratch (tokens, tables): their launches must not interleave, and a call
+	// that needs more room must not free what another has just handed to its kernels (round 2's advisor finding).  One
+	// call at a time per stream from sizing to the last launch; the stream's order does the rest.
+	std::mutex *use_mtx;
+	{
+		std::lock_guard<std::mutex> g(c->mtx);
+		use_mtx = &c->scratch_use[s];
+	}
+	std::lock_guard<std::mutex> use(*use_mtx);
 	{
 		std::lock_guard<std::mutex> g(c->mtx);
 		nxz_ctx::Scratch &r = c->scratch[s];
@@ -467,6 +477,12 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 		// many streams: one stream per lane (nxz_inflate_lanes.hip); the table workspace is made once
 		int init = 0;
 		uint8_t *ws;
+		std::mutex *use_mtx;                                           // (one call at a time per stream's table workspace, as in nxz_batch_compress)
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			use_mtx = &c->scratch_use[s];
+		}
+		std::lock_guard<std::mutex> use(*use_mtx);
 		{
 			std::lock_guard<std::mutex> g(c->mtx);
 			nxz_ctx::Scratch &sc = c->scratch[s];
@@ -928,20 +944,39 @@ struct CompressReq {
 };
 #define ROUND_MAX 32u
 
+static void round_free(nxz_ctx::Round &r)
+{
+	if (r.stream) (void)hipStreamDestroy(r.stream);
+	if (r.h_jobs) (void)hipHostFree(r.h_jobs);
+	if (r.h_res) (void)hipHostFree(r.h_res);
+	if (r.h_dht) (void)hipHostFree(r.h_dht);
+	if (r.h_cnt) (void)hipHostFree(r.h_cnt);
+	if (r.h_items) (void)hipHostFree(r.h_items);
+	if (r.d_prep) (void)hipFree(r.d_prep);
+	if (r.d_tok) (void)hipFree(r.d_tok);
+	if (r.d_cand2) (void)hipFree(r.d_cand2);
+	if (r.d_src) (void)hipFree(r.d_src);
+	const bool busy = r.busy;                    // (the caller's claim on the round stands)
+	r = nxz_ctx::Round();
+	r.busy = busy;
+}
+
 static bool round_init(nxz_ctx::Round &r)
 {
 	if (r.ready) return true;
 	static std::atomic<unsigned> round_turn{0};
-	HIPCHK(stream_create_spread(&r.stream, round_turn.fetch_add(1)), return false);
-	HIPCHK(hipHostMalloc((void **)&r.h_jobs, ROUND_MAX * sizeof(nxz_batch_job_t)), return false);
-	HIPCHK(hipHostMalloc((void **)&r.h_res, ROUND_MAX * sizeof(nxz_batch_result_t)), return false);
-	HIPCHK(hipHostMalloc((void **)&r.h_dht, ROUND_MAX * sizeof(nxz_batch_dht_t)), return false);
-	HIPCHK(hipHostMalloc((void **)&r.h_cnt, ROUND_MAX * 316 * sizeof(uint32_t)), return false);
-	HIPCHK(hipMalloc((void **)&r.d_prep, ROUND_MAX * sizeof(nxz_dht_prepared_t)), return false);
-	HIPCHK(hipMalloc((void **)&r.d_tok, (size_t)ROUND_MAX * NXZ_TOK_STRIDE), return false);
-	HIPCHK(hipMalloc((void **)&r.d_cand2, nxz_lz77_cand2_bytes() / NXZ_LZ77_MAX_GRID * ROUND_MAX), return false);
-	HIPCHK(hipMalloc((void **)&r.d_src, (size_t)ROUND_MAX * SUBBLOCK), return false);
-	HIPCHK(hipHostMalloc((void **)&r.h_items, ROUND_MAX * sizeof(nxz_ctx::Round::Item)), return false);
+	// (what a failed attempt got so far goes back: the next attempt would write over the pointers -- advisor, round 2)
+	auto fail = [&]() { round_free(r); return false; };
+	HIPCHK(stream_create_spread(&r.stream, round_turn.fetch_add(1)), return fail());
+	HIPCHK(hipHostMalloc((void **)&r.h_jobs, ROUND_MAX * sizeof(nxz_batch_job_t)), return fail());
+	HIPCHK(hipHostMalloc((void **)&r.h_res, ROUND_MAX * sizeof(nxz_batch_result_t)), return fail());
+	HIPCHK(hipHostMalloc((void **)&r.h_dht, ROUND_MAX * sizeof(nxz_batch_dht_t)), return fail());
+	HIPCHK(hipHostMalloc((void **)&r.h_cnt, ROUND_MAX * 316 * sizeof(uint32_t)), return fail());
+	HIPCHK(hipMalloc((void **)&r.d_prep, ROUND_MAX * sizeof(nxz_dht_prepared_t)), return fail());
+	HIPCHK(hipMalloc((void **)&r.d_tok, (size_t)ROUND_MAX * NXZ_TOK_STRIDE), return fail());
+	HIPCHK(hipMalloc((void **)&r.d_cand2, nxz_lz77_cand2_bytes() / NXZ_LZ77_MAX_GRID * ROUND_MAX), return fail());
+	HIPCHK(hipMalloc((void **)&r.d_src, (size_t)ROUND_MAX * SUBBLOCK), return fail());
+	HIPCHK(hipHostMalloc((void **)&r.h_items, ROUND_MAX * sizeof(nxz_ctx::Round::Item)), return fail());
 	r.ready = true;
 	return true;
 }

@@ -106,8 +106,9 @@ extern "C" int nx_gzwrite(void *file, const void *buf, unsigned len)
 extern "C" int nx_gzread(void *file, void *buf, unsigned len)
 {
 	GzState *g = (GzState *)file;
-	if (!g || g->writer || g->err != Z_OK || len == 0) return 0;
-	if (g->done) return 0;
+	if (!g || g->writer) return -1;
+	if (g->err != Z_OK) return -1;                       // (zlib's gzread: an error stays an error, -1, not "end of file")
+	if (len == 0 || g->done) return 0;
 	uLong before = g->strm.total_out, produced = 0;
 	g->strm.next_out = (Bytef *)buf;
 	g->strm.avail_out = len;
@@ -165,9 +166,12 @@ extern "C" int nx_gzread(void *file, void *buf, unsigned len)
 			if (g->eof && g->used == 0) { g->done = true; break; }
 			continue;
 		}
-		if (rc != Z_OK && rc != Z_BUF_ERROR) { g->err = rc; return 0; }
+		// a damaged member: what this call has made so far -- earlier members' bytes included -- is the caller's (zlib's
+		// gzread returns it; the error is what the NEXT call reports), -1 only when there is nothing
+		if (rc != Z_OK && rc != Z_BUF_ERROR) { g->err = rc; break; }
 	}
-	return (int)(produced + g->strm.total_out - before);
+	const uLong n = produced + g->strm.total_out - before;
+	return n == 0 && g->err != Z_OK ? -1 : (int)n;
 }
 
 extern "C" int nx_gzclose(void *file)

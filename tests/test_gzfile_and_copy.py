@@ -61,7 +61,7 @@ def test_gz_argument_errors(L, tmp_path):
     assert not L.nx_gzopen(str(tmp_path / "missing" / "x.gz").encode(), b"r")
     assert L.nx_gzclose(None) == Z.Z_STREAM_ERROR
     assert L.nx_gzwrite(None, b"x", 1) == 0
-    assert L.nx_gzread(None, C.create_string_buffer(4), 4) == 0
+    assert L.nx_gzread(None, C.create_string_buffer(4), 4) == -1          # (zlib's gzread: -1 for a bad handle)
 
 
 def test_inflate_copy_continues_independently(L):
@@ -145,6 +145,36 @@ def test_gzread_reads_every_member_of_a_multi_member_file(L, tmp_path):
             got += buf.raw[:k]
         assert L.nx_gzclose(g) == 0
         assert got == want, (step, len(got), len(want))
+
+
+def test_gzread_hands_out_what_it_made_before_a_damaged_member(L, tmp_path):
+    """zlib's gzread: a decode error does not take back the bytes the call has produced (they are returned, the
+    error is what the NEXT call reports: -1), and an error is not an end of file (round 2's advisor finding:
+    0 was returned and the first member's data of that call was lost)."""
+    good = b"a good member\n" * 3000
+    path = tmp_path / "damaged.gz"
+    bad = bytearray(gzip.compress(os.urandom(50000), 6))
+    bad[len(bad) // 2] ^= 0x55; bad[len(bad) // 2 + 1] ^= 0xaa           # damage inside the second member's data
+    bad[-8:-4] = b"\0\0\0\0"                                            # ... and its CRC for good measure
+    with open(path, "wb") as f:
+        f.write(gzip.compress(good, 6) + bytes(bad))
+    L.nx_gzopen.restype = C.c_void_p
+    L.nx_gzopen.argtypes = [C.c_char_p, C.c_char_p]
+    L.nx_gzread.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    L.nx_gzclose.argtypes = [C.c_void_p]
+    g = L.nx_gzopen(str(path).encode(), b"rb")
+    assert g
+    buf = C.create_string_buffer(1 << 20)
+    got, last = b"", 0
+    for _ in range(100):
+        last = L.nx_gzread(g, buf, 1 << 20)
+        if last <= 0:
+            break
+        got += buf.raw[:last]
+    assert got[:len(good)] == good                       # the first member came out whole, whatever happened behind it
+    assert last == -1                                     # and the end was an error, not an end of file
+    assert L.nx_gzread(g, buf, 16) == -1                  # it stays one
+    L.nx_gzclose(g)
 
 
 def test_small_feeds_do_not_lose_the_next_member(L):
