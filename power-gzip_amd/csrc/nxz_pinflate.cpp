@@ -508,6 +508,19 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			for (size_t k = 0; k < nj; k++) sum_us += h_res[k].crc * 0.01;
 			for (size_t k = 1; k < nj; k++) if (h_res[k].crc > h_res[slow].crc) slow = k;
 			fprintf(stderr, "nxz_inflate_stream: round %d: the pieces' decode times add up to %.0f us (%.1f us each; / 5120 wavefronts at a time: %.0f us)\n", attempt, sum_us, sum_us / nj, sum_us / 5120);
+			{
+				std::vector<uint32_t> tt(nj);
+				for (size_t k = 0; k < nj; k++) tt[k] = h_res[k].crc;
+				std::sort(tt.begin(), tt.end());
+				fprintf(stderr, "nxz_inflate_stream: round %d: piece times, us: p10 %.0f  p50 %.0f  p75 %.0f  p90 %.0f  p99 %.0f  max %.0f\n", attempt,
+					tt[nj / 10] * 0.01, tt[nj / 2] * 0.01, tt[nj * 3 / 4] * 0.01, tt[nj * 9 / 10] * 0.01, tt[nj * 99 / 100] * 0.01, tt[nj - 1] * 0.01);
+				// time per compressed byte, by decile of the pieces in launch order (longest first)
+				for (size_t d = 0; d < 10 && nj >= 100; d++) {
+					double us = 0, by = 0, ob = 0;
+					for (size_t k = d * nj / 10; k < (d + 1) * nj / 10; k++) { us += h_res[k].crc * 0.01; by += h_jobs[k].src_len; ob += h_res[k].tpbc; }
+					fprintf(stderr, "nxz_inflate_stream:   launch decile %zu: %.0f us, %.0f bytes in, %.0f out a piece\n", d, us / (nj / 10), by / (nj / 10), ob / (nj / 10));
+				}
+			}
 			const P &q = pc[who[slow]];
 			fprintf(stderr, "nxz_inflate_stream: round %d: %zu pieces; the longest took %.1f us (piece %zu, %s%s: %llu bytes in, %u out, cc %u)\n", attempt, nj, h_res[slow].crc * 0.01,
 				who[slow], q.tab >= 0 ? "cut" : "block", q.srem ? ", starts in a stored block" : "", (unsigned long long)q.cbytes, h_res[slow].tpbc, h_res[slow].cc);
