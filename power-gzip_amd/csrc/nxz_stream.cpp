@@ -639,6 +639,18 @@ extern "C" int nx_deflate(z_streamp strm, int flush)
 // ---------------------------------------------------------------------------
 namespace {
 
+// a byte vector whose resize() does not zero what it adds (the output of a part of a stream that waits for next_out is
+// copied over it at once: 3.7 MiB of memset per 1 MiB step of inflate() otherwise)
+template <class T> struct default_init_alloc : std::allocator<T> {
+	template <class U> struct rebind { using other = default_init_alloc<U>; };
+	template <class U, class... A> void construct(U *p, A &&... a)
+	{
+		if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+		else ::new ((void *)p) U(std::forward<A>(a)...);
+	}
+};
+typedef std::vector<uint8_t, default_init_alloc<uint8_t>> raw_bytes;
+
 struct Inflate {
 	uint64_t magic = MAGIC_INF;
 	z_streamp z = nullptr;
@@ -649,7 +661,7 @@ struct Inflate {
 	uint32_t held = 0, nheld = 0, gzflags = 0, xlen = 0, zcmf = 0, dictid = 0;
 	gz_headerp gzhead = nullptr;
 	uint32_t hcrc = 0;                                 // running crc of the gzip header bytes
-	std::vector<uint8_t> pend; size_t pend_off = 0;    // produced bytes waiting for next_out
+	raw_bytes pend; size_t pend_off = 0;               // produced bytes waiting for next_out (resize() leaves new bytes as they are: megabytes per call)
 	std::vector<uint8_t> hist;                         // last <= 32 KiB of output
 	std::vector<uint8_t> carry;                        // source bytes taken from next_in but not yet consumed by the engine
 	std::vector<uint8_t> unget;                        // bytes taken from next_in that lie BEHIND the stream's trailer (the next member's):
