@@ -11,10 +11,11 @@ FC = {"fht": pkg.FC_COMPRESS_FHT, "dhtgen": pkg.FC_COMPRESS_DHTGEN}[os.environ.g
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = pkg.Engine(0)
 src = bench.gen_blocks(torch, eng.dev, n, 0)
-if len(sys.argv) > 2 and sys.argv[2] == "corpus":
+if len(sys.argv) > 2 and sys.argv[2].startswith("corpus"):       # "corpus", or "corpus:<class>" (elf, msgpack, text, ...)
     import corpus
     _, blocks, _ = corpus.load(65536)
-    full = [np.frombuffer(b, np.uint8) for _, _, b in blocks if len(b) == 65536]
+    want = sys.argv[2][7:]
+    full = [np.frombuffer(b, np.uint8) for cls, _, b in blocks if len(b) == 65536 and (not want or cls == want)]
     host = np.stack([full[i % len(full)] for i in range(n)])
     src = torch.from_numpy(host).to(eng.dev)
 elif len(sys.argv) > 2:
