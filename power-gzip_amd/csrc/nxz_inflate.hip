@@ -410,7 +410,7 @@ __device__ __forceinline__ void inflate_body(const nxz_batch_job_t *__restrict__
 	// from src, which nxz_pinflate.cpp keeps 16-byte aligned inside the caller's stream)
 	const uint32_t hist_bytes = W16 ? 0 : job.hist_len < job.src_len ? job.hist_len : job.src_len;
 	const uint32_t hist = W16 ? WIN : hist_bytes;      // how far back a match may reach before the output
-	const uint32_t srclen = job.src_len - hist_bytes;
+	uint32_t srclen = job.src_len - hist_bytes;          // (a piece of a stream may run on behind it: `ext` below)
 	const NXZ_GLOBAL_AS uint8_t *src = (const NXZ_GLOBAL_AS uint8_t *)job.src + hist_bytes;
 	NXZ_GLOBAL_AS uint8_t *dst = (NXZ_GLOBAL_AS uint8_t *)job.dst;
 	const uint32_t cap = job.dst_cap;
@@ -519,6 +519,14 @@ __device__ __forceinline__ void inflate_body(const nxz_batch_job_t *__restrict__
 	// not fit, and how much of the source it has used, and is resumed with the rest
 	const bool stop_full = (job.reserved & 1) != 0;
 	uint64_t stop_bits = ~0ull;                    // source position (bits) of such a suspension
+	// A piece of a stream (W16) that reads the stream in place and whose range ends inside a STORED block -- the start
+	// it was cut at lies in stored data that looks like a header -- runs on: dht_index says how many bytes of the stream
+	// lie behind its range.  It copies the block out, follows the stored blocks behind it while they fit its room and
+	// stands at the first header that is no stored block's, or whose block does not fit (nxz_pinflate.cpp finds or makes
+	// the piece that starts there; up to round 3's end such a piece stopped where its range ended, and a second round of
+	// launches decoded the rest of the run: 0.2-0.35 ms a stream).
+	uint32_t ext_avail = (W16 && GW) ? job.dht_index : 0, ext_total = 0;       // (the bit the next piece starts at -- in_adler -- does not hold a stored block back: a cut inside one is none)
+	bool ext = false;
 
 	// flush window bytes [flushed, upto) to dst and fold them into the checksums
 	auto flush = [&](uint32_t upto) {
@@ -605,15 +613,24 @@ tables_ready:
 			uint64_t hdr = b.pos;
 			if (!b.have(3)) { o_sfbt = 0xe; o_subc = (uint32_t)(b.total_bits - hdr); break; }
 			uint32_t v = b.peek();
+			if (W16 && ext && ((v >> 1) & 3) != 0) { o_sfbt = 0xe; stop_bits = hdr; break; }      // (ran on through stored blocks: this one is none)
 			bfinal = v & 1; btype = (v >> 1) & 3;
 			b.pos += 3;
 			nheaders++;
 			if (btype == 0) {
 				b.pos = (b.pos + 7) & ~7ull;
-				if (!b.have(32)) { o_sfbt = 0xe | bfinal; o_subc = (uint32_t)(b.total_bits - hdr); break; }
+				if (!b.have(32)) {
+					if (W16 && ext) { o_sfbt = 0xe; stop_bits = hdr; break; }
+					o_sfbt = 0xe | bfinal; o_subc = (uint32_t)(b.total_bits - hdr); break;
+				}
 				uint32_t w = b.peek();
 				b.pos += 32;
-				if (((w ^ (w >> 16)) & 0xffff) != 0xffff) { cc = NXZ_CC_INVALID_DHT; break; }
+				if (((w ^ (w >> 16)) & 0xffff) != 0xffff) {
+					if (W16 && ext) { o_sfbt = 0xe; stop_bits = hdr; break; }                       // (whoever starts at this header says what is wrong with it)
+					cc = NXZ_CC_INVALID_DHT; break;
+				}
+				// (running on: a block that does not fit the room, or does not lie whole inside the stream, is left to the piece that starts here)
+				if (W16 && ext && ((w & 0xffff) > cap - out || (uint64_t)(w & 0xffff) * 8 > b.total_bits - b.pos)) { o_sfbt = 0xe; stop_bits = hdr; break; }
 				rem = w & 0xffff;
 				state = 1;
 			} else if (btype == 1) {
@@ -651,6 +668,11 @@ tables_ready:
 		} else if (state == 1) {
 			// stored bytes: byte aligned; copy through the window
 			uint32_t srcleft = (uint32_t)((b.total_bits - b.pos) >> 3);
+			if (W16 && ext_avail && rem > srcleft && rem <= cap - out && rem - srcleft <= ext_avail) {
+				srclen += ext_avail; b.srclen = srclen; b.total_bits = (uint64_t)srclen * 8;
+				ext_total = ext_avail; ext_avail = 0; ext = true;
+				srcleft = (uint32_t)((b.total_bits - b.pos) >> 3);
+			}
 			uint32_t n = rem < srcleft ? rem : srcleft;
 			bool full_stop = false;
 			if (n > cap - out) {
@@ -939,7 +961,7 @@ done:
 #endif
 	if (lane == 0) {
 		nxz_batch_result_t r;
-		uint32_t spbc = job.src_len, subc = o_subc;
+		uint32_t spbc = job.src_len + ext_total, subc = o_subc;
 		if (stop_bits != ~0ull) {                      // the source bytes touched, and the bits of the last one that are not used yet
 			const uint32_t touched = (uint32_t)((stop_bits + 7) >> 3);
 			spbc = hist_bytes + touched; subc = touched * 8 - (uint32_t)stop_bits;

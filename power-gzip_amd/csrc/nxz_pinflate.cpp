@@ -458,6 +458,9 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			if (p.srem) j.resume = p.srem | ((0x8u | p.sfin) << 16);                     // inside a stored block (on a byte boundary)
 			j.in_adler = (uint32_t)p.stop;
 			j.in_crc = p.tab >= 0 ? (uint32_t)p.tab + 1 : 0;                             // (which block's ready-made tables)
+			// (what of the stream lies behind the piece's range: a piece whose range ends inside a stored block runs on)
+			static const bool run_on = !(getenv("NXZ_PINFLATE_RUN_ON") && atoi(getenv("NXZ_PINFLATE_RUN_ON")) == 0);
+			j.dht_index = direct && run_on ? (uint32_t)std::min<uint64_t>(src_len - (p.cstart + p.cbytes), 0x7fffffffull) : 0;
 		}
 		if (!win0_made) {
 			// the window in front of the whole output: zeros, the caller's history at its end
@@ -537,7 +540,21 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			for (size_t i = 0; i + 1 < pc.size() && wi.size() < n0; i++) {
 				const P &p = pc[i];
 				const nxz_batch_result_t &r = p.res;
-				if (!p.done || r.cc != NXZ_CC_DATA_LENGTH || (r.sfbt & 0xe) != 0x8 || !r.tebc || pc[i + 1].srem) continue;
+				if (!p.done || r.cc != NXZ_CC_DATA_LENGTH) continue;
+				if ((r.sfbt & 0xe) == 0xe && r.spbc > p.cbytes) {
+					// it ran on through stored blocks behind its range and stands at a header, E (see below).  A piece starts
+					// there: nothing to ask.  Else: is that header a stored block's (one that did not fit), and where does its run end?
+					const uint64_t E = (p.cstart + r.spbc) * 8 - r.subc;
+					size_t jn = i + 1;
+					while (jn < pc.size() && pc[jn].bit < E) jn++;
+					if (jn < pc.size() && pc[jn].bit == E) continue;
+					nxz_walk_req_t &w = h_wq[wi.size()];
+					w.src = src; w.src_len = src_len;
+					w.bit = E; w.rem = 0; w.bfinal = 0;
+					wi.push_back(i);
+					continue;
+				}
+				if ((r.sfbt & 0xe) != 0x8 || !r.tebc || pc[i + 1].srem) continue;
 				nxz_walk_req_t &w = h_wq[wi.size()];
 				w.src = src; w.src_len = src_len;
 				w.bit = p.cstart * 8 + (p.stop ? p.stop : p.cbytes * 8) - r.subc;
@@ -595,14 +612,39 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			}
 			bool ends_well = !err;
 			if (!fin && i + 1 < pc.size()) {
-				const uint64_t used = (p.stop ? p.stop : p.cbytes * 8) - r.subc, want = pc[i + 1].bit - p.cstart * 8;
+				// (r.spbc beyond the piece's own bytes: it ran on through stored blocks behind its range, see below)
+				const uint64_t used = (r.spbc > p.cbytes ? (uint64_t)r.spbc * 8 : p.stop ? p.stop : p.cbytes * 8) - r.subc, want = pc[i + 1].bit - p.cstart * 8;
 				const uint32_t kind = r.sfbt & 0xe;
 				ends_well = r.cc == NXZ_CC_DATA_LENGTH && ((kind == 0xe && used == want) || (kind == 0xa && used == want + 3));
+				bool ran_on = false;
+				if (r.cc == NXZ_CC_DATA_LENGTH && kind == 0xe && r.spbc > p.cbytes && used > want && p.done) {
+					// Its range ended inside a stored block (the start it was cut at is stored data that looks like a
+					// header) and it went on: through that block and the stored ones behind it that fit its room, to a
+					// header, E.  The starts in between are none.  A piece starts at E: all is well.  None does (a block the
+					// search did not see, a fixed one, a stored one that did not fit): one is made, which takes what lies
+					// between E -- or the end of the stored run that begins at E -- and the next start, and is decoded next round.
+					const uint64_t E = p.cstart * 8 + used;
+					size_t jn = i + 1;
+					while (jn < pc.size() && pc[jn].bit < E) jn++;
+					swallow_until = E;
+					const bool at_end = E + 8 > src_len * 8;                       // (it stands where the source ends: a part of a stream)
+					if ((jn == pc.size() && at_end) || (jn < pc.size() && pc[jn].bit == E && pc[jn].tab < 0 && !pc[jn].srem)) ran_on = true;
+					else {
+						P q = P();
+						q.bit = E; q.capmul = capmul_for(src_len); q.tab = -1; q.hdr0 = 1; q.done = false;
+						swallow_until = std::max<uint64_t>(E + 1, run_end[i]);      // (+ 1: a cut that happens to stand on E goes as well)
+						nx.push_back(p);
+						nx.push_back(q);
+						again = true; confirmed = false;
+						continue;
+					}
+				}
 				// a cut inside a dynamic block: this piece must stand exactly there, still in the block it began in (it has
 				// read that block's header and no other, or none if it began at a cut itself)
 				// the next piece is the rest of the stored block this one stopped in (see below)
 				if (pc[i + 1].srem) ends_well = r.cc == NXZ_CC_DATA_LENGTH && kind == 0x8 && used == want && r.tebc == pc[i + 1].srem;
 				if (pc[i + 1].tab >= 0) ends_well = r.cc == NXZ_CC_DATA_LENGTH && kind == 0xc && (r.sfbt & 1) == pc[i + 1].cfin && used == want && r.adler == p.hdr0;
+				if (ran_on) ends_well = true;
 				if (!ends_well && trace)
 					fprintf(stderr, "nxz_inflate_stream: piece %zu (bit %llu, %llu bytes in, %u out, start %s) cc %u sfbt %#x subc %u: used %llu bits, next header thought at %llu\n",
 						i, (unsigned long long)p.bit, (unsigned long long)p.cbytes, r.tpbc, conf ? "confirmed" : "open", r.cc, r.sfbt, r.subc, (unsigned long long)used, (unsigned long long)want);
