@@ -788,9 +788,17 @@ extern "C" int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t 
 }
 
 // group maps / group windows: room for n / nxz_window_chain_group(0) + 1 maps (64 KiB each) and windows (32 KiB each).
-// Pieces per group: composing a group's maps takes 7.6 us a piece, a walk 2.3 us a step, so
-// 9.9 g + 2.3 n / g in all -- least at g = 0.48 sqrt(n).  (n = 0: the smallest group there is.)
-extern "C" uint32_t nxz_window_chain_group(uint32_t n) { return n == 0 || n < 400 ? 8 : n < 1600 ? 16 : 32; }
+// Pieces per group (n = 0: the smallest group there is): composing a group's maps takes ~7 us a piece, a walk over
+// piece or group maps in memory 1.7 us a step.
+extern "C" uint32_t nxz_window_chain_group(uint32_t n)
+{
+	static const uint32_t env = getenv("NXZ_CHAIN_GROUP") ? (uint32_t)atoi(getenv("NXZ_CHAIN_GROUP")) : 0;
+	if (n && (env == 8 || env == 16 || env == 32 || env == 64)) return env;
+	// (with the third level the walk over the groups no longer grows with their number, and short groups mean short
+	// composing: 8 pieces a group at every length -- 749 pieces: 1.30 -> 1.21 ms, 1405: 2.02 -> 1.94, 4926 and 6821: the same
+	// as with 16 or 32; up to the third level it was 8 / 16 / 32 by length, least at 0.48 sqrt(n))
+	return 8;
+}
 extern "C" int nxz_launch_window_chain(const void *pieces, uint32_t n, const uint8_t *win0, uint8_t *windows,
 				       uint16_t *gmaps, uint8_t *gwin, hipStream_t stream)
 {

@@ -365,7 +365,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	// (a whole stream with hardly anything to do side by side: the job loop serves as well.  A part of a stream is
 	// taken whatever it is made of -- stored blocks, fixed-Huffman blocks: the caller's alternative is one wavefront too)
 	if (pc.size() < 3 && !st) return -ENOTSUP;
-	const size_t n0 = pc.size(), ng0 = n0 / nxz_window_chain_group(0) + 1;
+	const size_t n0 = pc.size(), ng0 = n0 / nxz_window_chain_group(0) + n0 / (nxz_window_chain_group(0) * 16) + 4;   // (groups of the smallest size, and the groups of 16 of them)
 	// control arrays (sized for the first, longest list of pieces), then a bump area for copies and outputs
 	const size_t o_jobs = 0, o_res = o_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), o_items = o_res + up(n0 * sizeof(nxz_batch_result_t), 256),
 		     o_pieces = o_items + up((n0 + 4) * sizeof(CopyItem), 256), o_win0 = o_pieces + up(n0 * sizeof(Piece), 256),
