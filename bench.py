@@ -582,6 +582,48 @@ def api_leg(raw, args, mib=256, nthreads=16):
             return dict(out, error="nx_compress2 failed in a thread")
         out["threads_%d_x_64KiB" % T] = {"value": round(T * len(blocks) * BLOCK / dt / 2.0 ** 30, 3), "unit": "GiB/s uncompressed in, all threads",
                                          "us_per_call": round(dt / len(blocks) * 1e6, 1), "calls_per_thread": len(blocks)}
+    # the same harness shape at a size where the engine is meant to win: every thread 1 MiB buffers, one call per buffer,
+    # compress and decompress (the whole sizes x threads table: tools/api_sweep.py, profiles/r03_api_sweep.txt)
+    big = [data[i << 20:(i + 1) << 20] for i in range(min(48, len(data) >> 20))]
+    zbig = [zlib.compress(b, 6) for b in big[:16]]
+
+    def worker_big(res, k, inflate):
+        tot = 0
+        if inflate:
+            d = C.create_string_buffer(1 << 20)
+            for i in range(len(big)):
+                z = zbig[(i + k) % len(zbig)]
+                n = C.c_ulong(1 << 20)
+                if L.nx_uncompress(d, C.byref(n), z, len(z)) != 0 or n.value != (1 << 20):
+                    tot = -1
+                    break
+                tot += n.value
+        else:
+            c = C.c_ulong()
+            d = C.create_string_buffer(L.nx_compressBound(1 << 20))
+            for i in range(len(big)):
+                b = big[(i + k) % len(big)]
+                c.value = len(d)
+                if L.nx_compress2(d, C.byref(c), b, len(b), 1) != 0:
+                    tot = -1
+                    break
+                tot += len(b)
+        res[k] = tot
+
+    for inflate in (False, True):
+        res = [0] * nthreads
+        th = [threading.Thread(target=worker_big, args=(res, k, inflate)) for k in range(nthreads)]
+        t = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t
+        if min(res) < 0:
+            return dict(out, error="a 1 MiB call failed in a thread")
+        out["threads_%d_x_1MiB_%s" % (nthreads, "uncompress" if inflate else "compress2")] = {
+            "value": round(sum(res) / dt / 2.0 ** 30, 3), "unit": "GiB/s uncompressed, all threads", "us_per_call": round(dt / len(big) * 1e6, 1),
+            "calls_per_thread": len(big)}
     if not args.no_cpu_baseline:
         t = time.perf_counter()
         zlib.compress(data[:32 << 20], 1)
