@@ -1131,6 +1131,7 @@ __global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__
 		if (rend > rq.guess_bit + 64 + SYNC_RUN + 2048) rend = rq.guess_bit + 64 + SYNC_RUN + 2048;
 		uint32_t pos = rq.guess_bit + (uint32_t)lane;
 		bool alive = true;
+		uint32_t made = 0;                                          // bytes the tokens this lane walked over make (an estimate of the data's ratio for the caller)
 		auto step = [&]() __attribute__((always_inline)) {
 			const uint32_t o = pos - rbase, i = o >> 5, sh = o & 31;
 			const uint32_t a0 = region[i], a1 = region[i + 1], a2 = region[i + 2];
@@ -1138,9 +1139,10 @@ __global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__
 			uint32_t nb = 0;
 			const int sym = decode_sym<LBITS>(sm.hl, w0, nb);
 			if (sym < 0 || sym == 256 || sym >= 257 + 29) { alive = false; return; }
-			if (sym < 256) { pos += nb; return; }
+			if (sym < 256) { pos += nb; made++; return; }
 			uint32_t lbase, eb, dbase, ebd, nbd = 0;
 			len_params((uint32_t)sym - 257, lbase, eb);
+			made += lbase + (__builtin_amdgcn_alignbit(w1, w0, nb) & ((1u << eb) - 1));
 			const uint32_t o2 = nb + eb;                                      // <= 15 + 5
 			const int ds = decode_sym<DBITS>(sm.hd, __builtin_amdgcn_alignbit(w1, w0, o2), nbd);
 			if (ds < 0 || ds >= 30) { alive = false; return; }
@@ -1161,7 +1163,15 @@ __global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__
 				mx = x > mx ? x : mx; mn = y < mn ? y : mn;
 			}
 			if (mn == 0xffffffffu) break;                                     // no lane left
-			if (mn == mx) { out.bit = mx; out.lanes |= (uint32_t)__popcll(__ballot(alive)); break; }
+			if (mn == mx) {
+				// (bits 8..23: bytes of output per 256 bits of source on the way here, as the first lane still walking saw it)
+				const unsigned long long al = __ballot(alive);
+				const uint32_t l0 = (uint32_t)__builtin_ctzll(al);
+				const uint32_t m0 = (uint32_t)__shfl((int)made, (int)l0, 64), b0 = mx - (rq.guess_bit + l0);
+				uint32_t per256 = b0 ? (uint32_t)(((uint64_t)m0 << 8) / b0) : 0;
+				if (per256 > 0xffff) per256 = 0xffff;
+				out.bit = mx; out.lanes |= (uint32_t)__popcll(al) | per256 << 8; break;
+			}
 			while (__ballot(alive && pos < mx)) {
 				if (alive && pos < mx) { if (pos + 64 <= rend) step(); else alive = false; }
 			}

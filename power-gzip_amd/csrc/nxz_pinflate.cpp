@@ -249,7 +249,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	// With that few pieces the call takes as long as the longest piece, milliseconds for a block of 100 KiB.
 	// Inside a dynamic block any token boundary will do as a cut (the piece there is a job that resumes
 	// inside a dynamic block, with the block's table); token_sync_kernel finds boundaries near the bits asked for.
-	struct Sub { uint64_t bit; uint32_t tab, fin; };
+	struct Sub { uint64_t bit; uint32_t tab, fin, per256; };        // per256: bytes of output per 256 bits of source around the cut (token_sync_kernel's estimate)
 	std::vector<Sub> subs;
 	std::vector<nxz_batch_dht_t> tabs;
 	{
@@ -326,7 +326,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			for (size_t k = 0; k < nr; k++) {
 				if (rs[k].bit == 0xffffffffu) continue;
 				const uint32_t blk = rq[k].header_bit;
-				subs.push_back(Sub{ rq_base[k] + rs[k].bit, blk, blk == 0 && given ? (st->sfbt & 1u) : rs[k].lanes >> 31 });
+				subs.push_back(Sub{ rq_base[k] + rs[k].bit, blk, blk == 0 && given ? (st->sfbt & 1u) : rs[k].lanes >> 31, (rs[k].lanes >> 8) & 0xffff });
 			}
 			if (trace) fprintf(stderr, "nxz_inflate_stream: %zu blocks, %zu token boundaries asked for in %zu of them, %zu found\n", B.size(), nr, nb, subs.size());
 			lap("token boundaries");
@@ -341,6 +341,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		uint32_t hdr0;                          // block headers it has read while it is still in the block it began in
 		uint32_t srem, sfin;                    // starts inside a stored block: bytes of it still to come (else 0), its BFINAL
 		uint32_t cfin;                          // starts inside a dynamic block: its BFINAL
+		uint32_t per256;                        // bytes of output per 256 bits of source, estimated (0: not known)
 		size_t stage_off, out_off;              // its 16-byte aligned copy of those bytes / its 16-bit output, in the bump area
 		uint64_t cap;                           // output elements it may produce
 		uint32_t capmul;
@@ -358,7 +359,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		const uint64_t end = i + 1 < B.size() ? B[i + 1] : src_len * 8;
 		for (; k < subs.size() && subs[k].bit < end; k++) {
 			if (subs[k].bit < pc.back().bit + 2048 || subs[k].bit + 2048 > end) continue;     // (too close to its neighbours to be worth a piece)
-			p.bit = subs[k].bit; p.tab = (int)subs[k].tab; p.cfin = subs[k].fin;
+			p.bit = subs[k].bit; p.tab = (int)subs[k].tab; p.cfin = subs[k].fin; p.per256 = subs[k].per256;
 			pc.push_back(p);
 		}
 	}
@@ -435,7 +436,21 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			// (by counting, 64 bytes a bucket: a comparison sort of 7000 pieces is a quarter of a millisecond the device waits for)
 			constexpr size_t NB = 2048;
 			std::vector<uint32_t> cnt(NB + 1, 0);
-			auto bucket = [&](size_t i) -> size_t { const uint64_t b = pc[i].cbytes >> 6; return NB - 1 - (size_t)std::min<uint64_t>(b, NB - 1); };
+			// (a piece's time, in cycles of a wavefront on its own: 365 per byte of source + 5.4 per byte it makes -- DESIGN.md
+			// section 6 --, the latter from token_sync_kernel's estimate around the piece's first bit; a piece that starts at a
+			// block header takes the estimate of the first cut behind it, one without any the average)
+			static const bool by_time = !(getenv("NXZ_PINFLATE_LPT_TIME") && atoi(getenv("NXZ_PINFLATE_LPT_TIME")) == 0);
+			uint64_t sum256 = 0, n256 = 0;
+			for (size_t k = 0; k < pc.size(); k++) if (pc[k].per256) { sum256 += pc[k].per256; n256++; }
+			const uint32_t avg256 = n256 ? (uint32_t)(sum256 / n256) : 0;
+			auto bucket = [&](size_t i) -> size_t {
+				uint32_t r = pc[i].per256;
+				if (!r && i + 1 < pc.size() && pc[i + 1].tab >= 0) r = pc[i + 1].per256;
+				if (!r) r = avg256;
+				const uint64_t eq = by_time ? pc[i].cbytes * (23360 + 11 * (uint64_t)r) / 23360 : pc[i].cbytes;      // in bytes of source without output
+				const uint64_t b = eq >> 7;
+				return NB - 1 - (size_t)std::min<uint64_t>(b, NB - 1);
+			};
 			for (size_t k = 0; k < who.size(); k++) cnt[bucket(who[k]) + 1]++;
 			for (size_t b = 0; b < NB; b++) cnt[b + 1] += cnt[b];
 			std::vector<size_t> tw(who.size());
