@@ -103,6 +103,8 @@ def reduce_totals(torch, dist, dev, u_bytes, c_bytes, wall, distributed):
     if distributed:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if os.environ.get("NXZ_BENCH_TRACE_COLLECTIVES") and dist.get_rank() == 0:
+            print("collectives: backend %s, all_reduce SUM + MAX on %s, world %d" % (dist.get_backend(), tot.device.type, dist.get_world_size()), file=sys.stderr)
     return float(tot[0].item()), float(tot[1].item()), float(tmax.item())
 
 
@@ -935,6 +937,38 @@ def c2_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, n, st
     return line
 
 
+def launcher_command(n_gpus, argv, port):
+    """the command line that runs this bench on n_gpus ranks of one node (what the driver uses for N > 1)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n_gpus, argv, visible=None, run=None):
+    """`python bench.py --gpus N` without a launcher: one rank per GPU as FRESH child processes (this process has not
+    touched the GPU and never does: it relays rank 0's JSON line and the exit code).  Independent blocks shard over the
+    ranks, RCCL carries the two all-reduces of reduce_totals (the reference's analogue is a process that
+    opens whichever NX unit is nearest, lib/nx_zlib.c:568-576,1281-1287).  Returns the exit code."""
+    import socket
+    import subprocess
+    if visible is None:
+        import torch
+        visible = torch.cuda.device_count()            # (counting devices does not initialise the GPU)
+    if visible < n_gpus:
+        print("bench.py: %d GPUs requested, %d visible" % (n_gpus, visible), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launcher_command(n_gpus, argv, port)
+    p = (run or subprocess.run)(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(p.stdout)
+    sys.stdout.flush()
+    return p.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -952,6 +986,10 @@ def main():
     ap.add_argument("--no-corpus", action="store_true", help="(kept for old command lines: no effect)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the ranks ourselves, BEFORE anything in this process touches the GPU
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
@@ -959,10 +997,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." %
-                             (args.gpus, args.gpus))
-    distributed = world > 1
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree" % (args.gpus, world))
+    distributed = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ)   # under a launcher the collectives run, even on one rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:

@@ -34,7 +34,7 @@ void   nxz_inflate_take_unget(struct z_stream_s *strm, unsigned char *dst);
 /* AUTO mode's switchable streams (nxz_zlib_api.cpp): the parameters an engine stream was opened with, and whether
  * nothing has happened to it yet (no input taken, no dictionary, no header) -- then it can still become a
  * software zlib stream with the same parameters.  Return 0 if strm is not such a stream. */
-int nxz_deflate_pristine(struct z_stream_s *strm, int *level, int *wbits, int *strategy);
+int nxz_deflate_pristine(struct z_stream_s *strm, int *level, int *wbits, int *strategy, int *memlevel);
 int nxz_inflate_pristine(struct z_stream_s *strm, int *wbits);
 
 #ifdef __cplusplus

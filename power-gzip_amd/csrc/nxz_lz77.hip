@@ -42,14 +42,24 @@
 #include <stdint.h>
 #include "nxz_device.h"
 
-// Diagnostic only (tools/phase_profile.py): per-phase cycle sums of every workgroup's thread 0.
+// Diagnostic only (tools/phase_profile.py, a build with -DNXZ_LZ77_PROF: tools/build_variant.sh prof nxz_lz77.hip -DNXZ_LZ77_PROF):
+// per-phase cycle sums of every workgroup's thread 0.  Compiled out of the product: the counters cost a dozen
+// vector registers in a kernel that sits at its 128-register cap.
 __device__ unsigned long long *nxz_lz77_prof_buf = nullptr;
 #define NXZ_GLOBAL NXZ_GLOBAL_AS
+#ifdef NXZ_LZ77_PROF
 #define WPROF_BEGIN() unsigned long long wp_ = prof ? clock64() : 0
 #define WPROF_END(idx) do { if (prof) { const unsigned long long now_ = clock64(); wacc[(idx) - 16] += now_ - wp_; wp_ = now_; } } while (0)
 // (phase sums are collected in LDS and leave with one atomic per counter and job: the chain wave
 // waits on its own vector-memory counter, an atomic in flight there would be timed as chain)
 #define PROF(idx) do { if (prof) { if (t == 0) { unsigned long long now_ = clock64(); profacc[idx] += (uint32_t)(now_ - tprev); tprev = now_; } } } while (0)
+#define PCOUNT(idx, n) do { if (prof && lane == 0) atomicAdd(&profacc[idx], (uint32_t)(n)); } while (0)
+#else
+#define PCOUNT(idx, n) do { } while (0)
+#define WPROF_BEGIN() do { } while (0)
+#define WPROF_END(idx) do { } while (0)
+#define PROF(idx) do { } while (0)
+#endif
 
 namespace nxzl77 {
 
@@ -63,8 +73,24 @@ constexpr uint32_t ETILE = 2048;         // positions per encode step
 constexpr uint32_t LAZY_MAX = 32;
 constexpr uint32_t MAXMATCH = 258;
 constexpr uint32_t WINDOW = 32768;
-constexpr uint32_t LCAP = 40;            // lane-serial tail extension stops here; 16 lanes per tail beyond
+constexpr uint32_t OPEN2 = 24;           // bytes that the first level of M2 settles (8 from M1 + one 16-byte round trip)
 constexpr uint32_t NOHASH = 0xFFFFu;
+#ifndef NXZ_GROUP_ROUNDS
+#define NXZ_GROUP_ROUNDS 8
+#endif
+#ifndef NXZ_GROUP_MIN
+#define NXZ_GROUP_MIN 3
+#endif
+#ifndef NXZ_GROUP_MISS
+#define NXZ_GROUP_MISS 2
+#endif
+#ifndef NXZ_GROUP_GATE
+#define NXZ_GROUP_GATE 10
+#endif
+constexpr uint32_t GROUP_ROUNDS = NXZ_GROUP_ROUNDS;   // distances looked at per batch of 64 long positions (open tails are extended a group at a time)
+constexpr uint32_t GROUP_GATE = NXZ_GROUP_GATE;       // ... tails of a batch that must have a neighbour in the queue at their distance before the wave looks for groups at all
+constexpr uint32_t GROUP_MISS = NXZ_GROUP_MISS;       // ... distances with a tail on its own after which a batch is given up
+constexpr uint32_t GROUP_MIN = NXZ_GROUP_MIN;         // ... tails of one distance that are worth a trip of the whole wave
 // device scratch of a workgroup (16-bit units): carries a tile's second bucket entries from the chain
 // wave to the match waves (+ room for a piece past the end)
 constexpr uint32_t C2_STRIDE = PTILE + 1024;
@@ -81,7 +107,7 @@ constexpr uint32_t OFF_ENTRY = OFF_X + NSEG * 2;         // 1024 x u16
 constexpr uint32_t OFF_BITS  = OFF_ENTRY + NSEG * 2;     // 4096 + 64 bytes: the CRC tables before the first tile, match-phase queues later
 constexpr uint32_t BITS_BYTES = ETILE * 2 + 64;
 // during the match phase the window region holds: 16 x 96 queue entries (long positions), 16 x 80
-// (tails beyond LCAP) and the e-flag bitmap (PTILE + 288 bits)
+// (positions still open after OPEN2 bytes) and the e-flag bitmap (PTILE + 288 bits)
 constexpr uint32_t OFF_LQ    = OFF_X;
 constexpr uint32_t OFF_XQ    = OFF_LQ + 16 * 96 * 2;
 constexpr uint32_t OFF_EB    = OFF_XQ + 16 * 80 * 2;     // 2096 bytes; bit EBO + i = flag of tile position i
@@ -285,9 +311,13 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	uint32_t *scan = (uint32_t *)(lds + OFF_SCAN);
 	uint32_t *hist = (uint32_t *)(lds + OFF_HIST);
 	uint32_t *misc = (uint32_t *)(lds + OFF_MISC);
+#ifdef NXZ_LZ77_PROF
 	uint32_t *profacc = (uint32_t *)(lds + OFF_PROF);
+#endif
 
+#ifdef NXZ_LZ77_PROF
 	NXZ_GLOBAL unsigned long long *prof = (NXZ_GLOBAL unsigned long long *)nxz_lz77_prof_buf;
+#endif
 	// The grid is one workgroup per CU (the LDS image allows no more); a workgroup starts with job
 	// blockIdx.x and then draws further jobs from a counter (or strides by the grid without one), so
 	// nothing waits for a dispatch in between and slow jobs do not pile up in one place.  The draw
@@ -299,8 +329,10 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	int tid_ = threadIdx.x;
 	asm volatile("" : "+v"(tid_));
 	const int t = tid_, lane = t & 63, wave = t >> 6;
+#ifdef NXZ_LZ77_PROF
 	unsigned long long tprev = prof ? clock64() : 0;
 	unsigned long long wacc[4] = { 0, 0, 0, 0 };               // diagnostic: this wave's cycles in sections of the match phase
+#endif
 	const nxz_batch_job_t job = jobs[bid];
 	const uint32_t total = job.src_len;                  // window + block
 	const uint32_t h = job.hist_len < total ? job.hist_len : total;
@@ -327,7 +359,9 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	for (uint32_t i = t; i < HSIZE; i += NT) head[i] = 0;
 	if (t < 316) hist[t] = 0;
 	if (t < 16 && t != M_NEXT) misc[t] = FUSED && t == M_KEEP ? 3u : 0u;       // (FUSED: the block's header bits, BFINAL = 1, BTYPE = 01)
+#ifdef NXZ_LZ77_PROF
 	if (t < 20) profacc[t] = 0;
+#endif
 	// slice-by-4 CRC tables live in the (not yet used) bit buffer: T[k][i] = i advanced by k+1 zero bytes
 	{
 		uint32_t c = t & 255;
@@ -572,6 +606,10 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 			// Publishing needs no wait either: the flag store follows the data stores in LDS order.
 			uint8_t *headb = (uint8_t *)head;
 			__builtin_amdgcn_s_setprio(3);                    // the chain is the critical path of this phase
+			// (the lane number is made opaque per tile: the eight values lane + 64 u + 1 of a piece's steps would
+			// otherwise be computed once per kernel and kept -- three of them spilled, and reloaded right here)
+			int clane = lane;
+			asm volatile("" : "+v"(clane));
 			// Per 64-position step: read the bucket (both entries), store my position + 1 over its
 			// newest entry -- a plain 16-bit store: of the lanes of one store instruction that hit the
 			// same bucket the highest, i.e. the largest position, lands last (tools/micro/
@@ -595,7 +633,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 					uint32_t *slot = (uint32_t *)(headb + off[u]);
 					old[u] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					__builtin_amdgcn_wave_barrier();
-					*(uint16_t *)slot = (uint16_t)(h + tb0 + (piece << 9) + 64 * u + lane + 1);
+					*(uint16_t *)slot = (uint16_t)(h + tb0 + (piece << 9) + 64 * u + clane + 1);
 					__builtin_amdgcn_wave_barrier();
 				}
 			};
@@ -701,117 +739,177 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 			uint16_t *xq = (uint16_t *)(lds + OFF_XQ) + wave * 80;          // tails beyond LCAP
 			uint32_t xqn = 0;
 			uint32_t lqn = 0;
-			// tails that are still equal after LCAP bytes: 16 lanes per tail, 64 bytes per step
-			auto longext = [&](uint32_t nl) {
-				const uint32_t g = lane >> 4, li = lane & 15;
-				for (uint32_t base = 0; base < nl; base += 4) {
-					const bool act = base + g < nl;
-					const uint32_t i = act ? (uint32_t)xq[base + g] : 0;
-					const uint32_t r = h + tb0 + i, q = r - cand[i] - 1;
-					const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-					uint32_t N = 0;
-					bool done = !act;
-					for (uint32_t off = LCAP;; off += 64) {
-						const uint32_t o = off + 4 * li;
-						uint32_t x = 0;
-						if (!done && o < maxlen) x = lds_ld32(inw, q + o) ^ lds_ld32(inw, r + o);
-						const bool ev = !done && (x != 0 || o + 4 >= maxlen);   // mismatch or end of the compare
-						const unsigned long long mm = __ballot(ev);
-						const uint32_t gm = (uint32_t)(mm >> (16 * g)) & 0xffffu;
-						uint32_t myN = x ? o + ((uint32_t)__builtin_ctz(x) >> 3) : maxlen;
-						if (myN > maxlen) myN = maxlen;
-						const uint32_t firstN = __shfl(myN, gm ? (g << 4) + (uint32_t)__builtin_ctz(gm) : (uint32_t)lane, 64);
-						if (!done && gm) { N = firstN; done = true; }
-						if (!__ballot(!done)) break;
-					}
-					if (act && li == 0) mlen[i] = (uint8_t)(N - 3);
-				}
-			};
-			// 64 long positions: member of the successor's chain, or tail
-			auto stage2 = [&](uint32_t nq) {
-				const uint32_t ent = lane < nq ? (uint32_t)lq[lane] : 0;
-				__builtin_amdgcn_wave_barrier();
-				if (nq > 64 && 64 + lane < nq) lq[lane] = lq[64 + lane];
-				// almost always one position per entry; more only when neighbours have different distances
-				for (uint32_t pb = ent >> 12; __ballot(pb != 0); pb &= pb - 1) {
-				const uint32_t i = pb ? ((ent & 0xfff) << 2) + (uint32_t)__builtin_ctz(pb) : 0xffffffffu;
-				bool lg = false;
-				if (i != 0xffffffffu) {
-					// round trip 1: my distance and the verified positions i+1 .. i+32, not looking
-					// beyond the piece (another wave's)
-					const uint32_t dA = cand[i];
+			// M2 in two levels (a long position = one with 8 equal bytes whose direct successor does not go on at its distance):
+			//  level 1 (stage2, the queue lq[]): bytes 8..23 in one LDS round trip.  A mismatch among them makes the length
+			//     final -- seven in ten end here, and they pay for nothing else (up to round 3 every long position looked
+			//     for its successor first: two more round trips and the member bookkeeping for all of them).
+			//  level 2 (the queue xq[], 16 or more at a time): positions that are still open after OPEN2 = 24 bytes.  A
+			//     successor at the same distance inside those bytes makes one a member of that successor's chain (M3 reads its
+			//     length off the chain's end); the last position of a unit is settled after the barrier; the others are TAILS:
+			//     a. a GROUP at a time.  All the tails of one unit of 256 positions that have the same distance end at the
+			//        same few mismatches: the wave compares the 512 bytes behind the unit's start with those a distance in
+			//        front of them ONCE (8 bytes per lane, one ballot), and every tail of the group reads its end off -- the
+			//        first lane at or behind its own position that holds a mismatch (its first 24 bytes are known to be
+			//        equal, so a lane boundary up to 8 bytes behind its start is where it begins to look).  Data that repeats
+			//        at several distances at once (JSON, msgpack: neighbours take turns between two or three distances, a
+			//        chain is 4.6 positions long and its tail 113 bytes) costs one trip per distance instead of one per tail
+			//        and 16 bytes.  Whether a batch is worth the look is decided by a count: tails of one group stand close
+			//        together in the queue, so those whose distance is that of one of the two entries in front of them are
+			//        counted (two DPP moves); text and binaries, where every match has its own distance, stop there.
+			//     b. what is left: with a dozen or more every lane finishes its own, 32 bytes per LDS round trip (periodic
+			//        data, candidates at ever changing distances); else 16 lanes per tail, 64 bytes per step.
+			// The lengths are exact whichever way they are found (oracle/nxz_lz77.c step 4).
+			auto level2 = [&](uint32_t nl) {
+				for (uint32_t base = 0; base < nl; base += 64) {
+					const bool act = base + lane < nl;
+					const uint32_t i = act ? (uint32_t)xq[base + lane] : 0;
+					// round trip 1: my distance and the verified positions i+1 .. i+32, not looking beyond the unit (another wave's)
+					const uint32_t dT = cand[i];                            // my distance - 1
 					const uint32_t pend = (i | 255) + 1 < tn ? (i | 255) + 1 : tn;
 					uint32_t w32 = (uint32_t)((((uint64_t)vb[((i + 1) >> 5) + 1] << 32) | vb[(i + 1) >> 5]) >> ((i + 1) & 31));
 					if (pend - i <= 32) w32 &= (1u << (pend - i - 1)) - 1;
 					const uint32_t g1 = w32 ? (uint32_t)__builtin_ctz(w32) : 32, sp = w32 ? i + 1 + g1 : i;
-					// round trip 2: the successor's entry and (speculatively) bytes 8..23 of both strings
-					const uint32_t r = h + tb0 + i, q = r - dA - 1;
-					const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-					const bool same_d = w32 != 0 && cand[sp] == dA;
-					const uint32_t msp = mlen[sp];
-					uint32_t len = 8 + equal16(inw, q + 8, r + 8);
-					if (g1 < 8 && same_d) {
-						// the successor lies inside my 8 bytes: N = N(successor) + gap; for a direct
-						// successor with less than 8 bytes that is 8, which is what M1 stored
-						if (g1 || msp >= 5) {
-							const uint64_t km = (uint64_t)((2u << g1) - 1) << (i & 31);          // bits i .. sp-1
-							atomicOr(&kb[i >> 5], (uint32_t)km);
-							if (km >> 32) atomicOr(&kb[(i >> 5) + 1], (uint32_t)(km >> 32));
-						}
-					} else if (w32 == 0 && i + 1 == pend && pend < tn) {
-						// last position of the piece: settled after the barrier
-						atomicOr(&misc[(i >> 13) & 1 ? M_DEFER2 : M_DEFER], 1u << ((i >> 8) & 31));
-					} else {
-						// 24 bytes are compared by now.  A mismatch among them makes the length final.
-						// Otherwise a successor (same distance) inside those bytes makes me a member of
-						// its chain; failing that 16 more bytes are compared (LCAP = 8 + 2 x 16), after
-						// which a successor up to 32 away qualifies, and what is still open becomes a
-						// long tail.
-						bool open = len == 24 && maxlen > 24;
-						bool member = open && same_d && g1 < 24;
-						if (!member) {
-							if (open) { len += equal16(inw, q + 24, r + 24); open = len == LCAP && maxlen > LCAP; }
-							if (len > maxlen) len = maxlen;
-							mlen[i] = (uint8_t)(len - 3);
-							member = open && same_d;
-							lg = open && !same_d;
-						}
-						if (member) {
+					// round trip 2: the successor's distance
+					const bool same_d = w32 != 0 && cand[sp] == dT;
+					__builtin_amdgcn_wave_barrier();
+					bool lg = false;
+					if (act) {
+						if (same_d && g1 < OPEN2) {
+							// the successor lies inside my verified bytes: N = N(successor) + gap
 							const uint64_t km = (((uint64_t)2 << g1) - 1) << (i & 31);               // bits i .. sp-1
 							atomicOr(&kb[i >> 5], (uint32_t)km);
 							if (km >> 32) atomicOr(&kb[(i >> 5) + 1], (uint32_t)(km >> 32));
+						} else if (w32 == 0 && i + 1 == pend && pend < tn) {
+							// last position of the unit: settled after the barrier
+							atomicOr(&misc[(i >> 13) & 1 ? M_DEFER2 : M_DEFER], 1u << ((i >> 8) & 31));
+						} else
+							lg = true;
+					}
+					unsigned long long todo = __ballot(lg);                 // tails whose distance has not been looked at
+					PCOUNT(15, __popcll(todo));                             // ... tails
+#ifdef NXZ_GROUP_NEVER
+					todo = 0;
+#endif
+					if (todo) {
+						// worth a look at all?  Tails of one group stand close together in the queue (they come in position
+						// order): count those whose distance is that of one of the two entries in front of them
+						const uint32_t key = lg ? dT | (i >> 8) << 16 : 0x80000000u | (uint32_t)lane;
+						const uint32_t k1 = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)key, 0x111, 0xf, 0xf, false);   // row_shr:1
+						const uint32_t k2 = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)key, 0x112, 0xf, 0xf, false);   // row_shr:2
+						if ((uint32_t)__popcll(__ballot(key == k1 || key == k2)) < GROUP_GATE) todo = 0;
+					}
+					for (uint32_t round = 0, misses = 0; todo && round < GROUP_ROUNDS; round++) {
+						const int ldr = __builtin_ctzll(todo);
+						const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)dT, ldr);
+						const uint32_t uL = (uint32_t)__builtin_amdgcn_readlane((int)i, ldr) >> 8;
+						const bool mine = lg && dT == dL && (i >> 8) == uL;
+						const unsigned long long mm = __ballot(mine);
+						todo &= ~mm;
+						if ((uint32_t)__popcll(mm) < GROUP_MIN) {               // a tail on its own: the rounds below are cheaper,
+							if (++misses >= GROUP_MISS) break;                  // and where one is on its own most are
+							continue;
+						}
+						const uint32_t R = h + tb0 + (uL << 8);                 // 16-byte aligned
+						const uint32_t a = R + 8 + 8 * (uint32_t)lane;
+						const uint2 rv = *(const uint2 *)(lds + OFF_IN + a);
+						const uint32_t qa = a > dL ? a - dL - 1 : 0;            // (lanes in front of every tail of the group may lie in front of the data)
+						const uint32_t qw = qa >> 2, qs = qa & 3;
+						const uint32_t u0 = inw[qw], u1 = inw[qw + 1], u2 = inw[qw + 2];
+						const uint32_t x0 = rv.x ^ __builtin_amdgcn_alignbyte(u1, u0, qs), x1 = rv.y ^ __builtin_amdgcn_alignbyte(u2, u1, qs);
+						const uint32_t f = x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : 4 + ((x1 ? (uint32_t)__builtin_ctz(x1) : 32u) >> 3);
+						const unsigned long long eqm = __ballot((x0 | x1) == 0);
+						const uint32_t o = i & 255, l0 = o <= 8 ? 0 : (o - 1) >> 3;
+						const unsigned long long z = mine ? ~eqm >> l0 : 0;
+						const uint32_t fl = z ? l0 + (uint32_t)__builtin_ctzll(z) : (uint32_t)lane;
+						const uint32_t ff = __shfl(f, fl, 64);
+						if (mine) {
+							const uint32_t r = h + tb0 + i;
+							const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+							uint32_t N = z ? R + 8 + 8 * fl + ff - r : maxlen;
+							if (N > maxlen) N = maxlen;
+							mlen[i] = (uint8_t)(N - 3);
+							lg = false;
 						}
 					}
-				}
-				unsigned long long ml = __ballot(lg);
-				if (__popcll(ml) >= 12) {
-					// many long tails at once (periodic data, candidates at ever changing distances):
-					// every lane finishes its own, 16 bytes per LDS round trip
-					const uint32_t r = h + tb0 + i, q = lg ? r - cand[i] - 1 : 0;
-					const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-					uint32_t len = LCAP;
-					while (__ballot(lg)) {
-						if (lg) {
-							// 32 bytes per round trip
-							const uint32_t k1 = equal16(inw, q + len, r + len), k2 = equal16(inw, q + len + 16, r + len + 16);
-							const uint32_t k = k1 == 16 ? 16 + k2 : k1;
-							len += k;
-							if (k < 32 || len >= maxlen) {
-								lg = false;
-								mlen[i] = (uint8_t)((len < maxlen ? len : maxlen) - 3);
+					const unsigned long long ml = __ballot(lg);
+					const uint32_t nleft = (uint32_t)__popcll(ml);
+					if (nleft >= 12) {
+						const uint32_t r = h + tb0 + i, q = lg ? r - dT - 1 : 0;
+						const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+						uint32_t len = OPEN2;
+						while (__ballot(lg)) {
+							if (lg) {
+								const uint32_t k1 = equal16(inw, q + len, r + len), k2 = equal16(inw, q + len + 16, r + len + 16);
+								const uint32_t k = k1 == 16 ? 16 + k2 : k1;
+								len += k;
+								if (k < 32 || len >= maxlen) {
+									lg = false;
+									mlen[i] = (uint8_t)((len < maxlen ? len : maxlen) - 3);
+								}
 							}
 						}
+					} else if (nleft) {
+						// to the front of this batch's part of the queue (every entry of it is in a register by now)
+						if (lg) xq[base + __popcll(ml & ((1ull << lane) - 1))] = (uint16_t)i;
+						__builtin_amdgcn_wave_barrier();
+						const uint32_t g = lane >> 4, li = lane & 15;
+						for (uint32_t b4 = 0; b4 < nleft; b4 += 4) {
+							const bool act = b4 + g < nleft;
+							const uint32_t i = act ? (uint32_t)xq[base + b4 + g] : 0;
+							const uint32_t r = h + tb0 + i, q = r - cand[i] - 1;
+							const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+							uint32_t N = 0;
+							bool done = !act;
+							for (uint32_t off = OPEN2;; off += 64) {
+								const uint32_t o = off + 4 * li;
+								uint32_t x = 0;
+								if (!done && o < maxlen) x = lds_ld32(inw, q + o) ^ lds_ld32(inw, r + o);
+								const bool ev = !done && (x != 0 || o + 4 >= maxlen);   // mismatch or end of the compare
+								const unsigned long long mm = __ballot(ev);
+								const uint32_t gm = (uint32_t)(mm >> (16 * g)) & 0xffffu;
+								uint32_t myN = x ? o + ((uint32_t)__builtin_ctz(x) >> 3) : maxlen;
+								if (myN > maxlen) myN = maxlen;
+								const uint32_t firstN = __shfl(myN, gm ? (g << 4) + (uint32_t)__builtin_ctz(gm) : (uint32_t)lane, 64);
+								if (!done && gm) { N = firstN; done = true; }
+								if (!__ballot(!done)) break;
+							}
+							if (act && li == 0) mlen[i] = (uint8_t)(N - 3);
+						}
 					}
-					ml = 0;
 				}
-				if (ml) {
-					// collected until a few rounds of four are worth the trip
-					if (lg) xq[xqn + __popcll(ml & ((1ull << lane) - 1))] = (uint16_t)i;
-					xqn += (uint32_t)__popcll(ml);
-					__builtin_amdgcn_wave_barrier();
-					if (xqn >= 16) { longext(xqn); xqn = 0; }
-				}
-				}
+			};
+			// (ONE call site for either level, see the loop below: the kernel sits at its register cap and every copy of
+			// this code was paid for in spills)
+			auto stage2 = [&](uint32_t nq, bool last) {
+				const uint32_t ent = lane < nq ? (uint32_t)lq[lane] : 0;
+				__builtin_amdgcn_wave_barrier();
+				if (nq > 64 && 64 + lane < nq) lq[lane] = lq[64 + lane];
+				// almost always one position per entry; more only when neighbours have different distances
+				uint32_t pb = ent >> 12;
+				do {
+					const uint32_t i = pb ? ((ent & 0xfff) << 2) + (uint32_t)__builtin_ctz(pb) : 0xffffffffu;
+					bool open = false;
+					if (i != 0xffffffffu) {
+						const uint32_t r = h + tb0 + i, q = r - cand[i] - 1;
+						const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+						uint32_t len = 8 + equal16(inw, q + 8, r + 8);
+						open = len == OPEN2 && maxlen > OPEN2;
+						if (len > maxlen) len = maxlen;
+						if (!open) mlen[i] = (uint8_t)(len - 3);
+					}
+					const unsigned long long ml = __ballot(open);
+					if (ml) {
+						if (open) xq[xqn + __popcll(ml & ((1ull << lane) - 1))] = (uint16_t)i;
+						xqn += (uint32_t)__popcll(ml);
+						PCOUNT(14, __popcll(ml));                  // ... still open after OPEN2 bytes
+						__builtin_amdgcn_wave_barrier();
+					}
+					pb &= pb - 1;
+					const bool more = __ballot(pb != 0) != 0;
+					// (16 or more are worth the trip; the queue holds 80; the phase's last call empties it)
+					if (xqn >= 16 || (last && !more && nq <= 64 && xqn)) { level2(xqn); xqn = 0; }
+					if (!more) break;
+				} while (true);
 			};
 			// The unit of work a wave draws is 256 positions (four per lane): a tile is 64 of them, so the waves finish
 			// within one unit's time of each other (with whole pieces of 512 the last ones decided the phase).  A unit is
@@ -822,18 +920,18 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 				uint32_t unit = 0;
 				if (lane == 0) unit = atomicAdd(&misc[M_TICKET], 1u);
 				unit = __builtin_amdgcn_readfirstlane(unit);
-				if (unit >= nunits) break;
+				const bool last = unit >= nunits;                      // nothing left to draw: the queues are emptied
 				const uint32_t piece = unit >> 1;
+				uint32_t qbits = 0;
+				const uint32_t it = unit & 1;
+				const uint32_t ib = unit << 8;
+				const uint32_t i4 = ib + 4 * lane, r4 = h + tb0 + i4;       // r4 is a multiple of 4
 				WPROF_BEGIN();
-				while (__hip_atomic_load(&misc[M_PROGRESS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= piece)
-					__builtin_amdgcn_s_sleep(4);
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				WPROF_END(16);                                         // waiting for the chain
-				{
-					const uint32_t it = unit & 1;
-					const uint32_t ib = unit << 8;
-					const uint32_t i4 = ib + 4 * lane, r4 = h + tb0 + i4;       // r4 is a multiple of 4
-					uint32_t qbits = 0;
+				if (!last) {
+					while (__hip_atomic_load(&misc[M_PROGRESS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= piece)
+						__builtin_amdgcn_s_sleep(4);
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					WPROF_END(16);                                         // waiting for the chain
 					auto quad = [&](auto fullt) {
 						// FULL: far enough from the end of the tile and of the data, no clamps needed
 						constexpr bool FULL = decltype(fullt)::value;
@@ -875,7 +973,11 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 							};
 							uint32_t d1st, d2nd;
 							const uint32_t n1st = probe((j & 2 ? qq.y : qq.x) >> (16 * (j & 1)), d1st);
+#ifdef NXZ_ABL_NO_C2
+							const uint32_t n2nd = 0; d2nd = 0;
+#else
 							const uint32_t n2nd = probe(q2[j], d2nd);
+#endif
 							// the older entry only if it has more of the first eight bytes (oracle/nxz_lz77.c step 4)
 							const bool second = n2nd > n1st;
 							const uint32_t lenA = second ? n2nd : n1st;
@@ -922,29 +1024,28 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 						if (vbits) atomicOr(&vb[i4 >> 5], vbits << (i4 & 31));
 						if (kbits) atomicOr(&kb[i4 >> 5], kbits << (i4 & 31));
 					};
+#ifndef NXZ_ABL_NO_M1
 					if (ib + 256 <= tn && h + tb0 + ib + 256 + MAXMATCH + 8 <= end) quad(std::true_type{});
 					else quad(std::false_type{});
-					// queue entry: quad number | position bits.  One position per entry as a rule (a lane's
-					// second position gets an entry of its own), so that a batch is one pass in stage2
-					for (uint32_t rest = qbits, round = 0; round < 2; round++) {
-						const uint32_t bits = round ? rest : rest & (0u - rest);      // lowest position first, then what is left
-						const unsigned long long m = __ballot(bits != 0);
-						if (!m) break;
-						if (bits) lq[lqn + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((i4 >> 2) | bits << 12);
-						lqn += (uint32_t)__popcll(m);
-						__builtin_amdgcn_wave_barrier();
-						WPROF_END(17);                                 // M1
-						while (lqn >= 32) { stage2(lqn); lqn = lqn > 64 ? lqn - 64 : 0; }
-						WPROF_END(18);                                 // M2 (classification, tails)
-						rest &= rest - 1;
-					}
+#endif
 				}
-			}
-			{
-				WPROF_BEGIN();
-				if (lqn) stage2(lqn);
-				if (xqn) longext(xqn);
-				WPROF_END(19);                                         // M2, what was left in the queues
+				// queue entry: quad number | position bits.  One position per entry as a rule (a lane's
+				// second position gets an entry of its own), so that a batch is one pass in stage2
+				for (uint32_t rest = qbits, round = 0; round < 2; round++) {
+					const uint32_t bits = round ? rest : rest & (0u - rest);      // lowest position first, then what is left
+					const unsigned long long m = __ballot(bits != 0);
+#ifndef NXZ_ABL_NO_M2
+					if (bits) lq[lqn + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((i4 >> 2) | bits << 12);
+					lqn += (uint32_t)__popcll(m);
+					PCOUNT(13, __popcll(m));                       // positions queued for M2
+#endif
+					__builtin_amdgcn_wave_barrier();
+					WPROF_END(17);                                 // M1
+					while (lqn >= (last ? 1u : 32u) || (last && xqn)) { stage2(lqn, last); lqn = lqn > 64 ? lqn - 64 : 0; }
+					WPROF_END(18);                                 // M2 (classification, tails)
+					rest &= rest - 1;
+				}
+				if (last) break;
 			}
 		}
 		__syncthreads();
@@ -1356,6 +1457,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		}
 		results[bid] = r;
 	}
+#ifdef NXZ_LZ77_PROF
 	if (prof) {
 		// (one atomic per counter and job: thousands of waves adding to four addresses would stall every
 		// wave's next loads behind them)
@@ -1363,6 +1465,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		__syncthreads();
 		if (t < 20) __hip_atomic_fetch_add(&prof[t], (unsigned long long)profacc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
+#endif
 	if (COUNT) {
 		__syncthreads();
 		if (t < 316) counts[(size_t)bid * 316 + t] = (t == 256) ? 1u : hist[t];
@@ -1378,6 +1481,9 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 
 extern "C" int nxz_lz77_prof_set(unsigned long long *buf)
 {
+#ifndef NXZ_LZ77_PROF
+	if (buf) return -1;                                        // this build carries no counters
+#endif
 	return (int)hipMemcpyToSymbol(HIP_SYMBOL(nxz_lz77_prof_buf), &buf, sizeof(buf));
 }
 

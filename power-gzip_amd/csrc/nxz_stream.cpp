@@ -123,7 +123,7 @@ struct Deflate {
 	uint64_t magic = MAGIC_DEF;
 	z_streamp z = nullptr;
 	int wrap = HDR_ZLIB, level = 6, strategy = Z_DEFAULT_STRATEGY;
-	int init_wbits = 15, init_level = -1;               // as the caller gave them (AUTO mode may reopen the stream in software zlib)
+	int init_wbits = 15, init_level = -1, init_memlevel = 8;   // as the caller gave them (AUTO mode may reopen the stream in software zlib)
 	uint32_t max_history = 0;
 	enum St { INIT, BUSY, BFINAL, TRAILER } st = INIT;
 	std::vector<uint8_t> pend; size_t pend_off = 0;     // complete bytes waiting for next_out
@@ -452,13 +452,14 @@ bool deflate_batch(Deflate *s, int flush)
 	s->have_counts = false;                                          // (the next single job starts from the default table again)
 	// A flush request is honoured by the job that takes the last input (deflate_job).  When the batch left none,
 	// the flush rules of lib/nx_deflate.c:1081-1176 are applied here: the run ends on a byte boundary (a block
-	// that ended inside a byte is followed by an empty stored block already: pack_stream_kernel), so a sync / full
-	// flush only needs its 00 00 FF FF marker when the last block did not bring one, and a partial flush its
-	// empty fixed block.
+	// that ended inside a byte is followed by an empty stored block already: pack_stream_kernel); a sync / full
+	// flush gets its 00 00 FF FF marker here, ALWAYS -- round 3 looked at the run's last four bytes and left the
+	// marker out when they read 00 00 FF FF, which a stored or byte-aligned block's own data may end in (advisor
+	// finding: a client that strips the marker, permessage-deflate for one, would then cut real data; a second
+	// empty stored block behind one that the run brought along costs five bytes and is valid) --, a partial
+	// flush its empty fixed block.
 	if (!final && z->avail_in == 0 && s->used == 0 && (flush == Z_SYNC_FLUSH || flush == Z_FULL_FLUSH || flush == Z_PARTIAL_FLUSH)) {
-		static const uint8_t marker[4] = { 0, 0, 0xff, 0xff };
-		const bool marked = produced >= 4 && !memcmp(out + produced - 4, marker, 4);
-		if (!marked) s->stored_header(0, 0);
+		s->stored_header(0, 0);
 		if (flush == Z_PARTIAL_FLUSH) s->put_bits(2, 10);            // empty fixed block: BFINAL 0, BTYPE 01, EOB
 		if (flush == Z_FULL_FLUSH) { s->fifo.erase(s->fifo.begin(), s->fifo.begin() + s->hist_len); s->hist_len = 0; }
 	}
@@ -517,7 +518,7 @@ extern "C" int nx_deflateInit2_(z_streamp strm, int level, int method, int windo
 	if (!s->eng.begin()) { delete s; return Z_STREAM_ERROR; }                                  // "cannot open NX device"
 	s->z = strm;
 	s->wrap = windowBits < 0 ? HDR_RAW : windowBits > 15 ? HDR_GZIP : HDR_ZLIB;
-	s->init_wbits = windowBits; s->init_level = level_in;
+	s->init_wbits = windowBits; s->init_level = level_in; s->init_memlevel = memLevel;
 	s->level = level; s->max_history = maxhist;
 	// NX_GZIP_STRATEGY=0 forces fixed Huffman whatever the caller asked for (lib/nx_deflate.c:648-652)
 	s->strategy = (strategy == Z_FIXED || nxz_config()->strategy_override == 0) ? Z_FIXED : Z_DEFAULT_STRATEGY;
@@ -581,6 +582,7 @@ extern "C" int nx_deflateCopy(z_streamp dest, z_streamp source)
 	Deflate *d = new (std::nothrow) Deflate();
 	if (!d || !d->jb.job || !d->eng.begin()) { delete d; return Z_MEM_ERROR; }
 	d->z = dest; d->wrap = s->wrap; d->level = s->level; d->strategy = s->strategy; d->max_history = s->max_history;
+	d->init_wbits = s->init_wbits; d->init_level = s->init_level; d->init_memlevel = s->init_memlevel;
 	d->st = s->st; d->pend = s->pend; d->pend_off = s->pend_off; d->tail_bits = s->tail_bits; d->tail_n = s->tail_n;
 	d->fifo = s->fifo; d->hist_len = s->hist_len; d->used = s->used; d->gzhead = s->gzhead;
 	d->dict_id = s->dict_id; d->dict_len = s->dict_len; d->crc = s->crc; d->adler = s->adler; d->cksum_set = s->cksum_set;
@@ -746,6 +748,7 @@ int nxz_copy_to_device(nxz_ctx_t *, void *, const void *, size_t, void *) __attr
 int nxz_copy_to_host(nxz_ctx_t *, void *, const void *, size_t, void *) __attribute__((weak));
 int nxz_ctx_sync(nxz_ctx_t *, void *) __attribute__((weak));
 void *nxz_stream_create(nxz_ctx_t *) __attribute__((weak));
+int nxz_ctx_device(nxz_ctx_t *) __attribute__((weak));
 int nxz_engine_usable(void) __attribute__((weak));
 }
 constexpr size_t PARALLEL_INFLATE_MIN = 12u << 10;
@@ -773,24 +776,29 @@ bool parallel_inflate(Inflate *s)
 	const size_t cap = z->avail_out >= 2 * nin ? (size_t)z->avail_out : std::max<size_t>(z->avail_out, 32 * nin);
 	// device buffers for the stream and its output and a HIP stream to work on: a few sets, kept from call to call
 	// (grow only); callers on different threads take different sets and run side by side
+	// The sets belong to a DEVICE, not to a context: what nxz_dev_malloc hands out is plain device memory that outlives
+	// the context it was asked through, and since nxz_ctx_create(-1) gives every thread a GPU of its own in turn
+	// (nxz_pick_device) callers on different devices must never take over each other's set -- round 3 kept ONE pool for
+	// all of them and dropped a set's buffers and stream, unfreed, whenever the caller's context was another one
+	// (advisor finding: device memory leaked without bound on a multi-GPU host).
 	struct Slot {
 		std::mutex mtx;
 		uint8_t *src = nullptr, *dst = nullptr, *hist = nullptr;
 		size_t src_cap = 0, dst_cap = 0;
-		nxz_ctx_t *ctx = nullptr;
 		void *stream = nullptr;
 	};
-	constexpr int NSLOT = 32;
-	static Slot slots[NSLOT];
+	constexpr int NSLOT = 32, NDEV = 64;
+	static Slot slots[NDEV][NSLOT];
 	static std::atomic<unsigned> turn{0};
+	int dev = nxz_ctx_device ? nxz_ctx_device(ctx) : 0;
+	if (dev < 0 || dev >= NDEV) return false;
+	Slot *const pool = slots[dev];
 	Slot *slot = nullptr;
-	for (int k = 0; k < NSLOT && !slot; k++) if (slots[k].mtx.try_lock()) slot = &slots[k];
-	if (!slot) { slot = &slots[turn.fetch_add(1) % NSLOT]; slot->mtx.lock(); }
+	for (int k = 0; k < NSLOT && !slot; k++) if (pool[k].mtx.try_lock()) slot = &pool[k];
+	if (!slot) { slot = &pool[turn.fetch_add(1) % NSLOT]; slot->mtx.lock(); }
 	std::lock_guard<std::mutex> pool_guard(slot->mtx, std::adopt_lock);
 	uint8_t *&pool_src = slot->src, *&pool_dst = slot->dst, *&pool_hist = slot->hist;
 	size_t &pool_src_cap = slot->src_cap, &pool_dst_cap = slot->dst_cap;
-	nxz_ctx_t *&pool_ctx = slot->ctx;
-	if (pool_ctx != ctx) { pool_src = pool_dst = pool_hist = nullptr; pool_src_cap = pool_dst_cap = 0; pool_ctx = ctx; slot->stream = nullptr; }   // (a context that went away took its memory along)
 	if (!slot->stream && nxz_stream_create) slot->stream = nxz_stream_create(ctx);
 	void *const hs = slot->stream;               // (NULL, the default stream, if none could be made)
 	if (pool_src_cap < nin + 64) { if (pool_src) nxz_dev_free(ctx, pool_src); pool_src = (uint8_t *)nxz_dev_malloc(ctx, nin + 64); pool_src_cap = pool_src ? nin + 64 : 0; }
@@ -1025,7 +1033,7 @@ extern "C" int nx_inflateCopy(z_streamp dest, z_streamp source)
 	Inflate *d = new (std::nothrow) Inflate();
 	if (!d || !d->jb.job || !d->eng.begin()) { delete d; return Z_MEM_ERROR; }
 	*dest = *source;
-	d->z = dest; d->wrap = s->wrap; d->window_bits = s->window_bits; d->st = s->st;
+	d->z = dest; d->wrap = s->wrap; d->window_bits = s->window_bits; d->st = s->st; d->init_wbits = s->init_wbits;
 	d->held = s->held; d->nheld = s->nheld; d->gzflags = s->gzflags; d->xlen = s->xlen; d->zcmf = s->zcmf; d->dictid = s->dictid;
 	d->gzhead = s->gzhead; d->hcrc = s->hcrc;
 	d->pend = s->pend; d->pend_off = s->pend_off; d->hist = s->hist; d->carry = s->carry; d->unget = s->unget;
@@ -1041,6 +1049,7 @@ extern "C" int nx_inflateReset2(z_streamp strm, int windowBits)
 {
 	Inflate *s = istate(strm);
 	if (!s) return Z_STREAM_ERROR;
+	const int wbits_given = windowBits;
 	int wrap;                                                    // lib/nx_inflate.c:147-164
 	if (windowBits < 0) { wrap = HDR_RAW; windowBits = -windowBits; if (windowBits < 8 || windowBits > 15) return Z_STREAM_ERROR; }
 	else if (windowBits >= 8 && windowBits <= 15) wrap = HDR_ZLIB;
@@ -1049,6 +1058,7 @@ extern "C" int nx_inflateReset2(z_streamp strm, int windowBits)
 	else if (windowBits == 0) { wrap = HDR_ZLIB; windowBits = 15; }
 	else return Z_STREAM_ERROR;
 	s->wrap = wrap; s->window_bits = windowBits;
+	s->init_wbits = wbits_given;                                 // what AUTO mode reopens the stream with (nxz_inflate_pristine)
 	return inflate_reset(strm);
 }
 
@@ -1064,7 +1074,6 @@ extern "C" int nx_inflateInit2_(z_streamp strm, int windowBits, const char *vers
 	strm->state = (struct internal_state *)s;
 	int rc = nx_inflateReset2(strm, windowBits);
 	if (rc != Z_OK) { s->eng.end(); delete s; strm->state = Z_NULL; }
-	else s->init_wbits = windowBits;
 	return rc;
 }
 
@@ -1072,15 +1081,17 @@ extern "C" int nx_inflateInit2_(z_streamp strm, int windowBits, const char *vers
 extern "C" int nxz_inflate_pristine(z_streamp strm, int *wbits)
 {
 	Inflate *s = istate(strm);
-	if (!s || s->st != Inflate::HEADER || s->nheld || s->have_dict || s->gzhead || strm->total_in || strm->total_out || !s->carry.empty()) return 0;
+	if (!s || s->st != Inflate::HEADER || s->nheld || s->have_dict || s->gzhead || strm->total_in || strm->total_out || !s->carry.empty() ||
+	    !s->unget.empty())            // (the next gzip member's first bytes, kept over inflateReset: a reopened stream would lose them)
+		return 0;
 	*wbits = s->init_wbits;
 	return 1;
 }
-extern "C" int nxz_deflate_pristine(z_streamp strm, int *level, int *wbits, int *strategy)
+extern "C" int nxz_deflate_pristine(z_streamp strm, int *level, int *wbits, int *strategy, int *memlevel)
 {
 	Deflate *s = dstate(strm);
 	if (!s || s->st != Deflate::INIT || s->used || s->dict_len || s->gzhead || s->hist_len || strm->total_in || strm->total_out) return 0;
-	*level = s->init_level; *wbits = s->init_wbits; *strategy = s->strategy;
+	*level = s->init_level; *wbits = s->init_wbits; *strategy = s->strategy; *memlevel = s->init_memlevel;
 	return 1;
 }
 

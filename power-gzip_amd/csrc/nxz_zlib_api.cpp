@@ -149,31 +149,31 @@ EXPORT int deflateInit_(z_streamp s, int level, const char *ver, int size)
 	return deflateInit2_(s, level, Z_DEFLATED, 15, 8, Z_DEFAULT_STRATEGY, ver, size);
 }
 #define DISPATCH_DEF(call_nx, call_sw, err) do { init(); if (is_nx(s, MAGIC_DEF)) return call_nx; return sw.deflate ? call_sw : err; } while (0)
-// AUTO mode, first call of a stream: a caller that brings less than the break-even (nxz_config auto_comp_min /
-// auto_dec_min: measured, tools/api_sweep.py) is better served by software zlib -- the engine stream, to which
-// nothing has happened yet, is closed and the same z_stream reopened there with the parameters it was made with.
-// (The reference's switchable AUTO streams, lib/nx_map.c, lib/nx_zlib.h:376-422; its size rule is a fixed
-// 1024 bytes for one-shot calls only, lib/nx_zlib.h:88-89.)
+// AUTO mode, first call of a stream: a caller that brings ALL its input (Z_FINISH) and less of it than the break-even
+// (nxz_config auto_comp_min / auto_dec_min: measured, tools/api_sweep.py) is better served by software zlib -- the engine
+// stream, to which nothing has happened yet, is closed and the same z_stream reopened there with the parameters it
+// was made with.  Only with Z_FINISH, as the reference (lib/nx_zlib.h:389-419): "even when compressing a large amount
+// of data, the first call may not have enough input" -- a client that streams through 16-64 KiB buffers (zpipe,
+// minigz, gzip, CPython's zlib) stays on the engine, whose stream layer gathers small inputs before it runs a job.
 static bool auto_to_sw_deflate(z_streamp s, int flush)
 {
-	if (g_mode_def != MODE_AUTO || !sw.deflateInit2_ || !s || s->avail_in >= nxz_config()->auto_comp_min) return false;
-	if (flush != Z_FINISH && s->avail_in == 0) return false;           // (nothing to judge by yet)
-	int level, wbits, strategy;
-	if (!nxz_deflate_pristine(s, &level, &wbits, &strategy)) return false;
+	if (g_mode_def != MODE_AUTO || !sw.deflateInit2_ || !s || flush != Z_FINISH || s->avail_in >= nxz_config()->auto_comp_min) return false;
+	int level, wbits, strategy, memlevel;
+	if (!nxz_deflate_pristine(s, &level, &wbits, &strategy, &memlevel)) return false;
 	z_stream keep = *s;
 	nx_deflateEnd(s);
-	if (sw.deflateInit2_(s, level, Z_DEFLATED, wbits, 8, strategy, ZLIB_VERSION, (int)sizeof(z_stream)) != Z_OK) {
+	if (sw.deflateInit2_(s, level, Z_DEFLATED, wbits, memlevel, strategy, ZLIB_VERSION, (int)sizeof(z_stream)) != Z_OK) {
 		// (cannot happen with parameters the engine took; back to an engine stream)
 		*s = keep; s->state = Z_NULL;
-		(void)nx_deflateInit2_(s, level, Z_DEFLATED, wbits, 8, strategy, ZLIB_VERSION, (int)sizeof(z_stream));
+		(void)nx_deflateInit2_(s, level, Z_DEFLATED, wbits, memlevel, strategy, ZLIB_VERSION, (int)sizeof(z_stream));
 		return false;
 	}
 	s->next_in = keep.next_in; s->avail_in = keep.avail_in; s->next_out = keep.next_out; s->avail_out = keep.avail_out;
 	return true;
 }
-static bool auto_to_sw_inflate(z_streamp s)
+static bool auto_to_sw_inflate(z_streamp s, int flush)
 {
-	if (g_mode_inf != MODE_AUTO || !sw.inflateInit2_ || !s || s->avail_in == 0 || s->avail_in >= nxz_config()->auto_dec_min) return false;
+	if (g_mode_inf != MODE_AUTO || !sw.inflateInit2_ || !s || flush != Z_FINISH || s->avail_in == 0 || s->avail_in >= nxz_config()->auto_dec_min) return false;
 	int wbits;
 	if (!nxz_inflate_pristine(s, &wbits)) return false;
 	z_stream keep = *s;
@@ -237,7 +237,7 @@ EXPORT int inflate(z_streamp s, int flush)
 {
 	init();
 	bool nx = is_nx(s, MAGIC_INF);
-	if (nx && s->total_in == 0 && auto_to_sw_inflate(s)) nx = false;
+	if (nx && s->total_in == 0 && auto_to_sw_inflate(s, flush)) nx = false;
 	if (!nx && !sw.inflate) return Z_STREAM_ERROR;
 	if (!nxz_stats_enabled()) return nx ? nx_inflate(s, flush) : sw.inflate(s, flush);
 	const unsigned ai = s ? s->avail_in : 0, ao = s ? s->avail_out : 0;

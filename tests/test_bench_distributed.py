@@ -140,3 +140,46 @@ def test_mixed_batch_kinds():
     assert sizes[0] < 400 and sizes[4] < 400                         # zeros
     assert sizes[3] > 65536 and sizes[7] > 65536                     # random bytes: stored path
     assert 30000 < sizes[1] < 50000 and 20000 < sizes[2] < 50000     # 33-symbol text; text + LZ copies
+
+
+# ---- `python bench.py --gpus N` without a launcher starts its own ranks ----
+def test_launcher_builds_the_drivers_command_and_relays_rank0(capsys):
+    import bench
+
+    class Done:
+        returncode = 0
+        stdout = '{"metric": "x", "n_gpus": 4}\n'
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+    rc = bench.launch_ranks(4, ["--gpus", "4", "--steps", "3", "--warmup", "1"], visible=8, run=fake_run)
+    assert rc == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]      # the caller's arguments, unchanged
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"                            # dmabuf IPC for RCCL between processes
+    assert capsys.readouterr().out == Done.stdout                                      # rank 0's line, relayed
+
+
+def test_launcher_refuses_more_gpus_than_are_visible(capsys):
+    import bench
+    called = []
+    rc = bench.launch_ranks(8, ["--gpus", "8"], visible=1, run=lambda *a, **k: called.append(a))
+    assert rc == 2 and not called
+    assert "8 GPUs requested, 1 visible" in capsys.readouterr().err
+
+
+def test_bench_gpus_2_without_gpus_fails_with_a_clear_message():
+    """the whole script: no launcher in the environment, fewer devices than asked for"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2
+    assert "2 GPUs requested, 0 visible" in p.stderr

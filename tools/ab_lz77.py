@@ -14,10 +14,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     n = int(os.environ.get("AB_JOBS", "32768"))
     out = {}
     _, blocks, _ = corpus.load(65536)
-    full = [np.frombuffer(b, np.uint8) for _, _, b in blocks if len(b) == 65536]
-    host = np.stack([full[i % len(full)] for i in range(n)])
-    for name, fc, src in (("corpus", pkg.FC_COMPRESS_DHTGEN, torch.from_numpy(host).to(eng.dev)),
-                          ("synth", pkg.FC_COMPRESS_FHT, bench.gen_blocks(torch, eng.dev, n, 0))):
+    legs = []
+    for cls in os.environ.get("AB_CLASSES", "").split(","):          # "" = the whole corpus; "msgpack,json": those classes, a leg each
+        full = [np.frombuffer(b, np.uint8) for c, _, b in blocks if len(b) == 65536 and (not cls or c == cls)]
+        host = np.stack([full[i % len(full)] for i in range(n)])
+        legs.append((cls or "corpus", pkg.FC_COMPRESS_DHTGEN, torch.from_numpy(host).to(eng.dev)))
+    if os.environ.get("AB_SYNTH", "1") == "1":
+        legs.append(("synth", pkg.FC_COMPRESS_FHT, bench.gen_blocks(torch, eng.dev, n, 0)))
+    for name, fc, src in legs:
         dst = torch.empty((n, 73856), dtype=torch.uint8, device=eng.dev)
         jobs = eng.jobs_strided(src, 65536, np.full(n, 65536, np.uint32), dst, 73856, 73856)
         res = torch.empty(n * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=eng.dev)
@@ -29,9 +33,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     print("AB " + json.dumps(out))
     sys.exit(0)
 libs = sys.argv[1:]
+ref = None
 for rnd in range(int(os.environ.get("AB_ROUNDS", "2"))):
     for lib in libs:
         env = dict(os.environ, NXZ_ENGINE_LIB=lib)
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("AB ")]
-        print("%-32s %s" % (lib, line[0][3:] if line else "FAILED: " + p.stderr[-400:]), flush=True)
+        if not line:
+            print("%-28s FAILED: %s" % (lib, p.stderr[-400:]), flush=True)
+            continue
+        res = json.loads(line[0][3:])
+        if os.environ.get("AB_VERBOSE"):
+            print("%-28s %s" % (lib, line[0][3:]), flush=True)
+        sums = {k: (v["csum"], v["crcx"]) for k, v in res.items()}
+        ref = ref or sums
+        print("%-28s %s  lz77 ms: %s%s" % (lib, " ".join("%s %.1f" % (k, v["GiB_s"]) for k, v in res.items()),
+                                          " ".join("%.2f" % v["lz77_ms"] for v in res.values()), "" if sums == ref else "  OUTPUT DIFFERS from the first build's"), flush=True)

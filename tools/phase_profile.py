@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench
 pkg = importlib.import_module("power-gzip_amd")
-NAMES = ["load", "cksum", "seed", "hash", "chain (wave 0)", "M3b dist-1 runs", "pass1", "mark", "pass2 (token walk)", "out (records, counts, bitmaps)", "e-flags + piece links", "M3a members", "match after the chain", "-", "-", "-"]
+NAMES = ["load", "cksum", "seed", "hash", "chain (wave 0)", "M3b dist-1 runs", "pass1", "mark", "pass2 (token walk)", "out (records, counts, bitmaps)", "e-flags + piece links", "M3a members", "match after the chain", "(count) positions queued for M2", "(count) open after 24 bytes", "(count) tails"]
 FC = {"fht": pkg.FC_COMPRESS_FHT, "dhtgen": pkg.FC_COMPRESS_DHTGEN}[os.environ.get("FC", "fht")]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = pkg.Engine(0)
@@ -34,7 +34,7 @@ eng.compress(FC, jobs, n)
 torch.cuda.synchronize()
 eng.L.nxz_lz77_prof_set(None)
 p = prof.cpu().numpy().astype(np.float64) / n
-tot = p[:16].sum()
+tot = p[:13].sum()
 for i, name in enumerate(NAMES):
     print("%-20s %10.0f cycles/block  %5.1f%%" % (name, p[i], 100 * p[i] / tot))
 print("match waves, wave-cycles per block: waiting for the chain %.0f, M1 %.0f, M2 in the loop %.0f, M2 leftovers %.0f" % (p[16], p[17], p[18], p[19]))
