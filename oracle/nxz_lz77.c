@@ -33,6 +33,16 @@
  *     memory, a piece of latency away.
  *     Positions deep inside a byte run (the 12 bytes p-8 .. p+3 all equal)
  *     take no part in the table, neither lookup nor insert.
+ *  3b. The second entries are used in the first tile of a sub-block and, in
+ *     its later tiles, only if the first tile's parse made NXO_SECOND_MIN_TOKENS
+ *     tokens or more (a tile of 16384 positions: fewer than 3072 tokens is
+ *     data that compresses 5:1 and better).  Easy data does not need them:
+ *     there they cost the kernel a fifth of its match phase -- a second
+ *     probe per position, the second entries' upkeep in the chain, and
+ *     matches that take turns between two distances -- for 1 to 5 % of an
+ *     output that is 4 to 12 % smaller than zlib -1's anyway (JSON, msgpack,
+ *     XML, tables); text, binaries and fonts, where the second candidate
+ *     is worth 2 to 4 % and the margin to zlib -1 is thin, keep it.
  *  4. A bucket entry q is a candidate if dist = p-q <= 32768 and >= 4 bytes
  *     agree.  Of two candidates the one with more equal bytes among the
  *     first 8 is taken, the newest on a tie (8 bytes decide: what a lane can
@@ -83,6 +93,9 @@
 #endif
 #ifndef NXO_PIECE
 #define NXO_PIECE 512
+#endif
+#ifndef NXO_SECOND_MIN_TOKENS
+#define NXO_SECOND_MIN_TOKENS 3072   /* step 3b: tokens of a sub-block's first tile below which the later tiles do without second entries */
 #endif
 #define MINMATCH 4
 #define MAXMATCH 258
@@ -172,7 +185,8 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 	static __thread uint16_t mlen[NXO_SUBBLOCK];
 	static __thread uint16_t mdist[NXO_SUBBLOCK];
 	const uint32_t end = h + n;
-	uint32_t c, r, ntok = 0;
+	uint32_t c, r, ntok = 0, t0, t1;
+	int use_second = 1;
 
 	memset(head, 0, sizeof(head));
 	memset(head2, 0, sizeof(head2));
@@ -186,8 +200,12 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 			head[hv] = r + 1;
 		}
 	}
+	/* tile after tile: match finding, then the parse (the parse of a tile has no say in the match finding of the
+	 * next one -- except through the count of step 3b) */
+	for (t0 = 0; t0 < n; t0 = t1) {
+	t1 = t0 + NXO_PTILE < n ? t0 + NXO_PTILE : n;
 	/* 2-4. match finding per chunk */
-	for (c = 0; c < n; c += NXO_CHUNK) {
+	for (c = t0; c < t1; c += NXO_CHUNK) {
 		uint32_t cend = c + NXO_CHUNK < n ? c + NXO_CHUNK : n;
 		uint32_t j;
 		for (j = c; j < cend; j++) {
@@ -196,7 +214,7 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 			if (r + 4 <= end) {
 				uint32_t v = ld32(w + r);
 				int deep = deep_in_run(w, r);
-				uint32_t cand = deep ? 0 : head[hash4(v)], cand2 = deep ? 0 : head2[hash4(v)];
+				uint32_t cand = deep ? 0 : head[hash4(v)], cand2 = deep || !use_second ? 0 : head2[hash4(v)];
 				uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
 				uint32_t cap8 = maxlen < 8 ? maxlen : 8, a1 = 0, a2 = 0;
 				if (cand != 0 && r - (cand - 1) <= NXO_WINDOW && ld32(w + cand - 1) == v)
@@ -252,9 +270,8 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 			npend[0] = 0;
 		}
 	}
-	if (nxo_dbg_mlen) { memcpy(nxo_dbg_mlen, mlen, n * 2); memcpy(nxo_dbg_mdist, mdist, n * 2); }
-	/* 5. two-pass segment parse per PTILE */
-	for (c = 0; c < n; c += NXO_PTILE) {
+	/* 5. two-pass segment parse of the tile */
+	for (c = t0; c < t1; c += NXO_PTILE) {
 		uint32_t tend = c + NXO_PTILE < n ? c + NXO_PTILE : n;
 		uint32_t nseg = (tend - c + NXO_PSEG - 1) / NXO_PSEG, s;
 		static __thread uint32_t X[NXO_PTILE / NXO_PSEG], V[NXO_PTILE / NXO_PSEG], A[NXO_PTILE / NXO_PSEG];
@@ -298,6 +315,11 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 			entry = X[s];
 		}
 	}
+	/* 3b. what the first tile came to decides about the second entries for the rest of the sub-block */
+	if (t0 == 0)
+		use_second = ntok >= NXO_SECOND_MIN_TOKENS;
+	}
+	if (nxo_dbg_mlen) { memcpy(nxo_dbg_mlen, mlen, n * 2); memcpy(nxo_dbg_mdist, mdist, n * 2); }
 	return ntok;
 }
 

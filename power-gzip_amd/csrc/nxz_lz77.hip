@@ -75,6 +75,7 @@ constexpr uint32_t MAXMATCH = 258;
 constexpr uint32_t WINDOW = 32768;
 constexpr uint32_t OPEN2 = 24;           // bytes that the first level of M2 settles (8 from M1 + one 16-byte round trip)
 constexpr uint32_t NOHASH = 0xFFFFu;
+constexpr uint32_t SECOND_MIN_TOKENS = 3072; // oracle/nxz_lz77.c step 3b: tokens of the first tile below which the later tiles do without second bucket entries
 #ifndef NXZ_GROUP_ROUNDS
 #define NXZ_GROUP_ROUNDS 8
 #endif
@@ -121,7 +122,7 @@ constexpr uint32_t LDS_BYTES = OFF_PROF + 80;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
-enum { M_NREC = 0, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7, M_KEEP = 8, M_DEFER2 = 9 };
+enum { M_NREC = 0, M_TOK0 = 1, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7, M_KEEP = 8, M_DEFER2 = 9 };
 static_assert(M_TICKET == M_PROGRESS + 1 && M_DEFER == M_PROGRESS + 2, "cleared together");
 
 __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
@@ -519,6 +520,14 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	for (uint32_t tb0 = 0; tb0 < n; tb0 += PTILE) {
 		const uint32_t tn = n - tb0 < PTILE ? n - tb0 : PTILE;       // positions in this tile
 		const uint32_t nseg = (tn + PSEG - 1) / PSEG;
+		// second bucket entries: always in the first tile, later only where that tile's parse says the data is hard
+		// (oracle/nxz_lz77.c step 3b); wave-uniform, so the chain and M1 branch around what serves them
+		const bool use2 = tb0 == 0 || __builtin_amdgcn_readfirstlane(misc[M_TOK0]) >= SECOND_MIN_TOKENS;
+#ifdef NXZ_CHAIN_ALWAYS2
+#define CHAIN_USE2 true
+#else
+#define CHAIN_USE2 use2
+#endif
 
 		// ---- hash ----
 		// cand[i] = byte offset of the position's head[] slot (dummy slot for positions without a
@@ -638,6 +647,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 				}
 			};
 			auto note = [&](const uint4 pk, const uint32_t (&old)[8]) {
+				if (!CHAIN_USE2) return;
 				uint32_t off[8]; unpack(pk, off);
 #pragma unroll
 				for (int u = 0; u < 8; u++) *(uint16_t *)(headb + off[u] + 2) = (uint16_t)old[u];
@@ -651,10 +661,12 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 				// waves cannot turn one piece in place)
 #pragma unroll
 				for (int u = 0; u < 8; u++) cand[(piece << 9) + 64 * u + lane] = (uint16_t)o[u];
-				((NXZ_GLOBAL v4u *)g_c2)[(piece << 6) + lane] = (v4u){ __builtin_amdgcn_perm(o[1], o[0], 0x07060302), __builtin_amdgcn_perm(o[3], o[2], 0x07060302),
-										    __builtin_amdgcn_perm(o[5], o[4], 0x07060302), __builtin_amdgcn_perm(o[7], o[6], 0x07060302) };
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_s_waitcnt(0x0F71);                // vmcnt(1): all but this piece's store
+				if (CHAIN_USE2) {
+					((NXZ_GLOBAL v4u *)g_c2)[(piece << 6) + lane] = (v4u){ __builtin_amdgcn_perm(o[1], o[0], 0x07060302), __builtin_amdgcn_perm(o[3], o[2], 0x07060302),
+											    __builtin_amdgcn_perm(o[5], o[4], 0x07060302), __builtin_amdgcn_perm(o[7], o[6], 0x07060302) };
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_s_waitcnt(0x0F71);            // vmcnt(1): all but this piece's store
+				}
 				__builtin_amdgcn_wave_barrier();
 				if (lane == 0) __hip_atomic_store(&misc[M_PROGRESS], piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // pieces below `piece`
 				__builtin_amdgcn_wave_barrier();
@@ -932,16 +944,19 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 						__builtin_amdgcn_s_sleep(4);
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 					WPROF_END(16);                                         // waiting for the chain
-					auto quad = [&](auto fullt) {
+					auto quad = [&](auto fullt, auto use2t) {
 						// FULL: far enough from the end of the tile and of the data, no clamps needed
-						constexpr bool FULL = decltype(fullt)::value;
+						// USE2: with the second bucket entries (a variant of its own: a branch inside it cost the common case 2-4 %)
+						constexpr bool FULL = decltype(fullt)::value, USE2 = decltype(use2t)::value;
 						// the second bucket entries of my four positions: device scratch, written by the chain
 						// wave (this CU's L1 may hold the previous tile's: read past it)
 						// (transposed like cand[] before it is turned back: position w of the piece at 8 (w % 64) + w / 64)
-						uint32_t q2[4];
+						uint32_t q2[4] = { 0, 0, 0, 0 };
+						if constexpr (USE2) {
 #pragma unroll
-						for (int j = 0; j < 4; j++)
-							q2[j] = __hip_atomic_load(g_c2 + (piece << 9) + (4 * (lane & 15) + j) * 8 + 4 * it + (lane >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							for (int j = 0; j < 4; j++)
+								q2[j] = __hip_atomic_load(g_c2 + (piece << 9) + (4 * (lane & 15) + j) * 8 + 4 * it + (lane >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						}
 						const uint2 qq = *(const uint2 *)(cand + i4);
 						// deep-in-run positions took no part in the table (what the chain wave left
 						// in their place is meaningless): flags i-7 .. i+3 all set
@@ -973,11 +988,9 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 							};
 							uint32_t d1st, d2nd;
 							const uint32_t n1st = probe((j & 2 ? qq.y : qq.x) >> (16 * (j & 1)), d1st);
-#ifdef NXZ_ABL_NO_C2
-							const uint32_t n2nd = 0; d2nd = 0;
-#else
-							const uint32_t n2nd = probe(q2[j], d2nd);
-#endif
+							uint32_t n2nd = 0;
+							d2nd = 0;
+							if constexpr (USE2) n2nd = probe(q2[j], d2nd);
 							// the older entry only if it has more of the first eight bytes (oracle/nxz_lz77.c step 4)
 							const bool second = n2nd > n1st;
 							const uint32_t lenA = second ? n2nd : n1st;
@@ -1025,8 +1038,10 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 						if (kbits) atomicOr(&kb[i4 >> 5], kbits << (i4 & 31));
 					};
 #ifndef NXZ_ABL_NO_M1
-					if (ib + 256 <= tn && h + tb0 + ib + 256 + MAXMATCH + 8 <= end) quad(std::true_type{});
-					else quad(std::false_type{});
+					const bool full = ib + 256 <= tn && h + tb0 + ib + 256 + MAXMATCH + 8 <= end;
+					if (use2) { if (full) quad(std::true_type{}, std::true_type{}); else quad(std::false_type{}, std::true_type{}); }
+					else if (full) quad(std::true_type{}, std::false_type{});
+					else quad(std::false_type{}, std::false_type{});
 #endif
 				}
 				// queue entry: quad number | position bits.  One position per entry as a rule (a lane's
@@ -1333,6 +1348,12 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		}
 		__syncthreads();
 		PROF(8);
+		if (tb0 == 0 && n > PTILE && t < 512) {
+			// tokens of the first tile (oracle/nxz_lz77.c step 3b)
+			uint32_t c = (uint32_t)__popc(litbits[t]) + (uint32_t)__popc(tokbits[t]);
+			for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+			if (lane == 0) atomicAdd(&misc[M_TOK0], c);
+		}
 
 		// ---- out (FUSED): the tile's tokens as fixed-Huffman bits, straight into the target ----
 		if constexpr (FUSED) {
