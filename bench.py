@@ -75,6 +75,10 @@ def roof(achieved, traffic, kernel, peak_measured=None, **extra):
     """the roofline object of the contract (+ the figure against the copy kernel's rate on this box)"""
     out = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kernel}
+    if traffic is not None:
+        out["traffic_source"] = ("bytes per block of the committed rocprofv3 --pmc pass of this workload (profiles/%s; FETCH_SIZE / WRITE_SIZE "
+                                 "in runs of their own, corrected as MI355X_MICROARCH.md prescribes) x the blocks of this step -- not counters of this run"
+                                 % "|".join(sorted(set(PMC_SOURCE.values()))))
     if peak_measured:
         out["peak_measured"] = peak_measured
         out["frac_of_measured"] = round(achieved / peak_measured, 5)
@@ -204,6 +208,9 @@ def gen_mixed(torch, dev, n, first_index):
     return out
 
 
+PMC_SOURCE = {}
+
+
 def pmc_traffic(n_blocks, which="fht"):
     """HBM bytes per step from the committed PMC pass (profiles/*pmc_traffic_<which>.json, collected
     with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload and corrected as
@@ -216,6 +223,7 @@ def pmc_traffic(n_blocks, which="fht"):
         d = json.load(open(files[-1]))
         if d.get("block_bytes") != BLOCK:
             return None
+        PMC_SOURCE[which] = os.path.basename(files[-1])
         return float(d["traffic_bytes_per_block"]) * n_blocks
     except (OSError, ValueError, KeyError):
         return None
@@ -337,32 +345,44 @@ def timed_compress(torch, eng, fc, jobs, n, results, steps, warmup):
     return e0.elapsed_time(e1) / steps, [x / steps for x in st], launches // max(steps, 1)
 
 
-def what_binds():
+def what_binds(kernel_prefix="nxzl77::lz77_kernel<true, false>", leg="dhtgen"):
     """The path moves few bytes per instruction: what binds the LZ77 kernel is the issue of vector instructions and
-    the LDS pipe, from the committed counter passes (profiles/r02*_pmc_counters.json; tools/pmc_report.py)."""
+    the LDS pipe, from the latest committed counter pass (profiles/r*_pmc_counters.json, tools/prof_report.py: keys
+    "<kernel> [<leg>]", figures per unit = per 64 KiB block)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_counters.json")))
-    if not files:
-        return None
-    try:
-        k = json.load(open(files[-1]))["nxzl77::lz77_kernel<false>"]
-        valu, cyc = k["SQ_INSTS_VALU_per_job"], k["cu_cycles_per_job"]
-        return {"kernel": "nxzl77::lz77_kernel<false>", "source": os.path.basename(files[-1]),
-                "vector_issue_frac": round(valu * 4 / 4 / cyc, 3), "lds_busy_frac": k.get("lds_busy_share_of_kernel_time"),
-                "lds_bank_conflict_share": k.get("lds_bank_conflict_share_of_lds_cycles"),
-                "note": "a wave64 vector instruction occupies one of the CU's four SIMDs for four cycles: wave-instructions x 4 / 4 SIMDs / CU-cycles per block"}
-    except (OSError, ValueError, KeyError):
-        return None
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for key, k in d.items():
+            if not (key.startswith(kernel_prefix) and key.endswith("[%s]" % leg)):
+                continue
+            try:
+                valu = k.get("SQ_INSTS_VALU_per_unit", k.get("SQ_INSTS_VALU_per_job"))
+                cyc = k.get("cu_cycles_per_unit", k.get("cu_cycles_per_job"))
+                split = k.get("wave_cycles_split", {})
+                return {"kernel": key, "source": os.path.basename(f),
+                        "vector_issue_frac": round(valu * 4 / 4 / cyc, 3), "lds_busy_frac": k.get("lds_busy_share_of_kernel_time"),
+                        "lds_bank_conflict_share": k.get("lds_bank_conflict_share_of_lds_cycles"),
+                        "wave_cycles_active": split.get("SQ_ACTIVE_INST_ANY"), "wave_cycles_waiting": split.get("SQ_WAIT_ANY"),
+                        "note": "from the committed counter pass of the same workload, not this run; a wave64 vector instruction occupies one "
+                                "of the CU's four SIMDs for four cycles: wave-instructions x 4 / 4 SIMDs / CU-cycles per block"}
+            except (TypeError, ZeroDivisionError):
+                continue
+    return None
 
 
-def roofline(u_bytes, c_bytes, stage_ms, launches, traffic, kernel, peak_measured=None):
+def roofline(u_bytes, c_bytes, stage_ms, launches, traffic, kernel, peak_measured=None, leg="dhtgen"):
     """algorithmic bytes U + C over the time of the dominant kernel (the LZ77 kernel:
     it reads U; the entropy kernel writes C and is accounted with it: both are needed to move U + C),
     so achieved = (U + C) / (lz77 + dhtgen + entropy kernel time), measured by HIP events on the
     launch stream around every launch of the timed region."""
     kern_ms = sum(stage_ms)
     achieved = (u_bytes + c_bytes) / (kern_ms * 1e-3) / 1e9
-    return roof(achieved, traffic, kernel, peak_measured, what_binds=what_binds(),
+    return roof(achieved, traffic, kernel, peak_measured,
+                what_binds=what_binds("nxzl77::lz77_kernel<false, true>", "fht") if leg == "fht" else what_binds(),
                 kernel_ms=round(kern_ms, 3), lz77_ms=round(stage_ms[0], 3), dhtgen_ms=round(stage_ms[1], 3),
                 entropy_ms=round(stage_ms[2], 3), launches_per_step=launches,
                 avg_lz77_launch_ms=round(stage_ms[0] / max(launches, 1), 4),
@@ -438,6 +458,21 @@ def run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng):
     classes = {k: {"bytes": v[0], "ratio": round(v[0] / v[1], 4), "zlib1_ratio": round(v[0] / v[2], 4),
                    "vs_zlib1": round(v[2] / v[1], 4)} for k, v in sorted(per.items())}
     tot = [sum(v[i] for v in per.values()) for i in range(3)]
+    # the rate by class (the kernel's time depends on the data: 4096 jobs of every class, outside the timed region)
+    for cls in classes:
+        idx = [i for i, (c, _, b) in enumerate(blocks) if c == cls and len(b) == BLOCK]
+        if not idx:
+            continue
+        m = min(4096, n)                                   # (dst has n rows)
+        sel = torch.from_numpy(np.array([idx[i % len(idx)] for i in range(m)], np.int64)).to(dev)
+        src_c = src[:uniq].index_select(0, sel).contiguous()
+        dst_c = dst[:m]
+        jobs_c = eng.jobs_strided(src_c, BLOCK, np.full(m, BLOCK, np.uint32), dst_c, STRIDE_OUT, STRIDE_OUT)
+        res_c = torch.empty(m * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        ms_c, st_c, _ = timed_compress(torch, eng, pkg.FC_COMPRESS_DHTGEN, jobs_c, m, res_c, 3, 1)
+        classes[cls]["GiB_s"] = round(m * BLOCK / (ms_c * 1e-3) / 2.0 ** 30, 1)
+        classes[cls]["lz77_ms"] = round(st_c[0], 3); classes[cls]["jobs_timed"] = m
+        del src_c, jobs_c, res_c
     peak_m = copy_peak_gbs(torch, dev)
     line = {
         "metric": "GiB/s uncompressed in (deflate), real-data corpus in 64 KiB blocks, exact dynamic-Huffman table per block",
@@ -446,6 +481,9 @@ def run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng):
         "vs_baseline": None, "dtype": "u8",
         "data": "Silesia ($SILESIA_DIR, sha256-checked)" if name == "silesia" else
                 "real files of this image (recorded fallback corpus: Silesia is not on the box), replicated",
+        "corpus_skipped": report.get("skipped", []) if isinstance(report, dict) else [],
+        "data_note": "the %d unique blocks (%.0f MB) are replicated %d x: the SOURCE set fits the 256 MB Infinity Cache, which does not matter at "
+                     "1-2 %% of the HBM roof (the kernels are bound by instruction issue, roofline.what_binds)" % (uniq, uniq * BLOCK / 1e6, rep),
         "config": {"workload": "BASELINE configs[2]: dynamic-Huffman deflate (COMPRESS_DHTGEN: LZ77 + histogram, dhtgen on the device, "
                                "entropy) of the %s corpus cut at 64 KiB, %d jobs per GPU (%d unique blocks), device resident" % (name, n, uniq),
                    "corpus": name, "corpus_files": report, "unique_blocks": uniq, "jobs_per_gpu": n, "block_bytes": BLOCK,
@@ -469,7 +507,10 @@ def run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng):
             line["api"] = api_leg(raw, args)
         if not args.no_c2:
             torch.cuda.empty_cache()
-            line["c2"] = c2_measure(torch, dist, args, 0, 1, dev, False, pkg, eng, args.blocks or (1 << 18), max(2, args.steps // 2), 1)
+            # configs[1] at its stated size (2^20 blocks: 136 GiB of buffers + scratch) when the device has the room, else 2^18
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            n_c2 = args.blocks or ((1 << 20) if free_b > (212 << 30) else (1 << 18))   # source + target + the inflate leg's buffer + scratch
+            line["c2"] = c2_measure(torch, dist, args, 0, 1, dev, False, pkg, eng, n_c2, max(2, args.steps // 2), 1)
         if not args.no_c5:
             torch.cuda.empty_cache()
             line["c5"] = c5_measure(torch, dist, args, 0, 1, dev, False, pkg, eng, 163840, max(2, args.steps // 2), 1)
@@ -925,7 +966,7 @@ def c2_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, n, st
                    "blocks_per_gpu": n, "block_bytes": BLOCK, "ratio": round(tot_u / tot_c, 4),
                    "parallelism": "shard%d" % world},
         "roofline": roofline(u_bytes, c_bytes, st, launches, pmc_traffic(n, "fht"),
-                             "nxzl77::lz77_kernel<false> (dominant) + nxze::encode_kernel<false>", peak_m),
+                             "nxzl77::lz77_kernel<false, true> (one kernel: LZ77 + the fixed code)", peak_m, leg="fht"),
     }
     if inflate_info:
         line["inflate"] = inflate_info
