@@ -303,16 +303,21 @@ extern "C" int nxz_ctx_sync(nxz_ctx_t *c, void *stream)
 // ---------------------------------------------------------------------------
 // batched, device-resident interface
 // ---------------------------------------------------------------------------
-// Jobs per launch of the three compress kernels: bounds the token scratch (104 KiB per job, 832 MiB
-// for 8192).  Larger chunks cost memory, smaller ones time: the LZ77 kernel is one persistent
-// workgroup per CU, and at the end of a launch CUs idle until the last job is done (65536 synthetic
-// blocks: 124 GiB/s with 2048 jobs per launch, 129 with 4096, 131 with 8192, 133 with 16384).
-static size_t compress_chunk()
+// Jobs per launch of the three compress kernels: bounds the token scratch (104 KiB per job: 832 MiB for 8192
+// jobs, 6.6 GiB for 65536).  Larger chunks cost memory, smaller ones time: the LZ77 kernel is one persistent
+// workgroup per CU, at the end of a launch CUs idle until the last job is done, and every chunk is three launches
+// (the corpus, 262144 jobs: 92.8 GiB/s at 8192 jobs per launch, 94.7 at 16384, 95.8 at 32768, 96.4 at 65536).  So the
+// chunk grows with the batch -- a quarter of it, 8192 at least and 65536 at most: a caller with a few thousand jobs
+// never pays gigabytes for them -- and falls back to 8192 when the device has no room for more.
+// NXZ_COMPRESS_CHUNK fixes it.
+static size_t compress_chunk(size_t n)
 {
-	static const size_t v = [] { const char *e = getenv("NXZ_COMPRESS_CHUNK"); size_t x = e ? (size_t)strtoull(e, nullptr, 0) : 0; return x >= 256 ? x : (size_t)8192; }();
-	return v;
+	static const size_t v = [] { const char *e = getenv("NXZ_COMPRESS_CHUNK"); size_t x = e ? (size_t)strtoull(e, nullptr, 0) : 0; return x >= 256 ? x : (size_t)0; }();
+	if (v) return v;
+	size_t c = 8192;
+	while (c < 65536 && n >= 8 * c) c *= 2;
+	return c;
 }
-#define COMPRESS_CHUNK compress_chunk()
 
 // The compress function codes: LZ77 kernel (tokens, counts, checksums) -> [table generator] ->
 // entropy kernel, chunk after chunk on the caller's stream.
@@ -335,8 +340,9 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 	// the fixed code without counts: the LZ77 kernel writes the finished block itself (no tokens in device scratch,
 	// no entropy launch, and so no reason to cut the batch into chunks: one launch, one tail)
 	const bool fused = !isdht && !count;
-	const size_t nchunks = fused ? 1 : (n + COMPRESS_CHUNK - 1) / COMPRESS_CHUNK;
-	const size_t chunk = (n + nchunks - 1) / nchunks;
+	size_t want = compress_chunk(n);
+	size_t nchunks = fused ? 1 : (n + want - 1) / want;
+	size_t chunk = (n + nchunks - 1) / nchunks;
 	nxz_ctx::Scratch sc;
 	// Calls on ONE stream share that stream's scratch (tokens, tables): their launches must not interleave, and a call
 	// that needs more room must not free what another has just handed to its kernels (round 2's advisor finding).  One
@@ -354,7 +360,13 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 			// grows only: warm up once with the largest batch before timing a loop
 			if (r.d_tokens) { (void)hipStreamSynchronize(s); (void)hipFree(r.d_tokens); (void)hipFree(r.d_gen); (void)hipFree(r.d_counts); }
 			r.d_tokens = nullptr; r.d_gen = nullptr; r.d_counts = nullptr; r.chunk_cap = 0;
-			HIPCHK(hipMalloc((void **)&r.d_tokens, chunk * (size_t)NXZ_TOK_STRIDE), return -ENOMEM);
+			if (hipMalloc((void **)&r.d_tokens, chunk * (size_t)NXZ_TOK_STRIDE) != hipSuccess && want > 8192) {
+				// no room for the large chunk: the small one
+				(void)hipGetLastError();
+				r.d_tokens = nullptr;
+				want = 8192; nchunks = (n + want - 1) / want; chunk = (n + nchunks - 1) / nchunks;
+			}
+			if (!r.d_tokens) HIPCHK(hipMalloc((void **)&r.d_tokens, chunk * (size_t)NXZ_TOK_STRIDE), return -ENOMEM);
 			HIPCHK(hipMalloc((void **)&r.d_gen, chunk * sizeof(nxz_dht_prepared_t)), return -ENOMEM);
 			HIPCHK(hipMalloc((void **)&r.d_counts, chunk * 316 * sizeof(uint32_t)), return -ENOMEM);
 			r.chunk_cap = chunk;
