@@ -307,7 +307,7 @@ extern "C" int nxz_ctx_sync(nxz_ctx_t *c, void *stream)
 // jobs, 6.6 GiB for 65536).  Larger chunks cost memory, smaller ones time: the LZ77 kernel is one persistent
 // workgroup per CU, at the end of a launch CUs idle until the last job is done, and every chunk is three launches
 // (the corpus, 262144 jobs: 92.8 GiB/s at 8192 jobs per launch, 94.7 at 16384, 95.8 at 32768, 96.4 at 65536).  So the
-// chunk grows with the batch -- a quarter of it, 8192 at least and 65536 at most: a caller with a few thousand jobs
+// chunk grows with the batch -- a quarter to an eighth of it, 8192 at least and 65536 at most: a caller with a few thousand jobs
 // never pays gigabytes for them -- and falls back to 8192 when the device has no room for more.
 // NXZ_COMPRESS_CHUNK fixes it.
 static size_t compress_chunk(size_t n)
