@@ -35,7 +35,9 @@ typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 // the first position and one at the fourth).  Straight-line code, the same for every lane.
 struct Quad { uint32_t a0, a1, a2, nb; };
 
-template <bool DHT>
+// CHECK: a symbol without a code can occur (a caller's table; the table the device made of this very block's counts has
+// a code for every symbol the block uses -- nxz_dhtgen.hip as lib/nx_dhtgen.c:252-270 -- and the fixed code for all)
+template <bool CHECK>
 __device__ __forceinline__ Quad encode_quad(const uint32_t *lltab, const uint32_t *dtab, const uint32_t *rec, uint32_t &ri,
 					    uint32_t b, uint32_t lit4, uint32_t tok4, bool &missing)
 {
@@ -43,7 +45,7 @@ __device__ __forceinline__ Quad encode_quad(const uint32_t *lltab, const uint32_
 	const uint32_t e0 = lltab[b & 0xff], e1 = lltab[(b >> 8) & 0xff], e2 = lltab[(b >> 16) & 0xff], e3 = lltab[b >> 24];
 	uint64_t v[4] = { e0 & 0xffff, e1 & 0xffff, e2 & 0xffff, e3 & 0xffff };
 	uint32_t nbk[4] = { (lit4 & 1) ? e0 >> 16 : 0, (lit4 & 2) ? e1 >> 16 : 0, (lit4 & 4) ? e2 >> 16 : 0, (lit4 & 8) ? e3 >> 16 : 0 };
-	if (DHT) missing |= ((lit4 & 1) && !(e0 >> 16)) || ((lit4 & 2) && !(e1 >> 16)) || ((lit4 & 4) && !(e2 >> 16)) || ((lit4 & 8) && !(e3 >> 16));
+	if (CHECK) missing |= ((lit4 & 1) && !(e0 >> 16)) || ((lit4 & 2) && !(e1 >> 16)) || ((lit4 & 4) && !(e2 >> 16)) || ((lit4 & 8) && !(e3 >> 16));
 	// matches: at most two start in four positions (they are at least three bytes long), the second
 	// one only at the fourth position behind one at the first
 	if (__ballot(tok4 != 0)) {
@@ -56,7 +58,7 @@ __device__ __forceinline__ Quad encode_quad(const uint32_t *lltab, const uint32_
 			const uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
 			const uint32_t lt = lltab[257 + ls], dt = dtab[ds];
 			const uint32_t ll = lt >> 16, dl = dt >> 16;
-			if (DHT) missing |= ll == 0 || dl == 0;
+			if (CHECK) missing |= ll == 0 || dl == 0;
 			const uint32_t lo = (lt & 0xffff) | ((l3 & ((1u << le) - 1)) << ll);          // <= 20 bits
 			const uint32_t hi = (dt & 0xffff) | ((d & ((1u << de) - 1)) << dl);           // <= 28 bits
 			mv = (uint64_t)lo | ((uint64_t)hi << (ll + le));
@@ -105,7 +107,7 @@ __device__ __forceinline__ void emit_quad(uint32_t *w, const Quad &q, uint32_t b
 	if (endw > 3) atomicOr(&w[wi + 3], (uint32_t)(s2 >> 32));
 }
 
-template <bool DHT>
+template <bool DHT, bool CHECK = DHT>
 __global__ __launch_bounds__(NT) void encode_kernel(const nxz_batch_job_t *__restrict__ jobs_, const uint8_t *__restrict__ tokens_,
 						     const nxz_dht_prepared_t *__restrict__ tables_, int table_per_job,
 						     nxz_batch_result_t *__restrict__ results_, uint32_t njobs)
@@ -239,8 +241,8 @@ __global__ __launch_bounds__(NT) void encode_kernel(const nxz_batch_job_t *__res
 			// my first record: matches of the round in front of my positions
 			uint32_t ri = (uint32_t)rankpre[p0 >> 5 < 2048 ? p0 >> 5 : 2048] + (uint32_t)__popc(k.tokw & ((1u << (p0 & 31)) - 1)) - (uint32_t)rankpre[r0 >> 5];
 			if (p0 >= n) ri = 0;
-			q0 = encode_quad<DHT>(lltab, dtab, recbuf[par], ri, k.bytes.x, lit8 & 15, tok8 & 15, missing);
-			q1 = encode_quad<DHT>(lltab, dtab, recbuf[par], ri, k.bytes.y, lit8 >> 4, tok8 >> 4, missing);
+			q0 = encode_quad<CHECK>(lltab, dtab, recbuf[par], ri, k.bytes.x, lit8 & 15, tok8 & 15, missing);
+			q1 = encode_quad<CHECK>(lltab, dtab, recbuf[par], ri, k.bytes.y, lit8 >> 4, tok8 >> 4, missing);
 		}
 		const uint32_t nbits = q0.nb + q1.nb;
 		uint32_t incl = nbits;
@@ -319,7 +321,8 @@ extern "C" int nxz_launch_encode(int dht, int table_per_job, const nxz_batch_job
 				 const nxz_dht_prepared_t *tables, nxz_batch_result_t *results, hipStream_t stream)
 {
 	if (n == 0) return 0;
-	if (dht) hipLaunchKernelGGL(nxze::encode_kernel<true>, dim3((unsigned)n), dim3(nxze::NT), 0, stream, jobs, tokens, tables, table_per_job, results, (uint32_t)n);
+	if (dht && table_per_job) hipLaunchKernelGGL((nxze::encode_kernel<true, false>), dim3((unsigned)n), dim3(nxze::NT), 0, stream, jobs, tokens, tables, table_per_job, results, (uint32_t)n);
+	else if (dht) hipLaunchKernelGGL(nxze::encode_kernel<true>, dim3((unsigned)n), dim3(nxze::NT), 0, stream, jobs, tokens, tables, table_per_job, results, (uint32_t)n);
 	else hipLaunchKernelGGL(nxze::encode_kernel<false>, dim3((unsigned)n), dim3(nxze::NT), 0, stream, jobs, tokens, tables, 0, results, (uint32_t)n);
 	return (int)hipGetLastError();
 }

@@ -147,7 +147,7 @@ static constexpr unsigned JOB_COUNTERS = 256;
 // bring a table each (zlib's, the engine's own exact-table output) run twice as fast a stream per wave at every batch
 // size (81 against 40).  So a batch of NXZ_LANES_MIN streams or more is sampled first: 256 of its streams, the type
 // of their first block.
-#define NXZ_LANES_MIN 131072
+#define NXZ_LANES_MIN 81920   /* (fixed-code streams: 42 against 38 GiB/s at 65 536, 43 against 63 at 131 072) */
 #define NXZ_WINDOW_LDS_MAX 1024
 
 static std::mutex g_mtx;

@@ -91,6 +91,8 @@ uint32_t adler_combine(uint32_t a1, uint32_t a2, uint64_t len2)
 
 // grow-only device/pinned workspaces, a few per device: callers on different threads (each with a stream of
 // its own) decode side by side; a caller takes one that is free, or waits for the one its turn falls on
+// device bytes all workspaces hold (the figure the idle budget below is kept against)
+std::atomic<size_t> g_ws_bytes{0};
 struct Workspace {
 	void *dev = nullptr; size_t dev_cap = 0;
 	void *pin = nullptr; size_t pin_cap = 0;
@@ -101,9 +103,11 @@ struct Workspace {
 	{
 		if (d > dev_cap) {
 			if (dev) (void)hipFree(dev);
+			g_ws_bytes -= dev_cap;
 			dev = nullptr; dev_cap = 0;
 			if (hipMalloc(&dev, d) != hipSuccess) return false;
 			dev_cap = d;
+			g_ws_bytes += d;
 		}
 		if (p > pin_cap) {
 			if (pin) (void)hipHostFree(pin);
@@ -140,11 +144,23 @@ static inline uint32_t capmul_for(uint64_t src_len)
 	return (uint32_t)(fit > 100 ? 100 : fit < 32 ? 32 : fit);
 }
 constexpr uint64_t CAP_FLOOR_CUT = 32u << 10, CAP_FLOOR_BLOCK = 128u << 10;
+// ... and so is one that would take what all the workspaces hold between calls beyond a budget (NXZ_PINFLATE_IDLE_MB,
+// default 16384 MiB, twice what ONE workspace may keep: 32 callers of 1 MiB parts hold 32 x 32 MiB and never get here; 32
+// callers of 64 MiB streams would otherwise keep 32 x 9 GiB for as long as the process lives -- round 3 left that to a manual nxz_trim()).
+inline size_t idle_bytes()
+{
+	static const size_t v = (size_t)(getenv("NXZ_PINFLATE_IDLE_MB") ? atoll(getenv("NXZ_PINFLATE_IDLE_MB")) : 16384) << 20;
+	return v;
+}
 struct TrimOnExit {
 	Workspace &w;
 	~TrimOnExit()
 	{
-		if (w.dev_cap > keep_bytes()) { (void)hipFree(w.dev); w.dev = nullptr; w.dev_cap = 0; }
+		if (w.dev_cap > keep_bytes() || (w.dev_cap && g_ws_bytes.load() > idle_bytes())) {
+			(void)hipFree(w.dev);
+			g_ws_bytes -= w.dev_cap;
+			w.dev = nullptr; w.dev_cap = 0;
+		}
 	}
 };
 std::atomic<unsigned> g_ws_turn{0};
@@ -163,7 +179,7 @@ extern "C" size_t nxz_pinflate_trim(void)
 			if (!w.dev && !w.built) continue;
 			if (!w.mtx.try_lock()) continue;
 			if (hipSetDevice(d) == hipSuccess) {
-				if (w.dev) { freed += w.dev_cap; (void)hipFree(w.dev); w.dev = nullptr; w.dev_cap = 0; }
+				if (w.dev) { freed += w.dev_cap; g_ws_bytes -= w.dev_cap; (void)hipFree(w.dev); w.dev = nullptr; w.dev_cap = 0; }
 				if (w.built) { freed += w.built_cap; (void)hipFree(w.built); w.built = nullptr; w.built_cap = 0; }
 			}
 			w.mtx.unlock();

@@ -1,5 +1,5 @@
 """Soak run (not collected by pytest): 8 seeds x 1200 random blocks (kinds, sizes at tile / piece edges,
-histories) through the HIP deflate engine, compared bit for bit with the oracle.  python tests/soak_gpu.py"""
+histories) through the HIP deflate engine, compared bit for bit with the oracle.  python tests/soak_gpu.py [seeds [blocks per seed]]"""
 import importlib, os, random, sys, zlib
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -13,10 +13,12 @@ SI, SO = 65536 + 16, 73856
 kinds = ["zeros", "random", "text33", "alice", "lz", "periodic", "binary", "sparse"]
 edges = [0, 1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 511, 512, 513, 16383, 16384, 16385, 32767, 32768, 32769, 49152, 65535, 65536]
 bad = 0
-for seed in range(1, 9):
+NSEEDS = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+PER_SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
+for seed in range(1, NSEEDS + 1):
     rnd = random.Random(seed * 7919)
     blocks, hl_ = [], []
-    for i in range(1200):
+    for i in range(PER_SEED):
         hl = rnd.choice([0, 0, 0, 16, 48, 4096, 16384, 32768]); room = 65536 - hl
         n = rnd.choice(edges) if rnd.random() < 0.4 else rnd.randrange(0, room + 1); n = min(n, room)
         body = make_block(rnd.choice(kinds), n, seed=seed * 100000 + i)
@@ -41,3 +43,4 @@ for seed in range(1, 9):
             bad += 1; print("MISMATCH seed", seed, "block", i, len(b), hl, r["cc"][i])
     print("seed", seed, "done, mismatches so far", bad, flush=True)
 print("SOAK", "OK" if bad == 0 else "FAILED")
+sys.exit(1 if bad else 0)

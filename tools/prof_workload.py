@@ -5,6 +5,8 @@
   inflate_zlib6  zlib -6 streams of the corpus blocks, >= 65536 streams (a stream per wave, the target as window), 3 passes
   inflate_own    the engine's own fixed-Huffman output, 262144 streams (a stream per lane), 2 passes
   inflate_stream ONE 256 MiB zlib -6 stream, 3 passes
+  c5             BASELINE configs[4]: 163840 mixed blocks (10 GiB), bench.c5_prepare's step (compress + wrap + decompress + wrap + compare), 2 passes;
+                 c5:<kind> (zeros, text, lz, random): 40960 blocks of that kind only, compress and decompress
 Prints one JSON line: the leg, units per pass (blocks / streams / 64 KiB of output), passes, algorithmic bytes per unit."""
 import importlib, json, os, sys, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -90,4 +92,17 @@ elif leg == "inflate_stream":
         assert rc == 0 and info["out_len"] == len(data)
     torch.cuda.synchronize()
     print(json.dumps({"leg": leg, "units": len(data) // B, "passes": 3, "algorithmic_bytes_per_unit": (len(data) + len(comp)) / (len(data) // B)}))
+elif leg.startswith("c5"):
+    kind = leg[3:]
+    n = 163840 if not kind else 4 * 40960
+    src = bench.gen_mixed(torch, dev, n, 0)
+    if kind:
+        src = src[{"zeros": 0, "text": 1, "lz": 2, "random": 3}[kind]::4].contiguous()
+        n = src.shape[0]
+    step, info = bench.c5_prepare(torch, eng, pkg, src)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    assert int(info["flag"].item()) == 0
+    print(json.dumps({"leg": leg, "units": n, "passes": 2, "algorithmic_bytes_per_unit": 2 * (n * B + info["c_bytes"]) / n, "stored": info["stored"]}))
 eng.close()
