@@ -471,18 +471,24 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 	int rc;
 	const char *lm = getenv("NXZ_INFLATE_LANES_MIN");                    // tuning / test knob
 	const size_t lanes_min = lm ? (size_t)strtoull(lm, nullptr, 0) : (size_t)NXZ_LANES_MIN;
-	bool lanes = n >= lanes_min;
+	bool lanes = n >= lanes_min, by_len = false;
 	if (lanes && !lm) {
 		// what kind of streams?  (one small launch and a wait for it: nothing next to the tens of milliseconds such a batch takes)
 		uint32_t *h = nullptr;
 		{
 			std::lock_guard<std::mutex> g(c->mtx);
 			if (!c->h_sample) (void)hipHostMalloc((void **)&c->h_sample, 64 * sizeof(uint32_t));
-			h = c->h_sample ? c->h_sample + (c->sample_turn++ & 63) : nullptr;
+			h = c->h_sample ? c->h_sample + 4 * (c->sample_turn++ & 15) : nullptr;
 		}
 		if (h) {
-			*h = 0;
-			if (nxz_launch_sample_btype(jobs, n, h, s) == 0 && hipStreamSynchronize(s) == hipSuccess && *h > 64) lanes = false;   // a quarter or more with tables
+			h[0] = 0; h[1] = 0; h[2] = 0;
+			if (nxz_launch_sample_btype(jobs, n, h, s) == 0 && hipStreamSynchronize(s) == hipSuccess) {
+				if (h[0] > 64) lanes = false;                          // a quarter or more with tables
+				// streams of very different lengths (zeros beside text: BASELINE configs[4]): a wavefront takes as long as its
+				// longest stream, so the lane kernel gets them ordered by length; much of a size they stay as they come
+				// (neighbours in memory: ordering the bench's synthetic blocks cost 5 %)
+				by_len = h[2] > 8 * (uint64_t)h[1] + 4096;
+			}
 		}
 	}
 	if (lanes) {
@@ -509,7 +515,7 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 			}
 			ws = sc.d_lanes_ws;
 		}
-		rc = nxz_launch_inflate_lanes(jobs, n, results, dht_io, ws, init, s);
+		rc = nxz_launch_inflate_lanes(jobs, n, results, dht_io, ws, init | (by_len ? 2 : 0), s);
 	} else {
 		const char *wm = getenv("NXZ_INFLATE_LDS_MAX");                 // tuning / test knob
 		const size_t lds_max = wm ? (size_t)strtoull(wm, nullptr, 0) : (size_t)NXZ_WINDOW_LDS_MAX;

@@ -12,6 +12,7 @@
 // Per-lane lookup tables live in a workspace in HBM/L2 (3.3 KiB per resident lane); the fixed
 // Huffman tables are shared.  The wave-per-stream kernel stays for single host jobs.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdlib.h>
 #include <stdint.h>
 #include "nxz_device.h"
@@ -138,7 +139,8 @@ struct LaneState {
 __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const nxz_batch_job_t *__restrict__ jobs, size_t n,
 							   nxz_batch_result_t *__restrict__ results,
 							   nxz_batch_dht_t *__restrict__ dht_io,
-							   uint8_t *__restrict__ workspace, const uint8_t *__restrict__ fixed_ws)
+							   uint8_t *__restrict__ workspace, const uint8_t *__restrict__ fixed_ws,
+							   const uint32_t *__restrict__ order)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t lens_s[320];
 	const int lane = threadIdx.x;
@@ -149,8 +151,11 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 	uint8_t *shared_ws = workspace + ((size_t)blockIdx.x * 65 + 64 + 1) * WS_BYTES;
 
 	for (size_t g = blockIdx.x; g * 64 < n; g += gridDim.x) {
-		const size_t jid = g * 64 + lane;
-		const bool active = jid < n;
+		// order (may be NULL): the jobs by falling source length, so that the 64 streams of a wavefront are much of a
+		// size and the long ones go first (a wavefront takes as long as its longest stream: a batch of mixed kinds --
+		// zeros, text, copies by turns, BASELINE configs[4] -- ran at half the rate of its kinds one by one)
+		const bool active = g * 64 + lane < n;
+		const size_t jid = active && order ? order[g * 64 + lane] : g * 64 + lane;
 		nxz_batch_job_t job;
 		if (active) job = jobs[jid];
 		else { job.src = nullptr; job.dst = nullptr; job.src_len = 0; job.hist_len = 0; job.dst_cap = 0; job.resume = 0; job.in_crc = 0; job.in_adler = 1; }
@@ -640,11 +645,30 @@ static unsigned lanes_max_grid(void)
 }
 
 // workspace bytes a batch of n streams needs (grows with n up to the largest grid)
-extern "C" size_t nxz_inflate_lanes_workspace(size_t n)
+static size_t lanes_tables_bytes(size_t n)
 {
 	size_t groups = (n + 63) / 64;
 	size_t grid = groups < NXZ_LANES_MAX_GRID ? groups : NXZ_LANES_MAX_GRID;
-	return (grid * 65 + 1) * nxzl::WS_BYTES;
+	return ((grid * 65 + 1) * nxzl::WS_BYTES + 255) & ~(size_t)255;
+}
+static size_t lanes_sort_temp_bytes(size_t n)
+{
+	size_t t = 0;
+	(void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
+	return (t + 255) & ~(size_t)255;
+}
+// the tables' slots, then what ordering the jobs by length needs: keys and indices in and out, the sort's own room
+extern "C" size_t nxz_inflate_lanes_workspace(size_t n)
+{
+	return lanes_tables_bytes(n) + 4 * ((n * sizeof(uint32_t) + 255) & ~(size_t)255) + lanes_sort_temp_bytes(n);
+}
+
+namespace nxzl {
+__global__ void order_keys_kernel(const nxz_batch_job_t *__restrict__ jobs, uint32_t n, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { keys[i] = jobs[i].src_len >> 11; idx[i] = i; }          // (2 KiB classes: streams of one class stay in the caller's order, neighbours in memory)
+}
 }
 
 extern "C" int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream)
@@ -660,8 +684,20 @@ extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, n
 	if (!n) return 0;
 	size_t groups = (n + 63) / 64;
 	unsigned grid = (unsigned)(groups < lanes_max_grid() ? groups : lanes_max_grid());
-	if (init_fixed) hipLaunchKernelGGL(nxzl::fixed_tables_kernel, dim3(1), dim3(64), 0, stream, workspace);
-	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace);
+	if (init_fixed & 1) hipLaunchKernelGGL(nxzl::fixed_tables_kernel, dim3(1), dim3(64), 0, stream, workspace);
+	// the jobs by falling source length when the caller says they differ much (init_fixed bit 1; NXZ_LANES_ORDER=0 / 1: never / always)
+	static const int order_env = getenv("NXZ_LANES_ORDER") ? atoi(getenv("NXZ_LANES_ORDER")) : -1;
+	const bool ordered = order_env < 0 ? (init_fixed & 2) != 0 : order_env != 0;
+	uint32_t *order = nullptr;
+	if (ordered && n >= 128 && n < (1u << 31)) {
+		const size_t arr = (n * sizeof(uint32_t) + 255) & ~(size_t)255;
+		uint8_t *base = workspace + lanes_tables_bytes(n);
+		uint32_t *k_in = (uint32_t *)base, *k_out = (uint32_t *)(base + arr), *v_in = (uint32_t *)(base + 2 * arr), *v_out = (uint32_t *)(base + 3 * arr);
+		size_t tb = lanes_sort_temp_bytes(n);
+		hipLaunchKernelGGL(nxzl::order_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, jobs, (uint32_t)n, k_in, v_in);
+		if (hipcub::DeviceRadixSort::SortPairsDescending(base + 4 * arr, tb, k_in, k_out, v_in, v_out, (int)n, 0, 21, stream) == hipSuccess) order = v_out;
+	}
+	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace, order);
 	hipLaunchKernelGGL(nxzl::cksum_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
 	return (int)hipGetLastError();
 }

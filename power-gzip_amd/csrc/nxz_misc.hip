@@ -459,20 +459,22 @@ extern "C" int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_
 
 namespace nxz {
 // How many of 256 streams spread over a batch begin with a block that brings its own table (BTYPE 10): the batched
-// inflate picks its kernel by that (nxz_engine.cpp nxz_batch_decompress).  *out: the count.
+// inflate picks its kernel by that (nxz_engine.cpp nxz_batch_decompress).  out[0]: the count; out[1], out[2]: the shortest and the longest source among them.
 __global__ __launch_bounds__(256) void sample_btype_kernel(const nxz_batch_job_t *__restrict__ jobs, uint32_t n, uint32_t *out)
 {
-	__shared__ uint32_t cnt;
-	if (threadIdx.x == 0) cnt = 0;
+	__shared__ uint32_t cnt, lo, hi;
+	if (threadIdx.x == 0) { cnt = 0; lo = 0xffffffffu; hi = 0; }
 	__syncthreads();
 	const uint32_t i = (uint32_t)(((uint64_t)threadIdx.x * n) >> 8);
 	const nxz_batch_job_t j = jobs[i];
+	atomicMin(&lo, j.src_len - (j.hist_len < j.src_len ? j.hist_len : j.src_len));
+	atomicMax(&hi, j.src_len - (j.hist_len < j.src_len ? j.hist_len : j.src_len));
 	// (a job that resumes inside a stream names its block type in the resume word; a fresh stream in its first byte)
 	const uint32_t first = j.src_len > j.hist_len ? j.src[j.hist_len] : 0;
 	const bool dyn = (j.resume >> 16) & 15 ? ((j.resume >> 17) & 7) == 6 : ((first >> 1) & 3) == 2;
 	if (dyn) atomicAdd(&cnt, 1u);
 	__syncthreads();
-	if (threadIdx.x == 0) *out = cnt;
+	if (threadIdx.x == 0) { out[0] = cnt; out[1] = lo; out[2] = hi; }      // (and the shortest and the longest of the sampled streams)
 }
 }
 extern "C" int nxz_launch_sample_btype(const nxz_batch_job_t *jobs, size_t n, uint32_t *out, hipStream_t stream)
