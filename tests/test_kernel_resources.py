@@ -16,8 +16,9 @@ BUDGET = {
     "nxzl77::lz77_kernel<false, false>": (128, 64),   # 1024 threads per workgroup: 128 is the cap
     "nxzl77::lz77_kernel<true, false>": (128, 64),
     "nxzl77::lz77_kernel<false, true>": (128, 64),    # the fixed-Huffman form that writes the finished block
-    "nxze::encode_kernel<false>": (64, 0),            # seven workgroups of 256 threads per CU
-    "nxze::encode_kernel<true>": (64, 0),
+    "nxze::encode_kernel<false, false>": (64, 0),     # seven workgroups of 256 threads per CU
+    "nxze::encode_kernel<true, true>": (64, 0),       # a caller's table (symbols may be missing: checked)
+    "nxze::encode_kernel<true, false>": (64, 0),      # the table the device made of the block's own counts
     "nxzd::dhtgen_kernel": (64, 0),
     "nxzi::inflate_kernel<true, false>": (96, 0),     # a stream per wave, the target as window: five waves per SIMD
     "nxzi::inflate_kernel<true, true>": (96, 0),
