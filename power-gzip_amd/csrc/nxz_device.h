@@ -41,7 +41,8 @@ int nxz_launch_encode(int dht, int table_per_job, const nxz_batch_job_t *jobs, s
 int nxz_launch_dhtgen(const uint32_t *counts, size_t n, nxz_dht_prepared_t *prepared,
 		      nxz_batch_dht_t *tables, hipStream_t stream);   /* device dhtgen: counts[n][316] -> tables (either output may be NULL) */
 int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_dht_prepared_t *out, hipStream_t stream);
-int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
+int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);          /* round 1's kernel (kept for comparison: NXZ_WRAP_OLD=1) */
+int nxz_launch_wrap_sliced(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);   /* nxz_inflate_lanes.hip: the checksum kernel's pass, storing as it goes */
 int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 		       nxz_batch_dht_t *dht_io, int window_in_lds, hipStream_t stream);
 /* token boundaries inside dynamic blocks (nxz_inflate.hip token_sync_kernel; offsets in bits from src) */

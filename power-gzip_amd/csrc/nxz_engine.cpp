@@ -531,7 +531,8 @@ extern "C" int nxz_batch_wrap(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t 
 	if (!c) return -EINVAL;
 	(void)hipSetDevice(c->device);
 	hipStream_t s = (hipStream_t)stream;   // NULL = the HIP default stream
-	int rc = nxz_launch_wrap(jobs, n, results, s);
+	static const bool old_wrap = getenv("NXZ_WRAP_OLD") && atoi(getenv("NXZ_WRAP_OLD")) != 0;
+	int rc = old_wrap ? nxz_launch_wrap(jobs, n, results, s) : nxz_launch_wrap_sliced(jobs, n, results, s);
 	if (rc) { set_err("wrap launch", (hipError_t)rc); return -EIO; }
 	return 0;
 }
@@ -1157,7 +1158,7 @@ static int run_wrap(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j)
 	bj->src = s->d_in; bj->dst = s->d_out; bj->src_len = n; bj->dst_cap = INF_OUT_CAP;
 	HIPCHK(hipMemcpyAsync(s->d_in, s->h_in, n, hipMemcpyHostToDevice, s->stream), return -EIO);
 	HIPCHK(hipMemcpyAsync(s->d_job, bj, sizeof(*bj), hipMemcpyHostToDevice, s->stream), return -EIO);
-	if (nxz_launch_wrap(s->d_job, 1, s->d_res, s->stream)) return -EIO;
+	if (nxz_launch_wrap_sliced(s->d_job, 1, s->d_res, s->stream)) return -EIO;
 	HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, sizeof(nxz_batch_result_t), hipMemcpyDeviceToHost, s->stream), return -EIO);
 	HIPCHK(hipMemcpyAsync(s->h_out, s->d_out, n, hipMemcpyDeviceToHost, s->stream), return -EIO);
 	HIPCHK(hipStreamSynchronize(s->stream), return -EIO);

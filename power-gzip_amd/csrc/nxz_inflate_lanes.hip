@@ -507,27 +507,46 @@ constexpr uint32_t cxpow8(uint32_t n)            // x^(8n) mod P, compile time
 // loads, v_dot4 for the Adler sums), weighs a slice's raw CRC by x^(8 * bytes that follow it in
 // the chunk), and the XOR of all of them is the chunk's raw CRC (same scheme as the deflate
 // kernel of round 1).  Outputs that are not 16-byte aligned take the bytewise path.
+// WRAP (function code 0x1e: copy + checksums from the initial values, /root/reference lib/nx_deflate.c:1774, lib/nx_zlib.c:1398-1443):
+// the same pass over job.src that also stores what it reads to job.dst and writes the whole result record.  (Round 3's
+// wrap kernel walked 256 bytes a thread through a one-byte table and let thread 0 combine 256 slices with a
+// bit-serial multiply each: 0.8 TB/s.)
+template <bool WRAP>
 __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__restrict__ jobs, nxz_batch_result_t *__restrict__ results)
 {
 	__shared__ uint32_t T[1024];            // T[k*256 + i] = i advanced by k+1 zero bytes
 	__shared__ uint32_t red[3][256];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	const nxz_batch_job_t job = jobs[blockIdx.x];
-	const uint32_t n = results[blockIdx.x].tpbc;
+	nxz_batch_job_t job = jobs[blockIdx.x];
+	const uint32_t n = WRAP ? job.src_len : results[blockIdx.x].tpbc;
+	if (WRAP) {
+		if (n > job.dst_cap) {
+			if (t == 0) { nxz_batch_result_t r = {NXZ_CC_TARGET_SPACE, 0, 0, 0, 0, 0, 0, 0}; results[blockIdx.x] = r; }
+			return;
+		}
+		job.in_crc = 0; job.in_adler = 1;       // (WRAP ignores what the job brings: the caller combines, lib/nx_deflate.c:1565-1578)
+	}
+	uint8_t *const wdst = job.dst;
+	const uint32_t rd_cap = WRAP ? n : job.dst_cap;          // bytes that may be read at p
+	auto finish = [&](uint32_t crc, uint32_t adler) {
+		if (WRAP) { nxz_batch_result_t r; r.cc = 0; r.tpbc = n; r.tebc = 0; r.spbc = n; r.crc = crc; r.adler = adler; r.subc = 0; r.sfbt = 0; results[blockIdx.x] = r; }
+		else { results[blockIdx.x].crc = crc; results[blockIdx.x].adler = adler; }
+	};
 	for (int k = 0; k < 4; k++) {
 		uint32_t c = t;
 		for (int i = 0; i < 8 * (k + 1); i++) c = (c >> 1) ^ ((c & 1) ? 0xedb88320u : 0);
 		T[k * 256 + t] = c;
 	}
 	__syncthreads();
-	const uint8_t *p = job.dst;
-	if ((uintptr_t)p & 15) {
+	const uint8_t *p = WRAP ? job.src : job.dst;
+	if (((uintptr_t)p & 15) || (WRAP && ((uintptr_t)wdst & 15))) {
 		// bytewise: 256 contiguous pieces
 		uint32_t per = ((n + 255) / 256 + 15) & ~15u;
 		uint32_t lo = (uint32_t)t * per, hi = lo + per < n ? lo + per : n;
 		uint32_t crc = 0, s1 = 0, s2 = 0;
 		for (uint32_t i = lo; i < hi; i++) {
 			uint32_t byte = p[i];
+			if (WRAP) wdst[i] = (uint8_t)byte;
 			crc = T[(crc ^ byte) & 0xff] ^ (crc >> 8);
 			s1 += byte; s2 += s1;
 			if ((i & 0xfff) == 0xfff) { s1 %= 65521u; s2 %= 65521u; }
@@ -544,8 +563,7 @@ __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__res
 				a2 = (uint32_t)((a2 + (uint64_t)len * a1 + red[2][k]) % 65521u);
 				a1 = (a1 + red[1][k]) % 65521u;
 			}
-			results[blockIdx.x].crc = c ^ 0xffffffffu;
-			results[blockIdx.x].adler = (a2 << 16) | a1;
+			finish(c ^ 0xffffffffu, (a2 << 16) | a1);
 		}
 		return;
 	}
@@ -562,13 +580,18 @@ __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__res
 			for (int k = 0; k < 4; k++) {
 				q[k] = make_uint4(0, 0, 0, 0);
 				if (16u * k < nb) {
-					if ((size_t)base + (size_t)sl * 64 + 16 * k + 16 <= job.dst_cap) q[k] = sp[k];
-					else {                                          // never read past the caller's buffer
+					if ((size_t)base + (size_t)sl * 64 + 16 * k + 16 <= rd_cap) {
+						q[k] = sp[k];
+						if (WRAP) ((uint4 *)(wdst + base + (size_t)sl * 64))[k] = q[k];
+					} else {                                        // never read past the caller's buffer
 						const uint8_t *bp = (const uint8_t *)&sp[k];
 						uint32_t ww[4] = { 0, 0, 0, 0 };
 #pragma unroll
 						for (int b = 0; b < 16; b++)
-							if (16u * k + b < nb) ww[b >> 2] |= (uint32_t)bp[b] << (8 * (b & 3));
+							if (16u * k + b < nb) {
+								ww[b >> 2] |= (uint32_t)bp[b] << (8 * (b & 3));
+								if (WRAP) wdst[base + (size_t)sl * 64 + 16 * k + b] = bp[b];
+							}
 						q[k] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
 					}
 				}
@@ -628,13 +651,18 @@ __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__res
 			a1_run = (a1_run + b1) % 65521u;
 		}
 	}
-	if (t == 0) {
-		results[blockIdx.x].crc = c_run ^ 0xffffffffu;
-		results[blockIdx.x].adler = (a2_run << 16) | a1_run;
-	}
+	if (t == 0) finish(c_run ^ 0xffffffffu, (a2_run << 16) | a1_run);
 }
 
 } // namespace nxzl
+
+// the WRAP function code for a batch (nxz_engine.cpp nxz_batch_wrap)
+extern "C" int nxz_launch_wrap_sliced(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL(nxzl::cksum_kernel<true>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
+	return (int)hipGetLastError();
+}
 
 #define NXZ_LANES_MAX_GRID (1024u * NXZ_LANES_WPE)
 // resident wavefronts (each works its way through groups of 64 streams): NXZ_LANES_GRID overrides, for measurements
@@ -674,7 +702,7 @@ __global__ void order_keys_kernel(const nxz_batch_job_t *__restrict__ jobs, uint
 extern "C" int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream)
 {
 	if (!n) return 0;
-	hipLaunchKernelGGL(nxzl::cksum_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
+	hipLaunchKernelGGL(nxzl::cksum_kernel<false>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
 	return (int)hipGetLastError();
 }
 
@@ -698,6 +726,6 @@ extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, n
 		if (hipcub::DeviceRadixSort::SortPairsDescending(base + 4 * arr, tb, k_in, k_out, v_in, v_out, (int)n, 0, 21, stream) == hipSuccess) order = v_out;
 	}
 	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace, order);
-	hipLaunchKernelGGL(nxzl::cksum_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
+	hipLaunchKernelGGL(nxzl::cksum_kernel<false>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
 	return (int)hipGetLastError();
 }

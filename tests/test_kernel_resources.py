@@ -25,7 +25,8 @@ BUDGET = {
     "nxzi::inflate_kernel<false, false>": (128, 0),   # window in LDS: LDS bounds the occupancy, not registers
     "nxzi::inflate_kernel<false, true>": (128, 0),
     "nxzl::inflate_lanes_kernel": (128, 32),
-    "nxzl::cksum_kernel": (96, 0),
+    "nxzl::cksum_kernel<false>": (96, 0),
+    "nxzl::cksum_kernel<true>": (96, 0),            # the WRAP function code: the same pass, storing as it goes
     "nxzb::find_blocks_kernel": (96, 0),
     "nxzi::token_sync_kernel": (72, 0),               # (LDS bounds it at five wavefronts per SIMD: 72 registers allow seven)
     "nxzi::block_tables_kernel": (64, 0),
