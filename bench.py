@@ -857,7 +857,7 @@ def c5_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, total
     if rank != 0:
         return None
     value = 2.0 * tot_u * steps / wall_max / 2.0 ** 30
-    return {
+    line = {
         "metric": "GiB/s uncompressed in (deflate) + out (inflate), 10 GiB mixed-entropy 64 KiB blocks",
         "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(wall_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
@@ -867,9 +867,31 @@ def c5_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, total
                                "shrink + decompress + compare, device resident" % (total, world),
                    "total_blocks": total, "block_bytes": BLOCK, "ratio": round(tot_u / tot_c, 4),
                    "stored_blocks_rank0": info["stored"], "roundtrip_bit_exact": True, "parallelism": "shard%d" % world},
-        "roofline": roof(2 * (tot_u + tot_c) * steps / wall_max / 1e9 / world, None,
+        "roofline": roof(2 * (tot_u + tot_c) * steps / wall_max / 1e9 / world, pmc_traffic(n, "c5"),
                          "whole step (deflate + wrap + inflate kernels), wall clock, per GPU", copy_peak_gbs(torch, dev)),
     }
+    if world == 1 and not args.no_cpu_baseline:
+        # the reference's software path for the same step: zlib level 1 (fixed code) per block, stored when it does not
+        # shrink, and zlib's inflate back -- a bounded sample of the same mix
+        import zlib
+        sample = [row.tobytes() for row in src[:256].cpu().numpy()]
+        cores = usable_cores()
+        zd, nin, nout, nd = _cpu_run(sample, 1, cores, 3.0)
+        streams = []
+        for b in sample:
+            c = zlib.compressobj(1, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+            z = c.compress(b) + c.flush()
+            if len(z) >= len(b):                                  # stored: one block header per 65535 bytes
+                c = zlib.compressobj(0, zlib.DEFLATED, -15)
+                z = c.compress(b) + c.flush()
+            streams.append(z)
+        zi, _, _, ni = _cpu_run(streams, 2, cores, 3.0)
+        both = 2.0 / (1.0 / zd + 1.0 / zi)                        # in + out over the time of both passes
+        line["cpu_baseline"] = {"value": round(both, 4), "unit": "GiB/s uncompressed in + out", "cores": cores, "kind": "reference",
+                                "what": "system zlib 1.2.11: deflate level 1 Z_FIXED per block (stored when it does not shrink), then inflate of those streams",
+                                "sample": "%d + %d blocks of the same mix on %d pthreads" % (nd, ni, cores),
+                                "deflate_GiB_s": round(zd, 4), "inflate_GiB_s": round(zi, 4)}
+    return line
 
 
 def c2_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, n, steps, warmup):
