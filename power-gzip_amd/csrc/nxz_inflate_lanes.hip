@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 							   nxz_batch_result_t *__restrict__ results,
 							   nxz_batch_dht_t *__restrict__ dht_io,
 							   uint8_t *__restrict__ workspace, const uint8_t *__restrict__ fixed_ws,
-							   const uint32_t *__restrict__ order)
+							   const uint32_t *__restrict__ order, uint32_t per_wave)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t lens_s[320];
 	const int lane = threadIdx.x;
@@ -150,12 +150,15 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 	uint8_t *myws = workspace + ((size_t)blockIdx.x * 65 + lane + 1) * WS_BYTES;
 	uint8_t *shared_ws = workspace + ((size_t)blockIdx.x * 65 + 64 + 1) * WS_BYTES;
 
-	for (size_t g = blockIdx.x; g * 64 < n; g += gridDim.x) {
+	// per_wave: streams a wavefront takes at a time, 64 or 32.  The kernel lives on the number of wavefronts a CU holds --
+	// a lane waits for its stream's bytes, and only other wavefronts fill the gap --, so a batch that would leave the
+	// device half empty at 64 a wavefront (fewer than 131072 streams) runs 32 a wavefront on twice as many.
+	for (size_t g = blockIdx.x; g * per_wave < n; g += gridDim.x) {
 		// order (may be NULL): the jobs by falling source length, so that the 64 streams of a wavefront are much of a
 		// size and the long ones go first (a wavefront takes as long as its longest stream: a batch of mixed kinds --
 		// zeros, text, copies by turns, BASELINE configs[4] -- ran at half the rate of its kinds one by one)
-		const bool active = g * 64 + lane < n;
-		const size_t jid = active && order ? order[g * 64 + lane] : g * 64 + lane;
+		const bool active = (uint32_t)lane < per_wave && g * per_wave + lane < n;
+		const size_t jid = active && order ? order[g * per_wave + lane] : g * per_wave + lane;
 		nxz_batch_job_t job;
 		if (active) job = jobs[jid];
 		else { job.src = nullptr; job.dst = nullptr; job.src_len = 0; job.hist_len = 0; job.dst_cap = 0; job.resume = 0; job.in_crc = 0; job.in_adler = 1; }
@@ -673,9 +676,15 @@ static unsigned lanes_max_grid(void)
 }
 
 // workspace bytes a batch of n streams needs (grows with n up to the largest grid)
+static unsigned lanes_per_wave(size_t n)
+{
+	static const int env = getenv("NXZ_LANES_PER_WAVE") ? atoi(getenv("NXZ_LANES_PER_WAVE")) : 0;   // measurements: 32 or 64
+	if (env == 32 || env == 64) return (unsigned)env;
+	return n <= 64 * (size_t)(NXZ_LANES_MAX_GRID / 2) ? 32u : 64u;     /* (own fixed-code streams: 54 against 50 GiB/s at 98304, 67 against 62 at 131072; 58 against 82 at 196608) */
+}
 static size_t lanes_tables_bytes(size_t n)
 {
-	size_t groups = (n + 63) / 64;
+	size_t groups = (n + lanes_per_wave(n) - 1) / lanes_per_wave(n);
 	size_t grid = groups < NXZ_LANES_MAX_GRID ? groups : NXZ_LANES_MAX_GRID;
 	return ((grid * 65 + 1) * nxzl::WS_BYTES + 255) & ~(size_t)255;
 }
@@ -710,7 +719,8 @@ extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, n
 					nxz_batch_dht_t *dht_io, uint8_t *workspace, int init_fixed, hipStream_t stream)
 {
 	if (!n) return 0;
-	size_t groups = (n + 63) / 64;
+	const unsigned pw = lanes_per_wave(n);
+	size_t groups = (n + pw - 1) / pw;
 	unsigned grid = (unsigned)(groups < lanes_max_grid() ? groups : lanes_max_grid());
 	if (init_fixed & 1) hipLaunchKernelGGL(nxzl::fixed_tables_kernel, dim3(1), dim3(64), 0, stream, workspace);
 	// the jobs by falling source length when the caller says they differ much (init_fixed bit 1; NXZ_LANES_ORDER=0 / 1: never / always)
@@ -725,7 +735,7 @@ extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, n
 		hipLaunchKernelGGL(nxzl::order_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, jobs, (uint32_t)n, k_in, v_in);
 		if (hipcub::DeviceRadixSort::SortPairsDescending(base + 4 * arr, tb, k_in, k_out, v_in, v_out, (int)n, 0, 21, stream) == hipSuccess) order = v_out;
 	}
-	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace, order);
+	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace, order, pw);
 	hipLaunchKernelGGL(nxzl::cksum_kernel<false>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
 	return (int)hipGetLastError();
 }
