@@ -701,3 +701,64 @@ def test_all_35_canned_tables_encode_bit_exact(eng):
         assert exp is not None, (i, use[i])
         assert r["cc"][i] in (0, 64) and r["tpbc"][i] == len(exp) and r["tebc"][i] == nbits % 8, (i, use[i], r["cc"][i])
         assert out[i, :len(exp)].tobytes() == exp, (i, use[i])
+
+
+def test_second_entries_switch_follows_the_first_tile(eng):
+    """oracle/nxz_lz77.c step 3b: the later tiles of a sub-block use the second bucket entries only if the first tile
+    made 3072 tokens or more.  Blocks whose first tile is easy and whose rest is hard, the other way round, a first tile
+    right at the threshold (token counts 2900..3300 made by isolated bytes in zeros), with and without history: fixed
+    code and exact dynamic table, byte for byte the oracle's."""
+    import torch
+    rnd = np.random.RandomState(4)
+    text = make_block("alice", 65536, seed=3) + make_block("text33", 65536, seed=4)
+    json_like = (b'{"name": "entry", "id": %d, "tags": ["a", "b", "c"], "value": 3.14159},\n' * 2000)
+    blocks = []
+    blocks.append(bytes(16384) + text[:49152])                                    # easy first tile, hard rest
+    blocks.append(text[:16384] + (json_like % ((7,) * 2000))[:49152])             # hard first tile, easy rest
+    blocks.append((json_like % ((9,) * 2000))[:65536])                            # easy all the way
+    blocks.append(text[1000:66536])                                               # hard all the way
+    for k, lits in enumerate(range(2050, 2350, 40)):                              # first tiles around the threshold (a literal and a short run each: 1.4 tokens)
+        t0 = bytearray(16384)
+        pos = rnd.choice(16384 - 8, lits, replace=False)
+        t0[:] = bytes(16384)
+        for p in pos:
+            t0[p] = 1 + rnd.randint(250)                                          # isolated bytes in a sea of zeros: a literal and a short run each
+        blocks.append(bytes(t0) + text[20000 + 100 * k:20000 + 100 * k + 49152])
+    hist = text[5000:5000 + 16384]
+    src = pack_blocks(eng, blocks, STRIDE_IN)
+    lens = np.array([len(b) for b in blocks], np.uint32)
+    for fc in (pkg.FC_COMPRESS_FHT, pkg.FC_COMPRESS_DHTGEN):
+        dst = torch.zeros((len(blocks), STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+        jobs = eng.jobs_strided(src, STRIDE_IN, lens, dst, STRIDE_OUT, STRIDE_OUT)
+        res, _ = eng.compress(fc, jobs, len(blocks))
+        r = eng.results_to_host(res)
+        out = dst.cpu().numpy()
+        first_tile_tokens = []
+        for i, b in enumerate(blocks):
+            tok, nt = O.lz77(b)
+            t0, _ = O.lz77(b[:16384])
+            first_tile_tokens.append(_)
+            if fc == pkg.FC_COMPRESS_FHT:
+                exp, bits = O.deflate_fixed(b)
+            else:
+                ll, d = O.counts(tok, nt)
+                dht, dhtlen = O.dhtgen(ll, d)
+                exp, bits = O.deflate_dynamic(b, dht, dhtlen)
+            assert r["cc"][i] == 0 and r["tpbc"][i] == len(exp), (fc, i)
+            assert out[i, :len(exp)].tobytes() == exp, (fc, i)
+            dz = zlib.decompressobj(-15)
+            assert dz.decompress(exp) == b and dz.eof
+        # both sides of the threshold are among the cases (else the test proves nothing)
+        assert min(first_tile_tokens) < 3072 <= max(first_tile_tokens), sorted(first_tile_tokens)
+    # and with a window in front of the block (the first TILE OF THE BLOCK decides, not the window)
+    withh = [hist + b[:65536 - len(hist)] for b in blocks[:4]]
+    src = pack_blocks(eng, withh, STRIDE_IN)
+    dst = torch.zeros((len(withh), STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, STRIDE_IN, np.full(len(withh), 65536, np.uint32), dst, STRIDE_OUT, STRIDE_OUT,
+                            hist_len=np.full(len(withh), len(hist), np.uint32))
+    res, _ = eng.compress(pkg.FC_COMPRESS_RESUME_FHT, jobs, len(withh))
+    r = eng.results_to_host(res)
+    out = dst.cpu().numpy()
+    for i, b in enumerate(withh):
+        exp, bits = O.deflate_fixed(b, hist=len(hist))
+        assert r["tpbc"][i] == len(exp) and out[i, :len(exp)].tobytes() == exp, i
