@@ -471,7 +471,7 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 	int rc;
 	const char *lm = getenv("NXZ_INFLATE_LANES_MIN");                    // tuning / test knob
 	const size_t lanes_min = lm ? (size_t)strtoull(lm, nullptr, 0) : (size_t)NXZ_LANES_MIN;
-	bool lanes = n >= lanes_min, by_len = false;
+	bool lanes = n >= lanes_min, by_len = false, no_tables = false;
 	if (lanes && !lm) {
 		// what kind of streams?  (one small launch and a wait for it: nothing next to the tens of milliseconds such a batch takes)
 		uint32_t *h = nullptr;
@@ -488,6 +488,7 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 				// longest stream, so the lane kernel gets them ordered by length; much of a size they stay as they come
 				// (neighbours in memory: ordering the bench's synthetic blocks cost 5 %)
 				by_len = h[2] > 8 * (uint64_t)h[1] + 4096;
+				no_tables = h[0] == 0;                                 // none of the sampled streams begins with a dynamic block
 			}
 		}
 	}
@@ -515,7 +516,7 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 			}
 			ws = sc.d_lanes_ws;
 		}
-		rc = nxz_launch_inflate_lanes(jobs, n, results, dht_io, ws, init | (by_len ? 2 : 0), s);
+		rc = nxz_launch_inflate_lanes(jobs, n, results, dht_io, ws, init | (by_len ? 2 : 0) | (no_tables ? 4 : 0), s);
 	} else {
 		const char *wm = getenv("NXZ_INFLATE_LDS_MAX");                 // tuning / test knob
 		const size_t lds_max = wm ? (size_t)strtoull(wm, nullptr, 0) : (size_t)NXZ_WINDOW_LDS_MAX;

@@ -53,6 +53,9 @@ __device__ __forceinline__ int decode(const uint16_t *fast, const uint16_t *cnt,
 
 // The fixed code (RFC1951 3.2.6) needs no table: the symbol follows from the first 9 bits by
 // arithmetic, which takes the lookup (and its latency) out of every token of a type-1 block.
+#ifndef NXZ_LANES_LITS
+#define NXZ_LANES_LITS 6                // literals a lane may decode in one trip round its token loop
+#endif
 __device__ __forceinline__ int decode_fixed_ll(uint32_t bits, uint32_t &nb)
 {
 	const uint32_t r9 = __builtin_bitreverse32(bits) >> 23;       // the first 9 bits, first bit most significant
@@ -140,8 +143,11 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 							   nxz_batch_result_t *__restrict__ results,
 							   nxz_batch_dht_t *__restrict__ dht_io,
 							   uint8_t *__restrict__ workspace, const uint8_t *__restrict__ fixed_ws,
-							   const uint32_t *__restrict__ order, uint32_t per_wave)
+							   const uint32_t *__restrict__ order, uint32_t per_wave, const uint32_t *__restrict__ only_if)
 {
+	// only_if (may be NULL): launched behind the fixed-code kernel below, this one runs only when that one met a stream it
+	// does not do (the word is then set)
+	if (only_if && *(const volatile uint32_t *)only_if == 0) return;
 	__shared__ __attribute__((aligned(16))) uint8_t lens_s[320];
 	const int lane = threadIdx.x;
 	// slot 0 = fixed tables; then 65 slots per wave: one per lane and a spare that lanes with identical
@@ -373,11 +379,18 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 					if (bfinal) { final_eob = true; state = 3; break; }
 					state = 0;
 				} else {
-					const uint64_t sym_start = b.pos;
 					const uint32_t sfbt = (btype == 1 ? 0xa : 0xc) | bfinal;
 					uint32_t nb;
-					b.fill();
+					b.refill();                                     // every lane, here: see BitRd
 					int sym = btype == 1 ? decode_fixed_ll((uint32_t)b.bb, nb) : decode<LB>(T.lit, T.lcnt, T.lsym, (uint32_t)b.bb, nb);
+					// up to NXZ_LANES_LITS literals before the wavefront's lanes meet again (see the fixed-code kernel below)
+					for (int nl = 1; nl < NXZ_LANES_LITS && sym >= 0 && sym < 256 && b.have(nb) && w.out < cap; nl++) {
+						b.drop(nb);
+						w.lit((uint32_t)sym);
+						b.need(15);
+						sym = btype == 1 ? decode_fixed_ll((uint32_t)b.bb, nb) : decode<LB>(T.lit, T.lcnt, T.lsym, (uint32_t)b.bb, nb);
+					}
+					const uint64_t sym_start = b.pos;
 					if (sym < 0 || !b.have(nb)) {
 						if (!b.have(sym < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); }
 						else cc = NXZ_CC_MISSING_CODE;
@@ -395,11 +408,11 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 						if (sym >= 29) { cc = NXZ_CC_MISSING_CODE; state = 3; break; }
 						uint32_t lbase, eb;
 						len_params((uint32_t)sym, lbase, eb);
-						b.fill();
+						b.need(5);
 						if (!b.have(eb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); state = 3; break; }
 						uint32_t len = lbase + ((uint32_t)b.bb & ((1u << eb) - 1));
 						b.drop(eb);
-						b.fill();
+						b.need(15);
 						int ds = btype == 1 ? decode_fixed_d((uint32_t)b.bb, nb) : decode<DB>(T.dist, T.dcnt, T.dsym, (uint32_t)b.bb, nb);
 						if (ds < 0 || !b.have(nb)) {
 							if (!b.have(ds < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); }
@@ -410,7 +423,7 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 						b.drop(nb);
 						uint32_t dbase;
 						dist_params((uint32_t)ds, dbase, eb);
-						b.fill();
+						b.need(13);
 						if (!b.have(eb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); state = 3; break; }
 						uint32_t dist = dbase + ((uint32_t)b.bb & ((1u << eb) - 1));
 						b.drop(eb);
@@ -447,6 +460,157 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 }
 
 // fixed-Huffman table set (RFC1951 3.2.6) in workspace format
+// Streams of fixed-Huffman and stored blocks only -- what this engine's fixed-code deflate makes, and zlib's Z_FIXED: the
+// same lane-per-stream decode without anything a dynamic table needs (no header parse, no table builds by the whole
+// wave, no table pointers and no workspace): a kernel of its own, which the compiler gives fewer registers and the CU
+// more wavefronts.  A stream that turns out to hold a dynamic block (or resumes inside one) sets *bail, and the kernel
+// above, queued behind this one, then does the whole batch again.
+#ifndef NXZ_LANES_FIXED_WPE
+#define NXZ_LANES_FIXED_WPE 6
+#endif
+__global__ __launch_bounds__(64, NXZ_LANES_FIXED_WPE) void inflate_lanes_fixed_kernel(const nxz_batch_job_t *__restrict__ jobs, size_t n,
+							   nxz_batch_result_t *__restrict__ results,
+							   const uint32_t *__restrict__ order, uint32_t per_wave, uint32_t *__restrict__ bail)
+{
+	const int lane = threadIdx.x;
+	for (size_t g = blockIdx.x; g * per_wave < n; g += gridDim.x) {
+		const bool active = (uint32_t)lane < per_wave && g * per_wave + lane < n;
+		const size_t jid = active && order ? order[g * per_wave + lane] : g * per_wave + lane;
+		nxz_batch_job_t job;
+		if (active) job = jobs[jid];
+		else { job.src = nullptr; job.dst = nullptr; job.src_len = 0; job.hist_len = 0; job.dst_cap = 0; job.resume = 0; job.in_crc = 0; job.in_adler = 1; }
+		const uint32_t hist = job.hist_len < job.src_len ? job.hist_len : job.src_len;
+		const uint8_t *hsrc = job.src;                           // history bytes [0, hist)
+		uint8_t *dst = job.dst;
+		const uint32_t cap = job.dst_cap;
+		BitRd b;
+		b.src = job.src + hist; b.srclen = job.src_len - hist; b.bb = 0; b.bc = 0; b.pos = 0;
+		const uint32_t in_subc = (job.resume >> 20) & 7, in_sfbt = (job.resume >> 16) & 15, in_rem = job.resume & 0xffff;
+		if (b.srclen && in_subc) b.pos = 8 - in_subc;
+		OutWr w{ dst, 0, 0, 0, ((uintptr_t)dst & 3) == 0 };
+		uint32_t cc = 0, o_sfbt = 0, o_subc = 0, o_rem = 0;
+		uint32_t bfinal = 0, rem = 0;
+		int state = active ? 0 : 3;                              // 0 header, 1 stored, 2 fixed code, 3 done
+		bool final_eob = false, dyn = false;
+		if (active && (in_sfbt & 8)) {
+			const uint32_t kind = (in_sfbt >> 1) & 7;
+			bfinal = in_sfbt & 1;
+			if (kind == 4) { state = 1; rem = in_rem; }
+			else if (kind == 5) state = 2;
+			else if (kind == 6) { dyn = true; state = 3; }
+		}
+		while (__any(state != 3)) {
+			for (int steps = 0; steps < 4096 && state != 3; steps++) {
+				if (state == 0) {
+					b.sync();
+					const uint64_t hdr = b.pos;
+					if (!b.have(3)) { o_sfbt = 0xe; o_subc = (uint32_t)(b.total() - hdr); state = 3; break; }
+					const uint32_t v = b.take(3);
+					bfinal = v & 1;
+					const uint32_t btype = v >> 1;
+					if (btype == 0) {
+						b.pos = (b.pos + 7) & ~7ull; b.sync();
+						if (!b.have(32)) { o_sfbt = 0xe | bfinal; o_subc = (uint32_t)(b.total() - hdr); state = 3; break; }
+						const uint32_t lo = b.take(16), hi = b.take(16);
+						if ((lo ^ hi) != 0xffff) { cc = NXZ_CC_INVALID_DHT; state = 3; break; }
+						rem = lo; state = 1;
+					} else if (btype == 1) state = 2;
+					else if (btype == 2) { dyn = true; state = 3; }
+					else { cc = NXZ_CC_INVALID_DHT; state = 3; }
+				} else if (state == 1) {
+					const uint32_t sp = (uint32_t)(b.pos >> 3);
+					const uint32_t srcleft = b.srclen - sp;
+					const uint32_t k = rem < srcleft ? rem : srcleft;
+					if (k > cap - w.out) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
+					w.flush();
+					w.copy_in(b.src + sp, k);
+					rem -= k; b.pos = (uint64_t)(sp + k) * 8; b.sync();
+					if (rem) { o_sfbt = 0x8 | bfinal; o_subc = 0; o_rem = rem; state = 3; break; }
+					if (bfinal) { final_eob = true; state = 3; break; }
+					state = 0;
+				} else {
+					const uint32_t sfbt = 0xa | bfinal;
+					uint32_t nb;
+					b.refill();                                     // every lane, here: see BitRd
+					// up to NXZ_LANES_LITS literals before the wavefront's lanes meet again: a trip round the token loop costs the
+					// wavefront the same whatever its lanes do in it, and a lane with nothing but literals (text) had 64 Ki trips
+					// to make while the lanes with matches waited for it (c5: 123.6 ms -> 77 ms with 3, 71 with 6)
+					int sym = decode_fixed_ll((uint32_t)b.bb, nb);
+					for (int nl = 1; nl < NXZ_LANES_LITS && sym >= 0 && sym < 256 && b.have(nb) && w.out < cap; nl++) {
+						b.drop(nb);
+						w.lit((uint32_t)sym);
+						b.need(9);
+						sym = decode_fixed_ll((uint32_t)b.bb, nb);
+					}
+					const uint64_t sym_start = b.pos;
+					if (sym < 0 || !b.have(nb)) {
+						if (!b.have(sym < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); }
+						else cc = NXZ_CC_MISSING_CODE;
+						state = 3; break;
+					}
+					b.drop(nb);
+					if (sym < 256) {
+						if (w.out >= cap) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
+						w.lit((uint32_t)sym);
+					} else if (sym == 256) {
+						if (bfinal) { final_eob = true; state = 3; break; }
+						state = 0;
+					} else {
+						sym -= 257;
+						if (sym >= 29) { cc = NXZ_CC_MISSING_CODE; state = 3; break; }
+						uint32_t lbase, eb;
+						len_params((uint32_t)sym, lbase, eb);
+						b.need(5);
+						if (!b.have(eb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); state = 3; break; }
+						const uint32_t len = lbase + ((uint32_t)b.bb & ((1u << eb) - 1));
+						b.drop(eb);
+						b.need(5);
+						const int ds = decode_fixed_d((uint32_t)b.bb, nb);
+						if (ds < 0 || !b.have(nb)) {
+							if (!b.have(ds < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); }
+							else cc = NXZ_CC_INVALID_DIST;
+							state = 3; break;
+						}
+						if (ds >= 30) { cc = NXZ_CC_INVALID_DIST; state = 3; break; }
+						b.drop(nb);
+						uint32_t dbase;
+						dist_params((uint32_t)ds, dbase, eb);
+						b.need(13);
+						if (!b.have(eb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); state = 3; break; }
+						const uint32_t dist = dbase + ((uint32_t)b.bb & ((1u << eb) - 1));
+						b.drop(eb);
+						if (dist > w.out + hist || dist > 32768) { cc = NXZ_CC_INVALID_DIST; state = 3; break; }
+						if (len > cap - w.out) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
+						if (w.al && len <= 8 && dist >= len + 4 && dist <= w.out) { w.copy_short(len, dist); continue; }
+						w.flush();
+						if (dist > w.out) {
+							// (part of) the source is in the history buffer
+							for (uint32_t i = 0; i < len; i++) {
+								const int64_t sidx = (int64_t)w.out + i - dist;
+								dst[w.out + i] = sidx < 0 ? hsrc[hist + sidx] : dst[sidx];
+							}
+							w.out += len;
+						} else w.copy(len, dist);
+					}
+				}
+			}
+		}
+		w.flush();
+		if (__any(dyn) && lane == 0) *(volatile uint32_t *)bail = 1;      // (the other kernel does the batch again)
+		if (active) {
+			if (final_eob) { o_sfbt = 0; o_subc = (uint32_t)(b.total() - b.pos); }
+			nxz_batch_result_t r;
+			uint32_t spbc = job.src_len, subc = o_subc;
+			if (final_eob && subc > 0xfff8) { const uint32_t drop = (subc - 0xfff8 + 7) / 8; spbc -= drop; subc -= drop * 8; }
+			if (cc == 0 && !(final_eob && subc < 8)) cc = NXZ_CC_DATA_LENGTH;
+			r.cc = cc; r.tpbc = (cc == 0 || cc == NXZ_CC_DATA_LENGTH) ? w.out : 0;
+			r.tebc = o_rem; r.spbc = spbc; r.crc = 0; r.adler = 0;
+			r.subc = subc; r.sfbt = o_sfbt | (final_eob ? 0x100u : 0);
+			results[jid] = r;
+		}
+	}
+}
+
 __global__ void fixed_tables_kernel(uint8_t *ws)
 {
 	__shared__ uint8_t lens[320];
@@ -694,10 +858,15 @@ static size_t lanes_sort_temp_bytes(size_t n)
 	(void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
 	return (t + 255) & ~(size_t)255;
 }
-// the tables' slots, then what ordering the jobs by length needs: keys and indices in and out, the sort's own room
-extern "C" size_t nxz_inflate_lanes_workspace(size_t n)
+// the tables' slots, then what ordering the jobs by length needs: keys and indices in and out, the sort's own room; then the
+// word by which the fixed-code kernel asks for the general one
+static size_t lanes_bail_offset(size_t n)
 {
 	return lanes_tables_bytes(n) + 4 * ((n * sizeof(uint32_t) + 255) & ~(size_t)255) + lanes_sort_temp_bytes(n);
+}
+extern "C" size_t nxz_inflate_lanes_workspace(size_t n)
+{
+	return lanes_bail_offset(n) + 256;
 }
 
 namespace nxzl {
@@ -735,7 +904,20 @@ extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, n
 		hipLaunchKernelGGL(nxzl::order_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, jobs, (uint32_t)n, k_in, v_in);
 		if (hipcub::DeviceRadixSort::SortPairsDescending(base + 4 * arr, tb, k_in, k_out, v_in, v_out, (int)n, 0, 21, stream) == hipSuccess) order = v_out;
 	}
-	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace, order, pw);
+	// init_fixed bit 2: the sampled streams all begin with fixed-code or stored blocks: the kernel that does only those first, and
+	// this one behind it for the batch that turns out to hold a dynamic block somewhere (NXZ_LANES_FIXED=0: never)
+	// (NXZ_LANES_FIXED=2: always first, whatever the sample said -- the tests' way to put every stream through it)
+	const char *fe = getenv("NXZ_LANES_FIXED");
+	const int fixed_env = fe ? atoi(fe) : 1;
+	const bool fixed_first = fixed_env != 0;
+	if (fixed_env == 2) init_fixed |= 4;
+	uint32_t *bail = nullptr;
+	if (fixed_first && (init_fixed & 4)) {
+		bail = (uint32_t *)(workspace + lanes_bail_offset(n));
+		(void)hipMemsetAsync(bail, 0, sizeof(uint32_t), stream);
+		hipLaunchKernelGGL(nxzl::inflate_lanes_fixed_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, order, pw, bail);
+	}
+	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace, order, pw, bail);
 	hipLaunchKernelGGL(nxzl::cksum_kernel<false>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
 	return (int)hipGetLastError();
 }

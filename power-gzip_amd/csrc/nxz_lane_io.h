@@ -7,8 +7,10 @@
 #ifdef __HIPCC__
 #define NXZ_LANE_FN __device__ __forceinline__
 #define NXZ_LANE_ALIGNBYTE(hi, lo, sh) __builtin_amdgcn_alignbyte(hi, lo, sh)
+#define NXZ_LANE_GLOBAL __attribute__((address_space(1)))      // job buffers are device memory: global_load, not flat_load
 #else
 #define NXZ_LANE_FN inline
+#define NXZ_LANE_GLOBAL
 static inline uint32_t nxz_lane_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
 {
 	return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (sh & 3)));
@@ -26,13 +28,28 @@ struct BitRd {
 	NXZ_LANE_FN uint64_t total() const { return (uint64_t)srclen * 8; }
 	NXZ_LANE_FN bool have(uint32_t n) const { return pos + n <= total(); }
 	NXZ_LANE_FN void sync() { bb = 0; bc = 0; }
-	NXZ_LANE_FN void fill()            // bc >= 32 afterwards (zero bits past the end)
+	// A load by one lane is a load instruction of the whole wavefront, and those (64 lanes, 64 cache lines) are what the lane
+	// kernels are bound by -- so a lane that loads takes all the bytes bb has room for, and the kernels call refill() where
+	// every lane passes at the same time (the head of a trip round the token loop), whether a lane is short of bits or not.
+	// Afterwards: 57..64 bits while 8 bytes of the source remain (one unaligned 8-byte load); the last bytes come 4 at a
+	// time from the aligned dwords that hold them, and only when fewer than 32 bits are at hand (>= 32 afterwards, 25 right
+	// after a sync() at a bit inside a byte; zero bits past the end) -- a byte outside the source is never read.
+	NXZ_LANE_FN void refill()
 	{
-		if (bc >= 32) return;
+		if (bc > 56) return;
 		const uint64_t p2 = pos + bc;
 		const uint32_t byte = (uint32_t)(p2 >> 3), sh = (uint32_t)p2 & 7;
-		// the 4 bytes at src + byte from two aligned dwords (never touching a dword that holds no
-		// byte of the source), bytes past the end read as zero
+		if (byte + 8 <= srclen) {
+			uint64_t v;
+			__builtin_memcpy(&v, (const NXZ_LANE_GLOBAL uint8_t *)src + byte, 8);
+			const uint32_t room = 64 - bc + sh;                     // bits of v that fit, the sh already consumed ones included
+			const uint32_t nbits = room >= 64 ? 64 : room & ~7u;    // whole bytes
+			if (nbits < 64) v &= ((uint64_t)1 << nbits) - 1;
+			bb |= (v >> sh) << bc;
+			bc += nbits - sh;
+			return;
+		}
+		if (bc >= 32) return;
 		uint32_t v = 0;
 		if (byte < srclen) {
 			const uintptr_t a = (uintptr_t)src + byte;
@@ -45,6 +62,8 @@ struct BitRd {
 		bb |= (uint64_t)(v >> sh) << bc;
 		bc += 32 - sh;
 	}
+	NXZ_LANE_FN void fill() { if (bc < 32) refill(); }
+	NXZ_LANE_FN void need(uint32_t n) { if (bc < n) refill(); }        // n <= 32 (25 right after a sync())
 	NXZ_LANE_FN void drop(uint32_t n) { bb >>= n; bc -= n; pos += n; }
 	NXZ_LANE_FN uint32_t take(uint32_t n)      // caller checked have(n), n <= 16
 	{

@@ -10,29 +10,38 @@
 #include "nxz_lane_io.h"
 using namespace nxzl;
 
-static void fill_ref(BitRd &b)
+// what fill() promises: bb holds the stream's bits [pos, pos + bc), zeros above them and past the end of the source
+static bool fill_ok(const BitRd &b, uint64_t pos, uint32_t least)
 {
-	if (b.bc >= 32) return;
-	uint64_t p2 = b.pos + b.bc;
-	uint32_t byte = (uint32_t)(p2 >> 3), sh = (uint32_t)p2 & 7, v = 0;
-	for (uint32_t k = 0; k < 4; k++) if (byte + k < b.srclen) v |= (uint32_t)b.src[byte + k] << (8 * k);
-	b.bb |= (uint64_t)(v >> sh) << b.bc;
-	b.bc += 32 - sh;
+	if (b.pos != pos || b.bc > 64 || b.bc < least) return false;
+	for (uint32_t i = 0; i < b.bc; i++) {
+		const uint64_t bi = pos + i;
+		const uint32_t ref = (bi >> 3) < b.srclen ? (b.src[bi >> 3] >> (bi & 7)) & 1 : 0;
+		if (((b.bb >> i) & 1) != ref) return false;
+	}
+	return b.bc == 64 || (b.bb >> b.bc) == 0;
 }
 
 int main()
 {
 	srand(1);
 	for (int it = 0; it < 200000; it++) {
-		uint32_t n = rand() % 40, off = rand() % 8;
+		uint32_t n = rand() % 70, off = rand() % 8;
 		std::vector<uint8_t> buf(((off + n + 3) & ~3u) ? ((off + n + 3) & ~3u) : 4);
 		for (auto &x : buf) x = (uint8_t)rand();
-		BitRd a{ buf.data() + off, n, 0, 0, (uint64_t)(rand() % (n * 8 + 20)) }, b = a;
-		for (int k = 0; k < 6; k++) {
-			a.fill(); fill_ref(b);
-			if (a.bb != b.bb || a.bc != b.bc) { printf("fill mismatch\n"); return 1; }
-			uint32_t dr = rand() % 17; if (dr > a.bc) dr = a.bc;
-			a.drop(dr); b.drop(dr);
+		BitRd a{ buf.data() + off, n, 0, 0, (uint64_t)(rand() % (n * 8 + 20)) };
+		uint64_t pos = a.pos;
+		bool inside = (pos & 7) != 0;
+		for (int k = 0; k < 12; k++) {
+			uint32_t least = (rand() & 1) ? 32 : 1 + rand() % 32;
+			if (inside && least > 25) least = 25;
+			if (rand() % 4 == 0) a.refill();
+			if (least == 32) a.fill(); else a.need(least);
+			if (!fill_ok(a, pos, least)) { printf("fill mismatch (case %d step %d, bc %u)\n", it, k, a.bc); return 1; }
+			uint32_t dr = rand() % ((rand() & 1) ? 17 : 49); if (dr > a.bc) dr = a.bc;
+			a.drop(dr); pos += dr;
+			if (a.bc < 32) inside = false;                      // the next fill starts at a byte
+			if (rand() % 9 == 0) { a.pos = pos = (uint64_t)(rand() % (n * 8 + 20)); a.sync(); inside = (pos & 7) != 0; }
 		}
 	}
 	for (int it = 0; it < 40000; it++) {

@@ -32,17 +32,20 @@ def eng():
     os.environ.pop("NXZ_INFLATE_LANES_MIN", None)
 
 
-@pytest.fixture(params=["lanes", "waves", "waves-global-window"])
+@pytest.fixture(params=["lanes", "lanes-fixed", "waves", "waves-global-window"])
 def inflate_kernel(request):
-    """the three inflate kernels: a stream per lane, a stream per wave with its window in LDS, and
-    with the target buffer as its window (what mid-size batches get)"""
+    """the inflate kernels: a stream per lane; the same with the fixed-code-only kernel in front (which
+    hands a batch with a dynamic block in it back to the first); a stream per wave with its window in
+    LDS, and with the target buffer as its window (what mid-size batches get)"""
     old = os.environ.get("NXZ_INFLATE_LANES_MIN")
-    os.environ["NXZ_INFLATE_LANES_MIN"] = "32" if request.param == "lanes" else "1000000000"
+    os.environ["NXZ_INFLATE_LANES_MIN"] = "32" if request.param.startswith("lanes") else "1000000000"
+    os.environ["NXZ_LANES_FIXED"] = "2" if request.param == "lanes-fixed" else "0"
     if request.param == "waves-global-window":
         os.environ["NXZ_INFLATE_LDS_MAX"] = "0"
     yield request.param
     os.environ["NXZ_INFLATE_LANES_MIN"] = old if old is not None else "32"
     os.environ.pop("NXZ_INFLATE_LDS_MAX", None)
+    os.environ.pop("NXZ_LANES_FIXED", None)
 
 
 def pack_blocks(eng, blocks, stride):
@@ -672,6 +675,55 @@ def test_seeded_inflate_fuzz(eng, inflate_kernel):
         assert r["tpbc"][i] == len(d), i
         assert out[i, :len(d)].tobytes() == d, i
         assert r["crc"][i] == zlib.crc32(d) and r["adler"][i] == zlib.adler32(d), i
+
+
+def test_fixed_and_stored_only_streams_whole_and_cut(eng, inflate_kernel):
+    """what the fixed-code-only lane kernel keeps for itself: 300 streams of fixed-Huffman and stored blocks (zlib Z_FIXED
+    at levels 0-9, several blocks each), whole and cut at a random byte, sources at every alignment: output, suspend
+    state and checksums equal the CPU model's"""
+    import random
+    import torch
+    rnd = random.Random(11)
+    kinds = ["zeros", "random", "text33", "alice", "lz", "periodic", "binary", "sparse"]
+    cases = []
+    for i in range(300):
+        n = rnd.choice([0, 1, 3, 4, 5, 17, 258, 259, 4096, 40000]) if rnd.random() < 0.3 else rnd.randrange(0, 40001)
+        d = make_block(rnd.choice(kinds), n, seed=1300 + i)
+        co = zlib.compressobj(rnd.randrange(0, 10), zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+        c, pos = b"", 0
+        while pos < n and rnd.random() < 0.5:
+            k = rnd.randrange(1, n - pos + 1)
+            c += co.compress(d[pos:pos + k]) + co.flush(rnd.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+            pos += k
+        c += co.compress(d[pos:]) + co.flush()
+        if i % 3 == 0 and c:
+            c = c[:rnd.randrange(0, len(c))]
+        cases.append((d, c))
+    cstride = (max(len(c) for _, c in cases) + 64 + 15) & ~15
+    ostride = 40000 + 32
+    # sources at byte offsets 0..3 of a dword, targets too
+    host = np.zeros((len(cases), cstride), np.uint8)
+    for i, (_, c) in enumerate(cases):
+        host[i, i % 4:i % 4 + len(c)] = np.frombuffer(c, np.uint8)
+    src = torch.from_numpy(host).to(eng.dev)
+    dst = torch.zeros((len(cases), ostride), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, cstride, np.array([len(c) for _, c in cases], np.uint32), dst, ostride, ostride - 8)
+    jh = jobs.cpu().numpy().view(pkg.JOB_DTYPE).copy()
+    for i in range(len(cases)):
+        jh["src"][i] += i % 4
+        jh["dst"][i] += (i // 4) % 4
+    jobs = eng.to_device(jh)
+    r = eng.results_to_host(eng.decompress(jobs, len(cases)))
+    out = dst.cpu().numpy()
+    for i, (d, c) in enumerate(cases):
+        exp, st = O.inflate(c, ostride - 8)
+        assert st.err == 0, i
+        got = out[i, (i // 4) % 4:(i // 4) % 4 + st.tpbc].tobytes()
+        assert r["tpbc"][i] == st.tpbc and got == exp, i
+        assert (r["sfbt"][i] & 0xf) == st.out_sfbt and r["subc"][i] == st.out_subc, (i, r["sfbt"][i], st.out_sfbt)
+        if (st.out_sfbt & 0xe) == 0x8:
+            assert r["tebc"][i] == st.out_rembytecnt, i
+        assert r["crc"][i] == zlib.crc32(exp) and r["adler"][i] == zlib.adler32(exp), i
 
 
 def test_all_35_canned_tables_encode_bit_exact(eng):

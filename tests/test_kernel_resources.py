@@ -24,7 +24,8 @@ BUDGET = {
     "nxzi::inflate_kernel<true, true>": (96, 0),
     "nxzi::inflate_kernel<false, false>": (128, 0),   # window in LDS: LDS bounds the occupancy, not registers
     "nxzi::inflate_kernel<false, true>": (128, 0),
-    "nxzl::inflate_lanes_kernel": (128, 32),
+    "nxzl::inflate_lanes_kernel": (128, 48),          # a stream per lane, any block type: four waves per SIMD
+    "nxzl::inflate_lanes_fixed_kernel": (80, 24),     # ... stored and fixed-code blocks only: six
     "nxzl::cksum_kernel<false>": (96, 0),
     "nxzl::cksum_kernel<true>": (96, 0),            # the WRAP function code: the same pass, storing as it goes
     "nxzb::find_blocks_kernel": (96, 0),
