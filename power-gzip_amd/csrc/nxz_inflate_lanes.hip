@@ -352,6 +352,7 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 
 			// ---------- per-lane decode: run until this lane needs a table or is done ----------
 			for (int steps = 0; steps < 4096 && state != 3 && state != 4; steps++) {
+				w.commit();                                         // every lane, here: see OutWr
 				if (state == 0) {
 					b.sync();
 					uint64_t hdr = b.pos;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 						b.drop(eb);
 						if (dist > w.out + hist || dist > 32768) { cc = NXZ_CC_INVALID_DIST; state = 3; break; }
 						if (len > cap - w.out) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
-						if (w.al && len <= 8 && dist >= len + 4 && dist <= w.out) { w.copy_short(len, dist); continue; }
+						if (len <= 8 && dist >= 16 && dist <= w.out) { w.copy_short(len, dist); continue; }
 						w.flush();
 						if (dist > w.out) {
 							// (part of) the source is in the history buffer
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(64, NXZ_LANES_FIXED_WPE) void inflate_lanes_fixed_k
 		}
 		while (__any(state != 3)) {
 			for (int steps = 0; steps < 4096 && state != 3; steps++) {
+				w.commit();                                         // every lane, here: see OutWr
 				if (state == 0) {
 					b.sync();
 					const uint64_t hdr = b.pos;
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(64, NXZ_LANES_FIXED_WPE) void inflate_lanes_fixed_k
 						b.drop(eb);
 						if (dist > w.out + hist || dist > 32768) { cc = NXZ_CC_INVALID_DIST; state = 3; break; }
 						if (len > cap - w.out) { cc = NXZ_CC_TARGET_SPACE; state = 3; break; }
-						if (w.al && len <= 8 && dist >= len + 4 && dist <= w.out) { w.copy_short(len, dist); continue; }
+						if (len <= 8 && dist >= 16 && dist <= w.out) { w.copy_short(len, dist); continue; }
 						w.flush();
 						if (dist > w.out) {
 							// (part of) the source is in the history buffer

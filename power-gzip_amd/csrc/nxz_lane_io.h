@@ -78,42 +78,52 @@ struct BitRd {
 struct OutWr {
 	uint8_t *dst;
 	uint32_t out;        // bytes produced (including the pending ones)
-	uint32_t wb, wn;     // pending literal bytes (wn = 0..3), they belong to dst[out - wn, out)
-	bool al;             // dst is 4-byte aligned: dword stores allowed
+	uint64_t wb;         // pending bytes (literals and short matches), they belong to dst[out - wn, out)
+	uint32_t wn;         // 0 .. 8
+	bool al;             // dst is 4-byte aligned (the copies below use it)
+	// Stores, like the loads, are instructions of the whole wavefront whichever lane has something to store, so the pending
+	// bytes are written where every lane passes at the same time: commit(), once a trip round the token loop (4 or 8
+	// bytes, at whatever address: up to 3 stay pending), and in between only when the 8 are full.
+	template <typename V> NXZ_LANE_FN void put(uint32_t at, V v) { __builtin_memcpy((NXZ_LANE_GLOBAL uint8_t *)dst + at, &v, sizeof(V)); }
 	NXZ_LANE_FN void lit(uint32_t sym)
 	{
-		if (wn == 0 && (!al || (out & 3))) { dst[out++] = (uint8_t)sym; return; }
-		wb |= sym << (8 * wn);
+		if (wn == 8) { put<uint64_t>(out - 8, wb); wb = 0; wn = 0; }
+		wb |= (uint64_t)sym << (8 * wn);
 		wn++; out++;
-		if (wn == 4) { *(uint32_t *)(dst + out - 4) = wb; wb = 0; wn = 0; }
+	}
+	NXZ_LANE_FN void commit()
+	{
+		if (wn == 8) { put<uint64_t>(out - 8, wb); wb = 0; wn = 0; }
+		else if (wn >= 4) { put<uint32_t>(out - wn, (uint32_t)wb); wb >>= 32; wn -= 4; }
 	}
 	NXZ_LANE_FN void flush()
 	{
-		for (uint32_t k = 0; k < wn; k++) dst[out - wn + k] = (uint8_t)(wb >> (8 * k));
+		commit();
+		uint32_t at = out - wn;
+		if (wn & 2) { put<uint16_t>(at, (uint16_t)wb); wb >>= 16; at += 2; }
+		if (wn & 1) put<uint8_t>(at, (uint8_t)wb);
 		wb = 0; wn = 0;
 	}
-	// append n <= 8 bytes (low byte first), through the same four-at-a-time path as the literals
+	// append n <= 8 bytes (low byte first) to the pending ones
 	NXZ_LANE_FN void append(uint64_t v, uint32_t n)
 	{
-		while (n) {
-			if (wn == 0 && (!al || (out & 3))) { dst[out++] = (uint8_t)v; v >>= 8; n--; continue; }
-			const uint32_t k = 4 - wn < n ? 4 - wn : n;
-			wb |= (uint32_t)(v & (k == 4 ? 0xffffffffu : (1u << (8 * k)) - 1)) << (8 * wn);
-			wn += k; out += k; n -= k;
-			v = k == 4 ? v >> 32 : v >> (8 * k);
-			if (wn == 4) { *(uint32_t *)(dst + out - 4) = wb; wb = 0; wn = 0; }
+		if (n < 8) v &= ((uint64_t)1 << (8 * n)) - 1;
+		const uint32_t room = 8 - wn, k = n < room ? n : room;
+		if (k) wb |= v << (8 * wn);
+		wn += k; out += k;
+		if (k < n) {                                                        // the 8 are full: out they go, the rest begins anew
+			put<uint64_t>(out - 8, wb);
+			wb = k ? v >> (8 * k) : v;
+			wn = n - k; out += n - k;
 		}
 	}
-	// a short match (len <= 8) whose source lies clear of the pending bytes (dist >= len + 4): fetch
-	// the source bytes with aligned dword loads and append them -- no flush, no byte stores
+	// a short match (len <= 8) whose source lies clear of the pending bytes (dist >= 16): one 8-byte load, appended -- no
+	// flush, no store of its own
 	NXZ_LANE_FN void copy_short(uint32_t len, uint32_t dist)
 	{
-		const uintptr_t sa = (uintptr_t)(dst + out - dist);
-		const uint32_t *sw = (const uint32_t *)(sa & ~(uintptr_t)3);
-		const uint32_t bo = (uint32_t)sa & 3;
-		const uint32_t w0 = sw[0], w1 = bo + len > 4 ? sw[1] : 0, w2 = bo + len > 8 ? sw[2] : 0;
-		const uint32_t lo = NXZ_LANE_ALIGNBYTE(w1, w0, bo), hi = NXZ_LANE_ALIGNBYTE(w2, w1, bo);
-		append(((uint64_t)hi << 32) | lo, len);
+		uint64_t v;
+		__builtin_memcpy(&v, (const NXZ_LANE_GLOBAL uint8_t *)dst + out - dist, 8);
+		append(v, len);
 	}
 	// append n bytes of another buffer (stored blocks), pending bytes flushed by the caller: dword
 	// stores once the destination is aligned, the source dwords from aligned loads, eight in flight
@@ -170,11 +180,37 @@ struct OutWr {
 		}
 		copy1(len, dist);
 	}
+	// n bytes (16, 8, 4, 2 or 1) from s to d, any alignment: one load and one store
+	template <typename V> static NXZ_LANE_FN void move(uint8_t *d, const uint8_t *s)
+	{
+		V v;
+		__builtin_memcpy(&v, (const NXZ_LANE_GLOBAL uint8_t *)s, sizeof(V));
+		__builtin_memcpy((NXZ_LANE_GLOBAL uint8_t *)d, &v, sizeof(V));
+	}
+	struct V16 { uint64_t a, b; };
 	NXZ_LANE_FN void copy1(uint32_t len, uint32_t dist)
 	{
 		uint8_t *d = dst + out;
 		const uint8_t *s = d - dist;
 		uint32_t i = 0;
+		if (dist >= 16) {
+			// 16 bytes a load and a store, whatever the alignment: the lanes of a wavefront copy side by side, the longest
+			// match of the 64 sets the number of trips, and every trip is a load and a store instruction of the whole wavefront
+			// -- which is what bounds this kernel (nxz_inflate_lanes.hip) -- so the trips are made as few as can be
+			for (; i + 16 <= len; i += 16) move<V16>(d + i, s + i);
+			if (i < len) {
+				if (len >= 16) move<V16>(d + len - 16, s + len - 16);      // the last 16 bytes, some of them a second time
+				else {
+					const uint32_t r = len - i;
+					if (r & 8) { move<uint64_t>(d + i, s + i); i += 8; }
+					if (r & 4) { move<uint32_t>(d + i, s + i); i += 4; }
+					if (r & 2) { move<uint16_t>(d + i, s + i); i += 2; }
+					if (r & 1) d[i] = s[i];
+				}
+			}
+			out += len;
+			return;
+		}
 		if (al && len >= 8 && dist != 3) {
 			for (; (out + i) & 3; i++) d[i] = s[i];                             // align the destination (< 4 bytes)
 			if (dist >= 4) {

@@ -54,7 +54,7 @@ int main()
 				uint32_t dist = 1 + rand() % (w.out < 40 ? w.out : 40);
 				if (rand() % 4 == 0) dist = 1 + rand() % w.out;
 				uint32_t len = 3 + rand() % ((rand() & 1) ? 8 : 256); if (len > cap - w.out) break;
-				if (w.al && len <= 8 && dist >= len + 4) w.copy_short(len, dist);      // as the kernel chooses
+				if (len <= 8 && dist >= 16) w.copy_short(len, dist);                 // as the kernel chooses
 				else { w.flush(); w.copy(len, dist); }
 				for (uint32_t i = 0; i < len; i++) ref[rout + i] = ref[rout + i - dist];
 				rout += len;
@@ -62,6 +62,7 @@ int main()
 				if (w.out >= cap) break;
 				uint8_t c = (uint8_t)rand(); w.lit(c); ref[rout++] = c;
 			}
+			if (rand() % 3 == 0) w.commit();
 		}
 		w.flush();
 		if (w.out != rout || memcmp(m1.data() + off, ref, rout)) { printf("output mismatch, case %d\n", it); return 1; }
