@@ -917,7 +917,10 @@ extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, n
 	if (fixed_first && (init_fixed & 4)) {
 		bail = (uint32_t *)(workspace + lanes_bail_offset(n));
 		(void)hipMemsetAsync(bail, 0, sizeof(uint32_t), stream);
-		hipLaunchKernelGGL(nxzl::inflate_lanes_fixed_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, order, pw, bail);
+		// (no table slots to hold: its grid is bounded by the wavefronts the CUs hold; NXZ_LANES_FIXED_GRID overrides, for measurements)
+		static const unsigned fgmax = [] { const char *e = getenv("NXZ_LANES_FIXED_GRID"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 1024u * NXZ_LANES_FIXED_WPE; }();
+		const unsigned fgrid = (unsigned)(groups < fgmax ? groups : fgmax);
+		hipLaunchKernelGGL(nxzl::inflate_lanes_fixed_kernel, dim3(fgrid), dim3(64), 0, stream, jobs, n, results, order, pw, bail);
 	}
 	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace, order, pw, bail);
 	hipLaunchKernelGGL(nxzl::cksum_kernel<false>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
