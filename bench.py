@@ -976,7 +976,7 @@ def c2_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, n, st
         inflate_info = {"value": round(ub / (inf_ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out",
                         "ms_per_pass": round(inf_ms, 3), "kernel": "batched inflate (stream per lane / per wave by batch size) + cksum_kernel",
                         "what": "the fixed-Huffman output of the timed region", "scope": "one GPU (rank 0)", "roundtrip_bit_exact": True,
-                        "roofline": roof((ub + cb) / (inf_ms * 1e-3) / 1e9, pmc_traffic(n, "inflate_own"), "nxzl::inflate_lanes_kernel + cksum_kernel", peak_m)}
+                        "roofline": roof((ub + cb) / (inf_ms * 1e-3) / 1e9, pmc_traffic(n, "inflate_own"), "nxzl::inflate_lanes_fixed_kernel + cksum_kernel", peak_m)}
         del back
     u_bytes = float(n) * BLOCK
     c_bytes = float(res["tpbc"].astype(np.float64).sum())

@@ -147,7 +147,10 @@ static constexpr unsigned JOB_COUNTERS = 256;
 // bring a table each (zlib's, the engine's own exact-table output) run twice as fast a stream per wave at every batch
 // size (81 against 40).  So a batch of NXZ_LANES_MIN streams or more is sampled first: 256 of its streams, the type
 // of their first block.
-#define NXZ_LANES_MIN 81920   /* (fixed-code streams: 42 against 38 GiB/s at 65 536, 43 against 63 at 131 072) */
+// Round 4 (profiles/r04c_inflate_by_batch_size.txt): with its memory instructions issued where all lanes pass together
+// the lane kernel does fixed-code streams at 36 GiB/s at 16 384 streams, 62 at 32 768, 105 at 65 536, 154 at 131 072
+// (a stream per wave: 38, 42, 43, 44); streams with tables of their own are still the wave kernel's at every size.
+#define NXZ_LANES_MIN 20480
 #define NXZ_WINDOW_LDS_MAX 1024
 
 static std::mutex g_mtx;

@@ -845,7 +845,7 @@ static unsigned lanes_max_grid(void)
 static unsigned lanes_per_wave(size_t n)
 {
 	static const int env = getenv("NXZ_LANES_PER_WAVE") ? atoi(getenv("NXZ_LANES_PER_WAVE")) : 0;   // measurements: 32 or 64
-	if (env == 32 || env == 64) return (unsigned)env;
+	if (env == 8 || env == 16 || env == 32 || env == 64) return (unsigned)env;
 	return n <= 64 * (size_t)(NXZ_LANES_MAX_GRID / 2) ? 32u : 64u;     /* (own fixed-code streams: 54 against 50 GiB/s at 98304, 67 against 62 at 131072; 58 against 82 at 196608) */
 }
 static size_t lanes_tables_bytes(size_t n)

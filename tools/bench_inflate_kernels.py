@@ -35,6 +35,7 @@ for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "o
         row = []
         for kernel in ("waves", "lanes"):
             os.environ["NXZ_INFLATE_LANES_MIN"] = "1" if kernel == "lanes" else "1000000000"
+            os.environ["NXZ_LANES_FIXED"] = "2" if kind.startswith("own fixed") else "0"   # (the fixed-code-only kernel in front, as the engine's sampling would choose)
             os.environ["NXZ_INFLATE_LDS_MAX"] = "0"
             eng = pkg.Engine(0)
             if kind.startswith("zlib"):
