@@ -726,6 +726,53 @@ def test_fixed_and_stored_only_streams_whole_and_cut(eng, inflate_kernel):
         assert r["crc"][i] == zlib.crc32(exp) and r["adler"][i] == zlib.adler32(exp), i
 
 
+def test_a_dynamic_block_behind_the_sample_sends_the_batch_back_to_the_general_kernel(eng):
+    """the engine's own routing, no knob set: 20 480 fixed-code streams are sampled (256 of them, every 80th), found free of
+    dynamic blocks and given to the fixed-code-only lane kernel; three streams the sample does not see hold a dynamic block
+    (one at its head, two behind a fixed-code block), so that kernel raises its flag and the general one does the batch
+    again -- every stream's output, length and checksums are right"""
+    import random
+    import torch
+    rnd = random.Random(5)
+    n, size = 20480, 1024
+    kinds = ["text33", "alice", "lz", "binary"]
+    payloads = [make_block(kinds[i % 4], size, seed=2000 + i % 97) for i in range(97)]
+    fixed = []
+    for d in payloads:
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+        fixed.append(co.compress(d) + co.flush())
+    streams = [(payloads[i % 97], fixed[i % 97]) for i in range(n)]
+    odd = make_block("alice", 3000, seed=77)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    streams[7] = (odd, co.compress(odd) + co.flush())                                   # dynamic from the first byte
+    for at in (12345, 20479):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+        head = co.compress(odd[:500]) + co.flush(zlib.Z_FULL_FLUSH)                     # a fixed-code block, then a dynamic one
+        tail = zlib.compressobj(6, zlib.DEFLATED, -15)
+        streams[at] = (odd[:500] + odd, head + tail.compress(odd) + tail.flush())
+    assert all(i % 80 for i in (7, 12345, 20479))                                       # (the sample takes every 80th stream)
+    cstride = (max(len(c) for _, c in streams) + 31) & ~15
+    ostride = 3520
+    src = pack_blocks(eng, [c for _, c in streams], cstride)
+    dst = torch.zeros((n, ostride), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, cstride, np.array([len(c) for _, c in streams], np.uint32), dst, ostride, ostride)
+    saved = {k: os.environ.pop(k, None) for k in ("NXZ_INFLATE_LANES_MIN", "NXZ_LANES_FIXED")}
+    try:
+        r = eng.results_to_host(eng.decompress(jobs, n))
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+    out = dst.cpu().numpy()
+    assert (r["cc"] == 0).all(), np.unique(r["cc"])
+    for i in list(range(0, n, 509)) + [7, 8, 12344, 12345, 20478, 20479]:
+        d = streams[i][0]
+        assert r["tpbc"][i] == len(d) and out[i, :len(d)].tobytes() == d, i
+        assert r["crc"][i] == zlib.crc32(d) and r["adler"][i] == zlib.adler32(d), i
+    want = np.array([len(d) for d, _ in streams], np.uint32)
+    assert (r["tpbc"] == want).all()
+
+
 def test_all_35_canned_tables_encode_bit_exact(eng):
     """a11: every canned table of the reference (lib/nx_dht_builtin.c:104-840; all of them code every
     symbol) through COMPRESS_DHT on a block each of four kinds: bytes == the oracle's with the same table"""
