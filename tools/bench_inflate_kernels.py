@@ -33,7 +33,7 @@ print("%-34s %8s | %12s %12s" % ("streams", "n", "per wave", "per lane"))
 for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "own exact tables (corpus)"):
     for n in sizes:
         row = []
-        for kernel in ("waves", "lanes"):
+        for kernel in (("waves",) if os.environ.get("LANES") == "0" else ("waves", "lanes")):     # LANES=0: the wave kernel only
             os.environ["NXZ_INFLATE_LANES_MIN"] = "1" if kernel == "lanes" else "1000000000"
             os.environ["NXZ_LANES_FIXED"] = "2" if kind.startswith("own fixed") else "0"   # (the fixed-code-only kernel in front, as the engine's sampling would choose)
             os.environ["NXZ_INFLATE_LDS_MAX"] = "0"
@@ -70,4 +70,4 @@ for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "o
             eng.close()
             del jobs, dst
             torch.cuda.empty_cache()
-        print("%-34s %8d | %12.1f %12.1f" % (kind, n, row[0], row[1]), flush=True)
+        print("%-34s %8d | %12.1f %12.1f" % (kind, n, row[0], row[-1] if len(row) > 1 else float("nan")), flush=True)
