@@ -1,6 +1,6 @@
 """Soak run (not collected by pytest): seeded random zlib streams (all levels and strategies, flushed
-pieces, sizes 0..300 KB, with history and cut-off tails) through the three inflate kernels of the HIP
-engine, every result compared with the oracle (output, stop state, checksums).
+pieces, sizes 0..300 KB, with history and cut-off tails) through the inflate kernels of the HIP
+engine (a stream per lane with and without the fixed-code-only kernel in front, a stream per wave with the window in LDS and in the target), every result compared with the oracle (output, stop state, checksums).
 python tests/soak_inflate_gpu.py [seeds]"""
 import importlib, os, random, sys, zlib
 import numpy as np
@@ -42,7 +42,9 @@ for seed in range(1, nseeds + 1):
     for i, (c, _) in enumerate(cases): host[i, :len(c)] = np.frombuffer(c, np.uint8)
     src = torch.from_numpy(host).to(eng.dev)
     exp = [O.inflate(c, cap) for c, cap in cases]
-    for kernel, env in (("lanes", {"NXZ_INFLATE_LANES_MIN": "1"}), ("waves, window in LDS", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_LDS_MAX": "1000000000"}),
+    for kernel, env in (("lanes", {"NXZ_INFLATE_LANES_MIN": "1", "NXZ_LANES_FIXED": "0"}),
+                        ("lanes, the fixed-code-only kernel first", {"NXZ_INFLATE_LANES_MIN": "1", "NXZ_LANES_FIXED": "2"}),
+                        ("waves, window in LDS", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_LDS_MAX": "1000000000"}),
                         ("waves, target as window", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_LDS_MAX": "0"})):
         os.environ.update(env)
         dst = torch.full((len(cases), ostride), 0xAA, dtype=torch.uint8, device=eng.dev)

@@ -31,7 +31,7 @@ def test_deflate_is_stable_pass_after_pass_and_round_trips():
 
 
 def test_inflate_kernels_against_the_oracle():
-    """random zlib streams (levels, strategies, flushes, histories, cut-off tails) through the three batched inflate kernels"""
+    """random zlib streams (levels, strategies, flushes, histories, cut-off tails) through the batched inflate kernels (a stream per lane with and without the fixed-code-only kernel, a stream per wave twice)"""
     assert "SOAK OK" in _run("soak_inflate_gpu.py", 1)
 
 
