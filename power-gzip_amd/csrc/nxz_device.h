@@ -44,7 +44,10 @@ int nxz_launch_dht_prepare(const nxz_batch_dht_t *dht, size_t n, nxz_dht_prepare
 int nxz_launch_wrap(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);          /* round 1's kernel (kept for comparison: NXZ_WRAP_OLD=1) */
 int nxz_launch_wrap_sliced(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);   /* nxz_inflate_lanes.hip: the checksum kernel's pass, storing as it goes */
 int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
-		       nxz_batch_dht_t *dht_io, int window_in_lds, hipStream_t stream);
+		       nxz_batch_dht_t *dht_io, int window_in_lds, const uint32_t *order, hipStream_t stream);   /* order: NULL, or nxz_launch_order_by_length's */
+/* the jobs' indices by falling source length, in `workspace` (nxz_order_workspace(n) bytes); NULL when it cannot be made */
+size_t nxz_order_workspace(size_t n);
+const uint32_t *nxz_launch_order_by_length(const nxz_batch_job_t *jobs, size_t n, uint8_t *workspace, hipStream_t stream);
 /* token boundaries inside dynamic blocks (nxz_inflate.hip token_sync_kernel; offsets in bits from src) */
 typedef struct nxz_sync_req {
 	const uint8_t *src;      /* at or in front of the block's header, 4-byte aligned if the stream is */

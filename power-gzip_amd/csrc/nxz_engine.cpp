@@ -77,6 +77,8 @@ struct nxz_ctx {
 		size_t prepared_cap = 0;
 		uint8_t *d_lanes_ws = nullptr;            // per-lane decode tables of the batched inflate kernel
 		size_t lanes_cap = 0;
+		uint8_t *d_order_ws = nullptr;            // the jobs' order by length for the stream-per-wave kernel's larger batches
+		size_t order_cap = 0;
 		// compress: what the LZ77 kernel hands to the entropy kernel, for one chunk of jobs
 		uint8_t *d_tokens = nullptr;              // chunk x NXZ_TOK_STRIDE
 		nxz_dht_prepared_t *d_gen = nullptr;      // tables the device generated, one per job of the chunk
@@ -86,6 +88,7 @@ struct nxz_ctx {
 		void release() {
 			if (d_prepared) (void)hipFree(d_prepared);
 			if (d_lanes_ws) (void)hipFree(d_lanes_ws);
+			if (d_order_ws) (void)hipFree(d_order_ws);
 			if (d_tokens) (void)hipFree(d_tokens);
 			if (d_gen) (void)hipFree(d_gen);
 			if (d_counts) (void)hipFree(d_counts);
@@ -523,7 +526,36 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 	} else {
 		const char *wm = getenv("NXZ_INFLATE_LDS_MAX");                 // tuning / test knob
 		const size_t lds_max = wm ? (size_t)strtoull(wm, nullptr, 0) : (size_t)NXZ_WINDOW_LDS_MAX;
-		rc = nxz_launch_inflate(jobs, n, results, dht_io, n <= lds_max, s);
+		// A launch ends with its slowest stream, and the corpus' slowest block takes a wavefront 8 ms where the average takes 4:
+		// the long ones start first -- the jobs' indices by falling source length (zlib -6 streams of the corpus: 53.9 -> 77.1
+		// GiB/s at 16 384 streams, 67.4 -> 85.0 at 32 768, 83.1 -> 86.5 at 262 144, 26.1 -> 28.5 at 4096 where all are resident
+		// at once; profiles/r04c_inflate_by_batch_size.txt).  Not for the few streams that get the window in LDS.
+		// (NXZ_INFLATE_ORDER=0 / 1: never / always)
+		const uint32_t *order = nullptr;
+		const char *oe = getenv("NXZ_INFLATE_ORDER");
+		const int order_env = oe ? atoi(oe) : -1;
+		if (order_env < 0 ? n > lds_max : order_env != 0) {
+			std::mutex *use_mtx;
+			{
+				std::lock_guard<std::mutex> g(c->mtx);
+				use_mtx = &c->scratch_use[s];
+			}
+			std::lock_guard<std::mutex> use(*use_mtx);                     // (one call at a time per stream's scratch: the kernel reads the order)
+			uint8_t *ows = nullptr;
+			{
+				std::lock_guard<std::mutex> g(c->mtx);
+				nxz_ctx::Scratch &sc = c->scratch[s];
+				const size_t need = nxz_order_workspace(n);
+				if (sc.order_cap < need) {
+					if (sc.d_order_ws) { (void)hipStreamSynchronize(s); (void)hipFree(sc.d_order_ws); }
+					sc.d_order_ws = nullptr; sc.order_cap = 0;
+					if (hipMalloc((void **)&sc.d_order_ws, need) == hipSuccess) sc.order_cap = need;
+				}
+				ows = sc.d_order_ws;
+			}
+			order = nxz_launch_order_by_length(jobs, n, ows, s);              // (NULL: in the caller's order)
+			rc = nxz_launch_inflate(jobs, n, results, dht_io, n <= lds_max, order, s);
+		} else rc = nxz_launch_inflate(jobs, n, results, dht_io, n <= lds_max, nullptr, s);
 	}
 	if (rc) { set_err("inflate launch", (hipError_t)rc); return -EIO; }
 	return 0;
@@ -1196,7 +1228,7 @@ static int round_run_inflate(nxz_ctx *c, nxz_ctx::Round &R, std::vector<InflateR
 		R.h_dht[k] = *v[k]->dht;
 	}
 	if (nxz_launch_copy_items(R.h_items, (uint32_t)n, R.stream)) return -EIO;
-	if (nxz_launch_inflate(R.h_jobs, n, R.h_res, R.h_dht, 1, R.stream)) return -EIO;
+	if (nxz_launch_inflate(R.h_jobs, n, R.h_res, R.h_dht, 1, nullptr, R.stream)) return -EIO;
 	HIPCHK(hipStreamSynchronize(R.stream), return -EIO);
 	for (size_t k = 0; k < n; k++) {
 		v[k]->res = R.h_res[k];

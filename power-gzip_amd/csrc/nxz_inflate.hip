@@ -393,12 +393,15 @@ __device__ __forceinline__ int read_dht(Bits &b, Smem &sm, int &hlit, int &hdist
 template <bool GW, bool W16>
 __device__ __forceinline__ void inflate_body(const nxz_batch_job_t *__restrict__ jobs,
 					     nxz_batch_result_t *__restrict__ results,
-					     nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
+					     nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built, const uint32_t *__restrict__ order)
 {
 	__shared__ __attribute__((aligned(16))) SmemT<GW, W16> sm;
 	typedef typename SmemT<GW, W16>::elem_t elem_t;
 	const int lane = threadIdx.x;
-	const nxz_batch_job_t job = jobs[blockIdx.x];
+	// order (may be NULL): the jobs by falling source length -- a launch of a few rounds of wavefronts ends with its slowest
+	// stream, which had better be among the first to start (nxz_launch_inflate)
+	const uint32_t jid = order ? order[blockIdx.x] : blockIdx.x;
+	const nxz_batch_job_t job = jobs[jid];
 	// (pieces of a stream come longest first, and the launch ends with its slowest piece: the sixteenth of them in front
 	// gets the instruction issue of its SIMD before the others, the next quarter before the rest)
 	if (W16) {
@@ -579,7 +582,7 @@ __device__ __forceinline__ void inflate_body(const nxz_batch_job_t *__restrict__
 			state = 2; btype = 2;
 			// re-parse the table handed back by the caller -- or, a piece of a stream that begins at a cut inside a block
 			// whose tables were built for the whole block (in_crc, which such pieces have no use for: which): load them
-			const nxz_batch_dht_t *t = &dht_io[blockIdx.x];
+			const nxz_batch_dht_t *t = &dht_io[jid];
 			if (W16 && built && job.in_crc) {
 				load_built(sm, &built[job.in_crc - 1], lane);
 				have_dht = true; dhtbits = t->dhtlen;
@@ -650,7 +653,7 @@ tables_ready:
 				build<DBITS>(sm.hd, sm.lens + hlit, hdist, lane);
 				// keep the table bits for a possible suspend inside this block
 				if (dht_io) {
-					nxz_batch_dht_t *t = &dht_io[blockIdx.x];
+					nxz_batch_dht_t *t = &dht_io[jid];
 					uint64_t save = b.pos;
 					b.ensure((uint32_t)(tstart >> 3), 320);
 					for (uint32_t i = lane; i < (tbits + 31) / 32; i += 64) {
@@ -975,7 +978,7 @@ done:
 		r.tebc = o_rem; r.spbc = spbc;
 		r.crc = W16 ? (uint32_t)(wall_clock64() - t_begin) : crc_state ^ 0xffffffffu; r.adler = W16 ? nheaders : (ad2 << 16) | ad1;
 		r.subc = subc; r.sfbt = o_sfbt | (final_eob ? 0x100u : 0) | (((o_sfbt & 0xe) == 0xc && have_dht) ? (dhtbits << 16) : 0);
-		results[blockIdx.x] = r;
+		results[jid] = r;
 	}
 }
 
@@ -986,30 +989,30 @@ done:
 // one or two streams fit a CU anyway.
 template <bool GW, bool W16 = false>
 __global__ void inflate_kernel(const nxz_batch_job_t *__restrict__ jobs, nxz_batch_result_t *__restrict__ results,
-			       nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built);
+			       nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built, const uint32_t *__restrict__ order);
 template <>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void inflate_kernel<true, false>(const nxz_batch_job_t *__restrict__ jobs,
-		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
+		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built, const uint32_t *__restrict__ order)
 {
-	inflate_body<true, false>(jobs, results, dht_io, built);
+	inflate_body<true, false>(jobs, results, dht_io, built, order);
 }
 template <>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void inflate_kernel<true, true>(const nxz_batch_job_t *__restrict__ jobs,
-		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
+		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built, const uint32_t *__restrict__ order)
 {
-	inflate_body<true, true>(jobs, results, dht_io, built);
+	inflate_body<true, true>(jobs, results, dht_io, built, order);
 }
 template <>
 __global__ __launch_bounds__(64) void inflate_kernel<false, false>(const nxz_batch_job_t *__restrict__ jobs,
-		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
+		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built, const uint32_t *__restrict__ order)
 {
-	inflate_body<false, false>(jobs, results, dht_io, built);
+	inflate_body<false, false>(jobs, results, dht_io, built, order);
 }
 template <>
 __global__ __launch_bounds__(64) void inflate_kernel<false, true>(const nxz_batch_job_t *__restrict__ jobs,
-		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built)
+		nxz_batch_result_t *__restrict__ results, nxz_batch_dht_t *__restrict__ dht_io, const Built *__restrict__ built, const uint32_t *__restrict__ order)
 {
-	inflate_body<false, true>(jobs, results, dht_io, built);
+	inflate_body<false, true>(jobs, results, dht_io, built, order);
 }
 
 // ---- token boundaries inside a dynamic block (nxz_inflate_stream, few pieces) ----
@@ -1205,11 +1208,11 @@ extern "C" int nxz_inflate_prof_set(unsigned long long *buf)
 // for one job or one round of jobs); 0: the window is the target itself (16 streams per CU).  Checksums
 // by nxzl::cksum_kernel afterwards.
 extern "C" int nxz_launch_inflate(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
-				  nxz_batch_dht_t *dht_io, int window_in_lds, hipStream_t stream)
+				  nxz_batch_dht_t *dht_io, int window_in_lds, const uint32_t *order, hipStream_t stream)
 {
 	if (!n) return 0;
-	if (window_in_lds) hipLaunchKernelGGL(nxzi::inflate_kernel<false>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)nullptr);
-	else hipLaunchKernelGGL(nxzi::inflate_kernel<true>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)nullptr);
+	if (window_in_lds) hipLaunchKernelGGL(nxzi::inflate_kernel<false>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)nullptr, order);
+	else hipLaunchKernelGGL(nxzi::inflate_kernel<true>, dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)nullptr, order);
 	int rc = (int)hipGetLastError();
 	return rc ? rc : nxz_launch_cksum(jobs, n, results, stream);
 }
@@ -1223,7 +1226,7 @@ extern "C" int nxz_launch_inflate_w16(const nxz_batch_job_t *jobs, size_t n, nxz
 	// wavefront a fraction of the trip to device memory.  (Not for the odd pieces that are decoded again: long
 	// stored stretches are among them, which the other form copies four bytes per lane.)
 	static const unsigned lds_max = getenv("NXZ_INFLATE_W16_LDS_MAX") ? (unsigned)atoi(getenv("NXZ_INFLATE_W16_LDS_MAX")) : 512;
-	if (few_and_even && n <= lds_max) hipLaunchKernelGGL((nxzi::inflate_kernel<false, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)built);
-	else hipLaunchKernelGGL((nxzi::inflate_kernel<true, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)built);
+	if (few_and_even && n <= lds_max) hipLaunchKernelGGL((nxzi::inflate_kernel<false, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)built, (const uint32_t *)nullptr);
+	else hipLaunchKernelGGL((nxzi::inflate_kernel<true, true>), dim3((unsigned)n), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)built, (const uint32_t *)nullptr);
 	return (int)hipGetLastError();
 }

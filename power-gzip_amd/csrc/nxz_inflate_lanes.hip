@@ -910,6 +910,23 @@ __global__ void order_keys_kernel(const nxz_batch_job_t *__restrict__ jobs, uint
 }
 }
 
+// the jobs by falling source length, for a launch that ends with its slowest stream (this file's lane kernels, and the
+// stream-per-wave kernel's batches of a few rounds of wavefronts): keys, indices, the sort's own room in `workspace`
+extern "C" size_t nxz_order_workspace(size_t n)
+{
+	return 4 * ((n * sizeof(uint32_t) + 255) & ~(size_t)255) + lanes_sort_temp_bytes(n);
+}
+extern "C" const uint32_t *nxz_launch_order_by_length(const nxz_batch_job_t *jobs, size_t n, uint8_t *workspace, hipStream_t stream)
+{
+	if (n < 128 || n >= (1u << 31) || !workspace) return nullptr;
+	const size_t arr = (n * sizeof(uint32_t) + 255) & ~(size_t)255;
+	uint32_t *k_in = (uint32_t *)workspace, *k_out = (uint32_t *)(workspace + arr), *v_in = (uint32_t *)(workspace + 2 * arr), *v_out = (uint32_t *)(workspace + 3 * arr);
+	size_t tb = lanes_sort_temp_bytes(n);
+	hipLaunchKernelGGL(nxzl::order_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, jobs, (uint32_t)n, k_in, v_in);
+	if (hipcub::DeviceRadixSort::SortPairsDescending(workspace + 4 * arr, tb, k_in, k_out, v_in, v_out, (int)n, 0, 21, stream) != hipSuccess) return nullptr;
+	return v_out;
+}
+
 extern "C" int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream)
 {
 	if (!n) return 0;
@@ -928,15 +945,7 @@ extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, n
 	// the jobs by falling source length when the caller says they differ much (init_fixed bit 1; NXZ_LANES_ORDER=0 / 1: never / always)
 	static const int order_env = getenv("NXZ_LANES_ORDER") ? atoi(getenv("NXZ_LANES_ORDER")) : -1;
 	const bool ordered = order_env < 0 ? (init_fixed & 2) != 0 : order_env != 0;
-	uint32_t *order = nullptr;
-	if (ordered && n >= 128 && n < (1u << 31)) {
-		const size_t arr = (n * sizeof(uint32_t) + 255) & ~(size_t)255;
-		uint8_t *base = workspace + lanes_tables_bytes(n);
-		uint32_t *k_in = (uint32_t *)base, *k_out = (uint32_t *)(base + arr), *v_in = (uint32_t *)(base + 2 * arr), *v_out = (uint32_t *)(base + 3 * arr);
-		size_t tb = lanes_sort_temp_bytes(n);
-		hipLaunchKernelGGL(nxzl::order_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, jobs, (uint32_t)n, k_in, v_in);
-		if (hipcub::DeviceRadixSort::SortPairsDescending(base + 4 * arr, tb, k_in, k_out, v_in, v_out, (int)n, 0, 21, stream) == hipSuccess) order = v_out;
-	}
+	const uint32_t *order = ordered ? nxz_launch_order_by_length(jobs, n, workspace + lanes_tables_bytes(n), stream) : nullptr;
 	// init_fixed bit 2: the sampled streams all begin with fixed-code or stored blocks: the kernel that does only those first, and
 	// this one behind it for the batch that turns out to hold a dynamic block somewhere (NXZ_LANES_FIXED=0: never)
 	// (NXZ_LANES_FIXED=2: always first, whatever the sample said -- the tests' way to put every stream through it)
