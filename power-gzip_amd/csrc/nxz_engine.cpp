@@ -153,7 +153,11 @@ static constexpr unsigned JOB_COUNTERS = 256;
 // Round 4 (profiles/r04c_inflate_by_batch_size.txt): with its memory instructions issued where all lanes pass together
 // the lane kernel does fixed-code streams at 36 GiB/s at 16 384 streams, 62 at 32 768, 105 at 65 536, 154 at 131 072
 // (a stream per wave: 38, 42, 43, 44); streams with tables of their own are still the wave kernel's at every size.
-#define NXZ_LANES_MIN 20480
+// ... on the bench's synthetic blocks (ratio 1.75, a token every 2.3 bytes).  The corpus' blocks as fixed-code streams (ratio
+// 2.9) go through the wave kernel at 73 GiB/s from 32 768 streams on and through the lane kernel at 51 / 88 / 164 at 32 768 /
+// 65 536 / 262 144: the switch-over lies between the two kinds' break-evens.
+#define NXZ_LANES_MIN 49152
+#define NXZ_LANES_TABLES_MIN 229376   /* streams that bring tables: the lane kernel from here on */
 #define NXZ_WINDOW_LDS_MAX 1024
 
 static std::mutex g_mtx;
@@ -489,7 +493,10 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 		if (h) {
 			h[0] = 0; h[1] = 0; h[2] = 0;
 			if (nxz_launch_sample_btype(jobs, n, h, s) == 0 && hipStreamSynchronize(s) == hipSuccess) {
-				if (h[0] > 64) lanes = false;                          // a quarter or more with tables
+				// a quarter or more with tables: the wave kernel's, unless the batch is so large that the general lane kernel
+				// overtakes it (zlib -6 streams of the corpus, jobs by length: 96 against 87 GiB/s at 262 144 streams, 66 against 86
+				// at 131 072; profiles/r04c_inflate_by_batch_size.txt)
+				if (h[0] > 64 && n < NXZ_LANES_TABLES_MIN) lanes = false;
 				// streams of very different lengths (zeros beside text: BASELINE configs[4]): a wavefront takes as long as its
 				// longest stream, so the lane kernel gets them ordered by length; much of a size they stay as they come
 				// (neighbours in memory: ordering the bench's synthetic blocks cost 5 %)

@@ -942,9 +942,13 @@ extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, n
 	size_t groups = (n + pw - 1) / pw;
 	unsigned grid = (unsigned)(groups < lanes_max_grid() ? groups : lanes_max_grid());
 	if (init_fixed & 1) hipLaunchKernelGGL(nxzl::fixed_tables_kernel, dim3(1), dim3(64), 0, stream, workspace);
-	// the jobs by falling source length when the caller says they differ much (init_fixed bit 1; NXZ_LANES_ORDER=0 / 1: never / always)
+	// the jobs by falling source length, always (NXZ_LANES_ORDER=0: never).  Earlier in round 4 only when the sampled lengths
+	// differed eightfold (init_fixed bit 1, no longer looked at): ordering the bench's synthetic blocks, all of a size, cost
+	// 5 % -- neighbours in memory no longer neighbours in a wavefront.  With the kernels' memory instructions where all lanes
+	// pass together it pays everywhere: synthetic blocks 104.6 -> 112.7 GiB/s at 65 536 streams, 183.9 -> 187.7 at 2^18, the
+	// corpus' fixed-code streams 68.8 -> 88.2 and 145.7 -> 163.7 (a wavefront takes as long as its longest stream).
 	static const int order_env = getenv("NXZ_LANES_ORDER") ? atoi(getenv("NXZ_LANES_ORDER")) : -1;
-	const bool ordered = order_env < 0 ? (init_fixed & 2) != 0 : order_env != 0;
+	const bool ordered = order_env != 0;
 	const uint32_t *order = ordered ? nxz_launch_order_by_length(jobs, n, workspace + lanes_tables_bytes(n), stream) : nullptr;
 	// init_fixed bit 2: the sampled streams all begin with fixed-code or stored blocks: the kernel that does only those first, and
 	// this one behind it for the batch that turns out to hold a dynamic block somewhere (NXZ_LANES_FIXED=0: never)

@@ -731,14 +731,14 @@ def test_fixed_and_stored_only_streams_whole_and_cut(eng, inflate_kernel):
 
 
 def test_a_dynamic_block_behind_the_sample_sends_the_batch_back_to_the_general_kernel(eng):
-    """the engine's own routing, no knob set: 20 480 fixed-code streams are sampled (256 of them, every 80th), found free of
+    """the engine's own routing, no knob set: 49 152 fixed-code streams are sampled (256 of them, every 192nd), found free of
     dynamic blocks and given to the fixed-code-only lane kernel; three streams the sample does not see hold a dynamic block
     (one at its head, two behind a fixed-code block), so that kernel raises its flag and the general one does the batch
     again -- every stream's output, length and checksums are right"""
     import random
     import torch
     rnd = random.Random(5)
-    n, size = 20480, 1024
+    n, size = 49152, 1024
     kinds = ["text33", "alice", "lz", "binary"]
     payloads = [make_block(kinds[i % 4], size, seed=2000 + i % 97) for i in range(97)]
     fixed = []
@@ -749,12 +749,12 @@ def test_a_dynamic_block_behind_the_sample_sends_the_batch_back_to_the_general_k
     odd = make_block("alice", 3000, seed=77)
     co = zlib.compressobj(6, zlib.DEFLATED, -15)
     streams[7] = (odd, co.compress(odd) + co.flush())                                   # dynamic from the first byte
-    for at in (12345, 20479):
+    for at in (12345, 49151):
         co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
         head = co.compress(odd[:500]) + co.flush(zlib.Z_FULL_FLUSH)                     # a fixed-code block, then a dynamic one
         tail = zlib.compressobj(6, zlib.DEFLATED, -15)
         streams[at] = (odd[:500] + odd, head + tail.compress(odd) + tail.flush())
-    assert all(i % 80 for i in (7, 12345, 20479))                                       # (the sample takes every 80th stream)
+    assert all(i % 192 for i in (7, 12345, 49151))                                      # (the sample takes every 192nd stream)
     cstride = (max(len(c) for _, c in streams) + 31) & ~15
     ostride = 3520
     src = pack_blocks(eng, [c for _, c in streams], cstride)
@@ -769,7 +769,7 @@ def test_a_dynamic_block_behind_the_sample_sends_the_batch_back_to_the_general_k
                 os.environ[k] = v
     out = dst.cpu().numpy()
     assert (r["cc"] == 0).all(), np.unique(r["cc"])
-    for i in list(range(0, n, 509)) + [7, 8, 12344, 12345, 20478, 20479]:
+    for i in list(range(0, n, 509)) + [7, 8, 12344, 12345, 49150, 49151]:
         d = streams[i][0]
         assert r["tpbc"][i] == len(d) and out[i, :len(d)].tobytes() == d, i
         assert r["crc"][i] == zlib.crc32(d) and r["adler"][i] == zlib.adler32(d), i

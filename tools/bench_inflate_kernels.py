@@ -30,7 +30,7 @@ def timed(eng, jobs, n):
 
 
 print("%-34s %8s | %12s %12s" % ("streams", "n", "per wave", "per lane"))
-for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "own exact tables (corpus)"):
+for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "own fixed-Huffman (corpus)", "own exact tables (corpus)"):
     for n in sizes:
         row = []
         for kernel in (("waves",) if os.environ.get("LANES") == "0" else ("waves", "lanes")):     # LANES=0: the wave kernel only
@@ -59,7 +59,7 @@ for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "o
                 else:
                     host = np.stack([np.frombuffer(raw[i % len(raw)], np.uint8) for i in range(n)])
                     data = torch.from_numpy(host).to(eng.dev)
-                    fc = pkg.FC_COMPRESS_DHTGEN
+                    fc = pkg.FC_COMPRESS_FHT if "fixed" in kind else pkg.FC_COMPRESS_DHTGEN
                 comp = torch.empty((n, S), dtype=torch.uint8, device=eng.dev)
                 j1 = eng.jobs_strided(data, B, np.full(n, B, np.uint32), comp, S, S)
                 r = eng.results_to_host(eng.compress(fc, j1, n)[0])
