@@ -157,7 +157,7 @@ static constexpr unsigned JOB_COUNTERS = 256;
 // 2.9) go through the wave kernel at 73 GiB/s from 32 768 streams on and through the lane kernel at 51 / 88 / 164 at 32 768 /
 // 65 536 / 262 144: the switch-over lies between the two kinds' break-evens.
 #define NXZ_LANES_MIN 49152
-#define NXZ_LANES_TABLES_MIN 229376   /* streams that bring tables: the lane kernel from here on */
+#define NXZ_LANES_TABLES_MIN 163840   /* streams that bring tables: the lane kernel from here on */
 #define NXZ_WINDOW_LDS_MAX 1024
 
 static std::mutex g_mtx;
@@ -494,8 +494,8 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 			h[0] = 0; h[1] = 0; h[2] = 0;
 			if (nxz_launch_sample_btype(jobs, n, h, s) == 0 && hipStreamSynchronize(s) == hipSuccess) {
 				// a quarter or more with tables: the wave kernel's, unless the batch is so large that the general lane kernel
-				// overtakes it (zlib -6 streams of the corpus, jobs by length: 96 against 87 GiB/s at 262 144 streams, 66 against 86
-				// at 131 072; profiles/r04c_inflate_by_batch_size.txt)
+				// overtakes it (zlib -6 streams of the corpus: 75 against 86 GiB/s at 131 072 streams, 95 against 86 at 196 608, 102 at
+				// 262 144, 117 at 524 288; profiles/r04c_inflate_by_batch_size.txt)
 				if (h[0] > 64 && n < NXZ_LANES_TABLES_MIN) lanes = false;
 				// streams of very different lengths (zeros beside text: BASELINE configs[4]): a wavefront takes as long as its
 				// longest stream, so the lane kernel gets them ordered by length; much of a size they stay as they come

@@ -26,6 +26,7 @@ namespace nxzl {
 #endif
 constexpr int LB = NXZ_LANES_LB, DB = NXZ_LANES_DB;  // fast-table index bits
 constexpr uint32_t WS_LIT = 0, WS_DIST = 2048, WS_LCNT = 2560, WS_LSYM = 2592, WS_DCNT = 3168, WS_DSYM = 3200;
+constexpr uint32_t WS_LPK = 3264, WS_DPK = 3280;     // 16 bytes each: what the walk for codes longer than the fast table needs, packed (decode_long)
 constexpr uint32_t WS_LENS = 320;                     // code lengths of the block being set up (last part of a slot)
 constexpr uint32_t WS_BYTES = 3328 + WS_LENS;
 
@@ -52,20 +53,33 @@ __device__ __forceinline__ int decode_fast(const uint16_t *fast, uint32_t bits, 
 	nb = e >> 12;
 	return e ? (int)(e & 0xfff) : LONG_CODE;
 }
-template <int FB>
-__device__ __forceinline__ int decode(const uint16_t *fast, const uint16_t *cnt, const uint16_t *symt, uint32_t bits, uint32_t &nb)
+// A code longer than the fast table's FB bits: the canonical walk (count, first code and index per length) from where
+// FB bits leave it -- its state there does not depend on the bits -- with the counts of the lengths FB + 1 .. 15 (CB bits
+// each), the first code and the index at length FB + 1 packed in 16 bytes of the table set (build_tables): one load, a few
+// steps of arithmetic, one load of the symbol, where the walk through the counts in memory was a load a step.
+template <int FB, int CB>
+__device__ __forceinline__ int decode_long(const uint8_t *pk, const uint16_t *symt, uint32_t bits, uint32_t &nb)
 {
-	uint32_t e = fast[bits & ((1u << FB) - 1)];
-	if (e) { nb = e >> 12; return (int)(e & 0xfff); }
-	int code = 0, first = 0, index = 0;
-	for (int len = 1; len <= 15; len++) {
+	const uint4 p = *(const uint4 *)pk;
+	uint64_t cnts = (uint64_t)p.x | (uint64_t)p.y << 32;
+	int first = (int)(p.z & 0xffff), index = (int)(p.z >> 16);
+	int code = (int)((__builtin_bitreverse32(bits) >> (32 - FB)) << 1);
+	bits >>= FB;
+	for (int len = FB + 1; len <= 15; len++) {
 		code |= (int)(bits & 1); bits >>= 1;
-		int c = cnt[len];
+		const int c = (int)(cnts & ((1u << CB) - 1)); cnts >>= CB;
 		if (code - c < first) { nb = (uint32_t)len; return symt[index + (code - first)]; }
 		index += c; first += c; first <<= 1; code <<= 1;
 	}
 	nb = 16;
 	return -2;
+}
+template <int FB, int CB>
+__device__ __forceinline__ int decode(const uint16_t *fast, const uint8_t *pk, const uint16_t *symt, uint32_t bits, uint32_t &nb)
+{
+	uint32_t e = fast[bits & ((1u << FB) - 1)];
+	if (e) { nb = e >> 12; return (int)(e & 0xfff); }
+	return decode_long<FB, CB>(pk, symt, bits, nb);
 }
 
 // The fixed code (RFC1951 3.2.6) needs no table: the symbol follows from the first 9 bits by
@@ -124,12 +138,18 @@ __device__ void build_tables(uint8_t *ws, const uint8_t *lens, int hlit, int hdi
 		uint32_t offs = 0, next = 0;
 		{
 			uint32_t c = 0, o = 0;
+			uint64_t packed = 0;                                 // counts of the lengths FB + 1 .. 15, CB bits each (decode_long)
+			uint32_t at = 0, fi = 0;
+			const int CB = pass ? 5 : 9;
 			for (int b = 1; b < 16; b++) {
 				uint32_t cb = __shfl(mycnt, b, 64);
 				if (b == lane) { offs = o; next = c; }
+				if (b == FB + 1) fi = (c & 0xffff) | o << 16;      // first code and index at length FB + 1
+				if (b > FB) { packed |= (uint64_t)cb << at; at += CB; }
 				o += cb;
 				c = (c + cb) << 1;
 			}
+			if (lane == 0) *(uint4 *)(ws + (pass ? WS_DPK : WS_LPK)) = make_uint4((uint32_t)packed, (uint32_t)(packed >> 32), fi, 0);
 		}
 		if (lane < 16) cnt[lane] = (uint16_t)(lane ? mycnt : 0);
 		// sorted symbol list + fast entries: lane per symbol
@@ -420,7 +440,7 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 						b.need(15);
 						sym = btype == 1 ? decode_fixed_ll((uint32_t)b.bb, nb) : decode_fast<LB>(T.lit, (uint32_t)b.bb, nb);
 					}
-					if (sym == LONG_CODE) sym = decode<LB>(T.lit, T.lcnt, T.lsym, (uint32_t)b.bb, nb);     // (the one place: see decode_fast)
+					if (sym == LONG_CODE) sym = decode_long<LB, 9>((const uint8_t *)T.lit + (WS_LPK - WS_LIT), T.lsym, (uint32_t)b.bb, nb);     // (the one place: see decode_fast)
 					const uint64_t sym_start = b.pos;
 					if (sym < 0 || !b.have(nb)) {
 						if (!b.have(sym < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); }
@@ -444,7 +464,7 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 						uint32_t len = lbase + ((uint32_t)b.bb & ((1u << eb) - 1));
 						b.drop(eb);
 						b.need(15);
-						int ds = btype == 1 ? decode_fixed_d((uint32_t)b.bb, nb) : decode<DB>(T.dist, T.dcnt, T.dsym, (uint32_t)b.bb, nb);
+						int ds = btype == 1 ? decode_fixed_d((uint32_t)b.bb, nb) : decode<DB, 5>(T.dist, (const uint8_t *)T.lit + (WS_DPK - WS_LIT), T.dsym, (uint32_t)b.bb, nb);
 						if (ds < 0 || !b.have(nb)) {
 							if (!b.have(ds < 0 ? 15 : nb)) { o_sfbt = sfbt; o_subc = (uint32_t)(b.total() - sym_start); }
 							else cc = NXZ_CC_INVALID_DIST;
