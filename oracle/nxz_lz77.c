@@ -43,6 +43,18 @@
  *     output that is 4 to 12 % smaller than zlib -1's anyway (JSON, msgpack,
  *     XML, tables); text, binaries and fonts, where the second candidate
  *     is worth 2 to 4 % and the margin to zlib -1 is thin, keep it.
+ *  3c. Text that is not easy in the sense of 3b -- fewer than one byte in
+ *     NXO_TEXT_HIGH_DIV (16) of the first tile has its top bit set, and that
+ *     tile's parse made NXO_SECOND_MIN_TOKENS tokens or more: prose, program
+ *     sources, base64 -- does without the second entries in its later tiles
+ *     too, and without the lazy step of 5 there.  Its literals are cheap
+ *     (5 bits and fewer under the block's own table), so zlib -1, which spends
+ *     its 3-byte matches on them, is beaten by 7-8 % with everything on; the
+ *     two together cost such a block 4 % of its output and a tenth of the
+ *     kernel's time.  Binaries, fonts and text in scripts that live above
+ *     0x7f, where the margin to zlib -1 is thin, keep both.  (Per class on
+ *     the fallback corpus: text 1.08 -> 1.03-1.05 x zlib -1, sources 1.076 ->
+ *     1.036, base64 1.027 -> 1.014; overall 0.996 -> 0.993.)
  *  4. A bucket entry q is a candidate if dist = p-q <= 32768 and >= 4 bytes
  *     agree.  Of two candidates the one with more equal bytes among the
  *     first 8 is taken, the newest on a tie (8 bytes decide: what a lane can
@@ -94,6 +106,9 @@
 #ifndef NXO_PIECE
 #define NXO_PIECE 512
 #endif
+#ifndef NXO_TEXT_HIGH_DIV
+#define NXO_TEXT_HIGH_DIV 16         /* step 3c; 0 = no such rule */
+#endif
 #ifndef NXO_SECOND_MIN_TOKENS
 #define NXO_SECOND_MIN_TOKENS 3072   /* step 3b: tokens of a sub-block's first tile below which the later tiles do without second entries */
 #endif
@@ -124,7 +139,7 @@ static inline uint32_t match_len(const uint8_t *a, const uint8_t *b, uint32_t ma
  * tok != NULL the tokens are appended at tok[*ntok]. */
 static uint32_t walk(const uint8_t *w, uint32_t h, const uint16_t *mlen, const uint16_t *mdist,
 		     uint32_t p, uint32_t stop, uint32_t limit, uint32_t *tok, size_t *ntok, uint32_t *visited, uint32_t vbase,
-		     uint32_t *last_match)
+		     uint32_t *last_match, uint32_t lazy_max)
 {
 	while (p < stop) {
 		uint32_t len = mlen[p];
@@ -135,8 +150,7 @@ static uint32_t walk(const uint8_t *w, uint32_t h, const uint16_t *mlen, const u
 		if (len > limit - p)
 			len = limit - p;
 		if (len >= MINMATCH - 1 && mlen[p] >= MINMATCH) {
-#if NXO_LAZY_MAX
-			if (len < NXO_LAZY_MAX && p + 1 < limit) {
+			if (len < lazy_max && p + 1 < limit) {
 				uint32_t l2 = mlen[p + 1];
 				if (l2 > limit - p - 1)
 					l2 = limit - p - 1;
@@ -146,7 +160,6 @@ static uint32_t walk(const uint8_t *w, uint32_t h, const uint16_t *mlen, const u
 					continue;
 				}
 			}
-#endif
 			if (tok) tok[(*ntok)++] = NXO_TOK_MATCH | ((uint32_t)mdist[p] << 8) | (len - 3);
 			if (last_match) *last_match = p;
 			p += len;
@@ -186,7 +199,18 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 	static __thread uint16_t mdist[NXO_SUBBLOCK];
 	const uint32_t end = h + n;
 	uint32_t c, r, ntok = 0, t0, t1;
-	int use_second = 1;
+	int use_second = 1, text = 0;
+	uint32_t lazy_max = NXO_LAZY_MAX;
+
+#if NXO_TEXT_HIGH_DIV
+	{
+		/* 3c. text: fewer than one byte in NXO_TEXT_HIGH_DIV of the first tile has its top bit set */
+		uint32_t t0n = n < NXO_PTILE ? n : NXO_PTILE, high = 0;
+		for (r = 0; r < t0n; r++)
+			high += w[h + r] >> 7;
+		text = high * NXO_TEXT_HIGH_DIV < t0n;
+	}
+#endif
 
 	memset(head, 0, sizeof(head));
 	memset(head2, 0, sizeof(head2));
@@ -281,7 +305,7 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 			uint32_t sb = c + s * NXO_PSEG;
 			uint32_t se = sb + NXO_PSEG < tend ? sb + NXO_PSEG : tend;
 			V[s] = 0;
-			X[s] = walk(w, h, mlen, mdist, sb, se, tend, NULL, NULL, &V[s], sb, &A[s]);
+			X[s] = walk(w, h, mlen, mdist, sb, se, tend, NULL, NULL, &V[s], sb, &A[s], lazy_max);
 		}
 		if (nxo_dbg_x) for (s = 0; s < nseg; s++) nxo_dbg_x[c / NXO_PSEG + s] = X[s];
 		/* chain of entered segments: the segment containing `entry` is walked for real from `entry`:
@@ -296,7 +320,7 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 			se = sb + NXO_PSEG < tend ? sb + NXO_PSEG : tend;
 			while (p < X[s]) {
 				if (p < se && ((V[s] >> (p - sb)) & 1)) {
-					p = walk(w, h, mlen, mdist, p, se, tend, tok, &k, NULL, 0, NULL);
+					p = walk(w, h, mlen, mdist, p, se, tend, tok, &k, NULL, 0, NULL, lazy_max);
 					break;
 				}
 				if (A[s] != 0xffffffffu && p > A[s]) {
@@ -309,15 +333,18 @@ static size_t lz77_subblock(const uint8_t *w, uint32_t h, uint32_t n, uint32_t *
 					p = X[s];
 					break;
 				}
-				p = walk(w, h, mlen, mdist, p, p + 1, X[s], tok, &k, NULL, 0, NULL);
+				p = walk(w, h, mlen, mdist, p, p + 1, X[s], tok, &k, NULL, 0, NULL, lazy_max);
 			}
 			ntok = (uint32_t)k;
 			entry = X[s];
 		}
 	}
 	/* 3b. what the first tile came to decides about the second entries for the rest of the sub-block */
-	if (t0 == 0)
-		use_second = ntok >= NXO_SECOND_MIN_TOKENS;
+	if (t0 == 0) {
+		use_second = ntok >= NXO_SECOND_MIN_TOKENS && !text;
+		if (text && ntok >= NXO_SECOND_MIN_TOKENS)
+			lazy_max = 0;                      /* 3c */
+	}
 	}
 	if (nxo_dbg_mlen) { memcpy(nxo_dbg_mlen, mlen, n * 2); memcpy(nxo_dbg_mdist, mdist, n * 2); }
 	return ntok;

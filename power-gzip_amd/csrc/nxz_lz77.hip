@@ -54,7 +54,13 @@ __device__ unsigned long long *nxz_lz77_prof_buf = nullptr;
 // waits on its own vector-memory counter, an atomic in flight there would be timed as chain)
 #define PROF(idx) do { if (prof) { if (t == 0) { unsigned long long now_ = clock64(); profacc[idx] += (uint32_t)(now_ - tprev); tprev = now_; } } } while (0)
 #define PCOUNT(idx, n) do { if (prof && lane == 0) atomicAdd(&profacc[idx], (uint32_t)(n)); } while (0)
+#ifdef NXZ_LZ77_PROF2
+#define PC2(idx, n) do { if (prof && lane == 0) __hip_atomic_fetch_add(&prof[32 + (idx)], (unsigned long long)(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #else
+#define PC2(idx, n) do { } while (0)
+#endif
+#else
+#define PC2(idx, n) do { } while (0)
 #define PCOUNT(idx, n) do { } while (0)
 #define WPROF_BEGIN() do { } while (0)
 #define WPROF_END(idx) do { } while (0)
@@ -76,21 +82,18 @@ constexpr uint32_t WINDOW = 32768;
 constexpr uint32_t OPEN2 = 24;           // bytes that the first level of M2 settles (8 from M1 + one 16-byte round trip)
 constexpr uint32_t NOHASH = 0xFFFFu;
 constexpr uint32_t SECOND_MIN_TOKENS = 3072; // oracle/nxz_lz77.c step 3b: tokens of the first tile below which the later tiles do without second bucket entries
+constexpr uint32_t TEXT_HIGH_DIV = 16;       // oracle/nxz_lz77.c step 3c: fewer than 1 byte in 16 of the first tile with its top bit set = text
 #ifndef NXZ_GROUP_ROUNDS
-#define NXZ_GROUP_ROUNDS 8
+#define NXZ_GROUP_ROUNDS 24
 #endif
 #ifndef NXZ_GROUP_MIN
-#define NXZ_GROUP_MIN 3
-#endif
-#ifndef NXZ_GROUP_MISS
-#define NXZ_GROUP_MISS 2
+#define NXZ_GROUP_MIN 2
 #endif
 #ifndef NXZ_GROUP_GATE
-#define NXZ_GROUP_GATE 10
+#define NXZ_GROUP_GATE 3
 #endif
 constexpr uint32_t GROUP_ROUNDS = NXZ_GROUP_ROUNDS;   // distances looked at per batch of 64 long positions (open tails are extended a group at a time)
 constexpr uint32_t GROUP_GATE = NXZ_GROUP_GATE;       // ... tails of a batch that must have a neighbour in the queue at their distance before the wave looks for groups at all
-constexpr uint32_t GROUP_MISS = NXZ_GROUP_MISS;       // ... distances with a tail on its own after which a batch is given up
 constexpr uint32_t GROUP_MIN = NXZ_GROUP_MIN;         // ... tails of one distance that are worth a trip of the whole wave
 // device scratch of a workgroup (16-bit units): carries a tile's second bucket entries from the chain
 // wave to the match waves (+ room for a piece past the end)
@@ -105,13 +108,27 @@ constexpr uint32_t OFF_SBITS = OFF_MLEN + PTILE;         // 512 x u32   (aliased
 constexpr uint32_t OFF_MBITS = OFF_SBITS + PTILE / 8;    // 512 x u32   (aliased: JUMP u16[1024]; literal-token bitmap of the final walk)
 constexpr uint32_t OFF_X     = OFF_MBITS + PTILE / 8;    // 1024 x u16
 constexpr uint32_t OFF_ENTRY = OFF_X + NSEG * 2;         // 1024 x u16
-constexpr uint32_t OFF_BITS  = OFF_ENTRY + NSEG * 2;     // 4096 + 64 bytes: the CRC tables before the first tile, match-phase queues later
-constexpr uint32_t BITS_BYTES = ETILE * 2 + 64;
-// during the match phase the window region holds: 16 x 96 queue entries (long positions), 16 x 80
+constexpr uint32_t OFF_BITS  = OFF_ENTRY + NSEG * 2;     // the CRC tables (4 KiB) before the first tile, match-phase queues later
+// The match phase's queues, per wave: LQ_CAP long positions (a batch goes to level 1 of M2 when LQ_MIN are waiting: a unit adds
+// up to 64 at a time) and XQ_CAP positions that are still open after OPEN2 bytes (level 2 when XQ_MIN are waiting).  The
+// fuller a batch, the fewer trips: with 96 / 32 and 80 / 16 (round 4) level 1 ran 70 % full and level 2 with 16 lanes of 64.
+#ifndef NXZ_LQ_CAP
+#define NXZ_LQ_CAP 128
+#define NXZ_LQ_MIN 64
+#endif
+#ifndef NXZ_XQ_CAP
+#define NXZ_XQ_CAP 120
+#define NXZ_XQ_MIN 56
+#endif
+constexpr uint32_t LQ_CAP = NXZ_LQ_CAP, LQ_MIN = NXZ_LQ_MIN, XQ_CAP = NXZ_XQ_CAP, XQ_MIN = NXZ_XQ_MIN;
+static_assert(LQ_MIN + 64 <= LQ_CAP && XQ_MIN + 64 <= XQ_CAP && LQ_CAP % 8 == 0 && XQ_CAP % 8 == 0, "a batch of 64 must fit behind what waits");
+constexpr uint32_t BITS_BYTES = 16 * (LQ_CAP + XQ_CAP) * 2 + 2096 - NSEG * 4 < ETILE * 2 + 64 ? ETILE * 2 + 64 : 16 * (LQ_CAP + XQ_CAP) * 2 + 2096 - NSEG * 4;
+// during the match phase the window region holds: 16 x LQ_CAP queue entries (long positions), 16 x XQ_CAP
 // (positions still open after OPEN2 bytes) and the e-flag bitmap (PTILE + 288 bits)
 constexpr uint32_t OFF_LQ    = OFF_X;
-constexpr uint32_t OFF_XQ    = OFF_LQ + 16 * 96 * 2;
-constexpr uint32_t OFF_EB    = OFF_XQ + 16 * 80 * 2;     // 2096 bytes; bit EBO + i = flag of tile position i
+constexpr uint32_t OFF_DQ    = OFF_LQ;                   // after the match phase: the segments the distance-1 pass has to look at (1024 x u16)
+constexpr uint32_t OFF_XQ    = OFF_LQ + 16 * LQ_CAP * 2;
+constexpr uint32_t OFF_EB    = OFF_XQ + 16 * XQ_CAP * 2;     // 2096 bytes; bit EBO + i = flag of tile position i
 constexpr uint32_t EBO       = 32;                       // flags of the 32 positions in front of the tile come first
 static_assert(OFF_EB % 16 == 0 && OFF_EB + 2096 <= OFF_BITS + BITS_BYTES, "match-phase carve");
 constexpr uint32_t OFF_SCAN  = OFF_BITS + BITS_BYTES;    // 64 x u32
@@ -122,7 +139,7 @@ constexpr uint32_t LDS_BYTES = OFF_PROF + 80;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
-enum { M_NREC = 0, M_TOK0 = 1, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7, M_KEEP = 8, M_DEFER2 = 9 };
+enum { M_NREC = 0, M_TOK0 = 1, M_HIGH = 2, M_DQ = 3, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7, M_KEEP = 8, M_DEFER2 = 9 };
 static_assert(M_TICKET == M_PROGRESS + 1 && M_DEFER == M_PROGRESS + 2, "cleared together");
 
 __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
@@ -522,7 +539,12 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		const uint32_t nseg = (tn + PSEG - 1) / PSEG;
 		// second bucket entries: always in the first tile, later only where that tile's parse says the data is hard
 		// (oracle/nxz_lz77.c step 3b); wave-uniform, so the chain and M1 branch around what serves them
-		const bool use2 = tb0 == 0 || __builtin_amdgcn_readfirstlane(misc[M_TOK0]) >= SECOND_MIN_TOKENS;
+		// (step 3c: text -- few bytes of the first tile with their top bit set -- that is not easy either does without them
+		// too, and without the lazy step: its literals are cheap, what is lost there is a few per cent of a margin of 7-8)
+		const bool hard = __builtin_amdgcn_readfirstlane(misc[M_TOK0]) >= SECOND_MIN_TOKENS;
+		const bool text = __builtin_amdgcn_readfirstlane(misc[M_HIGH]) * TEXT_HIGH_DIV < (n < PTILE ? n : PTILE);
+		const bool use2 = tb0 == 0 || (hard && !text);
+		const uint32_t lazy_max = tb0 != 0 && hard && text ? 0u : LAZY_MAX;
 #ifdef NXZ_CHAIN_ALWAYS2
 #define CHAIN_USE2 true
 #else
@@ -540,12 +562,15 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		const uint32_t npieces = tnpad >> 9;
 		if (t < 3) misc[M_PROGRESS + t] = 0;                    // M_PROGRESS, M_TICKET, M_DEFER
 		if (t == 3) misc[M_DEFER2] = 0;
+		if (t == 4) misc[M_DQ] = 0;
 		sbits[t] = 0;                                           // vb and kb (adjacent, 2 x 512 words)
+		uint32_t nhigh = 0;                                     // bytes of the first tile with their top bit set (step 3c)
 		for (uint32_t piece = wave; piece < npieces; piece += NT / 64) {
 #pragma unroll
 			for (int it = 0; it < 2; it++) {
 				const uint32_t i = (piece << 9) + (it << 8) + 4 * lane, r = h + tb0 + i;   // r is a multiple of 4
 				const uint32_t d0 = inw[r >> 2], d1 = inw[(r >> 2) + 1];
+				if (tb0 == 0 && i < tn) nhigh += (uint32_t)__popc(d0 & 0x80808080u);     // (behind the data the image holds zeros)
 				const uint32_t v1 = __builtin_amdgcn_alignbyte(d1, d0, 1), v2 = __builtin_amdgcn_alignbyte(d1, d0, 2), v3 = __builtin_amdgcn_alignbyte(d1, d0, 3);
 				uint32_t o0 = hash4(d0) << 2, o1 = hash4(v1) << 2, o2 = hash4(v2) << 2, o3 = hash4(v3) << 2;
 				// positions that take no part in the table get the dummy slot of their chain lane
@@ -560,11 +585,13 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 				// deep_in_run): no lookup, no insert.  The 8 bytes r-4 .. r+3 of the first position
 				// are a cheap necessary condition for all four.
 				if (r >= 8 && d0 == __builtin_amdgcn_alignbyte(d0, d0, 1) && inw[(r >> 2) - 1] == d0) {
-					auto deep = [&](uint32_t rr, uint32_t v) { return lds_ld32(inw, rr - 8) == v && lds_ld32(inw, rr - 4) == v && v == __builtin_amdgcn_alignbyte(v, v, 1); };
-					if (deep(r, d0)) o0 = dummy;
-					if (deep(r + 1, v1)) o1 = dummy + 4;
-					if (deep(r + 2, v2)) o2 = dummy + 8;
-					if (deep(r + 3, v3)) o3 = dummy + 12;
+					// the bytes r-4 .. r+3 are one value: position r+j is deep if the 4-j bytes in front of them and the j
+					// behind them are that value too
+					const uint32_t x2 = inw[(r >> 2) - 2] ^ d0, y = d1 ^ d0;
+					if (x2 == 0) o0 = dummy;
+					if ((x2 & 0xffffff00u) == 0 && (y & 0xffu) == 0) o1 = dummy + 4;
+					if ((x2 & 0xffff0000u) == 0 && (y & 0xffffu) == 0) o2 = dummy + 8;
+					if ((x2 & 0xff000000u) == 0 && (y & 0xffffffu) == 0) o3 = dummy + 12;
 				}
 				*(uint2 *)(cand + i) = make_uint2(o0 | o1 << 16, o2 | o3 << 16);
 			}
@@ -574,6 +601,10 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 			for (int u = 0; u < 8; u++) o[u] = cand[(piece << 9) + (u << 6) + lane];
 			__builtin_amdgcn_wave_barrier();                      // LDS runs a wave's operations in order: reads before the write
 			((uint4 *)cand)[(piece << 6) + lane] = make_uint4(o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | o[5] << 16, o[6] | o[7] << 16);
+		}
+		if (tb0 == 0) {
+			for (int o = 32; o > 0; o >>= 1) nhigh += __shfl_down(nhigh, o, 64);
+			if (lane == 0 && nhigh) atomicAdd(&misc[M_HIGH], nhigh);
 		}
 		// e(x) = "byte x equals byte x-1" flags for the tile and 288 positions beyond: the lengths of the
 		// distance-1 candidates are runs of these flags (used by the match phase and M3)
@@ -747,8 +778,8 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 				const uint32_t lo = bm[b >> 5], hi = bm[(b >> 5) + 1], sh = b & 31;
 				return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
 			};
-			uint16_t *lq = (uint16_t *)(lds + OFF_LQ) + wave * 96;          // long positions: quad number | position bits << 12
-			uint16_t *xq = (uint16_t *)(lds + OFF_XQ) + wave * 80;          // tails beyond LCAP
+			uint16_t *lq = (uint16_t *)(lds + OFF_LQ) + wave * LQ_CAP;          // long positions: quad number | position bits << 12
+			uint16_t *xq = (uint16_t *)(lds + OFF_XQ) + wave * XQ_CAP;          // tails beyond LCAP
 			uint32_t xqn = 0;
 			uint32_t lqn = 0;
 			// M2 in two levels (a long position = one with 8 equal bytes whose direct successor does not go on at its distance):
@@ -797,8 +828,24 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 						} else
 							lg = true;
 					}
+					// the next 32 bytes of every tail, each lane its own: that ends the short ones (tables, XML: nearly all), and
+					// what is left is worth looking for groups in
+					if (__ballot(lg)) {
+						const uint32_t r = h + tb0 + i, q = lg ? r - dT - 1 : 0;
+						const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
+						if (lg) {
+							const uint32_t k1 = equal16(inw, q + OPEN2, r + OPEN2), k2 = equal16(inw, q + OPEN2 + 16, r + OPEN2 + 16);
+							const uint32_t k = k1 == 16 ? 16 + k2 : k1;
+							if (k < 32 || OPEN2 + k >= maxlen) {
+								lg = false;
+								mlen[i] = (uint8_t)((OPEN2 + k < maxlen ? OPEN2 + k : maxlen) - 3);
+							}
+						}
+					}
+					constexpr uint32_t SEEN = OPEN2 + 32;
 					unsigned long long todo = __ballot(lg);                 // tails whose distance has not been looked at
 					PCOUNT(15, __popcll(todo));                             // ... tails
+					PC2(0, 1);
 #ifdef NXZ_GROUP_NEVER
 					todo = 0;
 #endif
@@ -808,9 +855,12 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 						const uint32_t key = lg ? dT | (i >> 8) << 16 : 0x80000000u | (uint32_t)lane;
 						const uint32_t k1 = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)key, 0x111, 0xf, 0xf, false);   // row_shr:1
 						const uint32_t k2 = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)key, 0x112, 0xf, 0xf, false);   // row_shr:2
-						if ((uint32_t)__popcll(__ballot(key == k1 || key == k2)) < GROUP_GATE) todo = 0;
+						// ... and only those lead a round: a tail on its own never does (round 4 took the leaders in queue order
+						// and gave a batch up after two of them had no company)
+						todo = __ballot(lg && (key == k1 || key == k2));
+						if ((uint32_t)__popcll(todo) < GROUP_GATE) { todo = 0; PC2(13, 1); }
 					}
-					for (uint32_t round = 0, misses = 0; todo && round < GROUP_ROUNDS; round++) {
+					for (uint32_t round = 0; todo && round < GROUP_ROUNDS; round++) {
 						const int ldr = __builtin_ctzll(todo);
 						const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)dT, ldr);
 						const uint32_t uL = (uint32_t)__builtin_amdgcn_readlane((int)i, ldr) >> 8;
@@ -818,9 +868,10 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 						const unsigned long long mm = __ballot(mine);
 						todo &= ~mm;
 						if ((uint32_t)__popcll(mm) < GROUP_MIN) {               // a tail on its own: the rounds below are cheaper,
-							if (++misses >= GROUP_MISS) break;                  // and where one is on its own most are
+							PC2(4, 1);
 							continue;
 						}
+						PC2(2, 1); PC2(3, __popcll(mm));
 						const uint32_t R = h + tb0 + (uL << 8);                 // 16-byte aligned
 						const uint32_t a = R + 8 + 8 * (uint32_t)lane;
 						const uint2 rv = *(const uint2 *)(lds + OFF_IN + a);
@@ -848,8 +899,10 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 					if (nleft >= 12) {
 						const uint32_t r = h + tb0 + i, q = lg ? r - dT - 1 : 0;
 						const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
-						uint32_t len = OPEN2;
+						uint32_t len = SEEN;
+						PC2(5, 1); PC2(7, nleft);
 						while (__ballot(lg)) {
+							PC2(6, 1);
 							if (lg) {
 								const uint32_t k1 = equal16(inw, q + len, r + len), k2 = equal16(inw, q + len + 16, r + len + 16);
 								const uint32_t k = k1 == 16 ? 16 + k2 : k1;
@@ -865,6 +918,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 						if (lg) xq[base + __popcll(ml & ((1ull << lane) - 1))] = (uint16_t)i;
 						__builtin_amdgcn_wave_barrier();
 						const uint32_t g = lane >> 4, li = lane & 15;
+						PC2(8, 1); PC2(14, nleft);
 						for (uint32_t b4 = 0; b4 < nleft; b4 += 4) {
 							const bool act = b4 + g < nleft;
 							const uint32_t i = act ? (uint32_t)xq[base + b4 + g] : 0;
@@ -872,7 +926,8 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 							const uint32_t maxlen = end - r < MAXMATCH ? end - r : MAXMATCH;
 							uint32_t N = 0;
 							bool done = !act;
-							for (uint32_t off = OPEN2;; off += 64) {
+							for (uint32_t off = SEEN;; off += 64) {
+								PC2(9, 1);
 								const uint32_t o = off + 4 * li;
 								uint32_t x = 0;
 								if (!done && o < maxlen) x = lds_ld32(inw, q + o) ^ lds_ld32(inw, r + o);
@@ -918,8 +973,8 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 					}
 					pb &= pb - 1;
 					const bool more = __ballot(pb != 0) != 0;
-					// (16 or more are worth the trip; the queue holds 80; the phase's last call empties it)
-					if (xqn >= 16 || (last && !more && nq <= 64 && xqn)) { level2(xqn); xqn = 0; }
+					// (XQ_MIN or more are worth the trip; the phase's last call empties the queue)
+					if (xqn >= XQ_MIN || (last && !more && nq <= 64 && xqn)) { level2(xqn); xqn = 0; }
 					if (!more) break;
 				} while (true);
 			};
@@ -1056,7 +1111,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 #endif
 					__builtin_amdgcn_wave_barrier();
 					WPROF_END(17);                                 // M1
-					while (lqn >= (last ? 1u : 32u) || (last && xqn)) { stage2(lqn, last); lqn = lqn > 64 ? lqn - 64 : 0; }
+					while (lqn >= (last ? 1u : LQ_MIN) || (last && xqn)) { stage2(lqn, last); lqn = lqn > 64 ? lqn - 64 : 0; }
 					WPROF_END(18);                                 // M2 (classification, tails)
 					rest &= rest - 1;
 				}
@@ -1094,6 +1149,20 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		PROF(10);
 		// ---- M3: long members, then distance-1 runs ----
 		const uint32_t p0 = (uint32_t)t * PSEG;
+		{
+			// segments in which a run of four "equals its predecessor" flags starts: queued for the distance-1 pass below
+			const uint32_t *eb = (const uint32_t *)(lds + OFF_EB);
+			uint16_t *dq = (uint16_t *)(lds + OFF_DQ);
+			const uint32_t e32 = p0 < tn ? lds_ld32(eb, 2 * t + EBO / 8) : 0;
+			const bool runs = (e32 & (e32 >> 1) & (e32 >> 2) & (e32 >> 3) & 0xffff) != 0;
+			const unsigned long long rm = __ballot(runs);
+			if (rm) {
+				uint32_t qb = 0;
+				if (lane == 0) qb = atomicAdd(&misc[M_DQ], (uint32_t)__popcll(rm));
+				qb = __builtin_amdgcn_readfirstlane(qb);
+				if (runs) dq[qb + (uint32_t)__popcll(rm & ((1ull << lane) - 1))] = (uint16_t)t;
+			}
+		}
 		if (p0 < tn) {
 			// members of my 16 positions, last to first: N = (end of the chain) - position; the chain
 			// ends at the first non-member behind it, whose length is final (M1, M2 or the link pass).
@@ -1133,30 +1202,33 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		PROF(11);
 		// chain bookkeeping init: mark[] aliases the vb bitmap, which nobody reads any more
 		for (uint32_t s = t; s < NSEG; s += NT) mark[s] = 0;
-		uint32_t sm0 = 0, sm1 = 0, sm2 = 0, sm3 = 0;          // final stored lengths (len-3, 0 = none) of my 16 positions
-		if (p0 < tn) {
+		// distance 1: the length is the run of e flags that starts at the position; it wins ties.  Only the segments
+		// in which a run of four flags starts have anything to do, and where such runs are scattered (the blanks of
+		// text and sources, the zero words of binaries) every wavefront held one: they were queued by the lanes that
+		// own them (above, beside the members) and are worked through 64 at a time here.
+		{
 			const uint32_t *eb = (const uint32_t *)(lds + OFF_EB);
-			const uint32_t e32 = lds_ld32(eb, 2 * t + EBO / 8);     // my 16 flags and the next 16
-			const uint32_t e16 = e32 & 0xffff;
-			const uint32_t r4 = e32 & (e32 >> 1) & (e32 >> 2) & (e32 >> 3) & 0xffff;   // runs of >= 4 that start in my group
-			const uint4 mv = *(const uint4 *)(mlen + p0);
-			sm0 = mv.x; sm1 = mv.y; sm2 = mv.z; sm3 = mv.w;
-			if (r4) {
-				// distance 1: the length is the run of e flags that starts at the position; it wins ties
-				const uint4 c0 = ((const uint4 *)cand)[2 * t], c1 = ((const uint4 *)cand)[2 * t + 1];
+			const uint16_t *dq = (const uint16_t *)(lds + OFF_DQ);
+			const uint32_t qn = misc[M_DQ];
+			for (uint32_t qi = t; qi < qn; qi += NT) {
+				const uint32_t sg = dq[qi], q0 = sg * PSEG;
+				const uint32_t e32 = lds_ld32(eb, 2 * sg + EBO / 8);     // the segment's 16 flags and the next 16
+				const uint32_t e16 = e32 & 0xffff;
+				const uint4 mv = *(const uint4 *)(mlen + q0);
+				const uint4 c0 = ((const uint4 *)cand)[2 * sg], c1 = ((const uint4 *)cand)[2 * sg + 1];
 				const uint32_t mw[4] = { mv.x, mv.y, mv.z, mv.w };
 				uint32_t cw[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
 				uint32_t zb = 16;
 				if (e16 >> 15) {
-					uint32_t s0 = EBO + p0 + 16;
-					asm volatile("" : "+v"(s0));                      // as above
-					zb = first_zero(eb, s0, s0 + 272) - EBO - p0;
+					uint32_t s0 = EBO + q0 + 16;
+					asm volatile("" : "+v"(s0));                      // not hoisted out of the tile loop (it would be spilled)
+					zb = first_zero(eb, s0, s0 + 272) - EBO - q0;
 				}
-				const uint32_t r15 = h + tb0 + p0 + 15;
+				const uint32_t r15 = h + tb0 + q0 + 15;
 				uint32_t om[4] = { 0, 0, 0, 0 };
 #pragma unroll
 				for (int j = 15; j >= 0; j--) {
-					const uint32_t i = p0 + j, r = r15 - (15 - j);
+					const uint32_t i = q0 + j, r = r15 - (15 - j);
 					const uint32_t room = end > r ? end - r : 0;
 					const uint32_t ml = room < MAXMATCH ? room : MAXMATCH;
 					const uint32_t mj = (mw[j >> 2] >> (8 * (j & 3))) & 0xff;
@@ -1171,10 +1243,9 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 					om[j >> 2] |= (len ? len - 3 : 0) << (8 * (j & 3));
 					cw[j >> 1] = (cw[j >> 1] & ~(0xffffu << (16 * (j & 1)))) | cj << (16 * (j & 1));
 				}
-				sm0 = om[0]; sm1 = om[1]; sm2 = om[2]; sm3 = om[3];
-				*(uint4 *)(mlen + p0) = make_uint4(sm0, sm1, sm2, sm3);
-				((uint4 *)cand)[2 * t] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-				((uint4 *)cand)[2 * t + 1] = make_uint4(cw[4], cw[5], cw[6], cw[7]);
+				*(uint4 *)(mlen + q0) = make_uint4(om[0], om[1], om[2], om[3]);
+				((uint4 *)cand)[2 * sg] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+				((uint4 *)cand)[2 * sg + 1] = make_uint4(cw[4], cw[5], cw[6], cw[7]);
 			}
 		}
 		__syncthreads();
@@ -1183,6 +1254,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		// ---- parse pass 1: speculative walk of segment s from its own start ----
 		// The 16 stored lengths of the segment (+1 for the lazy look-ahead) are fetched with one
 		// 16-byte LDS read and the walk runs out of registers.
+		uint32_t sm0 = 0, sm1 = 0, sm2 = 0, sm3 = 0;          // final stored lengths (len-3, 0 = none) of my 16 positions
 		uint32_t seg_next = 0, seg_nz = 0;
 		uint32_t mm1 = 0, lit1 = 0;                            // what the speculative walk visits: match / literal token starts (16 bits)
 		uint32_t lastd = 0;                                    // distance - 1 of its last match
@@ -1200,7 +1272,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 			const uint32_t len = full < limit - p ? full : limit - p;
 			is_match = false;
 			if (full >= 4 && len >= 3) {
-				if (len < LAZY_MAX && p + 1 < limit) {
+				if (len < lazy_max && p + 1 < limit) {
 					uint32_t m2 = seg_m(k + 1);
 					uint32_t l2 = m2 ? m2 + 3 : 0;
 					if (l2 > limit - p - 1) l2 = limit - p - 1;
@@ -1212,6 +1284,10 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 			return 1;
 		};
 		if ((uint32_t)t < nseg) {
+			{
+				const uint4 mv = *(const uint4 *)(mlen + p0);
+				sm0 = mv.x; sm1 = mv.y; sm2 = mv.z; sm3 = mv.w;
+			}
 			seg_next = p0 + 16 < tn ? mlen[p0 + 16] : 0;
 			// 16-bit mask of positions that have a match (non-zero byte), 4 bits per dword
 			auto nz4 = [](uint32_t w) -> uint32_t {

@@ -39,3 +39,8 @@ for i, name in enumerate(NAMES):
     print("%-20s %10.0f cycles/block  %5.1f%%" % (name, p[i], 100 * p[i] / tot))
 print("match waves, wave-cycles per block: waiting for the chain %.0f, M1 %.0f, M2 in the loop %.0f, M2 leftovers %.0f" % (p[16], p[17], p[18], p[19]))
 print("total %.0f cycles/block (s_memtime ticks = 100 MHz? see guide)" % tot)
+if p[32:48].any():
+    N2 = ["level2 calls", "level2 entries", "group rounds", "tails settled by a group", "rounds that found no group", "batches to the lane-per-tail loop", "its trips",
+          "tails in it", "batches to the 16-lanes-per-tail path", "its steps", "level1 calls", "level1 entries", "members found in level 2", "batches the gate turned away", "tails in the 16-lane path"]
+    for i, name in enumerate(N2):
+        print("%-40s %10.1f per block" % (name, p[32 + i]))
