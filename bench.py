@@ -443,7 +443,9 @@ def run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng):
     r = eng.results_to_host(res)
     if not ((r["cc"] == 0) | (r["cc"] == 64)).all():
         raise SystemExit("corpus: engine reported errors %s" % np.unique(r["cc"]))
-    u_bytes, c_bytes = float(lens.astype(np.float64).sum()), float(r["tpbc"].astype(np.float64).sum())
+    # a block that did not shrink (cc 64) leaves the library as a stored block, 5 bytes of header (lib/nx_deflate.c:1274-1282)
+    out_bytes = np.where(r["cc"] == 64, lens.astype(np.int64) + 5, r["tpbc"].astype(np.int64))
+    u_bytes, c_bytes = float(lens.astype(np.float64).sum()), float(out_bytes.astype(np.float64).sum())
     # every output inflates back (on the device, full size) -- on every rank
     back = torch.zeros((n, BLOCK), dtype=torch.uint8, device=dev)
     jobs2 = eng.jobs_strided(dst, STRIDE_OUT, r["tpbc"].astype(np.uint32), back, BLOCK, BLOCK)
@@ -463,25 +465,36 @@ def run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng):
         c = zlib.compressobj(1, zlib.DEFLATED, -15)
         z = len(c.compress(b) + c.flush())
         a = per.setdefault(cls, [0, 0, 0])
-        a[0] += len(b); a[1] += int(r["tpbc"][i]); a[2] += z
+        a[0] += len(b); a[1] += int(out_bytes[i]); a[2] += z
     classes = {k: {"bytes": v[0], "ratio": round(v[0] / v[1], 4), "zlib1_ratio": round(v[0] / v[2], 4),
                    "vs_zlib1": round(v[2] / v[1], 4)} for k, v in sorted(per.items())}
     tot = [sum(v[i] for v in per.values()) for i in range(3)]
-    # the rate by class (the kernel's time depends on the data: 4096 jobs of every class, outside the timed region)
+    # the rate by class (the kernel's time depends on the data), outside the timed region: the headline's own buffers and job
+    # count filled with the full blocks of one class at a time, so that a class is launched in the same chunks as the headline
+    # (round 4 timed 4096 jobs in one 8192-job chunk: the tail of that one short launch read 4 % low)
+    src_u = src[:uniq].clone()
+    m = n if args.class_jobs <= 0 else min(args.class_jobs, n)
+    full_lens = np.full(m, BLOCK, np.uint32)
     for cls in classes:
         idx = [i for i, (c, _, b) in enumerate(blocks) if c == cls and len(b) == BLOCK]
         if not idx:
             continue
-        m = min(4096, n)                                   # (dst has n rows)
         sel = torch.from_numpy(np.array([idx[i % len(idx)] for i in range(m)], np.int64)).to(dev)
-        src_c = src[:uniq].index_select(0, sel).contiguous()
-        dst_c = dst[:m]
-        jobs_c = eng.jobs_strided(src_c, BLOCK, np.full(m, BLOCK, np.uint32), dst_c, STRIDE_OUT, STRIDE_OUT)
-        res_c = torch.empty(m * pkg.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-        ms_c, st_c, _ = timed_compress(torch, eng, pkg.FC_COMPRESS_DHTGEN, jobs_c, m, res_c, 3, 1)
+        torch.index_select(src_u, 0, sel, out=src[:m])
+        jobs_c = eng.jobs_strided(src[:m], BLOCK, full_lens, dst[:m], STRIDE_OUT, STRIDE_OUT)
+        ms_c, st_c, _ = timed_compress(torch, eng, pkg.FC_COMPRESS_DHTGEN, jobs_c, m, res, 2, 1)
         classes[cls]["GiB_s"] = round(m * BLOCK / (ms_c * 1e-3) / 2.0 ** 30, 1)
         classes[cls]["lz77_ms"] = round(st_c[0], 3); classes[cls]["jobs_timed"] = m
-        del src_c, jobs_c, res_c
+        del jobs_c, sel
+    del src_u
+    # what these rates say about the metric's own corpus: the twelve Silesia files by their published sizes, each at the rate
+    # of the class of this corpus that stands in for it (tests/corpus.py: SILESIA_AS_FALLBACK_CLASS)
+    silesia = None
+    if name != "silesia" and all(classes.get(c, {}).get("GiB_s") for c in set(corpus.SILESIA_AS_FALLBACK_CLASS.values())):
+        tot_b = float(sum(corpus.SILESIA_BYTES.values()))
+        secs = sum(corpus.SILESIA_BYTES[f] / classes[corpus.SILESIA_AS_FALLBACK_CLASS[f]]["GiB_s"] for f in corpus.SILESIA_BYTES)
+        silesia = {"value": round(tot_b / secs, 1), "unit": "GiB/s", "how": "12 files x published size / rate of the stand-in class (time-weighted)",
+                   "class_of_file": corpus.SILESIA_AS_FALLBACK_CLASS}
     peak_m = copy_peak_gbs(torch, dev)
     line = {
         "metric": "GiB/s uncompressed in (deflate), real-data corpus in 64 KiB blocks, exact dynamic-Huffman table per block",
@@ -497,11 +510,16 @@ def run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng):
                                "entropy) of the %s corpus cut at 64 KiB, %d jobs per GPU (%d unique blocks), device resident" % (name, n, uniq),
                    "corpus": name, "corpus_files": report, "unique_blocks": uniq, "jobs_per_gpu": n, "block_bytes": BLOCK,
                    "ratio": round(tot[0] / tot[1], 4), "zlib1_ratio": round(tot[0] / tot[2], 4), "ratio_vs_zlib1": round(tot[2] / tot[1], 4),
-                   "min_class_vs_zlib1": min(v["vs_zlib1"] for v in classes.values()), "classes": classes,
+                   "min_class_vs_zlib1": min(v["vs_zlib1"] for v in classes.values()),
+                   "min_class_GiB_s": min((v["GiB_s"] for v in classes.values() if "GiB_s" in v), default=None),
+                   "silesia_weighted_GiB_s": silesia, "classes": classes,
                    "roundtrip_bit_exact": True, "zlib_inflated_sample": min(uniq, 400), "parallelism": "shard%d" % world},
         "roofline": roofline(u_bytes, c_bytes, st, launches, pmc_traffic(n, "dhtgen"),
                              "nxzl77::lz77_kernel<true> (dominant) + nxzd::dhtgen_kernel + nxze::encode_kernel<true>", peak_m),
     }
+    if world > 1:
+        # a scaling line: the legs that belong to one GPU's report are left out, and the line says so
+        line["legs_skipped"] = ["cpu_baseline", "inflate_zlib6", "inflate_stream", "api", "c2", "c5"]
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_deflate(raw, "default", 10.0)
         line["cpu_baseline"]["parity_checked_blocks"] = oracle_parity(raw, out_u, r["tpbc"], True, k=64)
@@ -517,8 +535,7 @@ def run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng):
         if not args.no_c2:
             torch.cuda.empty_cache()
             # configs[1] at its stated size (2^20 blocks: 136 GiB of buffers + scratch) when the device has the room, else 2^18
-            free_b, _ = torch.cuda.mem_get_info(dev)
-            n_c2 = args.blocks or ((1 << 20) if free_b > (212 << 30) else (1 << 18))   # source + target + the inflate leg's buffer + scratch
+            n_c2 = args.blocks or c2_default_blocks(torch, dev)
             line["c2"] = c2_measure(torch, dist, args, 0, 1, dev, False, pkg, eng, n_c2, max(2, args.steps // 2), 1)
         if not args.no_c5:
             torch.cuda.empty_cache()
@@ -894,6 +911,13 @@ def c5_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, total
     return line
 
 
+def c2_default_blocks(torch, dev):
+    """configs[1] at its stated size (2^20 blocks: source + target + the inflate leg's buffer + scratch = 212 GiB) when THIS
+    device has that much free, else 2^18 (a shared or smaller device must not die in torch.empty)"""
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    return (1 << 20) if free_b > (212 << 30) else (1 << 18)
+
+
 def c2_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, n, steps, warmup):
     """BASELINE configs[1]: fixed-Huffman deflate of n synthetic 64 KiB blocks per GPU (weak scaling); the JSON
     line (rank 0) or None."""
@@ -1051,6 +1075,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="c2: 64 KiB blocks per GPU (default 2^20 = 64 GiB; as the side object of the default "
                                                          "config 2^18); c5: total blocks (default 163840 = 10 GiB)")
     ap.add_argument("--corpus-jobs", type=int, default=262144, help="jobs per GPU of the corpus config (the corpus is replicated)")
+    ap.add_argument("--class-jobs", type=int, default=0, help="corpus config: jobs of the per-class legs (0 = as many as the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inflate", action="store_true", help="skip the inflate legs")
     ap.add_argument("--no-api", action="store_true", help="skip the host-buffer API leg")
@@ -1086,7 +1111,13 @@ def main():
         if line:
             print(json.dumps(line), flush=True)
     elif args.config == "c2":
-        line = c2_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, args.blocks or (1 << 20), args.steps, args.warmup)
+        n_c2 = args.blocks or c2_default_blocks(torch, dev)
+        if distributed and not args.blocks:
+            # every rank the same count (weak scaling): the smallest any rank has room for
+            t = torch.tensor([n_c2], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            n_c2 = int(t.item())
+        line = c2_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, n_c2, args.steps, args.warmup)
         if line:
             print(json.dumps(line), flush=True)
     else:

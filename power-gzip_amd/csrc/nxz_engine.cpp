@@ -39,7 +39,8 @@ static void set_err(const char *what, hipError_t e)
 
 extern "C" const char *nxz_last_error(void) { return g_err; }
 extern "C" size_t nxz_pinflate_trim(void);
-extern "C" size_t nxz_trim(void) { return nxz_pinflate_trim(); }
+static size_t trim_compress_scratch();
+extern "C" size_t nxz_trim(void) { return nxz_pinflate_trim() + trim_compress_scratch(); }
 extern "C" const char *nxz_engine_version(void) { return NXZ_VERSION; }
 extern "C" size_t nxz_compress_bound(size_t n) { return ((n * 9 + 7) / 8 + 16 + 15) & ~(size_t)15; }
 
@@ -85,6 +86,25 @@ struct nxz_ctx {
 		uint32_t *d_counts = nullptr;             // symbol counts when the caller did not ask for them
 		uint16_t *d_cand2 = nullptr;              // LZ77 kernel: second bucket entries in transit, 32 KiB per workgroup
 		size_t chunk_cap = 0;
+		size_t chunk_limit = 0;                   // jobs per chunk the device had room for when a larger chunk could not be had (0: no such failure yet)
+		void release_chunk() {
+			if (d_tokens) (void)hipFree(d_tokens);
+			if (d_gen) (void)hipFree(d_gen);
+			if (d_counts) (void)hipFree(d_counts);
+			d_tokens = nullptr; d_gen = nullptr; d_counts = nullptr; chunk_cap = 0;
+		}
+		// the three buffers of a chunk, all or none
+		bool alloc_chunk(size_t chunk) {
+			if (hipMalloc((void **)&d_tokens, chunk * (size_t)NXZ_TOK_STRIDE) == hipSuccess &&
+			    hipMalloc((void **)&d_gen, chunk * sizeof(nxz_dht_prepared_t)) == hipSuccess &&
+			    hipMalloc((void **)&d_counts, chunk * 316 * sizeof(uint32_t)) == hipSuccess) {
+				chunk_cap = chunk;
+				return true;
+			}
+			(void)hipGetLastError();
+			release_chunk();
+			return false;
+		}
 		void release() {
 			if (d_prepared) (void)hipFree(d_prepared);
 			if (d_lanes_ws) (void)hipFree(d_lanes_ws);
@@ -366,20 +386,27 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 	{
 		std::lock_guard<std::mutex> g(c->mtx);
 		nxz_ctx::Scratch &r = c->scratch[s];
+		if (!fused && r.chunk_limit && want > r.chunk_limit) {
+			// a larger chunk could not be had on this device a call ago: not tried again before nxz_trim()
+			want = r.chunk_limit; nchunks = (n + want - 1) / want; chunk = (n + nchunks - 1) / nchunks;
+		}
 		if (!fused && r.chunk_cap < chunk) {
-			// grows only: warm up once with the largest batch before timing a loop
-			if (r.d_tokens) { (void)hipStreamSynchronize(s); (void)hipFree(r.d_tokens); (void)hipFree(r.d_gen); (void)hipFree(r.d_counts); }
-			r.d_tokens = nullptr; r.d_gen = nullptr; r.d_counts = nullptr; r.chunk_cap = 0;
-			if (hipMalloc((void **)&r.d_tokens, chunk * (size_t)NXZ_TOK_STRIDE) != hipSuccess && want > 8192) {
-				// no room for the large chunk: the small one
-				(void)hipGetLastError();
-				r.d_tokens = nullptr;
-				want = 8192; nchunks = (n + want - 1) / want; chunk = (n + nchunks - 1) / nchunks;
+			// grows only: warm up once with the largest batch before timing a loop.  The scratch of a chunk (104 KiB of
+			// tokens + a table + the counts per job) takes no more than a quarter of what the device has free right now.
+			if (r.d_tokens) { (void)hipStreamSynchronize(s); r.release_chunk(); }
+			const size_t per_job = (size_t)NXZ_TOK_STRIDE + sizeof(nxz_dht_prepared_t) + 316 * sizeof(uint32_t);
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > 8192 && chunk * per_job > free_b / 4) {
+				while (want > 8192 && want * per_job > free_b / 4) want /= 2;
+				nchunks = (n + want - 1) / want; chunk = (n + nchunks - 1) / nchunks;
+				r.chunk_limit = want;
 			}
-			if (!r.d_tokens) HIPCHK(hipMalloc((void **)&r.d_tokens, chunk * (size_t)NXZ_TOK_STRIDE), return -ENOMEM);
-			HIPCHK(hipMalloc((void **)&r.d_gen, chunk * sizeof(nxz_dht_prepared_t)), return -ENOMEM);
-			HIPCHK(hipMalloc((void **)&r.d_counts, chunk * 316 * sizeof(uint32_t)), return -ENOMEM);
-			r.chunk_cap = chunk;
+			while (!r.alloc_chunk(chunk)) {
+				if (want <= 1024) return -ENOMEM;
+				want = want > 8192 ? 8192 : want / 2;          // no room for the large chunk: the small one, then halves of it
+				nchunks = (n + want - 1) / want; chunk = (n + nchunks - 1) / nchunks;
+				r.chunk_limit = want;
+			}
 		}
 		if (!r.d_cand2) HIPCHK(hipMalloc((void **)&r.d_cand2, nxz_lz77_cand2_bytes()), return -ENOMEM);
 		if (isdht && !gen && r.prepared_cap < ntables) {
@@ -427,6 +454,36 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 		stamp();
 	}
 	return 0;
+}
+
+// nxz_trim(): the token scratch of every stream no batch call is working on goes back to the device (a chunk of 65536 jobs
+// is 6.6 GiB), and a remembered "no room for more than N jobs a chunk" is forgotten.  Returns the bytes freed.
+static size_t trim_compress_scratch()
+{
+	size_t freed = 0;
+	std::lock_guard<std::mutex> g(g_mtx);
+	for (nxz_ctx *c : g_ctx) {
+		if (!c) continue;
+		(void)hipSetDevice(c->device);
+		std::vector<std::pair<hipStream_t, std::mutex *>> streams;
+		{
+			std::lock_guard<std::mutex> g2(c->mtx);
+			for (auto &kv : c->scratch) streams.emplace_back(kv.first, &c->scratch_use[kv.first]);
+		}
+		for (auto &sm : streams) {
+			if (!sm.second->try_lock()) continue;              // a call is sizing or launching on that stream
+			(void)hipStreamSynchronize(sm.first);
+			{
+				std::lock_guard<std::mutex> g2(c->mtx);
+				nxz_ctx::Scratch &r = c->scratch[sm.first];
+				if (r.d_tokens) freed += r.chunk_cap * ((size_t)NXZ_TOK_STRIDE + sizeof(nxz_dht_prepared_t) + 316 * sizeof(uint32_t));
+				r.release_chunk();
+				r.chunk_limit = 0;
+			}
+			sm.second->unlock();
+		}
+	}
+	return freed;
 }
 
 // Measurement aid: with timing on, every compress batch records events around its kernels;

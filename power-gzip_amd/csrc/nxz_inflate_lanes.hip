@@ -22,10 +22,15 @@ namespace nxzl {
 
 #ifndef NXZ_LANES_LB
 #define NXZ_LANES_LB 10
+#endif
+#ifndef NXZ_LANES_DB
 #define NXZ_LANES_DB 8
 #endif
 constexpr int LB = NXZ_LANES_LB, DB = NXZ_LANES_DB;  // fast-table index bits
 constexpr uint32_t WS_LIT = 0, WS_DIST = 2048, WS_LCNT = 2560, WS_LSYM = 2592, WS_DCNT = 3168, WS_DSYM = 3200;
+static_assert((2u << LB) <= WS_DIST - WS_LIT && (2u << DB) <= WS_LCNT - WS_DIST, "the fast tables (16-bit entries) must fit their slices of the lane's table set");
+// (decode_long's packed counts: 9 bits a length for the literal/length code, 5 for the distance code -- every parser of this
+// engine, like zlib, turns HDIST > 30 away, so no length has more than 30 distance codes)
 constexpr uint32_t WS_LPK = 3264, WS_DPK = 3280;     // 16 bytes each: what the walk for codes longer than the fast table needs, packed (decode_long)
 constexpr uint32_t WS_LENS = 320;                     // code lengths of the block being set up (last part of a slot)
 constexpr uint32_t WS_BYTES = 3328 + WS_LENS;
@@ -264,8 +269,6 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 					uint64_t clp = 0;
 					for (int i = 0; i < hclen && !rc; i++) {
 						if (!have(3)) { rc = 1; break; }
-						const uint64_t order = 0x0F0E0D0C0B0A0908ull;   // unused (kept simple below)
-						(void)order;
 						static const uint8_t ord[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
 						clp |= (uint64_t)r.take(3) << (3 * ord[i]);
 					}

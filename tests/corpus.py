@@ -11,7 +11,10 @@ of a file is short), from the first source that is present:
   2. else a deterministic fallback that exists on any box of this image: alice29.txt (the
      reference's samples/alice29.txt, committed as the data fixture tests/golden/alice29.txt,
      sha256 pinned in SURVEY 8(d)) plus the first 4 MiB of a recorded list of system files of
-     several kinds (ELF, XML, JSON, tables, sources, msgpack, font, base64).  Every entry carries
+     several kinds (ELF, XML, JSON, tables, sources, msgpack, font, base64; since round 5 also an
+     image-like kind -- binary tables of 16- and 32-bit values that zlib -1 brings down to 1.5-1.8 : 1,
+     what Silesia's mr / x-ray / sao are -- and a packed kind that hardly shrinks at all: a zip and a
+     compressed code object).  Every entry carries
      the sha256 of the bytes used; a file that is missing or differs is skipped and reported.
 
 Test infrastructure and bench.py's corpus leg only.
@@ -55,7 +58,20 @@ FALLBACK = [   # (class, path, bytes used, sha256 of those bytes) -- recorded in
     ("base64", "/etc/ssl/certs/ca-certificates.crt", 222392, "3a8b34c06e15fb1172bb8d0b7bc2eaf83433ebfd4bfc467e1099468fe4a51061"),
     ("source", "/usr/lib/python3.10/typing.py", 92557, "ec7b7f73fc92827c78a7d2aff90cffe070530cad6c693460165c26f76d195f41"),
     ("source", "/opt/rocm/include/hip/amd_detail/amd_hip_runtime.h", 14276, "e51a973fd5dd9e07300cb7c5a51fbd2059531abc33f67a45d7fe7cdef79552c8"),
+    ("image", "/usr/lib/x86_64-linux-gnu/libicudata.so.70", 4194304, "a8419487114b78f91ca7454ee4444efca74934a7b3a130fe6911b8745022aa63"),
+    ("image", "/usr/lib/x86_64-linux-gnu/gconv/libCNS.so", 473096, "626ff0bd6f6c82866cd5be2ba12c01586566123f9cde41a5a1be9d3e3d9f4d94"),
+    ("packed", "/usr/local/lib/python3.10/dist-packages/scipy/special/tests/data/boost.npz", 1270643, "d73ecbbb51654522342ba0470a6263a9684e617c2b8374565fe3a79593f4b231"),
+    ("packed", "/opt/rocm/lib/hipblaslt/library/TensileLibrary_B8F8_SB8F8_HA_Bias_SAB_SAV_UA_Type_B8S_HPA_Contraction_l_Ailk_Bljk_Cijk_Dijk_gfx950.co", 1227962, "77e54e7a7b33c8bd91b5a88ff0c7af69046eb4e8f925086e72c3c363ecc7d27b"),
 ]
+
+# The twelve files of the Silesia corpus: published size in bytes, and the class of THIS corpus whose measured rate stands in
+# for it when bench.py says what the engine would read on Silesia (config.silesia_weighted_GiB_s).  Where no class is close
+# the slowest binary one is taken (osdb: a MySQL table file; reymont: a PDF -- Polish text above 0x7f, rule 3c does not see
+# it as text).
+SILESIA_BYTES = {"dickens": 10192446, "mozilla": 51220480, "mr": 9970564, "nci": 33553445, "ooffice": 6152192, "osdb": 10085684,
+                 "reymont": 6627202, "samba": 21606400, "sao": 7251944, "webster": 41458703, "x-ray": 8474240, "xml": 5345280}
+SILESIA_AS_FALLBACK_CLASS = {"dickens": "text", "webster": "text", "mozilla": "elf", "ooffice": "elf", "osdb": "elf", "reymont": "elf",
+                             "samba": "source", "nci": "table", "xml": "xml", "mr": "image", "x-ray": "image", "sao": "image"}
 
 
 def _cut(cls, name, data, block):

@@ -865,3 +865,78 @@ def test_second_entries_switch_follows_the_first_tile(eng):
     for i, b in enumerate(withh):
         exp, bits = O.deflate_fixed(b, hist=len(hist))
         assert r["tpbc"][i] == len(exp) and out[i, :len(exp)].tobytes() == exp, i
+
+
+def test_text_rule_follows_the_first_tile(eng):
+    """oracle/nxz_lz77.c step 3c: a sub-block whose first tile has fewer than one byte in 16 with its top bit set and
+    made 3072 tokens or more does without the second entries and without the lazy step in its later tiles.  Blocks on
+    both sides of the byte threshold (1023 / 1024 such bytes in 16384), bytes above 0x7f only behind the first tile, a
+    block shorter than a tile, easy text (few tokens), with and without history: byte for byte the oracle's."""
+    import torch
+    rnd = np.random.RandomState(9)
+    text = make_block("alice", 65536, seed=3) + make_block("text33", 65536, seed=4) + make_block("alice", 65536, seed=8)
+
+    def with_high(b, k, lo, hi):
+        b = bytearray(b)
+        for p in rnd.choice(hi - lo, k, replace=False):
+            b[lo + p] |= 0x80
+        return bytes(b)
+
+    blocks = [text[:65536], with_high(text[300:65836], 1023, 0, 16384), with_high(text[300:65836], 1024, 0, 16384),
+              with_high(text[700:66236], 1100, 0, 16384), with_high(text[900:66436], 9000, 16384, 65536),
+              text[2000:12000], with_high(text[2000:12000], 624, 0, 10000), with_high(text[2000:12000], 625, 0, 10000),
+              (b"key = value; " * 6000)[:65536], text[40000:40000 + 16384 + 5], text[50000:50000 + 32768]]
+    src = pack_blocks(eng, blocks, STRIDE_IN)
+    lens = np.array([len(b) for b in blocks], np.uint32)
+    for fc in (pkg.FC_COMPRESS_FHT, pkg.FC_COMPRESS_DHTGEN):
+        dst = torch.zeros((len(blocks), STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+        jobs = eng.jobs_strided(src, STRIDE_IN, lens, dst, STRIDE_OUT, STRIDE_OUT)
+        res, _ = eng.compress(fc, jobs, len(blocks))
+        r = eng.results_to_host(res)
+        out = dst.cpu().numpy()
+        for i, b in enumerate(blocks):
+            if fc == pkg.FC_COMPRESS_FHT:
+                exp, bits = O.deflate_fixed(b)
+            else:
+                tok, nt = O.lz77(b)
+                ll, d = O.counts(tok, nt)
+                dht, dhtlen = O.dhtgen(ll, d)
+                exp, bits = O.deflate_dynamic(b, dht, dhtlen)
+            assert r["cc"][i] == 0 and r["tpbc"][i] == len(exp), (fc, i)
+            assert out[i, :len(exp)].tobytes() == exp, (fc, i)
+            dz = zlib.decompressobj(-15)
+            assert dz.decompress(exp) == b and dz.eof
+    hist = text[5000:5000 + 16384]
+    withh = [hist + b[:65536 - len(hist)] for b in blocks[:5]]
+    src = pack_blocks(eng, withh, STRIDE_IN)
+    dst = torch.zeros((len(withh), STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+    jobs = eng.jobs_strided(src, STRIDE_IN, np.full(len(withh), 65536, np.uint32), dst, STRIDE_OUT, STRIDE_OUT,
+                            hist_len=np.full(len(withh), len(hist), np.uint32))
+    res, _ = eng.compress(pkg.FC_COMPRESS_RESUME_FHT, jobs, len(withh))
+    r = eng.results_to_host(res)
+    out = dst.cpu().numpy()
+    for i, b in enumerate(withh):
+        exp, bits = O.deflate_fixed(b, hist=len(hist))
+        assert r["tpbc"][i] == len(exp) and out[i, :len(exp)].tobytes() == exp, i
+
+
+def test_trim_gives_the_token_scratch_back_and_the_next_batch_works(eng):
+    """nxz_trim(): the scratch a dynamic-table batch left on its stream (tokens, tables, counts of a chunk) goes back to
+    the device; the next batch allocates again and gives the same bytes."""
+    import torch
+    blocks = [make_block(k, 65536, seed=70 + i) for i, k in enumerate(["alice", "lz", "binary", "text33"] * 8)]
+    src = pack_blocks(eng, blocks, STRIDE_IN)
+    lens = np.full(len(blocks), 65536, np.uint32)
+    outs = []
+    for rnd in range(2):
+        dst = torch.zeros((len(blocks), STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+        jobs = eng.jobs_strided(src, STRIDE_IN, lens, dst, STRIDE_OUT, STRIDE_OUT)
+        res, _ = eng.compress(pkg.FC_COMPRESS_DHTGEN, jobs, len(blocks))
+        r = eng.results_to_host(res)
+        assert (r["cc"] == 0).all()
+        outs.append((r["tpbc"].copy(), dst.cpu().numpy().copy()))
+        if rnd == 0:
+            eng.L.nxz_trim.restype = C.c_size_t
+            freed = eng.L.nxz_trim()
+            assert freed >= len(blocks) * 106496, freed
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()

@@ -17,7 +17,8 @@ def kname(s):
 
 
 def ours(k):
-    return "nxz" in k
+    # the engine's kernels, and the library kernels it launches itself (the radix sort of the inflate batches' job order)
+    return "nxz" in k or "rocprim" in k or "hipcub" in k
 
 
 def leg_info(leg, p):
