@@ -72,6 +72,12 @@ int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_batch_result_t
 			   uint64_t *offsets, uint8_t *packed, hipStream_t stream);
 int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);   /* items: { src, dst, uint64 bytes } */
 size_t nxz_inflate_lanes_workspace(size_t n);
+/* nxz_inflate_cut.hip: a batch too small to fill the device a stream per wavefront -- every stream cut inside its first block */
+unsigned nxz_inflate_cut_pieces(size_t n);                                   /* pieces per stream for a batch of n (below 2: not worth it) */
+size_t nxz_inflate_cut_workspace(size_t n, unsigned pieces, size_t arena);   /* device bytes: control arrays + `arena` bytes for the pieces' elements */
+int nxz_launch_copy_out(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, uint8_t *const *targets, size_t n, hipStream_t stream);   /* results[i].tpbc bytes of jobs[i].dst -> targets[i] */
+int nxz_launch_inflate_cut(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io,
+			   unsigned pieces, uint8_t *workspace, size_t arena, hipStream_t stream);
 int nxz_launch_pack_members(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n,
 			    uint64_t *offsets, uint8_t *packed, hipStream_t stream);
 int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,

@@ -80,6 +80,8 @@ struct nxz_ctx {
 		size_t lanes_cap = 0;
 		uint8_t *d_order_ws = nullptr;            // the jobs' order by length for the stream-per-wave kernel's larger batches
 		size_t order_cap = 0;
+		uint8_t *d_cut_ws = nullptr;              // small inflate batches cut into pieces (nxz_inflate_cut.hip): control arrays + the pieces' elements
+		size_t cut_cap = 0;
 		// compress: what the LZ77 kernel hands to the entropy kernel, for one chunk of jobs
 		uint8_t *d_tokens = nullptr;              // chunk x NXZ_TOK_STRIDE
 		nxz_dht_prepared_t *d_gen = nullptr;      // tables the device generated, one per job of the chunk
@@ -109,6 +111,7 @@ struct nxz_ctx {
 			if (d_prepared) (void)hipFree(d_prepared);
 			if (d_lanes_ws) (void)hipFree(d_lanes_ws);
 			if (d_order_ws) (void)hipFree(d_order_ws);
+			if (d_cut_ws) (void)hipFree(d_cut_ws);
 			if (d_tokens) (void)hipFree(d_tokens);
 			if (d_gen) (void)hipFree(d_gen);
 			if (d_counts) (void)hipFree(d_counts);
@@ -144,6 +147,9 @@ struct nxz_ctx {
 		uint8_t *d_tok = nullptr;
 		uint16_t *d_cand2 = nullptr;
 		uint8_t *d_src = nullptr;                 // the sources, brought over by one copy kernel (two kernels read them)
+		uint8_t *d_cut = nullptr;                 // decompress rounds: the workspace of nxz_inflate_cut.hip (made when first used)
+		size_t cut_arena = 0;
+		uint8_t **h_targets = nullptr;            // ... and where the jobs' outputs go from the device buffers they are decoded into
 		struct Item { const uint8_t *src; uint8_t *dst; uint64_t bytes; } *h_items = nullptr;
 		bool busy = false, ready = false;
 	} rounds[16];
@@ -587,6 +593,47 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 			ws = sc.d_lanes_ws;
 		}
 		rc = nxz_launch_inflate_lanes(jobs, n, results, dht_io, ws, init | (by_len ? 2 : 0) | (no_tables ? 4 : 0), s);
+	} else if ([&]() -> bool {
+		// A batch that does not fill the device a stream per wavefront (5120 at a time, each as slow as 20-100 MB/s): every stream
+		// is cut inside its first block and the pieces go side by side (nxz_inflate_cut.hip; zlib -6 streams of the corpus, 4096
+		// of them: 28.6 GiB/s a stream per wavefront).  NXZ_INFLATE_CUT=0 / 1: never / whenever two pieces a stream are allowed.
+		const char *ce = getenv("NXZ_INFLATE_CUT");
+		const int cut_env = ce ? atoi(ce) : -1;
+		if (cut_env == 0) return false;
+		unsigned P = nxz_inflate_cut_pieces(n);
+		// (left to itself: batches of 64 streams at most, where a call takes as long as its slowest stream and
+		// the pieces of all of them are resident at once; larger ones lose more to the rounds -- each as long as ITS
+		// slowest piece -- than the cuts win: profiles/r05_inflate_cut_by_batch_size.txt)
+		static const size_t auto_max = getenv("NXZ_INFLATE_CUT_MAX") ? (size_t)strtoull(getenv("NXZ_INFLATE_CUT_MAX"), nullptr, 0) : 64;
+		if (cut_env < 0 && (P < 4 || n > auto_max)) return false;
+		if (P < 2) { if (cut_env <= 0) return false; P = 2; }
+		// room for the pieces' 16-bit elements: half a megabyte a stream, a quarter of what the device has free at most
+		size_t arena = n * ((size_t)512 << 10), free_b = 0, total_b = 0;
+		if (arena < ((size_t)256 << 20)) arena = (size_t)256 << 20;
+		if (arena > ((size_t)8 << 30)) arena = (size_t)8 << 30;
+		std::mutex *use_mtx;
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			use_mtx = &c->scratch_use[s];
+		}
+		std::lock_guard<std::mutex> use(*use_mtx);                         // (one call at a time per stream's scratch)
+		uint8_t *ws = nullptr;
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			nxz_ctx::Scratch &sc = c->scratch[s];
+			size_t need = nxz_inflate_cut_workspace(n, P, arena);
+			if (sc.cut_cap < need) {
+				if (sc.d_cut_ws) { (void)hipStreamSynchronize(s); (void)hipFree(sc.d_cut_ws); }
+				sc.d_cut_ws = nullptr; sc.cut_cap = 0;
+				if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && arena > free_b / 4) { arena = free_b / 4; need = nxz_inflate_cut_workspace(n, P, arena); }
+				if (arena < ((size_t)16 << 20) || hipMalloc((void **)&sc.d_cut_ws, need) != hipSuccess) { (void)hipGetLastError(); return false; }
+				sc.cut_cap = need;
+			} else arena += sc.cut_cap - need;                             // (what a larger batch left: the arena takes it)
+			ws = sc.d_cut_ws;
+		}
+		rc = nxz_launch_inflate_cut(jobs, n, results, dht_io, P, ws, arena, s);
+		return true;
+	}()) {
 	} else {
 		const char *wm = getenv("NXZ_INFLATE_LDS_MAX");                 // tuning / test knob
 		const size_t lds_max = wm ? (size_t)strtoull(wm, nullptr, 0) : (size_t)NXZ_WINDOW_LDS_MAX;
@@ -1075,6 +1122,8 @@ static void round_free(nxz_ctx::Round &r)
 	if (r.d_tok) (void)hipFree(r.d_tok);
 	if (r.d_cand2) (void)hipFree(r.d_cand2);
 	if (r.d_src) (void)hipFree(r.d_src);
+	if (r.d_cut) (void)hipFree(r.d_cut);
+	if (r.h_targets) (void)hipHostFree(r.h_targets);
 	const bool busy = r.busy;                    // (the caller's claim on the round stands)
 	r = nxz_ctx::Round();
 	r.busy = busy;
@@ -1274,6 +1323,7 @@ static int run_wrap(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j)
 // stream-per-wave inflate kernel with a wavefront per job, instead of a launch per job on a stream of
 // its own, of which the device runs only a few at a time).
 struct InflateReq {
+	uint8_t *d_out = nullptr;             // the slot's device buffer for the output (rounds that cut the streams into pieces decode into it)
 	nxz_batch_job_t job;                  // src: the slot's device buffer (filled by the round's copy kernel from h_in); dst: the slot's pinned h_out
 	const uint8_t *h_in = nullptr;        // the slot's pinned staging of the source
 	nxz_batch_dht_t *dht = nullptr;       // the slot's pinned table: in when the job resumes inside a dynamic block, out when it suspends in one
@@ -1292,7 +1342,34 @@ static int round_run_inflate(nxz_ctx *c, nxz_ctx::Round &R, std::vector<InflateR
 		R.h_dht[k] = *v[k]->dht;
 	}
 	if (nxz_launch_copy_items(R.h_items, (uint32_t)n, R.stream)) return -EIO;
-	if (nxz_launch_inflate(R.h_jobs, n, R.h_res, R.h_dht, 1, nullptr, R.stream)) return -EIO;
+	// A wavefront per job takes 0.6-3 ms for 64 KiB however few jobs there are.  Jobs of a few KiB and more are cut into
+	// pieces instead (nxz_inflate_cut.hip: 16 streams of 64 KiB 1.0-1.4 GiB/s against 0.2-0.3); those decode into the slots'
+	// device buffers -- the pieces' elements are resolved against what is already there, which pinned host memory is too
+	// far away for -- and one more kernel takes the outputs to the callers' pinned targets.  NXZ_ROUND_CUT=0: never.
+	static const bool cut_on = !(getenv("NXZ_ROUND_CUT") && atoi(getenv("NXZ_ROUND_CUT")) == 0);
+	bool cut = cut_on;
+	if (cut) {
+		size_t longish = 0;
+		for (size_t k = 0; k < n; k++) {
+			const nxz_batch_job_t &j = v[k]->job;
+			if (j.src_len - (j.hist_len < j.src_len ? j.hist_len : j.src_len) >= 4096 && v[k]->d_out) longish++;
+		}
+		cut = longish > 0;
+	}
+	const unsigned P = 32;
+	if (cut && !R.d_cut) {
+		const size_t arena = (size_t)96 << 20;
+		if (hipMalloc((void **)&R.d_cut, nxz_inflate_cut_workspace(ROUND_MAX, P, arena)) != hipSuccess || hipHostMalloc((void **)&R.h_targets, ROUND_MAX * sizeof(uint8_t *)) != hipSuccess) {
+			(void)hipGetLastError();
+			if (R.d_cut) (void)hipFree(R.d_cut);
+			R.d_cut = nullptr; cut = false;
+		} else R.cut_arena = arena;
+	}
+	if (cut) {
+		for (size_t k = 0; k < n; k++) { R.h_targets[k] = R.h_jobs[k].dst; R.h_jobs[k].dst = v[k]->d_out; }
+		if (nxz_launch_inflate_cut(R.h_jobs, n, R.h_res, R.h_dht, P, R.d_cut, R.cut_arena, R.stream)) return -EIO;
+		if (nxz_launch_copy_out(R.h_jobs, R.h_res, R.h_targets, n, R.stream)) return -EIO;
+	} else if (nxz_launch_inflate(R.h_jobs, n, R.h_res, R.h_dht, 1, nullptr, R.stream)) return -EIO;
 	HIPCHK(hipStreamSynchronize(R.stream), return -EIO);
 	for (size_t k = 0; k < n; k++) {
 		v[k]->res = R.h_res[k];
@@ -1352,7 +1429,7 @@ static int run_decompress(nxz_ctx *c, Slot *s, nxz_crb_cpb_t *j, uint32_t fc)
 			memcpy(s->h_dht->dht, j->cpb.in_dht, NXZ_DHT_MAXSZ);
 		}
 	}
-	req.h_in = s->h_in; req.dht = s->h_dht;
+	req.h_in = s->h_in; req.dht = s->h_dht; req.d_out = s->d_out;
 	const uint64_t td0 = g_trace.on ? trace_ns() : 0;
 	{
 		const int rrc = round_submit_inflate(c, &req);

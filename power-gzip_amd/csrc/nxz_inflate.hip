@@ -28,6 +28,7 @@
 #include <type_traits>
 #include <stdint.h>
 #include "nxz_device.h"
+#include "nxz_inflate_tables.h"
 
 namespace nxzi {
 
@@ -47,18 +48,7 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 constexpr uint32_t WIN = 32768, WMASK = WIN - 1;
 constexpr uint32_t FLUSH = 16384;
 constexpr uint32_t STAGE = 512;              // staged compressed bytes (one-token path and headers only)
-constexpr int LBITS = 11, DBITS = 9;
-
-struct Huff {
-	uint16_t fast[1 << LBITS];   // symbol | len << 12 ; 0 = use slow path
-	uint16_t sym[288];           // symbols sorted by (len, symbol)
-	uint16_t count[16];
-};
-struct HuffD {
-	uint16_t fast[1 << DBITS];
-	uint16_t sym[32];
-	uint16_t count[16];
-};
+// (LBITS, DBITS, Huff, HuffD: nxz_inflate_tables.h)
 
 // GW: the window is the target itself (and the history in front of the source) in global memory,
 // for batches: 7.6 KiB of LDS per stream instead of 39.5, so 16 streams per CU instead of 4.
@@ -75,14 +65,6 @@ struct SmemT {
 	uint8_t cl[32];
 };
 
-// The decode tables of a dynamic block as they stand in LDS, kept in device memory: built once per block
-// (block_tables_kernel) for everything that starts inside the block -- the requests of token_sync_kernel,
-// the pieces that begin at a cut -- to load instead of reading the header and building them again.
-struct __attribute__((aligned(16))) Built {
-	Huff hl;
-	HuffD hd;
-	uint32_t ok, bfinal, end_bit, pad;         // end_bit: first bit behind the header, counted from the request's src (0: header not in the source)
-};
 static_assert(sizeof(Huff) % 16 == 0 && sizeof(HuffD) % 16 == 0 && sizeof(Built) % 16 == 0, "tables are copied 16 bytes a lane");
 
 template <typename Smem>
@@ -401,6 +383,7 @@ __device__ __forceinline__ void inflate_body(const nxz_batch_job_t *__restrict__
 	// order (may be NULL): the jobs by falling source length -- a launch of a few rounds of wavefronts ends with its slowest
 	// stream, which had better be among the first to start (nxz_launch_inflate)
 	const uint32_t jid = order ? order[blockIdx.x] : blockIdx.x;
+	if (jid == 0xffffffffu) return;                      // (a slot of the order that holds no job: nxz_inflate_cut.hip)
 	const nxz_batch_job_t job = jobs[jid];
 	// (pieces of a stream come longest first, and the launch ends with its slowest piece: the sixteenth of them in front
 	// gets the instruction issue of its SIMD before the others, the next quarter before the rest)
@@ -1196,6 +1179,19 @@ extern "C" int nxz_launch_token_sync(const nxz_sync_req_t *breqs, uint32_t nb, n
 	if (!n || !nb) return 0;
 	hipLaunchKernelGGL(nxzi::block_tables_kernel, dim3(nb), dim3(64), 0, stream, breqs, tables, (nxzi::Built *)built);
 	hipLaunchKernelGGL(nxzi::token_sync_kernel, dim3(n), dim3(64), 0, stream, reqs, res, (const nxzi::Built *)built);
+	return (int)hipGetLastError();
+}
+
+// pieces of many streams (nxz_inflate_cut.hip): the jobs `order` names, slots of 0xffffffff are none
+extern "C" int nxz_launch_inflate_w16_order(const nxz_batch_job_t *jobs, size_t nslots, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, const void *built,
+					    const uint32_t *order, hipStream_t stream)
+{
+	if (!nslots) return 0;
+	// (a few pieces, all of them resident at two per CU: the window of elements in LDS, where a match costs a lone wavefront a
+	// fraction of the trip to device memory)
+	static const unsigned lds_max = getenv("NXZ_INFLATE_W16_LDS_MAX") ? (unsigned)atoi(getenv("NXZ_INFLATE_W16_LDS_MAX")) : 512;
+	if (nslots <= lds_max) hipLaunchKernelGGL((nxzi::inflate_kernel<false, true>), dim3((unsigned)nslots), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)built, order);
+	else hipLaunchKernelGGL((nxzi::inflate_kernel<true, true>), dim3((unsigned)nslots), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)built, order);
 	return (int)hipGetLastError();
 }
 

@@ -751,7 +751,14 @@ void *nxz_stream_create(nxz_ctx_t *) __attribute__((weak));
 int nxz_ctx_device(nxz_ctx_t *) __attribute__((weak));
 int nxz_engine_usable(void) __attribute__((weak));
 }
-constexpr size_t PARALLEL_INFLATE_MIN = 12u << 10;
+// (12 KiB up to round 4.  Below some 64 KiB of stream a job does as well since the rounds of nxu_run_job cut their jobs
+// into pieces -- nxz_inflate_cut.hip, one sequence of launches for all callers of a round -- and better the more threads
+// call at once: 64 threads x 64 KiB buffers 1.18 against 0.40 GiB/s.  NXZ_PARALLEL_INFLATE_MIN overrides, bytes.)
+static size_t parallel_inflate_min()
+{
+	static const size_t v = getenv("NXZ_PARALLEL_INFLATE_MIN") ? (size_t)strtoull(getenv("NXZ_PARALLEL_INFLATE_MIN"), nullptr, 0) : (size_t)64 << 10;
+	return v;
+}
 constexpr size_t CARRY_KEEP = 1024;                // unconsumed source kept between calls at most: a dynamic block header (<= 290 bytes) and a token
 
 bool parallel_inflate(Inflate *s)
@@ -762,7 +769,7 @@ bool parallel_inflate(Inflate *s)
 	if (nxz_engine_usable && !nxz_engine_usable()) return false;       // (forked after the engine was opened: the job loop reports it)
 	static const bool off = getenv("NXZ_PARALLEL_INFLATE") && atoi(getenv("NXZ_PARALLEL_INFLATE")) == 0;   // 0: always job after job
 	const size_t nc = s->carry.size();
-	if (off || nc + z->avail_in < PARALLEL_INFLATE_MIN) return false;
+	if (off || nc + z->avail_in < parallel_inflate_min()) return false;
 	if (s->par_skip) { s->par_skip--; return false; }           // (declined a moment ago: this stream is not the kind)
 	nxz_ctx_t *ctx = (nxz_ctx_t *)s->eng.dev.paste_addr;
 	if (!ctx) return false;

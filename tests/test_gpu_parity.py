@@ -32,21 +32,27 @@ def eng():
     os.environ.pop("NXZ_INFLATE_LANES_MIN", None)
 
 
-@pytest.fixture(params=["lanes", "lanes-fixed", "waves", "waves-global-window", "waves-by-length"])
+@pytest.fixture(params=["lanes", "lanes-fixed", "waves", "waves-global-window", "waves-by-length", "cut", "cut-3"])
 def inflate_kernel(request):
     """the inflate kernels: a stream per lane; the same with the fixed-code-only kernel in front (which
     hands a batch with a dynamic block in it back to the first); a stream per wave with its window in
     LDS, with the target buffer as its window (what mid-size batches get), and that with the jobs taken
-    in the order of their lengths (what batches of more than one round of wavefronts get)"""
+    in the order of their lengths (what batches of more than one round of wavefronts get); every stream
+    cut inside its first block into up to 32 pieces (what small batches get: nxz_inflate_cut.hip), or 3"""
     old = os.environ.get("NXZ_INFLATE_LANES_MIN")
     os.environ["NXZ_INFLATE_LANES_MIN"] = "32" if request.param.startswith("lanes") else "1000000000"
     os.environ["NXZ_LANES_FIXED"] = "2" if request.param == "lanes-fixed" else "0"
+    os.environ["NXZ_INFLATE_CUT"] = "1" if request.param.startswith("cut") else "0"
+    if request.param == "cut-3":
+        os.environ["NXZ_INFLATE_CUT_PIECES"] = "3"
     if request.param in ("waves-global-window", "waves-by-length"):
         os.environ["NXZ_INFLATE_LDS_MAX"] = "0"
     if request.param == "waves-by-length":                  # (the jobs in the order of their lengths, as batches beyond one round of wavefronts go)
         os.environ["NXZ_INFLATE_ORDER"] = "1"
     yield request.param
     os.environ.pop("NXZ_INFLATE_ORDER", None)
+    os.environ.pop("NXZ_INFLATE_CUT", None)
+    os.environ.pop("NXZ_INFLATE_CUT_PIECES", None)
     os.environ["NXZ_INFLATE_LANES_MIN"] = old if old is not None else "32"
     os.environ.pop("NXZ_INFLATE_LDS_MAX", None)
     os.environ.pop("NXZ_LANES_FIXED", None)

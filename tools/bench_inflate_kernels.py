@@ -29,14 +29,18 @@ def timed(eng, jobs, n):
     return e0.elapsed_time(e1) / 2
 
 
-print("%-34s %8s | %12s %12s" % ("streams", "n", "per wave", "per lane"))
+print("%-34s %8s | %12s %12s %12s" % ("streams", "n", "per wave", "cut", "per lane"))
 for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "own fixed-Huffman (corpus)", "own exact tables (corpus)"):
     for n in sizes:
         row = []
-        for kernel in (("waves",) if os.environ.get("LANES") == "0" else ("waves", "lanes")):     # LANES=0: the wave kernel only
+        for kernel in (("waves", "cut") if os.environ.get("LANES") == "0" else ("waves", "cut", "lanes")):     # LANES=0: not the lane kernel
+            if kernel == "cut" and n > 24576:
+                row.append(float("nan"))
+                continue
             os.environ["NXZ_INFLATE_LANES_MIN"] = "1" if kernel == "lanes" else "1000000000"
+            os.environ["NXZ_INFLATE_CUT"] = "1" if kernel == "cut" else "0"                 # every stream cut inside its first block (nxz_inflate_cut.hip)
             os.environ["NXZ_LANES_FIXED"] = "2" if kind.startswith("own fixed") else "0"   # (the fixed-code-only kernel in front, as the engine's sampling would choose)
-            os.environ["NXZ_INFLATE_LDS_MAX"] = "0"
+            os.environ["NXZ_INFLATE_LDS_MAX"] = os.environ.get("LDS_MAX", "0")          # (LDS_MAX=1024: small batches as the engine runs them, the window in LDS)
             eng = pkg.Engine(0)
             if kind.startswith("zlib"):
                 streams = []
@@ -70,4 +74,4 @@ for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "o
             eng.close()
             del jobs, dst
             torch.cuda.empty_cache()
-        print("%-34s %8d | %12.1f %12.1f" % (kind, n, row[0], row[-1] if len(row) > 1 else float("nan")), flush=True)
+        print("%-34s %8d | %12.1f %12.1f %12.1f" % (kind, n, row[0], row[1], row[2] if len(row) > 2 else float("nan")), flush=True)
