@@ -390,6 +390,9 @@ int   nxz_copy_to_host(nxz_ctx_t *ctx, void *dst_host, const void *src_dev, size
  * LZ77, table generator and entropy kernels since the last call, and how many launches of each. */
 void nxz_ctx_stage_timing(nxz_ctx_t *ctx, int on);
 int  nxz_ctx_stage_ms(nxz_ctx_t *ctx, double ms[3], unsigned *launches);
+/* Measurement aid: of the last nxz_batch_decompress of n streams on `stream` that went a stream per lane, how many
+ * streams the fixed-code-only kernel handed back to the general one (waits for the stream; -ENOENT: no such batch). */
+int  nxz_ctx_lanes_handed_back(nxz_ctx_t *ctx, void *stream, size_t n, uint32_t *count);
 
 /* Block until everything queued on `stream` by this context has finished. */
 int nxz_ctx_sync(nxz_ctx_t *ctx, void *stream);

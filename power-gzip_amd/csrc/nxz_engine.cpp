@@ -564,7 +564,9 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 				// longest stream, so the lane kernel gets them ordered by length; much of a size they stay as they come
 				// (neighbours in memory: ordering the bench's synthetic blocks cost 5 %)
 				by_len = h[2] > 8 * (uint64_t)h[1] + 4096;
-				no_tables = h[0] == 0;                                 // none of the sampled streams begins with a dynamic block
+				// few of the sampled streams begin with a dynamic block: the fixed-code-only lane kernel first, which hands the
+				// streams it cannot do -- those, and any with a dynamic block further in -- to the general one, stream by stream
+				no_tables = h[0] <= 16;
 			}
 		}
 	}
@@ -670,6 +672,25 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 	}
 	if (rc) { set_err("inflate launch", (hipError_t)rc); return -EIO; }
 	return 0;
+}
+
+// (diagnostic / tests: how many streams of the last batch of n that `stream` ran through the lane kernels the fixed-code-only
+// kernel handed back to the general one; waits for the stream)
+extern "C" int nxz_inflate_lanes_handed_back(const uint8_t *workspace, size_t n, uint32_t *count);
+extern "C" int nxz_ctx_lanes_handed_back(nxz_ctx_t *c, void *stream, size_t n, uint32_t *count)
+{
+	if (!c || !count) return -EINVAL;
+	(void)hipSetDevice(c->device);
+	hipStream_t s = (hipStream_t)stream;
+	if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+	const uint8_t *ws = nullptr;
+	{
+		std::lock_guard<std::mutex> g(c->mtx);
+		auto it = c->scratch.find(s);
+		if (it != c->scratch.end()) ws = it->second.d_lanes_ws;
+	}
+	if (!ws) return -ENOENT;
+	return nxz_inflate_lanes_handed_back(ws, n, count) ? -EIO : 0;
 }
 
 extern "C" int nxz_batch_wrap(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n,

@@ -1195,6 +1195,15 @@ extern "C" int nxz_launch_inflate_w16_order(const nxz_batch_job_t *jobs, size_t 
 	return (int)hipGetLastError();
 }
 
+// the jobs `order` names (slots of 0xffffffff are none), a wavefront each, the target as window; no checksums (the caller's)
+extern "C" int nxz_launch_inflate_order_only(const nxz_batch_job_t *jobs, size_t nslots, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io,
+					     const uint32_t *order, hipStream_t stream)
+{
+	if (!nslots) return 0;
+	hipLaunchKernelGGL(nxzi::inflate_kernel<true>, dim3((unsigned)nslots), dim3(64), 0, stream, jobs, results, dht_io, (const nxzi::Built *)nullptr, order);
+	return (int)hipGetLastError();
+}
+
 extern "C" int nxz_inflate_prof_set(unsigned long long *buf)
 {
 	return (int)hipMemcpyToSymbol(HIP_SYMBOL(nxzi::prof_buf), &buf, sizeof(buf));

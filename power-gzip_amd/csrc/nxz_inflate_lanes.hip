@@ -189,11 +189,18 @@ __global__ __launch_bounds__(64, NXZ_LANES_WPE) void inflate_lanes_kernel(const 
 							   nxz_batch_result_t *__restrict__ results,
 							   nxz_batch_dht_t *__restrict__ dht_io,
 							   uint8_t *__restrict__ workspace, const uint8_t *__restrict__ fixed_ws,
-							   const uint32_t *__restrict__ order, uint32_t per_wave, const uint32_t *__restrict__ only_if)
+							   const uint32_t *__restrict__ order, uint32_t per_wave, const uint32_t *__restrict__ only_if, uint32_t skip)
 {
-	// only_if (may be NULL): launched behind the fixed-code kernel below, this one runs only when that one met a stream it
-	// does not do (the word is then set)
-	if (only_if && *(const volatile uint32_t *)only_if == 0) return;
+	// only_if (may be NULL): launched behind the fixed-code kernel below, this one does the streams that one handed back and
+	// no others: the word counts them, their indices follow it (a batch of 262 144 fixed-code streams with one dynamic block
+	// among them took twice its time up to round 4, when the word was a flag and this kernel did the whole batch again)
+	// (the first `skip` of them are the stream-per-wave kernel's: a lane takes tens of milliseconds for a stream however few there are)
+	if (only_if) {
+		const uint32_t c = *(const volatile uint32_t *)only_if;
+		if (c <= skip) return;
+		n = c - skip;
+		order = only_if + 64 + skip;
+	}
 	__shared__ __attribute__((aligned(16))) uint8_t lens_s[320];
 	const int lane = threadIdx.x;
 	// slot 0 = fixed tables; then 65 slots per wave: one per lane and a spare that lanes with identical
@@ -652,8 +659,17 @@ __global__ __launch_bounds__(64, NXZ_LANES_FIXED_WPE) void inflate_lanes_fixed_k
 			}
 		}
 		w.flush();
-		if (__any(dyn) && lane == 0) *(volatile uint32_t *)bail = 1;      // (the other kernel does the batch again)
-		if (active) {
+		{
+			// streams with a dynamic block in them: handed to the other kernel, which does them from their first byte
+			const unsigned long long dm = __ballot(dyn);
+			if (dm) {
+				uint32_t at = 0;
+				if (lane == 0) at = atomicAdd(bail, (uint32_t)__popcll(dm));
+				at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+				if (dyn) bail[64 + at + (uint32_t)__popcll(dm & ((1ull << lane) - 1))] = (uint32_t)jid;
+			}
+		}
+		if (active && !dyn) {
 			if (final_eob) { o_sfbt = 0; o_subc = (uint32_t)(b.total() - b.pos); }
 			nxz_batch_result_t r;
 			uint32_t spbc = job.src_len, subc = o_subc;
@@ -922,9 +938,16 @@ static size_t lanes_bail_offset(size_t n)
 }
 extern "C" size_t nxz_inflate_lanes_workspace(size_t n)
 {
-	return lanes_bail_offset(n) + 256;
+	return lanes_bail_offset(n) + 256 + ((n * sizeof(uint32_t) + 255) & ~(size_t)255);    // (the count of streams handed back, then their indices)
+}
+// (diagnostic / tests: how many streams the fixed-code kernel of the last batch on this workspace handed back; the caller has waited for the stream)
+extern "C" int nxz_inflate_lanes_handed_back(const uint8_t *workspace, size_t n, uint32_t *count)
+{
+	return (int)hipMemcpy(count, workspace + lanes_bail_offset(n), sizeof(uint32_t), hipMemcpyDeviceToHost);
 }
 
+extern "C" int nxz_launch_inflate_order_only(const nxz_batch_job_t *jobs, size_t nslots, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io,
+					     const uint32_t *order, hipStream_t stream);
 namespace nxzl {
 __global__ void order_keys_kernel(const nxz_batch_job_t *__restrict__ jobs, uint32_t n, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
 {
@@ -981,15 +1004,24 @@ extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, n
 	const bool fixed_first = fixed_env != 0;
 	if (fixed_env == 2) init_fixed |= 4;
 	uint32_t *bail = nullptr;
+	// streams the fixed-code kernel hands back: up to HANDBACK_WAVES of them a wavefront each (nxz_inflate.hip: 0.6-3 ms a stream,
+	// thousands side by side, where a lane takes 40 ms), what is beyond that by the general lane kernel
+	constexpr uint32_t HANDBACK_WAVES = 16384;
+	const uint32_t hb_slots = (uint32_t)(n < HANDBACK_WAVES ? n : HANDBACK_WAVES);
 	if (fixed_first && (init_fixed & 4)) {
 		bail = (uint32_t *)(workspace + lanes_bail_offset(n));
 		(void)hipMemsetAsync(bail, 0, sizeof(uint32_t), stream);
+		(void)hipMemsetAsync(bail + 64, 0xff, (size_t)hb_slots * sizeof(uint32_t), stream);
 		// (no table slots to hold: its grid is bounded by the wavefronts the CUs hold; NXZ_LANES_FIXED_GRID overrides, for measurements)
 		static const unsigned fgmax = [] { const char *e = getenv("NXZ_LANES_FIXED_GRID"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 1024u * NXZ_LANES_FIXED_WPE; }();
 		const unsigned fgrid = (unsigned)(groups < fgmax ? groups : fgmax);
 		hipLaunchKernelGGL(nxzl::inflate_lanes_fixed_kernel, dim3(fgrid), dim3(64), 0, stream, jobs, n, results, order, pw, bail);
 	}
-	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace, order, pw, bail);
+	if (bail) {
+		int rc = nxz_launch_inflate_order_only(jobs, hb_slots, results, dht_io, bail + 64, stream);
+		if (rc) return rc;
+	}
+	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace, order, pw, bail, bail ? hb_slots : 0u);
 	hipLaunchKernelGGL(nxzl::cksum_kernel<false>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
 	return (int)hipGetLastError();
 }

@@ -781,6 +781,31 @@ def test_a_dynamic_block_behind_the_sample_sends_the_batch_back_to_the_general_k
         assert r["crc"][i] == zlib.crc32(d) and r["adler"][i] == zlib.adler32(d), i
     want = np.array([len(d) for d, _ in streams], np.uint32)
     assert (r["tpbc"] == want).all()
+    # ... and the general kernel did those three streams and no others (up to round 4 it did the whole batch again)
+    back = C.c_uint32(0xffffffff)
+    eng.L.nxz_ctx_lanes_handed_back.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    assert eng.L.nxz_ctx_lanes_handed_back(eng.ctx, eng.stream_handle(), n, C.byref(back)) == 0
+    assert back.value == 3, back.value
+    # one stream in a hundred with a dynamic block (none where the sample looks): handed back one by one, all results right
+    dyn_at = [i for i in range(n) if i % 100 == 7]
+    for i in dyn_at:
+        streams[i] = streams[7]
+    src = pack_blocks(eng, [c for _, c in streams], cstride)
+    jobs = eng.jobs_strided(src, cstride, np.array([len(c) for _, c in streams], np.uint32), dst, ostride, ostride)
+    saved = {k: os.environ.pop(k, None) for k in ("NXZ_INFLATE_LANES_MIN", "NXZ_LANES_FIXED")}
+    try:
+        r = eng.results_to_host(eng.decompress(jobs, n))
+        assert eng.L.nxz_ctx_lanes_handed_back(eng.ctx, eng.stream_handle(), n, C.byref(back)) == 0
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+    assert back.value == len(set(dyn_at) | {12345, 49151}), back.value
+    assert (r["cc"] == 0).all() and (r["tpbc"] == np.array([len(d) for d, _ in streams], np.uint32)).all()
+    out = dst.cpu().numpy()
+    for i in dyn_at[:40] + [8, 12345]:
+        d = streams[i][0]
+        assert out[i, :len(d)].tobytes() == d and r["crc"][i] == zlib.crc32(d), i
 
 
 def test_all_35_canned_tables_encode_bit_exact(eng):
