@@ -33,7 +33,9 @@ typedef struct nxz_dht_prepared {
 extern "C" {
 #define NXZ_LZ77_MAX_GRID 512          /* workgroups of one LZ77 launch (one per CU) */
 #define NXZ_LZ77_FUSED_FHT 2            /* nxz_launch_lz77 count: the kernel writes the finished fixed-Huffman block itself (no entropy launch) */
+#define NXZ_LZ77_FUSED_GEN 3            /* ... the finished dynamic-Huffman block, with the table made of its own counts (`tokens`: nxz_lz77_gen_scratch_bytes() of scratch; counts may be NULL) */
 size_t nxz_lz77_cand2_bytes(void);     /* scratch of a launch: the second bucket entries in transit */
+size_t nxz_lz77_gen_scratch_bytes(void);
 int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n, uint8_t *tokens, uint16_t *cand2, nxz_batch_result_t *results,
 		    uint32_t *counts, uint32_t *job_counter, hipStream_t stream);
 int nxz_launch_encode(int dht, int table_per_job, const nxz_batch_job_t *jobs, size_t n, const uint8_t *tokens,

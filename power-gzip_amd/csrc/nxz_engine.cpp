@@ -87,6 +87,7 @@ struct nxz_ctx {
 		nxz_dht_prepared_t *d_gen = nullptr;      // tables the device generated, one per job of the chunk
 		uint32_t *d_counts = nullptr;             // symbol counts when the caller did not ask for them
 		uint16_t *d_cand2 = nullptr;              // LZ77 kernel: second bucket entries in transit, 32 KiB per workgroup
+		uint8_t *d_fuse = nullptr;                // the fused dynamic-Huffman form: two token slots and two table slots per workgroup (nxz_lz77.hip gen::)
 		size_t chunk_cap = 0;
 		size_t chunk_limit = 0;                   // jobs per chunk the device had room for when a larger chunk could not be had (0: no such failure yet)
 		void release_chunk() {
@@ -116,6 +117,7 @@ struct nxz_ctx {
 			if (d_gen) (void)hipFree(d_gen);
 			if (d_counts) (void)hipFree(d_counts);
 			if (d_cand2) (void)hipFree(d_cand2);
+			if (d_fuse) (void)hipFree(d_fuse);
 			*this = Scratch();
 		}
 	};
@@ -375,7 +377,15 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 	// equal chunks (a last chunk of a few jobs would cost three launches for nothing)
 	// the fixed code without counts: the LZ77 kernel writes the finished block itself (no tokens in device scratch,
 	// no entropy launch, and so no reason to cut the batch into chunks: one launch, one tail)
-	const bool fused = !isdht && !count;
+	// ... and so it can for the additive DHTGEN function codes (round 5, NXZ_FUSED_GEN=1): the table of a block is made, and the block
+	// encoded, inside the LZ77 kernel, a job behind the parse (nxz_lz77.hip gen::) -- one launch, 110 MB of scratch whatever the batch
+	// instead of 104 KiB a job of a chunk.  Not the default: 75.7 against 103.1 GiB/s on the corpus (profiles/r05_fused_dhtgen.txt) -- the
+	// table generator is a chain of dependent steps that ONE wavefront works through while fifteen wait at their barriers, where the
+	// kernel of nxz_dhtgen.hip has thirty tables in flight on a CU and hides every one's latency behind the others'.
+	const char *fge = getenv("NXZ_FUSED_GEN");                        // (read at every call: the tests switch it)
+	const bool fused_gen_on = fge && atoi(fge) != 0;
+	const bool fused_gen = gen && fused_gen_on;
+	const bool fused = (!isdht && !count) || fused_gen;
 	size_t want = compress_chunk(n);
 	size_t nchunks = fused ? 1 : (n + want - 1) / want;
 	size_t chunk = (n + nchunks - 1) / nchunks;
@@ -415,6 +425,7 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 			}
 		}
 		if (!r.d_cand2) HIPCHK(hipMalloc((void **)&r.d_cand2, nxz_lz77_cand2_bytes()), return -ENOMEM);
+		if (fused_gen && !r.d_fuse) HIPCHK(hipMalloc((void **)&r.d_fuse, nxz_lz77_gen_scratch_bytes()), return -ENOMEM);
 		if (isdht && !gen && r.prepared_cap < ntables) {
 			if (r.d_prepared) { (void)hipStreamSynchronize(s); (void)hipFree(r.d_prepared); }
 			r.d_prepared = nullptr; r.prepared_cap = 0;
@@ -446,7 +457,8 @@ extern "C" int nxz_batch_compress(nxz_ctx_t *c, int fc, const nxz_batch_job_t *j
 			c->tev.push_back(e);
 		};
 		stamp();
-		int rc = nxz_launch_lz77(fused ? NXZ_LZ77_FUSED_FHT : cnt != nullptr, jobs + off, m, sc.d_tokens, sc.d_cand2, results + off, cnt, jc, s);
+		int rc = fused_gen ? nxz_launch_lz77(NXZ_LZ77_FUSED_GEN, jobs + off, m, sc.d_fuse, sc.d_cand2, results + off, count ? counts + off * 316 : nullptr, jc, s)
+				   : nxz_launch_lz77(fused ? NXZ_LZ77_FUSED_FHT : cnt != nullptr, jobs + off, m, sc.d_tokens, sc.d_cand2, results + off, cnt, jc, s);
 		if (rc) { set_err("lz77 launch", (hipError_t)rc); return -EIO; }
 		stamp();
 		if (fused) { stamp(); stamp(); continue; }

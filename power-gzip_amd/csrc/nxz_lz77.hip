@@ -41,6 +41,7 @@
 #include <type_traits>
 #include <stdint.h>
 #include "nxz_device.h"
+#include "nxz_dhtgen_dev.h"
 
 // Diagnostic only (tools/phase_profile.py, a build with -DNXZ_LZ77_PROF: tools/build_variant.sh prof nxz_lz77.hip -DNXZ_LZ77_PROF):
 // per-phase cycle sums of every workgroup's thread 0.  Compiled out of the product: the counters cost a dozen
@@ -139,7 +140,7 @@ constexpr uint32_t LDS_BYTES = OFF_PROF + 80;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 static_assert(OFF_HEAD % 16 == 0 && OFF_BITS % 16 == 0 && OFF_SCAN % 16 == 0, "alignment");
 
-enum { M_NREC = 0, M_TOK0 = 1, M_HIGH = 2, M_DQ = 3, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7, M_KEEP = 8, M_DEFER2 = 9 };
+enum { M_NREC = 0, M_TOK0 = 1, M_HIGH = 2, M_DQ = 3, M_PROGRESS = 4, M_TICKET = 5, M_DEFER = 6, M_NEXT = 7, M_KEEP = 8, M_DEFER2 = 9, M_PREV = 12, M_JOBNO = 13 };
 static_assert(M_TICKET == M_PROGRESS + 1 && M_DEFER == M_PROGRESS + 2, "cleared together");
 
 __device__ __forceinline__ uint32_t lds_ld32(const uint32_t *inw, uint32_t r)
@@ -304,7 +305,307 @@ __device__ __forceinline__ void fx_emit(uint32_t *w, const Quad &q, uint32_t bit
 	if (endw > 3) atomicOr(&w[wi + 3], (uint32_t)(s2 >> 32));
 }
 
-template <bool COUNT, bool FUSED = false>
+
+// ---- the table and the Huffman coding inside the LZ77 kernel (GEN: the additive DHTGEN function codes) ----
+// One job = LZ77 + table + encode in one engine pass (/root/reference lib/nx_deflate.c:1841; the table as lib/nx_dhtgen.c:945-1034
+// makes it).  The table of a block needs the counts of the whole block, and making it is a chain of some 8000 dependent
+// instructions of ONE wavefront -- 40 K cycles with fifteen others waiting, a tenth of the block's time.  So the work is
+// pipelined over the jobs a workgroup takes: behind the last tile of job k wavefront 0 makes the table of job k (from the
+// histogram in LDS, into the workgroup's table slot in device scratch) WHILE wavefronts 1-15 encode job k - 1 (its tokens from
+// the workgroup's other token slot, its literals from the source, its table from the other table slot).  A workgroup's last
+// job is encoded behind its loop.  Tokens and tables never leave the L2: two slots of each per workgroup instead of one per job
+// of a 65536-job chunk (6.6 GiB), no launch of nxz_dhtgen.hip / nxz_encode.hip, whose code this is (bit for bit the same blocks).
+// All sixteen wavefronts must pass every workgroup barrier: wavefront 0 takes the encoders' barriers -- their number follows
+// from the block's size -- at the turning points of the table generator's loops, and the rest of them when it is done.
+namespace gen {
+constexpr uint32_t ENT = 960;                              // encoding threads (wavefronts 1-15)
+constexpr uint32_t RPOS = ENT * 8;                         // positions per round: 8 per lane, two quads of 4
+constexpr uint32_t HDR_WORDS = 74;
+constexpr uint32_t WW = ENT * 144 / 32 + HDR_WORDS + 2;    // window words: three 48-bit match tokens in 8 positions per lane
+constexpr uint32_t RECMAX = RPOS / 3 + 6;
+// LDS of the post phase (head[], cand[], mlen[] are free behind the last tile)
+constexpr uint32_t P_LL = OFF_HEAD, P_D = P_LL + 288 * 4, P_WIN = P_D + 32 * 4, P_REC = P_WIN + 2 * (WW + 2) * 4,
+		   P_RANK = P_REC + 2 * (RECMAX + 2) * 4, P_WSUM = P_RANK + 4104, P_DHT = (P_WSUM + 2 * 16 * 4 + 15) & ~15u, P_END = P_DHT + nxzd::WAVE_LDS;
+static_assert(P_WIN % 16 == 0 && P_END <= OFF_SBITS, "post-phase carve");
+__host__ __device__ constexpr size_t table_off(uint32_t grid) { return (size_t)grid * 2 * NXZ_TOK_STRIDE; }
+
+struct Credit {
+	static constexpr bool none = false;
+	uint32_t n;
+	__device__ __forceinline__ void operator()() { if (n) { __builtin_amdgcn_s_barrier(); n--; } }
+};
+// barriers the encoders of a block of n bytes pass (encode() below: three while they set up, two a round, one behind the
+// rounds, two more for a block without any round)
+__device__ __forceinline__ uint32_t encode_barriers(uint32_t n) { const uint32_t R = (n + RPOS - 1) / RPOS; return 3 + 2 * R + 1 + (R ? 0 : 2); }
+
+struct Quad { uint32_t a0, a1, a2, nb; };
+// (nxz_encode.hip encode_quad without the missing-code checks: the table has a code for every symbol the block uses)
+__device__ __forceinline__ Quad encode_quad(const uint32_t *lltab, const uint32_t *dtab, const uint32_t *rec, uint32_t &ri, uint32_t b, uint32_t lit4, uint32_t tok4)
+{
+	const uint32_t e0 = lltab[b & 0xff], e1 = lltab[(b >> 8) & 0xff], e2 = lltab[(b >> 16) & 0xff], e3 = lltab[b >> 24];
+	uint64_t v[4] = { e0 & 0xffff, e1 & 0xffff, e2 & 0xffff, e3 & 0xffff };
+	uint32_t nbk[4] = { (lit4 & 1) ? e0 >> 16 : 0, (lit4 & 2) ? e1 >> 16 : 0, (lit4 & 4) ? e2 >> 16 : 0, (lit4 & 8) ? e3 >> 16 : 0 };
+	if (__ballot(tok4 != 0)) {
+		auto one = [&](uint32_t r, uint64_t &mv, uint32_t &mn) {
+			const uint32_t l3 = r & 0xff, d = (r >> 8) & 0x7fff;
+			uint32_t le = l3 < 8 ? 0 : (29 - (uint32_t)__builtin_clz(l3 | 8));
+			const uint32_t ls = l3 == 255 ? 28 : (le << 2) + (l3 >> le);
+			if (l3 == 255) le = 0;
+			const uint32_t de = d < 4 ? 0 : (30 - (uint32_t)__builtin_clz(d | 4));
+			const uint32_t ds = d < 4 ? d : 2 * de + 2 + ((d >> de) & 1);
+			const uint32_t lt = lltab[257 + ls], dt = dtab[ds];
+			const uint32_t ll = lt >> 16, dl = dt >> 16;
+			const uint32_t lo = (lt & 0xffff) | ((l3 & ((1u << le) - 1)) << ll);
+			const uint32_t hi = (dt & 0xffff) | ((d & ((1u << de) - 1)) << dl);
+			mv = (uint64_t)lo | ((uint64_t)hi << (ll + le));
+			mn = ll + le + dl + de;
+		};
+		const uint32_t k1 = (uint32_t)__builtin_ctz(tok4 | 16);
+		uint64_t mv; uint32_t mn;
+		one(rec[ri], mv, mn);
+		ri += tok4 ? 1 : 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) if (k1 == (uint32_t)k) { v[k] = mv; nbk[k] = mn; }
+		if (__ballot(tok4 == 9)) {
+			one(rec[ri], mv, mn);
+			if (tok4 == 9) { v[3] = mv; nbk[3] = mn; ri++; }
+		}
+	}
+	uint64_t lo = nbk[0] ? v[0] : 0, hi = 0;
+	uint32_t off = nbk[0];
+#pragma unroll
+	for (int k = 1; k < 4; k++) {
+		const uint64_t x = nbk[k] ? v[k] : 0;
+		if (off < 64) { lo |= x << off; hi |= off ? x >> (64 - off) : 0; }
+		else hi |= x << (off - 64);
+		off += nbk[k];
+	}
+	Quad q;
+	q.a0 = (uint32_t)lo; q.a1 = (uint32_t)(lo >> 32); q.a2 = (uint32_t)hi; q.nb = off;
+	return q;
+}
+__device__ __forceinline__ void emit_quad(uint32_t *w, const Quad &q, uint32_t bitpos)
+{
+	if (!q.nb) return;
+	const uint32_t sh = bitpos & 31, wi = bitpos >> 5, endw = (sh + q.nb + 31) >> 5;
+	const uint64_t s0 = (uint64_t)q.a0 << sh, s1 = (uint64_t)q.a1 << sh, s2 = (uint64_t)q.a2 << sh;
+	atomicOr(&w[wi], (uint32_t)s0);
+	if (endw > 1) atomicOr(&w[wi + 1], (uint32_t)(s0 >> 32) | (uint32_t)s1);
+	if (endw > 2) atomicOr(&w[wi + 2], (uint32_t)(s1 >> 32) | (uint32_t)s2);
+	if (endw > 3) atomicOr(&w[wi + 3], (uint32_t)(s2 >> 32));
+}
+
+// wavefronts 1-15 (te = 0 .. 959): the block of job `bid` from its tokens at tk and its table tb_ (nxz_encode.hip's
+// encode_kernel<true, false>, 960 threads wide; EVERY __syncthreads here is counted in encode_barriers)
+__device__ __forceinline__ void encode(uint8_t *lds, const nxz_batch_job_t *__restrict__ jobs, uint32_t bid, const NXZ_GLOBAL uint8_t *tk,
+				       const NXZ_GLOBAL nxz_dht_prepared_t *tb, nxz_batch_result_t *__restrict__ results, const int te)
+{
+	typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+	typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+	uint32_t *lltab = (uint32_t *)(lds + P_LL), *dtab = (uint32_t *)(lds + P_D);
+	uint32_t *win0 = (uint32_t *)(lds + P_WIN);                      // win[par] = win0 + par * (WW + 2)
+	uint32_t *rec0 = (uint32_t *)(lds + P_REC);                      // recbuf[par] = rec0 + par * (RECMAX + 2)
+	uint16_t *rankpre = (uint16_t *)(lds + P_RANK);
+	uint32_t *wsum = (uint32_t *)(lds + P_WSUM);                     // wsum[par * 16 + wave]
+	const int lane = te & 63, wave = te >> 6;
+	const nxz_batch_job_t job = jobs[bid];
+	const uint32_t total = job.src_len;
+	const uint32_t h = job.hist_len < total ? job.hist_len : total;
+	const uint32_t n = total - h;
+	const NXZ_GLOBAL uint8_t *src = (const NXZ_GLOBAL uint8_t *)job.src + h;
+	const NXZ_GLOBAL uint32_t *litb = (const NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_LITBITS);
+	const NXZ_GLOBAL uint32_t *tokb = (const NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_MATCHBITS);
+	const NXZ_GLOBAL uint32_t *recs = (const NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_RECORDS);
+	NXZ_GLOBAL uint32_t *dstw = (NXZ_GLOBAL uint32_t *)job.dst;
+	const uint32_t cap_words = job.dst_cap >> 2;
+	const uint32_t nwords = (n + 31) >> 5;
+	struct Fetch { v2u bytes; uint32_t litw, tokw, rec[3]; };
+	auto fetch = [&](uint32_t r0, Fetch &f) {
+		const uint32_t p0 = r0 + 8 * (uint32_t)te;
+		f.bytes = (v2u){ 0, 0 }; f.litw = 0; f.tokw = 0;
+		if (p0 < n) {
+			f.litw = litb[p0 >> 5];
+			f.tokw = tokb[p0 >> 5];
+			if (p0 + 8 <= n) f.bytes = *(const NXZ_GLOBAL v2u *)(src + p0);
+			else {
+				uint64_t v = 0;
+				for (uint32_t i = 0; i < 8; i++) if (p0 + i < n) v |= (uint64_t)src[p0 + i] << (8 * i);
+				f.bytes = (v2u){ (uint32_t)v, (uint32_t)(v >> 32) };
+			}
+		}
+	};
+	auto fetch_recs = [&](uint32_t r0, Fetch &f) {
+		const uint32_t ra = rankpre[r0 >> 5], rb = rankpre[(r0 + RPOS) >> 5 < 2048 ? (r0 + RPOS) >> 5 : 2048];
+#pragma unroll
+		for (int j = 0; j < 3; j++) f.rec[j] = ra + (uint32_t)te + ENT * j < rb ? recs[ra + (uint32_t)te + ENT * j] : 0;
+	};
+	Fetch nx;
+	fetch(0, nx);
+	for (uint32_t i = te; i < 2 * (WW + 2); i += ENT) win0[i] = 0;
+	{
+		// the matches in front of every 32 positions: the first 256 threads, eight bitmap words each
+		uint32_t c[8], s = 0, incl = 0;
+		if (te < 256) {
+			const NXZ_GLOBAL v4u *tw = (const NXZ_GLOBAL v4u *)tokb;
+			v4u a = { 0, 0, 0, 0 }, b = a;
+			if (8u * te < nwords) { a = tw[2 * te]; b = tw[2 * te + 1]; }
+			const uint32_t w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+#pragma unroll
+			for (int k = 0; k < 8; k++) { c[k] = s; s += 8u * te + k < nwords ? (uint32_t)__popc(w[k]) : 0; }
+			incl = s;
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+			if (lane == 63) wsum[wave] = incl;
+		}
+		for (uint32_t i = te; i < 288; i += ENT) lltab[i] = tb->ll[i];
+		if (te < 32) dtab[te] = tb->d[te];
+		__syncthreads();                                              // 1
+		if (te < 256) {
+			uint32_t off = incl - s;
+			for (int k = 0; k < wave; k++) off += wsum[k];
+#pragma unroll
+			for (int k = 0; k < 8; k++) rankpre[8 * te + k] = (uint16_t)(off + c[k]);
+			if (te == 255) rankpre[2048] = (uint16_t)(off + s);
+		}
+	}
+	uint32_t base_bits;
+	{
+		const uint32_t hb = tb->dhtlen + 3;                          // BFINAL = 1 as emitted (the host rewrites it, lib/nx_deflate.c:158), BTYPE = 10
+		const uint32_t nw = (hb + 31) >> 5;
+		for (uint32_t i = te; i < nw && i < HDR_WORDS; i += ENT) {
+			const uint32_t cur = i < 74 ? tb->dhtw[i] : 0, prev = i ? tb->dhtw[i - 1] : 0;
+			uint32_t w = (cur << 3) | (i ? prev >> 29 : 5u);
+			if (i == (hb >> 5)) w &= (1u << (hb & 31)) - 1;
+			win0[i] = w;
+		}
+		base_bits = hb;
+	}
+	__syncthreads();                                                  // 2
+	{
+		fetch_recs(0, nx);
+#pragma unroll
+		for (int j = 0; j < 3; j++) if ((uint32_t)te + ENT * j < RECMAX) rec0[(uint32_t)te + ENT * j] = nx.rec[j];
+	}
+	__syncthreads();                                                  // 3
+	uint32_t wordbase = 0, par = 0;
+	for (uint32_t r0 = 0; r0 < n; r0 += RPOS, par ^= 1) {
+		const Fetch k = nx;
+		const bool more = r0 + RPOS < n;
+		if (more) { fetch(r0 + RPOS, nx); fetch_recs(r0 + RPOS, nx); }
+		uint32_t *w_ = win0 + par * (WW + 2);
+		const uint32_t *rb_ = rec0 + par * (RECMAX + 2);
+		const uint32_t p0 = r0 + 8 * (uint32_t)te;
+		const uint32_t sh8 = p0 & 24;
+		const uint32_t lit8 = (k.litw >> sh8) & 0xff, tok8 = (k.tokw >> sh8) & 0xff;
+		Quad q0{0, 0, 0, 0}, q1{0, 0, 0, 0};
+		if (__ballot((lit8 | tok8) != 0)) {
+			uint32_t ri = (uint32_t)rankpre[p0 >> 5 < 2048 ? p0 >> 5 : 2048] + (uint32_t)__popc(k.tokw & ((1u << (p0 & 31)) - 1)) - (uint32_t)rankpre[r0 >> 5];
+			if (p0 >= n) ri = 0;
+			q0 = encode_quad(lltab, dtab, rb_, ri, k.bytes.x, lit8 & 15, tok8 & 15);
+			q1 = encode_quad(lltab, dtab, rb_, ri, k.bytes.y, lit8 >> 4, tok8 >> 4);
+		}
+		const uint32_t nbits = q0.nb + q1.nb;
+		uint32_t incl = nbits;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+		if (lane == 63) wsum[par * 16 + wave] = incl;
+		__syncthreads();                                              // 2 a round: a
+		uint32_t bitpos = base_bits + incl - nbits, roundbits = 0;
+#pragma unroll
+		for (int w = 0; w < 15; w++) { const uint32_t s = wsum[par * 16 + w]; if (w < wave) bitpos += s; roundbits += s; }
+		emit_quad(w_, q0, bitpos);
+		emit_quad(w_, q1, bitpos + q0.nb);
+		if (more) {
+			uint32_t *rn = rec0 + (par ^ 1) * (RECMAX + 2);
+#pragma unroll
+			for (int j = 0; j < 3; j++) if ((uint32_t)te + ENT * j < RECMAX) rn[(uint32_t)te + ENT * j] = nx.rec[j];
+		}
+		__syncthreads();                                              // 2 a round: b
+		const uint32_t tot = base_bits + roundbits, nfull = tot >> 5;
+		for (uint32_t i = te; i < nfull; i += ENT) {
+			if (wordbase + i < cap_words) dstw[wordbase + i] = w_[i];
+			w_[i] = 0;
+		}
+		if (te == 0) {
+			const uint32_t keep = w_[nfull];
+			if (keep) atomicOr(&win0[(par ^ 1) * (WW + 2)], keep);
+			w_[nfull] = 0;
+		}
+		wordbase += nfull;
+		base_bits = tot & 31;
+	}
+	__syncthreads();                                                  // 1 behind the rounds
+	uint32_t *w_ = win0 + par * (WW + 2);
+	if (n == 0) {
+		// a job without any round still has its header in the window
+		const uint32_t nfull = base_bits >> 5;
+		for (uint32_t i = te; i < nfull; i += ENT)
+			if (wordbase + i < cap_words) dstw[wordbase + i] = w_[i];
+		const uint32_t keep = w_[nfull];
+		__syncthreads();                                              // 2 more for a block without a round: a
+		if (te == 0) w_[0] = keep;
+		wordbase += nfull;
+		base_bits &= 31;
+		__syncthreads();                                              // ... b
+	}
+	if (te == 0) {
+		const uint32_t lt = lltab[256];
+		uint32_t cc = 0;
+		if (wordbase > cap_words) cc = NXZ_CC_TARGET_SPACE;
+		if ((lt >> 16) == 0) cc = NXZ_CC_MISSING_CODE;
+		if (tb->status) cc = NXZ_CC_INVALID_DHT;
+		const uint64_t acc = (uint64_t)w_[0] | ((uint64_t)(lt & 0xffff) << base_bits);
+		const uint32_t bits = base_bits + (lt >> 16);
+		const uint64_t totbits = (uint64_t)wordbase * 32 + bits;
+		const uint32_t tpbc = (uint32_t)((totbits + 7) >> 3);
+		if (tpbc > job.dst_cap) cc = cc ? cc : NXZ_CC_TARGET_SPACE;
+		if (cc != NXZ_CC_TARGET_SPACE && (uint64_t)wordbase * 4 + (bits + 7) / 8 <= job.dst_cap) {
+			NXZ_GLOBAL uint8_t *o = (NXZ_GLOBAL uint8_t *)job.dst + (size_t)wordbase * 4;
+			for (uint32_t b = 0; b < (bits + 7) / 8; b++) o[b] = (uint8_t)(acc >> (8 * b));
+		}
+		if (cc == 0 && tpbc > total) cc = NXZ_CC_TPBC_GT_SPBC;
+		nxz_batch_result_t *r = results + bid;
+		r->cc = cc;
+		r->tpbc = cc == NXZ_CC_TARGET_SPACE ? 0 : tpbc;
+		r->tebc = (uint32_t)(totbits & 7);
+		r->sfbt = 0;
+	}
+}
+
+// behind a job's last tile (and once more behind a workgroup's last job): see above
+__device__ __forceinline__ void post(uint8_t *lds, const nxz_batch_job_t *__restrict__ jobs, NXZ_GLOBAL uint8_t *scratch, nxz_batch_result_t *__restrict__ results,
+				     bool have_cur, uint32_t cur_slot, uint32_t prev_plus1, uint32_t prev_slot, const int t)
+{
+	const NXZ_GLOBAL uint8_t *tabs = scratch + table_off(gridDim.x);
+	const bool have_prev = prev_plus1 != 0;
+	uint32_t nprev = 0;
+	if (have_prev) {
+		const uint32_t sl = jobs[prev_plus1 - 1].src_len, hl = jobs[prev_plus1 - 1].hist_len;
+		nprev = sl - (hl < sl ? hl : sl);
+	}
+	nprev = (uint32_t)__builtin_amdgcn_readfirstlane((int)nprev);
+	if (t < 64) {
+		Credit cr{ have_prev ? encode_barriers(nprev) : 0u };
+		if (have_cur) {
+			uint32_t *hist = (uint32_t *)(lds + OFF_HIST);
+			if (t == 0) hist[256] = 1;                               // the callers count EOB once (lib/nx_dht.c:189-195)
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_s_setprio(3);                           // (the one wavefront everything may end up waiting for)
+			nxzd::dhtgen_wave(lds + P_DHT, (const uint32_t *)hist, (nxz_dht_prepared_t *)(tabs + ((size_t)blockIdx.x * 2 + cur_slot) * sizeof(nxz_dht_prepared_t)),
+					  (nxz_batch_dht_t *)nullptr, t, cr);
+			__builtin_amdgcn_s_setprio(0);
+		}
+		while (cr.n) cr();
+	} else if (have_prev) {
+		encode(lds, jobs, prev_plus1 - 1, scratch + ((size_t)blockIdx.x * 2 + prev_slot) * NXZ_TOK_STRIDE,
+		       (const NXZ_GLOBAL nxz_dht_prepared_t *)(tabs + ((size_t)blockIdx.x * 2 + prev_slot) * sizeof(nxz_dht_prepared_t)), results, t - 64);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__syncthreads();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+} // namespace gen
+
+template <bool COUNT, bool FUSED = false, bool GEN = false>
 __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restrict__ jobs,
 						  uint8_t *__restrict__ tokens, uint16_t *__restrict__ cand2,
 						  nxz_batch_result_t *__restrict__ results,
@@ -340,6 +641,10 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	// blockIdx.x and then draws further jobs from a counter (or strides by the grid without one), so
 	// nothing waits for a dispatch in between and slow jobs do not pile up in one place.  The draw
 	// for the job after this one is issued at once; its latency hides behind the work.
+	if constexpr (GEN) {
+		if (threadIdx.x == 0) { misc[M_PREV] = 0; misc[M_JOBNO] = 0; }
+		__syncthreads();
+	}
 	for (uint32_t bid = blockIdx.x; bid < njobs;) {
 	if (next_job && threadIdx.x == 0) misc[M_NEXT] = gridDim.x + atomicAdd(next_job, 1u);   // parked in LDS, not in a register
 	// (the thread index is made opaque per job: what is derived from it would otherwise be hoisted out
@@ -376,7 +681,7 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	}
 	for (uint32_t i = t; i < HSIZE; i += NT) head[i] = 0;
 	if (t < 316) hist[t] = 0;
-	if (t < 16 && t != M_NEXT) misc[t] = FUSED && t == M_KEEP ? 3u : 0u;       // (FUSED: the block's header bits, BFINAL = 1, BTYPE = 01)
+	if (t < 16 && t != M_NEXT && !(GEN && (t == M_PREV || t == M_JOBNO))) misc[t] = FUSED && t == M_KEEP ? 3u : 0u;       // (FUSED: the block's header bits, BFINAL = 1, BTYPE = 01)
 #ifdef NXZ_LZ77_PROF
 	if (t < 20) profacc[t] = 0;
 #endif
@@ -524,7 +829,9 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 	const uint32_t cap_words = job.dst_cap >> 2;
 	uint32_t wordbase = 0, obits = 3;
 	// where this job's tokens go
-	NXZ_GLOBAL uint8_t *tk = (NXZ_GLOBAL uint8_t *)tokens + (size_t)bid * NXZ_TOK_STRIDE;
+	// (GEN: the workgroup's two token slots take turns, the job before this one is encoded from the other)
+	const uint32_t gslot = GEN ? (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_JOBNO]) & 1u : 0u;
+	NXZ_GLOBAL uint8_t *tk = (NXZ_GLOBAL uint8_t *)tokens + (GEN ? ((size_t)blockIdx.x * 2 + gslot) : (size_t)bid) * NXZ_TOK_STRIDE;
 	NXZ_GLOBAL uint32_t *g_lit = (NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_LITBITS);
 	NXZ_GLOBAL uint32_t *g_tok = (NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_MATCHBITS);
 	NXZ_GLOBAL uint32_t *g_rec = (NXZ_GLOBAL uint32_t *)(tk + NXZ_TOK_RECORDS);
@@ -1563,14 +1870,29 @@ __global__ __launch_bounds__(NT) void lz77_kernel(const nxz_batch_job_t *__restr
 		if (t < 20) __hip_atomic_fetch_add(&prof[t], (unsigned long long)profacc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 #endif
-	if (COUNT) {
+	if (COUNT && (!GEN || counts)) {
 		__syncthreads();
 		if (t < 316) counts[(size_t)bid * 316 + t] = (t == 256) ? 1u : hist[t];
+	}
+	if constexpr (GEN) {
+		// the table of this job (wavefront 0) while the job before it is encoded (wavefronts 1-15)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		const uint32_t prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_PREV]);
+		gen::post(lds, jobs, (NXZ_GLOBAL uint8_t *)tokens, results, true, gslot, prev, gslot ^ 1u, t);
+		if (t == 0) { misc[M_PREV] = bid + 1; misc[M_JOBNO] = misc[M_JOBNO] + 1; }
 	}
 	__syncthreads();                                           // the LDS image is reused by the next job
 	const uint32_t drawn = next_job ? misc[M_NEXT] : bid + gridDim.x;
 	__syncthreads();                                           // misc[M_NEXT] is rewritten at the top
 	bid = drawn;
+	}
+	if constexpr (GEN) {
+		// the workgroup's last job
+		const uint32_t prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_PREV]);
+		const uint32_t slot = ((uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_JOBNO]) & 1u) ^ 1u;
+		if (prev) gen::post(lds, jobs, (NXZ_GLOBAL uint8_t *)tokens, results, false, 0, prev, slot, (int)threadIdx.x);
 	}
 }
 
@@ -1587,6 +1909,8 @@ extern "C" int nxz_lz77_prof_set(unsigned long long *buf)
 // One persistent workgroup per CU; job_counter: one device word per launch in flight (or NULL:
 // workgroups stride over the jobs).  tokens: n x NXZ_TOK_STRIDE bytes of device scratch.
 // Device scratch a launch needs for the second bucket entries in transit (one tile per workgroup).
+// ... and for the fused dynamic-Huffman form: two token slots and two table slots per workgroup
+extern "C" size_t nxz_lz77_gen_scratch_bytes(void) { return nxzl77::gen::table_off(NXZ_LZ77_MAX_GRID) + (size_t)NXZ_LZ77_MAX_GRID * 2 * sizeof(nxz_dht_prepared_t); }
 extern "C" size_t nxz_lz77_cand2_bytes(void) { return (size_t)NXZ_LZ77_MAX_GRID * nxzl77::C2_STRIDE * sizeof(uint16_t); }
 
 extern "C" int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n, uint8_t *tokens, uint16_t *cand2, nxz_batch_result_t *results,
@@ -1594,9 +1918,10 @@ extern "C" int nxz_launch_lz77(int count, const nxz_batch_job_t *jobs, size_t n,
 {
 	using namespace nxzl77;
 	if (n == 0) return 0;
-	// count: 0 tokens for the entropy kernel, 1 tokens + symbol counts, 2 (NXZ_LZ77_FUSED_FHT) the finished fixed-Huffman block
+	// count: 0 tokens for the entropy kernel, 1 tokens + symbol counts, 2 (NXZ_LZ77_FUSED_FHT) the finished fixed-Huffman block,
+	// 3 (NXZ_LZ77_FUSED_GEN) the finished dynamic-Huffman block with the table of its own counts (`tokens`: nxz_lz77_gen_scratch_bytes())
 	void (*k)(const nxz_batch_job_t *, uint8_t *, uint16_t *, nxz_batch_result_t *, uint32_t *, uint32_t, uint32_t *);
-	k = count == 2 ? lz77_kernel<false, true> : count ? lz77_kernel<true> : lz77_kernel<false>;
+	k = count == 3 ? lz77_kernel<true, false, true> : count == 2 ? lz77_kernel<false, true> : count ? lz77_kernel<true> : lz77_kernel<false>;
 	// per device: the attribute belongs to the loaded code object of a device, and so does the CU count
 	static int ncu_of[64];
 	int dev = 0;

@@ -971,3 +971,41 @@ def test_trim_gives_the_token_scratch_back_and_the_next_batch_works(eng):
             freed = eng.L.nxz_trim()
             assert freed >= len(blocks) * 106496, freed
     assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+
+
+def test_fused_dhtgen_kernel_equals_the_three_kernels(eng):
+    """NXZ_FUSED_GEN=1: LZ77, table and encode in one kernel (nxz_lz77.hip gen::: the table of a block is made by one wavefront
+    while the others encode the block before it; a workgroup's last block behind its loop).  The same bytes, completion codes
+    and symbol counts as the three kernels, for batches of one job per workgroup, of several, and with ragged and empty blocks;
+    the oracle's for a sample."""
+    import torch
+    kinds = ["alice", "lz", "binary", "text33", "zeros", "random", "periodic", "sparse"]
+    for nb in (1, 5, 700):
+        sizes = [65536 if i % 7 else [0, 1, 30000 + i, 16384, 16385, 65535][i % 6] for i in range(nb)]
+        blocks = [make_block(kinds[i % len(kinds)], sizes[i], seed=900 + i) for i in range(nb)]
+        src = pack_blocks(eng, blocks, STRIDE_IN)
+        lens = np.array([len(b) for b in blocks], np.uint32)
+        got = {}
+        for mode in ("0", "1"):
+            os.environ["NXZ_FUSED_GEN"] = mode
+            try:
+                dst = torch.zeros((nb, STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+                jobs = eng.jobs_strided(src, STRIDE_IN, lens, dst, STRIDE_OUT, STRIDE_OUT)
+                res, cnt = eng.compress(pkg.FC_COMPRESS_DHTGEN_COUNT, jobs, nb)
+                r = eng.results_to_host(res)
+                got[mode] = (r.copy(), dst.cpu().numpy().copy(), cnt.cpu().numpy().copy())
+            finally:
+                os.environ.pop("NXZ_FUSED_GEN", None)
+        a, b = got["0"], got["1"]
+        for f in ("cc", "tpbc", "tebc", "spbc", "crc", "adler"):
+            assert (a[0][f] == b[0][f]).all(), (nb, f)
+        assert (a[2] == b[2]).all(), nb
+        for i in range(nb):
+            n = int(a[0]["tpbc"][i])
+            assert a[1][i, :n].tobytes() == b[1][i, :n].tobytes(), (nb, i)
+        for i in range(0, nb, max(1, nb // 12)):
+            tok, nt = O.lz77(blocks[i])
+            ll, d = O.counts(tok, nt)
+            dht, dhtlen = O.dhtgen(ll, d)
+            exp, bits = O.deflate_dynamic(blocks[i], dht, dhtlen)
+            assert b[0]["tpbc"][i] == len(exp) and b[1][i, :len(exp)].tobytes() == exp, (nb, i)
