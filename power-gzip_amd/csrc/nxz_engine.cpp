@@ -91,21 +91,21 @@ struct nxz_ctx {
 		size_t chunk_cap = 0;
 		size_t chunk_limit = 0;                   // jobs per chunk the device had room for when a larger chunk could not be had (0: no such failure yet)
 		void release_chunk() {
-			if (d_tokens) (void)hipFree(d_tokens);
-			if (d_gen) (void)hipFree(d_gen);
-			if (d_counts) (void)hipFree(d_counts);
+			if (d_tokens) (void)hipFree(d_tokens);                       // (d_gen and d_counts lie inside it)
 			d_tokens = nullptr; d_gen = nullptr; d_counts = nullptr; chunk_cap = 0;
 		}
 		// the three buffers of a chunk, all or none
 		bool alloc_chunk(size_t chunk) {
-			if (hipMalloc((void **)&d_tokens, chunk * (size_t)NXZ_TOK_STRIDE) == hipSuccess &&
-			    hipMalloc((void **)&d_gen, chunk * sizeof(nxz_dht_prepared_t)) == hipSuccess &&
-			    hipMalloc((void **)&d_counts, chunk * 316 * sizeof(uint32_t)) == hipSuccess) {
+			// (one allocation: the tokens, then the tables, then the counts)
+			const size_t tb = (chunk * (size_t)NXZ_TOK_STRIDE + 255) & ~(size_t)255, gb = (chunk * sizeof(nxz_dht_prepared_t) + 255) & ~(size_t)255;
+			if (hipMalloc((void **)&d_tokens, tb + gb + chunk * 316 * sizeof(uint32_t)) == hipSuccess) {
+				d_gen = (nxz_dht_prepared_t *)(d_tokens + tb);
+				d_counts = (uint32_t *)(d_tokens + tb + gb);
 				chunk_cap = chunk;
 				return true;
 			}
 			(void)hipGetLastError();
-			release_chunk();
+			d_tokens = nullptr; d_gen = nullptr; d_counts = nullptr;
 			return false;
 		}
 		void release() {
@@ -113,9 +113,7 @@ struct nxz_ctx {
 			if (d_lanes_ws) (void)hipFree(d_lanes_ws);
 			if (d_order_ws) (void)hipFree(d_order_ws);
 			if (d_cut_ws) (void)hipFree(d_cut_ws);
-			if (d_tokens) (void)hipFree(d_tokens);
-			if (d_gen) (void)hipFree(d_gen);
-			if (d_counts) (void)hipFree(d_counts);
+			if (d_tokens) (void)hipFree(d_tokens);                       // (d_gen and d_counts lie inside it)
 			if (d_cand2) (void)hipFree(d_cand2);
 			if (d_fuse) (void)hipFree(d_fuse);
 			*this = Scratch();
@@ -132,6 +130,7 @@ struct nxz_ctx {
 		nxz_batch_job_t *d_jobs = nullptr, *h_jobs = nullptr;
 		nxz_batch_result_t *d_res = nullptr, *h_res = nullptr;
 		uint64_t *d_off = nullptr, *h_total = nullptr;
+		uint8_t *d_base = nullptr, *h_base = nullptr; // ONE device and ONE pinned allocation hold all of the above (sixteen threads' first calls queue for the runtime's allocator)
 		size_t n = 0; uint64_t bytes = 0;
 		size_t cap = 0;                           // blocks per group the buffers hold
 	} lanes[2 * HOST_PAIRS];
@@ -315,8 +314,7 @@ extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 			auto it = c->scratch.find(l.stream);
 			if (it != c->scratch.end()) { it->second.release(); c->scratch.erase(it); }
 		}
-		(void)hipFree(l.d_src); (void)hipFree(l.d_dst); (void)hipFree(l.d_packed); (void)hipFree(l.d_jobs); (void)hipFree(l.d_res); (void)hipFree(l.d_off);
-		(void)hipHostFree(l.h_jobs); (void)hipHostFree(l.h_res); (void)hipHostFree(l.h_total);
+		(void)hipFree(l.d_base); (void)hipHostFree(l.h_base);
 		(void)hipStreamDestroy(l.stream);
 		l = nxz_ctx::HostLane();
 	}
@@ -796,7 +794,6 @@ static bool lane_need(nxz_ctx::HostLane &l, bool high, size_t blocks)
 		int least = 0, greatest = 0;
 		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
 		HIPCHK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, high ? greatest : least), return false);
-		HIPCHK(hipHostMalloc((void **)&l.h_total, sizeof(uint64_t)), return false);
 	}
 	if (blocks <= l.cap) return true;
 	size_t cap = 32;
@@ -804,19 +801,22 @@ static bool lane_need(nxz_ctx::HostLane &l, bool high, size_t blocks)
 	if (cap > HOST_GROUP) cap = HOST_GROUP;
 	if (l.cap) {
 		(void)hipStreamSynchronize(l.stream);
-		(void)hipFree(l.d_src); (void)hipFree(l.d_dst); (void)hipFree(l.d_packed); (void)hipFree(l.d_jobs); (void)hipFree(l.d_res); (void)hipFree(l.d_off);
-		(void)hipHostFree(l.h_jobs); (void)hipHostFree(l.h_res);
-		l.d_src = l.d_dst = l.d_packed = nullptr; l.d_jobs = l.h_jobs = nullptr; l.d_res = l.h_res = nullptr; l.d_off = nullptr;
+		(void)hipFree(l.d_base); (void)hipHostFree(l.h_base);
+		l.d_base = l.h_base = nullptr;
+		l.d_src = l.d_dst = l.d_packed = nullptr; l.d_jobs = l.h_jobs = nullptr; l.d_res = l.h_res = nullptr; l.d_off = nullptr; l.h_total = nullptr;
 		l.cap = 0;
 	}
-	HIPCHK(hipMalloc((void **)&l.d_src, cap * SUBBLOCK), return false);
-	HIPCHK(hipMalloc((void **)&l.d_dst, cap * HOST_SLOT), return false);
-	HIPCHK(hipMalloc((void **)&l.d_packed, cap * (SUBBLOCK + 16)), return false);
-	HIPCHK(hipMalloc((void **)&l.d_jobs, cap * sizeof(nxz_batch_job_t)), return false);
-	HIPCHK(hipHostMalloc((void **)&l.h_jobs, cap * sizeof(nxz_batch_job_t)), return false);
-	HIPCHK(hipMalloc((void **)&l.d_res, cap * sizeof(nxz_batch_result_t)), return false);
-	HIPCHK(hipHostMalloc((void **)&l.h_res, cap * sizeof(nxz_batch_result_t)), return false);
-	HIPCHK(hipMalloc((void **)&l.d_off, (cap + 1) * sizeof(uint64_t)), return false);
+	// one allocation on either side (round 4 made nine: with sixteen threads at their first call 30 streams and some 400
+	// allocations went through the runtime's lock one after the other -- 480 ms before the first call came back)
+	auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+	const size_t o_src = 0, o_dst = o_src + up(cap * SUBBLOCK), o_packed = o_dst + up(cap * HOST_SLOT), o_jobs = o_packed + up(cap * (SUBBLOCK + 16)),
+		     o_res = o_jobs + up(cap * sizeof(nxz_batch_job_t)), o_off = o_res + up(cap * sizeof(nxz_batch_result_t)), d_total = o_off + up((cap + 1) * sizeof(uint64_t));
+	const size_t p_jobs = 0, p_res = p_jobs + up(cap * sizeof(nxz_batch_job_t)), p_total = p_res + up(cap * sizeof(nxz_batch_result_t)), h_total_bytes = p_total + 256;
+	HIPCHK(hipMalloc((void **)&l.d_base, d_total), return false);
+	HIPCHK(hipHostMalloc((void **)&l.h_base, h_total_bytes), { (void)hipFree(l.d_base); l.d_base = nullptr; return false; });
+	l.d_src = l.d_base + o_src; l.d_dst = l.d_base + o_dst; l.d_packed = l.d_base + o_packed;
+	l.d_jobs = (nxz_batch_job_t *)(l.d_base + o_jobs); l.d_res = (nxz_batch_result_t *)(l.d_base + o_res); l.d_off = (uint64_t *)(l.d_base + o_off);
+	l.h_jobs = (nxz_batch_job_t *)(l.h_base + p_jobs); l.h_res = (nxz_batch_result_t *)(l.h_base + p_res); l.h_total = (uint64_t *)(l.h_base + p_total);
 	l.cap = cap;
 	return true;
 }
