@@ -1,6 +1,6 @@
 """Soak run (not collected by pytest): seeded random zlib streams (all levels and strategies, flushed
 pieces, sizes 0..300 KB, with history and cut-off tails) through the inflate kernels of the HIP
-engine (a stream per lane with and without the fixed-code-only kernel in front, a stream per wave with the window in LDS and in the target), every result compared with the oracle (output, stop state, checksums).
+engine (a stream per lane with and without the fixed-code-only kernel in front, a stream per wave with the window in LDS and in the target, every stream cut into pieces on the device), every result compared with the oracle (output, stop state, checksums).
 python tests/soak_inflate_gpu.py [seeds]"""
 import importlib, os, random, sys, zlib
 import numpy as np
@@ -45,7 +45,11 @@ for seed in range(1, nseeds + 1):
     for kernel, env in (("lanes", {"NXZ_INFLATE_LANES_MIN": "1", "NXZ_LANES_FIXED": "0"}),
                         ("lanes, the fixed-code-only kernel first", {"NXZ_INFLATE_LANES_MIN": "1", "NXZ_LANES_FIXED": "2"}),
                         ("waves, window in LDS", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_LDS_MAX": "1000000000"}),
-                        ("waves, target as window", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_LDS_MAX": "0"})):
+                        ("waves, target as window", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_LDS_MAX": "0"}),
+                        ("every stream cut into pieces on the device", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_CUT": "1"}),
+                        ("... three pieces a round, two rounds", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_CUT": "1", "NXZ_INFLATE_CUT_PIECES": "3", "NXZ_INFLATE_CUT_ROUNDS": "2"})):
+        os.environ["NXZ_INFLATE_CUT"] = "0"
+        os.environ.pop("NXZ_INFLATE_CUT_PIECES", None); os.environ.pop("NXZ_INFLATE_CUT_ROUNDS", None)
         os.environ.update(env)
         dst = torch.full((len(cases), ostride), 0xAA, dtype=torch.uint8, device=eng.dev)
         jobs = eng.jobs_strided(src, cstride, np.array([len(c) for c, _ in cases], np.uint32), dst, ostride, np.array([cap for _, cap in cases], np.uint32),
