@@ -536,8 +536,11 @@ def run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng):
             if len(raw_r04) != len(raw):
                 s4 = stream_leg(torch, eng, raw_r04, args)
                 line["inflate_stream"]["without_image_and_packed_classes"] = {k: s4[k] for k in ("value", "unit", "ms", "pieces", "bit_exact") if k in s4}
+                z4 = inflate_leg(torch, eng, pkg, raw_r04, max(1, -(-args.corpus_jobs // len(raw_r04))), dict_args(args, no_cpu_baseline=True))
+                line["inflate_zlib6"]["without_image_and_packed_classes"] = {k: z4[k] for k in ("value", "unit", "ms_per_pass", "streams", "bit_exact") if k in z4}
         if not args.no_api:
-            line["api"] = api_leg(raw, args)
+            raw_r04 = [b for cls, _, b in blocks if cls not in ("image", "packed")]
+            line["api"] = api_leg(raw, args, raw_r04=raw_r04 if len(raw_r04) != len(raw) else None)
         if not args.no_c2:
             torch.cuda.empty_cache()
             # configs[1] at its stated size (2^20 blocks: 136 GiB of buffers + scratch) when the device has the room, else 2^18
@@ -549,7 +552,7 @@ def run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng):
     print(json.dumps(line), flush=True)
 
 
-def api_leg(raw, args, mib=256, nthreads=16):
+def api_leg(raw, args, mib=256, nthreads=16, raw_r04=None):
     """Through the reference's own API (libnxz_amd.so: nx_compress2 / nx_uncompress, HOST buffers, PCIe and
     host copies inside the timed region): one call over `mib` MiB, and `nthreads` threads each compressing
     64 KiB buffers one call after the other (the shape of the reference's samples/compdecomp_th.c)."""
@@ -579,57 +582,72 @@ def api_leg(raw, args, mib=256, nthreads=16):
         raise SystemExit("api leg: zlib does not read nx_compress2's stream back")
     out["compress2_one_shot"] = {"value": round(len(data) / best / 2.0 ** 30, 2), "unit": "GiB/s uncompressed in", "MiB": mib,
                                  "ms": round(best * 1e3, 2), "ratio": round(len(data) / len(comp), 3), "zlib_reads_it_back": True}
-    z6 = zlib.compress(data, 6)
-    back = C.create_string_buffer(len(data))
-    best = 1e9
-    for it in range(4):
-        n = C.c_ulong(len(data))
-        t = time.perf_counter()
-        rc = L.nx_uncompress(back, C.byref(n), z6, len(z6))
-        dt = time.perf_counter() - t
-        if rc != 0 or n.value != len(data):
-            return dict(out, error="nx_uncompress returned %d" % rc)
-        if it:
-            best = min(best, dt)
-    if back.raw != data:
-        raise SystemExit("api leg: nx_uncompress of a zlib -6 stream differs from the source")
-    out["uncompress_one_shot"] = {"value": round(len(data) / best / 2.0 ** 30, 2), "unit": "GiB/s uncompressed out", "MiB": mib,
-                                  "ms": round(best * 1e3, 2), "stream": "zlib level 6, one zlib stream"}
-    # the same data as a .gz through inflate() with avail_in / avail_out steps of 64 KiB and 1 MiB
-    co = zlib.compressobj(6, zlib.DEFLATED, 31)
-    gz = co.compress(data[:64 << 20]) + co.flush()
-    gsrc = C.create_string_buffer(gz, len(gz))
-    gdst = C.create_string_buffer(1 << 20)
-    for step in (64 << 10, 1 << 20):
+    def inflate_side(data):
+        out = {}
+        z6 = zlib.compress(data, 6)
+        back = C.create_string_buffer(len(data))
         best = 1e9
-        for it in range(2):
-            st = Z.ZStream()
-            if L.nx_inflateInit2_(C.byref(st), 31, Z.VERSION, C.sizeof(Z.ZStream)) != 0:
-                return dict(out, error="nx_inflateInit2_ failed")
-            fed = total = 0
-            crc = 0
-            rc = 0
+        for it in range(4):
+            n = C.c_ulong(len(data))
             t = time.perf_counter()
-            while rc != Z.Z_STREAM_END:
-                if st.avail_in == 0 and fed < len(gz):
-                    k = min(step, len(gz) - fed)
-                    st.next_in = C.addressof(gsrc) + fed
-                    st.avail_in = k
-                    fed += k
-                st.next_out = C.addressof(gdst)
-                st.avail_out = step
-                rc = L.nx_inflate(C.byref(st), Z.Z_NO_FLUSH)
-                if rc not in (Z.Z_OK, Z.Z_STREAM_END, Z.Z_BUF_ERROR) or (rc == Z.Z_BUF_ERROR and st.avail_out == step and fed == len(gz)):
-                    return dict(out, error="nx_inflate in steps returned %d" % rc)
-                total += step - st.avail_out
+            rc = L.nx_uncompress(back, C.byref(n), z6, len(z6))
             dt = time.perf_counter() - t
-            crc = st.adler
-            L.nx_inflateEnd(C.byref(st))
-            best = min(best, dt)
-        if total != (64 << 20) or crc != zlib.crc32(data[:64 << 20]):
-            raise SystemExit("api leg: nx_inflate in steps of %d made %d bytes, crc %08x" % (step, total, crc))
-        out["inflate_in_steps_%dKiB" % (step >> 10)] = {"value": round(total / best / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out", "MiB": 64,
-                                                        "ms": round(best * 1e3, 1), "stream": "zlib level 6 .gz, avail_in = avail_out = the step"}
+            if rc != 0 or n.value != len(data):
+                return dict(out, error="nx_uncompress returned %d" % rc)
+            if it:
+                best = min(best, dt)
+        if back.raw != data:
+            raise SystemExit("api leg: nx_uncompress of a zlib -6 stream differs from the source")
+        out["uncompress_one_shot"] = {"value": round(len(data) / best / 2.0 ** 30, 2), "unit": "GiB/s uncompressed out", "MiB": mib,
+                                      "ms": round(best * 1e3, 2), "stream": "zlib level 6, one zlib stream"}
+        # the same data as a .gz through inflate() with avail_in / avail_out steps of 64 KiB and 1 MiB
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        gz = co.compress(data[:64 << 20]) + co.flush()
+        gsrc = C.create_string_buffer(gz, len(gz))
+        gdst = C.create_string_buffer(1 << 20)
+        for step in (64 << 10, 1 << 20):
+            best = 1e9
+            for it in range(2):
+                st = Z.ZStream()
+                if L.nx_inflateInit2_(C.byref(st), 31, Z.VERSION, C.sizeof(Z.ZStream)) != 0:
+                    return dict(out, error="nx_inflateInit2_ failed")
+                fed = total = 0
+                crc = 0
+                rc = 0
+                t = time.perf_counter()
+                while rc != Z.Z_STREAM_END:
+                    if st.avail_in == 0 and fed < len(gz):
+                        k = min(step, len(gz) - fed)
+                        st.next_in = C.addressof(gsrc) + fed
+                        st.avail_in = k
+                        fed += k
+                    st.next_out = C.addressof(gdst)
+                    st.avail_out = step
+                    rc = L.nx_inflate(C.byref(st), Z.Z_NO_FLUSH)
+                    if rc not in (Z.Z_OK, Z.Z_STREAM_END, Z.Z_BUF_ERROR) or (rc == Z.Z_BUF_ERROR and st.avail_out == step and fed == len(gz)):
+                        return dict(out, error="nx_inflate in steps returned %d" % rc)
+                    total += step - st.avail_out
+                dt = time.perf_counter() - t
+                crc = st.adler
+                L.nx_inflateEnd(C.byref(st))
+                best = min(best, dt)
+            if total != (64 << 20) or crc != zlib.crc32(data[:64 << 20]):
+                raise SystemExit("api leg: nx_inflate in steps of %d made %d bytes, crc %08x" % (step, total, crc))
+            out["inflate_in_steps_%dKiB" % (step >> 10)] = {"value": round(total / best / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out", "MiB": 64,
+                                                            "ms": round(best * 1e3, 1), "stream": "zlib level 6 .gz, avail_in = avail_out = the step"}
+        return out
+
+    side = inflate_side(data)
+    if "error" in side:
+        return dict(out, **side)
+    out.update(side)
+    if raw_r04 is not None:
+        # the same on the classes the corpus had up to round 4 (see run_corpus: the image-like and packed classes are all-literal and stored blocks under zlib -6)
+        b4 = b"".join(raw_r04)
+        side4 = inflate_side((b4 * ((mib << 20) // len(b4) + 1))[:mib << 20])
+        for k, v in side4.items():
+            if isinstance(v, dict) and k in out:
+                out[k]["without_image_and_packed_classes"] = v.get("value")
     blocks = [data[i * BLOCK:(i + 1) * BLOCK] for i in range(min(1024, len(data) // BLOCK))]
 
     def worker(res, k):
@@ -757,6 +775,15 @@ def stream_leg(torch, eng, raw, args, mib=256):
         out["cpu_baseline"] = {"value": round(len(data) / (time.perf_counter() - t0) / 2.0 ** 30, 4), "unit": "GiB/s uncompressed out", "cores": 1,
                                "kind": "reference", "what": "system zlib inflate of the same stream, one thread"}
     return out
+
+
+def dict_args(args, **over):
+    """a copy of the parsed arguments with some of them replaced"""
+    import copy
+    a = copy.copy(args)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
 
 
 def inflate_leg(torch, eng, pkg, raw, rep, args):

@@ -1385,7 +1385,9 @@ static int round_run_inflate(nxz_ctx *c, nxz_ctx::Round &R, std::vector<InflateR
 		size_t longish = 0;
 		for (size_t k = 0; k < n; k++) {
 			const nxz_batch_job_t &j = v[k]->job;
-			if (j.src_len - (j.hist_len < j.src_len ? j.hist_len : j.src_len) >= 4096 && v[k]->d_out) longish++;
+			// (long enough, and standing where a stream can be cut: at a block header or inside a dynamic block)
+			const uint32_t sfbt = (j.resume >> 16) & 15;
+			if (j.src_len - (j.hist_len < j.src_len ? j.hist_len : j.src_len) >= 4096 && v[k]->d_out && (sfbt == 0 || (sfbt & 0xe) == 0xe || (sfbt & 0xe) == 0xc)) longish++;
 		}
 		cut = longish > 0;
 	}

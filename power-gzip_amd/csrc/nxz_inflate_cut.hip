@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t hist_of(const nxz_batch_job_t &j) { return j
 // ---- plan: what this round looks at ----
 __global__ void plan_kernel(const nxz_batch_job_t *__restrict__ jobs, uint32_t n, uint32_t P, uint32_t PT, uint32_t round, nxz_sync_req_t *__restrict__ bq,
 			    nxz_sync_req_t *__restrict__ rq, Ctl *__restrict__ ctl, Arena *__restrict__ arena, unsigned long long arena_size,
-			    uint32_t *__restrict__ order, uint32_t *__restrict__ order2)
+			    uint32_t *__restrict__ order, uint32_t *__restrict__ order2, const nxz_batch_dht_t *__restrict__ dht_io, nxz_batch_dht_t *__restrict__ tb)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i == 0) {
@@ -97,12 +97,15 @@ __global__ void plan_kernel(const nxz_batch_job_t *__restrict__ jobs, uint32_t n
 	Ctl c;
 	if (round == 0) {
 		const uint32_t in_subc = (job.resume >> 20) & 7, in_sfbt = (job.resume >> 16) & 15;
-		// at a block header (a fresh stream, or one that was suspended there), its bytes where the piece kernel can load 16 a lane
-		const bool ok = srclen >= CUT_MIN_SRC && srclen < (1u << 28) && ((uintptr_t)S & 15) == 0 && (in_sfbt == 0 || (in_sfbt & 0xe) == 0xe) && job.dst_cap >= 1024;
+		// at a block header (a fresh stream, or one that was suspended there) or inside a dynamic block whose table the job brings (a
+		// part of a stream that a caller of inflate() feeds in steps); its bytes where the piece kernel can load 16 a lane
+		const bool inside = (in_sfbt & 0xe) == 0xc && dht_io != nullptr;
+		const bool ok = srclen >= CUT_MIN_SRC && srclen < (1u << 28) && ((uintptr_t)S & 15) == 0 && (in_sfbt == 0 || (in_sfbt & 0xe) == 0xe || inside) && job.dst_cap >= 1024;
 		c = Ctl();
 		c.state = ok ? ST_ACTIVE : ST_PLAIN;
 		c.cur_bit = srclen && in_subc ? 8 - in_subc : 0;
-		c.sfbt = 0xe;
+		c.sfbt = inside ? in_sfbt : 0xe;
+		if (ok && inside) tb[i] = dht_io[i];
 		const uint32_t ext0 = n * P <= 2048 ? EXT_FIRST_FEW : EXT_FIRST;
 		c.ext = srclen < ext0 ? srclen : ext0;
 	} else c = ctl[i];
@@ -486,7 +489,7 @@ extern "C" int nxz_launch_inflate_cut(const nxz_batch_job_t *jobs, size_t n, nxz
 	const unsigned nb = (unsigned)((n + 255) / 256);
 	int rc;
 	for (unsigned r = 0; r < rounds; r++) {
-		hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(256), 0, stream, jobs, (uint32_t)n, P, PT, r, bq, rq, ctl, ar, (unsigned long long)arena, order, order2);
+		hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(256), 0, stream, jobs, (uint32_t)n, P, PT, r, bq, rq, ctl, ar, (unsigned long long)arena, order, order2, dht_io, tb);
 		rc = nxz_launch_token_sync(bq, (uint32_t)n, tb, bt, rq, (uint32_t)(n * (P - 1)), rs, stream);
 		if (rc) return rc;
 		hipLaunchKernelGGL(jobs_kernel, dim3(nb), dim3(256), 0, stream, jobs, (uint32_t)n, P, PT, r, rs, tb, bt, ctl, pj, pd, elems, ar, order);

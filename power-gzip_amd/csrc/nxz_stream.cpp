@@ -674,6 +674,8 @@ struct Inflate {
 	uint8_t trailer[8]; uint32_t ntrailer = 0;
 	bool sync_point = false, have_dict = false;
 	uint32_t par_skip = 0, par_declined = 0;           // calls for which the parallel decode is not tried again; declines in a row
+	bool whole_at_once = false;                        // the call in work was told Z_FINISH before anything of the stream had been taken: a one-shot call
+	bool one_shot_hint = false;                        // ... or comes from nx_uncompress2, which holds the whole source
 	uint32_t ratio = 250;                              // last compressed/uncompressed per mille (:1234-1250)
 	Engine eng; JobBuf jb; std::vector<uint8_t> src, out;
 
@@ -751,13 +753,15 @@ void *nxz_stream_create(nxz_ctx_t *) __attribute__((weak));
 int nxz_ctx_device(nxz_ctx_t *) __attribute__((weak));
 int nxz_engine_usable(void) __attribute__((weak));
 }
-// (12 KiB up to round 4.  Below some 64 KiB of stream a job does as well since the rounds of nxu_run_job cut their jobs
-// into pieces -- nxz_inflate_cut.hip, one sequence of launches for all callers of a round -- and better the more threads
-// call at once: 64 threads x 64 KiB buffers 1.18 against 0.40 GiB/s.  NXZ_PARALLEL_INFLATE_MIN overrides, bytes.)
-static size_t parallel_inflate_min()
+// 12 KiB -- but 64 KiB for a stream that comes in ONE call (nx_uncompress, inflate() with Z_FINISH on a fresh stream: the shape of
+// samples/compdecomp_th.c): such a buffer is a job, and the rounds of nxu_run_job cut their jobs into pieces (nxz_inflate_cut.hip,
+// one sequence of launches for all callers of a round) -- the better the more threads call at once: 64 threads x 64 KiB buffers 1.7
+// against 0.40 GiB/s.  Not for a stream that comes in steps: what a step leaves over is often just short of the step, and as a
+// job it is cut in its first blocks only (inflate() in 64 KiB steps: 0.27 against 0.23 GiB/s).  NXZ_PARALLEL_INFLATE_MIN: both, bytes.
+static size_t parallel_inflate_min(bool whole_at_once)
 {
-	static const size_t v = getenv("NXZ_PARALLEL_INFLATE_MIN") ? (size_t)strtoull(getenv("NXZ_PARALLEL_INFLATE_MIN"), nullptr, 0) : (size_t)64 << 10;
-	return v;
+	static const size_t v = getenv("NXZ_PARALLEL_INFLATE_MIN") ? (size_t)strtoull(getenv("NXZ_PARALLEL_INFLATE_MIN"), nullptr, 0) : 0;
+	return v ? v : whole_at_once ? (size_t)64 << 10 : (size_t)12 << 10;
 }
 constexpr size_t CARRY_KEEP = 1024;                // unconsumed source kept between calls at most: a dynamic block header (<= 290 bytes) and a token
 
@@ -769,7 +773,7 @@ bool parallel_inflate(Inflate *s)
 	if (nxz_engine_usable && !nxz_engine_usable()) return false;       // (forked after the engine was opened: the job loop reports it)
 	static const bool off = getenv("NXZ_PARALLEL_INFLATE") && atoi(getenv("NXZ_PARALLEL_INFLATE")) == 0;   // 0: always job after job
 	const size_t nc = s->carry.size();
-	if (off || nc + z->avail_in < parallel_inflate_min()) return false;
+	if (off || nc + z->avail_in < parallel_inflate_min(s->whole_at_once)) return false;
 	if (s->par_skip) { s->par_skip--; return false; }           // (declined a moment ago: this stream is not the kind)
 	nxz_ctx_t *ctx = (nxz_ctx_t *)s->eng.dev.paste_addr;
 	if (!ctx) return false;
@@ -1155,6 +1159,7 @@ extern "C" int nx_inflate(z_streamp strm, int flush)
 	if (flush == Z_BLOCK || flush == Z_TREES) { strm->msg = (char *)"Z_BLOCK or Z_TREES not implemented"; return Z_STREAM_ERROR; }
 	if (strm->next_out == Z_NULL && strm->avail_out) return Z_STREAM_ERROR;
 	const uInt in0 = strm->avail_in, out0 = strm->avail_out;
+	s->whole_at_once = (flush == Z_FINISH || s->one_shot_hint) && strm->total_in == 0;
 	int rc = Z_OK;
 	uint32_t c;
 #define NEXT(state) do { s->st = Inflate::state; } while (0)
@@ -1352,6 +1357,7 @@ extern "C" int nx_uncompress2(Bytef *dest, uLongf *destLen, const Bytef *source,
 	st.next_in = (z_const Bytef *)source; st.avail_in = 0;
 	int rc = nx_inflateInit(&st);
 	if (rc != Z_OK) return rc;
+	if (Inflate *is = istate(&st)) is->one_shot_hint = len <= maxu;      // (the whole source is in the first call)
 	st.next_out = dest; st.avail_out = 0;
 	do {
 		if (st.avail_out == 0) { st.avail_out = left > maxu ? maxu : (uInt)left; left -= st.avail_out; }

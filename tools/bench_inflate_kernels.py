@@ -12,7 +12,8 @@ pkg = importlib.import_module("power-gzip_amd")
 B, S = 65536, 73856
 sizes = [int(x) for x in os.environ.get("SIZES", "4096,16384,65536,131072,262144").split(",")]
 _, blocks, _ = corpus.load(B)
-raw = [b for _, _, b in blocks if len(b) == B]
+only = [c for c in os.environ.get("CLASSES", "").split(",") if c]                  # CLASSES=text,xml: those classes of the corpus only
+raw = [b for cls, _, b in blocks if len(b) == B and (not only or cls in only)]
 
 
 def timed(eng, jobs, n):

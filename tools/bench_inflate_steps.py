@@ -15,7 +15,8 @@ import zstream as Z
 
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 _, blocks, _ = corpus.load(65536)
-raw = b"".join(b for _, _, b in blocks)
+only = [c for c in os.environ.get("CLASSES", "").split(",") if c]                  # CLASSES=text,xml: those classes of the corpus only
+raw = b"".join(b for cls, _, b in blocks if not only or cls in only)
 plain = (raw * (1 + (mib << 20) // len(raw)))[:mib << 20]
 co = zlib.compressobj(6, zlib.DEFLATED, 31)
 gz = co.compress(plain) + co.flush()
