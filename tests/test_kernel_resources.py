@@ -13,9 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel -> (max VGPRs, max scratch bytes per lane)
 BUDGET = {
-    "nxzl77::lz77_kernel<false, false>": (128, 64),   # 1024 threads per workgroup: 128 is the cap
-    "nxzl77::lz77_kernel<true, false>": (128, 64),
-    "nxzl77::lz77_kernel<false, true>": (128, 64),    # the fixed-Huffman form that writes the finished block
+    "nxzl77::lz77_kernel<false, false, false>": (128, 64),   # 1024 threads per workgroup: 128 is the cap
+    "nxzl77::lz77_kernel<true, false, false>": (128, 64),
+    "nxzl77::lz77_kernel<false, true, false>": (128, 64),    # the fixed-Huffman form that writes the finished block
+    "nxzl77::lz77_kernel<true, false, true>": (128, 64),     # the opt-in form that also makes the table and encodes
     "nxze::encode_kernel<false, false>": (64, 0),     # seven workgroups of 256 threads per CU
     "nxze::encode_kernel<true, true>": (64, 0),       # a caller's table (symbols may be missing: checked)
     "nxze::encode_kernel<true, false>": (64, 0),      # the table the device made of the block's own counts
@@ -25,7 +26,7 @@ BUDGET = {
     "nxzi::inflate_kernel<false, false>": (128, 0),   # window in LDS: LDS bounds the occupancy, not registers
     "nxzi::inflate_kernel<false, true>": (128, 0),
     "nxzl::inflate_lanes_kernel": (128, 48),          # a stream per lane, any block type: four waves per SIMD
-    "nxzl::inflate_lanes_fixed_kernel": (80, 24),     # ... stored and fixed-code blocks only: six
+    "nxzl::inflate_lanes_fixed_kernel": (80, 32),     # ... stored and fixed-code blocks only: six
     "nxzl::cksum_kernel<false>": (96, 0),
     "nxzl::cksum_kernel<true>": (96, 0),            # the WRAP function code: the same pass, storing as it goes
     "nxzb::find_blocks_kernel": (96, 0),
