@@ -72,6 +72,11 @@ int nxz_launch_sample_btype(const nxz_batch_job_t *jobs, size_t n, uint32_t *out
 int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream);
 int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n, uint32_t final_index,
 			   uint64_t *offsets, uint8_t *packed, hipStream_t stream);
+/* several callers' blocks in one batch, each caller's packed as its own stream: blocks [b0, b0 + n) are member's, block `fin`
+ * (an index into the batch, 0xffffffff: none) carries BFINAL, its n + 1 offsets stand at offsets[off0 ..], its stream goes to `packed` */
+typedef struct nxz_pack_member { uint32_t b0, n, fin, off0; uint8_t *packed; } nxz_pack_member_t;
+int nxz_launch_pack_member_streams(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t nblocks, const nxz_pack_member_t *members,
+				   size_t nmembers, const uint16_t *member_of, uint64_t *offsets, hipStream_t stream);
 int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);   /* items: { src, dst, uint64 bytes } */
 size_t nxz_inflate_lanes_workspace(size_t n);
 /* nxz_inflate_cut.hip: a batch too small to fill the device a stream per wavefront -- every stream cut inside its first block */

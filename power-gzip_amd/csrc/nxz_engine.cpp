@@ -130,12 +130,35 @@ struct nxz_ctx {
 		nxz_batch_job_t *d_jobs = nullptr, *h_jobs = nullptr;
 		nxz_batch_result_t *d_res = nullptr, *h_res = nullptr;
 		uint64_t *d_off = nullptr, *h_total = nullptr;
+		uint8_t *h_src = nullptr, *h_packed = nullptr; // pinned staging for calls of a few MiB (null above STAGE_MAX_BLOCKS per group)
 		uint8_t *d_base = nullptr, *h_base = nullptr; // ONE device and ONE pinned allocation hold all of the above (sixteen threads' first calls queue for the runtime's allocator)
 		size_t n = 0; uint64_t bytes = 0;
 		size_t cap = 0;                           // blocks per group the buffers hold
 	} lanes[2 * HOST_PAIRS];
 	std::mutex lanes_mtx[HOST_PAIRS];
 	std::atomic<unsigned> lanes_turn{0};
+	// nxz_deflate_host calls of a few MiB from many threads: the callers that are there at the same time put their blocks into
+	// ONE batch (a launch of each kernel for all of them, on one stream), as the rounds below do for single-block jobs --
+	// a HIP stream per caller does not get them side by side: the runtime maps the streams onto four hardware queues, and
+	// sixteen threads of 1 MiB calls ran at 4 GiB/s, two or three calls at a time (merged_deflate)
+	struct Merge {
+		enum State { FREE, OPEN, RUNNING, DONE } state = FREE;
+		hipStream_t stream = nullptr;
+		uint8_t *h_src = nullptr, *h_packed = nullptr;       // pinned: the callers copy their source in and their stream out themselves
+		uint8_t *d_src = nullptr, *d_dst = nullptr;
+		nxz_batch_job_t *h_jobs = nullptr;                   // pinned, read and written by the kernels in place, as a round's
+		nxz_batch_result_t *h_res = nullptr;
+		uint64_t *h_off = nullptr;
+		nxz_pack_member_t *h_mem = nullptr;
+		uint16_t *h_member_of = nullptr;
+		uint8_t *h_base = nullptr, *d_base = nullptr;
+		int fc = 0; uint32_t H = 0;
+		uint32_t slots = 0, jobs = 0, members = 0, filled = 0, left = 0;   // slots: 64 KiB units of staging (windows too); jobs: blocks
+		int rc = 0;
+		bool ready = false;
+	} merges[3];
+	std::mutex mm;
+	std::condition_variable mcv;
 	// nxu_run_job, compress: callers that arrive while a launch is in flight are gathered and go out
 	// together as one launch of each kernel (run_compress / round_run)
 	struct Round {
@@ -317,6 +340,18 @@ extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 		(void)hipFree(l.d_base); (void)hipHostFree(l.h_base);
 		(void)hipStreamDestroy(l.stream);
 		l = nxz_ctx::HostLane();
+	}
+	for (auto &m : c->merges) {
+		if (!m.stream) continue;
+		(void)hipStreamSynchronize(m.stream);
+		{
+			std::lock_guard<std::mutex> g2(c->mtx);
+			auto it = c->scratch.find(m.stream);
+			if (it != c->scratch.end()) { it->second.release(); c->scratch.erase(it); }
+		}
+		(void)hipFree(m.d_base); (void)hipHostFree(m.h_base);
+		(void)hipStreamDestroy(m.stream);
+		m = nxz_ctx::Merge();
 	}
 	for (auto &r : c->rounds) {
 		if (r.stream) { (void)hipStreamSynchronize(r.stream); (void)hipStreamDestroy(r.stream); }
@@ -732,6 +767,7 @@ extern "C" int nxz_batch_pack_gzip(nxz_ctx_t *c, const nxz_batch_job_t *jobs, co
 // nxz_deflate_host: a long HOST buffer -> one raw deflate stream in a HOST buffer
 // ---------------------------------------------------------------------------
 #define HOST_GROUP 256u                    /* blocks per group: 16 MiB in, one launch of each kernel */
+#define STAGE_MAX_BLOCKS 64u               /* groups up to this many blocks go through the lane's pinned staging */
 #define HOST_SLOT 73856u                   /* room for one block's output (nxz_compress_bound(65536) rounded) */
 
 static uint32_t gf2_mul32(uint32_t a, uint32_t b)
@@ -804,6 +840,7 @@ static bool lane_need(nxz_ctx::HostLane &l, bool high, size_t blocks)
 		(void)hipFree(l.d_base); (void)hipHostFree(l.h_base);
 		l.d_base = l.h_base = nullptr;
 		l.d_src = l.d_dst = l.d_packed = nullptr; l.d_jobs = l.h_jobs = nullptr; l.d_res = l.h_res = nullptr; l.d_off = nullptr; l.h_total = nullptr;
+		l.h_src = l.h_packed = nullptr;
 		l.cap = 0;
 	}
 	// one allocation on either side (round 4 made nine: with sixteen threads at their first call 30 streams and some 400
@@ -811,14 +848,160 @@ static bool lane_need(nxz_ctx::HostLane &l, bool high, size_t blocks)
 	auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
 	const size_t o_src = 0, o_dst = o_src + up(cap * SUBBLOCK), o_packed = o_dst + up(cap * HOST_SLOT), o_jobs = o_packed + up(cap * (SUBBLOCK + 16)),
 		     o_res = o_jobs + up(cap * sizeof(nxz_batch_job_t)), o_off = o_res + up(cap * sizeof(nxz_batch_result_t)), d_total = o_off + up((cap + 1) * sizeof(uint64_t));
-	const size_t p_jobs = 0, p_res = p_jobs + up(cap * sizeof(nxz_batch_job_t)), p_total = p_res + up(cap * sizeof(nxz_batch_result_t)), h_total_bytes = p_total + 256;
+	// Calls of a few MiB from many threads: the caller's pages are not pinned, and a copy straight from them makes the
+	// runtime pin and unpin them per call under the process's memory-map lock -- sixteen threads of 1 MiB calls ran at
+	// 4 GiB/s that way.  Up to STAGE_MAX_BLOCKS per group the lane has pinned staging of its own: the calling thread
+	// copies in and out of it (its own core's time), the DMA runs from pinned memory.
+	static const bool stage_on = !(getenv("NXZ_HOST_STAGE") && atoi(getenv("NXZ_HOST_STAGE")) == 0);
+	const bool stage = stage_on && cap <= STAGE_MAX_BLOCKS;
+	const size_t p_jobs = 0, p_res = p_jobs + up(cap * sizeof(nxz_batch_job_t)), p_total = p_res + up(cap * sizeof(nxz_batch_result_t)),
+		     p_src = p_total + 256, p_packed = p_src + (stage ? up(cap * SUBBLOCK) : 0), h_total_bytes = p_packed + (stage ? up(cap * (SUBBLOCK + 16)) : 0);
 	HIPCHK(hipMalloc((void **)&l.d_base, d_total), return false);
 	HIPCHK(hipHostMalloc((void **)&l.h_base, h_total_bytes), { (void)hipFree(l.d_base); l.d_base = nullptr; return false; });
 	l.d_src = l.d_base + o_src; l.d_dst = l.d_base + o_dst; l.d_packed = l.d_base + o_packed;
 	l.d_jobs = (nxz_batch_job_t *)(l.d_base + o_jobs); l.d_res = (nxz_batch_result_t *)(l.d_base + o_res); l.d_off = (uint64_t *)(l.d_base + o_off);
 	l.h_jobs = (nxz_batch_job_t *)(l.h_base + p_jobs); l.h_res = (nxz_batch_result_t *)(l.h_base + p_res); l.h_total = (uint64_t *)(l.h_base + p_total);
+	l.h_src = stage ? l.h_base + p_src : nullptr; l.h_packed = stage ? l.h_base + p_packed : nullptr;
 	l.cap = cap;
 	return true;
+}
+
+
+// ---- calls of a few MiB from many threads: one batch for the callers that are there together ------------------
+// A caller takes room for its blocks in the merge that is open (same function code and window), copies its source into
+// the merge's pinned staging and writes its job records -- every caller on its own core, side by side -- and waits.  The
+// merge goes out when all who took room have filled it and fewer than NXZ_MERGE_RUNNING (2) merges are in flight (so the
+// first caller goes alone at once and those who come while it is in flight go together, as in round_submit): whoever
+// sees that first queues one copy of the staging, nxz_batch_compress over all blocks and the two kernels that pack every
+// member's blocks as that member's stream straight into pinned memory, waits for the stream, and wakes the rest.  Each
+// caller then joins its blocks' checksums and copies its stream out.  Returns -EAGAIN when the merges cannot be set up
+// (the caller's own pair of lanes takes the call).
+#define MERGE_CAP 512u                     /* block slots of a merge: 32 MiB in */
+#define MERGE_MEMBERS 64u
+#define MERGE_OUT_STRIDE (SUBBLOCK + 32)   /* room per block in the packed staging: nxz_deflate_host_bound of a member fits its blocks' room */
+static uint32_t merge_max_blocks()
+{
+	const char *e = getenv("NXZ_MERGE_MAX_BLOCKS");                 // (read at every call: the tests switch it; 0: never)
+	const long x = e ? atol(e) : 64;
+	return (uint32_t)(x < 0 ? 0 : x > 128 ? 128 : x);
+}
+static bool merge_init(nxz_ctx *c, nxz_ctx::Merge &m)
+{
+	if (m.ready) return true;
+	static std::atomic<unsigned> turn{0};
+	auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+	const size_t p_src = 0, p_packed = p_src + up((size_t)MERGE_CAP * SUBBLOCK), p_jobs = p_packed + up((size_t)MERGE_CAP * MERGE_OUT_STRIDE),
+		     p_res = p_jobs + up(MERGE_CAP * sizeof(nxz_batch_job_t)), p_off = p_res + up(MERGE_CAP * sizeof(nxz_batch_result_t)),
+		     p_mem = p_off + up((MERGE_CAP + MERGE_MEMBERS) * sizeof(uint64_t)), p_of = p_mem + up(MERGE_MEMBERS * sizeof(nxz_pack_member_t)),
+		     p_total = p_of + up(MERGE_CAP * sizeof(uint16_t));
+	const size_t o_src = 0, o_dst = up((size_t)MERGE_CAP * SUBBLOCK), d_total = o_dst + up((size_t)MERGE_CAP * HOST_SLOT);
+	if (!m.stream) { HIPCHK(stream_create_spread(&m.stream, turn.fetch_add(1)), return false); }
+	HIPCHK(hipMalloc((void **)&m.d_base, d_total), return false);
+	HIPCHK(hipHostMalloc((void **)&m.h_base, p_total), { (void)hipFree(m.d_base); m.d_base = nullptr; return false; });
+	m.h_src = m.h_base + p_src; m.h_packed = m.h_base + p_packed;
+	m.h_jobs = (nxz_batch_job_t *)(m.h_base + p_jobs); m.h_res = (nxz_batch_result_t *)(m.h_base + p_res); m.h_off = (uint64_t *)(m.h_base + p_off);
+	m.h_mem = (nxz_pack_member_t *)(m.h_base + p_mem); m.h_member_of = (uint16_t *)(m.h_base + p_of);
+	m.d_src = m.d_base + o_src; m.d_dst = m.d_base + o_dst;
+	{
+		// the stream's token scratch for a full merge at once (it grows only, and every step up is a free and an allocation)
+		std::lock_guard<std::mutex> g(c->mtx);
+		nxz_ctx::Scratch &r = c->scratch[m.stream];
+		if (r.chunk_cap < MERGE_CAP) { if (r.d_tokens) r.release_chunk(); (void)r.alloc_chunk(MERGE_CAP); }
+	}
+	m.ready = true;
+	return true;
+}
+
+static int merged_deflate(nxz_ctx_t *c, int fc, const uint8_t *src, size_t src_len, int final, uint32_t H, size_t B,
+			  const uint8_t *prev, size_t prev_len, uint8_t *dst, size_t *out_len, uint32_t *crc, uint32_t *adler)
+{
+	typedef nxz_ctx::Merge Merge;
+	static const unsigned running_max = [] { const char *e = getenv("NXZ_MERGE_RUNNING"); int v = e ? atoi(e) : 2; return (unsigned)(v < 1 ? 1 : v > 3 ? 3 : v); }();
+	const uint32_t nblk = (uint32_t)((src_len + B - 1) / B);
+	const uint32_t h0 = !H ? 0 : (uint32_t)std::min<size_t>(H, prev_len) & ~15u;     // the window in front of the call's first block
+	const uint32_t need = nblk + (h0 ? 1 : 0);                                     // staging slots: [window][blocks]
+	std::unique_lock<std::mutex> lk(c->mm);
+	Merge *M = nullptr;
+	for (;;) {
+		Merge *fresh = nullptr;
+		for (auto &m : c->merges) {
+			if (m.state == Merge::OPEN && m.fc == fc && m.H == H && m.slots + need <= MERGE_CAP && m.members < MERGE_MEMBERS) { M = &m; break; }
+			if (m.state == Merge::FREE && !fresh) fresh = &m;
+		}
+		if (!M && fresh) {
+			if (!merge_init(c, *fresh)) return -EAGAIN;
+			M = fresh; M->state = Merge::OPEN; M->fc = fc; M->H = H; M->slots = M->jobs = M->members = M->filled = M->left = 0; M->rc = 0;
+		}
+		if (M) break;
+		c->mcv.wait(lk);
+	}
+	const uint32_t me = M->members++, s0 = M->slots, j0 = M->jobs;
+	M->slots += need; M->jobs += nblk; M->left++;
+	lk.unlock();
+
+	// my part of the staging, my job records, my line of the member table
+	uint8_t *const stage = M->h_src + (size_t)s0 * SUBBLOCK;
+	uint8_t *const dsrc = M->d_src + (size_t)s0 * SUBBLOCK;
+	if (h0) memcpy(stage, prev + prev_len - h0, h0);
+	memcpy(stage + h0, src, src_len);
+	for (uint32_t k = 0; k < nblk; k++) {
+		nxz_batch_job_t &j = M->h_jobs[j0 + k];
+		memset(&j, 0, sizeof(j));
+		const uint32_t hk = (uint32_t)std::min<uint64_t>(H, h0 + (uint64_t)k * B);     // (a multiple of 16: h0, B and H are)
+		j.src = dsrc + h0 + (size_t)k * B - hk; j.dst = M->d_dst + (size_t)(j0 + k) * HOST_SLOT;
+		j.hist_len = hk;
+		j.src_len = hk + (uint32_t)std::min<uint64_t>(B, src_len - (uint64_t)k * B);
+		j.dst_cap = HOST_SLOT; j.in_crc = 0; j.in_adler = 1;
+		M->h_member_of[j0 + k] = (uint16_t)me;
+	}
+	nxz_pack_member_t &pm = M->h_mem[me];
+	pm.b0 = j0; pm.n = nblk; pm.fin = final ? j0 + nblk - 1 : 0xffffffffu; pm.off0 = j0 + me;
+	pm.packed = M->h_packed + (size_t)j0 * MERGE_OUT_STRIDE;
+
+	lk.lock();
+	M->filled++;
+	while (M->state == Merge::OPEN) {
+		unsigned running = 0;
+		for (auto &m : c->merges) if (m.state == Merge::RUNNING) running++;
+		if (M->filled < M->members || running >= running_max) { c->mcv.wait(lk); continue; }
+		// it goes out, and I am the one to send it
+		M->state = Merge::RUNNING;
+		const uint32_t nj = M->jobs, ns = M->slots, nm = M->members;
+		lk.unlock();
+		int rc = 0;
+		(void)hipSetDevice(c->device);
+		if (hipMemcpyAsync(M->d_src, M->h_src, (size_t)ns * SUBBLOCK, hipMemcpyHostToDevice, M->stream) != hipSuccess) rc = -EIO;
+		if (!rc) rc = nxz_batch_compress(c, M->fc, M->h_jobs, nj, nullptr, 0, M->h_res, nullptr, M->stream);
+		if (!rc && nxz_launch_pack_member_streams(M->h_jobs, M->h_res, nj, M->h_mem, nm, M->h_member_of, M->h_off, M->stream)) rc = -EIO;
+		if (hipStreamSynchronize(M->stream) != hipSuccess && !rc) rc = -EIO;
+		lk.lock();
+		M->rc = rc;
+		M->state = Merge::DONE;
+		c->mcv.notify_all();
+	}
+	while (M->state != Merge::DONE) c->mcv.wait(lk);
+	const int rc = M->rc;
+	lk.unlock();
+
+	if (!rc) {
+		const uint64_t total = M->h_off[pm.off0 + nblk];
+		memcpy(dst, pm.packed, total);
+		const uint32_t op_block = crc_shift_op(B);
+		uint32_t run_crc = 0, run_adler = 1;
+		for (uint32_t k = 0; k < nblk; k++) {
+			const nxz_batch_job_t &j = M->h_jobs[j0 + k];
+			const uint32_t len = j.src_len - j.hist_len;
+			run_crc = gf2_mul32(run_crc, len == B ? op_block : crc_shift_op(len)) ^ M->h_res[j0 + k].crc;
+			run_adler = adler_join(run_adler, M->h_res[j0 + k].adler, len);
+		}
+		*out_len = total;
+		if (crc) *crc = run_crc;
+		if (adler) *adler = run_adler;
+	}
+	lk.lock();
+	if (--M->left == 0) { M->state = Merge::FREE; c->mcv.notify_all(); }
+	lk.unlock();
+	return rc;
 }
 
 static inline uint64_t trace_ns();
@@ -844,6 +1027,10 @@ extern "C" int nxz_deflate_host_hist(nxz_ctx_t *c, int fc, const uint8_t *src, s
 	if (H) fc |= 0x08;                                                  // the RESUME forms take hist_len
 	if (!prev) prev_len = 0;
 	(void)hipSetDevice(c->device);
+	if ((src_len + B - 1) / B <= merge_max_blocks()) {
+		const int r = merged_deflate(c, fc, src, src_len, final, H, B, prev, prev_len, dst, out_len, crc, adler);
+		if (r != -EAGAIN) return r;
+	}
 	int pair = -1;
 	for (int k = 0; k < HOST_PAIRS && pair < 0; k++) if (c->lanes_mtx[k].try_lock()) pair = k;
 	if (pair < 0) { pair = (int)(c->lanes_turn.fetch_add(1) % HOST_PAIRS); c->lanes_mtx[pair].lock(); }
@@ -879,8 +1066,16 @@ extern "C" int nxz_deflate_host_hist(nxz_ctx_t *c, int fc, const uint8_t *src, s
 		}
 		l.n = n; l.bytes = bytes;
 		HIPCHK(hipMemcpyAsync(l.d_jobs, l.h_jobs, n * sizeof(nxz_batch_job_t), hipMemcpyHostToDevice, l.stream), return -EIO);
-		if (h0 && !first) { HIPCHK(hipMemcpyAsync(l.d_src, prev + prev_len - h0, h0, hipMemcpyHostToDevice, l.stream), return -EIO); }
-		HIPCHK(hipMemcpyAsync(l.d_src + (first ? 0 : h0), src + first - (first ? h0 : 0), bytes + (first ? h0 : 0), hipMemcpyHostToDevice, l.stream), return -EIO);
+		const uint8_t *from = src + first - (first ? h0 : 0);
+		const size_t from_bytes = bytes + (first ? h0 : 0), at = first ? 0 : h0;
+		if (l.h_src) {                                                // the window and the blocks through the lane's pinned staging: one copy
+			if (at) memcpy(l.h_src, prev + prev_len - h0, h0);
+			memcpy(l.h_src + at, from, from_bytes);
+			HIPCHK(hipMemcpyAsync(l.d_src, l.h_src, at + from_bytes, hipMemcpyHostToDevice, l.stream), return -EIO);
+		} else {
+			if (at) { HIPCHK(hipMemcpyAsync(l.d_src, prev + prev_len - h0, h0, hipMemcpyHostToDevice, l.stream), return -EIO); }
+			HIPCHK(hipMemcpyAsync(l.d_src + at, from, from_bytes, hipMemcpyHostToDevice, l.stream), return -EIO);
+		}
 		int r = nxz_batch_compress(c, fc, l.d_jobs, n, nullptr, 0, l.d_res, nullptr, l.stream);
 		if (r) return r;
 		const uint32_t fin = final && gi == ngroups - 1 ? (uint32_t)(n - 1) : 0xffffffffu;
@@ -894,7 +1089,7 @@ extern "C" int nxz_deflate_host_hist(nxz_ctx_t *c, int fc, const uint8_t *src, s
 		HIPCHK(hipStreamSynchronize(l.stream), return -EIO);
 		const uint64_t total = *l.h_total;
 		if (pos + total > dst_cap) return -E2BIG;                   // cannot happen: the bound was checked
-		HIPCHK(hipMemcpyAsync(dst + pos, l.d_packed, total, hipMemcpyDeviceToHost, l.stream), return -EIO);
+		HIPCHK(hipMemcpyAsync(l.h_packed ? l.h_packed : dst + pos, l.d_packed, total, hipMemcpyDeviceToHost, l.stream), return -EIO);
 		for (size_t k = 0; k < l.n; k++) {                           // meanwhile: checksums of the run
 			const uint32_t len = l.h_jobs[k].src_len - l.h_jobs[k].hist_len;
 			const uint32_t op = len == B ? op_block : crc_shift_op(len);
@@ -902,6 +1097,7 @@ extern "C" int nxz_deflate_host_hist(nxz_ctx_t *c, int fc, const uint8_t *src, s
 			run_adler = adler_join(run_adler, l.h_res[k].adler, len);
 		}
 		HIPCHK(hipStreamSynchronize(l.stream), return -EIO);
+		if (l.h_packed) memcpy(dst + pos, l.h_packed, total);
 		pos += total;
 		return 0;
 	};

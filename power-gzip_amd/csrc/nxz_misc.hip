@@ -382,13 +382,10 @@ __global__ __launch_bounds__(1024) void stream_offsets_kernel(const nxz_batch_jo
 	if (t == 1023) offsets[n] = part[1023];
 }
 
-__global__ __launch_bounds__(256) void pack_stream_kernel(const nxz_batch_job_t *__restrict__ jobs, const nxz_batch_result_t *__restrict__ results,
-							  uint32_t final_index, const uint64_t *__restrict__ offsets, uint8_t *__restrict__ packed)
+// one block of the stream, by one workgroup of 256: `o` is where it goes
+__device__ inline void pack_block(const nxz_batch_job_t &job, const nxz_batch_result_t &r, const bool final, uint8_t *__restrict__ o)
 {
 	const uint32_t t = threadIdx.x;
-	const nxz_batch_job_t job = jobs[blockIdx.x];
-	const nxz_batch_result_t r = results[blockIdx.x];
-	const bool final = blockIdx.x == final_index;
 	const StreamPiece p = stream_piece(job, r, final);
 	const uint8_t *data = p.stored ? job.src + job.hist_len : job.dst;
 	// stored: [hdr 5][first][hdr 5][rest]; compressed: [keep][pad][00 00 FF FF]
@@ -415,7 +412,6 @@ __global__ __launch_bounds__(256) void pack_stream_kernel(const nxz_batch_job_t 
 		const uint32_t k = j - p.keep - p.pad;                      // after the pad byte: LEN = 0, NLEN = ffff
 		return j < p.keep + p.pad ? 0 : k < 2 ? 0 : 0xff;
 	};
-	uint8_t *o = packed + offsets[blockIdx.x];
 	const uint32_t size = p.size;
 	const uint32_t head = (uint32_t)((4 - ((uintptr_t)o & 3)) & 3);
 	const uint32_t nd = size > head ? (size - head) >> 2 : 0;
@@ -439,6 +435,45 @@ __global__ __launch_bounds__(256) void pack_stream_kernel(const nxz_batch_job_t 
 	}
 }
 
+
+__global__ __launch_bounds__(256) void pack_stream_kernel(const nxz_batch_job_t *__restrict__ jobs, const nxz_batch_result_t *__restrict__ results,
+							  uint32_t final_index, const uint64_t *__restrict__ offsets, uint8_t *__restrict__ packed)
+{
+	pack_block(jobs[blockIdx.x], results[blockIdx.x], blockIdx.x == final_index, packed + offsets[blockIdx.x]);
+}
+
+// ---- the same for several callers' streams at once ------------------------------------------------
+// nxz_deflate_host calls of a few MiB from many threads go out together (nxz_engine.cpp, merged calls): the batch holds
+// the blocks of all of them, member after member; each member's blocks become that member's stream.  A wavefront per
+// member lays out its offsets (a member has a few dozen blocks), a workgroup per block packs.
+__global__ __launch_bounds__(64) void member_stream_offsets_kernel(const nxz_batch_job_t *__restrict__ jobs, const nxz_batch_result_t *__restrict__ results,
+									const nxz_pack_member_t *__restrict__ members, uint64_t *__restrict__ offsets)
+{
+	const nxz_pack_member_t m = members[blockIdx.x];
+	const uint32_t lane = threadIdx.x;
+	uint64_t base = 0;
+	for (uint32_t i0 = 0; i0 < m.n; i0 += 64) {
+		const uint32_t i = i0 + lane;
+		const uint32_t size = i < m.n ? stream_piece(jobs[m.b0 + i], results[m.b0 + i], m.b0 + i == m.fin).size : 0;
+		uint64_t incl = size;
+		for (uint32_t d = 1; d < 64; d <<= 1) {
+			const uint64_t v = __shfl_up(incl, d);
+			if (lane >= d) incl += v;
+		}
+		if (i < m.n) offsets[m.off0 + i] = base + incl - size;
+		base += __shfl(incl, 63);
+	}
+	if (lane == 0) offsets[m.off0 + m.n] = base;
+}
+
+__global__ __launch_bounds__(256) void member_pack_stream_kernel(const nxz_batch_job_t *__restrict__ jobs, const nxz_batch_result_t *__restrict__ results,
+								      const nxz_pack_member_t *__restrict__ members, const uint16_t *__restrict__ member_of,
+								      const uint64_t *__restrict__ offsets)
+{
+	const nxz_pack_member_t m = members[member_of[blockIdx.x]];
+	pack_block(jobs[blockIdx.x], results[blockIdx.x], blockIdx.x == m.fin, m.packed + offsets[m.off0 + (blockIdx.x - m.b0)]);
+}
+
 } // namespace nxz
 
 extern "C" int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t n, uint32_t final_index,
@@ -447,6 +482,15 @@ extern "C" int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_bat
 	if (!n) return 0;
 	hipLaunchKernelGGL(nxz::stream_offsets_kernel, dim3(1), dim3(1024), 0, stream, jobs, results, (uint32_t)n, final_index, offsets);
 	hipLaunchKernelGGL(nxz::pack_stream_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, results, final_index, offsets, packed);
+	return (int)hipGetLastError();
+}
+
+extern "C" int nxz_launch_pack_member_streams(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t nblocks, const nxz_pack_member_t *members,
+					       size_t nmembers, const uint16_t *member_of, uint64_t *offsets, hipStream_t stream)
+{
+	if (!nblocks || !nmembers) return 0;
+	hipLaunchKernelGGL(nxz::member_stream_offsets_kernel, dim3((unsigned)nmembers), dim3(64), 0, stream, jobs, results, members, offsets);
+	hipLaunchKernelGGL(nxz::member_pack_stream_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, jobs, results, members, member_of, offsets);
 	return (int)hipGetLastError();
 }
 

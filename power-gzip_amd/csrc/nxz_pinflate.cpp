@@ -145,11 +145,20 @@ static inline uint32_t capmul_for(uint64_t src_len)
 }
 constexpr uint64_t CAP_FLOOR_CUT = 32u << 10, CAP_FLOOR_BLOCK = 128u << 10;
 // ... and so is one that would take what all the workspaces hold between calls beyond a budget (NXZ_PINFLATE_IDLE_MB,
-// default 16384 MiB, twice what ONE workspace may keep: 32 callers of 1 MiB parts hold 32 x 32 MiB and never get here; 32
+// default 16384 MiB or an eighth of the device's memory, at least twice what ONE workspace may keep: 32 callers of 1 MiB parts hold 32 x 32 MiB and never get here; 32
 // callers of 64 MiB streams would otherwise keep 32 x 9 GiB for as long as the process lives -- round 3 left that to a manual nxz_trim()).
 inline size_t idle_bytes()
 {
-	static const size_t v = (size_t)(getenv("NXZ_PINFLATE_IDLE_MB") ? atoll(getenv("NXZ_PINFLATE_IDLE_MB")) : 16384) << 20;
+	// (an eighth of the device's memory where that is more: sixteen threads of 16 MiB streams hold 22 GiB, and under the
+	// flat 16 GiB every call gave its 1.4 GiB back at its end and asked for them again at the next one's start -- one
+	// allocation after the other through the runtime: 0.4 GiB/s all told, single calls of three seconds)
+	static const size_t v = [] {
+		if (getenv("NXZ_PINFLATE_IDLE_MB")) return (size_t)atoll(getenv("NXZ_PINFLATE_IDLE_MB")) << 20;
+		size_t free_b = 0, total_b = 0;
+		const size_t flat = (size_t)16384 << 20;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return flat; }
+		return std::max(flat, total_b / 8);
+	}();
 	return v;
 }
 struct TrimOnExit {

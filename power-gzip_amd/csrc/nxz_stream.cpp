@@ -413,14 +413,18 @@ extern "C" {
 size_t nxz_deflate_host_bound_hist(size_t, uint32_t) __attribute__((weak));
 int nxz_deflate_host_hist(nxz_ctx_t *, int, const uint8_t *, size_t, int, uint32_t, const uint8_t *, size_t, uint8_t *, size_t, size_t *, uint32_t *, uint32_t *) __attribute__((weak));
 }
-constexpr size_t BATCH_MIN = 4 * JOB_UNIT;
+static size_t batch_min()
+{
+	static const size_t v = getenv("NXZ_BATCH_MIN") ? (size_t)strtoull(getenv("NXZ_BATCH_MIN"), nullptr, 0) : 0;
+	return v ? v : 2 * JOB_UNIT;
+}
 
 // true when it took input; what it leaves (less than a block) goes the job-after-job way
 bool deflate_batch(Deflate *s, int flush)
 {
 	z_streamp z = s->z;
 	if (!nxz_deflate_host_hist || !nxz_deflate_host_bound_hist) return false;
-	if (!s->eng.open || s->used != 0 || s->dict_len != 0 || s->pending() || z->avail_in < BATCH_MIN) return false;
+	if (!s->eng.open || s->used != 0 || s->dict_len != 0 || s->pending() || z->avail_in < batch_min()) return false;
 	// At the levels that carry history (5..9, max_history 4..32 KiB) a block's window is the input in front of
 	// it: blocks of 64 KiB - max_history, still side by side (nxz_deflate_host_hist); the first block's window
 	// is what the stream kept of the calls before (the front of the fifo).
@@ -748,6 +752,8 @@ void *nxz_dev_malloc(nxz_ctx_t *, size_t) __attribute__((weak));
 void nxz_dev_free(nxz_ctx_t *, void *) __attribute__((weak));
 int nxz_copy_to_device(nxz_ctx_t *, void *, const void *, size_t, void *) __attribute__((weak));
 int nxz_copy_to_host(nxz_ctx_t *, void *, const void *, size_t, void *) __attribute__((weak));
+void *nxz_pinned_malloc(nxz_ctx_t *, size_t) __attribute__((weak));
+void nxz_pinned_free(nxz_ctx_t *, void *) __attribute__((weak));
 int nxz_ctx_sync(nxz_ctx_t *, void *) __attribute__((weak));
 void *nxz_stream_create(nxz_ctx_t *) __attribute__((weak));
 int nxz_ctx_device(nxz_ctx_t *) __attribute__((weak));
@@ -797,7 +803,14 @@ bool parallel_inflate(Inflate *s)
 		uint8_t *src = nullptr, *dst = nullptr, *hist = nullptr;
 		size_t src_cap = 0, dst_cap = 0;
 		void *stream = nullptr;
+		// pinned staging for parts of a few MiB: a copy straight from (to) the caller's pages makes the runtime pin and
+		// unpin them per call under the process's memory-map lock, which is what sixteen threads of 1 MiB calls spent
+		// their time in; the calling thread's own memcpy to and from pinned memory costs a tenth of that
+		uint8_t *pin_in = nullptr, *pin_out = nullptr;
+		size_t pin_in_cap = 0, pin_out_cap = 0;
 	};
+	constexpr size_t STAGE_IN_MAX = (size_t)4 << 20, STAGE_OUT_MAX = (size_t)16 << 20;
+	static const bool stage_on = !(getenv("NXZ_HOST_STAGE") && atoi(getenv("NXZ_HOST_STAGE")) == 0) && nxz_pinned_malloc && nxz_pinned_free;
 	constexpr int NSLOT = 32, NDEV = 64;
 	static Slot slots[NDEV][NSLOT];
 	static std::atomic<unsigned> turn{0};
@@ -822,7 +835,23 @@ bool parallel_inflate(Inflate *s)
 	static const bool trace = getenv("NXZ_API_TRACE") != nullptr;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t0 = trace ? now() : 0;
-	if (ok) ok = (!nc || nxz_copy_to_device(ctx, d_src, s->carry.data(), nc, hs) == 0) && (!take || nxz_copy_to_device(ctx, d_src + nc, z->next_in, take, hs) == 0) &&
+	auto pin_need = [&](uint8_t *&p, size_t &have, size_t want, size_t most) {
+		if (!stage_on || want > most) return false;
+		if (have >= want) return true;
+		size_t to = std::max<size_t>((size_t)256 << 10, have);
+		while (to < want) to <<= 1;
+		if (p) nxz_pinned_free(ctx, p);
+		p = (uint8_t *)nxz_pinned_malloc(ctx, to);
+		have = p ? to : 0;
+		return p != nullptr;
+	};
+	if (ok && pin_need(slot->pin_in, slot->pin_in_cap, nin + nh, STAGE_IN_MAX)) {
+		uint8_t *const pi = slot->pin_in;
+		if (nc) memcpy(pi, s->carry.data(), nc);
+		if (take) memcpy(pi + nc, z->next_in, take);
+		if (nh) memcpy(pi + nin, s->hist.data(), nh);
+		ok = nxz_copy_to_device(ctx, d_src, pi, nin, hs) == 0 && (!nh || nxz_copy_to_device(ctx, d_hist, pi + nin, nh, hs) == 0);
+	} else if (ok) ok = (!nc || nxz_copy_to_device(ctx, d_src, s->carry.data(), nc, hs) == 0) && (!take || nxz_copy_to_device(ctx, d_src + nc, z->next_in, take, hs) == 0) &&
 		     (!nh || nxz_copy_to_device(ctx, d_hist, s->hist.data(), nh, hs) == 0);
 	if (ok && trace) (void)nxz_ctx_sync(ctx, hs);
 	const double t1 = trace ? now() : 0;
@@ -844,6 +873,14 @@ bool parallel_inflate(Inflate *s)
 	if (ok) {
 		s->pend.resize(later); s->pend_off = 0;
 		tail.resize((size_t)std::min<uint64_t>(out_len, WINDOW));
+		if (out_len && pin_need(slot->pin_out, slot->pin_out_cap, (size_t)out_len, STAGE_OUT_MAX)) {
+			ok = nxz_copy_to_host(ctx, slot->pin_out, d_dst, (size_t)out_len, hs) == 0 && nxz_ctx_sync(ctx, hs) == 0;
+			if (ok) {
+				if (direct) memcpy(z->next_out, slot->pin_out, direct);
+				if (later) memcpy(s->pend.data(), slot->pin_out + direct, later);
+				if (!tail.empty()) memcpy(tail.data(), slot->pin_out + out_len - tail.size(), tail.size());
+			}
+		} else
 		ok = (!direct || nxz_copy_to_host(ctx, z->next_out, d_dst, direct, hs) == 0) && (!later || nxz_copy_to_host(ctx, s->pend.data(), d_dst + direct, later, hs) == 0) &&
 		     (tail.empty() || nxz_copy_to_host(ctx, tail.data(), d_dst + out_len - tail.size(), tail.size(), hs) == 0) && nxz_ctx_sync(ctx, hs) == 0;
 		if (!ok) s->pend.clear();

@@ -7,6 +7,7 @@ import ctypes as C
 import os
 import zlib
 
+import numpy as np
 import pytest
 
 import zstream as Z
@@ -217,6 +218,56 @@ def test_threads_with_large_calls_work_side_by_side(L):
     for x in th:
         x.join()
     assert not bad, bad
+
+
+def test_calls_of_a_few_blocks_from_many_threads_go_out_as_one_batch_and_stay_apart():
+    """nxz_deflate_host calls of up to 32 blocks are merged: the callers that are there together share one launch of each
+    kernel (nxz_engine.cpp merged_deflate).  Sixteen threads, calls of 1 .. 32 blocks and odd lengths, both function
+    codes, final and not: every caller gets the stream of ITS bytes (zlib reads it, checksums match), and the stream is
+    byte for byte what the same call makes alone on its own pair of lanes (NXZ_MERGE_MAX_BLOCKS=0)."""
+    import importlib, threading
+    pkg = importlib.import_module("power-gzip_amd")
+    eng = pkg.Engine(0)
+    kinds = ("alice", "lz", "text33", "random", "zeros", "binary")
+    T, per = 16, 6
+    rng = np.random.default_rng(5)
+    sizes = [[int(rng.integers(1, 33)) * 65536 - int(rng.integers(0, 3)) * int(rng.integers(1, 60000)) for _ in range(per)] for _ in range(T)]
+    bufs = [[b"".join(make_block(kinds[(t + i + k) % 6], 65536, 777 * t + 13 * i + k) for k in range((n + 65535) // 65536))[:n] for i, n in enumerate(sizes[t])] for t in range(T)]
+    got = [[None] * per for _ in range(T)]
+    bad = []
+
+    def worker(t):
+        for i, b in enumerate(bufs[t]):
+            fc = pkg.FC_COMPRESS_DHTGEN if (t + i) % 3 else pkg.FC_COMPRESS_FHT
+            final = (t + i) % 4 != 0
+            rc, comp, crc, adler = eng.deflate_host(b, fc=fc, final=final)
+            if rc != 0 or crc != zlib.crc32(b) or adler != zlib.adler32(b):
+                bad.append((t, i, rc, "checksums"))
+                return
+            d = zlib.decompressobj(-15)
+            if d.decompress(comp) != b or d.eof != final:
+                bad.append((t, i, "zlib"))
+                return
+            got[t][i] = (fc, final, comp)
+
+    try:
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not bad, bad
+        os.environ["NXZ_MERGE_MAX_BLOCKS"] = "0"
+        try:
+            for t in range(0, T, 3):
+                for i, b in enumerate(bufs[t]):
+                    fc, final, comp = got[t][i]
+                    rc, alone, _, _ = eng.deflate_host(b, fc=fc, final=final)
+                    assert rc == 0 and alone == comp, (t, i, len(b))
+        finally:
+            del os.environ["NXZ_MERGE_MAX_BLOCKS"]
+    finally:
+        eng.close()
 
 
 def test_deflate_host_entry_point():
