@@ -270,6 +270,42 @@ def test_calls_of_a_few_blocks_from_many_threads_go_out_as_one_batch_and_stay_ap
         eng.close()
 
 
+def test_merged_calls_with_a_window_match_the_calls_made_alone(L):
+    """Levels 5..9 through the merged calls (blocks of 64 KiB - history with the input in front of them as window; the call's
+    first block sees the tail of the call before): eight threads, each a stream of three 1 MiB steps at its own level, all at
+    once.  zlib reads every stream, and every stream is byte for byte what the same steps make when no call is merged."""
+    import threading
+    T = 8
+    kinds = ("alice", "lz", "text33", "binary")
+    datas = [b"".join(make_block(kinds[(t + k) % 4], 65536, 31 * t + k) for k in range(40))[:(5 << 19) - 777 * t] for t in range(T)]
+    levels = [5, 6, 7, 9, 6, 9, 5, 8]
+    res = [None] * T
+    bad = []
+
+    def worker(t):
+        try:
+            out, _, adler = Z.deflate_all(L, datas[t], level=levels[t], wbits=15, step_in=1 << 20)
+            if zlib.decompress(out) != datas[t] or adler != zlib.adler32(datas[t]):
+                bad.append((t, "zlib"))
+            res[t] = out
+        except AssertionError as e:
+            bad.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not bad, bad
+    os.environ["NXZ_MERGE_MAX_BLOCKS"] = "0"
+    try:
+        for t in range(T):
+            alone, _, _ = Z.deflate_all(L, datas[t], level=levels[t], wbits=15, step_in=1 << 20)
+            assert alone == res[t], (t, levels[t])
+    finally:
+        del os.environ["NXZ_MERGE_MAX_BLOCKS"]
+
+
 def test_deflate_host_entry_point():
     """nxz_deflate_host itself (include/nxz_engine.h): any length, final or not, both function codes;
     runs that are not final end on a byte boundary and are continued by the next run."""

@@ -13,7 +13,10 @@ pkg = importlib.import_module("power-gzip_amd")
 
 def make_stream(mib, level, strategy=zlib.Z_DEFAULT_STRATEGY):
     name, blocks, _ = corpus.load(65536)
-    raw = b"".join(b for _, _, b in blocks)
+    only = [c for c in os.environ.get("CLASSES", "").split(",") if c]            # CLASSES=text,xml: those classes only; CLASSES=-image,-packed: all but those
+    drop = [c[1:] for c in only if c.startswith("-")]
+    keep = [c for c in only if not c.startswith("-")]
+    raw = b"".join(b for c, _, b in blocks if c not in drop and (not keep or c in keep))
     data = (raw * (mib * (1 << 20) // len(raw) + 1))[:mib << 20]
     c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
     t0 = time.perf_counter()
