@@ -354,7 +354,7 @@ def timed_compress(torch, eng, fc, jobs, n, results, steps, warmup):
     return e0.elapsed_time(e1) / steps, [x / steps for x in st], launches // max(steps, 1)
 
 
-def what_binds(kernel_prefix="nxzl77::lz77_kernel<true, false>", leg="dhtgen"):
+def what_binds(kernel_prefix="nxzl77::lz77_kernel<true, false", leg="dhtgen"):
     """The path moves few bytes per instruction: what binds the LZ77 kernel is the issue of vector instructions and
     the LDS pipe, from the latest committed counter pass (profiles/r*_pmc_counters.json, tools/prof_report.py: keys
     "<kernel> [<leg>]", figures per unit = per 64 KiB block)."""
@@ -391,7 +391,7 @@ def roofline(u_bytes, c_bytes, stage_ms, launches, traffic, kernel, peak_measure
     kern_ms = sum(stage_ms)
     achieved = (u_bytes + c_bytes) / (kern_ms * 1e-3) / 1e9
     return roof(achieved, traffic, kernel, peak_measured,
-                what_binds=what_binds("nxzl77::lz77_kernel<false, true>", "fht") if leg == "fht" else what_binds(),
+                what_binds=what_binds("nxzl77::lz77_kernel<false, true", "fht") if leg == "fht" else what_binds(),
                 kernel_ms=round(kern_ms, 3), lz77_ms=round(stage_ms[0], 3), dhtgen_ms=round(stage_ms[1], 3),
                 entropy_ms=round(stage_ms[2], 3), launches_per_step=launches,
                 avg_lz77_launch_ms=round(stage_ms[0] / max(launches, 1), 4),
@@ -515,7 +515,7 @@ def run_corpus(torch, dist, args, rank, world, dev, distributed, pkg, eng):
                    "silesia_weighted_GiB_s": silesia, "classes": classes,
                    "roundtrip_bit_exact": True, "zlib_inflated_sample": min(uniq, 400), "parallelism": "shard%d" % world},
         "roofline": roofline(u_bytes, c_bytes, st, launches, pmc_traffic(n, "dhtgen"),
-                             "nxzl77::lz77_kernel<true> (dominant) + nxzd::dhtgen_kernel + nxze::encode_kernel<true>", peak_m),
+                             "nxzl77::lz77_kernel<true, false, false> (dominant) + nxzd::dhtgen_kernel + nxze::encode_kernel<true, false>", peak_m),
     }
     if world > 1:
         # a scaling line: the legs that belong to one GPU's report are left out, and the line says so
@@ -1069,7 +1069,7 @@ def c2_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, n, st
                    "blocks_per_gpu": n, "block_bytes": BLOCK, "ratio": round(tot_u / tot_c, 4),
                    "parallelism": "shard%d" % world},
         "roofline": roofline(u_bytes, c_bytes, st, launches, pmc_traffic(n, "fht"),
-                             "nxzl77::lz77_kernel<false, true> (one kernel: LZ77 + the fixed code)", peak_m, leg="fht"),
+                             "nxzl77::lz77_kernel<false, true, false> (one kernel: LZ77 + the fixed code)", peak_m, leg="fht"),
     }
     if inflate_info:
         line["inflate"] = inflate_info

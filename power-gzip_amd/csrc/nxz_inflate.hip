@@ -30,6 +30,9 @@
 #include "nxz_device.h"
 #include "nxz_inflate_tables.h"
 
+#ifndef NXZ_INFLATE_LIT_STEP
+#define NXZ_INFLATE_LIT_STEP 1            /* 0: no short step for stretches of literals (for comparisons) */
+#endif
 namespace nxzi {
 
 // Diagnostic only (tools/bench_inflate_kinds.py): cycle sums of lane 0 of every stream.
@@ -545,6 +548,8 @@ __device__ __forceinline__ void inflate_body(const nxz_batch_job_t *__restrict__
 
 	// two 256-byte blocks of the source in registers (lane k: dword k), for the multi-token step
 	const bool fast_ok = ((uintptr_t)src & 3) == 0;
+	bool lit_mode = false;                                    // the last multi-token step met literals only: see there
+	constexpr bool lit_step_on = NXZ_INFLATE_LIT_STEP != 0;
 	uint32_t W0 = 0, W1 = 0, wbase = 0x80000000u;          // wbase: dword index of W0's lane 0 (a multiple of 64; none yet)
 	auto load_block = [&](uint32_t blk) -> uint32_t {
 		const uint32_t idx = blk * 64 + lane;
@@ -752,15 +757,47 @@ tables_ready:
 					const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)(i & 63)), hi = (uint32_t)__builtin_amdgcn_readlane((int)W1, (int)(i & 63));
 					return i < 64 ? lo : hi;
 				};
-				const uint32_t s0 = word(qi), s1 = word(qi + 1), s2 = word(qi + 2), s3 = word(qi + 3), s4 = word(qi + 4);
+				const uint32_t s0 = word(qi), s1 = word(qi + 1), s2 = word(qi + 2), s3 = word(qi + 3);
 				// this lane's 64 bits of the source: [pos + lane, pos + lane + 64)
 				const uint32_t bo = sh + (uint32_t)lane, di = bo >> 5, r = bo & 31;        // di = 0..2
 				const uint32_t a0 = di == 0 ? s0 : di == 1 ? s1 : s2;
 				const uint32_t a1 = di == 0 ? s1 : di == 1 ? s2 : s3;
-				const uint32_t a2 = di == 0 ? s2 : di == 1 ? s3 : s4;
-				const uint32_t w0 = __builtin_amdgcn_alignbit(a1, a0, r), w1 = __builtin_amdgcn_alignbit(a2, a1, r);
+				const uint32_t w0 = __builtin_amdgcn_alignbit(a1, a0, r);
 				// the whole token that would start at this lane's bit: literal, or length + distance
 				const uint32_t el = sm.hl.fast[w0 & ((1u << LBITS) - 1)];
+				if (lit_mode) {
+					// A stretch of literals (image-like and packed data: nine tokens in ten are, and a block of 16384 of them took a
+					// lone wavefront 2 ms): the step for literals alone -- no length and distance of the token that might start at
+					// a lane's bit, the tokens' places by a count of the starts in front of them -- for as long as the step before
+					// met nothing but literals.  A chain that meets something else ends there; the full step takes over.
+					const uint32_t lsym = el & 0xfff;
+					const uint32_t ltl = (el && lsym < 256) ? el >> 12 : 0;
+					uint32_t off = 0;
+					uint64_t starts = 0;
+					for (;;) {
+						uint32_t t = 0;
+#pragma unroll
+						for (int u = 0; u < 4; u++) {
+							t = (uint32_t)__builtin_amdgcn_readlane((int)ltl, (int)(off & 63));
+							t = off < 64 ? t : 0;
+							starts |= (uint64_t)((t + 63) >> 6) << (off & 63);
+							off += t;
+						}
+						if (!t || off > 63) break;
+					}
+					lit_mode = off > 63;                                      // (the chain left the lanes: literals all the way)
+					const uint32_t cnt = (uint32_t)__builtin_popcountll(starts);
+					if (!cnt || cnt > cap - out) { lit_mode = false; continue; }
+					if ((starts >> lane) & 1)
+						wr(out + __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0)), lsym);
+					out += cnt;
+					b.pos += off;
+					if (out - flushed >= FLUSH) break;
+					continue;
+				}
+				const uint32_t s4 = word(qi + 4);
+				const uint32_t a2 = di == 0 ? s2 : di == 1 ? s3 : s4;
+				const uint32_t w1 = __builtin_amdgcn_alignbit(a2, a1, r);
 				const uint32_t nb = el >> 12, sym = el & 0xfff;
 				const bool islit = el && sym < 256;
 				const bool islen = sym > 256 && sym < 257 + 29;
@@ -891,6 +928,7 @@ tables_ready:
 						   (uint32_t)__builtin_amdgcn_readlane((int)ob, (int)l));
 				}
 				out += total;
+				lit_mode = lit_step_on && !(starts & ~lits);                  // (nothing but literals: the next step may be the short one)
 				IPROF(3);
 				ICOUNT(4, 1); ICOUNT(5, out - out0); ICOUNT(6, off);
 				b.pos += off;
