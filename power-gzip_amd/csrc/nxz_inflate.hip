@@ -30,6 +30,9 @@
 #include "nxz_device.h"
 #include "nxz_inflate_tables.h"
 
+#ifndef NXZ_INFLATE_CHAIN_BY_LANE
+#define NXZ_INFLATE_CHAIN_BY_LANE 1       /* 0: the chain of token starts link by link in scalar arithmetic, as up to round 5 (for comparisons) */
+#endif
 #ifndef NXZ_INFLATE_LIT_STEP
 #define NXZ_INFLATE_LIT_STEP 1            /* 0: no short step for stretches of literals (for comparisons) */
 #endif
@@ -550,6 +553,51 @@ __device__ __forceinline__ void inflate_body(const nxz_batch_job_t *__restrict__
 	const bool fast_ok = ((uintptr_t)src & 3) == 0;
 	bool lit_mode = false;                                    // the last multi-token step met literals only: see there
 	constexpr bool lit_step_on = NXZ_INFLATE_LIT_STEP != 0;
+	// The chain of real token starts through the lanes' answers (tl: the bits of the token that would start at a lane's bit,
+	// 0: none for this step): every lane names the lane its token ends at -- itself when there is no token, or when the
+	// token reaches past the lanes -- and the walk is one v_readlane a link, the lane it reads being what the last one read
+	// out; a lane that names itself is where the chain ends (a link more does no harm: groups of four without a test).
+	// starts: the lanes on the chain that hold a token; off: the bits they use, all told.
+	// (Up to round 5 a link was ten scalar instructions -- the length read out, tested, added up, the start's bit shifted
+	// into place -- and the scalar unit, one for the CU's four SIMDs, was what a full batch waited for: 74 % busy.)
+	auto walk_chain = [&](const uint32_t tl, uint64_t &starts, uint32_t &off) __attribute__((always_inline)) {
+#if NXZ_INFLATE_CHAIN_BY_LANE
+		const uint32_t to = (uint32_t)lane + tl;
+		const uint32_t nxt = (tl && to < 64) ? to : (uint32_t)lane;
+		const uint64_t valid = __ballot(tl != 0);
+		uint32_t at = 0;
+		uint64_t seen = 0;
+		for (;;) {
+			uint32_t before = 0;
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				seen |= 1ull << at;
+				before = at;
+				at = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)at);
+			}
+			if (at == before) break;
+		}
+		starts = seen & valid;
+		off = 0;
+		if (starts) {
+			const uint32_t last = 63 - (uint32_t)__builtin_clzll(starts);
+			off = last + (uint32_t)__builtin_amdgcn_readlane((int)tl, (int)last);
+		}
+#else
+		off = 0; starts = 0;
+		for (;;) {
+			uint32_t t = 0;
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				t = (uint32_t)__builtin_amdgcn_readlane((int)tl, (int)(off & 63));
+				t = off < 64 ? t : 0;
+				starts |= (uint64_t)((t + 63) >> 6) << (off & 63);         // t is 0..63: 1 for a token, in scalar arithmetic
+				off += t;
+			}
+			if (!t || off > 63) break;
+		}
+#endif
+	};
 	uint32_t W0 = 0, W1 = 0, wbase = 0x80000000u;          // wbase: dword index of W0's lane 0 (a multiple of 64; none yet)
 	auto load_block = [&](uint32_t blk) -> uint32_t {
 		const uint32_t idx = blk * 64 + lane;
@@ -757,7 +805,13 @@ tables_ready:
 					const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)(i & 63)), hi = (uint32_t)__builtin_amdgcn_readlane((int)W1, (int)(i & 63));
 					return i < 64 ? lo : hi;
 				};
-				const uint32_t s0 = word(qi), s1 = word(qi + 1), s2 = word(qi + 2), s3 = word(qi + 3);
+				// (five dwords from qi on: in W0 alone fifteen steps in sixteen -- one v_readlane each then, no test and no select)
+				uint32_t s0, s1, s2, s3, s4;
+				if (qi < 60) {
+					s0 = (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)qi); s1 = (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)(qi + 1));
+					s2 = (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)(qi + 2)); s3 = (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)(qi + 3));
+					s4 = (uint32_t)__builtin_amdgcn_readlane((int)W0, (int)(qi + 4));
+				} else { s0 = word(qi); s1 = word(qi + 1); s2 = word(qi + 2); s3 = word(qi + 3); s4 = word(qi + 4); }
 				// this lane's 64 bits of the source: [pos + lane, pos + lane + 64)
 				const uint32_t bo = sh + (uint32_t)lane, di = bo >> 5, r = bo & 31;        // di = 0..2
 				const uint32_t a0 = di == 0 ? s0 : di == 1 ? s1 : s2;
@@ -772,19 +826,9 @@ tables_ready:
 					// met nothing but literals.  A chain that meets something else ends there; the full step takes over.
 					const uint32_t lsym = el & 0xfff;
 					const uint32_t ltl = (el && lsym < 256) ? el >> 12 : 0;
-					uint32_t off = 0;
-					uint64_t starts = 0;
-					for (;;) {
-						uint32_t t = 0;
-#pragma unroll
-						for (int u = 0; u < 4; u++) {
-							t = (uint32_t)__builtin_amdgcn_readlane((int)ltl, (int)(off & 63));
-							t = off < 64 ? t : 0;
-							starts |= (uint64_t)((t + 63) >> 6) << (off & 63);
-							off += t;
-						}
-						if (!t || off > 63) break;
-					}
+					uint32_t off;
+					uint64_t starts;
+					walk_chain(ltl, starts, off);
 					lit_mode = off > 63;                                      // (the chain left the lanes: literals all the way)
 					const uint32_t cnt = (uint32_t)__builtin_popcountll(starts);
 					if (!cnt || cnt > cap - out) { lit_mode = false; continue; }
@@ -795,7 +839,6 @@ tables_ready:
 					if (out - flushed >= FLUSH) break;
 					continue;
 				}
-				const uint32_t s4 = word(qi + 4);
 				const uint32_t a2 = di == 0 ? s2 : di == 1 ? s3 : s4;
 				const uint32_t w1 = __builtin_amdgcn_alignbit(a2, a1, r);
 				const uint32_t nb = el >> 12, sym = el & 0xfff;
@@ -820,19 +863,9 @@ tables_ready:
 				// the chain of real token starts
 				// (four links at a time without a branch: a link that meets the end of the chain -- a token that is
 				// not for this step, or the end of the lanes -- stays where it is)
-				uint32_t off = 0;
-				uint64_t starts = 0;
-				for (;;) {
-					uint32_t t = 0;
-#pragma unroll
-					for (int u = 0; u < 4; u++) {
-						t = (uint32_t)__builtin_amdgcn_readlane((int)tl, (int)(off & 63));
-						t = off < 64 ? t : 0;
-						starts |= (uint64_t)((t + 63) >> 6) << (off & 63);         // t is 0..63: 1 for a token, in scalar arithmetic
-						off += t;
-					}
-					if (!t || off > 63) break;
-				}
+				uint32_t off;
+				uint64_t starts;
+				walk_chain(tl, starts, off);
 				if (!starts) break;
 				IPROF(8);
 				// where each token writes: prefix sum of the byte counts over the token starts
@@ -892,7 +925,7 @@ tables_ready:
 							if ((uint32_t)lane < rest) tl_[k] = W16 ? ((const NXZ_GLOBAL_AS uint16_t *)sp)[full * PER + lane] : sp[full * PER + lane];
 						}
 					}
-#pragma unroll
+		#pragma unroll
 					for (int k = 0; k < 4; k++) {
 						NXZ_GLOBAL_AS uint8_t *dp = base + (size_t)mp[k] * ES;
 						const uint32_t full = mn[k] / PER, rest = mn[k] - full * PER;
