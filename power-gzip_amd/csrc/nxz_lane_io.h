@@ -18,6 +18,10 @@ static inline uint32_t nxz_lane_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
 #define NXZ_LANE_ALIGNBYTE(hi, lo, sh) nxz_lane_alignbyte(hi, lo, sh)
 #endif
 
+#ifndef NXZ_LANE_REFILL_ABOVE
+#define NXZ_LANE_REFILL_ABOVE 56     /* refill() loads unless more bits than this are at hand (56: whenever a whole byte fits) */
+#endif
+
 namespace nxzl {
 
 // per-lane bit reader over global memory
@@ -36,7 +40,7 @@ struct BitRd {
 	// after a sync() at a bit inside a byte; zero bits past the end) -- a byte outside the source is never read.
 	NXZ_LANE_FN void refill()
 	{
-		if (bc > 56) return;
+		if (bc > NXZ_LANE_REFILL_ABOVE) return;
 		const uint64_t p2 = pos + bc;
 		const uint32_t byte = (uint32_t)(p2 >> 3), sh = (uint32_t)p2 & 7;
 		if (byte + 8 <= srclen) {
