@@ -60,6 +60,8 @@ typedef struct nxz_sync_req {
 } nxz_sync_req_t;
 typedef struct nxz_sync_res { uint32_t bit; uint32_t lanes; } nxz_sync_res_t;   /* bit 0xffffffff: none found; lanes bit 31: the block's BFINAL */
 size_t nxz_built_tables_bytes(void);
+int nxz_launch_token_sync_more(const nxz_sync_req_t *breqs, uint32_t nb, nxz_batch_dht_t *tables, void *built, uint32_t first,
+			       const nxz_sync_req_t *reqs, uint32_t n, nxz_sync_res_t *res, hipStream_t stream);
 int nxz_launch_token_sync(const nxz_sync_req_t *breqs, uint32_t nb, nxz_batch_dht_t *tables, void *built,
 			  const nxz_sync_req_t *reqs, uint32_t n, nxz_sync_res_t *res, hipStream_t stream);
 /* runs of stored blocks (nxz_blockfind.hip stored_walk_kernel) */

@@ -1271,6 +1271,17 @@ extern "C" int nxz_launch_token_sync(const nxz_sync_req_t *breqs, uint32_t nb, n
 	return (int)hipGetLastError();
 }
 
+// more of the same later on (nxz_pinflate.cpp, pieces that are decoded again): the tables of nb further blocks go behind the
+// `first` that are there already, the requests name any of them
+extern "C" int nxz_launch_token_sync_more(const nxz_sync_req_t *breqs, uint32_t nb, nxz_batch_dht_t *tables, void *built, uint32_t first,
+					  const nxz_sync_req_t *reqs, uint32_t n, nxz_sync_res_t *res, hipStream_t stream)
+{
+	if (!n) return 0;
+	if (nb) hipLaunchKernelGGL(nxzi::block_tables_kernel, dim3(nb), dim3(64), 0, stream, breqs, tables, (nxzi::Built *)built + first);
+	hipLaunchKernelGGL(nxzi::token_sync_kernel, dim3(n), dim3(64), 0, stream, reqs, res, (const nxzi::Built *)built);
+	return (int)hipGetLastError();
+}
+
 // pieces of many streams (nxz_inflate_cut.hip): the jobs `order` names, slots of 0xffffffff are none
 extern "C" int nxz_launch_inflate_w16_order(const nxz_batch_job_t *jobs, size_t nslots, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, const void *built,
 					    const uint32_t *order, hipStream_t stream)

@@ -98,6 +98,7 @@ struct Workspace {
 	void *pin = nullptr; size_t pin_cap = 0;
 	hipStream_t own = nullptr;                  // for callers that name no stream
 	void *built = nullptr; size_t built_cap = 0; // the blocks' decode tables (nxz_inflate.hip Built), device memory
+	void *rc_pin = nullptr, *rc_dev = nullptr;  // requests, results and tables of the token boundaries asked for in later rounds (RECUT_BYTES each, made once)
 	std::mutex mtx;
 	bool need(size_t d, size_t p)
 	{
@@ -277,6 +278,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	struct Sub { uint64_t bit; uint32_t tab, fin, per256; };        // per256: bytes of output per 256 bits of source around the cut (token_sync_kernel's estimate)
 	std::vector<Sub> subs;
 	std::vector<nxz_batch_dht_t> tabs;
+	std::vector<uint64_t> blk_base;              // per table: the bit of the stream its requests count from
 	{
 		static const int split_max = getenv("NXZ_PINFLATE_SPLIT") ? atoi(getenv("NXZ_PINFLATE_SPLIT")) : 64;      // pieces per block at most (0, 1: blocks only)
 		static const uint64_t sub_min = getenv("NXZ_PINFLATE_PIECE_BITS") ? (uint64_t)atoll(getenv("NXZ_PINFLATE_PIECE_BITS")) : 4096;   // the shortest piece
@@ -298,6 +300,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		const uint64_t sub_bits = std::max<uint64_t>(std::max<uint64_t>(sub_min, 2048), all_bits / want);
 		std::vector<nxz_sync_req_t> rq, bq;          // requests; the blocks they lie in (bq: src, srclen, header_bit)
 		std::vector<uint64_t> rq_base;
+		blk_base.clear();
 		// (the first piece begins wherever the caller's part of the stream does: inside a dynamic block that is not
 		// the last -- then the table is the one the last suspension handed back --, or at a header of whatever kind)
 		const bool given0 = st && (st->sfbt & 8) && (st->sfbt & 0xe) != 0xe;
@@ -316,6 +319,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 			r.guess_bit = 0; r.limit_bit = (uint32_t)(end - base * 8);
 			if (i == 0 && given0) { r.header_bit = 0xffffffffu; given = true; }
 			bq.push_back(r);
+			blk_base.push_back(base * 8);
 			for (uint32_t k = 1; k < nsub; k++) {
 				r.header_bit = (uint32_t)(bq.size() - 1);         // (which block's tables)
 				r.guess_bit = (uint32_t)(B[i] + span * k / nsub - base * 8);
@@ -396,7 +400,8 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	// (a whole stream with hardly anything to do side by side: the job loop serves as well.  A part of a stream is
 	// taken whatever it is made of -- stored blocks, fixed-Huffman blocks: the caller's alternative is one wavefront too)
 	if (pc.size() < 3 && !st) return -ENOTSUP;
-	const size_t n0 = pc.size(), ng0 = n0 / nxz_window_chain_group(0) + n0 / (nxz_window_chain_group(0) * 16) + 4;   // (groups of the smallest size, and the groups of 16 of them)
+	// (n0: how many pieces the control arrays hold -- the first list, and an eighth more for the pieces that later rounds cut)
+	const size_t n0 = pc.size() + std::max<size_t>(64, pc.size() / 8), ng0 = n0 / nxz_window_chain_group(0) + n0 / (nxz_window_chain_group(0) * 16) + 4;   // (groups of the smallest size, and the groups of 16 of them)
 	// control arrays (sized for the first, longest list of pieces), then a bump area for copies and outputs
 	const size_t o_jobs = 0, o_res = o_jobs + up(n0 * sizeof(nxz_batch_job_t), 256), o_items = o_res + up(n0 * sizeof(nxz_batch_result_t), 256),
 		     o_pieces = o_items + up((n0 + 4) * sizeof(CopyItem), 256), o_win0 = o_pieces + up(n0 * sizeof(Piece), 256),
@@ -734,6 +739,114 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		pc.swap(nx);
 		if (!again) break;
 		if (attempt >= 23 || pc.size() < 2) return -ENOTSUP;
+
+		// ---- the pieces of a later round get token boundaries of their own ----
+		// A round lasts as long as its longest piece, and what is decoded again is few and long: the block behind a start that
+		// turned out to be none (deflate streams carried inside stored blocks have headers that pass every test: a block of
+		// 16384 literals as ONE piece is 1.6 ms), pieces whose output outgrew its room (6 KB of the stream that make 300 KB:
+		// 2 ms).  Such a piece is cut the way the blocks were cut before the first round -- with its block's table if it
+		// starts at a cut (the piece lies inside that block), else with the table of the header it starts at (what it holds
+		// behind that block's end, if anything, yields boundaries that the arrival check refutes: a round more, which is why
+		// this is done in the first rounds only).  NXZ_PINFLATE_RECUT=0: never.
+		static const bool recut_on = !(getenv("NXZ_PINFLATE_RECUT") && atoi(getenv("NXZ_PINFLATE_RECUT")) == 0);
+		if (recut_on && attempt < 3) {
+			constexpr uint64_t MIN_BITS = 6144 * 8, PIECE_BITS = 2048 * 8;
+			constexpr uint32_t MAXSUB = 8, MAXREQ = 2048, MAXBLK = 256;
+			constexpr size_t RECUT_BYTES = (size_t)256 << 10;
+			struct Cand { size_t i; uint32_t blk; bool fresh; uint64_t base_bits, end; size_t r0, r1; };
+			std::vector<Cand> cands;
+			std::vector<nxz_sync_req_t> rq, bqn;
+			const size_t built_room = ws.built ? ws.built_cap / nxz_built_tables_bytes() : 0;
+			size_t add = 0;
+			for (size_t i = 0; i < pc.size(); i++) {
+				const P &p = pc[i];
+				if (p.done || p.srem || (i == 0 && st && (st->sfbt & 8))) continue;
+				const uint64_t end = i + 1 < pc.size() ? pc[i + 1].bit : src_len * 8;
+				// (a piece that outgrew its room is long by what it makes, not by what it reads: 32 Ki elements a piece)
+				const bool grew = p.res.cc == NXZ_CC_TARGET_SPACE;
+				if (end <= p.bit || end - p.bit < (grew ? MIN_BITS / 3 : MIN_BITS)) continue;
+				const uint64_t span = end - p.bit;
+				const uint64_t want = std::max<uint64_t>(span / PIECE_BITS, grew ? p.cap / 32768 : 0);
+				const uint32_t nsub = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(MAXSUB, want), span / 4096);
+				if (nsub < 2) continue;
+				if (pc.size() + add + nsub - 1 > n0 || rq.size() + nsub - 1 > MAXREQ) break;
+				Cand c;
+				c.i = i; c.end = end; c.r0 = rq.size();
+				if (p.tab >= 0) {
+					if ((size_t)p.tab >= blk_base.size()) continue;
+					c.blk = (uint32_t)p.tab; c.fresh = false; c.base_bits = blk_base[(size_t)p.tab];
+				} else {
+					if (p.hdr0 != 1 || tabs.size() != blk_base.size() || tabs.size() + bqn.size() >= built_room || bqn.size() >= MAXBLK) continue;
+					const uint64_t base = (p.bit >> 3) & ~3ull;
+					nxz_sync_req_t r;
+					r.src = src + base;
+					r.srclen = (uint32_t)std::min<uint64_t>(src_len - base, 0x7fffffffull);
+					r.header_bit = (uint32_t)(p.bit - base * 8);
+					r.guess_bit = 0; r.limit_bit = (uint32_t)std::min<uint64_t>(end - base * 8, 0xfffffff0ull);
+					c.blk = (uint32_t)(tabs.size() + bqn.size()); c.fresh = true; c.base_bits = base * 8;
+					if (end - c.base_bits >= 0xffffffffull) continue;
+					bqn.push_back(r);
+				}
+				if (end - c.base_bits >= 0xffffffffull) continue;
+				for (uint32_t k = 1; k < nsub; k++) {
+					nxz_sync_req_t r;
+					r.src = src + c.base_bits / 8;
+					r.srclen = (uint32_t)std::min<uint64_t>(src_len - c.base_bits / 8, 0x7fffffffull);
+					r.header_bit = c.blk;
+					r.guess_bit = (uint32_t)(p.bit + span * k / nsub - c.base_bits);
+					r.limit_bit = (uint32_t)(end - c.base_bits);
+					rq.push_back(r);
+				}
+				c.r1 = rq.size();
+				cands.push_back(c);
+				add += nsub - 1;
+			}
+			const size_t nr = rq.size(), nbn = bqn.size();
+			const size_t o_rq = 0, o_bq = up(nr * sizeof(nxz_sync_req_t), 256), o_rs = o_bq + up(nbn * sizeof(nxz_sync_req_t), 256),
+				     o_tb = o_rs + up(nr * sizeof(nxz_sync_res_t), 256), tot = o_tb + up(nbn * sizeof(nxz_batch_dht_t), 256);
+			bool go = nr != 0 && tot <= RECUT_BYTES;
+			if (go && !ws.rc_pin) {
+				if (hipHostMalloc(&ws.rc_pin, RECUT_BYTES) != hipSuccess) { (void)hipGetLastError(); ws.rc_pin = nullptr; go = false; }
+				else if (!zc && hipMalloc(&ws.rc_dev, RECUT_BYTES) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(ws.rc_pin); ws.rc_pin = nullptr; ws.rc_dev = nullptr; go = false; }
+			}
+			if (go && !zc && !ws.rc_dev) go = false;
+			if (go) {
+				uint8_t *Pn = (uint8_t *)ws.rc_pin, *Dv = zc ? Pn : (uint8_t *)ws.rc_dev;
+				memcpy(Pn + o_rq, rq.data(), nr * sizeof(nxz_sync_req_t));
+				if (nbn) memcpy(Pn + o_bq, bqn.data(), nbn * sizeof(nxz_sync_req_t));
+				if (!zc && hipMemcpyAsync(Dv + o_rq, Pn + o_rq, o_rs, hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+				if (nxz_launch_token_sync_more((const nxz_sync_req_t *)(Dv + o_bq), (uint32_t)nbn, (nxz_batch_dht_t *)(Dv + o_tb), ws.built, (uint32_t)tabs.size(),
+							       (const nxz_sync_req_t *)(Dv + o_rq), (uint32_t)nr, (nxz_sync_res_t *)(Dv + o_rs), s)) return -EIO;
+				if (!zc && hipMemcpyAsync(Pn + o_rs, Dv + o_rs, tot - o_rs, hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+				if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+				const nxz_sync_res_t *rs = (const nxz_sync_res_t *)(Pn + o_rs);
+				const nxz_batch_dht_t *tb = (const nxz_batch_dht_t *)(Pn + o_tb);
+				for (size_t k = 0; k < nbn; k++) tabs.push_back(tb[k]);
+				for (const Cand &c : cands) if (c.fresh) blk_base.push_back(c.base_bits);
+				std::vector<P> out;
+				out.reserve(pc.size() + add);
+				size_t ci = 0, made = 0;
+				for (size_t i = 0; i < pc.size(); i++) {
+					out.push_back(pc[i]);
+					if (ci >= cands.size() || cands[ci].i != i) continue;
+					const Cand &c = cands[ci++];
+					uint64_t last = pc[i].bit;
+					for (size_t k = c.r0; k < c.r1; k++) {
+						if (rs[k].bit == 0xffffffffu) continue;
+						const uint64_t bit = c.base_bits + rs[k].bit;
+						if (bit < last + 2048 || bit + 2048 > c.end) continue;
+						P q = P();
+						q.bit = bit; q.tab = (int)c.blk; q.cfin = c.fresh ? rs[k].lanes >> 31 : pc[i].cfin; q.per256 = (rs[k].lanes >> 8) & 0xffff;
+						q.capmul = pc[i].capmul; q.hdr0 = 0; q.done = false;
+						out.push_back(q);
+						last = bit; made++;
+					}
+				}
+				if (trace) fprintf(stderr, "nxz_inflate_stream: round %d: %zu pieces to decode again asked for %zu token boundaries (%zu tables more): %zu found\n", attempt, cands.size(), nr, nbn, made);
+				pc.swap(out);
+				lap("token boundaries again");
+			}
+		}
 		for (size_t i = 0; i < pc.size(); i++)
 			if (!pc[i].done && !size_piece(pc[i], i + 1 < pc.size() ? &pc[i + 1] : nullptr)) return -ENOTSUP;
 	}
