@@ -448,12 +448,13 @@ __global__ __launch_bounds__(64) void check_headers_kernel(const uint8_t *__rest
 							    uint32_t nseg, uint32_t seg_bytes, const uint16_t *__restrict__ left)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s[SEG + LOOK + 16];
-	__shared__ uint32_t best;
+	__shared__ uint32_t best, npass, pass[16];
 	const int t = threadIdx.x;
 	const uint32_t seg = blockIdx.x;
 	if (seg >= nseg) return;
 	const uint16_t *o = left + (size_t)seg * (LEFT_MAX + 2);
 	const uint32_t n = o[0];
+	if (o[1] || !n) { if (t < NXZ_BLOCKFIND_MORE) first[nseg + (size_t)seg * NXZ_BLOCKFIND_MORE + t] = ~0ull; }
 	if (o[1]) return;                                  // (the first kernel did this segment itself)
 	if (!n) { if (t == 0) first[seg] = ~0ull; return; }
 	const uint64_t base = (uint64_t)seg * seg_bytes;
@@ -463,12 +464,31 @@ __global__ __launch_bounds__(64) void check_headers_kernel(const uint8_t *__rest
 	if (t == 0) best = 0xffffffffu;
 	__syncthreads();
 	const uint32_t limit = have * 8;
+	// (round 5: not the first header of the segment alone but up to NXZ_BLOCKFIND_MORE further ones, behind the nseg firsts in
+	// `first`: packed data -- deflate streams carried inside stored blocks -- puts headers that are none in front of the
+	// block's that follows the stored run, in the same segment; that block's start went unseen, and the block was decoded
+	// in a later round, as one piece)
+	if (t == 0) npass = 0;
+	__syncthreads();
 	for (uint32_t k = t; k < n; k += 64) {
 		const uint32_t p = o[2 + k];
-		if (p < best && header_ok(s, p, limit, 0xffffffffu)) atomicMin(&best, p);
+		if (header_ok(s, p, limit, 0xffffffffu)) { atomicMin(&best, p); const uint32_t at = atomicAdd(&npass, 1u); if (at < 16) pass[at] = p; }
 	}
 	__syncthreads();
-	if (t == 0) first[seg] = best == 0xffffffffu ? ~0ull : base * 8 + best;
+	if (t == 0) {
+		first[seg] = best == 0xffffffffu ? ~0ull : base * 8 + best;
+		// the others, the last ones first (what follows a stored run lies behind what the run holds)
+		uint32_t m = npass < 16 ? npass : 16, got = 0;
+		uint64_t *more = first + nseg + (size_t)seg * NXZ_BLOCKFIND_MORE;
+		for (uint32_t j = 0; j < NXZ_BLOCKFIND_MORE; j++) more[j] = ~0ull;
+		while (got < NXZ_BLOCKFIND_MORE) {
+			uint32_t hi = 0, at = 0xffffffffu;
+			for (uint32_t j = 0; j < m; j++) if (pass[j] != 0xffffffffu && pass[j] != best && pass[j] >= hi) { hi = pass[j]; at = j; }
+			if (at == 0xffffffffu) break;
+			more[got++] = base * 8 + pass[at];
+			pass[at] = 0xffffffffu;
+		}
+	}
 }
 
 // A run of stored blocks is followed header by header (a thread per request; LEN tells where the next header
@@ -770,6 +790,7 @@ extern "C" int nxz_launch_find_blocks(const uint8_t *src, uint64_t srclen, uint6
 	uint16_t *left = two && !diag ? (uint16_t *)scratch : nullptr;
 	hipLaunchKernelGGL(nxzb::find_blocks_kernel, dim3(nseg), dim3(nxzb::NT), 0, stream, src, srclen, first_bit, first, nseg, seg, diag, left);
 	if (left) hipLaunchKernelGGL(nxzb::check_headers_kernel, dim3(nseg), dim3(64), 0, stream, src, srclen, first, nseg, seg, (const uint16_t *)left);
+	else if (hipMemsetAsync(first + nseg, 0xff, (size_t)nseg * NXZ_BLOCKFIND_MORE * sizeof(uint64_t), stream) != hipSuccess) return -1;
 	return (int)hipGetLastError();
 }
 

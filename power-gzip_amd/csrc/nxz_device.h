@@ -60,6 +60,7 @@ typedef struct nxz_sync_req {
 } nxz_sync_req_t;
 typedef struct nxz_sync_res { uint32_t bit; uint32_t lanes; } nxz_sync_res_t;   /* bit 0xffffffff: none found; lanes bit 31: the block's BFINAL */
 size_t nxz_built_tables_bytes(void);
+#define NXZ_BLOCKFIND_MORE 3u      /* nxz_launch_find_blocks: `first` holds nseg first headers, then this many further ones per segment (~0: none) */
 int nxz_launch_token_sync_more(const nxz_sync_req_t *breqs, uint32_t nb, nxz_batch_dht_t *tables, void *built, uint32_t first,
 			       const nxz_sync_req_t *reqs, uint32_t n, nxz_sync_res_t *res, hipStream_t stream);
 int nxz_launch_token_sync(const nxz_sync_req_t *breqs, uint32_t nb, nxz_batch_dht_t *tables, void *built,

@@ -258,17 +258,28 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	const uint32_t SEG = nxz_blockfind_segment(src_len);
 	const uint32_t nseg = (uint32_t)((src_len + SEG - 1) / SEG);
 	// ---- block starts ----
-	const size_t o_left = up(nseg * sizeof(uint64_t), 256);             // (what the search's first kernel leaves for its second)
-	if (!ws.need(o_left + nxz_blockfind_scratch(nseg), nseg * sizeof(uint64_t))) return -ENOMEM;
+	const size_t nfirst = (size_t)nseg * (1 + NXZ_BLOCKFIND_MORE);         // the first header of every segment, then up to three more
+	const size_t o_left = up(nfirst * sizeof(uint64_t), 256);           // (what the search's first kernel leaves for its second)
+	if (!ws.need(o_left + nxz_blockfind_scratch(nseg), nfirst * sizeof(uint64_t))) return -ENOMEM;
 	if (nxz_launch_find_blocks(src, src_len, first_bit, (uint64_t *)(zc ? ws.pin : ws.dev), nseg, (uint8_t *)ws.dev + o_left, s)) return -EIO;
-	if (!zc && hipMemcpyAsync(ws.pin, ws.dev, nseg * sizeof(uint64_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
+	if (!zc && hipMemcpyAsync(ws.pin, ws.dev, nfirst * sizeof(uint64_t), hipMemcpyDeviceToHost, s) != hipSuccess) return -EIO;
 	if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
 	lap("block starts");
 	std::vector<uint64_t> B;
 	B.push_back(first_bit);
-	for (uint32_t i = 0; i < nseg; i++) {
-		const uint64_t p = ((const uint64_t *)ws.pin)[i];
-		if (p != ~0ull && p > first_bit + 64) B.push_back(p);
+	{
+		static const bool more_on = !(getenv("NXZ_PINFLATE_MORE_STARTS") && atoi(getenv("NXZ_PINFLATE_MORE_STARTS")) == 0);
+		const uint64_t *F = (const uint64_t *)ws.pin;
+		size_t extra = 0;
+		for (uint32_t i = 0; i < nseg; i++) {
+			uint64_t v[1 + NXZ_BLOCKFIND_MORE];
+			uint32_t m = 0;
+			if (F[i] != ~0ull) v[m++] = F[i];
+			for (uint32_t j = 0; more_on && j < NXZ_BLOCKFIND_MORE; j++) if (F[nseg + (size_t)i * NXZ_BLOCKFIND_MORE + j] != ~0ull) v[m++] = F[nseg + (size_t)i * NXZ_BLOCKFIND_MORE + j];
+			std::sort(v, v + m);
+			for (uint32_t j = 0; j < m; j++) if (v[j] > first_bit + 64 && v[j] > B.back()) { B.push_back(v[j]); extra += j != 0; }
+		}
+		if (trace) fprintf(stderr, "nxz_inflate_stream: %zu block starts, %zu of them not the first of their segment\n", B.size(), extra);
 	}
 
 	// ---- a stream (or part of one) of a few hundred blocks at most: more places to cut it at ----
