@@ -431,6 +431,7 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	// 0.9 ms of copies for 256 MiB.  NXZ_PINFLATE_STAGE=1 forces that.)
 	static const bool stage_env = getenv("NXZ_PINFLATE_STAGE") && atoi(getenv("NXZ_PINFLATE_STAGE")) != 0;
 	const bool direct = !stage_env && ((uintptr_t)src & 15) == 0;
+	static const uint32_t est_room = getenv("NXZ_PINFLATE_EST_ROOM") ? (uint32_t)atoi(getenv("NXZ_PINFLATE_EST_ROOM")) : 3;     // (halves: 1.5 x; 0: the multiplier alone)
 	auto size_piece = [&](P &p, const P *next) -> bool {
 		const uint64_t next_bit = next ? next->bit : 0;
 		p.cstart = direct ? (p.bit >> 3) & ~15ull : p.bit >> 3;
@@ -439,7 +440,12 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		if (p.cbytes > 0xfffffff0ull - 64) return false;
 		p.stop = next && next->tab >= 0 ? next_bit - p.cstart * 8 : 0;
 		if (p.stop > 0xffffffffull) return false;
-		const uint64_t cp = std::max<uint64_t>(p.cbytes * p.capmul, p.tab >= 0 ? CAP_FLOOR_CUT : CAP_FLOOR_BLOCK);
+		uint64_t cp = std::max<uint64_t>(p.cbytes * p.capmul, p.tab >= 0 ? CAP_FLOOR_CUT : CAP_FLOOR_BLOCK);
+		// (where token_sync_kernel saw the data make much more than the call's multiplier allows for -- long runs: 6 KB of a
+		// stream that make 300 KB --, EST_ROOM / 2 times what it saw: such a piece decoded again costs the call a round)
+		uint32_t r256 = p.per256;
+		if (!r256 && next && next->tab >= 0) r256 = next->per256;
+		if (est_room && r256 && p.capmul < 1032) cp = std::max<uint64_t>(cp, std::min<uint64_t>(p.cbytes * 1032, p.cbytes * (uint64_t)r256 * est_room / 64));    // (est_room: in halves)
 		if (cp > 0xfff00000ull) return false;
 		p.cap = up(cp, 256);
 		p.stage_off = bump; if (!direct) bump += up(p.cbytes + 64, 256);
