@@ -303,8 +303,9 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 		// (8192 up to 64 MiB of stream, 16384 beyond: 256 MiB of the round-4 corpus are 53 MiB of stream -- 7.4 ms with 8192 pieces, 8.9
 		// with 14692 --, with the image-like and packed classes of round 5 they are 86 MiB of literal-heavy blocks of 20 KB that
 		// hardly ever got a second piece at 8192 and take a wavefront 3.3 ms each: 16.3 ms with 8192, 14.1 with 12288, 13.9 with 16384,
-		// 15.8 with 24576)
-		const uint64_t many = many_env ? many_env : all_bits > ((uint64_t)64 << 23) ? 16384 : 8192;
+		// 15.8 with 24576; with four headers a segment from the block search and the later rounds' pieces cut: 10.5 ms with 16384,
+		// 9.65 with 12288, 9.94 with 10240)
+		const uint64_t many = many_env ? many_env : all_bits > ((uint64_t)64 << 23) ? 12288 : 8192;
 		static const uint64_t few = getenv("NXZ_PINFLATE_PIECES_SHORT") ? std::max<uint64_t>(1, (uint64_t)atoll(getenv("NXZ_PINFLATE_PIECES_SHORT"))) : 768;
 		static const uint64_t per_piece = getenv("NXZ_PINFLATE_PIECE_BYTES") ? std::max<uint64_t>(256, (uint64_t)atoll(getenv("NXZ_PINFLATE_PIECE_BYTES"))) : 2560;
 		const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(few, all_bits / (8 * per_piece)), std::max<uint64_t>(few, many));
