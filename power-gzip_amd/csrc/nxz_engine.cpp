@@ -159,6 +159,7 @@ struct nxz_ctx {
 	} merges[3];
 	std::mutex mm;
 	std::condition_variable mcv;
+	std::atomic<int> host_callers{0};                 // callers inside nxz_deflate_host at this moment
 	// nxu_run_job, compress: callers that arrive while a launch is in flight are gathered and go out
 	// together as one launch of each kernel (run_compress / round_run)
 	struct Round {
@@ -882,8 +883,8 @@ static bool lane_need(nxz_ctx::HostLane &l, bool high, size_t blocks)
 static uint32_t merge_max_blocks()
 {
 	const char *e = getenv("NXZ_MERGE_MAX_BLOCKS");                 // (read at every call: the tests switch it; 0: never)
-	const long x = e ? atol(e) : 64;
-	return (uint32_t)(x < 0 ? 0 : x > 128 ? 128 : x);
+	const long x = e ? atol(e) : 128;
+	return (uint32_t)(x < 0 ? 0 : x > 256 ? 256 : x);
 }
 static bool merge_init(nxz_ctx *c, nxz_ctx::Merge &m)
 {
@@ -1027,7 +1028,12 @@ extern "C" int nxz_deflate_host_hist(nxz_ctx_t *c, int fc, const uint8_t *src, s
 	if (H) fc |= 0x08;                                                  // the RESUME forms take hist_len
 	if (!prev) prev_len = 0;
 	(void)hipSetDevice(c->device);
-	if ((src_len + B - 1) / B <= merge_max_blocks()) {
+	// (a call of more than 64 blocks that is alone takes its own pair of lanes, whose groups overlap copies and kernels: 16 MiB
+	// on one thread 8.1 against 6.8 GiB/s merged; with others about, merged: sixteen threads of 8 MiB calls 12.4 -> 28-29 GiB/s.
+	// Not beyond 128 blocks: two members of 16 MiB fill a merge, 17 GiB/s either way.)
+	struct InCall { std::atomic<int> &n; int mine; InCall(std::atomic<int> &a) : n(a), mine(a.fetch_add(1) + 1) {} ~InCall() { n.fetch_sub(1); } } in_call(c->host_callers);
+	const size_t nblk_all = (src_len + B - 1) / B;
+	if (nblk_all <= merge_max_blocks() && (nblk_all <= 64 || in_call.mine > 1)) {
 		const int r = merged_deflate(c, fc, src, src_len, final, H, B, prev, prev_len, dst, out_len, crc, adler);
 		if (r != -EAGAIN) return r;
 	}
