@@ -810,7 +810,7 @@ bool parallel_inflate(Inflate *s)
 		uint8_t *pin_in = nullptr, *pin_out = nullptr;
 		size_t pin_in_cap = 0, pin_out_cap = 0;
 	};
-	constexpr size_t STAGE_IN_MAX = (size_t)4 << 20, STAGE_OUT_MAX = (size_t)8 << 20;   // (32 callers at most: 384 MiB of pinned memory if every one of them stages as much as it may)
+	constexpr size_t STAGE_IN_MAX = (size_t)8 << 20, STAGE_OUT_MAX = (size_t)16 << 20;  // (twelve callers at a time, see below: 288 MiB of pinned memory if every one of them stages as much as it may)
 	static const bool stage_on = !(getenv("NXZ_HOST_STAGE") && atoi(getenv("NXZ_HOST_STAGE")) == 0) && nxz_pinned_malloc && nxz_pinned_free;
 	constexpr int NSLOT = 32, NDEV = 64;
 	static Slot slots[NDEV][NSLOT];
