@@ -33,6 +33,9 @@
 #ifndef NXZ_INFLATE_CHAIN_BY_LANE
 #define NXZ_INFLATE_CHAIN_BY_LANE 1       /* 0: the chain of token starts link by link in scalar arithmetic, as up to round 5 (for comparisons) */
 #endif
+#ifndef NXZ_SYNC_EXTRA
+#define NXZ_SYNC_EXTRA 2048               /* token_sync_kernel: bits behind the stretch every lane walks alone in which the lanes may still fall in step */
+#endif
 #ifndef NXZ_INFLATE_LIT_STEP
 #define NXZ_INFLATE_LIT_STEP 1            /* 0: no short step for stretches of literals (for comparisons) */
 #endif
@@ -1203,7 +1206,7 @@ __global__ __launch_bounds__(64) void token_sync_kernel(const nxz_sync_req_t *__
 		if (rend > rq.limit_bit) rend = rq.limit_bit;
 		// (lanes that have not fallen in step 2048 bits behind the stretch each walked alone will hardly do so: the
 		// request is given up -- walking on to the end of the copy would make this wavefront the one the launch waits for)
-		if (rend > rq.guess_bit + 64 + SYNC_RUN + 2048) rend = rq.guess_bit + 64 + SYNC_RUN + 2048;
+		if (rend > rq.guess_bit + 64 + SYNC_RUN + NXZ_SYNC_EXTRA) rend = rq.guess_bit + 64 + SYNC_RUN + NXZ_SYNC_EXTRA;
 		uint32_t pos = rq.guess_bit + (uint32_t)lane;
 		bool alive = true;
 		uint32_t made = 0;                                          // bytes the tokens this lane walked over make (an estimate of the data's ratio for the caller)
