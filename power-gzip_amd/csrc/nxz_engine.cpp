@@ -160,6 +160,9 @@ struct nxz_ctx {
 	std::mutex mm;
 	std::condition_variable mcv;
 	std::atomic<int> host_callers{0};                 // callers inside nxz_deflate_host at this moment
+	hipStream_t split_stream = nullptr;               // nxz_batch_decompress: a large batch of streams that bring tables, shared out between two kernels
+	hipEvent_t split_ev[2] = { nullptr, nullptr };
+	std::mutex split_mtx;
 	// nxu_run_job, compress: callers that arrive while a launch is in flight are gathered and go out
 	// together as one launch of each kernel (run_compress / round_run)
 	struct Round {
@@ -359,6 +362,11 @@ extern "C" void nxz_ctx_destroy(nxz_ctx_t *c)
 		(void)hipHostFree(r.h_jobs); (void)hipHostFree(r.h_res); (void)hipHostFree(r.h_dht); (void)hipHostFree(r.h_cnt);
 		(void)hipFree(r.d_prep); (void)hipFree(r.d_tok); (void)hipFree(r.d_cand2); (void)hipFree(r.d_src); (void)hipHostFree(r.h_items);
 		r = nxz_ctx::Round();
+	}
+	if (c->split_stream) {
+		(void)hipStreamSynchronize(c->split_stream); (void)hipStreamDestroy(c->split_stream);
+		if (c->split_ev[0]) (void)hipEventDestroy(c->split_ev[0]);
+		if (c->split_ev[1]) (void)hipEventDestroy(c->split_ev[1]);
 	}
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	g_ctx[c->device] = nullptr;
@@ -580,8 +588,15 @@ extern "C" int nxz_batch_dhtgen(nxz_ctx_t *c, const uint32_t *counts, size_t n, 
 	return 0;
 }
 
+// force: 0 -- the kernel by the batch's size and kind; 1 -- a stream per lane, any block type; 2 -- a stream per wavefront
+static int batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, void *stream, int force);
+static hipError_t stream_create_spread(hipStream_t *s, unsigned turn);
 extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n,
 				    nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, void *stream)
+{
+	return batch_decompress(c, jobs, n, results, dht_io, stream, 0);
+}
+static int batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io, void *stream, int force)
 {
 	if (!c) return -EINVAL;
 	if (forked_child()) return -ENODEV;
@@ -590,8 +605,9 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 	int rc;
 	const char *lm = getenv("NXZ_INFLATE_LANES_MIN");                    // tuning / test knob
 	const size_t lanes_min = lm ? (size_t)strtoull(lm, nullptr, 0) : (size_t)NXZ_LANES_MIN;
-	bool lanes = n >= lanes_min, by_len = false, no_tables = false;
-	if (lanes && !lm) {
+	bool lanes = force ? (force & 3) == 1 : n >= lanes_min, by_len = (force & 4) != 0, no_tables = false;
+	bool split = false;
+	if (lanes && !lm && !force) {
 		// what kind of streams?  (one small launch and a wait for it: nothing next to the tens of milliseconds such a batch takes)
 		uint32_t *h = nullptr;
 		{
@@ -606,6 +622,11 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 				// overtakes it (zlib -6 streams of the corpus: 75 against 86 GiB/s at 131 072 streams, 95 against 86 at 196 608, 102 at
 				// 262 144, 117 at 524 288; profiles/r04c_inflate_by_batch_size.txt)
 				if (h[0] > 64 && n < NXZ_LANES_TABLES_MIN) lanes = false;
+				// ... and from there on BOTH, side by side on two HIP streams, each on its share of the batch (NXZ_INFLATE_SPLIT_PCT: the
+				// wavefront kernel's share, 40; 0: the lane kernel alone, as up to round 5): the lane kernel waits for memory three quarters
+				// of its time, the wavefront kernel is bound by what it issues -- 262 548 zlib -6 streams of the corpus 81.6 -> 84.4 GiB/s,
+				// of the round-4 classes 97.4 -> 110
+				else if (h[0] > 64 && n >= NXZ_LANES_TABLES_MIN) split = true;
 				// streams of very different lengths (zeros beside text: BASELINE configs[4]): a wavefront takes as long as its
 				// longest stream, so the lane kernel gets them ordered by length; much of a size they stay as they come
 				// (neighbours in memory: ordering the bench's synthetic blocks cost 5 %)
@@ -613,6 +634,29 @@ extern "C" int nxz_batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, s
 				// few of the sampled streams begin with a dynamic block: the fixed-code-only lane kernel first, which hands the
 				// streams it cannot do -- those, and any with a dynamic block further in -- to the general one, stream by stream
 				no_tables = h[0] <= 16;
+			}
+		}
+	}
+	static const int split_pct = getenv("NXZ_INFLATE_SPLIT_PCT") ? atoi(getenv("NXZ_INFLATE_SPLIT_PCT")) : 40;
+	if (split && split_pct > 0 && split_pct < 100) {
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			if (!c->split_stream) {
+				if (stream_create_spread(&c->split_stream, 1) != hipSuccess || hipEventCreateWithFlags(&c->split_ev[0], hipEventDisableTiming) != hipSuccess ||
+				    hipEventCreateWithFlags(&c->split_ev[1], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->split_stream = nullptr; }
+			}
+		}
+		if (c->split_stream) {
+			std::lock_guard<std::mutex> one(c->split_mtx);              // (one split batch at a time: the second stream and the events are the context's)
+			const size_t k = ((n * (size_t)(100 - split_pct) / 100) + 63) & ~(size_t)63;
+			if (k > 0 && k < n) {
+				HIPCHK(hipEventRecord(c->split_ev[0], s), return -EIO);
+				HIPCHK(hipStreamWaitEvent(c->split_stream, c->split_ev[0], 0), return -EIO);
+				const int r2 = batch_decompress(c, jobs + k, n - k, results + k, dht_io ? dht_io + k : nullptr, c->split_stream, 2);
+				const int r1 = batch_decompress(c, jobs, k, results, dht_io, s, 1 | (by_len ? 4 : 0));
+				HIPCHK(hipEventRecord(c->split_ev[1], c->split_stream), return -EIO);
+				HIPCHK(hipStreamWaitEvent(s, c->split_ev[1], 0), return -EIO);
+				return r1 ? r1 : r2;
 			}
 		}
 	}

@@ -505,6 +505,45 @@ def test_full_size_roundtrip_property(eng):
     assert ratio > 1.5
 
 
+def test_a_large_batch_of_streams_with_tables_goes_to_both_kernels_and_is_exact(eng):
+    """163 840 streams or more that bring tables are shared out: a stream per lane on the caller's HIP stream, a stream
+    per wavefront on a second one, side by side (nxz_engine.cpp, NXZ_INFLATE_SPLIT_PCT).  200 000 zlib -6 streams of
+    500 different short texts, lengths 200 .. 3000: every result (bytes, checksums, where the stream stood) is what
+    zlib says, whichever kernel took the stream -- and the same with the share at 0."""
+    import torch
+    rng = np.random.default_rng(3)
+    text = make_block("alice", 200000, 5)
+    uniq, comps = [], []
+    for k in range(500):
+        n = int(rng.integers(200, 3000)); o = int(rng.integers(0, len(text) - n))
+        d = text[o:o + n]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        c = co.compress(d) + co.flush()
+        assert (c[0] >> 1) & 3 == 2                          # a block that brings its table
+        uniq.append(d); comps.append(c)
+    n = 200000
+    SI, SO = 2048, 3072
+    which = rng.integers(0, 500, n)
+    src = np.zeros((500, SI), np.uint8)
+    for k, c in enumerate(comps):
+        src[k, :len(c)] = np.frombuffer(c, np.uint8)
+    d_src = torch.from_numpy(src).to(eng.dev)[torch.from_numpy(which).to(eng.dev)].contiguous()
+    lens = np.array([len(comps[k]) for k in which], np.uint32)
+    want_len = np.array([len(uniq[k]) for k in which], np.uint32)
+    want_crc = np.array([zlib.crc32(uniq[k]) for k in range(500)], np.uint32)[which]
+    expect = np.zeros((500, SO), np.uint8)
+    for k, d in enumerate(uniq):
+        expect[k, :len(d)] = np.frombuffer(d, np.uint8)
+    d_expect = torch.from_numpy(expect).to(eng.dev)[torch.from_numpy(which).to(eng.dev)]
+    for _ in range(2):
+        out = torch.zeros((n, SO), dtype=torch.uint8, device=eng.dev)
+        jobs = eng.jobs_strided(d_src, SI, lens, out, SO, SO)
+        r = eng.results_to_host(eng.decompress(jobs, n))
+        assert (r["cc"] == 0).all()
+        assert (r["tpbc"] == want_len).all() and (r["crc"] == want_crc).all()
+        assert torch.equal(out, d_expect)
+
+
 def test_batches_on_two_streams_at_once(eng):
     """Two batched compress launches in flight on different streams (each draws its jobs from its own
     counter) give what they give one after the other; more jobs than workgroups, fewer, and one."""
