@@ -1045,7 +1045,7 @@ def c2_measure(torch, dist, args, rank, world, dev, distributed, pkg, eng, n, st
                              "crc differs in %d" % (nbad, n, int((r2["cc"] != 0).sum()), np.unique(r2["cc"]), int((r2["crc"] != res["crc"]).sum())))
         ub, cb = float(n) * BLOCK, float(res["tpbc"].astype(np.float64).sum())
         inflate_info = {"value": round(ub / (inf_ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out",
-                        "ms_per_pass": round(inf_ms, 3), "kernel": "batched inflate (a stream per lane and a stream per wave side by side at this size) + cksum_kernel",
+                        "ms_per_pass": round(inf_ms, 3), "kernel": "batched inflate (a stream per lane, fixed-code blocks) + cksum_kernel",
                         "what": "the fixed-Huffman output of the timed region", "scope": "one GPU (rank 0)", "roundtrip_bit_exact": True,
                         "roofline": roof((ub + cb) / (inf_ms * 1e-3) / 1e9, pmc_traffic(n, "inflate_own"), "nxzl::inflate_lanes_fixed_kernel + cksum_kernel", peak_m)}
         del back
