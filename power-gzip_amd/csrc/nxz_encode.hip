@@ -17,6 +17,7 @@
 // Bit for bit the encoder of oracle/nxz_lz77.c (put_tokens / nxo_encode_fixed / nxo_encode_dynamic).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "nxz_device.h"
 
 namespace nxze {
@@ -321,7 +322,11 @@ extern "C" int nxz_launch_encode(int dht, int table_per_job, const nxz_batch_job
 				 const nxz_dht_prepared_t *tables, nxz_batch_result_t *results, hipStream_t stream)
 {
 	if (n == 0) return 0;
-	if (dht && table_per_job) hipLaunchKernelGGL((nxze::encode_kernel<true, false>), dim3((unsigned)n), dim3(nxze::NT), 0, stream, jobs, tokens, tables, table_per_job, results, (uint32_t)n);
+	// NXZ_ENCODE_CHECK=1: the tables the device made go through the kernel form that looks for symbols without a code as well
+	// (cc 11 instead of a zero-length code in the block if the LZ77 kernel's counts and its tokens ever disagreed) -- the same
+	// bytes, a few per cent slower; tests/test_gpu_parity.py runs the corpus blocks this way.  (Read at every call: the tests switch it.)
+	const char *chk = getenv("NXZ_ENCODE_CHECK");
+	if (dht && table_per_job && !(chk && atoi(chk) != 0)) hipLaunchKernelGGL((nxze::encode_kernel<true, false>), dim3((unsigned)n), dim3(nxze::NT), 0, stream, jobs, tokens, tables, table_per_job, results, (uint32_t)n);
 	else if (dht) hipLaunchKernelGGL(nxze::encode_kernel<true>, dim3((unsigned)n), dim3(nxze::NT), 0, stream, jobs, tokens, tables, table_per_job, results, (uint32_t)n);
 	else hipLaunchKernelGGL(nxze::encode_kernel<false>, dim3((unsigned)n), dim3(nxze::NT), 0, stream, jobs, tokens, tables, 0, results, (uint32_t)n);
 	return (int)hipGetLastError();

@@ -1048,3 +1048,35 @@ def test_fused_dhtgen_kernel_equals_the_three_kernels(eng):
             dht, dhtlen = O.dhtgen(ll, d)
             exp, bits = O.deflate_dynamic(blocks[i], dht, dhtlen)
             assert b[0]["tpbc"][i] == len(exp) and b[1][i, :len(exp)].tobytes() == exp, (nb, i)
+
+
+def test_missing_code_check_never_fires_on_device_made_tables(eng):
+    """NXZ_ENCODE_CHECK=1 sends the tables the device made of a block's own counts through the kernel form that looks for
+    symbols without a code (encode_kernel<true, true>, which a caller's table always takes; the default form has the check
+    compiled out -- round 4's advisor finding).  The LZ77 kernel's counts and its tokens agree and dhtgen gives every counted
+    symbol a code (lib/nx_dhtgen.c:252-270): no job answers cc 11, and the blocks are byte for byte those of the default form."""
+    import torch
+    kinds = ["alice", "lz", "binary", "text33", "zeros", "random", "periodic", "sparse"]
+    sizes = [65536 if i % 5 else [1, 2, 258, 30000 + i, 65535][(i // 5) % 5] for i in range(600)]
+    blocks = [make_block(kinds[i % len(kinds)], sizes[i], seed=4200 + i) for i in range(600)]
+    nb = len(blocks)
+    src = pack_blocks(eng, blocks, STRIDE_IN)
+    lens = np.array([len(b) for b in blocks], np.uint32)
+    got = {}
+    for mode in ("0", "1"):
+        os.environ["NXZ_ENCODE_CHECK"] = mode
+        try:
+            dst = torch.zeros((nb, STRIDE_OUT), dtype=torch.uint8, device=eng.dev)
+            jobs = eng.jobs_strided(src, STRIDE_IN, lens, dst, STRIDE_OUT, STRIDE_OUT)
+            res, cnt = eng.compress(pkg.FC_COMPRESS_DHTGEN_COUNT, jobs, nb)
+            r = eng.results_to_host(res)
+            got[mode] = (r.copy(), dst.cpu().numpy().copy())
+        finally:
+            os.environ.pop("NXZ_ENCODE_CHECK", None)
+    a, b = got["0"], got["1"]
+    assert (b[0]["cc"] != 11).all()
+    for f in ("cc", "tpbc", "tebc"):
+        assert (a[0][f] == b[0][f]).all(), f
+    for i in range(nb):
+        n = int(a[0]["tpbc"][i])
+        assert a[1][i, :n].tobytes() == b[1][i, :n].tobytes(), i
