@@ -1077,9 +1077,37 @@ extern "C" int nxz_deflate_host_hist(nxz_ctx_t *c, int fc, const uint8_t *src, s
 	// Not beyond 128 blocks: two members of 16 MiB fill a merge, 17 GiB/s either way.)
 	struct InCall { std::atomic<int> &n; int mine; InCall(std::atomic<int> &a) : n(a), mine(a.fetch_add(1) + 1) {} ~InCall() { n.fetch_sub(1); } } in_call(c->host_callers);
 	const size_t nblk_all = (src_len + B - 1) / B;
-	if (nblk_all <= merge_max_blocks() && (nblk_all <= 64 || in_call.mine > 1)) {
+	const uint32_t mmax = merge_max_blocks();
+	if (nblk_all <= mmax && (nblk_all <= 64 || in_call.mine > 1)) {
 		const int r = merged_deflate(c, fc, src, src_len, final, H, B, prev, prev_len, dst, out_len, crc, adler);
 		if (r != -EAGAIN) return r;
+	}
+	// A call beyond the merge's limit while other callers are about goes through the merges in slices of that many blocks, one
+	// after the other (every block of a stream starts on a byte boundary and sees the input in front of it as its window, so the
+	// slices' streams laid end to end ARE the call's stream, byte for byte): sixteen threads of 16 MiB calls on four pairs of
+	// lanes of their own ran at half the rate of 8 MiB calls (14 against 30 GiB/s).  NXZ_MERGE_SLICES=0: own lanes as before.
+	const char *sle = getenv("NXZ_MERGE_SLICES");                       // (read at every call: the tests switch it)
+	if (!(sle && atoi(sle) == 0) && nblk_all > mmax && mmax >= 64 && in_call.mine > 1) {
+		const size_t S = (size_t)mmax * B;
+		size_t off = 0, pos = 0;
+		uint32_t run_crc = 0, run_adler = 1;
+		while (off < src_len) {
+			const size_t len = std::min<size_t>(S, src_len - off);
+			size_t got = 0;
+			uint32_t ck = 0, ak = 1;
+			const int r = merged_deflate(c, fc, src + off, len, final && off + len == src_len, H, B, off ? src : prev, off ? off : prev_len, dst + pos, &got, &ck, &ak);
+			if (r == -EAGAIN && !off) break;                            // (no merges to be had: the lanes below, nothing is done yet)
+			if (r) return r == -EAGAIN ? -EIO : r;
+			run_crc = gf2_mul32(run_crc, crc_shift_op(len)) ^ ck;
+			run_adler = adler_join(run_adler, ak, len);
+			pos += got; off += len;
+		}
+		if (off == src_len) {
+			*out_len = pos;
+			if (crc) *crc = run_crc;
+			if (adler) *adler = run_adler;
+			return 0;
+		}
 	}
 	int pair = -1;
 	for (int k = 0; k < HOST_PAIRS && pair < 0; k++) if (c->lanes_mtx[k].try_lock()) pair = k;

@@ -34,6 +34,7 @@
 #include <time.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <vector>
 #include "nxz_device.h"
@@ -93,6 +94,8 @@ uint32_t adler_combine(uint32_t a1, uint32_t a2, uint64_t len2)
 // its own) decode side by side; a caller takes one that is free, or waits for the one its turn falls on
 // device bytes all workspaces hold (the figure the idle budget below is kept against)
 std::atomic<size_t> g_ws_bytes{0};
+// ... and those of them that calls are working in right now: what is IDLE is the difference
+std::atomic<size_t> g_ws_inuse{0};
 struct Workspace {
 	void *dev = nullptr; size_t dev_cap = 0;
 	void *pin = nullptr; size_t pin_cap = 0;
@@ -100,19 +103,36 @@ struct Workspace {
 	void *built = nullptr; size_t built_cap = 0; // the blocks' decode tables (nxz_inflate.hip Built), device memory
 	void *rc_pin = nullptr, *rc_dev = nullptr;  // requests, results and tables of the token boundaries asked for in later rounds (RECUT_BYTES each, made once)
 	std::mutex mtx;
+	int64_t last_used_ms = 0;                   // when the last call that worked in it ended (read and written under mtx)
 	bool need(size_t d, size_t p)
 	{
-		if (d > dev_cap) {
+		if (d > dev_cap) {                          // (only ever called by the call that holds the workspace: its bytes are in use)
+			const size_t cap_before = dev_cap;
 			if (dev) (void)hipFree(dev);
+			g_ws_inuse -= dev_cap;
 			g_ws_bytes -= dev_cap;
 			dev = nullptr; dev_cap = 0;
-			if (hipMalloc(&dev, d) != hipSuccess) return false;
+			// An eighth more than asked for, in whole 2 MiB pages: callers of streams of one kind need a few bytes more or less from one
+			// call to the next, and every step up is a hipFree and a hipMalloc of the whole workspace -- gigabytes, a few hundred
+			// milliseconds, one after the other through the runtime for all callers (sixteen threads of 64 MiB streams, 8 GB a
+			// workspace: 0.5 GiB/s, calls that waited four seconds for their buffers).
+			static const bool trace = getenv("NXZ_PINFLATE_TRACE") != nullptr;
+			if (trace) fprintf(stderr, "nxz_inflate_stream: a workspace grows from %zu to %zu MiB and more (all workspaces: %zu MiB, in use %zu MiB)\n", cap_before >> 20, d >> 20, g_ws_bytes.load() >> 20, g_ws_inuse.load() >> 20);
+			size_t want = (d + d / 8 + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+			if (hipMalloc(&dev, want) != hipSuccess) {
+				(void)hipGetLastError();
+				want = d;
+				if (hipMalloc(&dev, want) != hipSuccess) return false;
+			}
+			d = want;
 			dev_cap = d;
 			g_ws_bytes += d;
+			g_ws_inuse += d;
 		}
 		if (p > pin_cap) {
 			if (pin) (void)hipHostFree(pin);
 			pin = nullptr; pin_cap = 0;
+			p = (p + p / 8 + 0xffff) & ~(size_t)0xffff;           // (likewise)
 			if (hipHostMalloc(&pin, p) != hipSuccess) return false;
 			pin_cap = p;
 		}
@@ -162,14 +182,38 @@ inline size_t idle_bytes()
 	}();
 	return v;
 }
+inline int64_t ws_now_ms() { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+constexpr int64_t WS_LINGER_MS = 2000;
 struct TrimOnExit {
 	Workspace &w;
+	int dev;
 	~TrimOnExit()
 	{
-		if (w.dev_cap > keep_bytes() || (w.dev_cap && g_ws_bytes.load() > idle_bytes())) {
-			(void)hipFree(w.dev);
-			g_ws_bytes -= w.dev_cap;
-			w.dev = nullptr; w.dev_cap = 0;
+		// Both limits -- what ONE workspace may keep, what ALL may hold -- are about memory that lies idle BETWEEN calls.  While
+		// other calls are at work a workspace stays as it is: callers of streams of one size come in company, and the next of them
+		// takes this workspace a moment later (up to round 5's end the total, busy workspaces and all, was held against the budget:
+		// sixteen threads of 32 / 64 MiB nx_uncompress calls, 2.8 / 8 GiB a workspace, gave every workspace back at the call's end and
+		// asked for it again at the next one's start -- hipFree and hipMalloc of gigabytes, a few hundred milliseconds each, one after the
+		// other through the runtime for all callers: 0.4 GiB/s).  What has lain idle for two seconds while others work goes if it is
+		// over a limit; the call that leaves the device idle applies both limits to everything at once.
+		const int64_t now = ws_now_ms();
+		w.last_used_ms = now;
+		g_ws_inuse -= w.dev_cap;
+		static const bool trace = getenv("NXZ_PINFLATE_TRACE") != nullptr;
+		const size_t busy = g_ws_inuse.load();
+		auto idle_now = [&] { const size_t all = g_ws_bytes.load(), b = g_ws_inuse.load(); return all > b ? all - b : (size_t)0; };
+		auto drop = [&](Workspace &x) {
+			if (trace) fprintf(stderr, "nxz_inflate_stream: a workspace of %zu MiB is given back (all workspaces: %zu MiB, in use %zu MiB, idle budget %zu MiB)\n", x.dev_cap >> 20, g_ws_bytes.load() >> 20, g_ws_inuse.load() >> 20, idle_bytes() >> 20);
+			(void)hipFree(x.dev); g_ws_bytes -= x.dev_cap; x.dev = nullptr; x.dev_cap = 0;
+		};
+		const bool quiet = busy == 0;
+		if (quiet && w.dev_cap && (w.dev_cap > keep_bytes() || idle_now() > idle_bytes())) drop(w);
+		if (!quiet && idle_now() <= idle_bytes()) return;           // (others at work and nothing over the budget: no walk)
+		for (int k = 0; k < NWS; k++) {
+			Workspace &o = g_ws[dev][k];
+			if (&o == &w || !o.dev_cap || !o.mtx.try_lock()) continue;
+			if (o.dev_cap && (quiet || now - o.last_used_ms > WS_LINGER_MS) && (o.dev_cap > keep_bytes() || idle_now() > idle_bytes())) drop(o);
+			o.mtx.unlock();
 		}
 	}
 };
@@ -225,7 +269,8 @@ static int inflate_stream(nxz_ctx_t *c, const uint8_t *src, uint64_t src_len, ui
 	if (!wsp) { wsp = &g_ws[dev][g_ws_turn.fetch_add(1) % NWS]; wsp->mtx.lock(); }
 	Workspace &ws = *wsp;
 	std::lock_guard<std::mutex> guard(ws.mtx, std::adopt_lock);
-	TrimOnExit trim{ws};                                       // (destroyed before the guard: still under the lock)
+	g_ws_inuse += ws.dev_cap;
+	TrimOnExit trim{ws, dev};                                       // (destroyed before the guard: still under the lock)
 	static const bool own_stream = !(getenv("NXZ_PINFLATE_OWN_STREAM") && atoi(getenv("NXZ_PINFLATE_OWN_STREAM")) == 0);
 	if (!s && own_stream) {
 		if (!ws.own) {

@@ -775,6 +775,7 @@ constexpr size_t CARRY_KEEP = 1024;                // unconsumed source kept bet
 bool parallel_inflate(Inflate *s)
 {
 	z_streamp z = s->z;
+	const auto t_entry = std::chrono::steady_clock::now();
 	if (!nxz_inflate_stream_part || !nxz_dev_malloc || !nxz_dev_free || !nxz_copy_to_device || !nxz_copy_to_host || !nxz_ctx_sync) return false;
 	if (s->pending() || !s->eng.open) return false;
 	if (nxz_engine_usable && !nxz_engine_usable()) return false;       // (forked after the engine was opened: the job loop reports it)
@@ -833,8 +834,10 @@ bool parallel_inflate(Inflate *s)
 	size_t &pool_src_cap = slot->src_cap, &pool_dst_cap = slot->dst_cap;
 	if (!slot->stream && nxz_stream_create) slot->stream = nxz_stream_create(ctx);
 	void *const hs = slot->stream;               // (NULL, the default stream, if none could be made)
-	if (pool_src_cap < nin + 64) { if (pool_src) nxz_dev_free(ctx, pool_src); pool_src = (uint8_t *)nxz_dev_malloc(ctx, nin + 64); pool_src_cap = pool_src ? nin + 64 : 0; }
-	if (pool_dst_cap < cap + 64) { if (pool_dst) nxz_dev_free(ctx, pool_dst); pool_dst = (uint8_t *)nxz_dev_malloc(ctx, cap + 64); pool_dst_cap = pool_dst ? cap + 64 : 0; }
+	// (an eighth more than asked for, in whole MiB: the streams of one caller differ by a few bytes, and a step up is a free and an allocation through the runtime)
+	auto roomy = [](size_t n) { return (n + n / 8 + (((size_t)1 << 20) - 1)) & ~(((size_t)1 << 20) - 1); };
+	if (pool_src_cap < nin + 64) { if (pool_src) nxz_dev_free(ctx, pool_src); pool_src = (uint8_t *)nxz_dev_malloc(ctx, roomy(nin + 64)); pool_src_cap = pool_src ? roomy(nin + 64) : 0; }
+	if (pool_dst_cap < cap + 64) { if (pool_dst) nxz_dev_free(ctx, pool_dst); pool_dst = (uint8_t *)nxz_dev_malloc(ctx, roomy(cap + 64)); pool_dst_cap = pool_dst ? roomy(cap + 64) : 0; }
 	if (!pool_hist) pool_hist = (uint8_t *)nxz_dev_malloc(ctx, WINDOW);
 	uint8_t *d_src = pool_src, *d_dst = pool_dst, *d_hist = nh ? pool_hist : nullptr;
 	bool ok = d_src && d_dst && (!nh || d_hist);
@@ -893,7 +896,8 @@ bool parallel_inflate(Inflate *s)
 		     (tail.empty() || nxz_copy_to_host(ctx, tail.data(), d_dst + out_len - tail.size(), tail.size(), hs) == 0) && nxz_ctx_sync(ctx, hs) == 0;
 		if (!ok) s->pend.clear();
 	}
-	if (trace) fprintf(stderr, "nxz parallel_inflate: %zu bytes in (%zu carried), copy in %.2f ms, inflate %.2f ms, copy out %.2f ms (%llu bytes, %zu wait)%s\n", nin, nc, t1 - t0, t2 - t1, now() - t2,
+	if (trace) fprintf(stderr, "nxz parallel_inflate: %zu bytes in (%zu carried), %.2f ms for a turn and buffers, copy in %.2f ms, inflate %.2f ms, copy out %.2f ms (%llu bytes, %zu wait)%s\n", nin, nc,
+			   t0 - std::chrono::duration<double, std::milli>(t_entry.time_since_epoch()).count(), t1 - t0, t2 - t1, now() - t2,
 			   (unsigned long long)out_len, later, ok ? (st.final ? " -- final" : "") : " -- declined");
 	if (!ok) {
 		// declined: once is chance (the next part is tried again), again and again is the kind of stream
@@ -1358,6 +1362,14 @@ struct ApiTrace {
 					 ns_init / (double)calls * 1e-3, ns_body / (double)calls * 1e-3, ns_end / (double)calls * 1e-3);
 	}
 } g_api;
+struct ApiTraceU {
+	std::atomic<uint64_t> calls{0}, ns_init{0}, ns_body{0}, ns_end{0};
+	~ApiTraceU()
+	{
+		if (g_api.on && calls) fprintf(stderr, "nxz api trace: %llu nx_uncompress2 calls; per call: init %.1f us, inflate %.1f us, end %.1f us\n", (unsigned long long)calls,
+					       ns_init / (double)calls * 1e-3, ns_body / (double)calls * 1e-3, ns_end / (double)calls * 1e-3);
+	}
+} g_apiu;
 }
 
 extern "C" int nx_compress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen, int level)
@@ -1400,8 +1412,10 @@ extern "C" int nx_uncompress2(Bytef *dest, uLongf *destLen, const Bytef *source,
 	Byte buf[1];
 	if (*destLen) { left = *destLen; *destLen = 0; } else { left = 1; dest = buf; }
 	st.next_in = (z_const Bytef *)source; st.avail_in = 0;
+	const uint64_t t0 = g_api.on ? ApiTrace::now() : 0;
 	int rc = nx_inflateInit(&st);
 	if (rc != Z_OK) return rc;
+	const uint64_t t1 = g_api.on ? ApiTrace::now() : 0;
 	if (Inflate *is = istate(&st)) is->one_shot_hint = len <= maxu;      // (the whole source is in the first call)
 	st.next_out = dest; st.avail_out = 0;
 	do {
@@ -1412,7 +1426,9 @@ extern "C" int nx_uncompress2(Bytef *dest, uLongf *destLen, const Bytef *source,
 	*sourceLen -= len + st.avail_in;
 	if (dest != buf) *destLen = st.total_out;
 	else if (st.total_out && rc == Z_BUF_ERROR) left = 1;
+	const uint64_t t2 = g_api.on ? ApiTrace::now() : 0;
 	nx_inflateEnd(&st);
+	if (g_api.on) { g_apiu.calls++; g_apiu.ns_init += t1 - t0; g_apiu.ns_body += t2 - t1; g_apiu.ns_end += ApiTrace::now() - t2; }
 	return rc == Z_STREAM_END ? Z_OK : rc == Z_NEED_DICT ? Z_DATA_ERROR : rc == Z_BUF_ERROR && left + st.avail_out ? Z_DATA_ERROR : rc;
 }
 

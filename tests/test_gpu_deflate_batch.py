@@ -306,6 +306,74 @@ def test_merged_calls_with_a_window_match_the_calls_made_alone(L):
         del os.environ["NXZ_MERGE_MAX_BLOCKS"]
 
 
+def test_calls_beyond_the_merge_limit_go_through_the_merges_in_slices(L):
+    """nxz_deflate_host(_hist) calls of more than 128 blocks while other callers are about are cut into slices of 128 blocks that
+    join the merges one after the other (nxz_engine.cpp): six threads at once, calls of 130 .. 300 blocks and odd lengths, both
+    function codes, final and not, and two threads of level-6 / level-9 streams in steps of 12 MiB (blocks with the input in front
+    of them as window).  zlib reads every stream, the checksums are the data's, and every stream is byte for byte what the same
+    call makes on lanes of its own (NXZ_MERGE_SLICES=0)."""
+    import importlib, threading
+    pkg = importlib.import_module("power-gzip_amd")
+    eng = pkg.Engine(0)
+    kinds = ("alice", "lz", "text33", "random", "zeros", "binary")
+    T, per = 6, 2
+    nblocks = [[130, 257], [300, 129], [191, 256], [140, 222], [], []]
+    cut = [[0, 12345], [1, 0], [40000, 7], [0, 0], [], []]
+    bufs = [[b"".join(make_block(kinds[(t + i + k) % 6], 65536, 91 * t + 17 * i + k) for k in range(n))[:n * 65536 - cut[t][i]] for i, n in enumerate(nblocks[t])] for t in range(T)]
+    streams = {4: (6, b"".join(make_block(kinds[k % 4], 65536, 4000 + k) for k in range(400))[:(25 << 20) - 4321]),
+               5: (9, b"".join(make_block(kinds[(k + 2) % 4], 65536, 5000 + k) for k in range(330))[:(20 << 20) + 99])}
+    got = [[None] * per for _ in range(T)]
+    bad = []
+
+    def worker(t):
+        try:
+            if t in streams:
+                level, data = streams[t]
+                out, _, adler = Z.deflate_all(L, data, level=level, wbits=15, step_in=12 << 20)
+                if zlib.decompress(out) != data or adler != zlib.adler32(data):
+                    bad.append((t, "zlib"))
+                got[t][0] = out
+                return
+            for i, b in enumerate(bufs[t]):
+                fc = pkg.FC_COMPRESS_DHTGEN if (t + i) % 2 else pkg.FC_COMPRESS_FHT
+                final = (t + i) % 3 != 0
+                rc, comp, crc, adler = eng.deflate_host(b, fc=fc, final=final)
+                if rc != 0 or crc != zlib.crc32(b) or adler != zlib.adler32(b):
+                    bad.append((t, i, rc, "checksums"))
+                    return
+                d = zlib.decompressobj(-15)
+                if d.decompress(comp) != b or d.eof != final:
+                    bad.append((t, i, "zlib"))
+                    return
+                got[t][i] = (fc, final, comp)
+        except AssertionError as e:
+            bad.append((t, repr(e)))
+
+    try:
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not bad, bad
+        os.environ["NXZ_MERGE_SLICES"] = "0"
+        try:
+            for t in range(T):
+                if t in streams:
+                    level, data = streams[t]
+                    alone, _, _ = Z.deflate_all(L, data, level=level, wbits=15, step_in=12 << 20)
+                    assert alone == got[t][0], (t, level)
+                    continue
+                for i, b in enumerate(bufs[t]):
+                    fc, final, comp = got[t][i]
+                    rc, alone, _, _ = eng.deflate_host(b, fc=fc, final=final)
+                    assert rc == 0 and alone == comp, (t, i, len(b))
+        finally:
+            del os.environ["NXZ_MERGE_SLICES"]
+    finally:
+        eng.close()
+
+
 def test_deflate_host_entry_point():
     """nxz_deflate_host itself (include/nxz_engine.h): any length, final or not, both function codes;
     runs that are not final end on a byte boundary and are continued by the next run."""

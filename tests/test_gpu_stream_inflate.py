@@ -5,6 +5,7 @@ zlib-style API (nx_uncompress / nx_inflate on a whole .gz), where it replaces th
 import ctypes as C
 import importlib
 import os
+import sys
 import zlib
 
 import numpy as np
@@ -330,3 +331,48 @@ def test_the_part_interface_walks_a_stream_on_the_device(eng, data):
         hist = torch.from_numpy(np.frombuffer(tail, np.uint8).copy()).to(eng.dev)
         assert pos < len(comp)
     assert bytes(got) == plain and crc == zlib.crc32(plain)
+
+
+_IDLE_BUDGET_SCRIPT = r"""
+import ctypes as C, os, sys, threading, zlib
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import zstream as Z
+from datagen import make_block
+L = Z.load("gpu")
+E = C.CDLL(os.path.join(ROOT, "power-gzip_amd", "libnxz_engine.so"))
+E.nxz_pinflate_trim.restype = C.c_size_t
+kinds = ("alice", "lz", "text33", "binary")
+T = 6
+datas = [b"".join(make_block(kinds[(t + k) % 4], 65536, 61 * t + k) for k in range(64)) for t in range(T)]     # 4 MiB each
+comps = [zlib.compress(d, 6) for d in datas]
+bad = []
+def worker(t):
+    back = C.create_string_buffer(len(datas[t]))
+    for _ in range(4):
+        n = C.c_ulong(len(back))
+        if L.nx_uncompress(back, C.byref(n), comps[t], len(comps[t])) != 0 or back.raw[:n.value] != datas[t]:
+            bad.append(t)
+            return
+th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+for x in th: x.start()
+for x in th: x.join()
+print("bad", len(bad), "idle", E.nxz_pinflate_trim())
+"""
+
+
+def test_idle_workspaces_stay_inside_their_budget_and_busy_ones_are_left_alone():
+    """NXZ_PINFLATE_IDLE_MB: what the one-stream workspaces hold BETWEEN calls.  Six threads of 4 MiB nx_uncompress calls with a
+    budget of 300 MiB (a workspace of such a call is some 350 MiB): every call gets its bytes, and what nxz_pinflate_trim() finds
+    to give back when all is over -- all that lay idle -- is no more than the budget and one workspace (two calls that end at the
+    same moment: the one that leaves the device idle cannot take the other's, which is still locked), where six untrimmed
+    workspaces would be 2 GiB.  (The limits are about idle workspaces, not about those that calls are working in, and while
+    others work a workspace stays for two seconds: nxz_pinflate.cpp TrimOnExit.)"""
+    import subprocess
+    env = dict(os.environ, NXZ_PINFLATE_IDLE_MB="300")
+    p = subprocess.run([sys.executable, "-c", _IDLE_BUDGET_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in p.stdout.splitlines() if l.startswith("bad ")]
+    assert p.returncode == 0 and line, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    f = line[-1].split()
+    assert int(f[1]) == 0
+    assert int(f[3]) <= (300 << 20) + (512 << 20), line[-1]
