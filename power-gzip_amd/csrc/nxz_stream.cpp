@@ -825,6 +825,13 @@ bool parallel_inflate(Inflate *s)
 	static std::mutex gate_m; static std::condition_variable gate_cv; static int gate_n = 0;
 	struct Gate { bool on; Gate(bool o) : on(o) { if (on) { std::unique_lock<std::mutex> g(gate_m); gate_cv.wait(g, [] { return gate_n < gate_max; }); gate_n++; } }
 		      ~Gate() { if (on) { { std::lock_guard<std::mutex> g(gate_m); gate_n--; } gate_cv.notify_one(); } } } gate(gate_max > 0);
+	// (how many callers are in here right now: the pinned staging below is for company -- a caller that is alone copies straight
+	// from and to its own pages, which the runtime pins faster than one core copies them: one thread's 16 MiB nx_uncompress calls
+	// 4.2 -> 5.5 GiB/s, 8 MiB 3.3 -> 3.7; below a few MiB the staging is as fast)
+	static std::atomic<int> inside{0};
+	struct Inside { int n; Inside() : n(++inside) {} ~Inside() { --inside; } } in_here;
+	const bool company = in_here.n > 1;
+	constexpr size_t STAGE_ALONE_MAX = (size_t)2 << 20;
 	Slot *const pool = slots[dev];
 	Slot *slot = nullptr;
 	for (int k = 0; k < NSLOT && !slot; k++) if (pool[k].mtx.try_lock()) slot = &pool[k];
@@ -847,7 +854,7 @@ bool parallel_inflate(Inflate *s)
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t0 = trace ? now() : 0;
 	auto pin_need = [&](uint8_t *&p, size_t &have, size_t want, size_t most) {
-		if (!stage_on || want > most) return false;
+		if (!stage_on || want > most || (!company && want > STAGE_ALONE_MAX)) return false;
 		if (have >= want) return true;
 		size_t to = std::max<size_t>((size_t)256 << 10, have);
 		while (to < want) to <<= 1;
