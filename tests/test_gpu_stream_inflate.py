@@ -333,6 +333,57 @@ def test_the_part_interface_walks_a_stream_on_the_device(eng, data):
     assert bytes(got) == plain and crc == zlib.crc32(plain)
 
 
+def test_parts_beyond_the_pinned_staging_from_several_threads_at_once():
+    """Callers in company stage their copies through pinned memory (nxz_stream.cpp parallel_inflate) up to 8 MiB of source and
+    16 MiB of output; beyond, the copies go straight from and to the caller's pages.  Four threads at once: nx_uncompress of
+    40 MiB (21 MiB of stream), and inflate() of the same stream with all the input and room for 30 MiB of the output (the rest
+    waits and comes with the next calls): every byte and the checksum as zlib has them."""
+    import threading
+    from datagen import make_block
+    L = Z.load("gpu")
+    kinds = ("alice", "text33", "binary", "random", "lz")
+    base = [make_block(kinds[k % 5], 65536, 8800 + k) for k in range(160)]
+    datas = [b"".join(base[(k * (1, 3, 7, 9)[t] + t) % 160] for k in range(640)) for t in range(4)]       # (steps coprime to 160: no block comes again within 10 MiB)
+    comps = [zlib.compress(d, 1) for d in datas]
+    assert min(len(c) for c in comps) > (9 << 20)
+    bad = []
+
+    def worker(t):
+        d, c = datas[t], comps[t]
+        back = C.create_string_buffer(len(d))
+        for rep in range(2):
+            n = C.c_ulong(len(back))
+            if L.nx_uncompress(back, C.byref(n), c, len(c)) != Z.Z_OK or n.value != len(d) or back.raw != d:
+                bad.append((t, rep, "uncompress"))
+                return
+        st = Z.ZStream()
+        if L.nx_inflateInit2_(C.byref(st), 15, Z.VERSION, C.sizeof(Z.ZStream)) != Z.Z_OK:
+            bad.append((t, "init"))
+            return
+        src = C.create_string_buffer(c, len(c))
+        st.next_in = C.addressof(src); st.avail_in = len(c)
+        got = bytearray()
+        room = 30 << 20
+        rc = Z.Z_OK
+        for _ in range(64):
+            st.next_out = C.addressof(back); st.avail_out = room
+            rc = L.nx_inflate(C.byref(st), Z.Z_NO_FLUSH)
+            got += back.raw[:room - st.avail_out]
+            if rc != Z.Z_OK:
+                break
+            room = 3 << 20
+        if rc != Z.Z_STREAM_END or bytes(got) != d or st.adler != zlib.adler32(d) or st.total_in != len(c):
+            bad.append((t, "inflate", rc, len(got)))
+        L.nx_inflateEnd(C.byref(st))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not bad, bad
+
+
 _IDLE_BUDGET_SCRIPT = r"""
 import ctypes as C, os, sys, threading, zlib
 ROOT = sys.argv[1]
