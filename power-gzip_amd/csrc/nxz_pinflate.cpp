@@ -96,6 +96,7 @@ uint32_t adler_combine(uint32_t a1, uint32_t a2, uint64_t len2)
 std::atomic<size_t> g_ws_bytes{0};
 // ... and those of them that calls are working in right now: what is IDLE is the difference
 std::atomic<size_t> g_ws_inuse{0};
+inline size_t keep_bytes();
 struct Workspace {
 	void *dev = nullptr; size_t dev_cap = 0;
 	void *pin = nullptr; size_t pin_cap = 0;
@@ -119,6 +120,7 @@ struct Workspace {
 			static const bool trace = getenv("NXZ_PINFLATE_TRACE") != nullptr;
 			if (trace) fprintf(stderr, "nxz_inflate_stream: a workspace grows from %zu to %zu MiB and more (all workspaces: %zu MiB, in use %zu MiB)\n", cap_before >> 20, d >> 20, g_ws_bytes.load() >> 20, g_ws_inuse.load() >> 20);
 			size_t want = (d + d / 8 + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+			if (d <= keep_bytes() && want > keep_bytes()) want = keep_bytes();     // (a workspace sized to stay inside what one may keep -- capmul_for() -- stays inside it)
 			if (hipMalloc(&dev, want) != hipSuccess) {
 				(void)hipGetLastError();
 				want = d;
@@ -166,11 +168,13 @@ static inline uint32_t capmul_for(uint64_t src_len)
 }
 constexpr uint64_t CAP_FLOOR_CUT = 32u << 10, CAP_FLOOR_BLOCK = 128u << 10;
 // ... and so is one that would take what all the workspaces hold between calls beyond a budget (NXZ_PINFLATE_IDLE_MB,
-// default 16384 MiB or an eighth of the device's memory, at least twice what ONE workspace may keep: 32 callers of 1 MiB parts hold 32 x 32 MiB and never get here; 32
+// default 16384 MiB or a quarter of the device's memory, at least twice what ONE workspace may keep: 32 callers of 1 MiB parts hold 32 x 32 MiB and never get here; 32
 // callers of 64 MiB streams would otherwise keep 32 x 9 GiB for as long as the process lives -- round 3 left that to a manual nxz_trim()).
 inline size_t idle_bytes()
 {
-	// (an eighth of the device's memory where that is more: sixteen threads of 16 MiB streams hold 22 GiB, and under the
+	// (a quarter of the device's memory where that is more -- an eighth up to round 5's last session: the call that leaves the device
+	// idle between two bursts of sixteen 32 MiB streams, 3.6 GiB a workspace, gave six of them back, and the next burst began with
+	// their allocation -- : sixteen threads of 16 MiB streams hold 22 GiB, and under the
 	// flat 16 GiB every call gave its 1.4 GiB back at its end and asked for them again at the next one's start -- one
 	// allocation after the other through the runtime: 0.4 GiB/s all told, single calls of three seconds)
 	static const size_t v = [] {
@@ -178,7 +182,7 @@ inline size_t idle_bytes()
 		size_t free_b = 0, total_b = 0;
 		const size_t flat = (size_t)16384 << 20;
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return flat; }
-		return std::max(flat, total_b / 8);
+		return std::max(flat, total_b / 4);
 	}();
 	return v;
 }
