@@ -677,60 +677,65 @@ def api_leg(raw, args, mib=256, nthreads=16, raw_r04=None):
                                          "us_per_call": round(dt / len(blocks) * 1e6, 1), "calls_per_thread": len(blocks)}
     # the same harness shape at a size where the engine is meant to win: every thread 1 MiB buffers, one call per buffer,
     # compress and decompress (the whole sizes x threads table: tools/api_sweep.py, profiles/r03_api_sweep.txt)
-    big = [data[i << 20:(i + 1) << 20] for i in range(min(48, len(data) >> 20))]
-    zbig = [zlib.compress(b, 6) for b in big[:16]]
+    # ... and at 16 MiB, beyond what one merge takes from a caller: compress calls go through the merges in slices, the one-stream
+    # workspaces of the inflate side stay while other callers work (round 5's last session; before: 10-14 and 7 GiB/s)
+    for size, ncalls, nz in ((1 << 20, 48, 16), (16 << 20, 12, 4)):
+        big = [data[i * size:(i + 1) * size] for i in range(min(ncalls, len(data) // size))]
+        if len(big) < 2:
+            continue
+        zbig = [zlib.compress(b, 6) for b in big[:nz]]
 
-    # (every thread's first call -- which makes the thread's buffer set and streams -- before the clock, as the reference's harness has it,
-    # samples/compdecomp_th.c:161-185; what those first calls take is reported beside the rate: first_calls_ms)
-    def worker_big(res, k, inflate, gate, t_first):
-        tot = 0
-        if inflate:
-            d = C.create_string_buffer(1 << 20)
-            n = C.c_ulong(1 << 20)
-            t = time.perf_counter()
-            ok = L.nx_uncompress(d, C.byref(n), zbig[k % len(zbig)], len(zbig[k % len(zbig)])) == 0
-            t_first[k] = time.perf_counter() - t
-            gate.wait()
-            for i in range(len(big)):
-                z = zbig[(i + k) % len(zbig)]
-                n = C.c_ulong(1 << 20)
-                if not ok or L.nx_uncompress(d, C.byref(n), z, len(z)) != 0 or n.value != (1 << 20):
-                    tot = -1
-                    break
-                tot += n.value
-        else:
-            c = C.c_ulong()
-            d = C.create_string_buffer(L.nx_compressBound(1 << 20))
-            c.value = len(d)
-            t = time.perf_counter()
-            ok = L.nx_compress2(d, C.byref(c), big[k % len(big)], 1 << 20, 1) == 0
-            t_first[k] = time.perf_counter() - t
-            gate.wait()
-            for i in range(len(big)):
-                b = big[(i + k) % len(big)]
+        # (every thread's first call -- which makes the thread's buffer set and streams -- before the clock, as the reference's harness has it,
+        # samples/compdecomp_th.c:161-185; what those first calls take is reported beside the rate: first_calls_ms)
+        def worker_big(res, k, inflate, gate, t_first, size=size, big=big, zbig=zbig):
+            tot = 0
+            if inflate:
+                d = C.create_string_buffer(size)
+                n = C.c_ulong(size)
+                t = time.perf_counter()
+                ok = L.nx_uncompress(d, C.byref(n), zbig[k % len(zbig)], len(zbig[k % len(zbig)])) == 0
+                t_first[k] = time.perf_counter() - t
+                gate.wait()
+                for i in range(len(big)):
+                    z = zbig[(i + k) % len(zbig)]
+                    n = C.c_ulong(size)
+                    if not ok or L.nx_uncompress(d, C.byref(n), z, len(z)) != 0 or n.value != size:
+                        tot = -1
+                        break
+                    tot += n.value
+            else:
+                c = C.c_ulong()
+                d = C.create_string_buffer(L.nx_compressBound(size))
                 c.value = len(d)
-                if not ok or L.nx_compress2(d, C.byref(c), b, len(b), 1) != 0:
-                    tot = -1
-                    break
-                tot += len(b)
-        res[k] = tot
+                t = time.perf_counter()
+                ok = L.nx_compress2(d, C.byref(c), big[k % len(big)], size, 1) == 0
+                t_first[k] = time.perf_counter() - t
+                gate.wait()
+                for i in range(len(big)):
+                    b = big[(i + k) % len(big)]
+                    c.value = len(d)
+                    if not ok or L.nx_compress2(d, C.byref(c), b, len(b), 1) != 0:
+                        tot = -1
+                        break
+                    tot += len(b)
+            res[k] = tot
 
-    for inflate in (False, True):
-        res = [0] * nthreads
-        t_first = [0.0] * nthreads
-        clock = [0.0]
-        gate = threading.Barrier(nthreads, action=lambda: clock.__setitem__(0, time.perf_counter()))
-        th = [threading.Thread(target=worker_big, args=(res, k, inflate, gate, t_first)) for k in range(nthreads)]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        dt = time.perf_counter() - clock[0]
-        if min(res) < 0:
-            return dict(out, error="a 1 MiB call failed in a thread")
-        out["threads_%d_x_1MiB_%s" % (nthreads, "uncompress" if inflate else "compress2")] = {
-            "value": round(sum(res) / dt / 2.0 ** 30, 3), "unit": "GiB/s uncompressed, all threads", "us_per_call": round(dt / len(big) * 1e6, 1),
-            "calls_per_thread": len(big), "first_calls_ms": round(max(t_first) * 1e3, 1)}
+        for inflate in (False, True):
+            res = [0] * nthreads
+            t_first = [0.0] * nthreads
+            clock = [0.0]
+            gate = threading.Barrier(nthreads, action=lambda: clock.__setitem__(0, time.perf_counter()))
+            th = [threading.Thread(target=worker_big, args=(res, k, inflate, gate, t_first)) for k in range(nthreads)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            dt = time.perf_counter() - clock[0]
+            if min(res) < 0:
+                return dict(out, error="a %d MiB call failed in a thread" % (size >> 20))
+            out["threads_%d_x_%dMiB_%s" % (nthreads, size >> 20, "uncompress" if inflate else "compress2")] = {
+                "value": round(sum(res) / dt / 2.0 ** 30, 3), "unit": "GiB/s uncompressed, all threads", "us_per_call": round(dt / len(big) * 1e6, 1),
+                "calls_per_thread": len(big), "first_calls_ms": round(max(t_first) * 1e3, 1)}
     if not args.no_cpu_baseline:
         t = time.perf_counter()
         zlib.compress(data[:32 << 20], 1)
