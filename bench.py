@@ -736,6 +736,14 @@ def api_leg(raw, args, mib=256, nthreads=16, raw_r04=None):
             out["threads_%d_x_%dMiB_%s" % (nthreads, size >> 20, "uncompress" if inflate else "compress2")] = {
                 "value": round(sum(res) / dt / 2.0 ** 30, 3), "unit": "GiB/s uncompressed, all threads", "us_per_call": round(dt / len(big) * 1e6, 1),
                 "calls_per_thread": len(big), "first_calls_ms": round(max(t_first) * 1e3, 1)}
+    # what these calls left idle on the device (the one-stream workspaces of sixteen callers, the hosts' lanes) goes back before the legs
+    # that size themselves by the device's free memory (c2 at its stated 2^20 blocks wants 212 GiB free)
+    try:
+        E = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "power-gzip_amd", "libnxz_engine.so"))
+        E.nxz_trim.restype = C.c_size_t
+        out["trimmed_MiB"] = int(E.nxz_trim()) >> 20
+    except (OSError, AttributeError):
+        pass
     if not args.no_cpu_baseline:
         t = time.perf_counter()
         zlib.compress(data[:32 << 20], 1)
