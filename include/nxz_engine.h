@@ -393,6 +393,14 @@ int  nxz_ctx_stage_ms(nxz_ctx_t *ctx, double ms[3], unsigned *launches);
 /* Measurement aid: of the last nxz_batch_decompress of n streams on `stream` that went a stream per lane, how many
  * streams the fixed-code-only kernel handed back to the general one (waits for the stream; -ENOENT: no such batch). */
 int  nxz_ctx_lanes_handed_back(nxz_ctx_t *ctx, void *stream, size_t n, uint32_t *count);
+/* Measurement aid: of the last nxz_batch_decompress on `stream` that went a stream per workgroup (nxz_inflate_wg.hip), how many
+ * streams that kernel handed back to the stream-per-wavefront kernel (out16[15]) and why (out16[1..10]: the job's fields, a block
+ * header, a stored block, a dynamic table, its sub-tables, too many rounds, no end-of-block, a bad token, no room, a bad distance);
+ * waits for the stream; -ENOENT: no such batch. */
+int  nxz_ctx_wg_reasons(nxz_ctx_t *ctx, void *stream, uint32_t *out16);
+/* ... and, for a batch run with NXZ_WG_PROF=1, the cycles of one lane by phase and the counts (12 words: load, block headers, tables, first
+ * pass, later rounds, writing pass, matches, out; rounds, streams, coded blocks, pieces) */
+int  nxz_ctx_wg_prof(nxz_ctx_t *ctx, void *stream, unsigned long long *out12);
 
 /* Block until everything queued on `stream` by this context has finished. */
 int nxz_ctx_sync(nxz_ctx_t *ctx, void *stream);

@@ -92,6 +92,12 @@ int nxz_launch_pack_members(const nxz_batch_job_t *jobs, const nxz_batch_result_
 			    uint64_t *offsets, uint8_t *packed, hipStream_t stream);
 int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results,
 			     nxz_batch_dht_t *dht_io, uint8_t *workspace, int init_fixed, hipStream_t stream);
+/* nxz_inflate_wg.hip: a stream per workgroup, source, output and tables in LDS; what it cannot do goes a stream per wavefront behind it */
+size_t nxz_inflate_wg_workspace(size_t n);
+int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io,
+			  uint8_t *wg_ws, const uint32_t *order, hipStream_t stream);
+int nxz_inflate_wg_reasons(const uint8_t *wg_ws, uint32_t *out16);
+int nxz_inflate_wg_prof(const uint8_t *wg_ws, unsigned long long *out12);
 }
 #endif
 #endif

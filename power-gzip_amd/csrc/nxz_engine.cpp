@@ -82,6 +82,8 @@ struct nxz_ctx {
 		size_t order_cap = 0;
 		uint8_t *d_cut_ws = nullptr;              // small inflate batches cut into pieces (nxz_inflate_cut.hip): control arrays + the pieces' elements
 		size_t cut_cap = 0;
+		uint8_t *d_wg_ws = nullptr;               // a stream per workgroup (nxz_inflate_wg.hip): job counter, reasons, hand-back list
+		size_t wg_cap = 0;
 		// compress: what the LZ77 kernel hands to the entropy kernel, for one chunk of jobs
 		uint8_t *d_tokens = nullptr;              // chunk x NXZ_TOK_STRIDE
 		nxz_dht_prepared_t *d_gen = nullptr;      // tables the device generated, one per job of the chunk
@@ -113,6 +115,7 @@ struct nxz_ctx {
 			if (d_lanes_ws) (void)hipFree(d_lanes_ws);
 			if (d_order_ws) (void)hipFree(d_order_ws);
 			if (d_cut_ws) (void)hipFree(d_cut_ws);
+			if (d_wg_ws) (void)hipFree(d_wg_ws);
 			if (d_tokens) (void)hipFree(d_tokens);                       // (d_gen and d_counts lie inside it)
 			if (d_cand2) (void)hipFree(d_cand2);
 			if (d_fuse) (void)hipFree(d_fuse);
@@ -607,6 +610,41 @@ static int batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n,
 	const size_t lanes_min = lm ? (size_t)strtoull(lm, nullptr, 0) : (size_t)NXZ_LANES_MIN;
 	bool lanes = force ? (force & 3) == 1 : n >= lanes_min, by_len = (force & 4) != 0, no_tables = false;
 	bool split = false;
+	// A stream per WORKGROUP, source, output and tables in LDS (nxz_inflate_wg.hip): every batch, unless one of the older routes'
+	// knobs is set (the tests' way to name a route) or NXZ_INFLATE_WG=0.  What that kernel does not do -- streams that resume, bring a
+	// history, are longer than 64 KiB on either side, end early or are damaged -- it hands back, and those go a stream per wavefront.
+	const char *wge = getenv("NXZ_INFLATE_WG");                         // (read at every call: the tests switch it)
+	if (!force && (wge ? atoi(wge) != 0 : (!lm && !getenv("NXZ_INFLATE_CUT")))) {
+		std::mutex *use_mtx;
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			use_mtx = &c->scratch_use[s];
+		}
+		std::lock_guard<std::mutex> use(*use_mtx);                     // (one call at a time per stream's scratch)
+		uint8_t *wws = nullptr, *ows = nullptr;
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			nxz_ctx::Scratch &sc = c->scratch[s];
+			const size_t need = nxz_inflate_wg_workspace(n), oneed = n >= 128 ? nxz_order_workspace(n) : 0;
+			if (sc.wg_cap < need) {
+				if (sc.d_wg_ws) { (void)hipStreamSynchronize(s); (void)hipFree(sc.d_wg_ws); }
+				sc.d_wg_ws = nullptr; sc.wg_cap = 0;
+				HIPCHK(hipMalloc((void **)&sc.d_wg_ws, need), return -ENOMEM);
+				sc.wg_cap = need;
+			}
+			if (sc.order_cap < oneed) {
+				if (sc.d_order_ws) { (void)hipStreamSynchronize(s); (void)hipFree(sc.d_order_ws); }
+				sc.d_order_ws = nullptr; sc.order_cap = 0;
+				if (hipMalloc((void **)&sc.d_order_ws, oneed) == hipSuccess) sc.order_cap = oneed; else (void)hipGetLastError();
+			}
+			wws = sc.d_wg_ws;
+			ows = oneed && sc.order_cap >= oneed ? sc.d_order_ws : nullptr;
+		}
+		const uint32_t *order = ows ? nxz_launch_order_by_length(jobs, n, ows, s) : nullptr;   // (a workgroup draws stream after stream: the long ones first)
+		rc = nxz_launch_inflate_wg(jobs, n, results, dht_io, wws, order, s);
+		if (rc) { set_err("inflate launch", (hipError_t)rc); return -EIO; }
+		return 0;
+	}
 	if (lanes && !lm && !force) {
 		// what kind of streams?  (one small launch and a wait for it: nothing next to the tens of milliseconds such a batch takes)
 		uint32_t *h = nullptr;
@@ -781,6 +819,39 @@ extern "C" int nxz_ctx_lanes_handed_back(nxz_ctx_t *c, void *stream, size_t n, u
 	}
 	if (!ws) return -ENOENT;
 	return nxz_inflate_lanes_handed_back(ws, n, count) ? -EIO : 0;
+}
+
+// (diagnostic / tests: why the workgroup-per-stream kernel handed streams of the last batch on `stream` back: out16[1..14] by reason
+// (nxz_inflate_wg.hip R_*), out16[15] the streams handed back; waits for the stream)
+extern "C" int nxz_ctx_wg_reasons(nxz_ctx_t *c, void *stream, uint32_t *out16)
+{
+	if (!c || !out16) return -EINVAL;
+	(void)hipSetDevice(c->device);
+	hipStream_t s = (hipStream_t)stream;
+	if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+	const uint8_t *ws = nullptr;
+	{
+		std::lock_guard<std::mutex> g(c->mtx);
+		auto it = c->scratch.find(s);
+		if (it != c->scratch.end()) ws = it->second.d_wg_ws;
+	}
+	if (!ws) return -ENOENT;
+	return nxz_inflate_wg_reasons(ws, out16) ? -EIO : 0;
+}
+extern "C" int nxz_ctx_wg_prof(nxz_ctx_t *c, void *stream, unsigned long long *out12)
+{
+	if (!c || !out12) return -EINVAL;
+	(void)hipSetDevice(c->device);
+	hipStream_t s = (hipStream_t)stream;
+	if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+	const uint8_t *ws = nullptr;
+	{
+		std::lock_guard<std::mutex> g(c->mtx);
+		auto it = c->scratch.find(s);
+		if (it != c->scratch.end()) ws = it->second.d_wg_ws;
+	}
+	if (!ws) return -ENOENT;
+	return nxz_inflate_wg_prof(ws, out12) ? -EIO : 0;
 }
 
 extern "C" int nxz_batch_wrap(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n,

@@ -84,6 +84,8 @@ def load_library():
         L.nxz_deflate_host.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
                                        C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.nxz_ctx_sync.argtypes = [C.c_void_p, C.c_void_p]
+        L.nxz_ctx_wg_reasons.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nxz_ctx_wg_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.nx_function_begin.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.nx_function_end.argtypes = [C.c_void_p]
         L.nxu_run_job.argtypes = [C.c_void_p, C.c_void_p]
@@ -176,6 +178,28 @@ class Engine:
                                          dht_io.data_ptr() if dht_io is not None else None, self.stream_handle())
         self._check(rc, "nxz_batch_decompress")
         return results
+
+    def wg_reasons(self):
+        """of the last decompress batch that went a stream per workgroup: {"handed_back": n, reason: count}"""
+        out = (C.c_uint32 * 16)()
+        rc = self.L.nxz_ctx_wg_reasons(self.ctx, self.stream_handle(), out)
+        if rc:
+            return None
+        names = ["", "job", "header", "stored", "dht", "tables", "rounds", "no_eob", "token", "space", "dist"]
+        d = {names[i]: out[i] for i in range(1, 11) if out[i]}
+        d["handed_back"] = out[15]
+        return d
+
+    def wg_prof(self):
+        """NXZ_WG_PROF=1: one lane's cycles by phase, per stream, of the last batch that went a stream per workgroup"""
+        out = (C.c_uint64 * 12)()
+        if self.L.nxz_ctx_wg_prof(self.ctx, self.stream_handle(), out):
+            return None
+        names = ["load", "header", "tables", "first", "rounds", "write", "match", "out"]
+        ns = max(1, out[9])
+        d = {names[i]: out[i] / ns for i in range(8)}
+        d.update(rounds=out[8] / max(1, out[10]), streams=out[9], blocks=out[10] / ns, pieces=out[11] / max(1, out[10]))
+        return d
 
     def inflate_stream(self, src, src_len, dst, first_bit=0, hist=None):
         """one long raw-deflate stream (uint8 device tensor) -> dst (uint8 device tensor), in parallel by

@@ -32,9 +32,10 @@ def eng():
     os.environ.pop("NXZ_INFLATE_LANES_MIN", None)
 
 
-@pytest.fixture(params=["lanes", "lanes-fixed", "waves", "waves-global-window", "waves-by-length", "cut", "cut-3"])
+@pytest.fixture(params=["wg", "wg-128", "lanes", "lanes-fixed", "waves", "waves-global-window", "waves-by-length", "cut", "cut-3"])
 def inflate_kernel(request):
-    """the inflate kernels: a stream per lane; the same with the fixed-code-only kernel in front (which
+    """the inflate kernels: a stream per workgroup with everything in LDS (what every batch gets; what that kernel does not
+    do it hands to the stream-per-wavefront kernel), the same with pieces of 128 bits; a stream per lane; the same with the fixed-code-only kernel in front (which
     hands a batch with a dynamic block in it back to the first); a stream per wave with its window in
     LDS, with the target buffer as its window (what mid-size batches get), and that with the jobs taken
     in the order of their lengths (what batches of more than one round of wavefronts get); every stream
@@ -43,6 +44,9 @@ def inflate_kernel(request):
     os.environ["NXZ_INFLATE_LANES_MIN"] = "32" if request.param.startswith("lanes") else "1000000000"
     os.environ["NXZ_LANES_FIXED"] = "2" if request.param == "lanes-fixed" else "0"
     os.environ["NXZ_INFLATE_CUT"] = "1" if request.param.startswith("cut") else "0"
+    os.environ["NXZ_INFLATE_WG"] = "1" if request.param.startswith("wg") else "0"
+    if request.param == "wg-128":
+        os.environ["NXZ_WG_PMIN"] = "128"
     if request.param == "cut-3":
         os.environ["NXZ_INFLATE_CUT_PIECES"] = "3"
     if request.param in ("waves-global-window", "waves-by-length"):
@@ -51,6 +55,8 @@ def inflate_kernel(request):
         os.environ["NXZ_INFLATE_ORDER"] = "1"
     yield request.param
     os.environ.pop("NXZ_INFLATE_ORDER", None)
+    os.environ.pop("NXZ_INFLATE_WG", None)
+    os.environ.pop("NXZ_WG_PMIN", None)
     os.environ.pop("NXZ_INFLATE_CUT", None)
     os.environ.pop("NXZ_INFLATE_CUT_PIECES", None)
     os.environ["NXZ_INFLATE_LANES_MIN"] = old if old is not None else "32"

@@ -30,15 +30,17 @@ def timed(eng, jobs, n):
     return e0.elapsed_time(e1) / 2
 
 
-print("%-34s %8s | %12s %12s %12s" % ("streams", "n", "per wave", "cut", "per lane"))
+KERNELS = [k for k in os.environ.get("KERNELS", "wg,waves,cut,lanes").split(",") if k]    # KERNELS=wg: the workgroup-per-stream kernel only
+print("%-34s %8s | %s" % ("streams", "n", " ".join("%12s" % {"wg": "per workgroup", "waves": "per wave", "cut": "cut", "lanes": "per lane"}[k] for k in KERNELS)))
 for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "own fixed-Huffman (corpus)", "own exact tables (corpus)"):
     for n in sizes:
         row = []
-        for kernel in (("waves", "cut") if os.environ.get("LANES") == "0" else ("waves", "cut", "lanes")):     # LANES=0: not the lane kernel
+        for kernel in KERNELS:
             if kernel == "cut" and n > 24576:
                 row.append(float("nan"))
                 continue
             os.environ["NXZ_INFLATE_LANES_MIN"] = "1" if kernel == "lanes" else "1000000000"
+            os.environ["NXZ_INFLATE_WG"] = "1" if kernel == "wg" else "0"
             os.environ["NXZ_INFLATE_CUT"] = "1" if kernel == "cut" else "0"                 # every stream cut inside its first block (nxz_inflate_cut.hip)
             os.environ["NXZ_LANES_FIXED"] = "2" if kind.startswith("own fixed") else "0"   # (the fixed-code-only kernel in front, as the engine's sampling would choose)
             os.environ["NXZ_INFLATE_LDS_MAX"] = os.environ.get("LDS_MAX", "0")          # (LDS_MAX=1024: small batches as the engine runs them, the window in LDS)
@@ -57,6 +59,7 @@ for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "o
                 clen = np.tile(np.array([len(s) for s in streams], np.uint32), rep)[:n]
                 dst = torch.zeros((n, B), dtype=torch.uint8, device=eng.dev)
                 jobs = eng.jobs_strided(src, cs, clen, dst, B, B)
+                data = None
             else:
                 if "synthetic" in kind:
                     data = bench.gen_blocks(torch, eng.dev, n, 0)
@@ -72,7 +75,21 @@ for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "o
                 jobs = eng.jobs_strided(comp, S, r["tpbc"].astype(np.uint32), dst, B, B)
             ms = timed(eng, jobs, n)
             row.append(n * B / ms / 1e-3 / 2 ** 30)
+            if kernel == "wg":
+                # the bytes, not just the completion codes: against the blocks themselves
+                if data is not None:
+                    assert torch.equal(dst, data), "workgroup kernel: output differs"
+                else:
+                    got = dst[:len(raw)].cpu().numpy()
+                    for i, b in enumerate(raw[:n]):
+                        assert got[i].tobytes() == b, "workgroup kernel: stream %d differs" % i
+                why = eng.wg_reasons()
+                if why and why.get("handed_back"):
+                    print("    (handed back: %s)" % why, flush=True)
+                if os.environ.get("NXZ_WG_PROF"):
+                    pr = eng.wg_prof()
+                    print("    (cycles a stream: %s)" % ", ".join("%s %.0f" % (k, v) if v >= 100 else "%s %.2f" % (k, v) for k, v in pr.items()), flush=True)
             eng.close()
             del jobs, dst
             torch.cuda.empty_cache()
-        print("%-34s %8d | %12.1f %12.1f %12.1f" % (kind, n, row[0], row[1], row[2] if len(row) > 2 else float("nan")), flush=True)
+        print("%-34s %8d | %s" % (kind, n, " ".join("%12.1f" % v for v in row)), flush=True)
