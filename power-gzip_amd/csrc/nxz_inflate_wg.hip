@@ -33,7 +33,7 @@
 #include <stdlib.h>
 #include <stdint.h>
 #include "nxz_device.h"
-#define NXZ_SPIN_HINT() __builtin_amdgcn_s_sleep(1)
+#define NXZ_SPIN_HINT() do { } while (0)
 #define NXZ_WG_GLOBAL NXZ_GLOBAL_AS
 #else
 #include <stdint.h>
@@ -51,7 +51,7 @@ constexpr uint32_t OUT_MAX = 65536;
 constexpr uint32_t SRC_MAX = 65600;                   // bytes of source in LDS (incl. up to 15 bytes in front: the load is 16-byte aligned)
 constexpr uint32_t SRC_WORDS = SRC_MAX / 4 + 8;
 constexpr int RL = 10, RD = 9;                        // root bits of the literal/length and distance tables
-constexpr uint32_t LSUB = 384, DSUB = 256;            // sub-table entries (zlib's ENOUGH for 286 symbols, root 10: 1332 - 1024)
+constexpr uint32_t LSUB = 352, DSUB = 256;            // sub-table entries (zlib's ENOUGH for 286 symbols, root 10: 1332 - 1024)
 constexpr uint32_t NSUBMAX = (1u << RL) + (1u << RD);
 
 // table entry: bits 0..4 code bits (root entries: of the whole code; a link: unused), 5..7 kind, 8..11 extra bits (a link: the
@@ -65,10 +65,14 @@ __device__ __forceinline__ uint32_t e_xb(uint32_t e) { return (e >> 8) & 15; }
 enum { F_OK = 0, F_EOB = 1, F_ERR = 2, F_RUNOUT = 3 };
 // why a stream was handed back (dbg[reason]++)
 enum { R_JOB = 1, R_HEADER = 2, R_STORED = 3, R_DHT = 4, R_TABLES = 5, R_ROUNDS = 6, R_NOEOB = 7, R_TOKEN = 8, R_SPACE = 9, R_DIST = 10 };
+// PROF (NXZ_WG_PROF=1, measurements): thread 0's clock at the ends of the phases, summed over the launch's streams in prof[]:
+// load, block headers, dynamic headers read, tables, the first pass, the later rounds, prefix sum + the writing pass, the list of
+// matches, the matches, out; then counts: rounds, streams, coded blocks, pieces
+enum { P_LOAD, P_HEADER, P_DHT, P_TABLES, P_FIRST, P_ROUNDS, P_WRITE, P_LIST, P_MATCH, P_OUT, P_NROUNDS, P_STREAMS, P_BLOCKS, P_PIECES, P_N };
 
 struct __attribute__((aligned(16))) Lds {
 	uint32_t out[OUT_MAX / 4];
-	uint32_t src[SRC_WORDS];
+	uint32_t src[SRC_WORDS];            // the stream; when all blocks are decoded: the positions of the matches, 16 bits each
 	uint32_t mstart[OUT_MAX / 32];      // bit p: a match starts at output byte p (its record stands there)
 	uint32_t unres[OUT_MAX / 32];       // bit p: output byte p is part of a match that is not copied yet
 	uint32_t lit[(1 << RL) + LSUB];
@@ -79,10 +83,18 @@ struct __attribute__((aligned(16))) Lds {
 	uint8_t lens[320];
 	uint32_t wsum[NW];
 	// wave-uniform scalars, written by one thread in front of a barrier
-	uint32_t jid, bail, pos, outn, bfinal, btype, st_len, hlit, hdist, firstbad, total;
+	uint32_t jid, bail, pos, outn, bfinal, btype, st_len, hlit, hdist, firstbad;
+	uint32_t prof[P_N], tprev[2];
 };
 static_assert(NT == (1 << RL) && NT >= (1 << RD), "a lane per root entry");
 static_assert(sizeof(Lds) <= 163840, "the workgroup's LDS image must fit the CU's 160 KiB");
+static_assert(OUT_MAX / 3 * 2 <= SRC_WORDS * 4, "the list of matches must fit the room of the source");
+
+// The workgroup's LDS image: at namespace scope, so that the phases below can be functions of their own (each with its own
+// register allocation: as one inlined body the kernel spilled in its loops) and still address LDS directly.
+__shared__ Lds L;
+
+#define NXZ_WG_PHASE __device__ __attribute__((noinline))
 
 __device__ __forceinline__ void len_params(uint32_t s, uint32_t &base, uint32_t &extra)
 {
@@ -96,7 +108,7 @@ __device__ __forceinline__ void dist_params(uint32_t d, uint32_t &base, uint32_t
 }
 
 // 32 bits of the source at bit p (LDS; the array is zero behind the stream)
-__device__ __forceinline__ uint32_t peek32(const Lds &L, uint32_t p)
+__device__ __forceinline__ uint32_t peek32(uint32_t p)
 {
 	const uint32_t w = p >> 5;
 	return __builtin_amdgcn_alignbit(L.src[w + 1], L.src[w], p & 31);
@@ -158,7 +170,7 @@ __device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t len)
 }
 
 // exclusive prefix sum over the workgroup (all threads call it); *total = the sum
-__device__ __forceinline__ uint32_t block_scan(Lds &L, uint32_t v, uint32_t *total)
+__device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *total)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	uint32_t inc = v;
@@ -177,42 +189,57 @@ __device__ __forceinline__ uint32_t block_scan(Lds &L, uint32_t v, uint32_t *tot
 	return base + inc - v;
 }
 
-// ---- one piece: tokens that start in [st, lim).  WRITE: literals to their place, matches parked as records. ----
+// ---- one token: what stands at bit p.  Straight-line but for the two rare sub-table look-ups and the distance look-up
+// (lanes that hold a literal skip it): as a switch over the kind the compiler made 45 scalar instructions of mask
+// bookkeeping per token out of it.  (Measured and not kept: the stream's bits through a 64-bit window in registers that is
+// filled again only when the next look-up can run dry, a third of the LDS reads -- 19 % slower: these passes wait for the
+// chain of dependent look-ups, and the window's 64-bit shifts are in that chain.) ----
+struct Tok { uint32_t kind, next, val, dist; };          // K_LIT: val = the byte; K_LEN: val = length, dist; K_EOB; else: no token (K_INVALID).  next: the bit behind it
+__device__ __forceinline__ Tok token_at(uint32_t p)
+{
+	Tok t;
+	const uint32_t w = p >> 5, sh = p & 31;
+	const uint32_t a = L.src[w], b = L.src[w + 1], c = L.src[w + 2];
+	const uint32_t lo = __builtin_amdgcn_alignbit(b, a, sh), hi = __builtin_amdgcn_alignbit(c, b, sh);
+	uint32_t e = L.lit[lo & ((1u << RL) - 1)];
+	if (e_kind(e) == K_LINK) e = L.lit[(e >> 16) + ((lo >> RL) & ((1u << e_xb(e)) - 1))];
+	const uint32_t nb = e & 31, x = e_xb(e), q = nb + x;                 // (x: 0 unless a length; q <= 20)
+	const bool islen = e_kind(e) == K_LEN;
+	uint32_t d = 0;
+	t.dist = 0;
+	if (islen) {
+		const uint32_t db = __builtin_amdgcn_alignbit(hi, lo, q);
+		d = L.dist[db & ((1u << RD) - 1)];
+		if (e_kind(d) == K_LINK) d = L.dist[(d >> 16) + ((db >> RD) & ((1u << e_xb(d)) - 1))];
+		const uint32_t dl = d & 31, dx = e_xb(d);
+		t.dist = (d >> 16) + ((db >> dl) & ((1u << dx) - 1));             // dl + dx <= 28
+		d = e_kind(d) == K_DIST ? dl + dx : 0xffffffffu;
+	}
+	t.kind = d == 0xffffffffu ? (uint32_t)K_INVALID : e_kind(e);
+	t.val = (e >> 16) + ((lo >> nb) & ((1u << x) - 1));
+	t.next = p + q + (islen ? d : 0);
+	return t;
+}
+
+// ---- one piece: the tokens that start in [st, lim).  Returns end bit | flag << 24 | the bytes they make << 32.
+// WRITE: literals to their place in the output (from obase on), matches parked as records. ----
 template <bool WRITE>
-__device__ __forceinline__ void decode_piece(Lds &L, uint32_t st, uint32_t lim, uint32_t T, uint32_t obase, uint32_t &en, uint32_t &no, uint32_t &fl)
+__device__ __forceinline__ unsigned long long decode_piece(uint32_t st, uint32_t lim, uint32_t T, uint32_t obase)
 {
 	uint8_t *ob = (uint8_t *)L.out;
-	uint32_t p = st, n = 0;
-	fl = F_OK;
+	uint32_t p = st, n = 0, fl = F_OK;
 	while (p < lim) {
-		const uint32_t w = p >> 5, sh = p & 31;
-		const uint32_t a = L.src[w], b = L.src[w + 1], c = L.src[w + 2];
-		const uint32_t lo = __builtin_amdgcn_alignbit(b, a, sh), hi = __builtin_amdgcn_alignbit(c, b, sh);
-		uint32_t e = L.lit[lo & ((1u << RL) - 1)];
-		if (e_kind(e) == K_LINK) e = L.lit[(e >> 16) + ((lo >> RL) & ((1u << e_xb(e)) - 1))];
-		const uint32_t nb = e & 31, k = e_kind(e);
-		if (k == K_LIT) {
-			if (WRITE) ob[obase + n] = (uint8_t)(e >> 16);
-			n++; p += nb;
-			continue;
-		}
-		if (k == K_LEN) {
-			const uint32_t x = e_xb(e);
-			const uint32_t len = (e >> 16) + ((lo >> nb) & ((1u << x) - 1));
-			const uint32_t q = nb + x;                                        // <= 20
-			const uint32_t db = __builtin_amdgcn_alignbit(hi, lo, q);
-			uint32_t d = L.dist[db & ((1u << RD) - 1)];
-			if (e_kind(d) == K_LINK) d = L.dist[(d >> 16) + ((db >> RD) & ((1u << e_xb(d)) - 1))];
-			if (e_kind(d) != K_DIST) { fl = F_ERR; break; }
-			const uint32_t dl = d & 31, dx = e_xb(d);
-			const uint32_t dist = (d >> 16) + ((db >> dl) & ((1u << dx) - 1));  // dl + dx <= 28
-			p += q + dl + dx;
-			if (WRITE) {
-				const uint32_t at = obase + n;
-				if (dist > at) { fl = F_ERR; break; }
-				ob[at] = (uint8_t)(len - 3); ob[at + 1] = (uint8_t)(dist - 1); ob[at + 2] = (uint8_t)((dist - 1) >> 8);
+		const Tok t = token_at(p);
+		const bool lit = t.kind == K_LIT, len = t.kind == K_LEN;
+		if (!(lit | len)) { if (t.kind == K_EOB) { p = t.next; fl = F_EOB; } else fl = F_ERR; break; }
+		if (WRITE) {
+			const uint32_t at = obase + n;
+			if (lit) ob[at] = (uint8_t)t.val;
+			else {
+				if (t.dist > at) { fl = F_ERR; break; }
+				ob[at] = (uint8_t)(t.val - 3); ob[at + 1] = (uint8_t)(t.dist - 1); ob[at + 2] = (uint8_t)((t.dist - 1) >> 8);
 				atomicOr(&L.mstart[at >> 5], 1u << (at & 31));
-				const uint32_t last = at + len - 1, wa = at >> 5, wb = last >> 5;
+				const uint32_t last = at + t.val - 1, wa = at >> 5, wb = last >> 5;
 				const uint32_t ma = ~0u << (at & 31), mb = ~0u >> (31 - (last & 31));
 				if (wa == wb) atomicOr(&L.unres[wa], ma & mb);
 				else {
@@ -221,79 +248,133 @@ __device__ __forceinline__ void decode_piece(Lds &L, uint32_t st, uint32_t lim, 
 					atomicOr(&L.unres[wb], mb);
 				}
 			}
-			n += len;
-			continue;
 		}
-		if (k == K_EOB) { p += nb; fl = F_EOB; break; }
-		fl = F_ERR;
-		break;
+		n += lit ? 1u : t.val;
+		p = t.next;
 	}
 	if (p > T) fl = F_RUNOUT;            // the last token reaches beyond the source
-	en = p; no = n;
+	return (unsigned long long)(p | fl << 24) | (unsigned long long)n << 32;
 }
+NXZ_WG_PHASE unsigned long long piece_count(uint32_t st, uint32_t lim, uint32_t T) { return decode_piece<false>(st, lim, T, 0); }
+NXZ_WG_PHASE unsigned long long piece_write(uint32_t st, uint32_t lim, uint32_t T, uint32_t obase) { return decode_piece<true>(st, lim, T, obase); }
 
 // is no byte of [a, e) part of a match that is still to be copied?  (a < e)
-__device__ __forceinline__ bool range_there(const Lds &L, uint32_t a, uint32_t e)
+__device__ __forceinline__ bool range_there(uint32_t a, uint32_t e)
 {
+	// (relaxed atomic loads of the LDS words themselves: through a `volatile` pointer they became flat_load ... sc0 sc1, some
+	// thousand cycles a poll)
 	const uint32_t last = e - 1, wa = a >> 5, wb = last >> 5;
 	const uint32_t ma = ~0u << (a & 31), mb = ~0u >> (31 - (last & 31));
-	const volatile uint32_t *u = L.unres;
-	if (wa == wb) return (u[wa] & ma & mb) == 0;
-	uint32_t acc = (u[wa] & ma) | (u[wb] & mb);
-	for (uint32_t i = wa + 1; i < wb; i++) acc |= u[i];
+	if (wa == wb) return (__atomic_load_n(&L.unres[wa], __ATOMIC_RELAXED) & ma & mb) == 0;
+	uint32_t acc = (__atomic_load_n(&L.unres[wa], __ATOMIC_RELAXED) & ma) | (__atomic_load_n(&L.unres[wb], __ATOMIC_RELAXED) & mb);
+	for (uint32_t i = wa + 1; i < wb; i++) acc |= __atomic_load_n(&L.unres[i], __ATOMIC_RELAXED);
 	return acc == 0;
 }
 
-// out[m, m + len) = out[m - dist, ...), bytes written in front serve as source (dist < len)
-__device__ __forceinline__ void copy_match(Lds &L, uint32_t m, uint32_t len, uint32_t dist)
+// ---- the matches, when all blocks are decoded.  First their positions in order (from the bitmap, into the room the source
+// no longer needs), then lane t takes matches t, t + 1024, ...: all lanes work their way through the output side by side, so
+// what a match copies from is nearly always done by the time its lane comes to it (a lane per stretch of the output, in order,
+// waited for its neighbour's last bytes before it could begin).  A match is copied CHUNK bytes at a time, each chunk as soon as
+// the bitmap shows its source bytes there; the lowest match not yet copied can always go. ----
+NXZ_WG_PHASE void resolve_matches(uint32_t nres, int prof)
 {
-	uint8_t *ob = (uint8_t *)L.out;
+	const int tid = threadIdx.x;
+	uint16_t *ml = (uint16_t *)L.src;
+	const uint32_t w0 = L.mstart[2 * tid], w1 = L.mstart[2 * tid + 1];
+	uint32_t M;
+	uint32_t at = block_scan((uint32_t)__popc(w0) + (uint32_t)__popc(w1), &M);
+	for (uint32_t bits = w0; bits; bits &= bits - 1) ml[at++] = (uint16_t)(64 * (uint32_t)tid + (uint32_t)__builtin_ctz(bits));
+	for (uint32_t bits = w1; bits; bits &= bits - 1) ml[at++] = (uint16_t)(64 * (uint32_t)tid + 32 + (uint32_t)__builtin_ctz(bits));
+	__syncthreads();
+	if (prof && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; L.prof[P_LIST] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); }
+	// (nres lanes, not all: a link of the longest chain of matches that copy from matches costs as long as the polling wavefronts
+	// take to come round, and with all 1024 lanes abreast most of what a match copies from is still in the making)
+	// A trip round this loop is what such a link costs, so it is kept short and the same for every lane: one look at the bitmap
+	// (two words, whatever the chunk), one chunk inside one 16-byte group of the output.  A source 20 bytes away or more lies in
+	// front of the group: five source dwords asked for at once, four values.  A source 4 to 19 bytes away overlaps the group: dword
+	// after dword, each from the two dwords that hold its source.  A source 1 to 3 bytes away is a period: the four dwords follow from
+	// the bytes in front of the chunk.  Whole dwords are stored, the group's partial dwords merged by two LDS atomics each (they
+	// may hold other lanes' bytes).  (The first form of this loop copied head and tail bytes in loops of their own, a wait a byte:
+	// some lane of a wavefront always has such a match, and a trip cost every lane 3000 cycles.)
 	uint32_t *ow = L.out;
-	uint32_t k = 0;
-	const uint32_t head = (4 - (m & 3)) & 3;
-	if (dist >= 4) {
-		for (; k < head && k < len; k++) ob[m + k] = ob[m + k - dist];
-		for (; k + 4 <= len; k += 4) {
-			const uint32_t s = m + k - dist, si = s >> 2;
-			const uint32_t lo = ow[si], hi = ow[si + 1];
-			ow[(m + k) >> 2] = __builtin_amdgcn_alignbyte(hi, lo, s & 3);
+	uint32_t k = (uint32_t)tid < nres ? (uint32_t)tid : M, q = 0, qe = 0, dist = 0;
+	bool have = false;
+	for (;;) {
+		if (!have) {
+			if (k >= M) break;
+			const uint32_t m = ml[k];
+			k += nres;
+			const uint32_t r = __builtin_amdgcn_alignbyte(ow[(m >> 2) + 1], ow[m >> 2], m & 3);     // the record: length - 3, distance - 1
+			dist = ((r >> 8) & 0xffff) + 1;
+			q = m; qe = m + (r & 0xff) + 3; have = true;
 		}
-		for (; k < len; k++) ob[m + k] = ob[m + k - dist];
-		return;
+		const uint32_t c1 = qe < (q | 15) + 1 ? qe : (q | 15) + 1;
+		const uint32_t sa = q - dist, sl = (c1 - dist < q ? c1 - dist : q) - 1;      // first and last byte the chunk needs from in front of itself
+		const uint32_t u0 = __atomic_load_n(&L.unres[sa >> 5], __ATOMIC_RELAXED), u1 = __atomic_load_n(&L.unres[sl >> 5], __ATOMIC_RELAXED);
+		const uint32_t ma = ~0u << (sa & 31), mb = ~0u >> (31 - (sl & 31));
+		const bool there = ((sa >> 5) == (sl >> 5) ? (u0 & ma & mb) : ((u0 & ma) | (u1 & mb))) == 0;
+		if (there) {
+			__threadfence_block();
+			const uint32_t g = q >> 4 << 2;                                           // the group's first dword
+			const uint32_t lo = q & 15, hi = ((c1 - 1) & 15) + 1;                     // the chunk: bytes [lo, hi) of the group
+			// dword j of the group: bytes [b0, b1) of it are the chunk's; `put` stores or merges
+			auto put = [&](uint32_t j, uint32_t val) __attribute__((always_inline)) {
+				const uint32_t b0 = lo > 4 * j ? lo - 4 * j : 0, b1 = hi < 4 * j + 4 ? (hi > 4 * j ? hi - 4 * j : 0) : 4;
+				if (b0 >= b1) return;
+				const uint32_t mask = (b1 == 4 ? ~0u : (1u << (8 * b1)) - 1) & ~((1u << (8 * b0)) - 1);
+				if (mask == ~0u) ow[g + j] = val;
+				else { atomicAnd(&ow[g + j], ~mask); atomicOr(&ow[g + j], val & mask); }
+			};
+			if (dist >= 20) {
+				const int32_t s0 = (int32_t)(g * 4) - (int32_t)dist;               // (below 0 only in bytes that are not the chunk's)
+				const int32_t si = s0 >> 2;
+				const uint32_t bo = (uint32_t)s0 & 3;
+				const uint32_t w0 = ow[si < 0 ? 0 : si], w1 = ow[si + 1 < 0 ? 0 : si + 1], w2 = ow[si + 2 < 0 ? 0 : si + 2], w3 = ow[si + 3 < 0 ? 0 : si + 3], w4 = ow[si + 4];
+				put(0, __builtin_amdgcn_alignbyte(w1, w0, bo)); put(1, __builtin_amdgcn_alignbyte(w2, w1, bo));
+				put(2, __builtin_amdgcn_alignbyte(w3, w2, bo)); put(3, __builtin_amdgcn_alignbyte(w4, w3, bo));
+			} else if (dist >= 4) {
+#pragma unroll
+				for (uint32_t j = 0; j < 4; j++) {
+					if (4 * j + 4 <= lo || 4 * j >= hi) continue;
+					const int32_t s = (int32_t)((g + j) * 4) - (int32_t)dist, si = s >> 2;
+					const uint32_t a = ow[si < 0 ? 0 : si], b = ow[si + 1];
+					put(j, __builtin_amdgcn_alignbyte(b, a, (uint32_t)s & 3));
+				}
+			} else {
+				// the four bytes in front of the chunk hold the period; byte x of the output is byte (x - (q - dist)) % dist of it
+				const uint32_t f = __builtin_amdgcn_alignbyte(ow[q >> 2], ow[q >= 4 ? (q >> 2) - 1 : 0], q & 3) >> (8 * (4 - dist));
+				const uint32_t p0 = f & 0xff, p1 = dist > 1 ? (f >> 8) & 0xff : p0, p2 = dist > 2 ? (f >> 16) & 0xff : p0;
+				uint64_t pat;
+				if (dist == 3) {
+					const uint64_t t = (uint64_t)p0 | (uint64_t)p1 << 8 | (uint64_t)p2 << 16;
+					pat = t | t << 24 | t << 48;
+				} else pat = ((uint64_t)p0 | (uint64_t)p1 << 8) * 0x0001000100010001ull;
+#pragma unroll
+				for (uint32_t j = 0; j < 4; j++) {
+					const uint32_t x = 4 * j + 24 + dist - lo;                        // (group byte 4j) - (q - dist), + 24 (a multiple of every period) to stay above 0
+					// x % dist for dist 1, 2, 3 and x < 64 without a division
+					const uint32_t r = dist == 1 ? 0 : dist == 2 ? x & 1 : x - 3 * ((x * 171) >> 9);
+					put(j, (uint32_t)(pat >> (8 * r)));
+				}
+			}
+			__threadfence_block();
+			atomicAnd(&L.unres[q >> 5], ~((~0u << (q & 31)) & (~0u >> (31 - ((c1 - 1) & 31)))));
+			q = c1;
+			if (q == qe) have = false;
+		} else NXZ_SPIN_HINT();
 	}
-	// period 1, 2 or 3: eight bytes of the pattern, read where byte k of the match is byte k % dist of the period
-	const uint32_t p0 = ob[m - dist], p1 = dist > 1 ? ob[m - dist + 1] : p0, p2 = dist > 2 ? ob[m - dist + 2] : dist == 2 ? p0 : p0;
-	uint64_t pat;
-	if (dist == 3) {
-		const uint64_t t = (uint64_t)p0 | (uint64_t)p1 << 8 | (uint64_t)p2 << 16;
-		pat = t | t << 24 | t << 48;
-	} else {
-		const uint64_t t = (uint64_t)p0 | (uint64_t)p1 << 8;
-		pat = t * 0x0001000100010001ull;
-	}
-	uint32_t r = 0;                                           // k % dist
-	for (; k < head && k < len; k++) { ob[m + k] = (uint8_t)(pat >> (8 * r)); r = r + 1 == dist ? 0 : r + 1; }
-	for (; k + 4 <= len; k += 4) {
-		ow[(m + k) >> 2] = (uint32_t)(pat >> (8 * r));
-		if (dist == 3) r = r == 2 ? 0 : r + 1;                  // (r + 4) % 3
-	}
-	for (; k < len; k++) { ob[m + k] = (uint8_t)(pat >> (8 * r)); r = r + 1 == dist ? 0 : r + 1; }
 }
 
 // ---- the header of a dynamic block, by wavefront 0 (the algorithm of nxzi::read_dht; the stream's bits come from LDS):
 // code lengths into L.lens, L.hlit / L.hdist, L.pos behind the header.  false: not a header this kernel takes on. ----
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ bool read_header(Lds &L, uint32_t start, uint32_t T, int lane)
+NXZ_WG_PHASE bool read_header(uint32_t start, uint32_t T, int lane)
 {
+	start = uni(start); T = uni(T);                                   // (read from LDS: the same in every lane, and now the compiler knows)
 	if (start + 14 > T) return false;
 	const uint32_t d0 = start >> 5;
 	auto word_at = [&](uint32_t idx) -> uint32_t { return idx < SRC_WORDS ? L.src[idx] : 0; };
-	const uint32_t R0 = word_at(d0 + lane), R1 = word_at(d0 + 64 + lane);
-	auto word = [&](uint32_t i) -> uint32_t {
-		const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)R0, (int)(i & 63)), hi = (uint32_t)__builtin_amdgcn_readlane((int)R1, (int)(i & 63));
-		return i < 64 ? lo : hi;
-	};
-	const uint32_t v = peek32(L, start);
+	const uint32_t v = uni(peek32(start));
 	const int hlit = (int)(v & 31) + 257, hdist = (int)((v >> 5) & 31) + 1, hclen = (int)((v >> 10) & 15) + 4;
 	uint32_t pos = start + 14;
 	if (hlit > 286 || hdist > 30) return false;
@@ -303,7 +384,7 @@ __device__ __forceinline__ bool read_header(Lds &L, uint32_t start, uint32_t T, 
 	{
 		const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
 		uint32_t mine = 0, mysym = 0;
-		if (lane < hclen) { mine = peek32(L, pos + 3 * (uint32_t)lane) & 7; mysym = order[lane]; }
+		if (lane < hclen) { mine = peek32(pos + 3 * (uint32_t)lane) & 7; mysym = order[lane]; }
 		for (int i = 0; i < 19; i++) {
 			const uint32_t sy = (uint32_t)__builtin_amdgcn_readlane((int)mysym, i), ln = (uint32_t)__builtin_amdgcn_readlane((int)mine, i);
 			if (i < hclen && (uint32_t)lane == sy) myl = ln;
@@ -331,62 +412,227 @@ __device__ __forceinline__ bool read_header(Lds &L, uint32_t start, uint32_t T, 
 			if ((((uint32_t)lane + 64) & mask) == rev) thi = (uint32_t)sy | (l << 5);
 		}
 	}
-	int n = 0, prev = 0;
+	// ---- the code lengths themselves: up to 316 symbols of 2 to 14 bits, one after the other -- as a loop of the whole wavefront
+	// over them (nxzi::read_dht) 650 cycles a symbol, 100 000 a header, with fifteen wavefronts waiting.  So the lanes walk the
+	// sequence side by side, 32 bits of it each, as the pieces of a block are walked below: lane 0 begins at the first symbol,
+	// the others where their chunk begins; in the next round every lane begins where its neighbour ended, until no start
+	// moves (a code of at most 7 bits falls in step within a chunk or two).  Then the counts' prefix sum says where every
+	// lane's lengths go, and a last walk writes them (runs of zeros are nothing to write: the array is cleared first). ----
 	const int total = hlit + hdist;
-	uint64_t win = 0;
-	uint32_t wbits = 0;
-	while (n < total) {
-		if (pos + 1 > T) return false;
-		if (wbits < 14) {
-			const uint32_t o = uni(pos - d0 * 32), i = o >> 5, sh = o & 31;
-			if (i + 1 >= 128) return false;                            // (a header is 2283 bits at most)
-			win = (((uint64_t)word(i + 1) << 32) | word(i)) >> sh;
-			wbits = 64 - sh;
+	uint8_t *cl7 = (uint8_t *)L.pend;                                   // the 7-bit look-up as bytes: symbol | length << 5, 0xff: no such code
+	cl7[lane] = (uint8_t)tlo; cl7[lane + 64] = (uint8_t)thi;
+	for (int i = lane; i < 320; i += 64) L.lens[i] = 0;
+	__threadfence_block();
+	(void)__ballot(1);                                                  // (the wavefront's lanes are in step here -- the CPU shim's are not by themselves)
+	int n0 = 0;
+	uint32_t inh = 16;                                                  // the length in front of this window (16: none yet)
+	for (;;) {
+		const uint32_t cs = pos + 32 * (uint32_t)lane, ce = cs + 32;
+		uint64_t W;
+		{
+			const uint32_t w = cs >> 5, sh = cs & 31;
+			const uint32_t a = word_at(w), b = word_at(w + 1), c = word_at(w + 2);
+			W = (uint64_t)__builtin_amdgcn_alignbit(b, a, sh) | (uint64_t)__builtin_amdgcn_alignbit(c, b, sh) << 32;
 		}
-		const uint32_t bits = (uint32_t)win;
-		const uint32_t k = bits & 127;
-		const uint32_t e = k < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)tlo, (int)k) : (uint32_t)__builtin_amdgcn_readlane((int)thi, (int)(k - 64));
-		if (e == 0xff) return false;
-		const int sym = (int)(e & 31), len = (int)(e >> 5);
-		if (pos + (uint32_t)len > T) return false;
-		pos += (uint32_t)len;
-		win >>= len; wbits -= (uint32_t)len;
-		if (sym < 16) { if (lane == 0) L.lens[n] = (uint8_t)sym; n++; prev = sym; }
-		else {
-			const int eb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
-			if (pos + (uint32_t)eb > T) return false;
-			const int rep = (int)((bits >> len) & ((1u << eb) - 1)) + (sym == 18 ? 11 : 3);
-			pos += (uint32_t)eb;
-			win >>= eb; wbits -= (uint32_t)eb;
-			int val = 0;
-			if (sym == 16) { if (n == 0) return false; val = prev; }
-			if (n + rep > total) return false;
-			for (int q = lane; q < rep; q += 64) L.lens[n + q] = (uint8_t)val;
-			n += rep;
-			if (sym != 16) prev = 0;
+		// one walk: the symbols that start in [s, ce); WRITE: their lengths to L.lens from n on, at most `room` of them
+		uint32_t st = cs, en = cs, cnt = 0, pv = 16;
+		bool bad = false;
+		auto walk = [&]() __attribute__((always_inline)) {
+			uint32_t s = st, c = 0, v = 16;
+			bool bd = false;
+			while (s < ce) {
+				const uint32_t o = s - cs;
+				const uint32_t e = cl7[(uint32_t)(W >> o) & 127];
+				if (e == 0xff) { bd = true; break; }
+				const uint32_t len = e >> 5, sym = e & 31;
+				const uint32_t eb = sym < 16 ? 0 : sym == 16 ? 2 : sym == 17 ? 3 : 7;
+				const uint32_t rep = sym < 16 ? 1 : ((uint32_t)(W >> (o + len)) & ((1u << eb) - 1)) + (sym == 18 ? 11 : 3);
+				if (sym < 16) v = sym; else if (sym != 16) v = 0;
+				c += rep; s += len + eb;
+			}
+			en = s; cnt = c; pv = v; bad = bd;
+		};
+		walk();
+		for (;;) {
+			const uint32_t pen = __shfl_up(en, 1, 64), pbad = __shfl_up((uint32_t)bad, 1, 64);
+			const bool redo = lane > 0 && !pbad && pen != st;
+			if (!__ballot(redo)) break;
+			if (redo) { st = pen; walk(); }
 		}
+		const uint64_t badm = __ballot(bad);
+		const uint32_t fb = badm ? (uint32_t)__builtin_ctzll(badm) : 64;
+		uint32_t pc = cnt;                                                // inclusive prefix sum of the counts
+		uint32_t lv = pv;                                                 // ... and the last length that is known, up to and including this lane
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t oc = __shfl_up(pc, (unsigned)d, 64), ov = __shfl_up(lv, (unsigned)d, 64);
+			if (lane >= d) { pc += oc; if (lv == 16) lv = ov; }
+		}
+		const uint64_t reachm = __ballot(n0 + (int)pc >= total);
+		const uint32_t lstar = reachm ? (uint32_t)__builtin_ctzll(reachm) : 64;      // the lane in which the last length lies
+		if (fb < 64 && fb <= lstar) return false;                           // a code that is none, in front of the end
+		const uint32_t lastl = lstar < 64 ? lstar : 63;
+		if (__ballot((uint32_t)lane <= lastl && en > T)) return false;      // the source ends inside the header
+		uint32_t inherited = __shfl_up(lv, 1, 64);
+		if (lane == 0 || inherited == 16) inherited = lane == 0 ? inh : (inherited == 16 ? inh : inherited);
+		// the writing walk
+		uint32_t endpos = 0;
+		bool wrong = false;
+		if ((uint32_t)lane <= lastl) {
+			uint32_t s = st, v = inherited;
+			int n = n0 + (int)(pc - cnt);
+			while (s < ce && n < total) {
+				const uint32_t o = s - cs;
+				const uint32_t e = cl7[(uint32_t)(W >> o) & 127];
+				const uint32_t len = e >> 5, sym = e & 31;
+				const uint32_t eb = sym < 16 ? 0 : sym == 16 ? 2 : sym == 17 ? 3 : 7;
+				const int rep = sym < 16 ? 1 : (int)(((uint32_t)(W >> (o + len)) & ((1u << eb) - 1)) + (sym == 18 ? 11 : 3));
+				if (n + rep > total) { wrong = true; break; }
+				if (sym < 16) { L.lens[n] = (uint8_t)sym; v = sym; }
+				else if (sym == 16) {
+					if (v == 16) { wrong = true; break; }                     // "repeat the last length" with no length in front of it
+					for (int q = 0; q < rep; q++) L.lens[n + q] = (uint8_t)v;
+				} else v = 0;
+				n += rep; s += len + eb;
+			}
+			endpos = s;
+		}
+		if (__ballot(wrong)) return false;
+		if (lstar < 64) { pos = (uint32_t)__builtin_amdgcn_readlane((int)endpos, (int)lstar); break; }
+		// the sequence goes on behind this window
+		n0 += (int)(uint32_t)__builtin_amdgcn_readlane((int)pc, 63);
+		pos = (uint32_t)__builtin_amdgcn_readlane((int)en, 63);
+		const uint32_t l63 = (uint32_t)__builtin_amdgcn_readlane((int)lv, 63);
+		if (l63 != 16) inh = l63;
+		if (pos > T) return false;
 	}
+	__threadfence_block();
+	(void)__ballot(1);
 	if (lane == 0) { L.hlit = (uint32_t)hlit; L.hdist = (uint32_t)hdist; L.pos = pos; }
 	return true;
 }
 
-// PROF (NXZ_WG_PROF=1, measurements): thread 0's clock at the ends of the phases, summed over the launch's streams in prof[]:
-// 0 load, 1 block headers, 2 tables, 3 the first pass, 4 the later rounds, 5 prefix sum + the writing pass, 6 matches, 7 out;
-// 8 rounds, 9 streams, 10 coded blocks, 11 pieces
-enum { P_LOAD, P_HEADER, P_TABLES, P_FIRST, P_ROUNDS, P_WRITE, P_MATCH, P_OUT, P_NROUNDS, P_STREAMS, P_BLOCKS, P_PIECES, P_N };
+// ---- the decode tables of a block from L.lens (all lanes; R_TABLES in L.bail: the sub-tables do not fit) ----
+NXZ_WG_PHASE void build_tables(int hlit, int hdist)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	uint32_t cl[5], ccode[5];                                 // wave 0: literal/length symbols, wave 1: distance symbols (row 0)
+	for (uint32_t i = tid; i < NSUBMAX; i += NT) L.pend[i] = 0;
+	for (uint32_t i = tid; i < LSUB; i += NT) L.lit[(1u << RL) + i] = 0;
+	for (uint32_t i = tid; i < DSUB; i += NT) L.dist[(1u << RD) + i] = 0;
+	if (wave == 0) canon<5>(L.lens, hlit, L.lcount, L.lsym, cl, ccode, lane);
+	else if (wave == 1) { uint32_t l1[1], c1[1]; canon<1>(L.lens + hlit, hdist, L.dcount, L.dsym, l1, c1, lane); cl[0] = l1[0]; ccode[0] = c1[0]; }
+	__syncthreads();
+	{
+		uint32_t sym, len;
+		L.lit[tid] = root_walk<RL>((uint32_t)tid, L.lcount, L.lsym, sym, len) ? lit_entry(sym, len) : 0;
+		if (tid < (1 << RD)) L.dist[tid] = root_walk<RD>((uint32_t)tid, L.dcount, L.dsym, sym, len) ? dist_entry(sym, len) : 0;
+	}
+	// codes longer than the root: how many index bits the sub-table behind their root index needs
+	if (wave == 0) {
+#pragma unroll
+		for (int r = 0; r < 5; r++) if (cl[r] > (uint32_t)RL) {
+			const uint32_t lsb = __builtin_bitreverse32(ccode[r]) >> (32 - cl[r]);
+			atomicMax(&L.pend[lsb & ((1u << RL) - 1)], cl[r] - RL);
+		}
+	} else if (wave == 1 && cl[0] > (uint32_t)RD) {
+		const uint32_t lsb = __builtin_bitreverse32(ccode[0]) >> (32 - cl[0]);
+		atomicMax(&L.pend[(1u << RL) + (lsb & ((1u << RD) - 1))], cl[0] - RD);
+	}
+	__syncthreads();
+	{
+		const uint32_t sl = L.pend[tid], sd = tid < (1 << RD) ? L.pend[(1u << RL) + tid] : 0;
+		uint32_t totl, totd;
+		const uint32_t ol = block_scan(sl ? 1u << sl : 0, &totl);
+		const uint32_t od = block_scan(sd ? 1u << sd : 0, &totd);
+		if (sl) L.lit[tid] = mk(0, K_LINK, sl, (1u << RL) + ol);
+		if (sd) L.dist[tid] = mk(0, K_LINK, sd, (1u << RD) + od);
+		if (tid == 0 && (totl > LSUB || totd > DSUB)) L.bail = R_TABLES;
+	}
+	__syncthreads();
+	if (L.bail) return;
+	if (wave == 0) {
+#pragma unroll
+		for (int r = 0; r < 5; r++) if (cl[r] > (uint32_t)RL) {
+			const uint32_t lsb = __builtin_bitreverse32(ccode[r]) >> (32 - cl[r]);
+			const uint32_t link = L.lit[lsb & ((1u << RL) - 1)], rem = cl[r] - RL;
+			const uint32_t ent = lit_entry((uint32_t)(r * 64 + lane), cl[r]);
+			for (uint32_t k = lsb >> RL; k < (1u << e_xb(link)); k += 1u << rem) L.lit[(link >> 16) + k] = ent;
+		}
+	} else if (wave == 1 && cl[0] > (uint32_t)RD) {
+		const uint32_t lsb = __builtin_bitreverse32(ccode[0]) >> (32 - cl[0]);
+		const uint32_t link = L.dist[lsb & ((1u << RD) - 1)], rem = cl[0] - RD;
+		const uint32_t ent = dist_entry((uint32_t)lane, cl[0]);
+		for (uint32_t k = lsb >> RD; k < (1u << e_xb(link)); k += 1u << rem) L.dist[(link >> 16) + k] = ent;
+	}
+	__syncthreads();
+}
+
+// ---- a Huffman-coded block whose tables stand: the pieces in rounds, the prefix sum, the writing pass.  Leaves L.outn and
+// L.pos behind the block, or a reason in L.bail. ----
+NXZ_WG_PHASE void decode_block(uint32_t T, uint32_t cap, uint32_t pmin_bits, int prof)
+{
+	const int tid = threadIdx.x;
+#define WGPROF(idx) do { if (prof && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; L.prof[idx] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); } } while (0)
+	const uint32_t cur = L.pos, R = T - cur;
+	uint32_t np0 = R / pmin_bits;
+	np0 = np0 < 1 ? 1 : np0 > (uint32_t)NT ? (uint32_t)NT : np0;
+	const uint32_t pdw = (((R + np0 - 1) / np0 + 31) >> 5) | 1;          // dwords a piece, odd: neighbours begin in different LDS banks
+	const uint32_t P = pdw * 32;
+	const uint32_t NP = (R + P - 1) / P ? (R + P - 1) / P : 1;
+	const bool active = (uint32_t)tid < NP;
+	const uint32_t g = cur + (uint32_t)tid * P;
+	const uint32_t lim = (uint32_t)tid + 1 == NP ? T : g + P;
+	uint32_t st = g, no = 0, pe = F_ERR << 24;
+	if (active) { const unsigned long long r = piece_count(st, lim, T); pe = (uint32_t)r; no = (uint32_t)(r >> 32); L.pend[tid] = pe; }
+	if (tid == 0) L.firstbad = NP;
+	WGPROF(P_FIRST);
+	if (prof && tid == 0) L.prof[P_PIECES] += NP;
+	uint32_t rounds = 0;
+	for (;;) {
+		__syncthreads();
+		bool redo = false;
+		if (active && tid > 0) {
+			const uint32_t prev = L.pend[tid - 1];
+			if ((prev >> 24) == F_OK && (prev & 0xffffff) != st) { st = prev & 0xffffff; redo = true; }
+		}
+		if (!__syncthreads_or(redo)) break;
+		if (++rounds > 200) { if (tid == 0) L.bail = R_ROUNDS; break; }
+		if (redo) { const unsigned long long r = piece_count(st, lim, T); pe = (uint32_t)r; no = (uint32_t)(r >> 32); L.pend[tid] = pe; }
+	}
+	__syncthreads();
+	WGPROF(P_ROUNDS);
+	if (prof && tid == 0) L.prof[P_NROUNDS] += rounds;
+	if (L.bail) return;
+	if (active && (pe >> 24) != F_OK) atomicMin(&L.firstbad, (uint32_t)tid);
+	__syncthreads();
+	const uint32_t B = L.firstbad;
+	if (B >= NP) { if (tid == 0) L.bail = R_NOEOB; __syncthreads(); return; }
+	const uint32_t fb = L.pend[B] >> 24;
+	uint32_t tot;
+	const uint32_t obase = block_scan((uint32_t)tid <= B ? no : 0, &tot);
+	const uint32_t outn = L.outn;
+	if (fb != F_EOB || tot > cap - outn) { if (tid == 0) L.bail = fb != F_EOB ? R_TOKEN : R_SPACE; __syncthreads(); return; }
+	if ((uint32_t)tid <= B) {
+		const unsigned long long r = piece_write(st, lim, T, outn + obase);
+		if ((uint32_t)r != pe || (uint32_t)(r >> 32) != no) L.bail = R_DIST;                 // (a distance beyond the output so far)
+	}
+	__syncthreads();
+	if (L.bail) return;
+	if (tid == 0) { L.outn = outn + tot; L.pos = L.pend[B] & 0xffffff; }
+	WGPROF(P_WRITE);
+	__syncthreads();
+}
+
 template <bool PROF>
 __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *__restrict__ jobs, uint32_t n, nxz_batch_result_t *__restrict__ results,
 							 const uint32_t *__restrict__ order, uint32_t *__restrict__ ctr, uint32_t *__restrict__ bail,
-							 uint32_t pmin_bits, uint32_t *__restrict__ dbg, unsigned long long *__restrict__ prof)
+							 uint32_t pmin_bits, uint32_t nres, uint32_t *__restrict__ dbg, unsigned long long *__restrict__ prof)
 {
-	__shared__ Lds L;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	uint8_t *ob = (uint8_t *)L.out;
 	const uint8_t *sb = (const uint8_t *)L.src;
-	unsigned long long pacc[P_N] = { 0 }, tprev = 0;
-#define WGPROF(idx) do { if (PROF && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(); pacc[idx] += now_ - tprev; tprev = now_; } } while (0)
-#define WGCOUNT(idx, v) do { if (PROF && tid == 0) pacc[idx] += (unsigned long long)(v); } while (0)
-	if (PROF && tid == 0) tprev = (unsigned long long)clock64();
+	if (PROF && tid == 0) { for (int i = 0; i < P_N; i++) L.prof[i] = 0; const unsigned long long now_ = (unsigned long long)clock64(); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); }
 
 	for (;;) {
 		// ---- next stream ----
@@ -436,8 +682,8 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 			for (uint32_t i = tid; i < OUT_MAX / 32 / 4; i += NT) { b0[i] = z; b1[i] = z; }
 			if (tid == 0) L.pos = off * 8;
 		}
-		WGPROF(P_LOAD);
-		WGCOUNT(P_STREAMS, 1);
+		__syncthreads();
+		if (PROF) { WGPROF(P_LOAD); if (tid == 0) L.prof[P_STREAMS]++; }
 
 		// ---- block after block ----
 		bool done = false;
@@ -447,14 +693,14 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 				uint32_t p = L.pos;
 				if (p + 3 > T) L.bail = R_HEADER;
 				else {
-					const uint32_t v = peek32(L, p);
+					const uint32_t v = peek32(p);
 					L.bfinal = v & 1; L.btype = (v >> 1) & 3;
 					p += 3;
 					if (L.btype == 0) {
 						p = (p + 7) & ~7u;
 						if (p + 32 > T) L.bail = R_STORED;
 						else {
-							const uint32_t w = peek32(L, p), len = w & 0xffff;
+							const uint32_t w = peek32(p), len = w & 0xffff;
 							p += 32;
 							if (((w >> 16) ^ len) != 0xffff || p + 8 * len > T || len > cap - L.outn) L.bail = R_STORED;
 							L.st_len = len;
@@ -471,13 +717,15 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 				for (uint32_t i = tid; i < len; i += NT) ob[to + i] = sb[from + i];
 				__syncthreads();
 				if (tid == 0) { L.pos += 8 * len; L.outn += len; }
+				if (PROF) WGPROF(P_HEADER);
 				if (bfinal) { done = true; break; }
 				continue;
 			}
+			if (PROF) WGPROF(P_HEADER);
 			// ---- code lengths ----
 			if (btype == 2) {
 				if (wave == 0) {
-					const bool ok = read_header(L, L.pos, T, lane);
+					const bool ok = read_header(L.pos, T, lane);
 					if (!ok && lane == 0) L.bail = R_DHT;
 				}
 			} else {
@@ -486,8 +734,6 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 			}
 			__syncthreads();
 			if (L.bail) break;
-			WGPROF(P_HEADER);
-			WGCOUNT(P_BLOCKS, 1);
 			const int hlit = (int)L.hlit, hdist = (int)L.hdist;
 			// (the checks of nxzi::read_dht: an end-of-block code, no code over-subscribed)
 			if (btype == 2 && wave == 0) {
@@ -497,111 +743,14 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 				for (int o = 32; o > 0; o >>= 1) { k1 += __shfl(k1, lane ^ o, 64); k2 += __shfl(k2, lane ^ o, 64); }
 				if (lane == 0 && (L.lens[256] == 0 || k1 > (1u << 15) || k2 > (1u << 15))) L.bail = R_DHT;
 			}
-			// ---- tables ----
-			uint32_t cl[5], ccode[5];                                 // wave 0: literal/length symbols, wave 1: distance symbols (row 0)
-			for (uint32_t i = tid; i < NSUBMAX; i += NT) L.pend[i] = 0;
-			for (uint32_t i = tid; i < LSUB; i += NT) L.lit[(1u << RL) + i] = 0;
-			for (uint32_t i = tid; i < DSUB; i += NT) L.dist[(1u << RD) + i] = 0;
-			if (wave == 0) canon<5>(L.lens, hlit, L.lcount, L.lsym, cl, ccode, lane);
-			else if (wave == 1) { uint32_t l1[1], c1[1]; canon<1>(L.lens + hlit, hdist, L.dcount, L.dsym, l1, c1, lane); cl[0] = l1[0]; ccode[0] = c1[0]; }
 			__syncthreads();
 			if (L.bail) break;
-			{
-				uint32_t sym, len;
-				L.lit[tid] = root_walk<RL>((uint32_t)tid, L.lcount, L.lsym, sym, len) ? lit_entry(sym, len) : 0;
-				if (tid < (1 << RD)) L.dist[tid] = root_walk<RD>((uint32_t)tid, L.dcount, L.dsym, sym, len) ? dist_entry(sym, len) : 0;
-			}
-			// codes longer than the root: how many index bits the sub-table behind their root index needs
-			if (wave == 0) {
-#pragma unroll
-				for (int r = 0; r < 5; r++) if (cl[r] > (uint32_t)RL) {
-					const uint32_t lsb = __builtin_bitreverse32(ccode[r]) >> (32 - cl[r]);
-					atomicMax(&L.pend[lsb & ((1u << RL) - 1)], cl[r] - RL);
-				}
-			} else if (wave == 1 && cl[0] > (uint32_t)RD) {
-				const uint32_t lsb = __builtin_bitreverse32(ccode[0]) >> (32 - cl[0]);
-				atomicMax(&L.pend[(1u << RL) + (lsb & ((1u << RD) - 1))], cl[0] - RD);
-			}
-			__syncthreads();
-			{
-				const uint32_t sl = L.pend[tid], sd = tid < (1 << RD) ? L.pend[(1u << RL) + tid] : 0;
-				uint32_t totl, totd;
-				const uint32_t ol = block_scan(L, sl ? 1u << sl : 0, &totl);
-				const uint32_t od = block_scan(L, sd ? 1u << sd : 0, &totd);
-				if (sl) L.lit[tid] = mk(0, K_LINK, sl, (1u << RL) + ol);
-				if (sd) L.dist[tid] = mk(0, K_LINK, sd, (1u << RD) + od);
-				if (tid == 0 && (totl > LSUB || totd > DSUB)) L.bail = R_TABLES;
-			}
-			__syncthreads();
+			if (PROF) { WGPROF(P_DHT); if (tid == 0) L.prof[P_BLOCKS]++; }
+			build_tables(hlit, hdist);
 			if (L.bail) break;
-			if (wave == 0) {
-#pragma unroll
-				for (int r = 0; r < 5; r++) if (cl[r] > (uint32_t)RL) {
-					const uint32_t lsb = __builtin_bitreverse32(ccode[r]) >> (32 - cl[r]);
-					const uint32_t link = L.lit[lsb & ((1u << RL) - 1)], rem = cl[r] - RL;
-					const uint32_t ent = lit_entry((uint32_t)(r * 64 + lane), cl[r]);
-					for (uint32_t k = lsb >> RL; k < (1u << e_xb(link)); k += 1u << rem) L.lit[(link >> 16) + k] = ent;
-				}
-			} else if (wave == 1 && cl[0] > (uint32_t)RD) {
-				const uint32_t lsb = __builtin_bitreverse32(ccode[0]) >> (32 - cl[0]);
-				const uint32_t link = L.dist[lsb & ((1u << RD) - 1)], rem = cl[0] - RD;
-				const uint32_t ent = dist_entry((uint32_t)lane, cl[0]);
-				for (uint32_t k = lsb >> RD; k < (1u << e_xb(link)); k += 1u << rem) L.dist[(link >> 16) + k] = ent;
-			}
-			__syncthreads();
-			WGPROF(P_TABLES);
-
-			// ---- the pieces: rounds until every lane starts where its neighbour ended ----
-			const uint32_t cur = L.pos, R = T - cur;
-			uint32_t np0 = R / (pmin_bits ? pmin_bits : 512u);
-			np0 = np0 < 1 ? 1 : np0 > (uint32_t)NT ? (uint32_t)NT : np0;
-			const uint32_t pdw = (((R + np0 - 1) / np0 + 31) >> 5) | 1;          // dwords a piece, odd: neighbours begin in different LDS banks
-			const uint32_t P = pdw * 32;
-			const uint32_t NP = (R + P - 1) / P ? (R + P - 1) / P : 1;
-			const bool active = (uint32_t)tid < NP;
-			const uint32_t g = cur + (uint32_t)tid * P;
-			const uint32_t lim = (uint32_t)tid + 1 == NP ? T : g + P;
-			uint32_t st = g, en = 0, no = 0, fl = F_ERR;
-			if (active) { decode_piece<false>(L, st, lim, T, 0, en, no, fl); L.pend[tid] = en | fl << 24; }
-			if (tid == 0) L.firstbad = NP;
-			WGPROF(P_FIRST);
-			WGCOUNT(P_PIECES, NP);
-			uint32_t rounds = 0;
-			for (;;) {
-				__syncthreads();
-				bool redo = false;
-				if (active && tid > 0) {
-					const uint32_t pe = L.pend[tid - 1];
-					if ((pe >> 24) == F_OK && (pe & 0xffffff) != st) { st = pe & 0xffffff; redo = true; }
-				}
-				if (!__syncthreads_or(redo)) break;
-				if (++rounds > 64) { if (tid == 0) L.bail = R_ROUNDS; break; }
-				if (redo) { decode_piece<false>(L, st, lim, T, 0, en, no, fl); L.pend[tid] = en | fl << 24; }
-			}
-			__syncthreads();
-			WGPROF(P_ROUNDS);
-			WGCOUNT(P_NROUNDS, rounds);
+			if (PROF) WGPROF(P_TABLES);
+			decode_block(T, cap, pmin_bits, PROF);
 			if (L.bail) break;
-			if (active && fl != F_OK) atomicMin(&L.firstbad, (uint32_t)tid);
-			__syncthreads();
-			const uint32_t B = L.firstbad;
-			if (B >= NP) { if (tid == 0) L.bail = R_NOEOB; __syncthreads(); break; }
-			{
-				const uint32_t fb = L.pend[B] >> 24;
-				uint32_t tot;
-				const uint32_t obase = block_scan(L, (uint32_t)tid <= B ? no : 0, &tot);
-				const uint32_t outn = L.outn;
-				if (fb != F_EOB || tot > cap - outn) { if (tid == 0) L.bail = fb != F_EOB ? R_TOKEN : R_SPACE; __syncthreads(); break; }
-				if ((uint32_t)tid <= B) {
-					uint32_t en2, no2, fl2;
-					decode_piece<true>(L, st, lim, T, outn + obase, en2, no2, fl2);
-					if (fl2 != fl || no2 != no) L.bail = R_DIST;                 // (a distance beyond the output so far)
-				}
-				__syncthreads();
-				if (L.bail) break;
-				if (tid == 0) { L.outn = outn + tot; L.pos = L.pend[B] & 0xffffff; }
-				WGPROF(P_WRITE);
-			}
 			if (bfinal) { done = true; break; }
 		}
 		__syncthreads();
@@ -613,39 +762,10 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 			}
 			continue;
 		}
-		// ---- matches: every lane those that start in its 64 bytes, each as soon as its source is there ----
 		const uint32_t outn = L.outn;
-		{
-			uint32_t mw0 = L.mstart[2 * tid], mw1 = L.mstart[2 * tid + 1];
-			uint32_t m = 0, len = 0, dist = 0;
-			bool have = false;
-			while (mw0 | mw1 | (uint32_t)have) {
-				if (!have) {
-					const uint32_t h = mw0 ? 0 : 1, bits = mw0 ? mw0 : mw1, bit = (uint32_t)__builtin_ctz(bits);
-					m = (2 * (uint32_t)tid + h) * 32 + bit;
-					if (h) mw1 &= mw1 - 1; else mw0 &= mw0 - 1;
-					len = (uint32_t)ob[m] + 3; dist = ((uint32_t)ob[m + 1] | (uint32_t)ob[m + 2] << 8) + 1;
-					have = true;
-				}
-				const uint32_t a = m - dist, e = a + len < m ? a + len : m;
-				if (range_there(L, a, e)) {
-					__threadfence_block();
-					copy_match(L, m, len, dist);
-					__threadfence_block();
-					const uint32_t last = m + len - 1, wa = m >> 5, wb = last >> 5;
-					const uint32_t ma = ~0u << (m & 31), mb = ~0u >> (31 - (last & 31));
-					if (wa == wb) atomicAnd(&L.unres[wa], ~(ma & mb));
-					else {
-						atomicAnd(&L.unres[wa], ~ma);
-						for (uint32_t i = wa + 1; i < wb; i++) atomicAnd(&L.unres[i], 0u);
-						atomicAnd(&L.unres[wb], ~mb);
-					}
-					have = false;
-				} else NXZ_SPIN_HINT();
-			}
-		}
+		resolve_matches(nres, PROF);
 		__syncthreads();
-		WGPROF(P_MATCH);
+		if (PROF) WGPROF(P_MATCH);
 		// ---- out ----
 		{
 			NXZ_WG_GLOBAL v4u *gd = (NXZ_WG_GLOBAL v4u *)job.dst;
@@ -663,11 +783,10 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 				results[jid] = r;
 			}
 		}
-		WGPROF(P_OUT);
+		if (PROF) WGPROF(P_OUT);
 	}
-	if (PROF && tid == 0) for (int i = 0; i < P_N; i++) atomicAdd(&prof[i], pacc[i]);
+	if (PROF && tid == 0) for (int i = 0; i < P_N; i++) atomicAdd(&prof[i], (unsigned long long)L.prof[i]);
 #undef WGPROF
-#undef WGCOUNT
 }
 
 } // namespace nxzw
@@ -696,11 +815,13 @@ extern "C" int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_
 	(void)hipMemsetAsync(bail + 64, 0xff, n * sizeof(uint32_t), stream);
 	static const unsigned cus = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(v > 0 ? v : 256); }();
 	const char *pe = getenv("NXZ_WG_PMIN");                            // (read at every call: the tests switch it)
-	const unsigned pmin = pe && atoi(pe) >= 64 ? (unsigned)atoi(pe) : 512u;
+	const unsigned pmin = pe && atoi(pe) >= 64 ? (unsigned)atoi(pe) : 128u;
+	const char *nre = getenv("NXZ_WG_NRES");
+	const unsigned nres = nre && atoi(nre) >= 1 && atoi(nre) <= nxzw::NT ? (unsigned)atoi(nre) : 256u;
 	const unsigned grid = (unsigned)(n < cus ? n : cus);
 	const char *pr = getenv("NXZ_WG_PROF");
-	if (pr && atoi(pr)) hipLaunchKernelGGL(nxzw::inflate_wg_kernel<true>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin, dbg, prof);
-	else hipLaunchKernelGGL(nxzw::inflate_wg_kernel<false>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin, dbg, prof);
+	if (pr && atoi(pr)) hipLaunchKernelGGL(nxzw::inflate_wg_kernel<true>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin, nres, dbg, prof);
+	else hipLaunchKernelGGL(nxzw::inflate_wg_kernel<false>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin, nres, dbg, prof);
 	int rc = (int)hipGetLastError();
 	if (rc) return rc;
 	rc = nxz_launch_inflate_order_only(jobs, n, results, dht_io, bail + 64, stream);

@@ -192,13 +192,14 @@ class Engine:
 
     def wg_prof(self):
         """NXZ_WG_PROF=1: one lane's cycles by phase, per stream, of the last batch that went a stream per workgroup"""
-        out = (C.c_uint64 * 12)()
+        out = (C.c_uint64 * 16)()
         if self.L.nxz_ctx_wg_prof(self.ctx, self.stream_handle(), out):
             return None
-        names = ["load", "header", "tables", "first", "rounds", "write", "match", "out"]
-        ns = max(1, out[9])
-        d = {names[i]: out[i] / ns for i in range(8)}
-        d.update(rounds=out[8] / max(1, out[10]), streams=out[9], blocks=out[10] / ns, pieces=out[11] / max(1, out[10]))
+        names = ["load", "header", "dht", "tables", "first", "rounds", "write", "list", "match", "out"]
+        ns = max(1, out[11])
+        d = {names[i]: out[i] / ns for i in range(10)}
+        d["total"] = sum(out[i] for i in range(10)) / ns
+        d.update(nrounds=out[10] / max(1, out[12]), streams=out[11], blocks=out[12] / ns, pieces=out[13] / max(1, out[12]))
         return d
 
     def inflate_stream(self, src, src_len, dst, first_bit=0, hist=None):

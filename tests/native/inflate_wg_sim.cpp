@@ -43,6 +43,7 @@ int main(int argc, char **argv)
 	}
 	if (argc > 2) rng_state ^= (uint64_t)strtoull(argv[2], nullptr, 0) * 0x9E3779B97F4A7C15ull;
 	const uint32_t pmin = argc > 3 ? (uint32_t)atoi(argv[3]) : 512;
+	const uint32_t nres = argc > 4 ? (uint32_t)atoi(argv[4]) : 256;
 	auto slice = [&](size_t at, size_t n) { return std::vector<uint8_t>(text.begin() + at % (text.size() - n), text.begin() + at % (text.size() - n) + n); };
 	std::vector<Case> cases;
 	auto add = [&](const char *name, std::vector<uint8_t> plain, int level, int strategy, bool taken = true, uint32_t off = 0, uint32_t cap = 0) {
@@ -110,7 +111,7 @@ int main(int argc, char **argv)
 	}
 	std::vector<uint32_t> bail(64 + n, 0), dbg(16, 0);
 	uint32_t ctr = 0;
-	hipsim_run_block(0, 1, nxzw::NT, [&] { nxzw::inflate_wg_kernel<false>(jobs.data(), (uint32_t)n, res.data(), nullptr, &ctr, bail.data(), pmin, dbg.data(), nullptr); });
+	hipsim_run_block(0, 1, nxzw::NT, [&] { nxzw::inflate_wg_kernel<false>(jobs.data(), (uint32_t)n, res.data(), nullptr, &ctr, bail.data(), pmin, nres, dbg.data(), nullptr); });
 
 	int bad = 0;
 	std::vector<bool> handed(n, false);
