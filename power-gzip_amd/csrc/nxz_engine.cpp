@@ -180,6 +180,7 @@ struct nxz_ctx {
 		uint8_t *d_src = nullptr;                 // the sources, brought over by one copy kernel (two kernels read them)
 		uint8_t *d_cut = nullptr;                 // decompress rounds: the workspace of nxz_inflate_cut.hip (made when first used)
 		size_t cut_arena = 0;
+		uint8_t *d_wg = nullptr;                  // ... or of nxz_inflate_wg.hip (rounds of fresh streams of at most 64 KiB either side)
 		uint8_t **h_targets = nullptr;            // ... and where the jobs' outputs go from the device buffers they are decoded into
 		struct Item { const uint8_t *src; uint8_t *dst; uint64_t bytes; } *h_items = nullptr;
 		bool busy = false, ready = false;
@@ -216,6 +217,7 @@ static constexpr unsigned JOB_COUNTERS = 256;
 #define NXZ_LANES_MIN 49152
 #define NXZ_LANES_TABLES_MIN 163840   /* streams that bring tables: the lane kernel from here on */
 #define NXZ_WINDOW_LDS_MAX 1024
+#define NXZ_WG_MAX 8192             /* batches of at most this many streams: a stream per workgroup (nxz_inflate_wg.hip) */
 
 static std::mutex g_mtx;
 static nxz_ctx *g_ctx[64];
@@ -610,11 +612,16 @@ static int batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n,
 	const size_t lanes_min = lm ? (size_t)strtoull(lm, nullptr, 0) : (size_t)NXZ_LANES_MIN;
 	bool lanes = force ? (force & 3) == 1 : n >= lanes_min, by_len = (force & 4) != 0, no_tables = false;
 	bool split = false;
-	// A stream per WORKGROUP, source, output and tables in LDS (nxz_inflate_wg.hip): every batch, unless one of the older routes'
-	// knobs is set (the tests' way to name a route) or NXZ_INFLATE_WG=0.  What that kernel does not do -- streams that resume, bring a
-	// history, are longer than 64 KiB on either side, end early or are damaged -- it hands back, and those go a stream per wavefront.
+	// A stream per WORKGROUP, source, output and tables in LDS (nxz_inflate_wg.hip): batches of up to NXZ_WG_MAX streams, unless one of
+	// the older routes' knobs is set (the tests' way to name a route).  That kernel runs at one rate from a few hundred streams on (a
+	// CU a stream: 40-50 GiB/s on zlib -6 streams of the corpus, 65-75 on fixed-code blocks, profiles/r06_inflate_by_batch_size.txt),
+	// where a stream per wavefront needs 16 384 streams to get there and a stream per lane 100 000; above, the older kernels are ahead.
+	// What it does not do -- streams that resume, bring a history, are longer than 64 KiB on either side, end early or are damaged --
+	// it hands back, and those go a stream per wavefront behind it.  NXZ_INFLATE_WG=0 / 1: never / whatever the batch's size.
 	const char *wge = getenv("NXZ_INFLATE_WG");                         // (read at every call: the tests switch it)
-	if (!force && (wge ? atoi(wge) != 0 : (!lm && !getenv("NXZ_INFLATE_CUT")))) {
+	const char *wgm = getenv("NXZ_INFLATE_WG_MAX");
+	const size_t wg_max = wgm ? (size_t)strtoull(wgm, nullptr, 0) : (size_t)NXZ_WG_MAX;
+	if (!force && (wge ? atoi(wge) != 0 : (!lm && !getenv("NXZ_INFLATE_CUT") && n <= wg_max))) {
 		std::mutex *use_mtx;
 		{
 			std::lock_guard<std::mutex> g(c->mtx);
@@ -1501,6 +1508,7 @@ static void round_free(nxz_ctx::Round &r)
 	if (r.d_cand2) (void)hipFree(r.d_cand2);
 	if (r.d_src) (void)hipFree(r.d_src);
 	if (r.d_cut) (void)hipFree(r.d_cut);
+	if (r.d_wg) (void)hipFree(r.d_wg);
 	if (r.h_targets) (void)hipHostFree(r.h_targets);
 	const bool busy = r.busy;                    // (the caller's claim on the round stands)
 	r = nxz_ctx::Round();
@@ -1740,16 +1748,32 @@ static int round_run_inflate(nxz_ctx *c, nxz_ctx::Round &R, std::vector<InflateR
 		}
 		cut = longish > 0;
 	}
+	// A round of fresh streams of at most 64 KiB either side -- what nx_uncompress / inflate(Z_FINISH) of buffers up to 64 KiB are --
+	// goes a stream per WORKGROUP (nxz_inflate_wg.hip: 0.2-0.4 ms whatever the round holds, one launch; what that kernel hands
+	// back -- a stream that ends early, a target that is too small -- goes a wavefront each behind it).  NXZ_ROUND_WG=0: never.
+	static const bool wg_on = !(getenv("NXZ_ROUND_WG") && atoi(getenv("NXZ_ROUND_WG")) == 0);
+	bool wg = wg_on;
+	for (size_t k = 0; k < n && wg; k++) {
+		const nxz_batch_job_t &j = v[k]->job;
+		if (j.resume || j.hist_len || j.src_len > 65000 || j.dst_cap > 65536 || !v[k]->d_out) wg = false;
+	}
+	if (wg && !R.h_targets && hipHostMalloc((void **)&R.h_targets, ROUND_MAX * sizeof(uint8_t *)) != hipSuccess) { (void)hipGetLastError(); R.h_targets = nullptr; wg = false; }
+	if (wg && !R.d_wg && hipMalloc((void **)&R.d_wg, nxz_inflate_wg_workspace(ROUND_MAX)) != hipSuccess) { (void)hipGetLastError(); R.d_wg = nullptr; wg = false; }
 	const unsigned P = 32;
+	if (wg) cut = false;
 	if (cut && !R.d_cut) {
 		const size_t arena = (size_t)96 << 20;
-		if (hipMalloc((void **)&R.d_cut, nxz_inflate_cut_workspace(ROUND_MAX, P, arena)) != hipSuccess || hipHostMalloc((void **)&R.h_targets, ROUND_MAX * sizeof(uint8_t *)) != hipSuccess) {
+		if (hipMalloc((void **)&R.d_cut, nxz_inflate_cut_workspace(ROUND_MAX, P, arena)) != hipSuccess || (!R.h_targets && hipHostMalloc((void **)&R.h_targets, ROUND_MAX * sizeof(uint8_t *)) != hipSuccess)) {
 			(void)hipGetLastError();
 			if (R.d_cut) (void)hipFree(R.d_cut);
 			R.d_cut = nullptr; cut = false;
 		} else R.cut_arena = arena;
 	}
-	if (cut) {
+	if (wg) {
+		for (size_t k = 0; k < n; k++) { R.h_targets[k] = R.h_jobs[k].dst; R.h_jobs[k].dst = v[k]->d_out; }
+		if (nxz_launch_inflate_wg(R.h_jobs, n, R.h_res, R.h_dht, R.d_wg, nullptr, R.stream)) return -EIO;
+		if (nxz_launch_copy_out(R.h_jobs, R.h_res, R.h_targets, n, R.stream)) return -EIO;
+	} else if (cut) {
 		for (size_t k = 0; k < n; k++) { R.h_targets[k] = R.h_jobs[k].dst; R.h_jobs[k].dst = v[k]->d_out; }
 		if (nxz_launch_inflate_cut(R.h_jobs, n, R.h_res, R.h_dht, P, R.d_cut, R.cut_arena, R.stream)) return -EIO;
 		if (nxz_launch_copy_out(R.h_jobs, R.h_res, R.h_targets, n, R.stream)) return -EIO;

@@ -33,12 +33,17 @@
 #include <stdlib.h>
 #include <stdint.h>
 #include "nxz_device.h"
-#define NXZ_SPIN_HINT() do { } while (0)
+// no lane of the wavefront found its source there: stand back (the CU's older wavefronts get the instruction issue before the
+// younger ones, and a wavefront that spins at full rate keeps the one whose lane everybody waits for from its turn)
+#define NXZ_SPIN_HINT(progress) do { if (!__builtin_amdgcn_ballot_w64(progress)) __builtin_amdgcn_s_sleep(NXZ_WG_SLEEP); } while (0)
+#ifndef NXZ_WG_SLEEP
+#define NXZ_WG_SLEEP 2
+#endif
 #define NXZ_WG_GLOBAL NXZ_GLOBAL_AS
 #else
 #include <stdint.h>
 #include "../../include/nxz_engine.h"
-#define NXZ_SPIN_HINT() sched_yield()
+#define NXZ_SPIN_HINT(progress) do { if (!(progress)) sched_yield(); } while (0)
 #define NXZ_WG_GLOBAL
 #endif
 
@@ -68,7 +73,7 @@ enum { R_JOB = 1, R_HEADER = 2, R_STORED = 3, R_DHT = 4, R_TABLES = 5, R_ROUNDS 
 // PROF (NXZ_WG_PROF=1, measurements): thread 0's clock at the ends of the phases, summed over the launch's streams in prof[]:
 // load, block headers, dynamic headers read, tables, the first pass, the later rounds, prefix sum + the writing pass, the list of
 // matches, the matches, out; then counts: rounds, streams, coded blocks, pieces
-enum { P_LOAD, P_HEADER, P_DHT, P_TABLES, P_FIRST, P_ROUNDS, P_WRITE, P_LIST, P_MATCH, P_OUT, P_NROUNDS, P_STREAMS, P_BLOCKS, P_PIECES, P_N };
+enum { P_LOAD, P_HEADER, P_DHT, P_TABLES, P_FIRST, P_ROUNDS, P_WRITE, P_LIST, P_MATCH, P_OUT, P_NROUNDS, P_STREAMS, P_BLOCKS, P_PIECES, P_MTRIPS, P_MTRIPMAX, P_MWAITS, P_MATCHES, P_N };
 
 struct __attribute__((aligned(16))) Lds {
 	uint32_t out[OUT_MAX / 4];
@@ -84,7 +89,7 @@ struct __attribute__((aligned(16))) Lds {
 	uint32_t wsum[NW];
 	// wave-uniform scalars, written by one thread in front of a barrier
 	uint32_t jid, bail, pos, outn, bfinal, btype, st_len, hlit, hdist, firstbad;
-	uint32_t prof[P_N], tprev[2];
+	uint32_t prof[P_N], tprev[2], tripmax;
 };
 static_assert(NT == (1 << RL) && NT >= (1 << RD), "a lane per root entry");
 static_assert(sizeof(Lds) <= 163840, "the workgroup's LDS image must fit the CU's 160 KiB");
@@ -290,26 +295,36 @@ NXZ_WG_PHASE void resolve_matches(uint32_t nres, int prof)
 	// (nres lanes, not all: a link of the longest chain of matches that copy from matches costs as long as the polling wavefronts
 	// take to come round, and with all 1024 lanes abreast most of what a match copies from is still in the making)
 	// A trip round this loop is what such a link costs, so it is kept short and the same for every lane: one look at the bitmap
-	// (two words, whatever the chunk), one chunk inside one 16-byte group of the output.  A source 20 bytes away or more lies in
-	// front of the group: five source dwords asked for at once, four values.  A source 4 to 19 bytes away overlaps the group: dword
-	// after dword, each from the two dwords that hold its source.  A source 1 to 3 bytes away is a period: the four dwords follow from
-	// the bytes in front of the chunk.  Whole dwords are stored, the group's partial dwords merged by two LDS atomics each (they
-	// may hold other lanes' bytes).  (The first form of this loop copied head and tail bytes in loops of their own, a wait a byte:
-	// some lane of a wavefront always has such a match, and a trip cost every lane 3000 cycles.)
+	// (two words, whatever the chunk), then one chunk inside one 16-byte group of the output: five source dwords asked for at once,
+	// four values, whole dwords stored, the group's partial dwords merged by two LDS atomics each (they may hold other lanes'
+	// bytes).  ONE form for every distance: a chunk never reaches further than the distance it copies over, so its source lies
+	// wholly in front of it -- and a match that overlaps itself (distance d < its length) is a period, which may as well be copied
+	// over 2 d, 4 d, ... once that many of its bytes are there: a run of one byte value goes 1, 2, 4, 8, 16 bytes a trip.  (The
+	// first forms of this loop had a path of their own for distances below 20 and another for periods of 1 to 3, byte loops with
+	// a wait a byte: some lane of a wavefront always has such a match, and a trip cost every lane 2000-3000 cycles.)
 	uint32_t *ow = L.out;
-	uint32_t k = (uint32_t)tid < nres ? (uint32_t)tid : M, q = 0, qe = 0, dist = 0;
+	uint32_t k = (uint32_t)tid < nres ? (uint32_t)tid : M, m = 0, q = 0, qe = 0, dist = 0;
 	bool have = false;
-	for (;;) {
+	uint32_t trips = 0, waits = 0;
+	for (;; trips++) {
 		if (!have) {
 			if (k >= M) break;
-			const uint32_t m = ml[k];
+			m = ml[k];
 			k += nres;
 			const uint32_t r = __builtin_amdgcn_alignbyte(ow[(m >> 2) + 1], ow[m >> 2], m & 3);     // the record: length - 3, distance - 1
 			dist = ((r >> 8) & 0xffff) + 1;
 			q = m; qe = m + (r & 0xff) + 3; have = true;
 		}
-		const uint32_t c1 = qe < (q | 15) + 1 ? qe : (q | 15) + 1;
-		const uint32_t sa = q - dist, sl = (c1 - dist < q ? c1 - dist : q) - 1;      // first and last byte the chunk needs from in front of itself
+		// the distance this chunk copies over: a multiple of the match's that its bytes so far allow, 16 or more if possible
+		uint32_t ed = dist;
+		{
+			const uint32_t avail = q - m + dist;
+#pragma unroll
+			for (int i = 0; i < 4; i++) if (ed < 16 && 2 * ed <= avail) ed *= 2;
+		}
+		uint32_t c1 = qe < (q | 15) + 1 ? qe : (q | 15) + 1;
+		if (c1 > q + ed) c1 = q + ed;
+		const uint32_t sa = q - ed, sl = c1 - ed - 1;                             // first and last byte the chunk copies from
 		const uint32_t u0 = __atomic_load_n(&L.unres[sa >> 5], __ATOMIC_RELAXED), u1 = __atomic_load_n(&L.unres[sl >> 5], __ATOMIC_RELAXED);
 		const uint32_t ma = ~0u << (sa & 31), mb = ~0u >> (31 - (sl & 31));
 		const bool there = ((sa >> 5) == (sl >> 5) ? (u0 & ma & mb) : ((u0 & ma) | (u1 & mb))) == 0;
@@ -317,51 +332,30 @@ NXZ_WG_PHASE void resolve_matches(uint32_t nres, int prof)
 			__threadfence_block();
 			const uint32_t g = q >> 4 << 2;                                           // the group's first dword
 			const uint32_t lo = q & 15, hi = ((c1 - 1) & 15) + 1;                     // the chunk: bytes [lo, hi) of the group
-			// dword j of the group: bytes [b0, b1) of it are the chunk's; `put` stores or merges
-			auto put = [&](uint32_t j, uint32_t val) __attribute__((always_inline)) {
+			const int32_t s0 = (int32_t)(g * 4) - (int32_t)ed;                        // (below 0 only in bytes that are not the chunk's)
+			const int32_t si = s0 >> 2;
+			const uint32_t bo = (uint32_t)s0 & 3;
+			const uint32_t w0 = ow[si < 0 ? 0 : si], w1 = ow[si + 1 < 0 ? 0 : si + 1], w2 = ow[si + 2 < 0 ? 0 : si + 2], w3 = ow[si + 3 < 0 ? 0 : si + 3], w4 = ow[si + 4 < 0 ? 0 : si + 4];
+			const uint32_t v[4] = { __builtin_amdgcn_alignbyte(w1, w0, bo), __builtin_amdgcn_alignbyte(w2, w1, bo), __builtin_amdgcn_alignbyte(w3, w2, bo), __builtin_amdgcn_alignbyte(w4, w3, bo) };
+#pragma unroll
+			for (uint32_t j = 0; j < 4; j++) {
+				// dword j of the group: bytes [b0, b1) of it are the chunk's
 				const uint32_t b0 = lo > 4 * j ? lo - 4 * j : 0, b1 = hi < 4 * j + 4 ? (hi > 4 * j ? hi - 4 * j : 0) : 4;
-				if (b0 >= b1) return;
+				if (b0 >= b1) continue;
 				const uint32_t mask = (b1 == 4 ? ~0u : (1u << (8 * b1)) - 1) & ~((1u << (8 * b0)) - 1);
-				if (mask == ~0u) ow[g + j] = val;
-				else { atomicAnd(&ow[g + j], ~mask); atomicOr(&ow[g + j], val & mask); }
-			};
-			if (dist >= 20) {
-				const int32_t s0 = (int32_t)(g * 4) - (int32_t)dist;               // (below 0 only in bytes that are not the chunk's)
-				const int32_t si = s0 >> 2;
-				const uint32_t bo = (uint32_t)s0 & 3;
-				const uint32_t w0 = ow[si < 0 ? 0 : si], w1 = ow[si + 1 < 0 ? 0 : si + 1], w2 = ow[si + 2 < 0 ? 0 : si + 2], w3 = ow[si + 3 < 0 ? 0 : si + 3], w4 = ow[si + 4];
-				put(0, __builtin_amdgcn_alignbyte(w1, w0, bo)); put(1, __builtin_amdgcn_alignbyte(w2, w1, bo));
-				put(2, __builtin_amdgcn_alignbyte(w3, w2, bo)); put(3, __builtin_amdgcn_alignbyte(w4, w3, bo));
-			} else if (dist >= 4) {
-#pragma unroll
-				for (uint32_t j = 0; j < 4; j++) {
-					if (4 * j + 4 <= lo || 4 * j >= hi) continue;
-					const int32_t s = (int32_t)((g + j) * 4) - (int32_t)dist, si = s >> 2;
-					const uint32_t a = ow[si < 0 ? 0 : si], b = ow[si + 1];
-					put(j, __builtin_amdgcn_alignbyte(b, a, (uint32_t)s & 3));
-				}
-			} else {
-				// the four bytes in front of the chunk hold the period; byte x of the output is byte (x - (q - dist)) % dist of it
-				const uint32_t f = __builtin_amdgcn_alignbyte(ow[q >> 2], ow[q >= 4 ? (q >> 2) - 1 : 0], q & 3) >> (8 * (4 - dist));
-				const uint32_t p0 = f & 0xff, p1 = dist > 1 ? (f >> 8) & 0xff : p0, p2 = dist > 2 ? (f >> 16) & 0xff : p0;
-				uint64_t pat;
-				if (dist == 3) {
-					const uint64_t t = (uint64_t)p0 | (uint64_t)p1 << 8 | (uint64_t)p2 << 16;
-					pat = t | t << 24 | t << 48;
-				} else pat = ((uint64_t)p0 | (uint64_t)p1 << 8) * 0x0001000100010001ull;
-#pragma unroll
-				for (uint32_t j = 0; j < 4; j++) {
-					const uint32_t x = 4 * j + 24 + dist - lo;                        // (group byte 4j) - (q - dist), + 24 (a multiple of every period) to stay above 0
-					// x % dist for dist 1, 2, 3 and x < 64 without a division
-					const uint32_t r = dist == 1 ? 0 : dist == 2 ? x & 1 : x - 3 * ((x * 171) >> 9);
-					put(j, (uint32_t)(pat >> (8 * r)));
-				}
+				if (mask == ~0u) ow[g + j] = v[j];
+				else { atomicAnd(&ow[g + j], ~mask); atomicOr(&ow[g + j], v[j] & mask); }
 			}
 			__threadfence_block();
 			atomicAnd(&L.unres[q >> 5], ~((~0u << (q & 31)) & (~0u >> (31 - ((c1 - 1) & 31)))));
 			q = c1;
 			if (q == qe) have = false;
-		} else NXZ_SPIN_HINT();
+		} else waits++;
+		NXZ_SPIN_HINT(there);
+	}
+	if (prof) {
+		atomicAdd(&L.prof[P_MTRIPS], trips); atomicAdd(&L.prof[P_MWAITS], waits); atomicMax(&L.tripmax, trips);
+		if (tid == 0) L.prof[P_MATCHES] += M;
 	}
 }
 
@@ -372,7 +366,6 @@ NXZ_WG_PHASE bool read_header(uint32_t start, uint32_t T, int lane)
 {
 	start = uni(start); T = uni(T);                                   // (read from LDS: the same in every lane, and now the compiler knows)
 	if (start + 14 > T) return false;
-	const uint32_t d0 = start >> 5;
 	auto word_at = [&](uint32_t idx) -> uint32_t { return idx < SRC_WORDS ? L.src[idx] : 0; };
 	const uint32_t v = uni(peek32(start));
 	const int hlit = (int)(v & 31) + 257, hdist = (int)((v >> 5) & 31) + 1, hclen = (int)((v >> 10) & 15) + 4;
@@ -570,7 +563,7 @@ NXZ_WG_PHASE void build_tables(int hlit, int hdist)
 
 // ---- a Huffman-coded block whose tables stand: the pieces in rounds, the prefix sum, the writing pass.  Leaves L.outn and
 // L.pos behind the block, or a reason in L.bail. ----
-NXZ_WG_PHASE void decode_block(uint32_t T, uint32_t cap, uint32_t pmin_bits, int prof)
+NXZ_WG_PHASE void decode_block(uint32_t T, uint32_t cap, uint32_t pmin_bits, uint32_t max_rounds, int prof)
 {
 	const int tid = threadIdx.x;
 #define WGPROF(idx) do { if (prof && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; L.prof[idx] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); } } while (0)
@@ -597,7 +590,9 @@ NXZ_WG_PHASE void decode_block(uint32_t T, uint32_t cap, uint32_t pmin_bits, int
 			if ((prev >> 24) == F_OK && (prev & 0xffffff) != st) { st = prev & 0xffffff; redo = true; }
 		}
 		if (!__syncthreads_or(redo)) break;
-		if (++rounds > 200) { if (tid == 0) L.bail = R_ROUNDS; break; }
+		// (data whose codes are all of a length -- packed bytes under 8-bit codes -- never falls in step: such a block is the
+		// stream-per-wavefront kernel's, whose literal step takes it at full rate, and the sooner it goes there the better)
+		if (++rounds > max_rounds) { if (tid == 0) L.bail = R_ROUNDS; break; }
 		if (redo) { const unsigned long long r = piece_count(st, lim, T); pe = (uint32_t)r; no = (uint32_t)(r >> 32); L.pend[tid] = pe; }
 	}
 	__syncthreads();
@@ -649,8 +644,8 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 		const uint32_t off = (uint32_t)((uintptr_t)job.src & 15);
 		const uint32_t nbytes = off + job.src_len;                     // bytes of the LDS image that belong to the stream's granules
 		const uint32_t T = nbytes * 8;
-		const bool takes = job.resume == 0 && job.hist_len == 0 && job.src_len > 0 && nbytes <= SRC_MAX && ((uintptr_t)job.dst & 15) == 0 &&
-				   (job.reserved & NXZ_JOB_SUSPEND_WHEN_FULL) == 0;
+		const bool takes = job.resume == 0 && job.hist_len == 0 && job.src_len > 0 && nbytes <= SRC_MAX && ((uintptr_t)job.dst & 15) == 0;
+		// (NXZ_JOB_SUSPEND_WHEN_FULL needs no look: an output that does not fit is handed back like everything this kernel does not do)
 		if (!takes) {
 			if (tid == 0) { const uint32_t at = atomicAdd(bail, 1u); bail[64 + at] = jid; if (dbg) atomicAdd(&dbg[R_JOB], 1u); }
 			continue;
@@ -749,7 +744,7 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 			build_tables(hlit, hdist);
 			if (L.bail) break;
 			if (PROF) WGPROF(P_TABLES);
-			decode_block(T, cap, pmin_bits, PROF);
+			decode_block(T, cap, pmin_bits & 0xffff, pmin_bits >> 16, PROF);
 			if (L.bail) break;
 			if (bfinal) { done = true; break; }
 		}
@@ -763,8 +758,10 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 			continue;
 		}
 		const uint32_t outn = L.outn;
+		if (PROF && tid == 0) L.tripmax = 0;
 		resolve_matches(nres, PROF);
 		__syncthreads();
+		if (PROF && tid == 0) L.prof[P_MTRIPMAX] += L.tripmax;
 		if (PROF) WGPROF(P_MATCH);
 		// ---- out ----
 		{
@@ -816,12 +813,14 @@ extern "C" int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_
 	static const unsigned cus = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(v > 0 ? v : 256); }();
 	const char *pe = getenv("NXZ_WG_PMIN");                            // (read at every call: the tests switch it)
 	const unsigned pmin = pe && atoi(pe) >= 64 ? (unsigned)atoi(pe) : 128u;
+	const char *mre = getenv("NXZ_WG_ROUNDS");
+	const unsigned maxr = mre && atoi(mre) >= 2 && atoi(mre) <= 1024 ? (unsigned)atoi(mre) : 32u;
 	const char *nre = getenv("NXZ_WG_NRES");
-	const unsigned nres = nre && atoi(nre) >= 1 && atoi(nre) <= nxzw::NT ? (unsigned)atoi(nre) : 256u;
+	const unsigned nres = nre && atoi(nre) >= 1 && atoi(nre) <= nxzw::NT ? (unsigned)atoi(nre) : 1024u;
 	const unsigned grid = (unsigned)(n < cus ? n : cus);
 	const char *pr = getenv("NXZ_WG_PROF");
-	if (pr && atoi(pr)) hipLaunchKernelGGL(nxzw::inflate_wg_kernel<true>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin, nres, dbg, prof);
-	else hipLaunchKernelGGL(nxzw::inflate_wg_kernel<false>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin, nres, dbg, prof);
+	if (pr && atoi(pr)) hipLaunchKernelGGL(nxzw::inflate_wg_kernel<true>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin | maxr << 16, nres, dbg, prof);
+	else hipLaunchKernelGGL(nxzw::inflate_wg_kernel<false>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin | maxr << 16, nres, dbg, prof);
 	int rc = (int)hipGetLastError();
 	if (rc) return rc;
 	rc = nxz_launch_inflate_order_only(jobs, n, results, dht_io, bail + 64, stream);

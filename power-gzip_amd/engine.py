@@ -192,14 +192,15 @@ class Engine:
 
     def wg_prof(self):
         """NXZ_WG_PROF=1: one lane's cycles by phase, per stream, of the last batch that went a stream per workgroup"""
-        out = (C.c_uint64 * 16)()
+        out = (C.c_uint64 * 24)()
         if self.L.nxz_ctx_wg_prof(self.ctx, self.stream_handle(), out):
             return None
         names = ["load", "header", "dht", "tables", "first", "rounds", "write", "list", "match", "out"]
         ns = max(1, out[11])
         d = {names[i]: out[i] / ns for i in range(10)}
         d["total"] = sum(out[i] for i in range(10)) / ns
-        d.update(nrounds=out[10] / max(1, out[12]), streams=out[11], blocks=out[12] / ns, pieces=out[13] / max(1, out[12]))
+        d.update(nrounds=out[10] / max(1, out[12]), streams=out[11], blocks=out[12] / ns, pieces=out[13] / max(1, out[12]),
+                 match_trips_sum=out[14] / ns, match_trips_max=out[15] / ns, match_waits=out[16] / ns, matches=out[17] / ns)
         return d
 
     def inflate_stream(self, src, src_len, dst, first_bit=0, hist=None):

@@ -111,7 +111,7 @@ int main(int argc, char **argv)
 	}
 	std::vector<uint32_t> bail(64 + n, 0), dbg(16, 0);
 	uint32_t ctr = 0;
-	hipsim_run_block(0, 1, nxzw::NT, [&] { nxzw::inflate_wg_kernel<false>(jobs.data(), (uint32_t)n, res.data(), nullptr, &ctr, bail.data(), pmin, nres, dbg.data(), nullptr); });
+	hipsim_run_block(0, 1, nxzw::NT, [&] { nxzw::inflate_wg_kernel<false>(jobs.data(), (uint32_t)n, res.data(), nullptr, &ctr, bail.data(), pmin | 200u << 16, nres, dbg.data(), nullptr); });
 
 	int bad = 0;
 	std::vector<bool> handed(n, false);

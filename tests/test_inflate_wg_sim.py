@@ -1,0 +1,24 @@
+"""The workgroup-per-stream inflate kernel (power-gzip_amd/csrc/nxz_inflate_wg.hip, the product source itself) run on the CPU:
+tests/native/hip_cpu_shim.h gives a workgroup an OS thread per lane, barriers, ballots and shuffles, tests/native/inflate_wg_sim.cpp
+feeds it streams made by system zlib -- text, zeros, periods, stored blocks, huffman-only, mixed; streams it must hand back (too
+long, target too small, cut short, damaged) -- and compares every byte and every result record.  No GPU: this is the check that
+the algorithm (pieces in rounds, records, bitmap, resolve) is right before the kernel ever reaches the device."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="the kernel source uses clang builtins: needs ROCm's clang++")
+@pytest.mark.parametrize("seed,pmin,nres", [(1, 128, 1024), (2, 512, 64)])
+def test_workgroup_inflate_kernel_on_the_cpu(tmp_path, seed, pmin, nres):
+    exe = tmp_path / "inflate_wg_sim"
+    subprocess.run([CLANG, "-O1", "-g", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "native", "inflate_wg_sim.cpp"),
+                    "-o", str(exe), "-lz"], check=True)
+    r = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "alice29.txt"), str(seed), str(pmin), str(nres)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

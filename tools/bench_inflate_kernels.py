@@ -31,7 +31,7 @@ def timed(eng, jobs, n):
 
 
 KERNELS = [k for k in os.environ.get("KERNELS", "wg,waves,cut,lanes").split(",") if k]    # KERNELS=wg: the workgroup-per-stream kernel only
-print("%-34s %8s | %s" % ("streams", "n", " ".join("%12s" % {"wg": "per workgroup", "waves": "per wave", "cut": "cut", "lanes": "per lane"}[k] for k in KERNELS)))
+print("%-34s %8s | %s" % ("streams", "n", " ".join("%12s" % {"wg": "per workgroup", "waves": "per wave", "cut": "cut", "lanes": "per lane", "old": "as round 5", "engine": "the engine"}[k] for k in KERNELS)))
 for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "own fixed-Huffman (corpus)", "own exact tables (corpus)"):
     for n in sizes:
         row = []
@@ -44,6 +44,12 @@ for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "o
             os.environ["NXZ_INFLATE_CUT"] = "1" if kernel == "cut" else "0"                 # every stream cut inside its first block (nxz_inflate_cut.hip)
             os.environ["NXZ_LANES_FIXED"] = "2" if kind.startswith("own fixed") else "0"   # (the fixed-code-only kernel in front, as the engine's sampling would choose)
             os.environ["NXZ_INFLATE_LDS_MAX"] = os.environ.get("LDS_MAX", "0")          # (LDS_MAX=1024: small batches as the engine runs them, the window in LDS)
+            if kernel in ("old", "engine"):
+                # the engine's own choice: with the workgroup kernel out of it (what round 5 did), or as it stands
+                for k in ("NXZ_INFLATE_LANES_MIN", "NXZ_INFLATE_CUT", "NXZ_LANES_FIXED", "NXZ_INFLATE_LDS_MAX", "NXZ_INFLATE_WG"):
+                    os.environ.pop(k, None)
+                if kernel == "old":
+                    os.environ["NXZ_INFLATE_WG"] = "0"
             eng = pkg.Engine(0)
             if kind.startswith("zlib"):
                 streams = []
