@@ -384,6 +384,9 @@ void *nxz_stream_create(nxz_ctx_t *ctx);
 void  nxz_stream_destroy(nxz_ctx_t *ctx, void *stream);
 int   nxz_copy_to_device(nxz_ctx_t *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int   nxz_copy_to_host(nxz_ctx_t *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
+/* Measurement aid: a device-to-device copy by a 16-bytes-a-lane kernel (what the roofline's measured HBM peak is taken with);
+ * bytes a multiple of 16, both pointers 16-byte aligned; asynchronous on `stream`. */
+int   nxz_copy_device(nxz_ctx_t *ctx, void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 
 /* Measurement aid (bench.py's roofline): with timing on, every compress batch records events
  * around its kernels; nxz_ctx_stage_ms waits for them and returns the milliseconds spent in the

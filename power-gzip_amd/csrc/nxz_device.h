@@ -80,7 +80,8 @@ int nxz_launch_pack_stream(const nxz_batch_job_t *jobs, const nxz_batch_result_t
 typedef struct nxz_pack_member { uint32_t b0, n, fin, off0; uint8_t *packed; } nxz_pack_member_t;
 int nxz_launch_pack_member_streams(const nxz_batch_job_t *jobs, const nxz_batch_result_t *results, size_t nblocks, const nxz_pack_member_t *members,
 				   size_t nmembers, const uint16_t *member_of, uint64_t *offsets, hipStream_t stream);
-int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);   /* items: { src, dst, uint64 bytes } */
+int nxz_launch_copy_items(const void *items, uint32_t n, hipStream_t stream);
+int nxz_launch_copy16(const void *src, void *dst, size_t bytes, hipStream_t stream);   /* a plain device-to-device copy, 16 bytes a lane: the roofline's measured peak */   /* items: { src, dst, uint64 bytes } */
 size_t nxz_inflate_lanes_workspace(size_t n);
 /* nxz_inflate_cut.hip: a batch too small to fill the device a stream per wavefront -- every stream cut inside its first block */
 unsigned nxz_inflate_cut_pieces(size_t n);                                   /* pieces per stream for a batch of n (below 2: not worth it) */

@@ -1327,6 +1327,15 @@ extern "C" int nxz_copy_to_device(nxz_ctx_t *c, void *dst_dev, const void *src_h
 	HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream), return -EIO);
 	return 0;
 }
+// Measurement aid (bench.py's peak_measured): one device-to-device copy of `bytes` (a multiple of 16, both 16-byte aligned) by a
+// 16-bytes-a-lane kernel, asynchronous on `stream`
+extern "C" int nxz_copy_device(nxz_ctx_t *c, void *dst_dev, const void *src_dev, size_t bytes, void *stream)
+{
+	if (!c) return -EINVAL;
+	(void)hipSetDevice(c->device);
+	return nxz_launch_copy16(src_dev, dst_dev, bytes, (hipStream_t)stream) ? -EIO : 0;
+}
+
 extern "C" int nxz_copy_to_host(nxz_ctx_t *c, void *dst_host, const void *src_dev, size_t bytes, void *stream)
 {
 	if (!c) return -EINVAL;

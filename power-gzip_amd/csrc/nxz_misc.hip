@@ -542,3 +542,30 @@ extern "C" int nxz_launch_pack_members(const nxz_batch_job_t *jobs, const nxz_ba
 	hipLaunchKernelGGL(nxz::pack_members_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, results, offsets, packed);
 	return (int)hipGetLastError();
 }
+
+// ---- the achievable HBM figure (bench.py's roofline: peak_measured): a device-to-device copy, 16 bytes a lane, a grid of eight
+// workgroups a CU that strides through the buffer (MI355X_MICROARCH.md: 6.29 TB/s of read + written bytes this way) ----
+namespace nxz {
+typedef uint32_t copy_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy16_kernel(const copy_v4 *__restrict__ src, copy_v4 *__restrict__ dst, size_t n16)
+{
+	const NXZ_GLOBAL_AS copy_v4 *s = (const NXZ_GLOBAL_AS copy_v4 *)src;
+	NXZ_GLOBAL_AS copy_v4 *d = (NXZ_GLOBAL_AS copy_v4 *)dst;
+	const size_t stride = (size_t)gridDim.x * 256;
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	for (; i + 3 * stride < n16; i += 4 * stride) {
+		const copy_v4 a = __builtin_nontemporal_load(&s[i]), b = __builtin_nontemporal_load(&s[i + stride]),
+			      c = __builtin_nontemporal_load(&s[i + 2 * stride]), e = __builtin_nontemporal_load(&s[i + 3 * stride]);
+		__builtin_nontemporal_store(a, &d[i]); __builtin_nontemporal_store(b, &d[i + stride]);
+		__builtin_nontemporal_store(c, &d[i + 2 * stride]); __builtin_nontemporal_store(e, &d[i + 3 * stride]);
+	}
+	for (; i < n16; i += stride) d[i] = s[i];
+}
+}
+extern "C" int nxz_launch_copy16(const void *src, void *dst, size_t bytes, hipStream_t stream)
+{
+	if (((uintptr_t)src | (uintptr_t)dst | bytes) & 15) return (int)hipErrorInvalidValue;
+	static const unsigned cus = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(v > 0 ? v : 256); }();
+	hipLaunchKernelGGL(nxz::copy16_kernel, dim3(cus * 8), dim3(256), 0, stream, (const nxz::copy_v4 *)src, (nxz::copy_v4 *)dst, bytes / 16);
+	return (int)hipGetLastError();
+}

@@ -84,6 +84,7 @@ def load_library():
         L.nxz_deflate_host.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
                                        C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.nxz_ctx_sync.argtypes = [C.c_void_p, C.c_void_p]
+        L.nxz_copy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.nxz_ctx_wg_reasons.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.nxz_ctx_wg_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.nx_function_begin.argtypes = [C.c_int, C.c_int, C.c_void_p]
@@ -178,6 +179,10 @@ class Engine:
                                          dht_io.data_ptr() if dht_io is not None else None, self.stream_handle())
         self._check(rc, "nxz_batch_decompress")
         return results
+
+    def copy_device(self, dst, src):
+        """dst <- src (uint8 device tensors of equal size, a multiple of 16 bytes) by the engine's 16-bytes-a-lane copy kernel"""
+        self._check(self.L.nxz_copy_device(self.ctx, dst.data_ptr(), src.data_ptr(), src.numel(), self.stream_handle()), "nxz_copy_device")
 
     def wg_reasons(self):
         """of the last decompress batch that went a stream per workgroup: {"handed_back": n, reason: count}"""

@@ -6,7 +6,7 @@ kernel went from 96 to 99 VGPRs unnoticed and lost a wavefront per SIMD: 72.9 ->
 import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "power-gzip_amd", "csrc")
-FILES = ["nxz_lz77.hip", "nxz_encode.hip", "nxz_dhtgen.hip", "nxz_inflate.hip", "nxz_inflate_lanes.hip", "nxz_inflate_cut.hip", "nxz_misc.hip", "nxz_blockfind.hip"]
+FILES = ["nxz_lz77.hip", "nxz_encode.hip", "nxz_dhtgen.hip", "nxz_inflate.hip", "nxz_inflate_lanes.hip", "nxz_inflate_wg.hip", "nxz_inflate_cut.hip", "nxz_misc.hip", "nxz_blockfind.hip"]
 
 
 def demangle(names):
