@@ -76,6 +76,7 @@ enum { R_JOB = 1, R_HEADER = 2, R_STORED = 3, R_DHT = 4, R_TABLES = 5, R_ROUNDS 
 enum { P_LOAD, P_HEADER, P_DHT, P_TABLES, P_FIRST, P_ROUNDS, P_WRITE, P_LIST, P_MATCH, P_OUT, P_NROUNDS, P_STREAMS, P_BLOCKS, P_PIECES, P_MTRIPS, P_MTRIPMAX, P_MWAITS, P_MATCHES, P_N };
 
 struct __attribute__((aligned(16))) Lds {
+	uint32_t pad[4];                    // (the match copies read up to four dwords in front of the output without looking)
 	uint32_t out[OUT_MAX / 4];
 	uint32_t src[SRC_WORDS];            // the stream; when all blocks are decoded: the positions of the matches, 16 bits each
 	uint32_t mstart[OUT_MAX / 32];      // bit p: a match starts at output byte p (its record stands there)
@@ -302,28 +303,32 @@ NXZ_WG_PHASE void resolve_matches(uint32_t nres, int prof)
 	// over 2 d, 4 d, ... once that many of its bytes are there: a run of one byte value goes 1, 2, 4, 8, 16 bytes a trip.  (The
 	// first forms of this loop had a path of their own for distances below 20 and another for periods of 1 to 3, byte loops with
 	// a wait a byte: some lane of a wavefront always has such a match, and a trip cost every lane 2000-3000 cycles.)
+	// (And short in instructions: a wavefront on its own issues one every four or five cycles, so a trip of 230 instructions took
+	// 1200 cycles whatever the LDS did; now some 130: the distance carried from trip to trip, the group's byte mask spread to its
+	// four dwords by two multiplications each, every dword merged by the two atomics -- no "whole dword?" branches --, the source
+	// dwords read without a look at where the output begins: the four dwords in front of it are the image's own padding.)
 	uint32_t *ow = L.out;
-	uint32_t k = (uint32_t)tid < nres ? (uint32_t)tid : M, m = 0, q = 0, qe = 0, dist = 0;
+	uint32_t k = (uint32_t)tid < (nres & 0xffff) ? (uint32_t)tid : M, m = 0, q = 0, qe = 0, dist = 0, ed = 0;
 	bool have = false;
 	uint32_t trips = 0, waits = 0;
+	const bool lockstep = (nres & 0x10000) != 0;            // (measurements: all lanes trip for trip through a barrier)
+	nres &= 0xffff;
+	if (k != M && k >= nres) k = M;
 	for (;; trips++) {
+		if (lockstep) { if (!__syncthreads_or(have || k < M)) break; }
 		if (!have) {
-			if (k >= M) break;
+			if (k >= M) { if (lockstep) continue; break; }
 			m = ml[k];
 			k += nres;
 			const uint32_t r = __builtin_amdgcn_alignbyte(ow[(m >> 2) + 1], ow[m >> 2], m & 3);     // the record: length - 3, distance - 1
 			dist = ((r >> 8) & 0xffff) + 1;
-			q = m; qe = m + (r & 0xff) + 3; have = true;
+			q = m; qe = m + (r & 0xff) + 3; ed = dist; have = true;
 		}
-		// the distance this chunk copies over: a multiple of the match's that its bytes so far allow, 16 or more if possible
-		uint32_t ed = dist;
-		{
-			const uint32_t avail = q - m + dist;
-#pragma unroll
-			for (int i = 0; i < 4; i++) if (ed < 16 && 2 * ed <= avail) ed *= 2;
-		}
-		uint32_t c1 = qe < (q | 15) + 1 ? qe : (q | 15) + 1;
-		if (c1 > q + ed) c1 = q + ed;
+		// ed: the distance this chunk copies over -- the match's own, or for a match that overlaps itself a multiple of it that
+		// its bytes so far allow (doubled after every chunk until it is 16)
+		uint32_t c1 = (q | 15) + 1;
+		c1 = c1 < qe ? c1 : qe;
+		c1 = c1 < q + ed ? c1 : q + ed;
 		const uint32_t sa = q - ed, sl = c1 - ed - 1;                             // first and last byte the chunk copies from
 		const uint32_t u0 = __atomic_load_n(&L.unres[sa >> 5], __ATOMIC_RELAXED), u1 = __atomic_load_n(&L.unres[sl >> 5], __ATOMIC_RELAXED);
 		const uint32_t ma = ~0u << (sa & 31), mb = ~0u >> (31 - (sl & 31));
@@ -331,25 +336,23 @@ NXZ_WG_PHASE void resolve_matches(uint32_t nres, int prof)
 		if (there) {
 			__threadfence_block();
 			const uint32_t g = q >> 4 << 2;                                           // the group's first dword
-			const uint32_t lo = q & 15, hi = ((c1 - 1) & 15) + 1;                     // the chunk: bytes [lo, hi) of the group
+			const uint32_t be = ((2u << ((c1 - 1) & 15)) - 1) & (~0u << (q & 15));    // the chunk: these bytes of the group
 			const int32_t s0 = (int32_t)(g * 4) - (int32_t)ed;                        // (below 0 only in bytes that are not the chunk's)
 			const int32_t si = s0 >> 2;
 			const uint32_t bo = (uint32_t)s0 & 3;
-			const uint32_t w0 = ow[si < 0 ? 0 : si], w1 = ow[si + 1 < 0 ? 0 : si + 1], w2 = ow[si + 2 < 0 ? 0 : si + 2], w3 = ow[si + 3 < 0 ? 0 : si + 3], w4 = ow[si + 4 < 0 ? 0 : si + 4];
+			const uint32_t w0 = ow[si], w1 = ow[si + 1], w2 = ow[si + 2], w3 = ow[si + 3], w4 = ow[si + 4];   // (si >= -4: L.pad)
 			const uint32_t v[4] = { __builtin_amdgcn_alignbyte(w1, w0, bo), __builtin_amdgcn_alignbyte(w2, w1, bo), __builtin_amdgcn_alignbyte(w3, w2, bo), __builtin_amdgcn_alignbyte(w4, w3, bo) };
 #pragma unroll
 			for (uint32_t j = 0; j < 4; j++) {
-				// dword j of the group: bytes [b0, b1) of it are the chunk's
-				const uint32_t b0 = lo > 4 * j ? lo - 4 * j : 0, b1 = hi < 4 * j + 4 ? (hi > 4 * j ? hi - 4 * j : 0) : 4;
-				if (b0 >= b1) continue;
-				const uint32_t mask = (b1 == 4 ? ~0u : (1u << (8 * b1)) - 1) & ~((1u << (8 * b0)) - 1);
-				if (mask == ~0u) ow[g + j] = v[j];
-				else { atomicAnd(&ow[g + j], ~mask); atomicOr(&ow[g + j], v[j] & mask); }
+				const uint32_t nib = (be >> (4 * j)) & 15;
+				const uint32_t mask = ((nib * 0x00204081u) & 0x01010101u) * 0xffu;    // bit i of the nibble -> byte i
+				if (nib) { atomicAnd(&ow[g + j], ~mask); atomicOr(&ow[g + j], v[j] & mask); }
 			}
 			__threadfence_block();
 			atomicAnd(&L.unres[q >> 5], ~((~0u << (q & 31)) & (~0u >> (31 - ((c1 - 1) & 31)))));
 			q = c1;
 			if (q == qe) have = false;
+			else if (ed < 16 && 2 * ed <= q - m + dist) ed *= 2;
 		} else waits++;
 		NXZ_SPIN_HINT(there);
 	}
@@ -816,7 +819,7 @@ extern "C" int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_
 	const char *mre = getenv("NXZ_WG_ROUNDS");
 	const unsigned maxr = mre && atoi(mre) >= 2 && atoi(mre) <= 1024 ? (unsigned)atoi(mre) : 32u;
 	const char *nre = getenv("NXZ_WG_NRES");
-	const unsigned nres = nre && atoi(nre) >= 1 && atoi(nre) <= nxzw::NT ? (unsigned)atoi(nre) : 1024u;
+	const unsigned nres = nre && (atoi(nre) & 0xffff) >= 1 && (atoi(nre) & 0xffff) <= nxzw::NT ? (unsigned)atoi(nre) : 1024u;
 	const unsigned grid = (unsigned)(n < cus ? n : cus);
 	const char *pr = getenv("NXZ_WG_PROF");
 	if (pr && atoi(pr)) hipLaunchKernelGGL(nxzw::inflate_wg_kernel<true>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin | maxr << 16, nres, dbg, prof);
