@@ -80,7 +80,6 @@ struct __attribute__((aligned(16))) Lds {
 	uint32_t out[OUT_MAX / 4];
 	uint32_t src[SRC_WORDS];            // the stream; when all blocks are decoded: the positions of the matches, 16 bits each
 	uint32_t mstart[OUT_MAX / 32];      // bit p: a match starts at output byte p (its record stands there)
-	uint32_t unres[OUT_MAX / 32];       // bit p: output byte p is part of a match that is not copied yet
 	uint32_t lit[(1 << RL) + LSUB];
 	uint32_t dist[(1 << RD) + DSUB];
 	uint32_t pend[NSUBMAX];             // table build: sub-table bits per root index; the rounds: every piece's end | flag << 24
@@ -90,11 +89,12 @@ struct __attribute__((aligned(16))) Lds {
 	uint32_t wsum[NW];
 	// wave-uniform scalars, written by one thread in front of a barrier
 	uint32_t jid, bail, pos, outn, bfinal, btype, st_len, hlit, hdist, firstbad;
+	uint32_t span_m, span_len, span_dist;   // the match that reaches from the first half of the output into the second
 	uint32_t prof[P_N], tprev[2], tripmax;
 };
 static_assert(NT == (1 << RL) && NT >= (1 << RD), "a lane per root entry");
 static_assert(sizeof(Lds) <= 163840, "the workgroup's LDS image must fit the CU's 160 KiB");
-static_assert(OUT_MAX / 3 * 2 <= SRC_WORDS * 4, "the list of matches must fit the room of the source");
+static_assert(32768 * 2 <= SRC_WORDS * 4, "the pointers of half the output must fit the room of the source");
 
 // The workgroup's LDS image: at namespace scope, so that the phases below can be functions of their own (each with its own
 // register allocation: as one inlined body the kernel spilled in its loops) and still address LDS directly.
@@ -245,14 +245,6 @@ __device__ __forceinline__ unsigned long long decode_piece(uint32_t st, uint32_t
 				if (t.dist > at) { fl = F_ERR; break; }
 				ob[at] = (uint8_t)(t.val - 3); ob[at + 1] = (uint8_t)(t.dist - 1); ob[at + 2] = (uint8_t)((t.dist - 1) >> 8);
 				atomicOr(&L.mstart[at >> 5], 1u << (at & 31));
-				const uint32_t last = at + t.val - 1, wa = at >> 5, wb = last >> 5;
-				const uint32_t ma = ~0u << (at & 31), mb = ~0u >> (31 - (last & 31));
-				if (wa == wb) atomicOr(&L.unres[wa], ma & mb);
-				else {
-					atomicOr(&L.unres[wa], ma);
-					for (uint32_t i = wa + 1; i < wb; i++) atomicOr(&L.unres[i], ~0u);
-					atomicOr(&L.unres[wb], mb);
-				}
 			}
 		}
 		n += lit ? 1u : t.val;
@@ -264,102 +256,112 @@ __device__ __forceinline__ unsigned long long decode_piece(uint32_t st, uint32_t
 NXZ_WG_PHASE unsigned long long piece_count(uint32_t st, uint32_t lim, uint32_t T) { return decode_piece<false>(st, lim, T, 0); }
 NXZ_WG_PHASE unsigned long long piece_write(uint32_t st, uint32_t lim, uint32_t T, uint32_t obase) { return decode_piece<true>(st, lim, T, obase); }
 
-// is no byte of [a, e) part of a match that is still to be copied?  (a < e)
-__device__ __forceinline__ bool range_there(uint32_t a, uint32_t e)
-{
-	// (relaxed atomic loads of the LDS words themselves: through a `volatile` pointer they became flat_load ... sc0 sc1, some
-	// thousand cycles a poll)
-	const uint32_t last = e - 1, wa = a >> 5, wb = last >> 5;
-	const uint32_t ma = ~0u << (a & 31), mb = ~0u >> (31 - (last & 31));
-	if (wa == wb) return (__atomic_load_n(&L.unres[wa], __ATOMIC_RELAXED) & ma & mb) == 0;
-	uint32_t acc = (__atomic_load_n(&L.unres[wa], __ATOMIC_RELAXED) & ma) | (__atomic_load_n(&L.unres[wb], __ATOMIC_RELAXED) & mb);
-	for (uint32_t i = wa + 1; i < wb; i++) acc |= __atomic_load_n(&L.unres[i], __ATOMIC_RELAXED);
-	return acc == 0;
-}
-
-// ---- the matches, when all blocks are decoded.  First their positions in order (from the bitmap, into the room the source
-// no longer needs), then lane t takes matches t, t + 1024, ...: all lanes work their way through the output side by side, so
-// what a match copies from is nearly always done by the time its lane comes to it (a lane per stretch of the output, in order,
-// waited for its neighbour's last bytes before it could begin).  A match is copied CHUNK bytes at a time, each chunk as soon as
-// the bitmap shows its source bytes there; the lowest match not yet copied can always go. ----
-NXZ_WG_PHASE void resolve_matches(uint32_t nres, int prof)
+// ---- the matches, when all blocks are decoded: every byte of a match is the byte `distance` in front of it, which may itself
+// be a byte of a match ... down to a literal.  The first forms of this phase copied match after match, each as soon as a bitmap
+// showed its source bytes there: whatever the lanes' order, 130-260 matches deep in a 64 KiB block hang one behind the other,
+// and every link of that chain cost a trip of the polling loop, 1500 cycles -- 200 000 to 400 000 cycles a stream with most of
+// the CU waiting.  Now the chains are followed by POINTER JUMPING, a byte a pointer: P[x] = where byte x comes from (itself for
+// a literal), then P[x] = P[P[x]] for all x side by side until nothing moves -- a chain of depth d is flat after log2 d rounds
+// (a byte is 30-250 copies away from its literal; 6-8 rounds), whatever hangs on whatever.  Then one gather.  16 bits a pointer:
+// the room the source no longer needs holds them for 32 KiB of output, so the output goes in two halves; pointers of the
+// second half into the first are ends of their chains (those bytes are final by then). ----
+constexpr uint32_t HALF = 32768;
+NXZ_WG_PHASE void resolve_matches(uint32_t outn, int prof)
 {
 	const int tid = threadIdx.x;
-	uint16_t *ml = (uint16_t *)L.src;
-	const uint32_t w0 = L.mstart[2 * tid], w1 = L.mstart[2 * tid + 1];
-	uint32_t M;
-	uint32_t at = block_scan((uint32_t)__popc(w0) + (uint32_t)__popc(w1), &M);
-	for (uint32_t bits = w0; bits; bits &= bits - 1) ml[at++] = (uint16_t)(64 * (uint32_t)tid + (uint32_t)__builtin_ctz(bits));
-	for (uint32_t bits = w1; bits; bits &= bits - 1) ml[at++] = (uint16_t)(64 * (uint32_t)tid + 32 + (uint32_t)__builtin_ctz(bits));
-	__syncthreads();
-	if (prof && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; L.prof[P_LIST] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); }
-	// (nres lanes, not all: a link of the longest chain of matches that copy from matches costs as long as the polling wavefronts
-	// take to come round, and with all 1024 lanes abreast most of what a match copies from is still in the making)
-	// A trip round this loop is what such a link costs, so it is kept short and the same for every lane: one look at the bitmap
-	// (two words, whatever the chunk), then one chunk inside one 16-byte group of the output: five source dwords asked for at once,
-	// four values, whole dwords stored, the group's partial dwords merged by two LDS atomics each (they may hold other lanes'
-	// bytes).  ONE form for every distance: a chunk never reaches further than the distance it copies over, so its source lies
-	// wholly in front of it -- and a match that overlaps itself (distance d < its length) is a period, which may as well be copied
-	// over 2 d, 4 d, ... once that many of its bytes are there: a run of one byte value goes 1, 2, 4, 8, 16 bytes a trip.  (The
-	// first forms of this loop had a path of their own for distances below 20 and another for periods of 1 to 3, byte loops with
-	// a wait a byte: some lane of a wavefront always has such a match, and a trip cost every lane 2000-3000 cycles.)
-	// (And short in instructions: a wavefront on its own issues one every four or five cycles, so a trip of 230 instructions took
-	// 1200 cycles whatever the LDS did; now some 130: the distance carried from trip to trip, the group's byte mask spread to its
-	// four dwords by two multiplications each, every dword merged by the two atomics -- no "whole dword?" branches --, the source
-	// dwords read without a look at where the output begins: the four dwords in front of it are the image's own padding.)
-	uint32_t *ow = L.out;
-	uint32_t k = (uint32_t)tid < (nres & 0xffff) ? (uint32_t)tid : M, m = 0, q = 0, qe = 0, dist = 0, ed = 0;
-	bool have = false;
-	uint32_t trips = 0, waits = 0;
-	const bool lockstep = (nres & 0x10000) != 0;            // (measurements: all lanes trip for trip through a barrier)
-	nres &= 0xffff;
-	if (k != M && k >= nres) k = M;
-	for (;; trips++) {
-		if (lockstep) { if (!__syncthreads_or(have || k < M)) break; }
-		if (!have) {
-			if (k >= M) { if (lockstep) continue; break; }
-			m = ml[k];
-			k += nres;
-			const uint32_t r = __builtin_amdgcn_alignbyte(ow[(m >> 2) + 1], ow[m >> 2], m & 3);     // the record: length - 3, distance - 1
-			dist = ((r >> 8) & 0xffff) + 1;
-			q = m; qe = m + (r & 0xff) + 3; ed = dist; have = true;
-		}
-		// ed: the distance this chunk copies over -- the match's own, or for a match that overlaps itself a multiple of it that
-		// its bytes so far allow (doubled after every chunk until it is 16)
-		uint32_t c1 = (q | 15) + 1;
-		c1 = c1 < qe ? c1 : qe;
-		c1 = c1 < q + ed ? c1 : q + ed;
-		const uint32_t sa = q - ed, sl = c1 - ed - 1;                             // first and last byte the chunk copies from
-		const uint32_t u0 = __atomic_load_n(&L.unres[sa >> 5], __ATOMIC_RELAXED), u1 = __atomic_load_n(&L.unres[sl >> 5], __ATOMIC_RELAXED);
-		const uint32_t ma = ~0u << (sa & 31), mb = ~0u >> (31 - (sl & 31));
-		const bool there = ((sa >> 5) == (sl >> 5) ? (u0 & ma & mb) : ((u0 & ma) | (u1 & mb))) == 0;
-		if (there) {
-			__threadfence_block();
-			const uint32_t g = q >> 4 << 2;                                           // the group's first dword
-			const uint32_t be = ((2u << ((c1 - 1) & 15)) - 1) & (~0u << (q & 15));    // the chunk: these bytes of the group
-			const int32_t s0 = (int32_t)(g * 4) - (int32_t)ed;                        // (below 0 only in bytes that are not the chunk's)
-			const int32_t si = s0 >> 2;
-			const uint32_t bo = (uint32_t)s0 & 3;
-			const uint32_t w0 = ow[si], w1 = ow[si + 1], w2 = ow[si + 2], w3 = ow[si + 3], w4 = ow[si + 4];   // (si >= -4: L.pad)
-			const uint32_t v[4] = { __builtin_amdgcn_alignbyte(w1, w0, bo), __builtin_amdgcn_alignbyte(w2, w1, bo), __builtin_amdgcn_alignbyte(w3, w2, bo), __builtin_amdgcn_alignbyte(w4, w3, bo) };
+	uint8_t *ob = (uint8_t *)L.out;
+	uint16_t *P = (uint16_t *)L.src;
+#define WGPROF2(idx) do { if (prof && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; L.prof[idx] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); } } while (0)
+	for (uint32_t base = 0; base < outn; base += HALF) {
+		// A lane owns 32 bytes of the half -- one word of the bitmap of match starts, 32 pointers (16 registers), eight dwords
+		// of the output -- and makes ITS pointers: the match that reaches into its bytes from in front (the last start within 258
+		// bytes, if it is long enough; from the other half: the one match saved when that half was done), then the matches that
+		// start in its word.  Every lane the same 32 steps, whatever the matches' lengths.
+		const uint32_t i0 = 32 * (uint32_t)tid, x0 = base + i0;
+		uint32_t *p2 = (uint32_t *)(P + i0);                                 // pointers 2 j, 2 j + 1 of this lane: p2[j]
+		{
+			const uint32_t starts = L.mstart[x0 >> 5];
+			uint32_t own[9];                                                    // this lane's bytes and four behind them: the records of the matches that start here
 #pragma unroll
-			for (uint32_t j = 0; j < 4; j++) {
-				const uint32_t nib = (be >> (4 * j)) & 15;
-				const uint32_t mask = ((nib * 0x00204081u) & 0x01010101u) * 0xffu;    // bit i of the nibble -> byte i
-				if (nib) { atomicAnd(&ow[g + j], ~mask); atomicOr(&ow[g + j], v[j] & mask); }
+			for (uint32_t j = 0; j < 9; j++) own[j] = L.out[(x0 >> 2) + j];
+			uint32_t mend = 0, mdist = 1, mbeg = 0, mlen = 0, r = 0, even = 0; // the match the walk stands in: its end, distance, start, length; r = (x - mbeg) % mdist
+			{
+				// the last start in front of x0, within 258 bytes and within this half
+				const uint32_t lowest = x0 >= base + 288 ? (x0 - 258) >> 5 : base >> 5;
+				bool found = false;
+				for (uint32_t w = x0 >> 5; w-- > lowest;) {
+					const uint32_t bits = L.mstart[w];
+					if (bits) {
+						const uint32_t m = w * 32 + 31 - (uint32_t)__builtin_clz(bits), len = (uint32_t)ob[m] + 3;
+						if (m + len > x0) { mbeg = m; mlen = len; mend = m + len; mdist = ((uint32_t)ob[m + 1] | (uint32_t)ob[m + 2] << 8) + 1; }
+						found = true;
+						break;
+					}
+				}
+				if (!found && base && L.span_len && L.span_m + L.span_len > x0 && x0 < base + 288) { mbeg = L.span_m; mlen = L.span_len; mend = mbeg + mlen; mdist = L.span_dist; }
+				if (mend > x0 && mdist < mlen) r = (x0 - mbeg) % mdist;
 			}
-			__threadfence_block();
-			atomicAnd(&L.unres[q >> 5], ~((~0u << (q & 31)) & (~0u >> (31 - ((c1 - 1) & 31)))));
-			q = c1;
-			if (q == qe) have = false;
-			else if (ed < 16 && 2 * ed <= q - m + dist) ed *= 2;
-		} else waits++;
-		NXZ_SPIN_HINT(there);
+#pragma unroll
+			for (uint32_t j = 0; j < 32; j++) {
+				const uint32_t x = x0 + j;
+				if ((starts >> j) & 1) {
+					const uint32_t rec = __builtin_amdgcn_alignbyte(own[(j >> 2) + 1], own[j >> 2], j & 3);
+					mbeg = x; mlen = (rec & 0xff) + 3; mend = x + mlen; mdist = ((rec >> 8) & 0xffff) + 1; r = 0;
+				}
+				// a literal is its own source; a byte of a match comes from `distance` in front -- of a match that overlaps itself
+				// (a period) from the period in front of the match, not from its own bytes (else a run of one value is a chain as long
+				// as the run)
+				uint32_t src = x;
+				if (x < mend) src = mdist < mlen ? mbeg - mdist + r : x - mdist;
+				r = r + 1 == mdist ? 0 : r + 1;
+				if (j & 1) p2[j >> 1] = even | src << 16; else even = src;
+			}
+			// the match that reaches from this half into the next: its record will be gone by then
+			if (base == 0 && outn > HALF && tid == NT - 1) { L.span_m = mbeg; L.span_dist = mdist; L.span_len = mend > HALF ? mlen : 0; }
+		}
+		__syncthreads();
+		WGPROF2(P_LIST);
+		uint32_t pp[16];                                                     // ... in registers from here on
+		{
+			const v4u *p4 = (const v4u *)(P + i0);
+#pragma unroll
+			for (uint32_t j = 0; j < 4; j++) { const v4u v = p4[j]; pp[4 * j] = v.x; pp[4 * j + 1] = v.y; pp[4 * j + 2] = v.z; pp[4 * j + 3] = v.w; }
+		}
+		// rounds of jumping: the lane's own pointers stay in its registers; what moved is written back for the others to jump through
+		uint32_t rounds = 0, open = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < 16; j++) {                                  // (open: pointers that are not their own source)
+			if ((pp[j] & 0xffff) != x0 + 2 * j) open |= 1u << (2 * j);
+			if ((pp[j] >> 16) != x0 + 2 * j + 1) open |= 2u << (2 * j);
+		}
+		for (;;) {
+			bool moved = false;
+#pragma unroll
+			for (uint32_t j = 0; j < 16; j++) {
+				if (!((open >> (2 * j)) & 3)) continue;
+				uint32_t a = pp[j] & 0xffff, b = pp[j] >> 16;
+				const uint32_t na = a >= base ? P[a - base] : a, nb = b >= base ? P[b - base] : b;   // (a pointer into the first half: the end of its chain)
+				if (na == a) open &= ~(1u << (2 * j));
+				if (nb == b) open &= ~(2u << (2 * j));
+				if (na != a || nb != b) { pp[j] = na | nb << 16; p2[j] = pp[j]; moved = true; }
+			}
+			rounds++;
+			if (!__syncthreads_or(moved)) break;
+		}
+		WGPROF2(P_MWAITS);
+		// every byte from the end of its chain (this lane's 32 bytes: eight dwords of its own)
+		{
+			uint32_t *o4 = L.out + (x0 >> 2);
+#pragma unroll
+			for (uint32_t j = 0; j < 8; j++) {
+				const uint32_t pa = pp[2 * j], pb = pp[2 * j + 1];
+				o4[j] = (uint32_t)ob[pa & 0xffff] | (uint32_t)ob[pa >> 16] << 8 | (uint32_t)ob[pb & 0xffff] << 16 | (uint32_t)ob[pb >> 16] << 24;
+			}
+		}
+		if (prof && tid == 0) L.prof[P_MTRIPS] += rounds;
+		__syncthreads();
 	}
-	if (prof) {
-		atomicAdd(&L.prof[P_MTRIPS], trips); atomicAdd(&L.prof[P_MWAITS], waits); atomicMax(&L.tripmax, trips);
-		if (tid == 0) L.prof[P_MATCHES] += M;
-	}
+#undef WGPROF2
 }
 
 // ---- the header of a dynamic block, by wavefront 0 (the algorithm of nxzi::read_dht; the stream's bits come from LDS):
@@ -675,9 +677,9 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 				}
 				ls[i] = v;
 			}
-			v4u *b0 = (v4u *)L.mstart, *b1 = (v4u *)L.unres;
+			v4u *b0 = (v4u *)L.mstart;
 			const v4u z = { 0, 0, 0, 0 };
-			for (uint32_t i = tid; i < OUT_MAX / 32 / 4; i += NT) { b0[i] = z; b1[i] = z; }
+			for (uint32_t i = tid; i < OUT_MAX / 32 / 4; i += NT) b0[i] = z;
 			if (tid == 0) L.pos = off * 8;
 		}
 		__syncthreads();
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 		}
 		const uint32_t outn = L.outn;
 		if (PROF && tid == 0) L.tripmax = 0;
-		resolve_matches(nres, PROF);
+		resolve_matches(outn, PROF);
 		__syncthreads();
 		if (PROF && tid == 0) L.prof[P_MTRIPMAX] += L.tripmax;
 		if (PROF) WGPROF(P_MATCH);
@@ -817,7 +819,7 @@ extern "C" int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_
 	const char *pe = getenv("NXZ_WG_PMIN");                            // (read at every call: the tests switch it)
 	const unsigned pmin = pe && atoi(pe) >= 64 ? (unsigned)atoi(pe) : 128u;
 	const char *mre = getenv("NXZ_WG_ROUNDS");
-	const unsigned maxr = mre && atoi(mre) >= 2 && atoi(mre) <= 1024 ? (unsigned)atoi(mre) : 32u;
+	const unsigned maxr = mre && atoi(mre) >= 2 && atoi(mre) <= 1024 ? (unsigned)atoi(mre) : 256u;
 	const char *nre = getenv("NXZ_WG_NRES");
 	const unsigned nres = nre && (atoi(nre) & 0xffff) >= 1 && (atoi(nre) & 0xffff) <= nxzw::NT ? (unsigned)atoi(nre) : 1024u;
 	const unsigned grid = (unsigned)(n < cus ? n : cus);

@@ -205,7 +205,7 @@ class Engine:
         d = {names[i]: out[i] / ns for i in range(10)}
         d["total"] = sum(out[i] for i in range(10)) / ns
         d.update(nrounds=out[10] / max(1, out[12]), streams=out[11], blocks=out[12] / ns, pieces=out[13] / max(1, out[12]),
-                 match_trips_sum=out[14] / ns, match_trips_max=out[15] / ns, match_waits=out[16] / ns, matches=out[17] / ns)
+                 jump_rounds=out[14] / ns, jump_cycles=out[16] / ns)
         return d
 
     def inflate_stream(self, src, src_len, dst, first_bit=0, hist=None):
