@@ -195,60 +195,51 @@ __device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *total)
 	return base + inc - v;
 }
 
-// ---- one token: what stands at bit p.  Straight-line but for the two rare sub-table look-ups and the distance look-up
-// (lanes that hold a literal skip it): as a switch over the kind the compiler made 45 scalar instructions of mask
-// bookkeeping per token out of it.  (Measured and not kept: the stream's bits through a 64-bit window in registers that is
-// filled again only when the next look-up can run dry, a third of the LDS reads -- 19 % slower: these passes wait for the
-// chain of dependent look-ups, and the window's 64-bit shifts are in that chain.) ----
-struct Tok { uint32_t kind, next, val, dist; };          // K_LIT: val = the byte; K_LEN: val = length, dist; K_EOB; else: no token (K_INVALID).  next: the bit behind it
-__device__ __forceinline__ Tok token_at(uint32_t p)
-{
-	Tok t;
-	const uint32_t w = p >> 5, sh = p & 31;
-	const uint32_t a = L.src[w], b = L.src[w + 1], c = L.src[w + 2];
-	const uint32_t lo = __builtin_amdgcn_alignbit(b, a, sh), hi = __builtin_amdgcn_alignbit(c, b, sh);
-	uint32_t e = L.lit[lo & ((1u << RL) - 1)];
-	if (e_kind(e) == K_LINK) e = L.lit[(e >> 16) + ((lo >> RL) & ((1u << e_xb(e)) - 1))];
-	const uint32_t nb = e & 31, x = e_xb(e), q = nb + x;                 // (x: 0 unless a length; q <= 20)
-	const bool islen = e_kind(e) == K_LEN;
-	uint32_t d = 0;
-	t.dist = 0;
-	if (islen) {
-		const uint32_t db = __builtin_amdgcn_alignbit(hi, lo, q);
-		d = L.dist[db & ((1u << RD) - 1)];
-		if (e_kind(d) == K_LINK) d = L.dist[(d >> 16) + ((db >> RD) & ((1u << e_xb(d)) - 1))];
-		const uint32_t dl = d & 31, dx = e_xb(d);
-		t.dist = (d >> 16) + ((db >> dl) & ((1u << dx) - 1));             // dl + dx <= 28
-		d = e_kind(d) == K_DIST ? dl + dx : 0xffffffffu;
-	}
-	t.kind = d == 0xffffffffu ? (uint32_t)K_INVALID : e_kind(e);
-	t.val = (e >> 16) + ((lo >> nb) & ((1u << x) - 1));
-	t.next = p + q + (islen ? d : 0);
-	return t;
-}
-
 // ---- one piece: the tokens that start in [st, lim).  Returns end bit | flag << 24 | the bytes they make << 32.
-// WRITE: literals to their place in the output (from obase on), matches parked as records. ----
+// WRITE: literals to their place in the output (from obase on), matches parked as records.
+// A trip round the loop: 64 bits of the source at p (three dwords), the literal/length look-up; behind a LITERAL the next code lies
+// in the same 32 bits, and if that is a literal too the trip takes both (literal-heavy data -- binaries, images -- makes half
+// as many trips: a trip costs 1000-1300 cycles whatever it decodes, the chain of dependent LDS look-ups). ----
 template <bool WRITE>
 __device__ __forceinline__ unsigned long long decode_piece(uint32_t st, uint32_t lim, uint32_t T, uint32_t obase)
 {
 	uint8_t *ob = (uint8_t *)L.out;
 	uint32_t p = st, n = 0, fl = F_OK;
 	while (p < lim) {
-		const Tok t = token_at(p);
-		const bool lit = t.kind == K_LIT, len = t.kind == K_LEN;
-		if (!(lit | len)) { if (t.kind == K_EOB) { p = t.next; fl = F_EOB; } else fl = F_ERR; break; }
+		const uint32_t w = p >> 5, sh = p & 31;
+		const uint32_t a = L.src[w], b = L.src[w + 1], c = L.src[w + 2];
+		const uint32_t lo = __builtin_amdgcn_alignbit(b, a, sh), hi = __builtin_amdgcn_alignbit(c, b, sh);
+		uint32_t e = L.lit[lo & ((1u << RL) - 1)];
+		if (e_kind(e) == K_LINK) e = L.lit[(e >> 16) + ((lo >> RL) & ((1u << e_xb(e)) - 1))];
+		const uint32_t nb = e & 31, kind = e_kind(e);
+		if (kind == K_LIT) {
+			if (WRITE) ob[obase + n] = (uint8_t)(e >> 16);
+			n++; p += nb;
+			// the code behind it (its 15 bits at most are among the 32 at hand): a literal again?
+			const uint32_t e2 = L.lit[(lo >> nb) & ((1u << RL) - 1)];
+			if (e_kind(e2) == K_LIT && p < lim) {
+				if (WRITE) ob[obase + n] = (uint8_t)(e2 >> 16);
+				n++; p += e2 & 31;
+			}
+			continue;
+		}
+		if (kind != K_LEN) { if (kind == K_EOB) { p += nb; fl = F_EOB; } else fl = F_ERR; break; }
+		const uint32_t x = e_xb(e), q = nb + x;                            // (q <= 20)
+		const uint32_t len = (e >> 16) + ((lo >> nb) & ((1u << x) - 1));
+		const uint32_t db = __builtin_amdgcn_alignbit(hi, lo, q);
+		uint32_t d = L.dist[db & ((1u << RD) - 1)];
+		if (e_kind(d) == K_LINK) d = L.dist[(d >> 16) + ((db >> RD) & ((1u << e_xb(d)) - 1))];
+		if (e_kind(d) != K_DIST) { fl = F_ERR; break; }
+		const uint32_t dl = d & 31, dx = e_xb(d);
+		const uint32_t dist = (d >> 16) + ((db >> dl) & ((1u << dx) - 1));     // dl + dx <= 28
 		if (WRITE) {
 			const uint32_t at = obase + n;
-			if (lit) ob[at] = (uint8_t)t.val;
-			else {
-				if (t.dist > at) { fl = F_ERR; break; }
-				ob[at] = (uint8_t)(t.val - 3); ob[at + 1] = (uint8_t)(t.dist - 1); ob[at + 2] = (uint8_t)((t.dist - 1) >> 8);
-				atomicOr(&L.mstart[at >> 5], 1u << (at & 31));
-			}
+			if (dist > at) { fl = F_ERR; break; }
+			ob[at] = (uint8_t)(len - 3); ob[at + 1] = (uint8_t)(dist - 1); ob[at + 2] = (uint8_t)((dist - 1) >> 8);
+			atomicOr(&L.mstart[at >> 5], 1u << (at & 31));
 		}
-		n += lit ? 1u : t.val;
-		p = t.next;
+		n += len;
+		p += q + dl + dx;
 	}
 	if (p > T) fl = F_RUNOUT;            // the last token reaches beyond the source
 	return (unsigned long long)(p | fl << 24) | (unsigned long long)n << 32;
@@ -340,9 +331,11 @@ NXZ_WG_PHASE void resolve_matches(uint32_t outn, int prof)
 			for (uint32_t j = 0; j < 16; j++) {
 				if (!((open >> (2 * j)) & 3)) continue;
 				uint32_t a = pp[j] & 0xffff, b = pp[j] >> 16;
-				const uint32_t na = a >= base ? P[a - base] : a, nb = b >= base ? P[b - base] : b;   // (a pointer into the first half: the end of its chain)
-				if (na == a) open &= ~(1u << (2 * j));
-				if (nb == b) open &= ~(2u << (2 * j));
+				// two links a round (the rounds' barriers and the sixteen blocks of this loop cost more than the look-ups once few
+				// pointers are still open)
+				uint32_t na = a >= base ? P[a - base] : a, nb = b >= base ? P[b - base] : b;   // (a pointer into the first half: the end of its chain)
+				if (na == a) open &= ~(1u << (2 * j)); else { const uint32_t n2 = na >= base ? P[na - base] : na; if (n2 == na) open &= ~(1u << (2 * j)); na = n2; }
+				if (nb == b) open &= ~(2u << (2 * j)); else { const uint32_t n2 = nb >= base ? P[nb - base] : nb; if (n2 == nb) open &= ~(2u << (2 * j)); nb = n2; }
 				if (na != a || nb != b) { pp[j] = na | nb << 16; p2[j] = pp[j]; moved = true; }
 			}
 			rounds++;
