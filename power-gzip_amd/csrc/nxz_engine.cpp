@@ -217,7 +217,6 @@ static constexpr unsigned JOB_COUNTERS = 256;
 #define NXZ_LANES_MIN 49152
 #define NXZ_LANES_TABLES_MIN 163840   /* streams that bring tables: the lane kernel from here on */
 #define NXZ_WINDOW_LDS_MAX 1024
-#define NXZ_WG_MAX 8192             /* batches of at most this many streams: a stream per workgroup (nxz_inflate_wg.hip) */
 
 static std::mutex g_mtx;
 static nxz_ctx *g_ctx[64];
@@ -612,16 +611,33 @@ static int batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n,
 	const size_t lanes_min = lm ? (size_t)strtoull(lm, nullptr, 0) : (size_t)NXZ_LANES_MIN;
 	bool lanes = force ? (force & 3) == 1 : n >= lanes_min, by_len = (force & 4) != 0, no_tables = false;
 	bool split = false;
-	// A stream per WORKGROUP, source, output and tables in LDS (nxz_inflate_wg.hip): batches of up to NXZ_WG_MAX streams, unless one of
-	// the older routes' knobs is set (the tests' way to name a route).  That kernel runs at one rate from a few hundred streams on (a
-	// CU a stream: 40-50 GiB/s on zlib -6 streams of the corpus, 65-75 on fixed-code blocks, profiles/r06_inflate_by_batch_size.txt),
-	// where a stream per wavefront needs 16 384 streams to get there and a stream per lane 100 000; above, the older kernels are ahead.
-	// What it does not do -- streams that resume, bring a history, are longer than 64 KiB on either side, end early or are damaged --
-	// it hands back, and those go a stream per wavefront behind it.  NXZ_INFLATE_WG=0 / 1: never / whatever the batch's size.
+	// A stream per WORKGROUP, source, output and tables in LDS (nxz_inflate_wg.hip): every batch, unless one of the older routes' knobs
+	// is set (the tests' way to name a route) -- except batches of NXZ_LANES_MIN streams and more whose sampled streams begin with
+	// fixed-code or stored blocks: those stay the fixed-code lane kernel's.  That kernel runs at one rate from a few thousand streams
+	// on (a CU a stream; profiles/r06_inflate_by_batch_size.txt: zlib -6 streams of the corpus 78 GiB/s from 4096 streams on, own
+	// exact-table streams 69 at 16 384 and 100 at 262 144, fixed-code synthetic blocks 111-117), where a stream per wavefront needs
+	// 16 384 streams for 56 and levels off at 66, and a stream per lane needs 100 000; only fixed-code streams by the hundred thousand
+	// (154-178 a stream per lane) and zlib -6 streams at 262 144 (85, both older kernels side by side) are ahead of it.  What it does not
+	// do -- streams that resume, bring a history, are longer than 64 KiB on either side, end early or are damaged -- it hands back, and
+	// those go a stream per wavefront behind it.  NXZ_INFLATE_WG=0 / 1: never / always; NXZ_INFLATE_WG_MAX: batches up to that size only.
 	const char *wge = getenv("NXZ_INFLATE_WG");                         // (read at every call: the tests switch it)
 	const char *wgm = getenv("NXZ_INFLATE_WG_MAX");
-	const size_t wg_max = wgm ? (size_t)strtoull(wgm, nullptr, 0) : (size_t)NXZ_WG_MAX;
-	if (!force && (wge ? atoi(wge) != 0 : (!lm && !getenv("NXZ_INFLATE_CUT") && n <= wg_max))) {
+	const size_t wg_max = wgm ? (size_t)strtoull(wgm, nullptr, 0) : ~(size_t)0;
+	bool wg = !force && (wge ? atoi(wge) != 0 : (!lm && !getenv("NXZ_INFLATE_CUT") && n <= wg_max));
+	if (wg && !wge && n >= lanes_min) {
+		// (the sample the older routes take below: here only "do these streams bring tables?")
+		uint32_t *h = nullptr;
+		{
+			std::lock_guard<std::mutex> g(c->mtx);
+			if (!c->h_sample) (void)hipHostMalloc((void **)&c->h_sample, 64 * sizeof(uint32_t));
+			h = c->h_sample ? c->h_sample + 4 * (c->sample_turn++ & 15) : nullptr;
+		}
+		if (h) {
+			h[0] = 0; h[1] = 0; h[2] = 0;
+			if (nxz_launch_sample_btype(jobs, n, h, s) == 0 && hipStreamSynchronize(s) == hipSuccess && h[0] <= 16) wg = false;
+		}
+	}
+	if (wg) {
 		std::mutex *use_mtx;
 		{
 			std::lock_guard<std::mutex> g(c->mtx);

@@ -9,7 +9,7 @@ import threading
 import time
 import zlib
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import zstream as Z  # noqa: E402
 import corpus  # noqa: E402

@@ -2,7 +2,7 @@
 gzip members in host memory (memcpy to pinned staging, PCIe both ways, kernels, packing), and back.
 usage: python tools/bench_blocked.py [MiB] [fixed]"""
 import ctypes as C, os, sys, time, gzip
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench

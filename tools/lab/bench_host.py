@@ -4,7 +4,7 @@ overlap the kernels.  (The bench `value` is the device-resident rate; this is th
 usage: python tools/bench_host.py [blocks] [chunk]"""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench

@@ -1,7 +1,7 @@
 """Throughput of the inflate engine on the deflate engine's own output (and on zlib level-6 streams)."""
 import importlib, os, sys, time, zlib
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench

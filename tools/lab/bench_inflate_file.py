@@ -1,7 +1,7 @@
 """Wave-kernel inflate time of 64 KiB pieces of a FILE (zlib -6 raw streams), a stream per wave:
 window in LDS against the target as window.  usage: bench_inflate_file.py <file> [offset]"""
 import importlib, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
 import importlib, os, sys, time, zlib
 import numpy as np

@@ -3,7 +3,7 @@ lane (nxz_inflate_lanes.hip) and a stream per wave (nxz_inflate.hip).  The engin
 them at NXZ_LANES_MIN streams (nxz_engine.cpp; NXZ_INFLATE_LANES_MIN overrides it for this sweep).
 usage: python tools/bench_inflate_sizes.py   (spawns one child per kernel)"""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
 import importlib, os, sys, time, zlib
 import numpy as np

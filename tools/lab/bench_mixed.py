@@ -6,7 +6,7 @@ stored copies with the WRAP function code -- what the library does per job (lib/
 usage: python tools/bench_mixed.py [blocks]"""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench

@@ -2,7 +2,7 @@
 """Deflate pipeline by function code on bench.py's synthetic blocks: fixed Huffman (LZ77 kernel ->
 entropy kernel) and the DHTGEN code (LZ77 + counts -> device dhtgen -> entropy)."""
 import importlib, json, os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 

@@ -3,7 +3,7 @@
 corpus data (tests/corpus.py) repeated to `mib` MiB, compressed by zlib at `level` as ONE raw stream,
 inflated on the device, compared bit for bit, CRC-32 against zlib's.  usage: bench_stream.py [mib] [level]"""
 import importlib, json, os, sys, time, zlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch

@@ -1,7 +1,7 @@
 """nx_uncompress of ONE zlib -6 stream by size of the data (host buffers): where the parallel path pays.
 usage: python tools/bench_uncompress_sizes.py"""
 import ctypes as C, os, sys, time, zlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import zstream as Z
 import corpus

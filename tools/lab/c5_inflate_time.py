@@ -2,7 +2,7 @@
 through the fixed-code deflate, what shrank through the batched inflate; milliseconds per pass.  NXZ_ENGINE_LIB picks another
 build of the engine (tools/build_variant.sh) for an A/B.  usage: python tools/c5_inflate_time.py"""
 import importlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch, bench
 pkg = importlib.import_module("power-gzip_amd")

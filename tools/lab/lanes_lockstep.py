@@ -3,7 +3,7 @@ wavefronts issue?  40 960 fixed-code text streams a lane each, once all differen
 for all 64 lanes of a load, and the lanes run dry together): round 4, before the kernels were rebuilt, 99.8 ms against 57.3
 (DESIGN.md section 6).  usage: python tools/lanes_lockstep.py"""
 import importlib, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ["NXZ_INFLATE_LANES_MIN"] = "1"
 import numpy as np, torch, bench
