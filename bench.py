@@ -52,8 +52,10 @@ _copy_peak = None
 def copy_peak_gbs(torch, dev, eng=None):
     """the achievable HBM figure, measured on this box with a copy kernel (1 GiB device to device, read +
     written bytes over the time of the copy by HIP events on the copy's stream).  The engine's own copy kernel -- 16 bytes a
-    lane, eight workgroups a CU, the form MI355X_MICROARCH.md measured 6.29 TB/s with -- when an engine is at hand (the runtime's
-    device-to-device memcpy, which rounds 1-5 took, reads 5.0-5.2 TB/s on the same boxes); the better of the two."""
+    lane, six workgroups a CU, nontemporal -- when an engine is at hand, an elementwise torch kernel, and the runtime's
+    device-to-device memcpy (which rounds 1-5 took alone: 4.8-5.5 TB/s on these boxes, the kernels 6.0); the best of the three.
+    (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy; tools/lab/copy_peak.py: no grid or unrolling reached more than
+    6.04 here.)"""
     global _copy_peak
     if _copy_peak is None:
         n = 1 << 30
@@ -61,7 +63,8 @@ def copy_peak_gbs(torch, dev, eng=None):
         b = torch.empty(n, dtype=torch.uint8, device=dev)
         a.zero_()
         best = 0.0
-        for copy in ([lambda: b.copy_(a)] + ([lambda: eng.copy_device(b, a)] if eng is not None else [])):
+        a32, b32 = a.view(torch.float32), b.view(torch.float32)
+        for copy in ([lambda: b.copy_(a), lambda: torch.add(a32, 0.0, out=b32)] + ([lambda: eng.copy_device(b, a)] if eng is not None else [])):
             copy()
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -700,7 +703,7 @@ def api_leg(raw, args, mib=256, nthreads=16, raw_r04=None):
                 t = time.perf_counter()
                 ok = L.nx_uncompress(d, C.byref(n), zbig[k % len(zbig)], len(zbig[k % len(zbig)])) == 0
                 t_first[k] = time.perf_counter() - t
-                gate.wait()
+                gate.wait(timeout=120)
                 for i in range(len(big)):
                     z = zbig[(i + k) % len(zbig)]
                     n = C.c_ulong(size)
@@ -715,7 +718,7 @@ def api_leg(raw, args, mib=256, nthreads=16, raw_r04=None):
                 t = time.perf_counter()
                 ok = L.nx_compress2(d, C.byref(c), big[k % len(big)], size, 1) == 0
                 t_first[k] = time.perf_counter() - t
-                gate.wait()
+                gate.wait(timeout=120)
                 for i in range(len(big)):
                     b = big[(i + k) % len(big)]
                     c.value = len(d)
@@ -730,7 +733,14 @@ def api_leg(raw, args, mib=256, nthreads=16, raw_r04=None):
             t_first = [0.0] * nthreads
             clock = [0.0]
             gate = threading.Barrier(nthreads, action=lambda: clock.__setitem__(0, time.perf_counter()))
-            th = [threading.Thread(target=worker_big, args=(res, k, inflate, gate, t_first)) for k in range(nthreads)]
+            def guarded(*a, gate=gate, res=res):
+                # (a worker that raises before the gate must not leave the others waiting there)
+                try:
+                    worker_big(*a)
+                except Exception:                                           # noqa: BLE001 -- any failure: the leg reports it
+                    gate.abort()
+                    res[a[1]] = -1
+            th = [threading.Thread(target=guarded, args=(res, k, inflate, gate, t_first)) for k in range(nthreads)]
             for x in th:
                 x.start()
             for x in th:
@@ -740,7 +750,8 @@ def api_leg(raw, args, mib=256, nthreads=16, raw_r04=None):
                 return dict(out, error="a %d MiB call failed in a thread" % (size >> 20))
             out["threads_%d_x_%dMiB_%s" % (nthreads, size >> 20, "uncompress" if inflate else "compress2")] = {
                 "value": round(sum(res) / dt / 2.0 ** 30, 3), "unit": "GiB/s uncompressed, all threads", "us_per_call": round(dt / len(big) * 1e6, 1),
-                "calls_per_thread": len(big), "first_calls_ms": round(max(t_first) * 1e3, 1)}
+                "calls_per_thread": len(big), "first_calls_ms": round(max(t_first) * 1e3, 1), "warm": True,
+                "value_incl_first_calls": round(sum(res) * (len(big) + 1) / len(big) / (dt + max(t_first)) / 2.0 ** 30, 3)}
     # what these calls left idle on the device (the one-stream workspaces of sixteen callers, the hosts' lanes) goes back before the legs
     # that size themselves by the device's free memory (c2 at its stated 2^20 blocks wants 212 GiB free)
     try:

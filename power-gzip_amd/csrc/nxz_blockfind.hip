@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64) void check_headers_kernel(const uint8_t *__rest
 							    uint32_t nseg, uint32_t seg_bytes, const uint16_t *__restrict__ left)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s[SEG + LOOK + 16];
-	__shared__ uint32_t best, npass, pass[16];
+	__shared__ uint32_t best, npass;
 	const int t = threadIdx.x;
 	const uint32_t seg = blockIdx.x;
 	if (seg >= nseg) return;
@@ -468,27 +468,31 @@ __global__ __launch_bounds__(64) void check_headers_kernel(const uint8_t *__rest
 	// `first`: packed data -- deflate streams carried inside stored blocks -- puts headers that are none in front of the
 	// block's that follows the stored run, in the same segment; that block's start went unseen, and the block was decoded
 	// in a later round, as one piece)
-	if (t == 0) npass = 0;
-	__syncthreads();
-	for (uint32_t k = t; k < n; k += 64) {
+	// (which ones: the NXZ_BLOCKFIND_MORE LAST passers, found by as many rounds of a maximum below the one before -- the first form kept
+	// the first sixteen passers in the order they arrived in, so that with more than sixteen the pieces, the rounds and the timings of
+	// nxz_inflate_stream differed from run to run, and a late true header could be lost to early false ones: advisor finding of round 5)
+	uint64_t mine = 0;                                   // this lane's candidates that passed, by their index k / 64 (a segment leaves LEFT_MAX at most)
+	for (uint32_t k = t, i = 0; k < n; k += 64, i++) {
 		const uint32_t p = o[2 + k];
-		if (header_ok(s, p, limit, 0xffffffffu)) { atomicMin(&best, p); const uint32_t at = atomicAdd(&npass, 1u); if (at < 16) pass[at] = p; }
+		if (header_ok(s, p, limit, 0xffffffffu)) { atomicMin(&best, p); if (i < 64) mine |= 1ull << i; }
 	}
 	__syncthreads();
-	if (t == 0) {
-		first[seg] = best == 0xffffffffu ? ~0ull : base * 8 + best;
-		// the others, the last ones first (what follows a stored run lies behind what the run holds)
-		uint32_t m = npass < 16 ? npass : 16, got = 0;
-		uint64_t *more = first + nseg + (size_t)seg * NXZ_BLOCKFIND_MORE;
-		for (uint32_t j = 0; j < NXZ_BLOCKFIND_MORE; j++) more[j] = ~0ull;
-		while (got < NXZ_BLOCKFIND_MORE) {
-			uint32_t hi = 0, at = 0xffffffffu;
-			for (uint32_t j = 0; j < m; j++) if (pass[j] != 0xffffffffu && pass[j] != best && pass[j] >= hi) { hi = pass[j]; at = j; }
-			if (at == 0xffffffffu) break;
-			more[got++] = base * 8 + pass[at];
-			pass[at] = 0xffffffffu;
+	uint64_t *more = first + nseg + (size_t)seg * NXZ_BLOCKFIND_MORE;
+	uint32_t below = 0xffffffffu;
+	for (uint32_t j = 0; j < NXZ_BLOCKFIND_MORE; j++) {
+		if (t == 0) npass = 0;                               // (npass: this round's maximum + 1, 0: none)
+		__syncthreads();
+		for (uint64_t m = mine; m; m &= m - 1) {
+			const uint32_t p = o[2 + t + 64 * (uint32_t)__builtin_ctzll(m)];
+			if (p != best && p < below) atomicMax(&npass, p + 1);
 		}
+		__syncthreads();
+		const uint32_t got = npass;
+		if (t == 0) more[j] = got ? base * 8 + (got - 1) : ~0ull;
+		below = got ? got - 1 : 0;
+		__syncthreads();
 	}
+	if (t == 0) first[seg] = best == 0xffffffffu ? ~0ull : base * 8 + best;
 }
 
 // A run of stored blocks is followed header by header (a thread per request; LEN tells where the next header

@@ -536,13 +536,23 @@ static size_t trim_compress_scratch()
 		}
 		for (auto &sm : streams) {
 			if (!sm.second->try_lock()) continue;              // a call is sizing or launching on that stream
-			(void)hipStreamSynchronize(sm.first);
+			// (a stream the caller has destroyed meanwhile -- nxz_stream_destroy drops its entry, a stream of the caller's own may be gone
+			// without a word: a failed wait means "leave it alone")
+			bool there;
 			{
 				std::lock_guard<std::mutex> g2(c->mtx);
-				nxz_ctx::Scratch &r = c->scratch[sm.first];
-				if (r.d_tokens) freed += r.chunk_cap * ((size_t)NXZ_TOK_STRIDE + sizeof(nxz_dht_prepared_t) + 316 * sizeof(uint32_t));
-				r.release_chunk();
-				r.chunk_limit = 0;
+				there = c->scratch.find(sm.first) != c->scratch.end();
+			}
+			if (there && hipStreamSynchronize(sm.first) != hipSuccess) { (void)hipGetLastError(); there = false; }
+			if (there) {
+				std::lock_guard<std::mutex> g2(c->mtx);
+				auto it = c->scratch.find(sm.first);               // (find, not []: an entry that went away in between stays away)
+				if (it != c->scratch.end()) {
+					nxz_ctx::Scratch &r = it->second;
+					if (r.d_tokens) freed += r.chunk_cap * ((size_t)NXZ_TOK_STRIDE + sizeof(nxz_dht_prepared_t) + 316 * sizeof(uint32_t));
+					r.release_chunk();
+					r.chunk_limit = 0;
+				}
 			}
 			sm.second->unlock();
 		}

@@ -543,21 +543,23 @@ extern "C" int nxz_launch_pack_members(const nxz_batch_job_t *jobs, const nxz_ba
 	return (int)hipGetLastError();
 }
 
-// ---- the achievable HBM figure (bench.py's roofline: peak_measured): a device-to-device copy, 16 bytes a lane, a grid of eight
+// ---- the achievable HBM figure (bench.py's roofline: peak_measured): a device-to-device copy, 16 bytes a lane, a grid of a few
 // workgroups a CU that strides through the buffer (MI355X_MICROARCH.md: 6.29 TB/s of read + written bytes this way) ----
 namespace nxz {
 typedef uint32_t copy_v4 __attribute__((ext_vector_type(4)));
+template <bool NT, int U>
 __global__ __launch_bounds__(256) void copy16_kernel(const copy_v4 *__restrict__ src, copy_v4 *__restrict__ dst, size_t n16)
 {
 	const NXZ_GLOBAL_AS copy_v4 *s = (const NXZ_GLOBAL_AS copy_v4 *)src;
 	NXZ_GLOBAL_AS copy_v4 *d = (NXZ_GLOBAL_AS copy_v4 *)dst;
 	const size_t stride = (size_t)gridDim.x * 256;
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	for (; i + 3 * stride < n16; i += 4 * stride) {
-		const copy_v4 a = __builtin_nontemporal_load(&s[i]), b = __builtin_nontemporal_load(&s[i + stride]),
-			      c = __builtin_nontemporal_load(&s[i + 2 * stride]), e = __builtin_nontemporal_load(&s[i + 3 * stride]);
-		__builtin_nontemporal_store(a, &d[i]); __builtin_nontemporal_store(b, &d[i + stride]);
-		__builtin_nontemporal_store(c, &d[i + 2 * stride]); __builtin_nontemporal_store(e, &d[i + 3 * stride]);
+	for (; i + (U - 1) * stride < n16; i += U * stride) {
+		copy_v4 v[U];
+#pragma unroll
+		for (int k = 0; k < U; k++) v[k] = NT ? __builtin_nontemporal_load(&s[i + k * stride]) : s[i + k * stride];
+#pragma unroll
+		for (int k = 0; k < U; k++) { if (NT) __builtin_nontemporal_store(v[k], &d[i + k * stride]); else d[i + k * stride] = v[k]; }
 	}
 	for (; i < n16; i += stride) d[i] = s[i];
 }
@@ -566,6 +568,19 @@ extern "C" int nxz_launch_copy16(const void *src, void *dst, size_t bytes, hipSt
 {
 	if (((uintptr_t)src | (uintptr_t)dst | bytes) & 15) return (int)hipErrorInvalidValue;
 	static const unsigned cus = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(v > 0 ? v : 256); }();
-	hipLaunchKernelGGL(nxz::copy16_kernel, dim3(cus * 8), dim3(256), 0, stream, (const nxz::copy_v4 *)src, (nxz::copy_v4 *)dst, bytes / 16);
+	// (NXZ_COPY_VARIANT, measurements: grid per CU * 100 + nontemporal * 10 + unroll)
+	const char *e = getenv("NXZ_COPY_VARIANT");
+	const int var = e ? atoi(e) : 611;      // (six workgroups a CU, nontemporal, one 16-byte load and store in flight a lane: 6.04 TB/s; eight a CU with four in flight 4.6, the runtime's memcpy 4.8-5.5: tools/lab/copy_peak.py)
+	const unsigned per_cu = (unsigned)(var / 100 > 0 ? var / 100 : 8);
+	const bool nt = (var / 10) % 10 != 0;
+	const int u = var % 10;
+	const dim3 g(cus * per_cu), b(256);
+	const nxz::copy_v4 *sp = (const nxz::copy_v4 *)src; nxz::copy_v4 *dp = (nxz::copy_v4 *)dst; const size_t n16 = bytes / 16;
+	if (nt && u >= 4) hipLaunchKernelGGL((nxz::copy16_kernel<true, 4>), g, b, 0, stream, sp, dp, n16);
+	else if (nt && u == 2) hipLaunchKernelGGL((nxz::copy16_kernel<true, 2>), g, b, 0, stream, sp, dp, n16);
+	else if (nt) hipLaunchKernelGGL((nxz::copy16_kernel<true, 1>), g, b, 0, stream, sp, dp, n16);
+	else if (u >= 4) hipLaunchKernelGGL((nxz::copy16_kernel<false, 4>), g, b, 0, stream, sp, dp, n16);
+	else if (u == 2) hipLaunchKernelGGL((nxz::copy16_kernel<false, 2>), g, b, 0, stream, sp, dp, n16);
+	else hipLaunchKernelGGL((nxz::copy16_kernel<false, 1>), g, b, 0, stream, sp, dp, n16);
 	return (int)hipGetLastError();
 }

@@ -212,7 +212,9 @@ struct TrimOnExit {
 		};
 		const bool quiet = busy == 0;
 		if (quiet && w.dev_cap && (w.dev_cap > keep_bytes() || idle_now() > idle_bytes())) drop(w);
-		if (!quiet && idle_now() <= idle_bytes()) return;           // (others at work and nothing over the budget: no walk)
+		// (others at work: still a walk -- a workspace beyond what ONE may keep that has lain idle for two seconds goes whatever the
+		// total is: under steady load from many threads the call that leaves the device quiet may never come, and the 8-9 GiB
+		// workspaces of callers long gone stayed for good)
 		for (int k = 0; k < NWS; k++) {
 			Workspace &o = g_ws[dev][k];
 			if (&o == &w || !o.dev_cap || !o.mtx.try_lock()) continue;
@@ -234,11 +236,13 @@ extern "C" size_t nxz_pinflate_trim(void)
 	for (int d = 0; d < 64; d++)
 		for (int k = 0; k < NWS; k++) {
 			Workspace &w = g_ws[d][k];
-			if (!w.dev && !w.built) continue;
+			if (!w.dev && !w.built && !w.rc_pin && !w.rc_dev) continue;
 			if (!w.mtx.try_lock()) continue;
 			if (hipSetDevice(d) == hipSuccess) {
 				if (w.dev) { freed += w.dev_cap; g_ws_bytes -= w.dev_cap; (void)hipFree(w.dev); w.dev = nullptr; w.dev_cap = 0; }
 				if (w.built) { freed += w.built_cap; (void)hipFree(w.built); w.built = nullptr; w.built_cap = 0; }
+				if (w.rc_pin) { (void)hipHostFree(w.rc_pin); w.rc_pin = nullptr; }
+				if (w.rc_dev) { (void)hipFree(w.rc_dev); w.rc_dev = nullptr; }
 			}
 			w.mtx.unlock();
 		}
