@@ -1790,7 +1790,9 @@ static int round_run_inflate(nxz_ctx *c, nxz_ctx::Round &R, std::vector<InflateR
 	bool wg = wg_on;
 	for (size_t k = 0; k < n && wg; k++) {
 		const nxz_batch_job_t &j = v[k]->job;
-		if (j.resume || j.hist_len || j.src_len > 65000 || j.dst_cap > 65536 || !v[k]->d_out) wg = false;
+		// (the target: what a caller with 64 KiB of room hands a job -- its room, a window and a quarter, lib/nx_inflate.c's fifo_out; a
+		// stream that makes more than 64 KiB after all is handed back by the kernel and costs a wavefront's 3-8 ms)
+		if (j.resume || j.hist_len || j.src_len > 65000 || j.dst_cap > 65536 + 40960 || !v[k]->d_out) wg = false;
 	}
 	if (wg && !R.h_targets && hipHostMalloc((void **)&R.h_targets, ROUND_MAX * sizeof(uint8_t *)) != hipSuccess) { (void)hipGetLastError(); R.h_targets = nullptr; wg = false; }
 	if (wg && !R.d_wg && hipMalloc((void **)&R.d_wg, nxz_inflate_wg_workspace(ROUND_MAX)) != hipSuccess) { (void)hipGetLastError(); R.d_wg = nullptr; wg = false; }
