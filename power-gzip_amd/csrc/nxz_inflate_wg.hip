@@ -87,8 +87,14 @@ struct __attribute__((aligned(16))) Lds {
 	uint16_t lsym[288], dsym[32];
 	uint8_t lens[320];
 	uint32_t wsum[NW];
+	uint32_t nout[NT];                  // the rounds: the bytes every piece makes
+	uint16_t list[NT];                  // the rounds: the pieces to decode again (piece | start - first bit << 10)
+	uint32_t nredo[2];
 	// wave-uniform scalars, written by one thread in front of a barrier
 	uint32_t jid, bail, pos, outn, bfinal, btype, st_len, hlit, hdist, firstbad;
+	// the stream in parts: the window of the source (its first byte's offset, its bits, does it reach the stream's end, is it there),
+	// the output (bytes of it in front of LDS position 0, the first LDS position memory does not have yet, the lowest a distance may reach)
+	uint32_t wb, wbits, wend, wvalid, aoff, fl0, lowest, inblock, act, cut, stall, done;
 	uint32_t span_m, span_len, span_dist;   // the match that reaches from the first half of the output into the second
 	uint32_t prof[P_N], tprev[2], tripmax;
 };
@@ -257,13 +263,13 @@ NXZ_WG_PHASE unsigned long long piece_write(uint32_t st, uint32_t lim, uint32_t 
 // the room the source no longer needs holds them for 32 KiB of output, so the output goes in two halves; pointers of the
 // second half into the first are ends of their chains (those bytes are final by then). ----
 constexpr uint32_t HALF = 32768;
-NXZ_WG_PHASE void resolve_matches(uint32_t outn, int prof)
+NXZ_WG_PHASE void resolve_matches(uint32_t from, uint32_t outn, int prof)
 {
 	const int tid = threadIdx.x;
 	uint8_t *ob = (uint8_t *)L.out;
 	uint16_t *P = (uint16_t *)L.src;
 #define WGPROF2(idx) do { if (prof && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; L.prof[idx] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); } } while (0)
-	for (uint32_t base = 0; base < outn; base += HALF) {
+	for (uint32_t base = from; base < outn; base += HALF) {
 		// A lane owns 32 bytes of the half -- one word of the bitmap of match starts, 32 pointers (16 registers), eight dwords
 		// of the output -- and makes ITS pointers: the match that reaches into its bytes from in front (the last start within 258
 		// bytes, if it is long enough; from the other half: the one match saved when that half was done), then the matches that
@@ -559,13 +565,21 @@ NXZ_WG_PHASE void build_tables(int hlit, int hdist)
 	__syncthreads();
 }
 
-// ---- a Huffman-coded block whose tables stand: the pieces in rounds, the prefix sum, the writing pass.  Leaves L.outn and
-// L.pos behind the block, or a reason in L.bail. ----
-NXZ_WG_PHASE void decode_block(uint32_t T, uint32_t cap, uint32_t pmin_bits, uint32_t max_rounds, int prof)
+// what a span leaves for the stream's loop to do next: the block is over; the block goes on (behind the span, or behind the
+// window); the output in LDS must go to memory first
+enum { A_NEXT = 0, A_MORE = 1, A_FLUSH = 2 };
+
+// ---- a span of a Huffman-coded block whose tables stand: at most spanbits of the window from L.pos on (T: the window's bits) --
+// the pieces in rounds, the prefix sum, the writing pass for as many pieces as the room in LDS takes (a piece is all there or not
+// at all: a match never lies across a flush).  Leaves L.outn and L.pos behind the last piece written and L.act, or a reason in
+// L.bail.  capleft: what the job's target still takes. ----
+NXZ_WG_PHASE void decode_span(uint32_t T, uint32_t spanbits, uint32_t capleft, uint32_t pmin_bits, uint32_t max_rounds, int prof)
 {
 	const int tid = threadIdx.x;
 #define WGPROF(idx) do { if (prof && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; L.prof[idx] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); } } while (0)
-	const uint32_t cur = L.pos, R = T - cur;
+	const uint32_t cur = L.pos, R = T - cur < spanbits ? T - cur : spanbits, E = cur + R;
+	const uint32_t outn = L.outn, room = OUT_MAX - outn;
+	const bool wend = L.wend != 0;
 	uint32_t np0 = R / pmin_bits;
 	np0 = np0 < 1 ? 1 : np0 > (uint32_t)NT ? (uint32_t)NT : np0;
 	const uint32_t pdw = (((R + np0 - 1) / np0 + 31) >> 5) | 1;          // dwords a piece, odd: neighbours begin in different LDS banks
@@ -573,26 +587,51 @@ NXZ_WG_PHASE void decode_block(uint32_t T, uint32_t cap, uint32_t pmin_bits, uin
 	const uint32_t NP = (R + P - 1) / P ? (R + P - 1) / P : 1;
 	const bool active = (uint32_t)tid < NP;
 	const uint32_t g = cur + (uint32_t)tid * P;
-	const uint32_t lim = (uint32_t)tid + 1 == NP ? T : g + P;
+	const uint32_t lim = (uint32_t)tid + 1 == NP ? E : g + P;
 	uint32_t st = g, no = 0, pe = F_ERR << 24;
-	if (active) { const unsigned long long r = piece_count(st, lim, T); pe = (uint32_t)r; no = (uint32_t)(r >> 32); L.pend[tid] = pe; }
-	if (tid == 0) L.firstbad = NP;
+	if (active) { const unsigned long long r = piece_count(st, lim, T); pe = (uint32_t)r; L.pend[tid] = pe; L.nout[tid] = (uint32_t)(r >> 32); }
+	if (tid == 0) { L.firstbad = NP; L.cut = NT; L.nredo[0] = 0; L.nredo[1] = 0; }
 	WGPROF(P_FIRST);
 	if (prof && tid == 0) L.prof[P_PIECES] += NP;
+	// The rounds: a piece whose neighbour in front ended elsewhere than the piece began is decoded again from there.  Who must go
+	// again is scattered over the wavefronts and fewer every round: the pieces to do go on a list and the first lanes take one
+	// each -- after the second round a wavefront or two decode while the others wait at the barrier, and a wavefront that has
+	// the CU's LDS to itself makes its trips three times as fast.
 	uint32_t rounds = 0;
 	for (;;) {
 		__syncthreads();
+		const uint32_t par = rounds & 1;
 		bool redo = false;
 		if (active && tid > 0) {
 			const uint32_t prev = L.pend[tid - 1];
 			if ((prev >> 24) == F_OK && (prev & 0xffffff) != st) { st = prev & 0xffffff; redo = true; }
 		}
-		if (!__syncthreads_or(redo)) break;
+		{
+			const unsigned long long m = __ballot(redo);
+			if (m) {
+				uint32_t base = 0;
+				if ((tid & 63) == 0) base = atomicAdd(&L.nredo[par], (uint32_t)__popcll(m));
+				base = __shfl(base, 0, 64);
+				// (a piece's new start lies within a token of its first bit: 6 bits beside the piece's number)
+				if (redo) L.list[base + (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1))] = (uint16_t)((uint32_t)tid | (st - g) << 10);
+			}
+		}
+		__syncthreads();
+		const uint32_t cnt = L.nredo[par];
+		if (!cnt) break;
 		// (data whose codes are all of a length -- packed bytes under 8-bit codes -- never falls in step: such a block is the
 		// stream-per-wavefront kernel's, whose literal step takes it at full rate, and the sooner it goes there the better)
 		if (++rounds > max_rounds) { if (tid == 0) L.bail = R_ROUNDS; break; }
-		if (redo) { const unsigned long long r = piece_count(st, lim, T); pe = (uint32_t)r; no = (uint32_t)(r >> 32); L.pend[tid] = pe; }
+		if (tid == 0) { L.nredo[par ^ 1] = 0; if (prof) { L.prof[P_MATCHES] += cnt; if (rounds <= 2) L.prof[P_MTRIPMAX] += cnt; } }
+		if ((uint32_t)tid < cnt) {
+			const uint32_t ent = L.list[tid], j = ent & 1023;
+			const uint32_t gj = cur + j * P, limj = j + 1 == NP ? E : gj + P;
+			const unsigned long long r = piece_count(gj + (ent >> 10), limj, T);
+			L.pend[j] = (uint32_t)r; L.nout[j] = (uint32_t)(r >> 32);
+		}
 	}
+	__syncthreads();
+	if (active) { pe = L.pend[tid]; no = L.nout[tid]; }
 	__syncthreads();
 	WGPROF(P_ROUNDS);
 	if (prof && tid == 0) L.prof[P_NROUNDS] += rounds;
@@ -600,22 +639,124 @@ NXZ_WG_PHASE void decode_block(uint32_t T, uint32_t cap, uint32_t pmin_bits, uin
 	if (active && (pe >> 24) != F_OK) atomicMin(&L.firstbad, (uint32_t)tid);
 	__syncthreads();
 	const uint32_t B = L.firstbad;
-	if (B >= NP) { if (tid == 0) L.bail = R_NOEOB; __syncthreads(); return; }
-	const uint32_t fb = L.pend[B] >> 24;
+	const uint32_t fb = B < NP ? L.pend[B] >> 24 : (uint32_t)F_OK;
+	// the pieces in front of B are whole; B's is if it met the end of the block.  A token that reaches behind the window is
+	// read again when the window has moved -- unless the window ends where the stream ends.
+	uint32_t why = 0;
+	if (fb == F_ERR || (fb == F_RUNOUT && wend)) why = R_TOKEN;
+	else if (B >= NP && E == T && wend) why = R_NOEOB;
+	const uint32_t nc = fb == F_EOB ? B + 1 : B < NP ? B : NP;
 	uint32_t tot;
-	const uint32_t obase = block_scan((uint32_t)tid <= B ? no : 0, &tot);
-	const uint32_t outn = L.outn;
-	if (fb != F_EOB || tot > cap - outn) { if (tid == 0) L.bail = fb != F_EOB ? R_TOKEN : R_SPACE; __syncthreads(); return; }
-	if ((uint32_t)tid <= B) {
+	const uint32_t obase = block_scan((uint32_t)tid < nc ? no : 0, &tot);
+	if (!why && tot > capleft) why = R_SPACE;
+	if (why) { if (tid == 0) L.bail = why; __syncthreads(); return; }
+	uint32_t C = nc;
+	if (tot > room) {
+		if ((uint32_t)tid < nc && obase + no > room) atomicMin(&L.cut, (uint32_t)tid);
+		__syncthreads();
+		C = L.cut;
+	}
+	if ((uint32_t)tid < C) {
 		const unsigned long long r = piece_write(st, lim, T, outn + obase);
 		if ((uint32_t)r != pe || (uint32_t)(r >> 32) != no) L.bail = R_DIST;                 // (a distance beyond the output so far)
+		if ((uint32_t)tid + 1 == C) { L.outn = outn + obase + no; L.pos = pe & 0xffffff; }
 	}
-	__syncthreads();
-	if (L.bail) return;
-	if (tid == 0) { L.outn = outn + tot; L.pos = L.pend[B] & 0xffffff; }
+	if (tid == 0) {
+		const uint32_t act = C < nc ? (uint32_t)A_FLUSH : fb == F_EOB ? (uint32_t)A_NEXT : (uint32_t)A_MORE;
+		L.act = act;
+		if (act == A_NEXT) { L.inblock = 0; if (L.bfinal) L.done = 1; }
+		// a span that got nowhere: once is the window's end (it moves now), twice is a stream this kernel does not take
+		if (C == 0 && act != A_FLUSH) { if (++L.stall >= 2) L.bail = R_TOKEN; } else L.stall = 0;
+	}
 	WGPROF(P_WRITE);
 	__syncthreads();
 }
+
+// ---- the window: 64 KiB of the source from the 16-byte granule of byte `from` on, zeros behind the stream's end ----
+NXZ_WG_PHASE void load_window(const NXZ_WG_GLOBAL uint8_t *gsrc, uint32_t nbytes, uint32_t from)
+{
+	const int tid = threadIdx.x;
+	const uint32_t wbn = from & ~15u;
+	const uint32_t avail = nbytes - wbn, wl = avail < SRC_MAX ? avail : SRC_MAX;
+	const NXZ_WG_GLOBAL v4u *gq = (const NXZ_WG_GLOBAL v4u *)(gsrc + wbn);
+	const uint32_t full = wl >> 4, chunks = (wl + 15) >> 4;
+	v4u *ls = (v4u *)L.src;
+	for (uint32_t i = tid; i < chunks + 2 && i < SRC_WORDS / 4; i += NT) {
+		v4u v = { 0, 0, 0, 0 };
+		if (i < chunks) {
+			v = gq[i];
+			if (i >= full) {                                       // the stream's last bytes: what follows them in the granule counts as zero
+				const uint32_t keep = wl & 15;
+				uint32_t wv[4] = { v.x, v.y, v.z, v.w };
+				for (uint32_t q = 0; q < 4; q++) {
+					if (4 * q >= keep) wv[q] = 0;
+					else if (4 * q + 4 > keep) wv[q] &= (1u << (8 * (keep & 3))) - 1;
+				}
+				v.x = wv[0]; v.y = wv[1]; v.z = wv[2]; v.w = wv[3];
+			}
+		}
+		ls[i] = v;
+	}
+	__syncthreads();
+	if (tid == 0) { L.pos = L.wb * 8 + L.pos - wbn * 8; L.wb = wbn; L.wbits = wl * 8; L.wend = wbn + wl == nbytes; L.wvalid = 1; }
+	__syncthreads();
+}
+
+// ---- what LDS holds of the output and memory does not yet (from L.fl0 on): the matches followed to their bytes, out 16 bytes
+// a lane.  Not the stream's end: the last 32 KiB stay, as the first half of the output (the window of distances), the rest of
+// the stream follows them in the second half; the source's window is gone (the pointers stood in its room). ----
+NXZ_WG_PHASE void flush_out(NXZ_WG_GLOBAL uint8_t *dst, bool final, int prof)
+{
+	const int tid = threadIdx.x;
+	uint8_t *ob = (uint8_t *)L.out;
+	const uint32_t fl0 = L.fl0, outn = L.outn;
+	if (prof && tid == 0) L.tripmax = 0;
+	resolve_matches(fl0, outn, prof);
+	__syncthreads();
+	WGPROF(P_MATCH);
+	{
+		const uint32_t g0 = L.aoff + fl0, m = outn - fl0;
+		uint32_t h = (16 - (g0 & 15)) & 15;
+		h = h < m ? h : m;
+		if ((uint32_t)tid < h) dst[g0 + tid] = ob[fl0 + tid];
+		const uint32_t mid = (m - h) >> 4, l0 = fl0 + h;
+		NXZ_WG_GLOBAL v4u *gd = (NXZ_WG_GLOBAL v4u *)(dst + g0 + h);
+		if ((l0 & 15) == 0) {
+			const v4u *lo = (const v4u *)(ob + l0);
+			for (uint32_t i = tid; i < mid; i += NT) gd[i] = lo[i];
+		} else {
+			const uint32_t sh = l0 & 3;
+			for (uint32_t i = tid; i < mid; i += NT) {
+				const uint32_t w = (l0 >> 2) + 4 * i;
+				const uint32_t a = L.out[w], b = L.out[w + 1], c = L.out[w + 2], d = L.out[w + 3], e = L.out[w + 4 < OUT_MAX / 4 ? w + 4 : w + 3];
+				v4u v;
+				v.x = __builtin_amdgcn_alignbyte(b, a, sh); v.y = __builtin_amdgcn_alignbyte(c, b, sh);
+				v.z = __builtin_amdgcn_alignbyte(d, c, sh); v.w = __builtin_amdgcn_alignbyte(e, d, sh);
+				gd[i] = v;
+			}
+		}
+		const uint32_t tail = (m - h) & 15;
+		if ((uint32_t)tid < tail) dst[g0 + h + 16 * mid + tid] = ob[l0 + 16 * mid + tid];
+	}
+	WGPROF(P_OUT);
+	if (final) return;
+	__syncthreads();
+	{
+		const uint32_t shift = outn - HALF, sh = shift & 3, w0 = (32 * (uint32_t)tid + shift) >> 2;
+		uint32_t v[9];
+#pragma unroll
+		for (uint32_t j = 0; j < 9; j++) v[j] = L.out[w0 + j < OUT_MAX / 4 ? w0 + j : OUT_MAX / 4 - 1];
+		__syncthreads();
+#pragma unroll
+		for (uint32_t j = 0; j < 8; j++) L.out[8 * (uint32_t)tid + j] = __builtin_amdgcn_alignbyte(v[j + 1], v[j], sh);
+		v4u *b0 = (v4u *)L.mstart;
+		const v4u z = { 0, 0, 0, 0 };
+		for (uint32_t i = tid; i < OUT_MAX / 32 / 4; i += NT) b0[i] = z;
+		if (tid == 0) { L.aoff += shift; L.outn = HALF; L.fl0 = HALF; L.span_len = 0; L.wvalid = 0; L.act = A_MORE; }
+	}
+	__syncthreads();
+}
+#undef WGPROF
 
 template <bool PROF>
 __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *__restrict__ jobs, uint32_t n, nxz_batch_result_t *__restrict__ results,
@@ -625,6 +766,8 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	uint8_t *ob = (uint8_t *)L.out;
 	const uint8_t *sb = (const uint8_t *)L.src;
+	(void)nres;
+#define WGPROF(idx) do { if (PROF && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; L.prof[idx] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); } } while (0)
 	if (PROF && tid == 0) { for (int i = 0; i < P_N; i++) L.prof[i] = 0; const unsigned long long now_ = (unsigned long long)clock64(); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); }
 
 	for (;;) {
@@ -633,121 +776,141 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 		if (tid == 0) {
 			const uint32_t k = atomicAdd(ctr, 1u);
 			L.jid = k < n ? (order ? order[k] : k) : 0xffffffffu;
-			L.bail = 0; L.outn = 0;
+			L.bail = 0; L.outn = 0; L.fl0 = 0; L.aoff = 0; L.lowest = 0; L.inblock = 0; L.act = A_NEXT; L.stall = 0;
+			L.wvalid = 0; L.wb = 0; L.span_len = 0; L.done = 0; L.st_len = 0;
 		}
 		__syncthreads();
 		const uint32_t jid = L.jid;
 		if (jid == 0xffffffffu) break;
 		const nxz_batch_job_t job = jobs[jid];
 		const uint32_t off = (uint32_t)((uintptr_t)job.src & 15);
-		const uint32_t nbytes = off + job.src_len;                     // bytes of the LDS image that belong to the stream's granules
-		const uint32_t T = nbytes * 8;
-		const bool takes = job.resume == 0 && job.hist_len == 0 && job.src_len > 0 && nbytes <= SRC_MAX && ((uintptr_t)job.dst & 15) == 0;
+		const uint32_t nbytes = off + job.src_len;                     // the stream's bytes from its first 16-byte granule on
+		const bool takes = job.resume == 0 && job.hist_len == 0 && job.src_len > 0 && job.src_len < (1u << 28) && ((uintptr_t)job.dst & 15) == 0;
 		// (NXZ_JOB_SUSPEND_WHEN_FULL needs no look: an output that does not fit is handed back like everything this kernel does not do)
 		if (!takes) {
 			if (tid == 0) { const uint32_t at = atomicAdd(bail, 1u); bail[64 + at] = jid; if (dbg) atomicAdd(&dbg[R_JOB], 1u); }
 			continue;
 		}
-		const uint32_t cap = job.dst_cap < OUT_MAX ? job.dst_cap : OUT_MAX;
-		// ---- the source into LDS (16 bytes a lane, zeros behind it), the bitmaps cleared ----
+		// a stream that may not fit LDS in one piece goes in spans sized by what it made of its source so far
+		const bool longmode = nbytes > SRC_MAX || job.dst_cap > OUT_MAX + 40960;
+		const NXZ_WG_GLOBAL uint8_t *gsrc = (const NXZ_WG_GLOBAL uint8_t *)(job.src - off);
 		{
-			const NXZ_WG_GLOBAL v4u *g = (const NXZ_WG_GLOBAL v4u *)(job.src - off);
-			const uint32_t full = nbytes >> 4, chunks = (nbytes + 15) >> 4;
-			v4u *ls = (v4u *)L.src;
-			for (uint32_t i = tid; i < chunks + 2 && i < SRC_WORDS / 4; i += NT) {
-				v4u v = { 0, 0, 0, 0 };
-				if (i < chunks) {
-					v = g[i];
-					if (i >= full) {                                       // the stream's last bytes: what follows them in the granule counts as zero
-						const uint32_t keep = nbytes & 15;
-						uint32_t wv[4] = { v.x, v.y, v.z, v.w };
-						for (uint32_t q = 0; q < 4; q++) {
-							if (4 * q >= keep) wv[q] = 0;
-							else if (4 * q + 4 > keep) wv[q] &= (1u << (8 * (keep & 3))) - 1;
-						}
-						v.x = wv[0]; v.y = wv[1]; v.z = wv[2]; v.w = wv[3];
-					}
-				}
-				ls[i] = v;
-			}
 			v4u *b0 = (v4u *)L.mstart;
 			const v4u z = { 0, 0, 0, 0 };
 			for (uint32_t i = tid; i < OUT_MAX / 32 / 4; i += NT) b0[i] = z;
 			if (tid == 0) L.pos = off * 8;
 		}
-		__syncthreads();
-		if (PROF) { WGPROF(P_LOAD); if (tid == 0) L.prof[P_STREAMS]++; }
+		if (PROF && tid == 0) L.prof[P_STREAMS]++;
 
-		// ---- block after block ----
-		bool done = false;
+		// ---- the stream: window, block header, span after span, a flush when LDS is full ----
 		for (;;) {
 			__syncthreads();
-			if (tid == 0) {
-				uint32_t p = L.pos;
-				if (p + 3 > T) L.bail = R_HEADER;
-				else {
-					const uint32_t v = peek32(p);
-					L.bfinal = v & 1; L.btype = (v >> 1) & 3;
-					p += 3;
-					if (L.btype == 0) {
-						p = (p + 7) & ~7u;
-						if (p + 32 > T) L.bail = R_STORED;
-						else {
-							const uint32_t w = peek32(p), len = w & 0xffff;
-							p += 32;
-							if (((w >> 16) ^ len) != 0xffff || p + 8 * len > T || len > cap - L.outn) L.bail = R_STORED;
-							L.st_len = len;
-						}
-					} else if (L.btype == 3) L.bail = R_HEADER;
-					L.pos = p;
-				}
-			}
-			__syncthreads();
-			if (L.bail) break;
-			const uint32_t btype = L.btype, bfinal = L.bfinal;
-			if (btype == 0) {
-				const uint32_t len = L.st_len, from = L.pos >> 3, to = L.outn;
-				for (uint32_t i = tid; i < len; i += NT) ob[to + i] = sb[from + i];
-				__syncthreads();
-				if (tid == 0) { L.pos += 8 * len; L.outn += len; }
-				if (PROF) WGPROF(P_HEADER);
-				if (bfinal) { done = true; break; }
+			if (L.bail || L.done) break;
+			const uint32_t outn = L.outn, made = L.aoff + outn;
+			if (L.act == A_FLUSH || (OUT_MAX - outn < 4096 && outn > L.fl0)) {
+				// (a flush frees 32 KiB at least: a piece that makes more than that is not this kernel's)
+				if (outn <= HALF || outn == L.fl0) { __syncthreads(); if (tid == 0) L.bail = R_SPACE; continue; }
+				flush_out((NXZ_WG_GLOBAL uint8_t *)job.dst, false, PROF);
 				continue;
 			}
-			if (PROF) WGPROF(P_HEADER);
-			// ---- code lengths ----
-			if (btype == 2) {
-				if (wave == 0) {
-					const bool ok = read_header(L.pos, T, lane);
-					if (!ok && lane == 0) L.bail = R_DHT;
+			uint32_t spanbits = longmode ? 24576u * 8 : 0xffffffffu;
+			if (made >= 4096 && (longmode || L.fl0)) {
+				const uint32_t used = L.wb * 8 + L.pos - off * 8;
+				const unsigned long long sbits = (unsigned long long)(OUT_MAX - outn) * used / made;
+				spanbits = sbits > (1u << 28) ? 1u << 28 : (uint32_t)sbits + (uint32_t)(sbits >> 4);
+				if (spanbits < 16384) spanbits = 16384;
+			}
+			{
+				const uint32_t want = (spanbits < 49152u * 8 ? spanbits : 49152u * 8) + 4096 * 8;
+				if (!L.wvalid || (!L.wend && (L.wbits < L.pos || L.wbits - L.pos < want))) {
+					load_window(gsrc, nbytes, L.wb + (L.pos >> 3));
+					WGPROF(P_LOAD);
 				}
-			} else {
-				for (int i = tid; i < 320; i += NT) L.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
-				if (tid == 0) { L.hlit = 288; L.hdist = 30; }
 			}
-			__syncthreads();
-			if (L.bail) break;
-			const int hlit = (int)L.hlit, hdist = (int)L.hdist;
-			// (the checks of nxzi::read_dht: an end-of-block code, no code over-subscribed)
-			if (btype == 2 && wave == 0) {
-				uint32_t k1 = 0, k2 = 0;
-				for (int i = lane; i < hlit; i += 64) if (L.lens[i]) k1 += 1u << (15 - L.lens[i]);
-				if (lane < hdist && L.lens[hlit + lane]) k2 = 1u << (15 - L.lens[hlit + lane]);
-				for (int o = 32; o > 0; o >>= 1) { k1 += __shfl(k1, lane ^ o, 64); k2 += __shfl(k2, lane ^ o, 64); }
-				if (lane == 0 && (L.lens[256] == 0 || k1 > (1u << 15) || k2 > (1u << 15))) L.bail = R_DHT;
+			const uint32_t T = L.wbits;
+			if (!L.inblock) {
+				__syncthreads();
+				if (tid == 0) {
+					uint32_t p = L.pos;
+					if (p + 3 > T) L.bail = R_HEADER;
+					else {
+						const uint32_t v = peek32(p);
+						L.bfinal = v & 1; L.btype = (v >> 1) & 3;
+						p += 3;
+						if (L.btype == 0) {
+							p = (p + 7) & ~7u;
+							if (p + 32 > T) L.bail = R_STORED;
+							else {
+								const uint32_t w = peek32(p), len = w & 0xffff;
+								p += 32;
+								if (((w >> 16) ^ len) != 0xffff || (p >> 3) + len > nbytes - L.wb) L.bail = R_STORED;
+								L.st_len = len;
+							}
+						} else if (L.btype == 3) L.bail = R_HEADER;
+						L.pos = p;
+						L.inblock = L.btype == 0 ? 2 : 1;
+					}
+				}
+				__syncthreads();
+				if (L.bail) continue;
+				const uint32_t btype = L.btype;
+				WGPROF(P_HEADER);
+				if (btype != 0) {
+					// ---- code lengths ----
+					if (btype == 2) {
+						if (wave == 0) {
+							const bool ok = read_header(L.pos, T, lane);
+							if (!ok && lane == 0) L.bail = R_DHT;
+						}
+					} else {
+						for (int i = tid; i < 320; i += NT) L.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
+						if (tid == 0) { L.hlit = 288; L.hdist = 30; }
+					}
+					__syncthreads();
+					if (L.bail) continue;
+					const int hlit = (int)L.hlit, hdist = (int)L.hdist;
+					// (the checks of nxzi::read_dht: an end-of-block code, no code over-subscribed)
+					if (btype == 2 && wave == 0) {
+						uint32_t k1 = 0, k2 = 0;
+						for (int i = lane; i < hlit; i += 64) if (L.lens[i]) k1 += 1u << (15 - L.lens[i]);
+						if (lane < hdist && L.lens[hlit + lane]) k2 = 1u << (15 - L.lens[hlit + lane]);
+						for (int o = 32; o > 0; o >>= 1) { k1 += __shfl(k1, lane ^ o, 64); k2 += __shfl(k2, lane ^ o, 64); }
+						if (lane == 0 && (L.lens[256] == 0 || k1 > (1u << 15) || k2 > (1u << 15))) L.bail = R_DHT;
+					}
+					__syncthreads();
+					if (L.bail) continue;
+					if (PROF) { WGPROF(P_DHT); if (tid == 0) L.prof[P_BLOCKS]++; }
+					build_tables(hlit, hdist);
+					if (L.bail) continue;
+					WGPROF(P_TABLES);
+				}
 			}
-			__syncthreads();
-			if (L.bail) break;
-			if (PROF) { WGPROF(P_DHT); if (tid == 0) L.prof[P_BLOCKS]++; }
-			build_tables(hlit, hdist);
-			if (L.bail) break;
-			if (PROF) WGPROF(P_TABLES);
-			decode_block(T, cap, pmin_bits & 0xffff, pmin_bits >> 16, PROF);
-			if (L.bail) break;
-			if (bfinal) { done = true; break; }
+			if (L.inblock == 2) {
+				// ---- a stored block, or as much of it as LDS has room for ----
+				const uint32_t rem = L.st_len, pos = L.pos, room = OUT_MAX - outn;
+				const uint32_t k = rem < room ? rem : room;
+				if (rem > job.dst_cap - made) { __syncthreads(); if (tid == 0) L.bail = R_SPACE; continue; }
+				if (k == 0 && rem) { __syncthreads(); if (tid == 0) L.act = A_FLUSH; continue; }
+				const uint32_t from = pos >> 3;
+				const bool in_window = L.wvalid && pos <= T && from + k <= (T >> 3);
+				if (in_window) for (uint32_t i = tid; i < k; i += NT) ob[outn + i] = sb[from + i];
+				else {
+					const NXZ_WG_GLOBAL uint8_t *gs = gsrc + L.wb + from;
+					for (uint32_t i = tid; i < k; i += NT) ob[outn + i] = gs[i];
+				}
+				__syncthreads();
+				if (tid == 0) {
+					L.pos = pos + 8 * k; L.outn = outn + k; L.st_len = rem - k;
+					if (!in_window) L.wvalid = 0;
+					if (rem == k) { L.inblock = 0; if (L.bfinal) L.done = 1; }
+				}
+				WGPROF(P_HEADER);
+				continue;
+			}
+			decode_span(T, spanbits, job.dst_cap - made, pmin_bits & 0xffff, pmin_bits >> 16, PROF);
 		}
 		__syncthreads();
-		if (!done || L.bail) {
+		if (L.bail) {
 			if (tid == 0) {
 				const uint32_t at = atomicAdd(bail, 1u);
 				bail[64 + at] = jid;
@@ -755,30 +918,16 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 			}
 			continue;
 		}
-		const uint32_t outn = L.outn;
-		if (PROF && tid == 0) L.tripmax = 0;
-		resolve_matches(outn, PROF);
-		__syncthreads();
-		if (PROF && tid == 0) L.prof[P_MTRIPMAX] += L.tripmax;
-		if (PROF) WGPROF(P_MATCH);
-		// ---- out ----
-		{
-			NXZ_WG_GLOBAL v4u *gd = (NXZ_WG_GLOBAL v4u *)job.dst;
-			const v4u *lo = (const v4u *)L.out;
-			const uint32_t full = outn >> 4;
-			for (uint32_t i = tid; i < full; i += NT) gd[i] = lo[i];
-			if ((uint32_t)tid < (outn & 15)) ((NXZ_WG_GLOBAL uint8_t *)job.dst)[full * 16 + tid] = ob[full * 16 + tid];
-			if (tid == 0) {
-				// (the record of nxzl::inflate_lanes_kernel for a stream that ran to its final end-of-block)
-				nxz_batch_result_t r;
-				uint32_t spbc = job.src_len, subc = T - L.pos;
-				if (subc > 0xfff8) { const uint32_t drop = (subc - 0xfff8 + 7) / 8; spbc -= drop; subc -= drop * 8; }
-				r.cc = subc < 8 ? 0 : NXZ_CC_DATA_LENGTH;
-				r.tpbc = outn; r.tebc = 0; r.spbc = spbc; r.crc = 0; r.adler = 0; r.subc = subc; r.sfbt = 0x100u;
-				results[jid] = r;
-			}
+		flush_out((NXZ_WG_GLOBAL uint8_t *)job.dst, true, PROF);
+		if (tid == 0) {
+			// (the record of nxzl::inflate_lanes_kernel for a stream that ran to its final end-of-block)
+			nxz_batch_result_t r;
+			uint32_t spbc = job.src_len, subc = (nbytes - L.wb) * 8 - L.pos;
+			if (subc > 0xfff8) { const uint32_t drop = (subc - 0xfff8 + 7) / 8; spbc -= drop; subc -= drop * 8; }
+			r.cc = subc < 8 ? 0 : NXZ_CC_DATA_LENGTH;
+			r.tpbc = L.aoff + L.outn; r.tebc = 0; r.spbc = spbc; r.crc = 0; r.adler = 0; r.subc = subc; r.sfbt = 0x100u;
+			results[jid] = r;
 		}
-		if (PROF) WGPROF(P_OUT);
 	}
 	if (PROF && tid == 0) for (int i = 0; i < P_N; i++) atomicAdd(&prof[i], (unsigned long long)L.prof[i]);
 #undef WGPROF

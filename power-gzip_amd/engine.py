@@ -205,7 +205,7 @@ class Engine:
         d = {names[i]: out[i] / ns for i in range(10)}
         d["total"] = sum(out[i] for i in range(10)) / ns
         d.update(nrounds=out[10] / max(1, out[12]), streams=out[11], blocks=out[12] / ns, pieces=out[13] / max(1, out[12]),
-                 jump_rounds=out[14] / ns, jump_cycles=out[16] / ns)
+                 jump_rounds=out[14] / ns, jump_cycles=out[16] / ns, redone=out[17] / max(1, out[12]), redone_in_2=out[15] / max(1, out[12]))
         return d
 
     def inflate_stream(self, src, src_len, dst, first_bit=0, hist=None):

@@ -3,7 +3,7 @@
 // by system zlib.  Checks: every stream the kernel takes comes out byte for byte with the result record of a finished
 // stream; every stream it does not take is on the hand-back list (and only those); damaged streams are handed back, never
 // "decoded".
-//   usage: inflate_wg_sim <file with sample text> [seed] [pmin_bits]
+//   usage: inflate_wg_sim <file with sample text> [seed] [pmin_bits] [unused] [bytes of the long cases]
 #include "hip_cpu_shim.h"
 #include "../../power-gzip_amd/csrc/nxz_inflate_wg.hip"
 #include <zlib.h>
@@ -44,6 +44,7 @@ int main(int argc, char **argv)
 	if (argc > 2) rng_state ^= (uint64_t)strtoull(argv[2], nullptr, 0) * 0x9E3779B97F4A7C15ull;
 	const uint32_t pmin = argc > 3 ? (uint32_t)atoi(argv[3]) : 512;
 	const uint32_t nres = argc > 4 ? (uint32_t)atoi(argv[4]) : 256;
+	const size_t longn = argc > 5 ? (size_t)atoi(argv[5]) : 600000;      // bytes of the long cases (the simulation takes a minute per MiB)
 	auto slice = [&](size_t at, size_t n) { return std::vector<uint8_t>(text.begin() + at % (text.size() - n), text.begin() + at % (text.size() - n) + n); };
 	std::vector<Case> cases;
 	auto add = [&](const char *name, std::vector<uint8_t> plain, int level, int strategy, bool taken = true, uint32_t off = 0, uint32_t cap = 0) {
@@ -83,7 +84,30 @@ int main(int argc, char **argv)
 		add("mixed -1 memlevel", m, 1, Z_DEFAULT_STRATEGY, true, 1);
 	}
 	// what the kernel must hand back
-	add("too long for LDS", slice(rnd(), 70000), 6, Z_DEFAULT_STRATEGY, false);
+	// streams longer than LDS: in spans, the output flushed 32 KiB and more at a time
+	add("text 70000 -6", slice(rnd(), 70000), 6, Z_DEFAULT_STRATEGY);
+	{
+		std::vector<uint8_t> big;
+		while (big.size() < longn) { const std::vector<uint8_t> s = slice(rnd(), 50000); big.insert(big.end(), s.begin(), s.end()); }
+		add("text long -6", big, 6, Z_DEFAULT_STRATEGY, true, 7);
+		add("text long -1", big, 1, Z_DEFAULT_STRATEGY);
+		add("text long fixed", big, 6, Z_FIXED, true, 2);
+		add("text 300K huffman only", std::vector<uint8_t>(big.begin(), big.begin() + longn / 2), 6, Z_HUFFMAN_ONLY);
+		std::vector<uint8_t> v(longn / 2 > 65536 ? longn / 2 : 65536);
+		for (auto &b : v) b = (uint8_t)rnd();
+		add("random 300K stored", v, 6, Z_DEFAULT_STRATEGY, true, 9);
+		add("random 300K -0", v, 0, Z_DEFAULT_STRATEGY);
+		add("random 64K fixed", std::vector<uint8_t>(v.begin(), v.begin() + 65536), 6, Z_FIXED);
+		add("zeros 1M", std::vector<uint8_t>(longn * 2, 0), 6, Z_DEFAULT_STRATEGY);
+		for (size_t i = 0; i < v.size(); i++) v[i] = (uint8_t)("abcdefghijklmnopqrstuvwxyz0123456"[i % 33]);
+		add("period 33, 300K", v, 6, Z_DEFAULT_STRATEGY);
+		std::vector<uint8_t> m = big;
+		for (size_t i = longn / 6; i < longn / 3; i++) m[i] = (uint8_t)rnd();
+		for (size_t i = longn / 2; i < longn / 2 + longn / 8; i++) m[i] = 0;
+		add("mixed long -6", m, 6, Z_DEFAULT_STRATEGY, true, 15);
+		add("mixed long -9", m, 9, Z_DEFAULT_STRATEGY);
+		add("long, target too small", std::vector<uint8_t>(big.begin(), big.begin() + longn / 3), 6, Z_DEFAULT_STRATEGY, false, 0, (uint32_t)(longn / 4));
+	}
 	add("target too small", slice(rnd(), 30000), 6, Z_DEFAULT_STRATEGY, false, 0, 29999);
 	{
 		Case c = cases[0]; c.name = "cut short"; c.stream.resize(c.stream.size() / 2); c.expect_taken = false; cases.push_back(c);
@@ -102,7 +126,7 @@ int main(int argc, char **argv)
 		srcbuf[i].assign(c.stream.size() + 64 + 16, 0xa5);
 		uint8_t *base = (uint8_t *)(((uintptr_t)srcbuf[i].data() + 15) & ~(uintptr_t)15) + c.src_off;
 		memcpy(base, c.stream.data(), c.stream.size());
-		dstbuf[i].assign(65536 + 5000 + 32, 0xcd);
+		dstbuf[i].assign((c.plain.size() > 65536 ? c.plain.size() : 65536) + 5000 + 32, 0xcd);
 		uint8_t *dst = (uint8_t *)(((uintptr_t)dstbuf[i].data() + 15) & ~(uintptr_t)15);
 		memset(&jobs[i], 0, sizeof(jobs[i]));
 		jobs[i].src = base; jobs[i].dst = dst; jobs[i].src_len = (uint32_t)c.stream.size(); jobs[i].dst_cap = c.cap == 65536 ? (uint32_t)(c.plain.size() > 65536 ? c.plain.size() : 65536) : c.cap;

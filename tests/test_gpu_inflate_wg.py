@@ -153,3 +153,33 @@ def test_the_engine_sends_batches_up_to_its_limit_through_this_kernel(eng):
         assert (r2["crc"] == r["crc"]).all() and (r2["tpbc"] == r["tpbc"]).all()
     finally:
         os.environ.pop("NXZ_INFLATE_WG_MAX", None)
+
+
+def test_streams_longer_than_lds_go_in_spans(eng):
+    """a stream of any length is this kernel's too: the source through a 64 KiB window, the output flushed 32 KiB and more at a
+    time, the last 32 KiB staying in LDS as the window of distances.  Every kind of data, level and block type; multi-block;
+    stored blocks that lie across windows; output sizes round the edges of the halves."""
+    rnd = random.Random(21)
+    cases = []
+    sizes = [65537, 70000, 98304, 98305, 131072, 200000, 262144, 300001, 524288, 1 << 20, (1 << 20) + 17, 2 << 20]
+    kinds = ["alice", "lz", "text33", "zeros", "random", "periodic", "binary", "sparse"]
+    for i in range(48):
+        n = sizes[i % len(sizes)] if i < 36 else rnd.randrange(65537, 1 << 20)
+        d = make_block(kinds[i % len(kinds)], n, seed=400 + i)
+        level, strat = [(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY),
+                        (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)][i % 7]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strat)
+        if i % 5 == 4:
+            k = n // 2
+            c = co.compress(d[:k]) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(d[k:]) + co.flush()
+        else:
+            c = co.compress(d) + co.flush()
+        cases.append((d, c))
+    r, out, why = _run(eng, cases, cap=(2 << 20) + 64, offsets=[i % 16 for i in range(len(cases))])
+    for i, (d, c) in enumerate(cases):
+        assert r["cc"][i] == 0 and r["sfbt"][i] == 0x100 and r["tpbc"][i] == len(d) and r["spbc"][i] == len(c), (i, len(d), r["cc"][i], r["tpbc"][i])
+        assert out[i, :len(d)].tobytes() == d, i
+        assert (out[i, len(d):len(d) + 8] == 0xcd).all(), i
+        assert r["crc"][i] == zlib.crc32(d) and r["adler"][i] == zlib.adler32(d), i
+    print("long streams handed back:", why)
+    assert why["handed_back"] <= 4, why
