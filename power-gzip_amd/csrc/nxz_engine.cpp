@@ -1783,16 +1783,16 @@ static int round_run_inflate(nxz_ctx *c, nxz_ctx::Round &R, std::vector<InflateR
 		}
 		cut = longish > 0;
 	}
-	// A round of fresh streams of at most 64 KiB either side -- what nx_uncompress / inflate(Z_FINISH) of buffers up to 64 KiB are --
-	// goes a stream per WORKGROUP (nxz_inflate_wg.hip: 0.2-0.4 ms whatever the round holds, one launch; what that kernel hands
-	// back -- a stream that ends early, a target that is too small -- goes a wavefront each behind it).  NXZ_ROUND_WG=0: never.
+	// A round of fresh streams -- what nx_uncompress / inflate(Z_FINISH) of whole buffers are -- goes a stream per WORKGROUP
+	// (nxz_inflate_wg.hip: 0.2-0.4 ms for buffers of 64 KiB whatever the round holds, 0.8 ms for 256 KiB, one launch; what that
+	// kernel hands back -- a stream that ends early, a target that is too small -- goes a wavefront each behind it).
+	// NXZ_ROUND_WG=0: never; NXZ_ROUND_WG_MAX: source bytes of a job at most.
 	static const bool wg_on = !(getenv("NXZ_ROUND_WG") && atoi(getenv("NXZ_ROUND_WG")) == 0);
+	static const uint32_t wg_src_max = getenv("NXZ_ROUND_WG_MAX") ? (uint32_t)strtoul(getenv("NXZ_ROUND_WG_MAX"), nullptr, 0) : 400000u;
 	bool wg = wg_on;
 	for (size_t k = 0; k < n && wg; k++) {
 		const nxz_batch_job_t &j = v[k]->job;
-		// (the target: what a caller with 64 KiB of room hands a job -- its room, a window and a quarter, lib/nx_inflate.c's fifo_out; a
-		// stream that makes more than 64 KiB after all is handed back by the kernel and costs a wavefront's 3-8 ms)
-		if (j.resume || j.hist_len || j.src_len > 65000 || j.dst_cap > 65536 + 40960 || !v[k]->d_out) wg = false;
+		if (j.resume || j.hist_len || j.src_len > wg_src_max || !v[k]->d_out) wg = false;
 	}
 	if (wg && !R.h_targets && hipHostMalloc((void **)&R.h_targets, ROUND_MAX * sizeof(uint8_t *)) != hipSuccess) { (void)hipGetLastError(); R.h_targets = nullptr; wg = false; }
 	if (wg && !R.d_wg && hipMalloc((void **)&R.d_wg, nxz_inflate_wg_workspace(ROUND_MAX)) != hipSuccess) { (void)hipGetLastError(); R.d_wg = nullptr; wg = false; }

@@ -216,36 +216,49 @@ __device__ __forceinline__ unsigned long long decode_piece(uint32_t st, uint32_t
 		const uint32_t a = L.src[w], b = L.src[w + 1], c = L.src[w + 2];
 		const uint32_t lo = __builtin_amdgcn_alignbit(b, a, sh), hi = __builtin_amdgcn_alignbit(c, b, sh);
 		uint32_t e = L.lit[lo & ((1u << RL) - 1)];
-		if (e_kind(e) == K_LINK) e = L.lit[(e >> 16) + ((lo >> RL) & ((1u << e_xb(e)) - 1))];
-		const uint32_t nb = e & 31, kind = e_kind(e);
-		if (kind == K_LIT) {
-			if (WRITE) ob[obase + n] = (uint8_t)(e >> 16);
-			n++; p += nb;
-			// the code behind it (its 15 bits at most are among the 32 at hand): a literal again?
-			const uint32_t e2 = L.lit[(lo >> nb) & ((1u << RL) - 1)];
-			if (e_kind(e2) == K_LIT && p < lim) {
-				if (WRITE) ob[obase + n] = (uint8_t)(e2 >> 16);
-				n++; p += e2 & 31;
-			}
-			continue;
-		}
-		if (kind != K_LEN) { if (kind == K_EOB) { p += nb; fl = F_EOB; } else fl = F_ERR; break; }
-		const uint32_t x = e_xb(e), q = nb + x;                            // (q <= 20)
-		const uint32_t len = (e >> 16) + ((lo >> nb) & ((1u << x) - 1));
-		const uint32_t db = __builtin_amdgcn_alignbit(hi, lo, q);
+		uint32_t nb = e & 31, kind = e_kind(e), x = e_xb(e), q = nb + x;           // (a literal: x = 0)
+		// The look-up behind a literal and the distance look-up behind a length are BOTH issued, whatever the code turns out to
+		// be: their latencies overlap, a wavefront whose lanes meet both kinds walks both paths anyway, and the choice is made by
+		// masks -- one straight run of instructions for a literal (or two) and for a match whose codes lie in the root tables.
+		const uint32_t e2 = L.lit[(lo >> nb) & ((1u << RL) - 1)];
+		uint32_t db = __builtin_amdgcn_alignbit(hi, lo, q);
 		uint32_t d = L.dist[db & ((1u << RD) - 1)];
-		if (e_kind(d) == K_LINK) d = L.dist[(d >> 16) + ((db >> RD) & ((1u << e_xb(d)) - 1))];
-		if (e_kind(d) != K_DIST) { fl = F_ERR; break; }
+		const uint32_t ml = 0u - (uint32_t)(kind == K_LIT);                       // all ones: a literal
+		const uint32_t okm = (uint32_t)(kind == K_LEN) & (uint32_t)(e_kind(d) == K_DIST);
+		if (__builtin_expect(!(ml | okm), 0)) {
+			// the rest: a code of a sub-table (either kind), the end of the block, no code at all
+			if (kind == K_LINK) {
+				e = L.lit[(e >> 16) + ((lo >> RL) & ((1u << x) - 1))];
+				nb = e & 31; kind = e_kind(e); x = e_xb(e); q = nb + x;
+				if (kind == K_LIT) {
+					if (WRITE) ob[obase + n] = (uint8_t)(e >> 16);
+					n++; p += nb;
+					continue;
+				}
+				db = __builtin_amdgcn_alignbit(hi, lo, q);
+				d = L.dist[db & ((1u << RD) - 1)];
+			}
+			if (kind != K_LEN) { if (kind == K_EOB) { p += nb; fl = F_EOB; } else fl = F_ERR; break; }
+			if (e_kind(d) == K_LINK) d = L.dist[(d >> 16) + ((db >> RD) & ((1u << e_xb(d)) - 1))];
+			if (e_kind(d) != K_DIST) { fl = F_ERR; break; }
+		}
+		const uint32_t m2 = ml & (0u - ((uint32_t)(e_kind(e2) == K_LIT) & (uint32_t)(p + nb < lim)));   // ... and a literal behind it that starts in the piece
+		const uint32_t mlen = (e >> 16) + ((lo >> nb) & ((1u << x) - 1));
 		const uint32_t dl = d & 31, dx = e_xb(d);
-		const uint32_t dist = (d >> 16) + ((db >> dl) & ((1u << dx) - 1));     // dl + dx <= 28
 		if (WRITE) {
 			const uint32_t at = obase + n;
-			if (dist > at) { fl = F_ERR; break; }
-			ob[at] = (uint8_t)(len - 3); ob[at + 1] = (uint8_t)(dist - 1); ob[at + 2] = (uint8_t)((dist - 1) >> 8);
-			atomicOr(&L.mstart[at >> 5], 1u << (at & 31));
+			if (ml) {
+				ob[at] = (uint8_t)(e >> 16);
+				if (m2) ob[at + 1] = (uint8_t)(e2 >> 16);
+			} else {
+				const uint32_t dist = (d >> 16) + ((db >> dl) & ((1u << dx) - 1));     // dl + dx <= 28
+				if (dist > at - L.lowest) { fl = F_ERR; break; }
+				ob[at] = (uint8_t)(mlen - 3); ob[at + 1] = (uint8_t)(dist - 1); ob[at + 2] = (uint8_t)((dist - 1) >> 8);
+				atomicOr(&L.mstart[at >> 5], 1u << (at & 31));
+			}
 		}
-		n += len;
-		p += q + dl + dx;
+		p += ((nb + (e2 & 31 & m2)) & ml) | ((q + dl + dx) & ~ml);
+		n += ((1u + (m2 & 1)) & ml) | (mlen & ~ml);
 	}
 	if (p > T) fl = F_RUNOUT;            // the last token reaches beyond the source
 	return (unsigned long long)(p | fl << 24) | (unsigned long long)n << 32;
