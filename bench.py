@@ -852,11 +852,32 @@ def inflate_leg(torch, eng, pkg, raw, rep, args):
     if not ok:
         raise SystemExit("inflate leg: zlib -6 streams did not inflate to their sources")
     u, cb = float(ulen.astype(np.float64).sum()), float(clen.astype(np.float64).sum())
+    # (the engine's routes by batch size, nxz_engine.cpp batch_decompress: up to 196 607 streams a stream per workgroup)
+    wg_kernel = "nxzw::inflate_wg_kernel<false> (a stream per workgroup: source, output and tables in LDS) + nxzl::cksum_kernel"
+    old_kernels = "nxzl::inflate_lanes_kernel (a stream per lane) and nxzi::inflate_kernel (a stream per wavefront) side by side + nxzl::cksum_kernel"
     out = {"value": round(u / (ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out", "ms_per_pass": round(ms, 3),
            "streams": n, "made_by": "zlib level 6, raw deflate, one stream per 64 KiB block", "bit_exact": True,
-           "roofline": roof((u + cb) / (ms * 1e-3) / 1e9, pmc_traffic(n, "inflate_zlib6"),
-                            "batched inflate (a stream per lane and a stream per wave side by side at this size) + cksum_kernel", copy_peak_gbs(torch, eng.dev, eng),
+           "roofline": roof((u + cb) / (ms * 1e-3) / 1e9, pmc_traffic(n, "inflate_zlib6"), wg_kernel if n < 196608 else old_kernels, copy_peak_gbs(torch, eng.dev, eng),
                             kernel_ms=round(ms, 3))}
+    # the same call on the first k streams of the batch: what a caller with fewer streams at hand gets
+    by_size = {}
+    for k in (256, 1024, 4096, 16384, 65536):
+        if k >= n:
+            continue
+        eng.decompress(jobs, k, results=res)
+        torch.cuda.synchronize(eng.dev)
+        e0.record()
+        for _ in range(3):
+            eng.decompress(jobs, k, results=res)
+        e1.record()
+        torch.cuda.synchronize(eng.dev)
+        mk = e0.elapsed_time(e1) / 3
+        rk = eng.results_to_host(res)
+        if not (bool((rk["cc"][:k] == 0).all()) and bool((rk["tpbc"][:k] == ulen[:k]).all())):
+            raise SystemExit("inflate leg: a batch of %d streams did not inflate" % k)
+        by_size[str(k)] = {"value": round(float(ulen[:k].astype(np.float64).sum()) / (mk * 1e-3) / 2.0 ** 30, 3), "ms_per_pass": round(mk, 3)}
+    if by_size:
+        out["by_batch_size"] = dict(by_size, unit="GiB/s uncompressed out", kernel=wg_kernel)
     if not args.no_cpu_baseline:
         cores = usable_cores()
         z1, _, _, _ = _cpu_run(streams, 2, 1, 2.0)

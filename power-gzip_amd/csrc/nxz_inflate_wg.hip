@@ -266,6 +266,50 @@ __device__ __forceinline__ unsigned long long decode_piece(uint32_t st, uint32_t
 NXZ_WG_PHASE unsigned long long piece_count(uint32_t st, uint32_t lim, uint32_t T) { return decode_piece<false>(st, lim, T, 0); }
 NXZ_WG_PHASE unsigned long long piece_write(uint32_t st, uint32_t lim, uint32_t T, uint32_t obase) { return decode_piece<true>(st, lim, T, obase); }
 
+// ---- the counting walk of ONE piece by a whole wavefront.  What the later rounds cost is the walk of the few pieces at the
+// heads of the chains that have not fallen in step, token after token, each a trip of 500 cycles, while a thousand lanes wait.
+// Here the 64 lanes decode the tokens that WOULD start at the next 64 bits, one bit each, side by side (one trip), and the walk
+// then only follows the lengths from the true position on -- a register read a token, four to five tokens a trip.  Same result
+// as piece_count (the tokens that start in [st, lim), their bytes, the flag), in every lane. ----
+NXZ_WG_PHASE unsigned long long piece_count_wave(uint32_t st, uint32_t lim, uint32_t T, int lane)
+{
+	uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)st), n = 0, fl = F_OK;
+	lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)lim);
+	while (p0 < lim) {
+		const uint32_t p = p0 + (uint32_t)lane;
+		const uint32_t w = p >> 5, sh = p & 31;
+		const uint32_t a = L.src[w], b = L.src[w + 1], c = L.src[w + 2];
+		const uint32_t lo = __builtin_amdgcn_alignbit(b, a, sh), hi = __builtin_amdgcn_alignbit(c, b, sh);
+		uint32_t e = L.lit[lo & ((1u << RL) - 1)];
+		if (e_kind(e) == K_LINK) e = L.lit[(e >> 16) + ((lo >> RL) & ((1u << e_xb(e)) - 1))];
+		const uint32_t nb = e & 31, kind = e_kind(e), x = e_xb(e), q = nb + x;
+		// what this bit would be the start of: bits to the next token | bytes it makes << 8 | (1 the end of the block, 2 no token) << 24
+		uint32_t tok = nb | 1u << 8;
+		if (kind == K_LEN) {
+			const uint32_t db = __builtin_amdgcn_alignbit(hi, lo, q);
+			uint32_t d = L.dist[db & ((1u << RD) - 1)];
+			if (e_kind(d) == K_LINK) d = L.dist[(d >> 16) + ((db >> RD) & ((1u << e_xb(d)) - 1))];
+			const uint32_t mlen = (e >> 16) + ((lo >> nb) & ((1u << x) - 1));
+			tok = e_kind(d) == K_DIST ? (q + (d & 31) + e_xb(d)) | mlen << 8 : 2u << 24;
+		} else if (kind != K_LIT) tok = kind == K_EOB ? nb | 1u << 24 : 2u << 24;
+		// the walk: a register read a token
+		const uint32_t olim = lim - p0 < 64 ? lim - p0 : 64;
+		uint32_t o = 0, t;
+		do {
+			t = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)o);
+			if (t >> 24) break;
+			n += t >> 8; o += t & 0xff;
+		} while (o < olim);
+		p0 += o;
+		if (t >> 24) {
+			if ((t >> 24) == 1) { p0 += t & 0xff; fl = F_EOB; } else fl = F_ERR;
+			break;
+		}
+	}
+	if (p0 > T) fl = F_RUNOUT;
+	return (unsigned long long)(p0 | fl << 24) | (unsigned long long)n << 32;
+}
+
 // ---- the matches, when all blocks are decoded: every byte of a match is the byte `distance` in front of it, which may itself
 // be a byte of a match ... down to a literal.  The first forms of this phase copied match after match, each as soon as a bitmap
 // showed its source bytes there: whatever the lanes' order, 130-260 matches deep in a 64 KiB block hang one behind the other,
@@ -590,6 +634,8 @@ NXZ_WG_PHASE void decode_span(uint32_t T, uint32_t spanbits, uint32_t capleft, u
 {
 	const int tid = threadIdx.x;
 #define WGPROF(idx) do { if (prof && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; L.prof[idx] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); } } while (0)
+	const uint32_t coop_max = max_rounds >> 16;                             // (so many pieces to decode again or fewer: a wavefront each)
+	max_rounds &= 0xffff;
 	const uint32_t cur = L.pos, R = T - cur < spanbits ? T - cur : spanbits, E = cur + R;
 	const uint32_t outn = L.outn, room = OUT_MAX - outn;
 	const bool wend = L.wend != 0;
@@ -632,11 +678,20 @@ NXZ_WG_PHASE void decode_span(uint32_t T, uint32_t spanbits, uint32_t capleft, u
 		__syncthreads();
 		const uint32_t cnt = L.nredo[par];
 		if (!cnt) break;
-		// (data whose codes are all of a length -- packed bytes under 8-bit codes -- never falls in step: such a block is the
-		// stream-per-wavefront kernel's, whose literal step takes it at full rate, and the sooner it goes there the better)
+		// (a round settles one more piece from the front at least, so there are never more rounds than pieces; the limit is a knob
+		// of the tests.  Packed data under nearly flat codes needs hundreds of rounds -- still cheaper than handing the stream back:
+		// own exact-table streams of the corpus, 4096 of them, 34 -> 94 GiB/s when the limit went from 256 to "none")
 		if (++rounds > max_rounds) { if (tid == 0) L.bail = R_ROUNDS; break; }
 		if (tid == 0) { L.nredo[par ^ 1] = 0; if (prof) { L.prof[P_MATCHES] += cnt; if (rounds <= 2) L.prof[P_MTRIPMAX] += cnt; } }
-		if ((uint32_t)tid < cnt) {
+		if (cnt <= coop_max) {
+			// few pieces left -- the heads of the chains: a wavefront each
+			for (uint32_t k = (uint32_t)tid >> 6; k < cnt; k += NW) {
+				const uint32_t ent = L.list[k], j = ent & 1023;
+				const uint32_t gj = cur + j * P, limj = j + 1 == NP ? E : gj + P;
+				const unsigned long long r = piece_count_wave(gj + (ent >> 10), limj, T, tid & 63);
+				if ((tid & 63) == 0) { L.pend[j] = (uint32_t)r; L.nout[j] = (uint32_t)(r >> 32); }
+			}
+		} else if ((uint32_t)tid < cnt) {
 			const uint32_t ent = L.list[tid], j = ent & 1023;
 			const uint32_t gj = cur + j * P, limj = j + 1 == NP ? E : gj + P;
 			const unsigned long long r = piece_count(gj + (ent >> 10), limj, T);
@@ -779,7 +834,6 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	uint8_t *ob = (uint8_t *)L.out;
 	const uint8_t *sb = (const uint8_t *)L.src;
-	(void)nres;
 #define WGPROF(idx) do { if (PROF && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; L.prof[idx] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); } } while (0)
 	if (PROF && tid == 0) { for (int i = 0; i < P_N; i++) L.prof[i] = 0; const unsigned long long now_ = (unsigned long long)clock64(); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); }
 
@@ -920,7 +974,7 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 				WGPROF(P_HEADER);
 				continue;
 			}
-			decode_span(T, spanbits, job.dst_cap - made, pmin_bits & 0xffff, pmin_bits >> 16, PROF);
+			decode_span(T, spanbits, job.dst_cap - made, pmin_bits & 0xffff, pmin_bits >> 16 | nres << 16, PROF);
 		}
 		__syncthreads();
 		if (L.bail) {
@@ -974,9 +1028,9 @@ extern "C" int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_
 	const char *pe = getenv("NXZ_WG_PMIN");                            // (read at every call: the tests switch it)
 	const unsigned pmin = pe && atoi(pe) >= 64 ? (unsigned)atoi(pe) : 128u;
 	const char *mre = getenv("NXZ_WG_ROUNDS");
-	const unsigned maxr = mre && atoi(mre) >= 2 && atoi(mre) <= 1024 ? (unsigned)atoi(mre) : 256u;
-	const char *nre = getenv("NXZ_WG_NRES");
-	const unsigned nres = nre && (atoi(nre) & 0xffff) >= 1 && (atoi(nre) & 0xffff) <= nxzw::NT ? (unsigned)atoi(nre) : 1024u;
+	const unsigned maxr = mre && atoi(mre) >= 2 && atoi(mre) <= 1024 ? (unsigned)atoi(mre) : 1024u;
+	const char *nre = getenv("NXZ_WG_COOP");                           // so many pieces left in a round or fewer: a wavefront walks each
+	const unsigned nres = nre && atoi(nre) >= 0 && atoi(nre) <= 1024 ? (unsigned)atoi(nre) : 16u;
 	const unsigned grid = (unsigned)(n < cus ? n : cus);
 	const char *pr = getenv("NXZ_WG_PROF");
 	if (pr && atoi(pr)) hipLaunchKernelGGL(nxzw::inflate_wg_kernel<true>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin | maxr << 16, nres, dbg, prof);

@@ -770,6 +770,7 @@ static size_t parallel_inflate_min(bool whole_at_once)
 	static const size_t v = getenv("NXZ_PARALLEL_INFLATE_MIN") ? (size_t)strtoull(getenv("NXZ_PARALLEL_INFLATE_MIN"), nullptr, 0) : 0;
 	return v ? v : whole_at_once ? (size_t)64 << 10 : (size_t)12 << 10;
 }
+static std::atomic<int> g_inflate_callers{0};    // threads inside nx_inflate right now
 constexpr size_t CARRY_KEEP = 1024;                // unconsumed source kept between calls at most: a dynamic block header (<= 290 bytes) and a token
 
 bool parallel_inflate(Inflate *s)
@@ -782,6 +783,12 @@ bool parallel_inflate(Inflate *s)
 	static const bool off = getenv("NXZ_PARALLEL_INFLATE") && atoi(getenv("NXZ_PARALLEL_INFLATE")) == 0;   // 0: always job after job
 	const size_t nc = s->carry.size();
 	if (off || nc + z->avail_in < parallel_inflate_min(s->whole_at_once)) return false;
+	// A whole stream of up to a few hundred KiB from a caller who is not alone: as ONE job -- the rounds of nxu_run_job take the
+	// callers' jobs together, a stream per workgroup in one launch (nxz_inflate_wg.hip), where the parts of this function run their
+	// sequences of small kernels one caller after the other: 16 threads x 256 KiB buffers 1.7 -> 2.9 GiB/s, x 512 KiB 2.5 -> 3.0.
+	// (A caller alone is better off here from 256 KiB on: one workgroup makes 0.3-0.4 GiB/s of one stream.)
+	if (s->whole_at_once && g_inflate_callers.load(std::memory_order_relaxed) > 1 && nc + z->avail_in <= (size_t)384 << 10 &&
+	    (size_t)z->avail_out + WINDOW + (WINDOW >> 2) <= ((size_t)1 << 20)) return false;
 	if (s->par_skip) { s->par_skip--; return false; }           // (declined a moment ago: this stream is not the kind)
 	nxz_ctx_t *ctx = (nxz_ctx_t *)s->eng.dev.paste_addr;
 	if (!ctx) return false;
@@ -1215,6 +1222,7 @@ extern "C" int nx_inflate(z_streamp strm, int flush)
 	if (flush == Z_BLOCK || flush == Z_TREES) { strm->msg = (char *)"Z_BLOCK or Z_TREES not implemented"; return Z_STREAM_ERROR; }
 	if (strm->next_out == Z_NULL && strm->avail_out) return Z_STREAM_ERROR;
 	const uInt in0 = strm->avail_in, out0 = strm->avail_out;
+	struct Caller { Caller() { g_inflate_callers.fetch_add(1, std::memory_order_relaxed); } ~Caller() { g_inflate_callers.fetch_sub(1, std::memory_order_relaxed); } } caller_here;
 	s->whole_at_once = (flush == Z_FINISH || s->one_shot_hint) && strm->total_in == 0;
 	int rc = Z_OK;
 	uint32_t c;

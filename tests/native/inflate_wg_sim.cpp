@@ -3,7 +3,7 @@
 // by system zlib.  Checks: every stream the kernel takes comes out byte for byte with the result record of a finished
 // stream; every stream it does not take is on the hand-back list (and only those); damaged streams are handed back, never
 // "decoded".
-//   usage: inflate_wg_sim <file with sample text> [seed] [pmin_bits] [unused] [bytes of the long cases]
+//   usage: inflate_wg_sim <file with sample text> [seed] [pmin_bits] [pieces a wavefront walks] [bytes of the long cases]
 #include "hip_cpu_shim.h"
 #include "../../power-gzip_amd/csrc/nxz_inflate_wg.hip"
 #include <zlib.h>
@@ -43,7 +43,7 @@ int main(int argc, char **argv)
 	}
 	if (argc > 2) rng_state ^= (uint64_t)strtoull(argv[2], nullptr, 0) * 0x9E3779B97F4A7C15ull;
 	const uint32_t pmin = argc > 3 ? (uint32_t)atoi(argv[3]) : 512;
-	const uint32_t nres = argc > 4 ? (uint32_t)atoi(argv[4]) : 256;
+	const uint32_t nres = argc > 4 ? (uint32_t)atoi(argv[4]) : 16;          // (so many pieces left in a round or fewer: a wavefront walks each)
 	const size_t longn = argc > 5 ? (size_t)atoi(argv[5]) : 600000;      // bytes of the long cases (the simulation takes a minute per MiB)
 	auto slice = [&](size_t at, size_t n) { return std::vector<uint8_t>(text.begin() + at % (text.size() - n), text.begin() + at % (text.size() - n) + n); };
 	std::vector<Case> cases;

@@ -812,9 +812,11 @@ def test_a_dynamic_block_behind_the_sample_sends_the_batch_back_to_the_general_k
     dst = torch.zeros((n, ostride), dtype=torch.uint8, device=eng.dev)
     jobs = eng.jobs_strided(src, cstride, np.array([len(c) for _, c in streams], np.uint32), dst, ostride, ostride)
     saved = {k: os.environ.pop(k, None) for k in ("NXZ_INFLATE_LANES_MIN", "NXZ_LANES_FIXED")}
+    os.environ["NXZ_INFLATE_WG"] = "0"            # (a batch of this size goes a stream per workgroup since round 6: this test is the lane kernels')
     try:
         r = eng.results_to_host(eng.decompress(jobs, n))
     finally:
+        os.environ.pop("NXZ_INFLATE_WG", None)
         for k, v in saved.items():
             if v is not None:
                 os.environ[k] = v
@@ -838,10 +840,12 @@ def test_a_dynamic_block_behind_the_sample_sends_the_batch_back_to_the_general_k
     src = pack_blocks(eng, [c for _, c in streams], cstride)
     jobs = eng.jobs_strided(src, cstride, np.array([len(c) for _, c in streams], np.uint32), dst, ostride, ostride)
     saved = {k: os.environ.pop(k, None) for k in ("NXZ_INFLATE_LANES_MIN", "NXZ_LANES_FIXED")}
+    os.environ["NXZ_INFLATE_WG"] = "0"            # (a batch of this size goes a stream per workgroup since round 6: this test is the lane kernels')
     try:
         r = eng.results_to_host(eng.decompress(jobs, n))
         assert eng.L.nxz_ctx_lanes_handed_back(eng.ctx, eng.stream_handle(), n, C.byref(back)) == 0
     finally:
+        os.environ.pop("NXZ_INFLATE_WG", None)
         for k, v in saved.items():
             if v is not None:
                 os.environ[k] = v

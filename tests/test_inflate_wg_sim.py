@@ -14,7 +14,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="the kernel source uses clang builtins: needs ROCm's clang++")
-@pytest.mark.parametrize("seed,pmin,nres", [(1, 128, 1024), (2, 512, 64)])
+@pytest.mark.parametrize("seed,pmin,nres", [(1, 128, 16), (2, 160, 1024)])   # (nres: so many pieces left in a round or fewer and a wavefront walks each)
 def test_workgroup_inflate_kernel_on_the_cpu(tmp_path, seed, pmin, nres):
     exe = tmp_path / "inflate_wg_sim"
     subprocess.run([CLANG, "-O1", "-g", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "native", "inflate_wg_sim.cpp"),

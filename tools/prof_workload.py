@@ -2,7 +2,7 @@
 """One leg of the bench workload for profiling runs (rocprofv3 --kernel-trace --stats / --pmc ... -- python3 tools/prof_workload.py <leg>):
   fht            fixed-Huffman deflate of 65536 synthetic blocks (bench.gen_blocks), 3 passes
   dhtgen         COMPRESS_DHTGEN of the real-data corpus replicated to >= 65536 jobs, 3 passes
-  inflate_zlib6  zlib -6 streams of the corpus blocks, >= 65536 streams (a stream per wave, the target as window), 3 passes
+  inflate_zlib6  zlib -6 streams of the corpus blocks, >= 65536 streams (the route the engine chooses: a stream per workgroup), 3 passes
   inflate_own    the engine's own fixed-Huffman output, 262144 streams (a stream per lane), 2 passes
   inflate_stream ONE 256 MiB zlib -6 stream, 3 passes
   c5             BASELINE configs[4]: 163840 mixed blocks (10 GiB), bench.c5_prepare's step (compress + wrap + decompress + wrap + compare), 2 passes;
