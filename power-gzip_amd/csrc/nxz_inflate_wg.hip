@@ -1,11 +1,11 @@
-// nxz_inflate_wg.hip -- batched DEFLATE decompression, one stream per WORKGROUP, the whole stream in LDS.
+// nxz_inflate_wg.hip -- batched DEFLATE decompression, one stream per WORKGROUP, the stream in LDS.
 //
 // Same engine function as nxz_inflate.hip / nxz_inflate_lanes.hip (GZIP_FC_DECOMPRESS, issued at /root/reference
 // lib/nx_inflate.c:909-912; outputs inc_nx/nxu.h:403-541; CPU restatement: oracle/nxz_inflate.c) for the streams a batch is
-// made of nearly always: a fresh stream (no resume state, no history) of at most 64 KiB of output and 64 KiB of source that
-// runs to its final end-of-block.  Anything else -- an error of any kind, a stream that ends early, a target that is too
-// small, resume fields -- is HANDED BACK (a list of job indices, as inflate_lanes_fixed_kernel does it) to the kernels that
-// know every case; this one never reports an error itself.
+// made of nearly always: a fresh stream (no resume state, no history) that runs to its final end-of-block, of any length.
+// Anything else -- an error of any kind, a stream that ends early, a target that is too small, resume fields -- is HANDED
+// BACK (a list of job indices, as inflate_lanes_fixed_kernel does it) to the kernels that know every case; this one never
+// reports an error itself.
 //
 // Why a workgroup per stream: a CU of gfx950 has 160 KiB of LDS, which holds a 64 KiB block's source AND its output AND its
 // decode tables.  So the source is read from HBM once, coalesced; the output is written once, coalesced; every table look-up,
@@ -14,17 +14,17 @@
 // spends thirty wave-instructions on a token.  Here 1024 lanes decode ONE Huffman-coded block side by side:
 //   1. the block's header is read by one wavefront, the decode tables (10 / 9 root bits + sub-tables, 32-bit entries that
 //      carry base and extra-bit count) are built by all;
-//   2. the rest of the source is cut into pieces, a lane each.  Lane 0 starts at the block's first token, the others at a
-//      guess; every lane decodes (lengths only) to the first token that starts in the next piece.  Huffman-coded data
-//      synchronises itself, so most lanes END on a true token boundary although they began on a false one: in the next
-//      round every lane begins where its neighbour ended, and the rounds go on until no lane's start moves (usually 2-4);
-//      the lane that met the end-of-block code ends the block;
+//   2. the span to decode is cut into pieces, a lane each.  Lane 0 starts at the first token, the others at a guess; every
+//      lane decodes (lengths only) to the first token that starts in the next piece.  Huffman-coded data synchronises itself,
+//      so most lanes END on a true token boundary although they began on a false one: in the next round every piece whose
+//      neighbour ended elsewhere is walked again from there, until no start moves (6-8 rounds; never more than pieces);
 //   3. a prefix sum over the pieces' output counts gives every lane its place in the output; a last pass writes the
-//      literals and parks every match as a 3-byte record in the first bytes of the room it will fill (two bitmaps: where
-//      matches start, which bytes are not there yet);
-//   4. when all blocks are decoded, every lane resolves the matches that start in its 64 bytes of the output, in order, each
-//      as soon as its source bytes are there (the bitmap says so; the lowest unresolved match can always go);
+//      literals and parks every match as a 3-byte record in the first bytes of the room it will fill (a bitmap: where
+//      matches start);
+//   4. when LDS is full or the stream is over, the matches are resolved by pointer jumping (resolve_matches) and
 //   5. the output leaves LDS 16 bytes a lane.  (CRC-32 / Adler-32: nxzl::cksum_kernel behind this one, as for the lane kernels.)
+// A stream longer than LDS goes in spans: the source through a 64 KiB window, the output flushed with its last 32 KiB kept
+// as the window of distances (flush_out), a piece committed whole or not at all.
 //
 // Written against a small subset of the device language (barriers, ballots, shuffles, LDS atomics) so that
 // tests/native/hip_cpu_shim.h can run a workgroup on the CPU, an OS thread per lane: tests/test_inflate_wg_sim.py.
@@ -33,17 +33,10 @@
 #include <stdlib.h>
 #include <stdint.h>
 #include "nxz_device.h"
-// no lane of the wavefront found its source there: stand back (the CU's older wavefronts get the instruction issue before the
-// younger ones, and a wavefront that spins at full rate keeps the one whose lane everybody waits for from its turn)
-#define NXZ_SPIN_HINT(progress) do { if (!__builtin_amdgcn_ballot_w64(progress)) __builtin_amdgcn_s_sleep(NXZ_WG_SLEEP); } while (0)
-#ifndef NXZ_WG_SLEEP
-#define NXZ_WG_SLEEP 2
-#endif
 #define NXZ_WG_GLOBAL NXZ_GLOBAL_AS
 #else
 #include <stdint.h>
 #include "../../include/nxz_engine.h"
-#define NXZ_SPIN_HINT(progress) do { if (!(progress)) sched_yield(); } while (0)
 #define NXZ_WG_GLOBAL
 #endif
 
@@ -639,7 +632,7 @@ NXZ_WG_PHASE void decode_span(uint32_t T, uint32_t spanbits, uint32_t capleft, u
 	const uint32_t cur = L.pos, R = T - cur < spanbits ? T - cur : spanbits, E = cur + R;
 	const uint32_t outn = L.outn, room = OUT_MAX - outn;
 	const bool wend = L.wend != 0;
-	uint32_t np0 = R / pmin_bits;
+	uint32_t np0 = (R + pmin_bits - 1) / pmin_bits;                      // (pieces of pmin_bits at most unless the lanes run out: a piece of 2-bit tokens, 258 bytes each, must fit the 32 KiB a flush frees)
 	np0 = np0 < 1 ? 1 : np0 > (uint32_t)NT ? (uint32_t)NT : np0;
 	const uint32_t pdw = (((R + np0 - 1) / np0 + 31) >> 5) | 1;          // dwords a piece, odd: neighbours begin in different LDS banks
 	const uint32_t P = pdw * 32;

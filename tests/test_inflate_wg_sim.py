@@ -19,6 +19,6 @@ def test_workgroup_inflate_kernel_on_the_cpu(tmp_path, seed, pmin, nres):
     exe = tmp_path / "inflate_wg_sim"
     subprocess.run([CLANG, "-O1", "-g", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "native", "inflate_wg_sim.cpp"),
                     "-o", str(exe), "-lz"], check=True)
-    r = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "alice29.txt"), str(seed), str(pmin), str(nres), "120000"],
+    r = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "alice29.txt"), str(seed), str(pmin), str(nres), "70000"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

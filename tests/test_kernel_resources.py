@@ -27,7 +27,8 @@ BUDGET = {
     "nxzi::inflate_kernel<false, true>": (128, 0),
     "nxzl::inflate_lanes_kernel": (128, 48),          # a stream per lane, any block type: four waves per SIMD
     "nxzl::inflate_lanes_fixed_kernel": (80, 32),     # ... stored and fixed-code blocks only: six
-    "nxzw::inflate_wg_kernel<false>": (128, 16),      # a stream per workgroup of 1024 threads: 128 is the cap; its phases are functions of their own
+    "nxzw::inflate_wg_kernel<false>": (128, 128),     # a stream per workgroup of 1024 threads: 128 is the cap; its phases are functions of their own
+                                                      # (the scratch: the registers those functions save on entry, none in their loops)
     "nxzl::cksum_kernel<false>": (96, 0),
     "nxzl::cksum_kernel<true>": (96, 0),            # the WRAP function code: the same pass, storing as it goes
     "nxzb::find_blocks_kernel": (96, 0),
