@@ -368,18 +368,21 @@ NXZ_WG_PHASE void resolve_matches(uint32_t from, uint32_t outn, int prof)
 		}
 		__syncthreads();
 		WGPROF2(P_LIST);
-		uint32_t pp[16];                                                     // ... in registers from here on
-		{
-			const v4u *p4 = (const v4u *)(P + i0);
+		// The jumping and the gather go by ANOTHER split of the half than the build's: a lane takes the four bytes 4 g .. 4 g + 3
+		// of the groups g = tid, tid + 1024, ... (eight of them) -- the wavefront's lanes stand on 256 consecutive bytes, whose
+		// sources are mostly consecutive too (the bytes of a match), so the wavefront's look-ups fall into neighbouring LDS banks
+		// instead of 64 random ones, and its own pointers and output dwords are side by side.
+		struct alignas(8) U2 { uint32_t x, y; };
+		U2 *PG = (U2 *)P;
+		uint32_t pp[16];                                                     // pp[2 j], pp[2 j + 1]: the pointers of group tid + NT j
 #pragma unroll
-			for (uint32_t j = 0; j < 4; j++) { const v4u v = p4[j]; pp[4 * j] = v.x; pp[4 * j + 1] = v.y; pp[4 * j + 2] = v.z; pp[4 * j + 3] = v.w; }
-		}
-		// rounds of jumping: the lane's own pointers stay in its registers; what moved is written back for the others to jump through
+		for (uint32_t j = 0; j < 8; j++) { const U2 v = PG[(uint32_t)tid + NT * j]; pp[2 * j] = v.x; pp[2 * j + 1] = v.y; }
 		uint32_t rounds = 0, open = 0;
 #pragma unroll
 		for (uint32_t j = 0; j < 16; j++) {                                  // (open: pointers that are not their own source)
-			if ((pp[j] & 0xffff) != x0 + 2 * j) open |= 1u << (2 * j);
-			if ((pp[j] >> 16) != x0 + 2 * j + 1) open |= 2u << (2 * j);
+			const uint32_t xg = base + 4 * ((uint32_t)tid + NT * (j >> 1)) + 2 * (j & 1);
+			if ((pp[j] & 0xffff) != xg) open |= 1u << (2 * j);
+			if ((pp[j] >> 16) != xg + 1) open |= 2u << (2 * j);
 		}
 		for (;;) {
 			bool moved = false;
@@ -392,19 +395,18 @@ NXZ_WG_PHASE void resolve_matches(uint32_t from, uint32_t outn, int prof)
 				uint32_t na = a >= base ? P[a - base] : a, nb = b >= base ? P[b - base] : b;   // (a pointer into the first half: the end of its chain)
 				if (na == a) open &= ~(1u << (2 * j)); else { const uint32_t n2 = na >= base ? P[na - base] : na; if (n2 == na) open &= ~(1u << (2 * j)); na = n2; }
 				if (nb == b) open &= ~(2u << (2 * j)); else { const uint32_t n2 = nb >= base ? P[nb - base] : nb; if (n2 == nb) open &= ~(2u << (2 * j)); nb = n2; }
-				if (na != a || nb != b) { pp[j] = na | nb << 16; p2[j] = pp[j]; moved = true; }
+				if (na != a || nb != b) { pp[j] = na | nb << 16; ((uint32_t *)P)[2 * ((uint32_t)tid + NT * (j >> 1)) + (j & 1)] = pp[j]; moved = true; }
 			}
 			rounds++;
 			if (!__syncthreads_or(moved)) break;
 		}
 		WGPROF2(P_MWAITS);
-		// every byte from the end of its chain (this lane's 32 bytes: eight dwords of its own)
+		// every byte from the end of its chain
 		{
-			uint32_t *o4 = L.out + (x0 >> 2);
 #pragma unroll
 			for (uint32_t j = 0; j < 8; j++) {
 				const uint32_t pa = pp[2 * j], pb = pp[2 * j + 1];
-				o4[j] = (uint32_t)ob[pa & 0xffff] | (uint32_t)ob[pa >> 16] << 8 | (uint32_t)ob[pb & 0xffff] << 16 | (uint32_t)ob[pb >> 16] << 24;
+				L.out[(base >> 2) + (uint32_t)tid + NT * j] = (uint32_t)ob[pa & 0xffff] | (uint32_t)ob[pa >> 16] << 8 | (uint32_t)ob[pb & 0xffff] << 16 | (uint32_t)ob[pb >> 16] << 24;
 			}
 		}
 		if (prof && tid == 0) L.prof[P_MTRIPS] += rounds;

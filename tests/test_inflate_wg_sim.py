@@ -13,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
+PARAMS = [(1, 128, 16)] + ([(2, 160, 1024), (3, 250, 0)] if os.environ.get("NXZ_SIM_FULL") else [])   # (two minutes a run; nres: pieces left in a round up to which a wavefront walks each)
+
+
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="the kernel source uses clang builtins: needs ROCm's clang++")
-@pytest.mark.parametrize("seed,pmin,nres", [(1, 128, 16), (2, 160, 1024)])   # (nres: so many pieces left in a round or fewer and a wavefront walks each)
+@pytest.mark.parametrize("seed,pmin,nres", PARAMS)
 def test_workgroup_inflate_kernel_on_the_cpu(tmp_path, seed, pmin, nres):
     exe = tmp_path / "inflate_wg_sim"
     subprocess.run([CLANG, "-O1", "-g", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "native", "inflate_wg_sim.cpp"),
