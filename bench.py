@@ -876,6 +876,9 @@ def inflate_leg(torch, eng, pkg, raw, rep, args):
         if not (bool((rk["cc"][:k] == 0).all()) and bool((rk["tpbc"][:k] == ulen[:k]).all())):
             raise SystemExit("inflate leg: a batch of %d streams did not inflate" % k)
         by_size[str(k)] = {"value": round(float(ulen[:k].astype(np.float64).sum()) / (mk * 1e-3) / 2.0 ** 30, 3), "ms_per_pass": round(mk, 3)}
+        if k == 65536:
+            by_size[str(k)]["roofline"] = roof((float(ulen[:k].astype(np.float64).sum()) + float(clen[:k].astype(np.float64).sum())) / (mk * 1e-3) / 1e9,
+                                               pmc_traffic(k, "inflate_wg"), wg_kernel, copy_peak_gbs(torch, eng.dev, eng), kernel_ms=round(mk, 3))
     if by_size:
         out["by_batch_size"] = dict(by_size, unit="GiB/s uncompressed out", kernel=wg_kernel)
     if not args.no_cpu_baseline:

@@ -393,8 +393,16 @@ NXZ_WG_PHASE void resolve_matches(uint32_t from, uint32_t outn, int prof)
 				// two links a round (the rounds' barriers and the sixteen blocks of this loop cost more than the look-ups once few
 				// pointers are still open)
 				uint32_t na = a >= base ? P[a - base] : a, nb = b >= base ? P[b - base] : b;   // (a pointer into the first half: the end of its chain)
-				if (na == a) open &= ~(1u << (2 * j)); else { const uint32_t n2 = na >= base ? P[na - base] : na; if (n2 == na) open &= ~(1u << (2 * j)); na = n2; }
-				if (nb == b) open &= ~(2u << (2 * j)); else { const uint32_t n2 = nb >= base ? P[nb - base] : nb; if (n2 == nb) open &= ~(2u << (2 * j)); nb = n2; }
+				if (na == a) open &= ~(1u << (2 * j)); else {
+					uint32_t n2 = na >= base ? P[na - base] : na;
+					if (n2 == na) open &= ~(1u << (2 * j)); else { const uint32_t n3 = n2 >= base ? P[n2 - base] : n2; if (n3 == n2) open &= ~(1u << (2 * j)); n2 = n3; }
+					na = n2;
+				}
+				if (nb == b) open &= ~(2u << (2 * j)); else {
+					uint32_t n2 = nb >= base ? P[nb - base] : nb;
+					if (n2 == nb) open &= ~(2u << (2 * j)); else { const uint32_t n3 = n2 >= base ? P[n2 - base] : n2; if (n3 == n2) open &= ~(2u << (2 * j)); n2 = n3; }
+					nb = n2;
+				}
 				if (na != a || nb != b) { pp[j] = na | nb << 16; ((uint32_t *)P)[2 * ((uint32_t)tid + NT * (j >> 1)) + (j & 1)] = pp[j]; moved = true; }
 			}
 			rounds++;

@@ -3,7 +3,7 @@
 # their own as MI355X_MICROARCH.md's rocprofv3 section prescribes): tools/prof_all.sh <out dir> [legs...]
 set -u
 OUT=${1:-gpurun_out/prof}; shift
-LEGS=${@:-fht dhtgen inflate_zlib6 inflate_own inflate_stream c5}
+LEGS=${@:-fht dhtgen inflate_zlib6 inflate_wg inflate_own inflate_stream c5}
 mkdir -p $OUT
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 for leg in $LEGS; do

@@ -9,7 +9,7 @@ Corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are in KB
 import collections, csv, glob, json, os, sys
 src, prefix = sys.argv[1], sys.argv[2]
 CLOCK, CUS = 2.4e9, 256
-LEGS = ["fht", "dhtgen", "inflate_zlib6", "inflate_own", "inflate_stream", "c5"]
+LEGS = ["fht", "dhtgen", "inflate_zlib6", "inflate_wg", "inflate_own", "inflate_stream", "c5"]
 
 
 def kname(s):
@@ -70,7 +70,7 @@ for leg in LEGS:
         wr = write[k].get("WRITE_SIZE", 0.0) * 1024 / own_units
         per[k] = {"read": round(rd), "write": round(wr), "avg_launch_ms": round(tot_ns.get(k, 0) / max(calls.get(k, 1), 1) * 1e-6, 4), "launches": calls.get(k)}
     total = sum(v["read"] + v["write"] for v in per.values())
-    unit = {"fht": "64 KiB block", "dhtgen": "64 KiB block (corpus)", "inflate_zlib6": "stream of one 64 KiB block", "inflate_own": "stream of one 64 KiB block",
+    unit = {"fht": "64 KiB block", "dhtgen": "64 KiB block (corpus)", "inflate_zlib6": "stream of one 64 KiB block", "inflate_wg": "stream of one 64 KiB block", "inflate_own": "stream of one 64 KiB block",
             "inflate_stream": "64 KiB of output", "c5": "64 KiB block of the mixed batch, one whole step (compress + wrap + decompress + wrap)"}[leg]
     json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate runs) --output-format csv -- python3 tools/prof_workload.py %s" % leg,
                "unit": unit, "block_bytes": 65536, "units_per_pass": info["units"], "passes": info["passes"],
