@@ -852,12 +852,11 @@ def inflate_leg(torch, eng, pkg, raw, rep, args):
     if not ok:
         raise SystemExit("inflate leg: zlib -6 streams did not inflate to their sources")
     u, cb = float(ulen.astype(np.float64).sum()), float(clen.astype(np.float64).sum())
-    # (the engine's routes by batch size, nxz_engine.cpp batch_decompress: up to 196 607 streams a stream per workgroup)
+    # (the engine's route for streams that bring tables, nxz_engine.cpp batch_decompress: a stream per workgroup at every batch size)
     wg_kernel = "nxzw::inflate_wg_kernel<false> (a stream per workgroup: source, output and tables in LDS) + nxzl::cksum_kernel"
-    old_kernels = "nxzl::inflate_lanes_kernel (a stream per lane) and nxzi::inflate_kernel (a stream per wavefront) side by side + nxzl::cksum_kernel"
     out = {"value": round(u / (ms * 1e-3) / 2.0 ** 30, 3), "unit": "GiB/s uncompressed out", "ms_per_pass": round(ms, 3),
            "streams": n, "made_by": "zlib level 6, raw deflate, one stream per 64 KiB block", "bit_exact": True,
-           "roofline": roof((u + cb) / (ms * 1e-3) / 1e9, pmc_traffic(n, "inflate_zlib6"), wg_kernel if n < 196608 else old_kernels, copy_peak_gbs(torch, eng.dev, eng),
+           "roofline": roof((u + cb) / (ms * 1e-3) / 1e9, pmc_traffic(n, "inflate_wg"), wg_kernel, copy_peak_gbs(torch, eng.dev, eng),
                             kernel_ms=round(ms, 3))}
     # the same call on the first k streams of the batch: what a caller with fewer streams at hand gets
     by_size = {}

@@ -622,20 +622,18 @@ static int batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n,
 	bool lanes = force ? (force & 3) == 1 : n >= lanes_min, by_len = (force & 4) != 0, no_tables = false;
 	bool split = false;
 	// A stream per WORKGROUP, source, output and tables in LDS (nxz_inflate_wg.hip): every batch, unless one of the older routes' knobs
-	// is set (the tests' way to name a route) -- except the very large ones: from 98 304 streams on the batches whose sampled streams
-	// begin with fixed-code or stored blocks (the fixed-code lane kernel's), from 196 608 on all of them.  That kernel runs at one rate
-	// from a few thousand streams on (a CU a stream; profiles/r06_inflate_by_batch_size.txt: zlib -6 streams of the corpus 81-82 GiB/s
-	// from 4096 streams on, own exact-table streams 89-96 from 65 536, fixed-code synthetic blocks 120-127), where a stream per
-	// wavefront needs 16 384 streams for 56 and levels off at 66, and a stream per lane needs 100 000; only fixed-code streams by the
-	// hundred thousand (157-178 a stream per lane) and zlib -6 streams at 262 144 (86, both older kernels side by side) are ahead of
-	// it.  Streams of any length are its own (in spans, the output flushed in halves); what it does not do -- streams that resume or
-	// bring a history, end early or are damaged, blocks that do not fall in step -- it hands back, and those go a stream per wavefront
-	// behind it.  NXZ_INFLATE_WG=0 / 1: never / always; NXZ_INFLATE_WG_MAX: batches up to that size only.
+	// is set (the tests' way to name a route) -- except, from 98 304 streams on, the batches whose sampled streams begin with fixed-code
+	// or stored blocks (the fixed-code lane kernel's: 153-173 GiB/s against 138).  That kernel runs at one rate from a few thousand
+	// streams on (a CU a stream; profiles/r06_inflate_by_batch_size.txt: zlib -6 streams of the corpus 89-91 GiB/s from 4096 streams on,
+	// own exact-table streams 109-112, fixed-code synthetic blocks 132-138), where a stream per wavefront needs 16 384 streams for 56
+	// and levels off at 66, and a stream per lane needs 100 000 (zlib -6 streams at 262 144, both older kernels side by side: 87).
+	// Streams of any length are its own (in spans, the output flushed in halves); what it does not do -- streams that resume or bring
+	// a history, end early or are damaged -- it hands back, and those go a stream per wavefront behind it.
+	// NXZ_INFLATE_WG=0 / 1: never / always; NXZ_INFLATE_WG_MAX: batches up to that size only.
 	const char *wge = getenv("NXZ_INFLATE_WG");                         // (read at every call: the tests switch it)
 	const char *wgm = getenv("NXZ_INFLATE_WG_MAX");
 	const size_t wg_max = wgm ? (size_t)strtoull(wgm, nullptr, 0) : ~(size_t)0;
 	bool wg = !force && (wge ? atoi(wge) != 0 : (!lm && !getenv("NXZ_INFLATE_CUT") && n <= wg_max));
-	if (wg && !wge && n >= 196608) wg = false;
 	if (wg && !wge && n >= 98304) {
 		// (the sample the older routes take below: here only "do these streams bring tables?")
 		uint32_t *h = nullptr;

@@ -2,8 +2,8 @@
 """One leg of the bench workload for profiling runs (rocprofv3 --kernel-trace --stats / --pmc ... -- python3 tools/prof_workload.py <leg>):
   fht            fixed-Huffman deflate of 65536 synthetic blocks (bench.gen_blocks), 3 passes
   dhtgen         COMPRESS_DHTGEN of the real-data corpus replicated to >= 65536 jobs, 3 passes
-  inflate_zlib6  zlib -6 streams of the corpus blocks, >= 262144 streams as the bench leg runs them (the older kernels side by side), 3 passes
-  inflate_wg     the same streams, >= 65536 of them: a stream per workgroup (nxz_inflate_wg.hip), 3 passes
+  inflate_zlib6  zlib -6 streams of the corpus blocks, >= 262144 streams as the bench leg runs them, 3 passes
+  inflate_wg     the same streams, >= 65536 of them (both: a stream per workgroup, nxz_inflate_wg.hip), 3 passes
   inflate_own    the engine's own fixed-Huffman output, 262144 streams (a stream per lane), 2 passes
   inflate_stream ONE 256 MiB zlib -6 stream, 3 passes
   c5             BASELINE configs[4]: 163840 mixed blocks (10 GiB), bench.c5_prepare's step (compress + wrap + decompress + wrap + compare), 2 passes;
