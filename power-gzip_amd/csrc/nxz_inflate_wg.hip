@@ -276,28 +276,29 @@ NXZ_WG_PHASE unsigned long long piece_count_wave(uint32_t st, uint32_t lim, uint
 		uint32_t e = L.lit[lo & ((1u << RL) - 1)];
 		if (e_kind(e) == K_LINK) e = L.lit[(e >> 16) + ((lo >> RL) & ((1u << e_xb(e)) - 1))];
 		const uint32_t nb = e & 31, kind = e_kind(e), x = e_xb(e), q = nb + x;
-		// what this bit would be the start of: bits to the next token | bytes it makes << 8 | (1 the end of the block, 2 no token) << 24
+		// what this bit would be the start of: bits to the next token | bytes it makes << 8; the end of the block and "no token"
+		// stand as a step of 128 bits that makes nothing (the walk below ends on it by itself) | the code's bits << 17 | 1 or 2 << 24
 		uint32_t tok = nb | 1u << 8;
 		if (kind == K_LEN) {
 			const uint32_t db = __builtin_amdgcn_alignbit(hi, lo, q);
 			uint32_t d = L.dist[db & ((1u << RD) - 1)];
 			if (e_kind(d) == K_LINK) d = L.dist[(d >> 16) + ((db >> RD) & ((1u << e_xb(d)) - 1))];
 			const uint32_t mlen = (e >> 16) + ((lo >> nb) & ((1u << x) - 1));
-			tok = e_kind(d) == K_DIST ? (q + (d & 31) + e_xb(d)) | mlen << 8 : 2u << 24;
-		} else if (kind != K_LIT) tok = kind == K_EOB ? nb | 1u << 24 : 2u << 24;
-		// the walk: a register read a token
+			tok = e_kind(d) == K_DIST ? (q + (d & 31) + e_xb(d)) | mlen << 8 : 128u | 2u << 24;
+		} else if (kind != K_LIT) tok = kind == K_EOB ? 128u | nb << 17 | 1u << 24 : 128u | 2u << 24;
+		// the walk: a register read a token, one way out of the loop
 		const uint32_t olim = lim - p0 < 64 ? lim - p0 : 64;
 		uint32_t o = 0, t;
 		do {
 			t = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)o);
-			if (t >> 24) break;
-			n += t >> 8; o += t & 0xff;
+			n += (t >> 8) & 0x1ff; o += t & 0xff;
 		} while (o < olim);
-		p0 += o;
 		if (t >> 24) {
-			if ((t >> 24) == 1) { p0 += t & 0xff; fl = F_EOB; } else fl = F_ERR;
+			p0 += o - 128;
+			if ((t >> 24) == 1) { p0 += (t >> 17) & 127; fl = F_EOB; } else fl = F_ERR;
 			break;
 		}
+		p0 += o;
 	}
 	if (p0 > T) fl = F_RUNOUT;
 	return (unsigned long long)(p0 | fl << 24) | (unsigned long long)n << 32;
