@@ -88,6 +88,8 @@ struct __attribute__((aligned(16))) Lds {
 	// the stream in parts: the window of the source (its first byte's offset, its bits, does it reach the stream's end, is it there),
 	// the output (bytes of it in front of LDS position 0, the first LDS position memory does not have yet, the lowest a distance may reach)
 	uint32_t wb, wbits, wend, wvalid, aoff, fl0, lowest, inblock, act, cut, stall, done;
+	// the header's code lengths by all wavefronts (read_lengths): every segment's first bit and what stands in front of it; the walk's state
+	uint32_t segin[NW], hstate, hn, hprev, hein, hend, hpos;
 	uint32_t span_m, span_len, span_dist;   // the match that reaches from the first half of the output into the second
 	uint32_t prof[P_N], tprev[2], tripmax;
 };
@@ -427,7 +429,7 @@ NXZ_WG_PHASE void resolve_matches(uint32_t from, uint32_t outn, int prof)
 // ---- the header of a dynamic block, by wavefront 0 (the algorithm of nxzi::read_dht; the stream's bits come from LDS):
 // code lengths into L.lens, L.hlit / L.hdist, L.pos behind the header.  false: not a header this kernel takes on. ----
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-NXZ_WG_PHASE bool read_header(uint32_t start, uint32_t T, int lane)
+NXZ_WG_PHASE bool read_header(uint32_t start, uint32_t T, int lane, bool codes_only)
 {
 	start = uni(start); T = uni(T);                                   // (read from LDS: the same in every lane, and now the compiler knows)
 	if (start + 14 > T) return false;
@@ -482,6 +484,10 @@ NXZ_WG_PHASE bool read_header(uint32_t start, uint32_t T, int lane)
 	for (int i = lane; i < 320; i += 64) L.lens[i] = 0;
 	__threadfence_block();
 	(void)__ballot(1);                                                  // (the wavefront's lanes are in step here -- the CPU shim's are not by themselves)
+	if (codes_only) {                                                   // (the lengths themselves: read_lengths, all wavefronts)
+		if (lane == 0) { L.hlit = (uint32_t)hlit; L.hdist = (uint32_t)hdist; L.hpos = pos; }
+		return true;
+	}
 	int n0 = 0;
 	uint32_t inh = 16;                                                  // the length in front of this window (16: none yet)
 	for (;;) {
@@ -568,6 +574,108 @@ NXZ_WG_PHASE bool read_header(uint32_t start, uint32_t T, int lane)
 	(void)__ballot(1);
 	if (lane == 0) { L.hlit = (uint32_t)hlit; L.hdist = (uint32_t)hdist; L.pos = pos; }
 	return true;
+}
+
+// ---- the code lengths of a dynamic block's header by ALL wavefronts (read_header with codes_only has left the look-up of the
+// code-length code, the counts and the position): up to 316 symbols of 2 to 14 bits, one after the other -- one wavefront
+// alone took 22 000 cycles for them with fifteen waiting.  A window of 1024 bits, a lane a bit:
+//   1. every lane looks up the symbol that WOULD start at its bit;
+//   2. a wavefront's 64 bits are a segment; a symbol of the segment in front reaches at most 13 bits into it, so fourteen
+//      lanes walk the segment from its fourteen possible first bits: where the walk leaves the segment, how many lengths it
+//      makes, the last length it defines;
+//   3. one lane strings the segments together (sixteen look-ups): every segment's true first bit, the count and the last
+//      length in front of it; the segment in which the count reaches the header's total is the last;
+//   4. every wavefront follows its segment from the true first bit (scalar: a register read a symbol), a prefix sum over the
+//      lanes on the way gives every symbol its place, and those lanes write.
+// L.bail = R_DHT: not a header this kernel takes on.  L.pos: behind the header. ----
+NXZ_WG_PHASE void read_lengths(uint32_t T)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint8_t *cl7 = (const uint8_t *)L.pend;
+	const uint32_t total = L.hlit + L.hdist;
+	uint32_t *tk = L.nout, *seg = (uint32_t *)L.list;
+	if (tid == 0) { L.hn = 0; L.hprev = 16; L.hein = 0; L.hend = 0xffffffffu; }
+	__syncthreads();
+	for (;;) {
+		const uint32_t pos = L.hpos;
+		// 1. bits to the next symbol | lengths it stands for << 8 | the symbol << 16; no such code: a step out of every segment, flagged
+		const uint32_t v = peek32(pos + (uint32_t)tid);
+		const uint32_t e = cl7[v & 127];
+		const uint32_t len = e >> 5, sym = e & 31;
+		const uint32_t eb = sym < 16 ? 0 : sym == 16 ? 2 : sym == 17 ? 3 : 7;
+		const uint32_t rep = sym < 16 ? 1 : ((v >> len) & ((1u << eb) - 1)) + (sym == 18 ? 11 : 3);
+		const bool valid = e != 0xff;
+		const uint32_t tok = valid ? (len + eb) | rep << 8 | sym << 16 : 128u | 1u << 24;
+		tk[tid] = tok;
+		__syncthreads();
+		// 2. exit (4 bits) | met no-such-code << 4 | last length defined (16: none) << 8 | lengths << 16
+		if (lane < 14) {
+			uint32_t o = (uint32_t)lane, cnt = 0, lastdef = 16, stop = 0;
+			while (o < 64) {
+				const uint32_t t = tk[64 * wave + o];
+				if (t >> 24) { stop = 1; break; }
+				const uint32_t sy = (t >> 16) & 31;
+				cnt += (t >> 8) & 0xff;
+				if (sy != 16) lastdef = sy < 16 ? sy : 0;
+				o += t & 0xff;
+			}
+			seg[16 * wave + lane] = ((o - 64) & 15) | stop << 4 | lastdef << 8 | cnt << 16;
+		}
+		__syncthreads();
+		// 3. first bit | lengths in front << 4 | last length in front << 20 | 1 << 31 for every segment the header reaches into
+		if (tid == 0) {
+			uint32_t en = L.hein, n = L.hn, prev = L.hprev, state = 0;
+			for (uint32_t w = 0; w < NW; w++) L.segin[w] = 0;
+			for (uint32_t w = 0; w < NW; w++) {
+				const uint32_t ent = seg[16 * w + en];
+				L.segin[w] = en | n << 4 | prev << 20 | 1u << 31;
+				n += ent >> 16;
+				if (n >= total) { state = 1; break; }                      // (what the segment holds behind the header's end: step 4 looks)
+				if (ent & 16) { state = 2; break; }                         // no such code in front of the header's end
+				if (((ent >> 8) & 31) != 16) prev = (ent >> 8) & 31;
+				en = ent & 15;
+			}
+			L.hstate = state; L.hn = n; L.hprev = prev; L.hein = en; L.hpos = pos + 64 * NW;
+		}
+		__syncthreads();
+		if (L.hstate == 2) { if (tid == 0) L.bail = R_DHT; __syncthreads(); return; }
+		// 4.
+		const uint32_t sin = L.segin[wave];
+		if (sin >> 31) {
+			const uint32_t en = uni(sin & 15), n_in = uni((sin >> 4) & 0xffff), prev_in = uni((sin >> 20) & 31);
+			unsigned long long path = 0;
+			uint32_t o = en;
+			do {
+				const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)o);
+				path |= 1ull << o;
+				o += t & 0xff;
+			} while (o < 64);
+			const bool on = (path >> lane) & 1;
+			uint32_t inc = on && valid ? rep : 0;                            // inclusive prefix sum of the lengths on the way
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, (unsigned)d, 64); if (lane >= d) inc += up; }
+			const uint32_t at = n_in + inc - (on && valid ? rep : 0);
+			// the last length defined in front of this lane's symbol
+			const unsigned long long defm = __ballot(on && valid && sym != 16) & ((1ull << lane) - 1);
+			const uint32_t defval = sym < 16 ? sym : 0;
+			const uint32_t from = defm ? 63u - (uint32_t)__builtin_clzll(defm) : 0u;
+			const uint32_t got = __shfl(defval, (int)from, 64);
+			const uint32_t pv = defm ? got : prev_in;
+			if (on && at < total) {
+				bool wrong = !valid || at + rep > total || (sym == 16 && pv == 16);   // no such code; more lengths than announced; "repeat" with nothing in front
+				if (!wrong) {
+					if (sym < 16) L.lens[at] = (uint8_t)sym;
+					else if (sym == 16) for (uint32_t q = 0; q < rep; q++) L.lens[at + q] = (uint8_t)pv;
+					if (at + rep == total) L.hend = pos + (uint32_t)tid + (tok & 0xff);
+				} else L.bail = R_DHT;
+			}
+		}
+		__syncthreads();
+		if (L.bail) return;
+		if (L.hstate == 1) break;
+	}
+	if (tid == 0) { if (L.hend > T) L.bail = R_DHT; else L.pos = L.hend; }
+	__syncthreads();
 }
 
 // ---- the decode tables of a block from L.lens (all lanes; R_TABLES in L.bail: the sub-tables do not fit) ----
@@ -930,9 +1038,11 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 					// ---- code lengths ----
 					if (btype == 2) {
 						if (wave == 0) {
-							const bool ok = read_header(L.pos, T, lane);
+							const bool ok = read_header(L.pos, T, lane, true);
 							if (!ok && lane == 0) L.bail = R_DHT;
 						}
+						__syncthreads();
+						if (!L.bail) read_lengths(T);
 					} else {
 						for (int i = tid; i < 320; i += NT) L.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
 						if (tid == 0) { L.hlit = 288; L.hdist = 30; }
