@@ -623,19 +623,26 @@ NXZ_WG_PHASE void read_lengths(uint32_t T)
 		}
 		__syncthreads();
 		// 3. first bit | lengths in front << 4 | last length in front << 20 | 1 << 31 for every segment the header reaches into
-		if (tid == 0) {
-			uint32_t en = L.hein, n = L.hn, prev = L.hprev, state = 0;
-			for (uint32_t w = 0; w < NW; w++) L.segin[w] = 0;
+		if (wave == 0) {
+			// (wavefront 0, the segments' entries in its registers -- lane e holds what the walk from bit e found in every segment -- so
+			// that the chain from segment to segment reads registers, not LDS: sixteen dependent LDS look-ups by one lane were 6000 cycles)
+			uint32_t col[NW];
+#pragma unroll
+			for (uint32_t w = 0; w < NW; w++) col[w] = lane < 16 ? seg[16 * w + (uint32_t)lane] : 0;
+			uint32_t en = uni(L.hein), n = uni(L.hn), prev = uni(L.hprev), state = 0, mine = 0;
+#pragma unroll
 			for (uint32_t w = 0; w < NW; w++) {
-				const uint32_t ent = seg[16 * w + en];
-				L.segin[w] = en | n << 4 | prev << 20 | 1u << 31;
-				n += ent >> 16;
-				if (n >= total) { state = 1; break; }                      // (what the segment holds behind the header's end: step 4 looks)
-				if (ent & 16) { state = 2; break; }                         // no such code in front of the header's end
-				if (((ent >> 8) & 31) != 16) prev = (ent >> 8) & 31;
-				en = ent & 15;
+				if (state == 0) {
+					const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)col[w], (int)en);
+					if ((uint32_t)lane == w) mine = en | n << 4 | prev << 20 | 1u << 31;
+					n += ent >> 16;
+					if (n >= total) state = 1;                                // (what the segment holds behind the header's end: step 4 looks)
+					else if (ent & 16) state = 2;                              // no such code in front of the header's end
+					else { if (((ent >> 8) & 31) != 16) prev = (ent >> 8) & 31; en = ent & 15; }
+				}
 			}
-			L.hstate = state; L.hn = n; L.hprev = prev; L.hein = en; L.hpos = pos + 64 * NW;
+			if (lane < NW) L.segin[lane] = mine;
+			if (lane == 0) { L.hstate = state; L.hn = n; L.hprev = prev; L.hein = en; L.hpos = pos + 64 * NW; }
 		}
 		__syncthreads();
 		if (L.hstate == 2) { if (tid == 0) L.bail = R_DHT; __syncthreads(); return; }
