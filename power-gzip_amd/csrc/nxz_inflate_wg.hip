@@ -176,16 +176,30 @@ __device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t len)
 	return mk(len, K_DIST, xb, base);
 }
 
+// inclusive prefix sum over the wavefront: on the device by DPP moves (four shifts within the rows of 16, two broadcasts across
+// them: six vector instructions), not by six LDS-crossbar shuffles of a hundred cycles each
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane)
+{
+#ifndef NXZ_CPU_SIM
+	(void)lane;
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+	return v;
+#else
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, (unsigned)d, 64); if (lane >= d) v += o; }
+	return v;
+#endif
+}
+
 // exclusive prefix sum over the workgroup (all threads call it); *total = the sum
 __device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *total)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	uint32_t inc = v;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint32_t o = __shfl_up(inc, (unsigned)d, 64);
-		if (lane >= d) inc += o;
-	}
+	const uint32_t inc = wave_scan_incl(v, lane);
 	__syncthreads();                               // (wsum may still be read from the last scan)
 	if (lane == 63) L.wsum[wave] = inc;
 	__syncthreads();
@@ -658,9 +672,7 @@ NXZ_WG_PHASE void read_lengths(uint32_t T)
 				o += t & 0xff;
 			} while (o < 64);
 			const bool on = (path >> lane) & 1;
-			uint32_t inc = on && valid ? rep : 0;                            // inclusive prefix sum of the lengths on the way
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, (unsigned)d, 64); if (lane >= d) inc += up; }
+			const uint32_t inc = wave_scan_incl(on && valid ? rep : 0, lane);   // inclusive prefix sum of the lengths on the way
 			const uint32_t at = n_in + inc - (on && valid ? rep : 0);
 			// the last length defined in front of this lane's symbol
 			const unsigned long long defm = __ballot(on && valid && sym != 16) & ((1ull << lane) - 1);
@@ -789,7 +801,7 @@ NXZ_WG_PHASE void decode_span(uint32_t T, uint32_t spanbits, uint32_t capleft, u
 			if (m) {
 				uint32_t base = 0;
 				if ((tid & 63) == 0) base = atomicAdd(&L.nredo[par], (uint32_t)__popcll(m));
-				base = __shfl(base, 0, 64);
+				base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 				// (a piece's new start lies within a token of its first bit: 6 bits beside the piece's number)
 				if (redo) L.list[base + (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1))] = (uint16_t)((uint32_t)tid | (st - g) << 10);
 			}
