@@ -66,7 +66,7 @@ enum { R_JOB = 1, R_HEADER = 2, R_STORED = 3, R_DHT = 4, R_TABLES = 5, R_ROUNDS 
 // PROF (NXZ_WG_PROF=1, measurements): thread 0's clock at the ends of the phases, summed over the launch's streams in prof[]:
 // load, block headers, dynamic headers read, tables, the first pass, the later rounds, prefix sum + the writing pass, the list of
 // matches, the matches, out; then counts: rounds, streams, coded blocks, pieces
-enum { P_LOAD, P_HEADER, P_DHT, P_TABLES, P_FIRST, P_ROUNDS, P_WRITE, P_LIST, P_MATCH, P_OUT, P_NROUNDS, P_STREAMS, P_BLOCKS, P_PIECES, P_MTRIPS, P_MTRIPMAX, P_MWAITS, P_MATCHES, P_N };
+enum { P_LOAD, P_HEADER, P_DHT, P_TABLES, P_FIRST, P_ROUNDS, P_WRITE, P_LIST, P_MATCH, P_OUT, P_NROUNDS, P_STREAMS, P_BLOCKS, P_PIECES, P_MTRIPS, P_MTRIPMAX, P_MWAITS, P_MATCHES, P_R1, P_R2, P_R3, P_R4, P_R5, P_R6, P_C3, P_C4, P_C5, P_C6, P_N };
 
 struct __attribute__((aligned(16))) Lds {
 	uint32_t pad[4];                    // (the match copies read up to four dwords in front of the output without looking)
@@ -813,7 +813,8 @@ NXZ_WG_PHASE void decode_span(uint32_t T, uint32_t spanbits, uint32_t capleft, u
 		// of the tests.  Packed data under nearly flat codes needs hundreds of rounds -- still cheaper than handing the stream back:
 		// own exact-table streams of the corpus, 4096 of them, 34 -> 94 GiB/s when the limit went from 256 to "none")
 		if (++rounds > max_rounds) { if (tid == 0) L.bail = R_ROUNDS; break; }
-		if (tid == 0) { L.nredo[par ^ 1] = 0; if (prof) { L.prof[P_MATCHES] += cnt; if (rounds <= 2) L.prof[P_MTRIPMAX] += cnt; } }
+		if (tid == 0) { L.nredo[par ^ 1] = 0; if (prof) { L.prof[P_MATCHES] += cnt; if (rounds <= 2) L.prof[P_MTRIPMAX] += cnt; if (rounds >= 3 && rounds <= 6) L.prof[P_C3 + rounds - 3] += cnt;
+			const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; if (rounds >= 2 && rounds <= 7) L.prof[P_R1 + rounds - 2] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); } }
 		if (cnt <= coop_max) {
 			// few pieces left -- the heads of the chains: a wavefront each
 			for (uint32_t k = (uint32_t)tid >> 6; k < cnt; k += NW) {
@@ -1142,7 +1143,7 @@ extern "C" int nxz_launch_inflate_order_only(const nxz_batch_job_t *jobs, size_t
 // control words of a launch: the job counter, the reasons, then the hand-back list (a count, the indices from word 64 on)
 extern "C" size_t nxz_inflate_wg_workspace(size_t n)
 {
-	return 256 + 256 + 256 + ((n * sizeof(uint32_t) + 255) & ~(size_t)255);
+	return 1024 + 256 + ((n * sizeof(uint32_t) + 255) & ~(size_t)255);
 }
 
 // All n streams a workgroup each; the streams the kernel hands back are decoded behind it by the kernel that knows every
@@ -1153,9 +1154,9 @@ extern "C" int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_
 {
 	if (!n) return 0;
 	if (n >= (1u << 31)) return (int)hipErrorInvalidValue;
-	uint32_t *ctr = (uint32_t *)wg_ws, *dbg = (uint32_t *)(wg_ws + 256), *bail = (uint32_t *)(wg_ws + 512);
+	uint32_t *ctr = (uint32_t *)wg_ws, *dbg = (uint32_t *)(wg_ws + 256), *bail = (uint32_t *)(wg_ws + 1024);
 	unsigned long long *prof = (unsigned long long *)(wg_ws + 320);
-	(void)hipMemsetAsync(wg_ws, 0, 512 + 256, stream);
+	(void)hipMemsetAsync(wg_ws, 0, 1024 + 256, stream);
 	(void)hipMemsetAsync(bail + 64, 0xff, n * sizeof(uint32_t), stream);
 	static const unsigned cus = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(v > 0 ? v : 256); }();
 	const char *pe = getenv("NXZ_WG_PMIN");                            // (read at every call: the tests switch it)
@@ -1179,7 +1180,7 @@ extern "C" int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_
 extern "C" int nxz_inflate_wg_reasons(const uint8_t *wg_ws, uint32_t *out16)
 {
 	int rc = (int)hipMemcpy(out16, wg_ws + 256, 15 * sizeof(uint32_t), hipMemcpyDeviceToHost);
-	if (!rc) rc = (int)hipMemcpy(out16 + 15, wg_ws + 512, sizeof(uint32_t), hipMemcpyDeviceToHost);
+	if (!rc) rc = (int)hipMemcpy(out16 + 15, wg_ws + 1024, sizeof(uint32_t), hipMemcpyDeviceToHost);
 	return rc;
 }
 // (NXZ_WG_PROF=1: thread 0's cycles by phase and the counts, 12 words -- nxzw::P_*)

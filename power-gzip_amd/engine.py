@@ -197,7 +197,7 @@ class Engine:
 
     def wg_prof(self):
         """NXZ_WG_PROF=1: one lane's cycles by phase, per stream, of the last batch that went a stream per workgroup"""
-        out = (C.c_uint64 * 24)()
+        out = (C.c_uint64 * 32)()
         if self.L.nxz_ctx_wg_prof(self.ctx, self.stream_handle(), out):
             return None
         names = ["load", "header", "dht", "tables", "first", "rounds", "write", "list", "match", "out"]
@@ -205,7 +205,7 @@ class Engine:
         d = {names[i]: out[i] / ns for i in range(10)}
         d["total"] = sum(out[i] for i in range(10)) / ns
         d.update(nrounds=out[10] / max(1, out[12]), streams=out[11], blocks=out[12] / ns, pieces=out[13] / max(1, out[12]),
-                 jump_rounds=out[14] / ns, jump_cycles=out[16] / ns, redone=out[17] / max(1, out[12]), redone_in_2=out[15] / max(1, out[12]))
+                 jump_rounds=out[14] / ns, jump_cycles=out[16] / ns, redone=out[17] / max(1, out[12]), redone_in_2=out[15] / max(1, out[12]), per_round=[round(out[18 + i] / ns) for i in range(6)], cnt_r3_6=[round(out[24 + i] / max(1, out[12]), 1) for i in range(4)])
         return d
 
     def inflate_stream(self, src, src_len, dst, first_bit=0, hist=None):

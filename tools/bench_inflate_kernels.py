@@ -94,7 +94,7 @@ for kind in ("zlib -6 of the corpus blocks", "own fixed-Huffman (synthetic)", "o
                     print("    (handed back: %s)" % why, flush=True)
                 if os.environ.get("NXZ_WG_PROF"):
                     pr = eng.wg_prof()
-                    print("    (cycles a stream: %s)" % ", ".join("%s %.0f" % (k, v) if v >= 100 else "%s %.2f" % (k, v) for k, v in pr.items()), flush=True)
+                    print("    (cycles a stream: %s)" % ", ".join(("%s %.0f" % (k, v) if v >= 100 else "%s %.2f" % (k, v)) if not isinstance(v, list) else "%s %s" % (k, v) for k, v in pr.items()), flush=True)
             eng.close()
             del jobs, dst
             torch.cuda.empty_cache()

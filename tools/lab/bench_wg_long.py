@@ -56,7 +56,7 @@ for kib in sizes:
                     print("    (handed back: %s)" % why, flush=True)
                 if os.environ.get("NXZ_WG_PROF"):
                     pr = eng.wg_prof()
-                    print("    (cycles a stream: %s)" % ", ".join("%s %.0f" % (k, v) if v >= 100 else "%s %.2f" % (k, v) for k, v in pr.items()), flush=True)
+                    print("    (cycles a stream: %s)" % ", ".join(("%s %.0f" % (k, v) if v >= 100 else "%s %.2f" % (k, v)) if not isinstance(v, list) else "%s %s" % (k, v) for k, v in pr.items()), flush=True)
             eng.close()
             del jobs, dst, src
             torch.cuda.empty_cache()
