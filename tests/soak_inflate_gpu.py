@@ -1,6 +1,6 @@
 """Soak run (not collected by pytest): seeded random zlib streams (all levels and strategies, flushed
 pieces, sizes 0..300 KB, with history and cut-off tails) through the inflate kernels of the HIP
-engine (a stream per lane with and without the fixed-code-only kernel in front, a stream per wave with the window in LDS and in the target, every stream cut into pieces on the device), every result compared with the oracle (output, stop state, checksums).
+engine (a stream per workgroup, a stream per lane with and without the fixed-code-only kernel in front, a stream per wave with the window in LDS and in the target, every stream cut into pieces on the device), every result compared with the oracle (output, stop state, checksums).
 python tests/soak_inflate_gpu.py [seeds]"""
 import importlib, os, random, sys, zlib
 import numpy as np
@@ -42,13 +42,16 @@ for seed in range(1, nseeds + 1):
     for i, (c, _) in enumerate(cases): host[i, :len(c)] = np.frombuffer(c, np.uint8)
     src = torch.from_numpy(host).to(eng.dev)
     exp = [O.inflate(c, cap) for c, cap in cases]
-    for kernel, env in (("lanes", {"NXZ_INFLATE_LANES_MIN": "1", "NXZ_LANES_FIXED": "0"}),
+    for kernel, env in (("a stream per workgroup (what it does not take: handed back to a wavefront each)", {"NXZ_INFLATE_WG": "1"}),
+                        ("... pieces of 250 bits, a wavefront a piece from the first round on", {"NXZ_INFLATE_WG": "1", "NXZ_WG_PMIN": "250", "NXZ_WG_COOP": "1024"}),
+                        ("lanes", {"NXZ_INFLATE_LANES_MIN": "1", "NXZ_LANES_FIXED": "0"}),
                         ("lanes, the fixed-code-only kernel first", {"NXZ_INFLATE_LANES_MIN": "1", "NXZ_LANES_FIXED": "2"}),
                         ("waves, window in LDS", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_LDS_MAX": "1000000000"}),
                         ("waves, target as window", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_LDS_MAX": "0"}),
                         ("every stream cut into pieces on the device", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_CUT": "1"}),
                         ("... three pieces a round, two rounds", {"NXZ_INFLATE_LANES_MIN": "1000000000", "NXZ_INFLATE_CUT": "1", "NXZ_INFLATE_CUT_PIECES": "3", "NXZ_INFLATE_CUT_ROUNDS": "2"})):
         os.environ["NXZ_INFLATE_CUT"] = "0"
+        for k in ("NXZ_INFLATE_WG", "NXZ_WG_PMIN", "NXZ_WG_COOP", "NXZ_INFLATE_LANES_MIN", "NXZ_LANES_FIXED", "NXZ_INFLATE_LDS_MAX"): os.environ.pop(k, None)
         os.environ.pop("NXZ_INFLATE_CUT_PIECES", None); os.environ.pop("NXZ_INFLATE_CUT_ROUNDS", None)
         os.environ.update(env)
         dst = torch.full((len(cases), ostride), 0xAA, dtype=torch.uint8, device=eng.dev)
