@@ -214,7 +214,7 @@ __device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *total)
 // WRITE: literals to their place in the output (from obase on), matches parked as records.
 // A trip round the loop: 64 bits of the source at p (three dwords), the literal/length look-up; behind a LITERAL the next code lies
 // in the same 32 bits, and if that is a literal too the trip takes both (literal-heavy data -- binaries, images -- makes half
-// as many trips: a trip costs 1000-1300 cycles whatever it decodes, the chain of dependent LDS look-ups). ----
+// as many trips: with all sixteen wavefronts at work a trip costs 1200 cycles whatever it decodes -- 75 instructions a wavefront). ----
 template <bool WRITE>
 __device__ __forceinline__ unsigned long long decode_piece(uint32_t st, uint32_t lim, uint32_t T, uint32_t obase)
 {
@@ -326,7 +326,7 @@ NXZ_WG_PHASE unsigned long long piece_count_wave(uint32_t st, uint32_t lim, uint
 // and every link of that chain cost a trip of the polling loop, 1500 cycles -- 200 000 to 400 000 cycles a stream with most of
 // the CU waiting.  Now the chains are followed by POINTER JUMPING, a byte a pointer: P[x] = where byte x comes from (itself for
 // a literal), then P[x] = P[P[x]] for all x side by side until nothing moves -- a chain of depth d is flat after log2 d rounds
-// (a byte is 30-250 copies away from its literal; 6-8 rounds), whatever hangs on whatever.  Then one gather.  16 bits a pointer:
+// (a byte is 30-250 copies away from its literal; three links a round: 3-4 rounds), whatever hangs on whatever.  Then one gather.  16 bits a pointer:
 // the room the source no longer needs holds them for 32 KiB of output, so the output goes in two halves; pointers of the
 // second half into the first are ends of their chains (those bytes are final by then). ----
 constexpr uint32_t HALF = 32768;
@@ -407,7 +407,7 @@ NXZ_WG_PHASE void resolve_matches(uint32_t from, uint32_t outn, int prof)
 			for (uint32_t j = 0; j < 16; j++) {
 				if (!((open >> (2 * j)) & 3)) continue;
 				uint32_t a = pp[j] & 0xffff, b = pp[j] >> 16;
-				// two links a round (the rounds' barriers and the sixteen blocks of this loop cost more than the look-ups once few
+				// three links a round (the rounds' barriers and the sixteen blocks of this loop cost more than the look-ups once few
 				// pointers are still open)
 				uint32_t na = a >= base ? P[a - base] : a, nb = b >= base ? P[b - base] : b;   // (a pointer into the first half: the end of its chain)
 				if (na == a) open &= ~(1u << (2 * j)); else {
@@ -785,8 +785,9 @@ NXZ_WG_PHASE void decode_span(uint32_t T, uint32_t spanbits, uint32_t capleft, u
 	if (prof && tid == 0) L.prof[P_PIECES] += NP;
 	// The rounds: a piece whose neighbour in front ended elsewhere than the piece began is decoded again from there.  Who must go
 	// again is scattered over the wavefronts and fewer every round: the pieces to do go on a list and the first lanes take one
-	// each -- after the second round a wavefront or two decode while the others wait at the barrier, and a wavefront that has
-	// the CU's LDS to itself makes its trips three times as fast.
+	// each; sixteen or fewer: a wavefront each (piece_count_wave).  What the later rounds cost is the longest chain of pieces that
+	// have not fallen in step, token after token -- a round of a few pieces takes as long as a round of all of them (the slowest
+	// lane's twenty trips), a wavefront a piece 40 % of that.
 	uint32_t rounds = 0;
 	for (;;) {
 		__syncthreads();
@@ -961,7 +962,7 @@ NXZ_WG_PHASE void flush_out(NXZ_WG_GLOBAL uint8_t *dst, bool final, int prof)
 template <bool PROF>
 __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *__restrict__ jobs, uint32_t n, nxz_batch_result_t *__restrict__ results,
 							 const uint32_t *__restrict__ order, uint32_t *__restrict__ ctr, uint32_t *__restrict__ bail,
-							 uint32_t pmin_bits, uint32_t nres, uint32_t *__restrict__ dbg, unsigned long long *__restrict__ prof)
+							 uint32_t pmin_bits, uint32_t coop, uint32_t *__restrict__ dbg, unsigned long long *__restrict__ prof)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	uint8_t *ob = (uint8_t *)L.out;
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 				WGPROF(P_HEADER);
 				continue;
 			}
-			decode_span(T, spanbits, job.dst_cap - made, pmin_bits & 0xffff, pmin_bits >> 16 | nres << 16, PROF);
+			decode_span(T, spanbits, job.dst_cap - made, pmin_bits & 0xffff, pmin_bits >> 16 | coop << 16, PROF);
 		}
 		__syncthreads();
 		if (L.bail) {
@@ -1164,11 +1165,11 @@ extern "C" int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_
 	const char *mre = getenv("NXZ_WG_ROUNDS");
 	const unsigned maxr = mre && atoi(mre) >= 2 && atoi(mre) <= 1024 ? (unsigned)atoi(mre) : 1024u;
 	const char *nre = getenv("NXZ_WG_COOP");                           // so many pieces left in a round or fewer: a wavefront walks each
-	const unsigned nres = nre && atoi(nre) >= 0 && atoi(nre) <= 1024 ? (unsigned)atoi(nre) : 16u;
+	const unsigned coop = nre && atoi(nre) >= 0 && atoi(nre) <= 1024 ? (unsigned)atoi(nre) : 16u;
 	const unsigned grid = (unsigned)(n < cus ? n : cus);
 	const char *pr = getenv("NXZ_WG_PROF");
-	if (pr && atoi(pr)) hipLaunchKernelGGL(nxzw::inflate_wg_kernel<true>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin | maxr << 16, nres, dbg, prof);
-	else hipLaunchKernelGGL(nxzw::inflate_wg_kernel<false>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin | maxr << 16, nres, dbg, prof);
+	if (pr && atoi(pr)) hipLaunchKernelGGL(nxzw::inflate_wg_kernel<true>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin | maxr << 16, coop, dbg, prof);
+	else hipLaunchKernelGGL(nxzw::inflate_wg_kernel<false>, dim3(grid), dim3(nxzw::NT), 0, stream, jobs, (uint32_t)n, results, order, ctr, bail, pmin | maxr << 16, coop, dbg, prof);
 	int rc = (int)hipGetLastError();
 	if (rc) return rc;
 	rc = nxz_launch_inflate_order_only(jobs, n, results, dht_io, bail + 64, stream);
