@@ -90,6 +90,7 @@ struct __attribute__((aligned(16))) Lds {
 	uint32_t wb, wbits, wend, wvalid, aoff, fl0, lowest, inblock, act, cut, stall, done;
 	// the header's code lengths by all wavefronts (read_lengths): every segment's first bit and what stands in front of it; the walk's state
 	uint32_t segin[NW], hstate, hn, hprev, hein, hend, hpos;
+	uint32_t fixed_ok;                  // the tables in lit / dist are the fixed code's (they stand from stream to stream)
 	uint32_t span_m, span_len, span_dist;   // the match that reaches from the first half of the output into the second
 	uint32_t prof[P_N], tprev[2], tripmax;
 };
@@ -968,6 +969,7 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 	uint8_t *ob = (uint8_t *)L.out;
 	const uint8_t *sb = (const uint8_t *)L.src;
 #define WGPROF(idx) do { if (PROF && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(), then_ = (unsigned long long)L.tprev[0] | (unsigned long long)L.tprev[1] << 32; L.prof[idx] += (uint32_t)(now_ - then_); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); } } while (0)
+	if (tid == 0) L.fixed_ok = 0;
 	if (PROF && tid == 0) { for (int i = 0; i < P_N; i++) L.prof[i] = 0; const unsigned long long now_ = (unsigned long long)clock64(); L.tprev[0] = (uint32_t)now_; L.tprev[1] = (uint32_t)(now_ >> 32); }
 
 	for (;;) {
@@ -1055,7 +1057,9 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 				if (L.bail) continue;
 				const uint32_t btype = L.btype;
 				WGPROF(P_HEADER);
-				if (btype != 0) {
+				// (the tables of the fixed code stand from the last block that used them -- the workgroup's last stream, as a rule: a batch of
+				// fixed-code streams builds them once a workgroup, not once a stream)
+				if (btype != 0 && !(btype == 1 && L.fixed_ok)) {
 					// ---- code lengths ----
 					if (btype == 2) {
 						if (wave == 0) {
@@ -1082,8 +1086,10 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 					__syncthreads();
 					if (L.bail) continue;
 					if (PROF) { WGPROF(P_DHT); if (tid == 0) L.prof[P_BLOCKS]++; }
+					if (tid == 0) L.fixed_ok = 0;
 					build_tables(hlit, hdist);
 					if (L.bail) continue;
+					if (tid == 0) L.fixed_ok = btype == 1;
 					WGPROF(P_TABLES);
 				}
 			}
