@@ -623,9 +623,9 @@ static int batch_decompress(nxz_ctx_t *c, const nxz_batch_job_t *jobs, size_t n,
 	bool split = false;
 	// A stream per WORKGROUP, source, output and tables in LDS (nxz_inflate_wg.hip): every batch, unless one of the older routes' knobs
 	// is set (the tests' way to name a route) -- except, from 98 304 streams on, the batches whose sampled streams begin with fixed-code
-	// or stored blocks (the fixed-code lane kernel's: 154-178 GiB/s against 144).  That kernel runs at one rate from a few thousand
+	// or stored blocks (the fixed-code lane kernel's: 158-177 GiB/s against 151).  That kernel runs at one rate from a few thousand
 	// streams on (a CU a stream; profiles/r06_inflate_by_batch_size.txt: zlib -6 streams of the corpus 96-99 GiB/s from 4096 streams on,
-	// own exact-table streams 116-120, fixed-code synthetic blocks 138-144), where a stream per wavefront needs 16 384 streams for 56
+	// own exact-table streams 115-120, fixed-code synthetic blocks 144-151), where a stream per wavefront needs 16 384 streams for 56
 	// and levels off at 66, and a stream per lane needs 100 000 (zlib -6 streams at 262 144, both older kernels side by side: 87).
 	// Streams of any length are its own (in spans, the output flushed in halves); what it does not do -- streams that resume or bring
 	// a history, end early or are damaged -- it hands back, and those go a stream per wavefront behind it.
