@@ -760,7 +760,8 @@ void *nxz_stream_create(nxz_ctx_t *) __attribute__((weak));
 int nxz_ctx_device(nxz_ctx_t *) __attribute__((weak));
 int nxz_engine_usable(void) __attribute__((weak));
 }
-// 12 KiB -- but 64 KiB for a stream that comes in ONE call (nx_uncompress, inflate() with Z_FINISH on a fresh stream: the shape of
+// 12 KiB -- but 112 KiB (round 6; 64 before: one workgroup decodes a whole stream of up to 350 KiB of output faster than the
+// one-stream pipeline starts up: a 256 KiB buffer 0.80 -> 0.71 ms) for a stream that comes in ONE call (nx_uncompress, inflate() with Z_FINISH on a fresh stream: the shape of
 // samples/compdecomp_th.c): such a buffer is a job, and the rounds of nxu_run_job cut their jobs into pieces (nxz_inflate_cut.hip,
 // one sequence of launches for all callers of a round) -- the better the more threads call at once: 64 threads x 64 KiB buffers 1.7
 // against 0.40 GiB/s.  Not for a stream that comes in steps: what a step leaves over is often just short of the step, and as a
@@ -768,7 +769,7 @@ int nxz_engine_usable(void) __attribute__((weak));
 static size_t parallel_inflate_min(bool whole_at_once)
 {
 	static const size_t v = getenv("NXZ_PARALLEL_INFLATE_MIN") ? (size_t)strtoull(getenv("NXZ_PARALLEL_INFLATE_MIN"), nullptr, 0) : 0;
-	return v ? v : whole_at_once ? (size_t)64 << 10 : (size_t)12 << 10;
+	return v ? v : whole_at_once ? (size_t)112 << 10 : (size_t)12 << 10;
 }
 static std::atomic<int> g_inflate_callers{0};    // threads inside nx_inflate right now
 constexpr size_t CARRY_KEEP = 1024;                // unconsumed source kept between calls at most: a dynamic block header (<= 290 bytes) and a token
