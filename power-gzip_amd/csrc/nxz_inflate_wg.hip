@@ -77,6 +77,7 @@ struct __attribute__((aligned(16))) Lds {
 	uint32_t dist[(1 << RD) + DSUB];
 	uint32_t pend[NSUBMAX];             // table build: sub-table bits per root index; the rounds: every piece's end | flag << 24
 	uint16_t lcount[16], dcount[16];
+	uint16_t crow[6][16];               // the table build: symbols per code length in every row of 64 symbols (five literal/length rows, the distance row)
 	uint16_t lsym[288], dsym[32];
 	uint8_t lens[320];
 	uint32_t wsum[NW];
@@ -702,12 +703,47 @@ NXZ_WG_PHASE void read_lengths(uint32_t T)
 NXZ_WG_PHASE void build_tables(int hlit, int hdist)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	uint32_t cl[5], ccode[5];                                 // wave 0: literal/length symbols, wave 1: distance symbols (row 0)
 	for (uint32_t i = tid; i < NSUBMAX; i += NT) L.pend[i] = 0;
 	for (uint32_t i = tid; i < LSUB; i += NT) L.lit[(1u << RL) + i] = 0;
 	for (uint32_t i = tid; i < DSUB; i += NT) L.dist[(1u << RD) + i] = 0;
-	if (wave == 0) canon<5>(L.lens, hlit, L.lcount, L.lsym, cl, ccode, lane);
-	else if (wave == 1) { uint32_t l1[1], c1[1]; canon<1>(L.lens + hlit, hdist, L.dcount, L.dsym, l1, c1, lane); cl[0] = l1[0]; ccode[0] = c1[0]; }
+	// The canonical codes (RFC 1951 3.2.2), a wavefront a row of 64 symbols: wavefronts 0-4 the literal/length symbols, wavefront 5
+	// the distance symbols (one wavefront for all five rows took 7000 cycles with the others waiting).  Per length: the row's
+	// count by a ballot and the lane's rank among the row's symbols of its length; then, the rows' counts side by side in LDS,
+	// every wavefront works out for ITS symbols where the length's codes and places begin and how many symbols of the rows in front
+	// share them.
+	uint32_t myl = 0, mycode = 0, rk = 0;                       // this lane's symbol: its code length, its code; its rank in its row
+	const uint32_t mysym = wave < 5 ? (uint32_t)(wave * 64 + lane) : (uint32_t)lane;
+	if (wave < 6) {
+		const int n = wave < 5 ? hlit : hdist;
+		myl = (int)mysym < n ? L.lens[(wave < 5 ? 0 : hlit) + (int)mysym] : 0;
+		const uint64_t below = (1ull << lane) - 1;
+		for (uint32_t bl = 1; bl <= 15; bl++) {
+			const uint64_t m = __ballot(myl == bl);
+			if (lane == 0) L.crow[wave][bl] = (uint16_t)__popcll(m);
+			if (myl == bl) rk = (uint32_t)__popcll(m & below);
+		}
+		if (lane == 0) L.crow[wave][0] = 0;
+	}
+	__syncthreads();
+	if (wave < 6) {
+		// lane b < 16: the symbols of length b in all rows of this alphabet, and in the rows in front of this one
+		const int r0 = wave < 5 ? 0 : 5, r1 = wave < 5 ? 5 : 6;
+		uint32_t tb = 0, bel = 0;
+		for (int r = r0; r < r1; r++) { const uint32_t v = L.crow[r][lane & 15]; tb += v; if (r < wave) bel += v; }
+		if (lane >= 16) tb = 0;
+		const uint32_t offs = wave_scan_incl(tb, lane) - tb;       // where length b's symbols begin in the sorted list
+		uint32_t cb = 0;                                           // the first code of length b: c_b = (c_(b-1) + n_(b-1)) << 1
+		for (int k = 1; k <= 14; k++) {
+			const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)tb, k);
+			if (lane > k && lane < 16) cb += tk << (lane - k);
+		}
+		const uint32_t c_l = __shfl(cb, (int)myl, 64), o_l = __shfl(offs, (int)myl, 64), b_l = __shfl(bel, (int)myl, 64);
+		if (myl) {
+			mycode = c_l + b_l + rk;
+			(wave < 5 ? L.lsym : L.dsym)[o_l + b_l + rk] = (uint16_t)mysym;
+		}
+		if ((wave == 0 || wave == 5) && lane < 16) (wave == 0 ? L.lcount : L.dcount)[lane] = (uint16_t)tb;
+	}
 	__syncthreads();
 	{
 		uint32_t sym, len;
@@ -715,15 +751,12 @@ NXZ_WG_PHASE void build_tables(int hlit, int hdist)
 		if (tid < (1 << RD)) L.dist[tid] = root_walk<RD>((uint32_t)tid, L.dcount, L.dsym, sym, len) ? dist_entry(sym, len) : 0;
 	}
 	// codes longer than the root: how many index bits the sub-table behind their root index needs
-	if (wave == 0) {
-#pragma unroll
-		for (int r = 0; r < 5; r++) if (cl[r] > (uint32_t)RL) {
-			const uint32_t lsb = __builtin_bitreverse32(ccode[r]) >> (32 - cl[r]);
-			atomicMax(&L.pend[lsb & ((1u << RL) - 1)], cl[r] - RL);
-		}
-	} else if (wave == 1 && cl[0] > (uint32_t)RD) {
-		const uint32_t lsb = __builtin_bitreverse32(ccode[0]) >> (32 - cl[0]);
-		atomicMax(&L.pend[(1u << RL) + (lsb & ((1u << RD) - 1))], cl[0] - RD);
+	if (wave < 5 && myl > (uint32_t)RL) {
+		const uint32_t lsb = __builtin_bitreverse32(mycode) >> (32 - myl);
+		atomicMax(&L.pend[lsb & ((1u << RL) - 1)], myl - RL);
+	} else if (wave == 5 && myl > (uint32_t)RD) {
+		const uint32_t lsb = __builtin_bitreverse32(mycode) >> (32 - myl);
+		atomicMax(&L.pend[(1u << RL) + (lsb & ((1u << RD) - 1))], myl - RD);
 	}
 	__syncthreads();
 	{
@@ -737,18 +770,15 @@ NXZ_WG_PHASE void build_tables(int hlit, int hdist)
 	}
 	__syncthreads();
 	if (L.bail) return;
-	if (wave == 0) {
-#pragma unroll
-		for (int r = 0; r < 5; r++) if (cl[r] > (uint32_t)RL) {
-			const uint32_t lsb = __builtin_bitreverse32(ccode[r]) >> (32 - cl[r]);
-			const uint32_t link = L.lit[lsb & ((1u << RL) - 1)], rem = cl[r] - RL;
-			const uint32_t ent = lit_entry((uint32_t)(r * 64 + lane), cl[r]);
-			for (uint32_t k = lsb >> RL; k < (1u << e_xb(link)); k += 1u << rem) L.lit[(link >> 16) + k] = ent;
-		}
-	} else if (wave == 1 && cl[0] > (uint32_t)RD) {
-		const uint32_t lsb = __builtin_bitreverse32(ccode[0]) >> (32 - cl[0]);
-		const uint32_t link = L.dist[lsb & ((1u << RD) - 1)], rem = cl[0] - RD;
-		const uint32_t ent = dist_entry((uint32_t)lane, cl[0]);
+	if (wave < 5 && myl > (uint32_t)RL) {
+		const uint32_t lsb = __builtin_bitreverse32(mycode) >> (32 - myl);
+		const uint32_t link = L.lit[lsb & ((1u << RL) - 1)], rem = myl - RL;
+		const uint32_t ent = lit_entry(mysym, myl);
+		for (uint32_t k = lsb >> RL; k < (1u << e_xb(link)); k += 1u << rem) L.lit[(link >> 16) + k] = ent;
+	} else if (wave == 5 && myl > (uint32_t)RD) {
+		const uint32_t lsb = __builtin_bitreverse32(mycode) >> (32 - myl);
+		const uint32_t link = L.dist[lsb & ((1u << RD) - 1)], rem = myl - RD;
+		const uint32_t ent = dist_entry(mysym, myl);
 		for (uint32_t k = lsb >> RD; k < (1u << e_xb(link)); k += 1u << rem) L.dist[(link >> 16) + k] = ent;
 	}
 	__syncthreads();
