@@ -761,9 +761,9 @@ NXZ_WG_PHASE void build_tables(int hlit, int hdist)
 	__syncthreads();
 	{
 		const uint32_t sl = L.pend[tid], sd = tid < (1 << RD) ? L.pend[(1u << RL) + tid] : 0;
-		uint32_t totl, totd;
-		const uint32_t ol = block_scan(sl ? 1u << sl : 0, &totl);
-		const uint32_t od = block_scan(sd ? 1u << sd : 0, &totd);
+		uint32_t tot2;                                              // (both sums in one scan: 16 bits each are room enough)
+		const uint32_t o2 = block_scan((sl ? 1u << sl : 0) | (sd ? 1u << sd : 0) << 16, &tot2);
+		const uint32_t ol = o2 & 0xffff, od = o2 >> 16, totl = tot2 & 0xffff, totd = tot2 >> 16;
 		if (sl) L.lit[tid] = mk(0, K_LINK, sl, (1u << RL) + ol);
 		if (sd) L.dist[tid] = mk(0, K_LINK, sd, (1u << RD) + od);
 		if (tid == 0 && (totl > LSUB || totd > DSUB)) L.bail = R_TABLES;
@@ -1110,7 +1110,8 @@ __global__ __launch_bounds__(NT) void inflate_wg_kernel(const nxz_batch_job_t *_
 						uint32_t k1 = 0, k2 = 0;
 						for (int i = lane; i < hlit; i += 64) if (L.lens[i]) k1 += 1u << (15 - L.lens[i]);
 						if (lane < hdist && L.lens[hlit + lane]) k2 = 1u << (15 - L.lens[hlit + lane]);
-						for (int o = 32; o > 0; o >>= 1) { k1 += __shfl(k1, lane ^ o, 64); k2 += __shfl(k2, lane ^ o, 64); }
+						k1 = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(k1, lane), 63);
+						k2 = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(k2, lane), 63);
 						if (lane == 0 && (L.lens[256] == 0 || k1 > (1u << 15) || k2 > (1u << 15))) L.bail = R_DHT;
 					}
 					__syncthreads();
