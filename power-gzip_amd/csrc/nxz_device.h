@@ -96,7 +96,8 @@ int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, nxz_batch_re
 /* nxz_inflate_wg.hip: a stream per workgroup, source, output and tables in LDS; what it cannot do goes a stream per wavefront behind it */
 size_t nxz_inflate_wg_workspace(size_t n);
 int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io,
-			  uint8_t *wg_ws, const uint32_t *order, hipStream_t stream);
+			  uint8_t *wg_ws, const uint32_t *order, uint8_t *const *targets, hipStream_t stream);   /* targets (may be NULL): the outputs there too, in the checksum pass */
+int nxz_launch_cksum_copy(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, uint8_t *const *targets, hipStream_t stream);
 int nxz_inflate_wg_reasons(const uint8_t *wg_ws, uint32_t *out16);
 int nxz_inflate_wg_prof(const uint8_t *wg_ws, unsigned long long *out12);
 }

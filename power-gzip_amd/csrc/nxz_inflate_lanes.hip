@@ -750,9 +750,13 @@ constexpr uint32_t cxpow8(uint32_t n)            // x^(8n) mod P, compile time
 // the same pass over job.src that also stores what it reads to job.dst and writes the whole result record.  (Round 3's
 // wrap kernel walked 256 bytes a thread through a one-byte table and let thread 0 combine 256 slices with a
 // bit-serial multiply each: 0.8 TB/s.)
-template <bool WRAP>
-__global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__restrict__ jobs, nxz_batch_result_t *__restrict__ results)
+// MODE 2 (round 6): checksums AND the output on its way to the caller's target (targets[i], pinned host memory: the rounds of
+// nxu_run_job) -- one pass and one launch instead of checksums, then a copy kernel; the result record keeps what the inflate
+// kernel wrote, a job that failed is not copied.
+template <int MODE>
+__global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__restrict__ jobs, nxz_batch_result_t *__restrict__ results, uint8_t *const *__restrict__ targets)
 {
+	constexpr bool WRAP = MODE == 1;
 	__shared__ uint32_t T[1024];            // T[k*256 + i] = i advanced by k+1 zero bytes
 	__shared__ uint32_t red[3][256];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -765,7 +769,9 @@ __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__res
 		}
 		job.in_crc = 0; job.in_adler = 1;       // (WRAP ignores what the job brings: the caller combines, lib/nx_deflate.c:1565-1578)
 	}
-	uint8_t *const wdst = job.dst;
+	uint8_t *const wdst = MODE == 2 ? targets[blockIdx.x] : job.dst;
+	bool copy = WRAP;                                       // store what is read
+	if (MODE == 2) { const uint32_t cc = results[blockIdx.x].cc; copy = cc == 0 || cc == NXZ_CC_DATA_LENGTH; }
 	const uint32_t rd_cap = WRAP ? n : job.dst_cap;          // bytes that may be read at p
 	auto finish = [&](uint32_t crc, uint32_t adler) {
 		if (WRAP) { nxz_batch_result_t r; r.cc = 0; r.tpbc = n; r.tebc = 0; r.spbc = n; r.crc = crc; r.adler = adler; r.subc = 0; r.sfbt = 0; results[blockIdx.x] = r; }
@@ -778,14 +784,14 @@ __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__res
 	}
 	__syncthreads();
 	const uint8_t *p = WRAP ? job.src : job.dst;
-	if (((uintptr_t)p & 15) || (WRAP && ((uintptr_t)wdst & 15))) {
+	if (((uintptr_t)p & 15) || (copy && ((uintptr_t)wdst & 15))) {
 		// bytewise: 256 contiguous pieces
 		uint32_t per = ((n + 255) / 256 + 15) & ~15u;
 		uint32_t lo = (uint32_t)t * per, hi = lo + per < n ? lo + per : n;
 		uint32_t crc = 0, s1 = 0, s2 = 0;
 		for (uint32_t i = lo; i < hi; i++) {
 			uint32_t byte = p[i];
-			if (WRAP) wdst[i] = (uint8_t)byte;
+			if (copy) wdst[i] = (uint8_t)byte;
 			crc = T[(crc ^ byte) & 0xff] ^ (crc >> 8);
 			s1 += byte; s2 += s1;
 			if ((i & 0xfff) == 0xfff) { s1 %= 65521u; s2 %= 65521u; }
@@ -821,7 +827,7 @@ __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__res
 				if (16u * k < nb) {
 					if ((size_t)base + (size_t)sl * 64 + 16 * k + 16 <= rd_cap) {
 						q[k] = sp[k];
-						if (WRAP) ((uint4 *)(wdst + base + (size_t)sl * 64))[k] = q[k];
+						if (copy) ((uint4 *)(wdst + base + (size_t)sl * 64))[k] = q[k];
 					} else {                                        // never read past the caller's buffer
 						const uint8_t *bp = (const uint8_t *)&sp[k];
 						uint32_t ww[4] = { 0, 0, 0, 0 };
@@ -829,7 +835,7 @@ __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__res
 						for (int b = 0; b < 16; b++)
 							if (16u * k + b < nb) {
 								ww[b >> 2] |= (uint32_t)bp[b] << (8 * (b & 3));
-								if (WRAP) wdst[base + (size_t)sl * 64 + 16 * k + b] = bp[b];
+								if (copy) wdst[base + (size_t)sl * 64 + 16 * k + b] = bp[b];
 							}
 						q[k] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
 					}
@@ -899,7 +905,7 @@ __global__ __launch_bounds__(256) void cksum_kernel(const nxz_batch_job_t *__res
 extern "C" int nxz_launch_wrap_sliced(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream)
 {
 	if (!n) return 0;
-	hipLaunchKernelGGL(nxzl::cksum_kernel<true>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
+	hipLaunchKernelGGL(nxzl::cksum_kernel<1>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results, (uint8_t *const *)nullptr);
 	return (int)hipGetLastError();
 }
 
@@ -973,10 +979,18 @@ extern "C" const uint32_t *nxz_launch_order_by_length(const nxz_batch_job_t *job
 	return v_out;
 }
 
+// checksums of the outputs, and the outputs to targets[i] in the same pass (the rounds of nxu_run_job: device buffers -> pinned host)
+extern "C" int nxz_launch_cksum_copy(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, uint8_t *const *targets, hipStream_t stream)
+{
+	if (!n) return 0;
+	hipLaunchKernelGGL(nxzl::cksum_kernel<2>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results, targets);
+	return (int)hipGetLastError();
+}
+
 extern "C" int nxz_launch_cksum(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, hipStream_t stream)
 {
 	if (!n) return 0;
-	hipLaunchKernelGGL(nxzl::cksum_kernel<false>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
+	hipLaunchKernelGGL(nxzl::cksum_kernel<0>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results, (uint8_t *const *)nullptr);
 	return (int)hipGetLastError();
 }
 
@@ -1022,6 +1036,6 @@ extern "C" int nxz_launch_inflate_lanes(const nxz_batch_job_t *jobs, size_t n, n
 		if (rc) return rc;
 	}
 	hipLaunchKernelGGL(nxzl::inflate_lanes_kernel, dim3(grid), dim3(64), 0, stream, jobs, n, results, dht_io, workspace, workspace, order, pw, bail, bail ? hb_slots : 0u);
-	hipLaunchKernelGGL(nxzl::cksum_kernel<false>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results);
+	hipLaunchKernelGGL(nxzl::cksum_kernel<0>, dim3((unsigned)n), dim3(256), 0, stream, jobs, results, (uint8_t *const *)nullptr);
 	return (int)hipGetLastError();
 }

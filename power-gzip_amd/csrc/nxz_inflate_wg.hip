@@ -1186,9 +1186,10 @@ extern "C" size_t nxz_inflate_wg_workspace(size_t n)
 
 // All n streams a workgroup each; the streams the kernel hands back are decoded behind it by the kernel that knows every
 // case, a wavefront each (nxzi::inflate_kernel through the list: a slot that holds no job ends at once).  order (may be
-// NULL): the jobs by falling source length.  Checksums by nxzl::cksum_kernel.
+// NULL): the jobs by falling source length.  Checksums by nxzl::cksum_kernel -- with targets (may be NULL), the outputs go
+// there in the same pass (the rounds of nxu_run_job: device buffers to pinned host memory).
 extern "C" int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_batch_result_t *results, nxz_batch_dht_t *dht_io,
-				     uint8_t *wg_ws, const uint32_t *order, hipStream_t stream)
+				     uint8_t *wg_ws, const uint32_t *order, uint8_t *const *targets, hipStream_t stream)
 {
 	if (!n) return 0;
 	if (n >= (1u << 31)) return (int)hipErrorInvalidValue;
@@ -1211,7 +1212,7 @@ extern "C" int nxz_launch_inflate_wg(const nxz_batch_job_t *jobs, size_t n, nxz_
 	if (rc) return rc;
 	rc = nxz_launch_inflate_order_only(jobs, n, results, dht_io, bail + 64, stream);
 	if (rc) return rc;
-	return nxz_launch_cksum(jobs, n, results, stream);
+	return targets ? nxz_launch_cksum_copy(jobs, n, results, targets, stream) : nxz_launch_cksum(jobs, n, results, stream);
 }
 
 // (diagnostic / tests: the reasons of the last launch on this workspace, 16 words; [0] unused, [15] = streams handed back; the caller has waited for the stream)

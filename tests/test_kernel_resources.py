@@ -29,8 +29,9 @@ BUDGET = {
     "nxzl::inflate_lanes_fixed_kernel": (80, 32),     # ... stored and fixed-code blocks only: six
     "nxzw::inflate_wg_kernel<false>": (128, 128),     # a stream per workgroup of 1024 threads: 128 is the cap; its phases are functions of their own
                                                       # (the scratch: the registers those functions save on entry, none in their loops)
-    "nxzl::cksum_kernel<false>": (96, 0),
-    "nxzl::cksum_kernel<true>": (96, 0),            # the WRAP function code: the same pass, storing as it goes
+    "nxzl::cksum_kernel<0>": (96, 0),
+    "nxzl::cksum_kernel<1>": (96, 0),               # the WRAP function code: the same pass, storing as it goes
+    "nxzl::cksum_kernel<2>": (96, 0),               # checksums and the outputs to the callers' pinned targets (nxu_run_job's rounds)
     "nxzb::find_blocks_kernel": (96, 0),
     "nxzi::token_sync_kernel": (72, 0),               # (LDS bounds it at five wavefronts per SIMD: 72 registers allow seven)
     "nxzi::block_tables_kernel": (64, 0),
