@@ -1807,7 +1807,7 @@ static int round_run_inflate(nxz_ctx *c, nxz_ctx::Round &R, std::vector<InflateR
 	}
 	// (the sources to the device buffers -- except for a round that goes a stream per workgroup: that kernel reads a stream once,
 	// 16 bytes a lane, and does so straight from the callers' pinned staging; and its checksum pass takes the outputs to the
-	// pinned targets as it reads them: three launches a round less, 178 -> 160 us for a call of 64 KiB)
+	// pinned targets as it reads them: two launches a round less, 158 -> 145 us for a call of 64 KiB)
 	if (!wg && nxz_launch_copy_items(R.h_items, (uint32_t)n, R.stream)) return -EIO;
 	if (wg) {
 		for (size_t k = 0; k < n; k++) { R.h_targets[k] = R.h_jobs[k].dst; R.h_jobs[k].dst = v[k]->d_out; R.h_jobs[k].src = v[k]->h_in; }
